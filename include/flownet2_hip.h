@@ -1,0 +1,178 @@
+/*
+ * flownet2_hip.h -- C ABI of libflownet2_hip.so: the MI355X (gfx950) implementation of the
+ * FlowNet2 hot-path operators of lmb-freiburg/flownet2 (a Caffe fork).
+ *
+ * Every entry point below replaces one Layer<Dtype>::Forward_gpu / Backward_gpu (Dtype = float) of
+ * the reference; the reference interface it stands in for is cited as file:line relative to the
+ * reference tree.  INTEGRATION.md shows the adapter (a Caffe Layer<float> subclass calling these
+ * functions with Blob::gpu_data() pointers) that a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All tensors are dense NCHW fp32 (Blob layout, include/caffe/blob.hpp:153-164), DEVICE pointers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream, which is what the
+ *    reference uses for every launch).
+ *  - Functions never allocate, free or synchronise; scratch comes from the caller through
+ *    (workspace, workspace_bytes) whose size the matching *_workspace_bytes() reports.
+ *  - Return value: FN2_OK (0) or a negative fn2_status; fn2_last_error_string() returns a
+ *    thread-local description of the last failure.  The reference aborts through glog CHECK /
+ *    LOG(FATAL) in these situations (src/caffe/common.cpp:58); the adapter turns non-zero into
+ *    LOG(FATAL), the Python host raises.
+ *  - The library is stateless and re-entrant; it uses the current HIP device.
+ *
+ * The CPU oracle (oracle/fn2_oracle.c, test infrastructure only) exports the same functions with a
+ * `_cpu` suffix, HOST pointers and no stream / workspace arguments.
+ */
+#ifndef FLOWNET2_HIP_H_
+#define FLOWNET2_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FN2_VERSION_MAJOR 0
+#define FN2_VERSION_MINOR 1
+
+typedef enum fn2_status {
+  FN2_OK = 0,
+  FN2_ERR_INVALID_ARG = -1,   /* a CHECK in the reference's LayerSetUp/Reshape would have fired */
+  FN2_ERR_UNSUPPORTED = -2,   /* configuration the reference rejects with LOG(FATAL)            */
+  FN2_ERR_WORKSPACE = -3,     /* workspace NULL or too small                                     */
+  FN2_ERR_LAUNCH = -4         /* hipGetLastError() after the launch was not hipSuccess           */
+} fn2_status;
+
+/* "maj.min (gfx950)" */
+const char* fn2_version(void);
+const char* fn2_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation  (type: "Correlation")
+ *   params  <- CorrelationParameter, src/caffe/proto/caffe.proto:628-644 (field for field)
+ *   shapes  <- CorrelationLayer::Reshape, src/caffe/layers/correlation_layer.cpp:41-84
+ *   forward <- CorrelationLayer::Forward_gpu, src/caffe/layers/correlation_layer.cu:431-504
+ *              (blob_rearrange_kernel2 :23-42, CorrelateData :45-114, CorrelateDataSubtract :252-293)
+ *   backward<- CorrelationLayer::Backward_gpu, src/caffe/layers/correlation_layer.cu:507-603
+ *              (CorrelateDataBackward0/1 :117-249, ...Subtract :297-427)
+ * ---------------------------------------------------------------------------------------------- */
+enum { FN2_CORR_MULTIPLY = 0, FN2_CORR_SUBTRACT = 1 };   /* CorrelationParameter.CorrelationType */
+
+typedef struct fn2_corr_params {
+  int pad;               /* pad              = 2  [default 0]  */
+  int kernel_size;       /* kernel_size      = 3  (odd, required) */
+  int max_displacement;  /* max_displacement = 4  (required)   */
+  int stride1;           /* stride_1         = 5  [default 1]  */
+  int stride2;           /* stride_2         = 6  [default 1]  */
+  int corr_type;         /* correlation_type = 15 [default MULTIPLY] */
+  int do_abs;            /* do_abs = 7: parsed but never used by the reference (correlation_layer.cpp:29); ignored */
+} fn2_corr_params;
+
+/* Reshape: top = [N, topC, topH, topW].  Errors: even kernel_size, stride <= 0, top dims < 1
+ * (correlation_layer.cpp:22,62-63), pad < max_displacement (the reference reads out of bounds
+ * there; we refuse). */
+int fn2_correlation_out_shape(const fn2_corr_params* p, int C, int H, int W,
+                              int* topC, int* topH, int* topW);
+/* No workspace is needed by the current kernels (the reference's rbot1_/rbot2_ padded NHWC
+ * scratch, correlation_layer.cpp:76-82, is gone); always returns 0.  Kept so the ABI can grow. */
+size_t fn2_correlation_workspace_bytes(const fn2_corr_params* p, int N, int C, int H, int W);
+int fn2_correlation_forward(const fn2_corr_params* p,
+                            const float* bottom0, const float* bottom1, float* top,
+                            int N, int C, int H, int W,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* Writes (overwrites) both bottom diffs; like the reference it ignores propagate_down
+ * (correlation_layer.cu:508-603).  Either diff pointer may be NULL to skip that half. */
+int fn2_correlation_backward(const fn2_corr_params* p,
+                             const float* bottom0, const float* bottom1, const float* top_diff,
+                             float* bottom0_diff, float* bottom1_diff,
+                             int N, int C, int H, int W,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FlowWarp  (type: "FlowWarp")
+ *   params  <- FlowWarpParameter.fill_value {ZERO=1, NOT_A_NUMBER=2}, caffe.proto:553-560
+ *   forward <- FlowWarpLayer::Forward_gpu, src/caffe/layers/flow_warp_layer.cu:357-458
+ *              (CPU twin flow_warp_layer.cpp:58-117)
+ *   backward<- FlowWarpLayer::Backward_gpu, src/caffe/layers/flow_warp_layer.cu:461-514
+ *              (kernel :169-229; CPU twin flow_warp_layer.cpp:120-199)
+ * ---------------------------------------------------------------------------------------------- */
+enum { FN2_FILL_ZERO = 1, FN2_FILL_NAN = 2 };
+
+/* image [N,C,H,W], flow [N,2,H,W] (channel 0 = x/u, 1 = y/v), warped [N,C,H,W]. */
+int fn2_flow_warp_forward(const float* image, const float* flow, float* warped,
+                          int N, int C, int H, int W, int fill_value, void* stream);
+/* image_diff [N,C,H,W] and flow_diff [N,2,H,W] are both overwritten.  propagate_* == 0 zeroes the
+ * corresponding diff after the pass exactly as flow_warp_layer.cu:507-508 does.  image_diff is
+ * accumulated with float atomics (as the reference, :197-200): summation order is not
+ * deterministic. */
+int fn2_flow_warp_backward(const float* image, const float* flow, const float* warped_diff,
+                           float* image_diff, float* flow_diff,
+                           int N, int C, int H, int W,
+                           int propagate_image, int propagate_flow, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Resample  (type: "Resample")  -- forward only (resample_layer.cu:209-213 is LOG(FATAL))
+ *   params  <- ResampleParameter {width=1,height=2,type=3,antialias=4,factor=5(unused)}, caffe.proto:665-677
+ *   forward <- ResampleLayer::Forward_gpu, src/caffe/layers/resample_layer.cu:128-206
+ *              (InterpolationKernel :39-95, NearestNeighborKernel :97-125)
+ * ---------------------------------------------------------------------------------------------- */
+enum { FN2_RESAMPLE_NEAREST = 1, FN2_RESAMPLE_LINEAR = 2, FN2_RESAMPLE_CUBIC = 3, FN2_RESAMPLE_AREA = 4 };
+
+/* in [N,C,Hin,Win] -> out [N,C,Hout,Wout]; AREA -> FN2_ERR_UNSUPPORTED (resample_layer.cpp:17-20). */
+int fn2_resample_forward(const float* in, float* out, int N, int C,
+                         int Hin, int Win, int Hout, int Wout,
+                         int type, int antialias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * L1Loss  (type: "L1Loss")
+ *   params  <- L1LossParameter, caffe.proto:619-625
+ *   forward <- L1LossLayer::Forward_gpu, src/caffe/layers/l1loss_layer.cu:67-143
+ *   backward<- L1LossLayer::Backward_gpu, src/caffe/layers/l1loss_layer.cu:146-188
+ * The reference keeps mask_/sign_/normalize_coeff_ as layer state between the two calls
+ * (l1_loss_layer.hpp); here forward leaves {loss, normalize_coeff} in the workspace and backward
+ * recomputes the element-wise terms from the inputs, so the pair stays stateless.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fn2_l1loss_params {
+  int l2_per_location;          /* = 1 [false] */
+  int l2_prescale_by_channels;  /* = 2 [false] */
+  int normalize_by_num_entries; /* = 3 [false] */
+  float epsilon;                /* = 4 [1e-2]  */
+  float plateau;                /* = 3001 [0]  */
+} fn2_l1loss_params;
+
+size_t fn2_l1loss_workspace_bytes(int N, int C, int H, int W);
+/* bottom1 may be NULL (single-bottom form, l1loss_layer.cpp:15-17).  loss_out: DEVICE float[1]
+ * (the reference writes the scalar on the host, l1loss_layer.cu:142; we keep it on the device so
+ * there is no sync).  The first 2 floats of the workspace hold {loss, normalize_coeff} afterwards. */
+int fn2_l1loss_forward(const fn2_l1loss_params* p, const float* bottom0, const float* bottom1,
+                       float* loss_out, int N, int C, int H, int W,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* top_diff = top[0]->cpu_diff()[0] (the loss weight, layer.hpp:444-458).  Must be called with the
+ * workspace the matching forward filled.  bottom1_diff may be NULL. */
+int fn2_l1loss_backward(const fn2_l1loss_params* p, const float* bottom0, const float* bottom1,
+                        float top_diff, float* bottom0_diff, float* bottom1_diff,
+                        int N, int C, int H, int W,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ChannelNorm  (type: "ChannelNorm")
+ *   forward <- ChannelNormLayer::Forward_gpu, src/caffe/layers/channel_norm_layer.cu:50-67
+ *   backward<- ChannelNormLayer::Backward_gpu, :69-90 (which passes host pointers to the kernel --
+ *              a reference bug; we implement what NormBackward :37-47 computes)
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_channel_norm_forward(const float* bottom, float* top, int N, int C, int H, int W, void* stream);
+int fn2_channel_norm_backward(const float* bottom, const float* top, const float* top_diff,
+                              float* bottom_diff, int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Downsample  (type: "Downsample") -- forward only
+ *   forward <- DownsampleLayer::Forward_gpu, src/caffe/layers/downsample_layer.cu:75-129
+ *              (DownsampleFeatures :15-72).  Same-size input: the reference shares the blob
+ *              (downsample_layer.cpp:53-56); we copy.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_downsample_forward(const float* bottom, float* top, int N, int C,
+                           int Hin, int Win, int Hout, int Wout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* FLOWNET2_HIP_H_ */

@@ -1,0 +1,173 @@
+"""ctypes front-end of the CPU oracle (oracle/fn2_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by flownet2_amd/.  All arrays are host numpy float32, C-contiguous NCHW.
+
+Parity status: see the header of fn2_oracle.c (pinned against the reference's own kernels through
+oracle/_ref + tests/golden for Correlation / FlowWarp / Resample / ChannelNorm / Downsample;
+"parity unpinned" for L1Loss).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfn2_oracle.so")
+
+MULTIPLY, SUBTRACT = 0, 1
+FILL_ZERO, FILL_NAN = 1, 2
+NEAREST, LINEAR, CUBIC, AREA = 1, 2, 3, 4
+
+
+class CorrParams(C.Structure):
+    _fields_ = [("pad", C.c_int), ("kernel_size", C.c_int), ("max_displacement", C.c_int),
+                ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int)]
+
+
+class L1Params(C.Structure):
+    _fields_ = [("l2_per_location", C.c_int), ("l2_prescale_by_channels", C.c_int),
+                ("normalize_by_num_entries", C.c_int), ("epsilon", C.c_float), ("plateau", C.c_float)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "fn2_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libfn2_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ValueError(f"oracle {what} failed with status {rc}")
+
+
+def num_threads() -> int:
+    return lib().fn2_oracle_num_threads()
+
+
+def corr_params(pad=0, kernel_size=1, max_displacement=0, stride1=1, stride2=1, corr_type=MULTIPLY, do_abs=0):
+    return CorrParams(pad, kernel_size, max_displacement, stride1, stride2, corr_type, do_abs)
+
+
+def correlation_out_shape(p: CorrParams, Cc, H, W):
+    tc, th, tw = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().fn2_correlation_out_shape_cpu(C.byref(p), Cc, H, W, C.byref(tc), C.byref(th), C.byref(tw)), "correlation_out_shape")
+    return tc.value, th.value, tw.value
+
+
+def correlation_forward(p: CorrParams, b0, b1):
+    b0, b1 = _f32(b0), _f32(b1)
+    N, Cc, H, W = b0.shape
+    tc, th, tw = correlation_out_shape(p, Cc, H, W)
+    top = np.empty((N, tc, th, tw), np.float32)
+    _check(lib().fn2_correlation_forward_cpu(C.byref(p), _p(b0), _p(b1), _p(top), N, Cc, H, W), "correlation_forward")
+    return top
+
+
+def correlation_backward(p: CorrParams, b0, b1, top_diff):
+    b0, b1, top_diff = _f32(b0), _f32(b1), _f32(top_diff)
+    N, Cc, H, W = b0.shape
+    d0, d1 = np.empty_like(b0), np.empty_like(b1)
+    _check(lib().fn2_correlation_backward_cpu(C.byref(p), _p(b0), _p(b1), _p(top_diff), _p(d0), _p(d1), N, Cc, H, W), "correlation_backward")
+    return d0, d1
+
+
+def flow_warp_forward(image, flow, fill_value=FILL_ZERO):
+    image, flow = _f32(image), _f32(flow)
+    N, Cc, H, W = image.shape
+    assert flow.shape == (N, 2, H, W)
+    out = np.empty_like(image)
+    _check(lib().fn2_flow_warp_forward_cpu(_p(image), _p(flow), _p(out), N, Cc, H, W, fill_value), "flow_warp_forward")
+    return out
+
+
+def flow_warp_backward(image, flow, warped_diff, propagate_image=True, propagate_flow=True):
+    image, flow, warped_diff = _f32(image), _f32(flow), _f32(warped_diff)
+    N, Cc, H, W = image.shape
+    di, df = np.empty_like(image), np.empty_like(flow)
+    _check(lib().fn2_flow_warp_backward_cpu(_p(image), _p(flow), _p(warped_diff), _p(di), _p(df), N, Cc, H, W,
+                                            int(propagate_image), int(propagate_flow)), "flow_warp_backward")
+    return di, df
+
+
+def resample_forward(x, Hout, Wout, type=LINEAR, antialias=True):
+    x = _f32(x)
+    N, Cc, H, W = x.shape
+    out = np.empty((N, Cc, Hout, Wout), np.float32)
+    _check(lib().fn2_resample_forward_cpu(_p(x), _p(out), N, Cc, H, W, Hout, Wout, type, int(antialias)), "resample_forward")
+    return out
+
+
+def l1_params(l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False,
+              epsilon=1e-2, plateau=0.0):
+    return L1Params(int(l2_per_location), int(l2_prescale_by_channels), int(normalize_by_num_entries),
+                    float(epsilon), float(plateau))
+
+
+def l1loss_forward(p: L1Params, b0, b1=None):
+    b0 = _f32(b0)
+    b1 = _f32(b1) if b1 is not None else None
+    N, Cc, H, W = b0.shape
+    loss, norm = C.c_float(), C.c_float()
+    _check(lib().fn2_l1loss_forward_cpu(C.byref(p), _p(b0), _p(b1), C.byref(loss), C.byref(norm), N, Cc, H, W), "l1loss_forward")
+    return loss.value, norm.value
+
+
+def l1loss_backward(p: L1Params, b0, b1, top_diff, normalize_coeff):
+    b0 = _f32(b0)
+    b1 = _f32(b1) if b1 is not None else None
+    N, Cc, H, W = b0.shape
+    d0 = np.empty_like(b0)
+    d1 = np.empty_like(b0) if b1 is not None else None
+    _check(lib().fn2_l1loss_backward_cpu(C.byref(p), _p(b0), _p(b1), C.c_float(top_diff), C.c_float(normalize_coeff),
+                                         _p(d0), _p(d1), N, Cc, H, W), "l1loss_backward")
+    return d0, d1
+
+
+def channel_norm_forward(x):
+    x = _f32(x)
+    N, Cc, H, W = x.shape
+    out = np.empty((N, 1, H, W), np.float32)
+    _check(lib().fn2_channel_norm_forward_cpu(_p(x), _p(out), N, Cc, H, W), "channel_norm_forward")
+    return out
+
+
+def channel_norm_backward(x, top, top_diff):
+    x, top, top_diff = _f32(x), _f32(top), _f32(top_diff)
+    N, Cc, H, W = x.shape
+    d = np.empty_like(x)
+    _check(lib().fn2_channel_norm_backward_cpu(_p(x), _p(top), _p(top_diff), _p(d), N, Cc, H, W), "channel_norm_backward")
+    return d
+
+
+def downsample_forward(x, Hout, Wout):
+    x = _f32(x)
+    N, Cc, H, W = x.shape
+    out = np.empty((N, Cc, Hout, Wout), np.float32)
+    _check(lib().fn2_downsample_forward_cpu(_p(x), _p(out), N, Cc, H, W, Hout, Wout), "downsample_forward")
+    return out

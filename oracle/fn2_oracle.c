@@ -1,0 +1,611 @@
+/*
+ * fn2_oracle.c -- CPU restatement of the FlowNet2 hot-path layers of lmb-freiburg/flownet2.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under flownet2_amd/ may import, link or call this file; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * PARITY STATUS: the reference ships NO CPU implementation for Correlation / Resample / L1Loss /
+ * Downsample (correlation_layer.cpp:87-96, resample_layer.cpp:58-62, l1loss_layer.cpp:93-102,
+ * downsample_layer.cpp:60-64 are NOT_IMPLEMENTED / LOG(FATAL)), has no test or golden vector for
+ * any FlowNet2 layer (src/caffe/test/ is stock BVLC), and its build (boost/glog/protobuf/BLAS/
+ * CUDA) cannot run in this image.  This file therefore restates the reference's CUDA kernels line
+ * by line in plain C.  Two pins exist (see oracle/README.md):
+ *   (1) oracle/_ref: the reference's OWN .cu/.cpp sources for Correlation, FlowWarp, Resample,
+ *       ChannelNorm and Downsample compiled in place with hipcc against stand-in caffe headers
+ *       (oracle/stubs/) and run on the GPU box; tests/golden/ holds vectors it produced.
+ *   (2) an independent fp64 numpy re-derivation + numeric gradient checks (tests/).
+ * L1Loss is composed from stock Caffe sub-layers in the reference and has no such pin:
+ * "parity unpinned" for L1Loss.
+ *
+ * All file:line citations are relative to the reference tree.
+ * Arithmetic notes: nvcc contracts `sum += a*b` into an FMA by default, so the restatement uses
+ * fmaf() where the reference has that pattern; summation ORDER follows the reference kernels.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include "../include/flownet2_hip.h"
+
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+#define FN2_API __attribute__((visibility("default")))
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+FN2_API int fn2_oracle_num_threads(void) {
+#if defined(_OPENMP)
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation shapes: CorrelationLayer::LayerSetUp / Reshape, correlation_layer.cpp:13-84
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct corr_geom {
+  int kr, border, pH, pW, topH, topW, ngr, ngw, topC;
+} corr_geom;
+
+static int corr_geometry(const fn2_corr_params* p, int C, int H, int W, corr_geom* g) {
+  if (!p || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  if (p->kernel_size < 1 || p->kernel_size % 2 == 0) return FN2_ERR_INVALID_ARG;   /* cpp:22 */
+  if (p->stride1 < 1 || p->stride2 < 1 || p->max_displacement < 0 || p->pad < 0) return FN2_ERR_INVALID_ARG;
+  g->kr = (p->kernel_size - 1) / 2;                      /* cpp:56 */
+  g->border = p->max_displacement + g->kr;               /* cpp:57 */
+  g->pH = H + 2 * p->pad;                                /* cpp:52 */
+  g->pW = W + 2 * p->pad;                                /* cpp:53 */
+  g->topW = (int)ceilf((float)(g->pW - g->border * 2) / (float)p->stride1);   /* cpp:59 */
+  g->topH = (int)ceilf((float)(g->pH - g->border * 2) / (float)p->stride1);   /* cpp:60 */
+  if (g->topW < 1 || g->topH < 1) return FN2_ERR_INVALID_ARG;                 /* cpp:62-63 */
+  g->ngr = p->max_displacement / p->stride2;             /* cpp:66 */
+  g->ngw = g->ngr * 2 + 1;                               /* cpp:67 */
+  g->topC = g->ngw * g->ngw;                             /* cpp:70 */
+  /* The kernels index the padded blob at y1+j+s2p with no bounds check (correlation_layer.cu:95);
+   * pad < max_displacement reads outside it.  Refuse instead of reproducing undefined behaviour. */
+  if (p->pad < p->max_displacement) return FN2_ERR_INVALID_ARG;
+  if (p->corr_type != FN2_CORR_MULTIPLY && p->corr_type != FN2_CORR_SUBTRACT) return FN2_ERR_INVALID_ARG;
+  return FN2_OK;
+}
+
+FN2_API int fn2_correlation_out_shape_cpu(const fn2_corr_params* p, int C, int H, int W,
+                                          int* topC, int* topH, int* topW) {
+  corr_geom g;
+  int rc = corr_geometry(p, C, H, W, &g);
+  if (rc) return rc;
+  if (topC) *topC = g.topC;
+  if (topH) *topH = g.topH;
+  if (topW) *topW = g.topW;
+  return FN2_OK;
+}
+
+/* blob_rearrange_kernel2, correlation_layer.cu:23-42 + the cudaMemset at :447-448:
+ * NCHW -> zero-padded N (H+2p) (W+2p) C */
+static float* rearrange_padded(const float* in, int N, int C, int H, int W, int pad) {
+  const int pH = H + 2 * pad, pW = W + 2 * pad;
+  float* out = (float*)calloc((size_t)N * pH * pW * C, sizeof(float));
+  if (!out) return NULL;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x)
+        for (int ch = 0; ch < C; ++ch)
+          out[(((size_t)n * pH + (y + pad)) * pW + (x + pad)) * C + ch] =
+              in[(((size_t)n * C + ch) * H + y) * W + x];
+  return out;
+}
+
+/* CorrelateData, correlation_layer.cu:45-114 (MULTIPLY) and CorrelateDataSubtract :252-293. */
+FN2_API int fn2_correlation_forward_cpu(const fn2_corr_params* p, const float* bottom0,
+                                        const float* bottom1, float* top, int N, int C, int H, int W) {
+  corr_geom g;
+  int rc = corr_geometry(p, C, H, W, &g);
+  if (rc) return rc;
+  float* r0 = rearrange_padded(bottom0, N, C, H, W, p->pad);
+  float* r1 = rearrange_padded(bottom1, N, C, H, W, p->pad);
+  if (!r0 || !r1) { free(r0); free(r1); return FN2_ERR_WORKSPACE; }
+  const int K = p->kernel_size, md = p->max_displacement, s1 = p->stride1, s2 = p->stride2;
+  const int pH = g.pH, pW = g.pW;
+  const size_t topcount = (size_t)g.topC * g.topH * g.topW;
+  const int sumelems = K * K * C;                                          /* :110 / :288 */
+
+  if (p->corr_type == FN2_CORR_MULTIPLY) {
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int item = 0; item < N; ++item)
+      for (int by = 0; by < g.topH; ++by)          /* blockIdx.y */
+        for (int bx = 0; bx < g.topW; ++bx) {      /* blockIdx.x */
+          const int x1 = bx * s1 + md;             /* :56 */
+          const int y1 = by * s1 + md;             /* :57 */
+          for (int tc = 0; tc < g.topC; ++tc) {
+            const int s2o = (tc % g.ngw - g.ngr) * s2;   /* :81 */
+            const int s2p = (tc / g.ngw - g.ngr) * s2;   /* :82 */
+            /* 32 lanes, lane t accumulates channels ch = t, t+32, ... over (j,i)  (:84-97) */
+            float lane[32];
+            for (int t = 0; t < 32; ++t) lane[t] = 0.f;
+            for (int j = 0; j < K; ++j)
+              for (int i = 0; i < K; ++i) {
+                const float* a = r0 + (((size_t)item * pH + y1 + j) * pW + x1 + i) * C;
+                const float* b = r1 + (((size_t)item * pH + y1 + s2p + j) * pW + x1 + s2o + i) * C;
+                for (int ch = 0; ch < C; ++ch) lane[ch & 31] = fmaf(a[ch], b[ch], lane[ch & 31]);
+              }
+            float total = 0.f;                                         /* :103-106 lane-order sum */
+            for (int t = 0; t < 32; ++t) total += lane[t];
+            top[(size_t)item * topcount + ((size_t)tc * g.topH + by) * g.topW + bx] =
+                total / (float)sumelems;                               /* :109 */
+          }
+        }
+  } else {
+    const int kr = g.kr;
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int item = 0; item < N; ++item)
+      for (int c = 0; c < g.topC; ++c)
+        for (int y = 0; y < g.topH; ++y)
+          for (int x = 0; x < g.topW; ++x) {
+            const int s2o = (c % g.ngw - g.ngr) * s2;                  /* :264 */
+            const int s2p = (c / g.ngw - g.ngr) * s2;                  /* :265 */
+            const int x1 = x * s1 + kr + md;                           /* :268 */
+            const int y1 = y * s1 + kr + md;                           /* :269 */
+            float sum = 0.f;
+            for (int j = -kr; j <= kr; ++j)
+              for (int i = -kr; i <= kr; ++i) {
+                const float* a = r0 + (((size_t)item * pH + y1 + j) * pW + x1 + i) * C;
+                const float* b = r1 + (((size_t)item * pH + y1 + s2p + j) * pW + x1 + s2o + i) * C;
+                for (int l = 0; l < C; ++l) sum += fabsf(a[l] - b[l]);  /* :285 */
+              }
+            top[(size_t)item * topcount + ((size_t)c * g.topH + y) * g.topW + x] = sum / (float)sumelems;
+          }
+  }
+  free(r0);
+  free(r1);
+  return FN2_OK;
+}
+
+/* Integer ceil/floor division the way the kernels do it (ROUND_OFF trick, correlation_layer.cu:131-140). */
+static inline int ceil_div_ro(int a, int s) { const int ro = 50000, ros = s * ro; return (a + ros - 1) / s + 1 - ro; }
+static inline int floor_div_ro(int a, int s) { const int ro = 50000, ros = s * ro; return (a + ros) / s - ro; }
+
+/* CorrelateDataBackward0 / 1, correlation_layer.cu:117-249; ...Subtract :297-427. */
+FN2_API int fn2_correlation_backward_cpu(const fn2_corr_params* p, const float* bottom0,
+                                         const float* bottom1, const float* top_diff,
+                                         float* bottom0_diff, float* bottom1_diff,
+                                         int N, int C, int H, int W) {
+  corr_geom g;
+  int rc = corr_geometry(p, C, H, W, &g);
+  if (rc) return rc;
+  float* r0 = rearrange_padded(bottom0, N, C, H, W, p->pad);
+  float* r1 = rearrange_padded(bottom1, N, C, H, W, p->pad);
+  if (!r0 || !r1) { free(r0); free(r1); return FN2_ERR_WORKSPACE; }
+  const int md = p->max_displacement, s1 = p->stride1, s2 = p->stride2, pad = p->pad;
+  const int kr = g.kr, pH = g.pH, pW = g.pW, ngr = g.ngr, ngw = g.ngw;
+  const int topH = g.topH, topW = g.topW, topC = g.topC;
+  const int sumelems = (kr * 2 + 1) * (kr * 2 + 1) * C;
+  const size_t bottomcount = (size_t)C * H * W;
+  const int sub = (p->corr_type == FN2_CORR_SUBTRACT);
+
+  if (bottom0_diff) {
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int item = 0; item < N; ++item)
+      for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx) {
+          const int l = xx + pad, m = yy + pad;                                   /* :125-126 */
+          int xmin = ceil_div_ro(l - 2 * kr - md, s1);                             /* :135 */
+          int ymin = ceil_div_ro(m - 2 * kr - md, s1);                             /* :136 */
+          int xmax = floor_div_ro(l - md, s1);                                     /* :139 */
+          int ymax = floor_div_ro(m - md, s1);                                     /* :140 */
+          const int live = (xmax >= 0 && ymax >= 0 && xmin <= topW - 1 && ymin <= topH - 1);   /* :144 */
+          if (live) { xmin = imax(0, xmin); xmax = imin(topW - 1, xmax); ymin = imax(0, ymin); ymax = imin(topH - 1, ymax); }
+          for (int n = 0; n < C; ++n) {
+            float sum = 0.f;
+            if (live)
+              for (int pp = -ngr; pp <= ngr; ++pp)
+                for (int o = -ngr; o <= ngr; ++o) {
+                  const int s2o = s2 * o, s2p = s2 * pp;
+                  const size_t idx = (((size_t)item * pH + (m + s2p)) * pW + (l + s2o)) * C + n;   /* :158 */
+                  float coef;
+                  if (!sub) coef = r1[idx];                                         /* :159 */
+                  else coef = (r0[idx] >= r1[idx]) ? 1.f : -1.f;                    /* :341 */
+                  const int op = (pp + ngr) * ngw + (o + ngr);                      /* :162 */
+                  const size_t off = ((size_t)item * topC + op);
+                  for (int y = ymin; y <= ymax; ++y)
+                    for (int x = xmin; x <= xmax; ++x)
+                      sum = fmaf(top_diff[(off * topH + y) * topW + x], coef, sum);   /* :168 */
+                }
+            bottom0_diff[(size_t)item * bottomcount + ((size_t)n * H + yy) * W + xx] = sum / (float)sumelems;   /* :175-176 */
+          }
+        }
+  }
+  if (bottom1_diff) {
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int item = 0; item < N; ++item)
+      for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx) {
+          const int l = xx + pad, m = yy + pad;
+          for (int n = 0; n < C; ++n) {
+            float sum = 0.f;
+            for (int pp = -ngr; pp <= ngr; ++pp)
+              for (int o = -ngr; o <= ngr; ++o) {
+                const int s2o = s2 * o, s2p = s2 * pp;
+                int xmin = ceil_div_ro(l - 2 * kr - md - s2o, s1);                 /* :212 */
+                int ymin = ceil_div_ro(m - 2 * kr - md - s2p, s1);                 /* :213 */
+                int xmax = floor_div_ro(l - md - s2o, s1);                         /* :216 */
+                int ymax = floor_div_ro(m - md - s2p, s1);                         /* :217 */
+                if (xmax >= 0 && ymax >= 0 && xmin <= topW - 1 && ymin <= topH - 1) {   /* :219 */
+                  xmin = imax(0, xmin); xmax = imin(topW - 1, xmax);
+                  ymin = imax(0, ymin); ymax = imin(topH - 1, ymax);
+                  const size_t idx = (((size_t)item * pH + (m - s2p)) * pW + (l - s2o)) * C + n;   /* :228 */
+                  float coef;
+                  if (!sub) coef = r0[idx];                                        /* :229 */
+                  else coef = (r0[idx] >= r1[idx]) ? -1.f : 1.f;                   /* :408 */
+                  const int op = (pp + ngr) * ngw + (o + ngr);
+                  const size_t off = ((size_t)item * topC + op);
+                  for (int y = ymin; y <= ymax; ++y)
+                    for (int x = xmin; x <= xmax; ++x)
+                      sum = fmaf(top_diff[(off * topH + y) * topW + x], coef, sum);   /* :238 */
+                }
+              }
+            bottom1_diff[(size_t)item * bottomcount + ((size_t)n * H + yy) * W + xx] = sum / (float)sumelems;   /* :245-246 */
+          }
+        }
+  }
+  free(r0);
+  free(r1);
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * FlowWarp: flow_warp_layer.cpp:58-117 (Forward_cpu), GPU twin flow_warp_layer.cu:58-122.
+ * The GPU kernel pre-multiplies the four bilinear coefficients (:93-96) and then sums
+ * coeffTL*TL + coeffTR*TR + coeffBL*BL + coeffBR*BR (:110-114); the CPU twin writes the same
+ * expression left-associated.  nvcc contracts that chain into mul + 3 fma; we do the same.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+FN2_API int fn2_flow_warp_forward_cpu(const float* image, const float* flow, float* warped,
+                                      int N, int C, int H, int W, int fill_value) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  if (fill_value != FN2_FILL_ZERO && fill_value != FN2_FILL_NAN) return FN2_ERR_INVALID_ARG;
+  const size_t wh = (size_t)W * H, whc = wh * C;
+  const float fill = (fill_value == FN2_FILL_ZERO) ? 0.f : u2f(0xFFE00000u);   /* cu:372-375 */
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const size_t off = whc * n;
+        const float fx = flow[2 * wh * n + (size_t)y * W + x];                 /* cpp:80 */
+        const float fy = flow[2 * wh * n + wh + (size_t)y * W + x];            /* cpp:81 */
+        const float x2 = (float)x + fx, y2 = (float)y + fy;
+        if (x2 >= 0 && y2 >= 0 && x2 < W && y2 < H) {                           /* cpp:86 */
+          const int ixL = (int)x2, iyT = (int)y2;
+          const int ixR = imin(ixL + 1, W - 1), iyB = imin(iyT + 1, H - 1);
+          const float alpha = x2 - ixL, beta = y2 - iyT;
+          const float cTL = (1 - alpha) * (1 - beta), cTR = alpha * (1 - beta);
+          const float cBL = (1 - alpha) * beta, cBR = alpha * beta;
+          for (int c = 0; c < C; ++c) {
+            const float* im = image + off + c * wh;
+            const float TL = im[(size_t)iyT * W + ixL], TR = im[(size_t)iyT * W + ixR];
+            const float BL = im[(size_t)iyB * W + ixL], BR = im[(size_t)iyB * W + ixR];
+            warped[off + c * wh + (size_t)y * W + x] = fmaf(cBR, BR, fmaf(cBL, BL, fmaf(cTR, TR, cTL * TL)));
+          }
+        } else {
+          for (int c = 0; c < C; ++c) warped[off + c * wh + (size_t)y * W + x] = fill;   /* cpp:110-114 */
+        }
+      }
+  return FN2_OK;
+}
+
+/* flow_warp_layer.cu:169-229 (GPU backward; memsets at :478-479, propagate_down at :507-508).
+ * Sequential scatter here: the reference's atomicAdd order is unspecified. */
+FN2_API int fn2_flow_warp_backward_cpu(const float* image, const float* flow, const float* warped_diff,
+                                       float* image_diff, float* flow_diff, int N, int C, int H, int W,
+                                       int propagate_image, int propagate_flow) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t wh = (size_t)W * H, whc = wh * C;
+  memset(image_diff, 0, sizeof(float) * whc * N);
+  memset(flow_diff, 0, sizeof(float) * wh * 2 * N);
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        const size_t off = whc * n;
+        const float x2 = (float)x + flow[2 * wh * n + (size_t)y * W + x];
+        const float y2 = (float)y + flow[2 * wh * n + wh + (size_t)y * W + x];
+        if (x2 >= 0.f && y2 >= 0.f && x2 < W && y2 < H) {
+          const int ixL = (int)x2, iyT = (int)y2;
+          const int ixR = imin(ixL + 1, W - 1), iyB = imin(iyT + 1, H - 1);
+          const float alpha = x2 - ixL, beta = y2 - iyT;
+          for (int c = 0; c < C; ++c) {
+            const float g = warped_diff[off + c * wh + (size_t)y * W + x];
+            float* d = image_diff + off + c * wh;
+            d[(size_t)iyT * W + ixL] += g * (1 - alpha) * (1 - beta);          /* cu:197 */
+            d[(size_t)iyT * W + ixR] += g * alpha * (1 - beta);                /* cu:198 */
+            d[(size_t)iyB * W + ixL] += g * (1 - alpha) * beta;                /* cu:199 */
+            d[(size_t)iyB * W + ixR] += g * alpha * beta;                      /* cu:200 */
+          }
+          float gamma = iyB - y2;                                              /* cu:203 */
+          float bot = 0.f;
+          for (int c = 0; c < C; ++c) {
+            const float* im = image + off + c * wh;
+            float temp = 0.f;
+            temp += gamma * (im[(size_t)iyT * W + ixR] - im[(size_t)iyT * W + ixL]);
+            temp += (1 - gamma) * (im[(size_t)iyB * W + ixR] - im[(size_t)iyB * W + ixL]);
+            bot += warped_diff[off + c * wh + (size_t)y * W + x] * temp;
+          }
+          flow_diff[2 * wh * n + (size_t)y * W + x] = bot;                     /* cu:214 */
+          gamma = ixR - x2;                                                     /* cu:216 */
+          bot = 0.f;
+          for (int c = 0; c < C; ++c) {
+            const float* im = image + off + c * wh;
+            float temp = 0.f;
+            temp += gamma * (im[(size_t)iyB * W + ixL] - im[(size_t)iyT * W + ixL]);
+            temp += (1 - gamma) * (im[(size_t)iyB * W + ixR] - im[(size_t)iyT * W + ixR]);
+            bot += warped_diff[off + c * wh + (size_t)y * W + x] * temp;
+          }
+          flow_diff[2 * wh * n + wh + (size_t)y * W + x] = bot;                /* cu:227 */
+        }
+      }
+  if (!propagate_image) memset(image_diff, 0, sizeof(float) * whc * N);
+  if (!propagate_flow) memset(flow_diff, 0, sizeof(float) * wh * 2 * N);
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Resample: resample_layer.cu:14-206.
+ * ---------------------------------------------------------------------------------------------- */
+static inline float bicubic_coeff(float x_) {                 /* :14-20 */
+  const float x = fabsf(x_);
+  if (x <= 1.0f) return x * x * (1.5f * x - 2.5f) + 1.0f;
+  else if (x < 2.0f) return x * (x * (-0.5f * x + 2.5f) - 4.0f) + 2.0f;
+  else return 0.0f;
+}
+static inline float triangle_coeff(float x) {                 /* :28-33 */
+  if (-1 <= x && x < 0) return x + 1;
+  if (0 <= x && x <= 1) return 1 - x;
+  return 0;
+}
+
+FN2_API int fn2_resample_forward_cpu(const float* in, float* out, int N, int C, int Hin, int Win,
+                                     int Hout, int Wout, int type, int antialias_param) {
+  if (N < 0 || C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return FN2_ERR_INVALID_ARG;
+  if (type != FN2_RESAMPLE_NEAREST && type != FN2_RESAMPLE_LINEAR && type != FN2_RESAMPLE_CUBIC)
+    return FN2_ERR_UNSUPPORTED;                                                  /* resample_layer.cpp:17-20 */
+  const float fx = (float)Win / (float)Wout;                                     /* :146 */
+  const float fy = (float)Hin / (float)Hout;                                     /* :147 */
+  const int in_cs = Win * Hin, out_cs = Wout * Hout;
+  const long nthreads = (long)N * C * out_cs;
+  if (type == FN2_RESAMPLE_NEAREST) {
+#pragma omp parallel for schedule(static)
+    for (long index = 0; index < nthreads; ++index) {
+      const int c = (int)(index / out_cs);
+      const int x_out = (int)(index % out_cs) % Wout, y_out = (int)(index % out_cs) / Wout;
+      const float x_in = x_out * fx + fy / 2.0f - 0.5f;                          /* :117 (sic: fy) */
+      const float y_in = y_out * fy + fx / 2.0f - 0.5f;                          /* :118 (sic: fx) */
+      int xr = (int)roundf(x_in), yr = (int)roundf(y_in);                        /* :120-121 */
+      /* The reference does not clamp (:123) and reads out of bounds when fx != fy pushes the
+       * rounded index outside; clamp so the oracle itself stays defined. */
+      xr = imin(imax(xr, 0), Win - 1);
+      yr = imin(imax(yr, 0), Hin - 1);
+      out[index] = in[(size_t)c * in_cs + (size_t)yr * Win + xr];
+    }
+    return FN2_OK;
+  }
+  const int cubic = (type == FN2_RESAMPLE_CUBIC);
+  const int is_down = (fx > 1) || (fy > 1);                                      /* :179 */
+  const int antialias = is_down && antialias_param;                              /* :180 */
+  const int kernel_width = cubic ? 4 : 2;                                        /* :182-185 */
+#pragma omp parallel for schedule(static)
+  for (long index = 0; index < nthreads; ++index) {
+    const int c = (int)(index / out_cs);
+    const int x_out = (int)(index % out_cs) % Wout, y_out = (int)(index % out_cs) / Wout;
+    const float x_in = x_out * fx + fy / 2.0f - 0.5f;                            /* :62 */
+    const float y_in = y_out * fy + fx / 2.0f - 0.5f;                            /* :63 */
+    const int xr = (int)roundf(x_in), yr = (int)roundf(y_in);                    /* :65-66 */
+    float sum = 0, wsum = 0;
+    const float ax = 1.0f / (antialias ? fx : 1.0f);                             /* :71 */
+    const float ay = 1.0f / (antialias ? fy : 1.0f);                             /* :72 */
+    const int rx = (fx < 1.0f) ? 2 : (int)ceilf((float)kernel_width / ax);       /* :73 */
+    const int ry = (fy < 1.0f) ? 2 : (int)ceilf((float)kernel_width / ay);       /* :74 */
+    for (int y = yr - ry; y <= yr + ry; ++y)
+      for (int x = xr - rx; x <= xr + rx; ++x) {
+        if (y < 0 || x < 0) continue;
+        if (y >= Hin || x >= Win) continue;
+        const float dx = x_in - x, dy = y_in - y;
+        float w;
+        if (cubic) w = ax * bicubic_coeff(ax * dx) * ay * bicubic_coeff(ay * dy);      /* :87 */
+        else w = ax * triangle_coeff(ax * dx) * ay * triangle_coeff(ay * dy);          /* :89 */
+        sum = fmaf(w, in[(size_t)c * in_cs + (size_t)y * Win + x], sum);                /* :90 */
+        wsum += w;
+      }
+    out[index] = (!wsum) ? 0 : (sum / wsum);                                      /* :93 */
+  }
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * L1Loss: l1loss_layer.cpp:11-90 (composition) + l1loss_layer.cu:67-190.
+ * Sub-layers: Eltwise SUM coeff (+1,-1) (eltwise_layer.cpp:59-65), Power^2, 1x1 Convolution with a
+ * constant filler (sum over channels), Power^0.5 with shift epsilon (power_layer.cu:9-30, :33-83).
+ * The reduction is a cublasSdot in the reference (order unspecified); we accumulate in double.
+ * ---------------------------------------------------------------------------------------------- */
+FN2_API int fn2_l1loss_forward_cpu(const fn2_l1loss_params* p, const float* b0, const float* b1,
+                                   float* loss_out, float* normalize_coeff_out,
+                                   int N, int C, int H, int W) {
+  if (!p || N < 1 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W, count = (size_t)N * C * hw;
+  double nvalid = 0;
+#pragma omp parallel for reduction(+ : nvalid) schedule(static)
+  for (size_t i = 0; i < count; ++i) {
+    const float d = b1 ? (b0[i] - b1[i]) : b0[i];
+    nvalid += (d == d) ? 1.0 : 0.0;                                /* FindNotNaNs cu:20-24; dot(mask,mask) cu:87 */
+  }
+  float norm;
+  if (p->normalize_by_num_entries) norm = (float)nvalid / (float)C;      /* cu:86-88 */
+  else norm = (float)N;                                                  /* cu:90 */
+  double dot = 0;
+  if (p->l2_per_location) {
+    const float wgt = p->l2_prescale_by_channels ? 1.f / (float)C : 1.f;    /* cpp:47-51 */
+    const float plat2 = p->plateau * p->plateau;                             /* cu:104 */
+#pragma omp parallel for reduction(+ : dot) schedule(static)
+    for (size_t q = 0; q < (size_t)N * hw; ++q) {
+      const size_t n = q / hw, s = q % hw;
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const size_t i = (n * C + c) * hw + s;
+        float d = b1 ? (b0[i] - b1[i]) : b0[i];
+        d = (d == d) ? d : 0.f;                                     /* KillMasked cu:95-96 */
+        acc += wgt * (d * d);                                       /* square cu:99, 1x1 conv cu:100 */
+      }
+      if (p->plateau > 0 && fabsf(acc) < plat2) acc = 0.f;          /* cu:103-114 */
+      dot += (double)sqrtf(acc + p->epsilon);                       /* Power(0.5, shift eps) cu:117; dot with ones cu:119 */
+    }
+  } else {
+#pragma omp parallel for reduction(+ : dot) schedule(static)
+    for (size_t i = 0; i < count; ++i) {
+      float d = b1 ? (b0[i] - b1[i]) : b0[i];
+      int keep = (d == d);
+      if (p->plateau > 0 && fabsf(d) < p->plateau) keep = 0;        /* MaskPlateauValues cu:52-56,123-126 (NaN: fabs(NaN)<p false) */
+      d = keep ? d : 0.f;                                           /* KillMasked cu:132-134 */
+      const float sign = d > 0 ? 1.f : -1.f;                        /* ComputeSign cu:11-15 */
+      dot += (double)(d * sign);                                    /* cu:139 */
+    }
+  }
+  if (loss_out) *loss_out = (float)dot / norm;                      /* cu:141 */
+  if (normalize_coeff_out) *normalize_coeff_out = norm;
+  return FN2_OK;
+}
+
+FN2_API int fn2_l1loss_backward_cpu(const fn2_l1loss_params* p, const float* b0, const float* b1,
+                                    float top_diff, float normalize_coeff,
+                                    float* b0_diff, float* b1_diff, int N, int C, int H, int W) {
+  if (!p || N < 1 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  const float alpha = top_diff / normalize_coeff;                   /* cu:155 */
+  if (p->l2_per_location) {
+    const float wgt = p->l2_prescale_by_channels ? 1.f / (float)C : 1.f;
+    const float plat2 = p->plateau * p->plateau;
+#pragma omp parallel for schedule(static)
+    for (size_t q = 0; q < (size_t)N * hw; ++q) {
+      const size_t n = q / hw, s = q % hw;
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const size_t i = (n * C + c) * hw + s;
+        float d = b1 ? (b0[i] - b1[i]) : b0[i];
+        d = (d == d) ? d : 0.f;
+        acc += wgt * (d * d);
+      }
+      int plateau_kill = 0;
+      if (p->plateau > 0 && fabsf(acc) < plat2) { acc = 0.f; plateau_kill = 1; }
+      const float e = sqrtf(acc + p->epsilon);
+      /* sqrt_output diff = alpha * 1 (cu:158); Power backward general branch (power_layer.cu:62-74):
+       * diff = top_data / (x + shift) * 0.5 * top_diff */
+      float ds = (e / (acc + p->epsilon)) * 0.5f * alpha;
+      if (plateau_kill) ds = 0.f;                                   /* cu:162-166 */
+      for (int c = 0; c < C; ++c) {
+        const size_t i = (n * C + c) * hw + s;
+        float d = b1 ? (b0[i] - b1[i]) : b0[i];
+        const int valid = (d == d);
+        d = valid ? d : 0.f;
+        /* conv backward: wgt * ds; square backward (power_layer.cu:48-52): 2 * d * that */
+        float g = (2.f * d) * (wgt * ds);
+        g = valid ? g : 0.f;                                        /* KillMasked cu:179-180 */
+        b0_diff[i] = g;                                             /* Eltwise backward coeff +1 */
+        if (b1 && b1_diff) b1_diff[i] = -g;                         /* coeff -1 */
+      }
+    }
+  } else {
+    const size_t count = (size_t)N * C * hw;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < count; ++i) {
+      float d = b1 ? (b0[i] - b1[i]) : b0[i];
+      int keep = (d == d);
+      if (p->plateau > 0 && fabsf(d) < p->plateau) keep = 0;
+      d = keep ? d : 0.f;
+      const float sign = d > 0 ? 1.f : -1.f;
+      float g = alpha * sign;                                       /* cu:175-176 */
+      g = keep ? g : 0.f;                                           /* cu:179-180 */
+      b0_diff[i] = g;
+      if (b1 && b1_diff) b1_diff[i] = -g;
+    }
+  }
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ChannelNorm: channel_norm_layer.cpp:43-69 / .cu:16-47.
+ * ---------------------------------------------------------------------------------------------- */
+FN2_API int fn2_channel_norm_forward_cpu(const float* bottom, float* top, int N, int C, int H, int W) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+  for (size_t q = 0; q < (size_t)N * hw; ++q) {
+    const size_t n = q / hw, s = q % hw;
+    float norm = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = bottom[(n * C + c) * hw + s];
+      norm = fmaf(v, v, norm);                                       /* cu:27-28 */
+    }
+    top[q] = sqrtf(norm);                                            /* cu:31-32 */
+  }
+  return FN2_OK;
+}
+
+FN2_API int fn2_channel_norm_backward_cpu(const float* bottom, const float* top, const float* top_diff,
+                                          float* bottom_diff, int N, int C, int H, int W) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < (size_t)N * C * hw; ++i) {
+    const size_t n = i / (C * hw), s = i % hw;
+    /* cu:45: float * float / (float + 1e-9 [double]) -> evaluated in double, rounded on store */
+    bottom_diff[i] = (float)((double)(top_diff[n * hw + s] * bottom[i]) / ((double)top[n * hw + s] + 1e-9));
+  }
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Downsample: downsample_layer.cu:15-72, host :75-129.
+ * ---------------------------------------------------------------------------------------------- */
+FN2_API int fn2_downsample_forward_cpu(const float* bottom, float* top, int N, int C, int Hin, int Win,
+                                       int Hout, int Wout) {
+  if (N < 0 || C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return FN2_ERR_INVALID_ARG;
+  if (Hin == Hout && Win == Wout) {                                  /* downsample_layer.cpp:53-56 shares the blob */
+    memcpy(top, bottom, sizeof(float) * (size_t)N * C * Hin * Win);
+    return FN2_OK;
+  }
+  const float widthScale = (float)(Win - 1) / (float)(Wout - 1);      /* :104 */
+  const float heightScale = (float)(Hin - 1) / (float)(Hout - 1);     /* :105 */
+  const int wradius = (int)ceilf(widthScale), hradius = (int)ceilf(heightScale);   /* :107-108 */
+  const long topcount = (long)N * C * Hout * Wout;
+#pragma omp parallel for schedule(static)
+  for (long index = 0; index < topcount; ++index) {
+    const int destx = (int)(index % Wout), desty = (int)((index / Wout) % Hout);
+    const long cn = index / Wout / Hout;
+    const float botx = ((float)destx / (float)(Wout - 1)) * (float)(Win - 1);      /* :27 */
+    const float boty = ((float)desty / (float)(Hout - 1)) * (float)(Hin - 1);      /* :28 */
+    const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                /* :30-31 */
+    const float* src = bottom + (size_t)cn * Hin * Win;
+    float accum_value = 0, accum_weight = 0, accum_nan = 0;
+    for (int yoff = -hradius; yoff <= hradius; ++yoff) {
+      const int by = iboty + yoff;
+      for (int xoff = -wradius; xoff <= wradius; ++xoff) {
+        const int bx = ibotx + xoff;
+        if (bx >= 0 && by >= 0 && bx < Win && by < Hin) {
+          float sample = src[(size_t)by * Win + bx];
+          float weight = fmaxf(0.0f, 1.0f - (fabsf((float)bx - botx) / widthScale)) *
+                         fmaxf(0.0f, 1.0f - (fabsf((float)by - boty) / heightScale));   /* :52 */
+          if (sample != sample) { accum_nan += weight; sample = 0; weight = 0; }       /* :53-57 */
+          accum_value = fmaf(sample, weight, accum_value);                              /* :59 */
+          accum_weight += weight;                                                       /* :60 */
+        }
+      }
+    }
+    if (accum_nan / accum_weight > 0.5f) top[index] = u2f(0x7fffffffu);               /* :64-65 */
+    else top[index] = accum_value / accum_weight;                                      /* :67 */
+  }
+  return FN2_OK;
+}
