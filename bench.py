@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- FlowNetC forward throughput on MI355X (BASELINE.json configs[1]).
+
+A "step" = one FlowNetC deploy forward over one batch of 8 synthetic 448x320 image pairs per GPU
+(weak scaling: every rank owns its own batch, no data-path collective -- SURVEY.md section 8e).
+`--mode train` times fwd + bwd + RCCL gradient all-reduce + Adam instead (configs[3]).
+
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it is launched through
+torch.distributed.run with one rank per GPU.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from flownet2_amd import functional as Fn   # noqa: E402
+from flownet2_amd import nets, ops          # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6290 measured copy)
+F32_MFMA_PEAK_TFLOPS = 157.3    # same table: dense f32-input MFMA peak (= f32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--width", type=int, default=448)
+    ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--corr-iters", type=int, default=200)
+    return ap.parse_args()
+
+
+def synth_batch(batch, h, w, seed, device):
+    """uint8-valued BGR images as scripts/run-flownet.py:28-35 feeds them (raw 0..255 floats)."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (batch, 3, h, w)).astype(np.float32)
+    b = np.roll(a, (3, -5), (2, 3)) + rng.normal(0, 2, a.shape).astype(np.float32)
+    return torch.from_numpy(a).to(device), torch.from_numpy(np.clip(b, 0, 255).astype(np.float32)).to(device)
+
+
+def corr_roofline(device, batch, h, w, iters):
+    """Time the correlation kernel alone (HIP events on the launch stream) at the conv3 shape of the workload."""
+    C, H, W, D2 = 256, h // 8, w // 8, 441
+    g = torch.Generator(device=device).manual_seed(0)
+    a = torch.randn(batch, C, H, W, device=device, generator=g)
+    b = torch.randn(batch, C, H, W, device=device, generator=g)
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    out = torch.empty(batch, D2, H, W, device=device)
+    for _ in range(10):
+        ops.correlation_forward(p, a, b, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.correlation_forward(p, a, b, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters                       # seconds per launch
+    # per-launch events (includes launch gaps) vs back-to-back average: take the back-to-back average
+    alg_bytes = 4.0 * batch * H * W * (2 * C + D2)               # read both maps once + write top once
+    alg_flops = 2.0 * C * D2 * batch * H * W
+    tf = alg_flops / t / 1e12
+    gbps = alg_bytes / t / 1e9
+    return {
+        "kernel": "corr_fwd (K=1,md=20,s2=2) [%d,%d,%d,%d]" % (batch, C, H, W),
+        "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "us_per_launch": round(t * 1e6, 2),
+        "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
+        "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
+        "note": "exact-fp32 correlation is FMA-bound (59 flop/B > machine balance); hbm = algorithmic bytes / time",
+    }
+
+
+def cpu_baseline(P_cpu, img0, img1, flow_gpu, budget_s=20.0):
+    """Oracle leg: the same graph on the host (C oracle ops + torch-CPU fp32 conv), bounded sample."""
+    import oracle
+    from oracle import backend as cpu_backend
+    i0, i1 = img0.cpu(), img1.cpu()
+    n = i0.shape[0]
+    with torch.no_grad():
+        t0 = time.time()
+        flow_cpu = nets.deploy_forward("C", P_cpu, i0, i1, cpu_backend)
+        first = time.time() - t0
+        reps, total = 1, first
+        while total + first < budget_s and reps < 5:
+            t0 = time.time()
+            nets.deploy_forward("C", P_cpu, i0, i1, cpu_backend)
+            total += time.time() - t0
+            reps += 1
+    epe = float(((flow_gpu.cpu() - flow_cpu) ** 2).sum(1).sqrt().mean())
+    cores = max(oracle.num_threads(), torch.get_num_threads())
+    return {"value": round(n * reps / total, 3), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x FlowNetC deploy forward, batch {n} @{i0.shape[3]}x{i0.shape[2]}: C oracle "
+                      f"(restated reference kernels, OpenMP) + torch-CPU fp32 conv; {os.cpu_count()} host cpus"}, epe
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); cuda not available")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    B, H, W = args.batch, args.height, args.width
+    P_cpu = nets.init_params("C", seed=0)                      # same weights on every rank (replicas)
+    P = {k: v.to(device) for k, v in P_cpu.items()}
+    img0, img1 = synth_batch(B, H, W, seed=1234 + rank, device=device)
+
+    if args.mode == "train":
+        for v in P.values():
+            v.requires_grad_(True)
+        plist = list(P.values())
+        opt = torch.optim.Adam(plist, lr=1e-5)
+        gt = torch.randn(B, 2, H, W, device=device) * 5
+        gt[torch.rand(B, 1, H, W, device=device).expand(-1, 2, -1, -1) < 0.05] = float("nan")
+        flat = None
+
+        def step():
+            nonlocal flat
+            opt.zero_grad(set_to_none=False)
+            pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
+            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], Fn), gt, Fn)
+            loss.backward()
+            if world > 1:
+                # one flat fp32 bucket (39.18 M floats = 156.7 MB): sum over ranks, scale 1/world (parallel.cpp:377)
+                grads = [p.grad for p in plist]
+                flat = torch._utils._flatten_dense_tensors(grads)
+                dist.all_reduce(flat)
+                flat.mul_(1.0 / world)
+                for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                    g.copy_(s)
+            opt.step()
+            return loss
+    else:
+        def step():
+            with torch.no_grad():
+                return nets.deploy_forward("C", P, img0, img1, Fn)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        conv_gf = nets.conv_flops("C", H, W) * B / 1e9
+        res = {
+            "metric": "image-pairs/sec FlowNetC " + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
+            "value": round(pairs / elapsed, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FlowNetC %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
+                                   "pairs, seeded random-init weights (39.18 M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H),
+                       "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
+                       "conv_stack": "MIOpen fp32 via torch (%.1f GFLOP/step/GPU)" % conv_gf},
+            "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
+        }
+        if world == 1:
+            res["roofline"] = corr_roofline(device, B, H, W, args.corr_iters)
+            if args.mode == "fwd" and not args.no_cpu_baseline:
+                cb, epe = cpu_baseline(P_cpu, img0, img1, out)
+                res["cpu_baseline"] = cb
+                res["epe_vs_cpu_oracle"] = epe
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

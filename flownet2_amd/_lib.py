@@ -1,0 +1,92 @@
+"""ctypes binding of libflownet2_hip.so (the C ABI in include/flownet2_hip.h).
+
+There is NO fallback: if the shared library is missing or does not load, every operator raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libflownet2_hip.so")
+
+# every symbol include/flownet2_hip.h declares
+EXPORTS = [
+    "fn2_version", "fn2_last_error_string",
+    "fn2_correlation_out_shape", "fn2_correlation_workspace_bytes", "fn2_correlation_forward", "fn2_correlation_backward",
+    "fn2_flow_warp_forward", "fn2_flow_warp_backward",
+    "fn2_resample_forward",
+    "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
+    "fn2_channel_norm_forward", "fn2_channel_norm_backward",
+    "fn2_downsample_forward",
+]
+
+
+class Fn2Error(RuntimeError):
+    """Non-zero status from the C ABI (the reference would have hit CHECK / LOG(FATAL))."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[fn2 status {status}] {message}")
+        self.status = status
+
+
+class CorrParams(C.Structure):
+    _fields_ = [("pad", C.c_int), ("kernel_size", C.c_int), ("max_displacement", C.c_int),
+                ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int)]
+
+
+class L1LossParams(C.Structure):
+    _fields_ = [("l2_per_location", C.c_int), ("l2_prescale_by_channels", C.c_int),
+                ("normalize_by_num_entries", C.c_int), ("epsilon", C.c_float), ("plateau", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises if the native library is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} not found: the HIP extension is not built. Run `python -m flownet2_amd.build` "
+            "(or __graft_entry__.build()). flownet2_amd has no CPU / PyTorch fallback.")
+    L = C.CDLL(SO_PATH)
+    vp, fp, i, sz = C.c_void_p, C.c_void_p, C.c_int, C.c_size_t
+    L.fn2_version.restype = C.c_char_p
+    L.fn2_last_error_string.restype = C.c_char_p
+    L.fn2_correlation_out_shape.argtypes = [C.POINTER(CorrParams), i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.fn2_correlation_workspace_bytes.argtypes = [C.POINTER(CorrParams), i, i, i, i]
+    L.fn2_correlation_workspace_bytes.restype = sz
+    L.fn2_correlation_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_correlation_backward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_flow_warp_forward.argtypes = [fp, fp, fp, i, i, i, i, i, vp]
+    L.fn2_flow_warp_backward.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, i, i, vp]
+    L.fn2_resample_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, i, vp]
+    L.fn2_l1loss_workspace_bytes.argtypes = [i, i, i, i]
+    L.fn2_l1loss_workspace_bytes.restype = sz
+    L.fn2_l1loss_forward.argtypes = [C.POINTER(L1LossParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_l1loss_backward.argtypes = [C.POINTER(L1LossParams), fp, fp, C.c_float, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_channel_norm_forward.argtypes = [fp, fp, i, i, i, i, vp]
+    L.fn2_channel_norm_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]
+    L.fn2_downsample_forward.argtypes = [fp, fp, i, i, i, i, i, i, vp]
+    if hasattr(L, "fn2_debug_set_correlation_impl"):
+        L.fn2_debug_set_correlation_impl.argtypes = [i]
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"{SO_PATH} does not export {name}")
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:   # default restype: status code
+            pass
+    _lib = L
+    return L
+
+
+def check(status: int):
+    if status != 0:
+        raise Fn2Error(status, lib().fn2_last_error_string().decode())
+
+
+def version() -> str:
+    return lib().fn2_version().decode()

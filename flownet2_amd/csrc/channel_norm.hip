@@ -1,0 +1,120 @@
+// ChannelNorm + Downsample for gfx950 (HBM-bound streaming kernels).
+//
+// ChannelNorm: ChannelNormLayer::Forward_gpu / Backward_gpu, reference
+//   src/caffe/layers/channel_norm_layer.cu:16-90.
+// Downsample : DownsampleLayer::Forward_gpu, reference src/caffe/layers/downsample_layer.cu:15-129.
+#include "fn2_common.hpp"
+
+#include <cmath>
+
+namespace fn2 {
+
+__global__ void __launch_bounds__(256) channel_norm_fwd(const float* __restrict__ bot, float* __restrict__ top,
+                                                        int N, int C, size_t hw) {
+  const long long total = (long long)N * hw;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const size_t n = idx / hw, s = idx % hw;
+    const float* p = bot + n * C * hw + s;
+    float norm = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = p[(size_t)c * hw];
+      norm = fmaf(v, v, norm);          // :27-28
+    }
+    top[idx] = sqrtf(norm);             // :31-32
+  }
+}
+
+__global__ void __launch_bounds__(256) channel_norm_bwd(const float* __restrict__ bot, const float* __restrict__ top,
+                                                        const float* __restrict__ top_diff, float* __restrict__ bot_diff,
+                                                        int N, int C, size_t hw) {
+  const long long total = (long long)N * C * hw;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const size_t n = idx / (C * hw), s = idx % hw;
+    // :45 -- `top_data + 1e-9` promotes the quotient to double in the reference.
+    bot_diff[idx] = (float)((double)(top_diff[n * hw + s] * bot[idx]) / ((double)top[n * hw + s] + 1e-9));
+  }
+}
+
+struct DownArgs {
+  int NC, Hin, Win, Hout, Wout, wradius, hradius;
+  float widthScale, heightScale;
+};
+
+__global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+  const long long total = (long long)a.NC * a.Hout * a.Wout;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int destx = (int)(idx % a.Wout), desty = (int)((idx / a.Wout) % a.Hout);
+    const long long cn = idx / a.Wout / a.Hout;
+    const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
+    const float boty = ((float)desty / (float)(a.Hout - 1)) * (float)(a.Hin - 1);     // :28
+    const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                   // :30-31
+    const float* p = src + (size_t)cn * a.Hin * a.Win;
+    float accum_value = 0.f, accum_weight = 0.f, accum_nan = 0.f;
+    for (int yoff = -a.hradius; yoff <= a.hradius; ++yoff) {
+      const int by = iboty + yoff;
+      for (int xoff = -a.wradius; xoff <= a.wradius; ++xoff) {
+        const int bx = ibotx + xoff;
+        if (bx >= 0 && by >= 0 && bx < a.Win && by < a.Hin) {
+          float sample = p[(size_t)by * a.Win + bx];
+          float weight = fmaxf(0.0f, 1.0f - (fabsf((float)bx - botx) / a.widthScale)) *
+                         fmaxf(0.0f, 1.0f - (fabsf((float)by - boty) / a.heightScale));   // :52
+          if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }    // :53-57
+          accum_value = fmaf(sample, weight, accum_value);
+          accum_weight += weight;
+        }
+      }
+    }
+    if (accum_nan / accum_weight > 0.5f) dst[idx] = __builtin_bit_cast(float, 0x7fffffffu);   // :64-65
+    else dst[idx] = accum_value / accum_weight;                                               // :67
+  }
+}
+
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API int fn2_channel_norm_forward(const float* bottom, float* top, int N, int C, int H, int W, void* stream) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
+  if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
+  if (N == 0) return FN2_OK;
+  const size_t hw = (size_t)H * W;
+  hipLaunchKernelGGL(channel_norm_fwd, dim3(blocks_for((long long)N * hw, 256)), dim3(256), 0, as_stream(stream), bottom, top, N, C, hw);
+  return check_launch("channel_norm_forward");
+}
+
+FN2_API int fn2_channel_norm_backward(const float* bottom, const float* top, const float* top_diff, float* bottom_diff,
+                                      int N, int C, int H, int W, void* stream) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
+  if (!bottom || !top || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
+  if (N == 0) return FN2_OK;
+  const size_t hw = (size_t)H * W;
+  hipLaunchKernelGGL(channel_norm_bwd, dim3(blocks_for((long long)N * C * hw, 256)), dim3(256), 0, as_stream(stream), bottom, top,
+                     top_diff, bottom_diff, N, C, hw);
+  return check_launch("channel_norm_backward");
+}
+
+FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C, int Hin, int Win, int Hout, int Wout,
+                                   void* stream) {
+  if (N < 0 || C < 1 || Hin < 1 || Win < 1) return fail(FN2_ERR_INVALID_ARG, "downsample: bad bottom shape");
+  if (Hout < 1 || Wout < 1) return fail(FN2_ERR_INVALID_ARG, "DownsampleLayer must have top_height > 0 and top_width > 0");
+  if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "downsample: NULL blob pointer");
+  if (N == 0) return FN2_OK;
+  hipStream_t st = as_stream(stream);
+  if (Hin == Hout && Win == Wout) {   // downsample_layer.cpp:53-56 shares the blob; we copy
+    if (bottom != top &&
+        hipMemcpyAsync(top, bottom, sizeof(float) * (size_t)N * C * Hin * Win, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(FN2_ERR_LAUNCH, "downsample: hipMemcpyAsync failed");
+    return FN2_OK;
+  }
+  DownArgs a;
+  a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
+  a.widthScale = (float)(Win - 1) / (float)(Wout - 1);     // :104
+  a.heightScale = (float)(Hin - 1) / (float)(Hout - 1);    // :105
+  a.wradius = (int)std::ceil(a.widthScale);                // :107
+  a.hradius = (int)std::ceil(a.heightScale);               // :108
+  hipLaunchKernelGGL(downsample_fwd, dim3(blocks_for((long long)a.NC * Hout * Wout, 256)), dim3(256), 0, st, bottom, top, a);
+  return check_launch("downsample_forward");
+}

@@ -1,0 +1,224 @@
+// Correlation (cost volume) for gfx950.
+//
+// Replaces CorrelationLayer::Forward_gpu / Backward_gpu (reference:
+// src/caffe/layers/correlation_layer.cu:431-603) behind fn2_correlation_{forward,backward}.
+//
+// Unlike the reference there is no padded NHWC scratch copy (blob_rearrange_kernel2 + two
+// cudaMemsets, correlation_layer.cu:447-458): every kernel reads the NCHW inputs directly and
+// treats out-of-image positions as the zero padding.
+//
+// Kernels in this file
+//   corr_fwd_generic / corr_bwd{0,1}_generic : any (kernel_size, stride_1, stride_2, pad, type);
+//       one thread per output element, x fastest (coalesced).  Fallback + cross-check.
+//   corr_fwd_mfma (correlation_mfma.hip)     : the FlowNetC fast path, kernel_size 1, stride_1 1,
+//       MULTIPLY: banded GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
+#include "fn2_common.hpp"
+
+#include <cmath>
+
+namespace fn2 {
+
+struct CorrGeom {
+  int N, C, H, W;
+  int pad, K, md, s1, s2, kr;
+  int topC, topH, topW, ngr, ngw;
+  int type;
+};
+
+// CorrelationLayer::LayerSetUp + Reshape, correlation_layer.cpp:13-84.
+int corr_geometry(const fn2_corr_params* p, int N, int C, int H, int W, CorrGeom* g) {
+  if (!p) return fail(FN2_ERR_INVALID_ARG, "correlation: params == NULL");
+  if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "correlation: bad bottom shape [%d,%d,%d,%d]", N, C, H, W);
+  if (p->kernel_size < 1 || p->kernel_size % 2 == 0)
+    return fail(FN2_ERR_INVALID_ARG, "correlation: Odd kernel size required (got %d)", p->kernel_size);
+  if (p->stride1 < 1 || p->stride2 < 1) return fail(FN2_ERR_INVALID_ARG, "correlation: strides must be >= 1");
+  if (p->max_displacement < 0 || p->pad < 0) return fail(FN2_ERR_INVALID_ARG, "correlation: negative pad / max_displacement");
+  if (p->corr_type != FN2_CORR_MULTIPLY && p->corr_type != FN2_CORR_SUBTRACT)
+    return fail(FN2_ERR_INVALID_ARG, "correlation: unknown correlation_type %d", p->corr_type);
+  g->N = N; g->C = C; g->H = H; g->W = W;
+  g->pad = p->pad; g->K = p->kernel_size; g->md = p->max_displacement; g->s1 = p->stride1; g->s2 = p->stride2;
+  g->type = p->corr_type;
+  g->kr = (g->K - 1) / 2;
+  const int border = g->md + g->kr;
+  g->topW = (int)std::ceil((float)(W + 2 * g->pad - border * 2) / (float)g->s1);
+  g->topH = (int)std::ceil((float)(H + 2 * g->pad - border * 2) / (float)g->s1);
+  if (g->topW < 1 || g->topH < 1)
+    return fail(FN2_ERR_INVALID_ARG, "Correlation cannot be done with current settings. Neighborhood and kernel don't fit in blob");
+  g->ngr = g->md / g->s2;
+  g->ngw = 2 * g->ngr + 1;
+  g->topC = g->ngw * g->ngw;
+  if (g->pad < g->md)
+    return fail(FN2_ERR_INVALID_ARG, "correlation: pad (%d) < max_displacement (%d) reads outside the padded blob in the reference; refused", g->pad, g->md);
+  return FN2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic forward: thread per top element.
+// ---------------------------------------------------------------------------------------------
+template <bool SUB>
+__global__ void __launch_bounds__(256) corr_fwd_generic(const float* __restrict__ b0, const float* __restrict__ b1,
+                                                        float* __restrict__ top, CorrGeom g) {
+  const long long total = (long long)g.N * g.topC * g.topH * g.topW;
+  const size_t plane = (size_t)g.H * g.W;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % g.topW);
+    const int y = (int)((idx / g.topW) % g.topH);
+    const int tc = (int)((idx / g.topW / g.topH) % g.topC);
+    const int n = (int)(idx / g.topW / g.topH / g.topC);
+    const int s2o = (tc % g.ngw - g.ngr) * g.s2;
+    const int s2p = (tc / g.ngw - g.ngr) * g.s2;
+    const float* a_n = b0 + (size_t)n * g.C * plane;
+    const float* b_n = b1 + (size_t)n * g.C * plane;
+    float sum = 0.f;
+    for (int j = 0; j < g.K; ++j) {
+      const int ya = y * g.s1 + g.md + j - g.pad, yb = ya + s2p;
+      for (int i = 0; i < g.K; ++i) {
+        const int xa = x * g.s1 + g.md + i - g.pad, xb = xa + s2o;
+        const bool a_in = (ya >= 0) & (ya < g.H) & (xa >= 0) & (xa < g.W);
+        const bool b_in = (yb >= 0) & (yb < g.H) & (xb >= 0) & (xb < g.W);
+        const float* ap = a_n + (size_t)ya * g.W + xa;
+        const float* bp = b_n + (size_t)yb * g.W + xb;
+        if (!SUB) {
+          if (a_in && b_in)
+            for (int c = 0; c < g.C; ++c) sum = fmaf(ap[c * plane], bp[c * plane], sum);
+        } else {
+          for (int c = 0; c < g.C; ++c) {
+            const float av = a_in ? ap[c * plane] : 0.f;
+            const float bv = b_in ? bp[c * plane] : 0.f;
+            sum += fabsf(av - bv);
+          }
+        }
+      }
+    }
+    top[idx] = sum / (float)(g.K * g.K * g.C);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic backward: thread per bottom element (x fastest), gather over displacements -- no atomics.
+// Window arithmetic as CorrelateDataBackward0/1 (correlation_layer.cu:131-150, :212-224).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ceil_div(int a, int s) { return (a >= 0) ? (a + s - 1) / s : -((-a) / s); }
+__device__ __forceinline__ int floor_div(int a, int s) { return (a >= 0) ? a / s : -((-a + s - 1) / s); }
+
+__device__ __forceinline__ float padded_at(const float* plane_ptr, int m, int l, const CorrGeom& g) {
+  const int y = m - g.pad, x = l - g.pad;
+  return ((y >= 0) & (y < g.H) & (x >= 0) & (x < g.W)) ? plane_ptr[(size_t)y * g.W + x] : 0.f;
+}
+
+template <bool SUB, int WHICH>
+__global__ void __launch_bounds__(256) corr_bwd_generic(const float* __restrict__ b0, const float* __restrict__ b1,
+                                                        const float* __restrict__ top_diff,
+                                                        float* __restrict__ bdiff, CorrGeom g) {
+  const long long total = (long long)g.N * g.C * g.H * g.W;
+  const size_t plane = (size_t)g.H * g.W;
+  const size_t tplane = (size_t)g.topH * g.topW;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % g.W);
+    const int y = (int)((idx / g.W) % g.H);
+    const int c = (int)((idx / g.W / g.H) % g.C);
+    const int n = (int)(idx / g.W / g.H / g.C);
+    const int l = x + g.pad, m = y + g.pad;
+    const float* p0 = b0 + ((size_t)n * g.C + c) * plane;
+    const float* p1 = b1 + ((size_t)n * g.C + c) * plane;
+    const float* td = top_diff + (size_t)n * g.topC * tplane;
+    float sum = 0.f;
+    for (int pp = -g.ngr; pp <= g.ngr; ++pp) {
+      for (int o = -g.ngr; o <= g.ngr; ++o) {
+        const int s2o = g.s2 * o, s2p = g.s2 * pp;
+        const int sx = (WHICH == 0) ? 0 : s2o, sy = (WHICH == 0) ? 0 : s2p;
+        int xmin = ceil_div(l - 2 * g.kr - g.md - sx, g.s1);
+        int ymin = ceil_div(m - 2 * g.kr - g.md - sy, g.s1);
+        int xmax = floor_div(l - g.md - sx, g.s1);
+        int ymax = floor_div(m - g.md - sy, g.s1);
+        if (!(xmax >= 0 && ymax >= 0 && xmin <= g.topW - 1 && ymin <= g.topH - 1)) continue;
+        xmin = max(0, xmin); xmax = min(g.topW - 1, xmax);
+        ymin = max(0, ymin); ymax = min(g.topH - 1, ymax);
+        const int mm = (WHICH == 0) ? m + s2p : m - s2p;
+        const int ll = (WHICH == 0) ? l + s2o : l - s2o;
+        float coef;
+        if (!SUB) {
+          coef = padded_at((WHICH == 0) ? p1 : p0, mm, ll, g);
+        } else {
+          const float v0 = padded_at(p0, mm, ll, g), v1 = padded_at(p1, mm, ll, g);
+          coef = (WHICH == 0) ? ((v0 >= v1) ? 1.f : -1.f) : ((v0 >= v1) ? -1.f : 1.f);
+        }
+        const float* t = td + (size_t)((pp + g.ngr) * g.ngw + (o + g.ngr)) * tplane;
+        for (int yy = ymin; yy <= ymax; ++yy)
+          for (int xx = xmin; xx <= xmax; ++xx) sum = fmaf(t[(size_t)yy * g.topW + xx], coef, sum);
+      }
+    }
+    bdiff[idx] = sum / (float)((g.kr * 2 + 1) * (g.kr * 2 + 1) * g.C);
+  }
+}
+
+// correlation_mfma.hip
+bool corr_fwd_mfma_supported(const CorrGeom& g);
+int corr_fwd_mfma_launch(const CorrGeom& g, const float* b0, const float* b1, float* top, hipStream_t st);
+
+// Set by the tests / bench through fn2_debug_set_correlation_impl: 0 = auto, 1 = force generic.
+static int g_force_generic = 0;
+
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API int fn2_debug_set_correlation_impl(int impl) {
+  g_force_generic = (impl == 1);
+  return FN2_OK;
+}
+
+FN2_API int fn2_correlation_out_shape(const fn2_corr_params* p, int C, int H, int W, int* topC, int* topH, int* topW) {
+  CorrGeom g;
+  int rc = corr_geometry(p, 1, C, H, W, &g);
+  if (rc) return rc;
+  if (topC) *topC = g.topC;
+  if (topH) *topH = g.topH;
+  if (topW) *topW = g.topW;
+  return FN2_OK;
+}
+
+FN2_API size_t fn2_correlation_workspace_bytes(const fn2_corr_params*, int, int, int, int) { return 0; }
+
+FN2_API int fn2_correlation_forward(const fn2_corr_params* p, const float* bottom0, const float* bottom1, float* top,
+                                    int N, int C, int H, int W, void*, size_t, void* stream) {
+  CorrGeom g;
+  int rc = corr_geometry(p, N, C, H, W, &g);
+  if (rc) return rc;
+  if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation_forward: NULL blob pointer");
+  if (N == 0) return FN2_OK;
+  hipStream_t st = as_stream(stream);
+  if (!g_force_generic && corr_fwd_mfma_supported(g)) return corr_fwd_mfma_launch(g, bottom0, bottom1, top, st);
+  const long long total = (long long)N * g.topC * g.topH * g.topW;
+  const unsigned blocks = blocks_for(total, 256);
+  if (g.type == FN2_CORR_MULTIPLY)
+    hipLaunchKernelGGL(corr_fwd_generic<false>, dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top, g);
+  else
+    hipLaunchKernelGGL(corr_fwd_generic<true>, dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top, g);
+  return check_launch("correlation_forward");
+}
+
+FN2_API int fn2_correlation_backward(const fn2_corr_params* p, const float* bottom0, const float* bottom1,
+                                     const float* top_diff, float* bottom0_diff, float* bottom1_diff,
+                                     int N, int C, int H, int W, void*, size_t, void* stream) {
+  CorrGeom g;
+  int rc = corr_geometry(p, N, C, H, W, &g);
+  if (rc) return rc;
+  if (!bottom0 || !bottom1 || !top_diff) return fail(FN2_ERR_INVALID_ARG, "correlation_backward: NULL blob pointer");
+  if (N == 0) return FN2_OK;
+  hipStream_t st = as_stream(stream);
+  const long long total = (long long)N * C * H * W;
+  const unsigned blocks = blocks_for(total, 256);
+  const bool sub = (g.type == FN2_CORR_SUBTRACT);
+  if (bottom0_diff) {
+    if (!sub) hipLaunchKernelGGL((corr_bwd_generic<false, 0>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom0_diff, g);
+    else hipLaunchKernelGGL((corr_bwd_generic<true, 0>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom0_diff, g);
+  }
+  if (bottom1_diff) {
+    if (!sub) hipLaunchKernelGGL((corr_bwd_generic<false, 1>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom1_diff, g);
+    else hipLaunchKernelGGL((corr_bwd_generic<true, 1>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom1_diff, g);
+  }
+  return check_launch("correlation_backward");
+}

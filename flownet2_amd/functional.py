@@ -1,0 +1,97 @@
+"""torch.autograd glue over the HIP operators (used by the FlowNet graphs in nets.py).
+
+Forward and backward both run the hand-written HIP kernels through the C ABI; autograd only routes
+tensors.  Gradient-stopping layers (Resample, Downsample: AllowBackward() == false in the
+reference, resample_layer.hpp:25, downsample_layer.hpp:30) return no gradient.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class _Correlation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b0, b1, params):
+        ctx.params = params
+        ctx.save_for_backward(b0, b1)
+        return ops.correlation_forward(params, b0, b1)
+
+    @staticmethod
+    def backward(ctx, g):
+        b0, b1 = ctx.saved_tensors
+        d0, d1 = ops.correlation_backward(ctx.params, b0, b1, g.contiguous(),
+                                          need0=ctx.needs_input_grad[0], need1=ctx.needs_input_grad[1])
+        return d0, d1, None
+
+
+def correlation(b0, b1, pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1, correlation_type=ops.MULTIPLY):
+    p = ops.corr_params(pad, kernel_size, max_displacement, stride_1, stride_2, correlation_type)
+    return _Correlation.apply(b0.contiguous(), b1.contiguous(), p)
+
+
+class _FlowWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, flow, fill_value):
+        ctx.save_for_backward(image, flow)
+        return ops.flow_warp_forward(image, flow, fill_value)
+
+    @staticmethod
+    def backward(ctx, g):
+        image, flow = ctx.saved_tensors
+        di, df = ops.flow_warp_backward(image, flow, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (di if ctx.needs_input_grad[0] else None), (df if ctx.needs_input_grad[1] else None), None
+
+
+def flow_warp(image, flow, fill_value=ops.FILL_ZERO):
+    return _FlowWarp.apply(image.contiguous(), flow.contiguous(), fill_value)
+
+
+def resample(x, height, width, type=ops.LINEAR, antialias=True):
+    with torch.no_grad():
+        return ops.resample_forward(x.detach().contiguous(), height, width, type, antialias)
+
+
+def downsample(x, top_height, top_width):
+    with torch.no_grad():
+        return ops.downsample_forward(x.detach().contiguous(), top_height, top_width)
+
+
+class _ChannelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        top = ops.channel_norm_forward(x)
+        ctx.save_for_backward(x, top)
+        return top
+
+    @staticmethod
+    def backward(ctx, g):
+        x, top = ctx.saved_tensors
+        return ops.channel_norm_backward(x, top, g.contiguous())
+
+
+def channel_norm(x):
+    return _ChannelNorm.apply(x.contiguous())
+
+
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b0, b1, params):
+        loss, ws = ops.l1loss_forward(params, b0, b1)
+        ctx.params, ctx.ws = params, ws
+        ctx.save_for_backward(b0, b1)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        b0, b1 = ctx.saved_tensors
+        # the C ABI takes the loss weight as a host float, like top[0]->cpu_diff()[0] (l1loss_layer.cu:155)
+        d0, d1 = ops.l1loss_backward(ctx.params, b0, b1, float(g), ctx.ws)
+        return (d0 if ctx.needs_input_grad[0] else None), (d1 if (b1 is not None and ctx.needs_input_grad[1]) else None), None
+
+
+def l1_loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False,
+            epsilon=1e-2, plateau=0.0):
+    p = ops.l1_params(l2_per_location, l2_prescale_by_channels, normalize_by_num_entries, epsilon, plateau)
+    return _L1Loss.apply(b0.contiguous(), b1.contiguous() if b1 is not None else None, p)

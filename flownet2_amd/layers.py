@@ -1,0 +1,424 @@
+"""Host-side mirror of the reference's operator/plugin interface for the hot-path layers.
+
+Same names, argument meaning and error behaviour as the Caffe `Layer<Dtype>` API
+(include/caffe/layer.hpp:42-53,69-76,94-152,484-537) and the layer registry
+(include/caffe/layer_factory.hpp:67-84): a layer is created from a LayerParameter by its prototxt
+`type:` string, `SetUp` = CheckBlobCounts -> LayerSetUp -> Reshape -> SetLossWeights, `Forward`
+re-runs Reshape unless `reshape_every_iter` is false, `Backward(top, propagate_down, bottom)` writes
+`bottom[i].diff`.  Blobs are NCHW fp32 with separate data / diff (include/caffe/blob.hpp:153-164,
+269-270); here both live in HBM as torch tensors and the layers hand their device pointers to the C
+ABI in include/flownet2_hip.h.  CHECK / LOG(FATAL) of the reference become exceptions.
+
+The C++ twin of this file for a real Caffe tree is flownet2_amd/csrc/caffe_adapter/ (INTEGRATION.md).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import Fn2Error
+
+
+class CheckError(ValueError):
+    """A glog CHECK / LOG(FATAL) of the reference."""
+
+
+def CHECK(cond, msg):
+    if not cond:
+        raise CheckError(msg)
+
+
+class Blob:
+    """include/caffe/blob.hpp: NCHW tensor with data and diff, device-resident."""
+
+    def __init__(self, *shape, device: Optional[torch.device] = None):
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.data: Optional[torch.Tensor] = None
+        self.diff: Optional[torch.Tensor] = None
+        self._shape: List[int] = []
+        if shape:
+            self.Reshape(*shape)
+
+    @classmethod
+    def from_tensor(cls, t: torch.Tensor) -> "Blob":
+        b = cls(device=t.device)
+        b._shape = list(t.shape)
+        b.data = t.contiguous().float()
+        return b
+
+    def Reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (list, tuple)):
+            shape = tuple(shape[0])
+        shape = [int(s) for s in shape]
+        CHECK(all(s >= 0 for s in shape), "blob dims must be >= 0")
+        if shape != self._shape or self.data is None:
+            self._shape = shape
+            self.data = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            self.diff = None
+
+    def ReshapeLike(self, other: "Blob"):
+        self.Reshape(*other.shape())
+
+    def shape(self, i: Optional[int] = None):
+        return list(self._shape) if i is None else self._shape[i]
+
+    def num_axes(self):
+        return len(self._shape)
+
+    def count(self):
+        n = 1
+        for s in self._shape:
+            n *= s
+        return n
+
+    def _legacy(self, i):
+        CHECK(len(self._shape) <= 4, "Cannot use legacy accessors on Blobs with > 4 axes.")
+        return self._shape[i] if i < len(self._shape) else 1
+
+    def num(self): return self._legacy(0)
+    def channels(self): return self._legacy(1)
+    def height(self): return self._legacy(2)
+    def width(self): return self._legacy(3)
+
+    # gpu_data()/mutable_gpu_data()/gpu_diff()/mutable_gpu_diff() of the reference
+    def gpu_data(self) -> torch.Tensor:
+        return self.data
+
+    def mutable_gpu_diff(self) -> torch.Tensor:
+        if self.diff is None or list(self.diff.shape) != self._shape:
+            self.diff = torch.zeros(self._shape, dtype=torch.float32, device=self.device)
+        return self.diff
+
+    gpu_diff = mutable_gpu_diff
+
+    def cpu_data(self):
+        return self.data.detach().cpu().numpy()
+
+    def cpu_diff(self):
+        return self.mutable_gpu_diff().detach().cpu().numpy()
+
+
+@dataclass
+class LayerParameter:
+    """The subset of caffe.proto's LayerParameter (:312-425) these layers read.  The *_param dicts
+    use the proto field names (correlation_param: caffe.proto:628-644, flow_warp_param :553-560,
+    resample_param :665-677, l1_loss_param :619-625, downsample_param :646-649)."""
+    name: str = ""
+    type: str = ""
+    bottom: List[str] = field(default_factory=list)
+    top: List[str] = field(default_factory=list)
+    loss_weight: List[float] = field(default_factory=list)
+    reshape_every_iter: bool = True          # caffe.proto:424
+    correlation_param: Dict = field(default_factory=dict)
+    flow_warp_param: Dict = field(default_factory=dict)
+    resample_param: Dict = field(default_factory=dict)
+    l1_loss_param: Dict = field(default_factory=dict)
+    downsample_param: Dict = field(default_factory=dict)
+
+
+class Layer:
+    """include/caffe/layer.hpp.  Only the GPU mode exists (Forward == Forward_gpu)."""
+
+    def __init__(self, param: LayerParameter):
+        self.layer_param_ = param
+        self.loss_: List[float] = []
+
+    # --- interface subclasses implement -------------------------------------------------------
+    def LayerSetUp(self, bottom: Sequence[Blob], top: Sequence[Blob]): pass
+    def Reshape(self, bottom: Sequence[Blob], top: Sequence[Blob]): raise NotImplementedError
+    def Forward_gpu(self, bottom, top): raise NotImplementedError
+    def Backward_gpu(self, top, propagate_down, bottom): raise NotImplementedError
+    def type(self) -> str: return ""
+    def ExactNumBottomBlobs(self): return -1
+    def MinBottomBlobs(self): return -1
+    def MaxBottomBlobs(self): return -1
+    def ExactNumTopBlobs(self): return -1
+    def MinTopBlobs(self): return -1
+    def MaxTopBlobs(self): return -1
+    def AllowBackward(self) -> bool: return True      # layer.hpp:322-324
+
+    # --- layer.hpp:69-76 -----------------------------------------------------------------------
+    def SetUp(self, bottom, top):
+        self.CheckBlobCounts(bottom, top)
+        self.LayerSetUp(bottom, top)
+        self.Reshape(bottom, top)
+        self.SetLossWeights(top)
+
+    def CheckBlobCounts(self, bottom, top):               # layer.hpp:397-435
+        t = self.type()
+        if self.ExactNumBottomBlobs() >= 0:
+            CHECK(self.ExactNumBottomBlobs() == len(bottom), f"{t} Layer takes {self.ExactNumBottomBlobs()} bottom blob(s) as input.")
+        if self.MinBottomBlobs() >= 0:
+            CHECK(self.MinBottomBlobs() <= len(bottom), f"{t} Layer takes at least {self.MinBottomBlobs()} bottom blob(s) as input.")
+        if self.MaxBottomBlobs() >= 0:
+            CHECK(self.MaxBottomBlobs() >= len(bottom), f"{t} Layer takes at most {self.MaxBottomBlobs()} bottom blob(s) as input.")
+        if self.ExactNumTopBlobs() >= 0:
+            CHECK(self.ExactNumTopBlobs() == len(top), f"{t} Layer produces {self.ExactNumTopBlobs()} top blob(s) as output.")
+        if self.MinTopBlobs() >= 0:
+            CHECK(self.MinTopBlobs() <= len(top), f"{t} Layer produces at least {self.MinTopBlobs()} top blob(s) as output.")
+        if self.MaxTopBlobs() >= 0:
+            CHECK(self.MaxTopBlobs() >= len(top), f"{t} Layer produces at most {self.MaxTopBlobs()} top blob(s) as output.")
+
+    def SetLossWeights(self, top):                         # layer.hpp:444-458
+        lw = list(self.layer_param_.loss_weight)
+        self.loss_ = [0.0] * len(top)
+        if lw:
+            CHECK(len(top) == len(lw), "loss_weight must be unspecified or specified once per top blob.")
+            for i, w in enumerate(lw):
+                if w == 0:
+                    continue
+                self.loss_[i] = float(w)
+                top[i].mutable_gpu_diff().fill_(float(w))
+
+    def loss(self, top_id):
+        return self.loss_[top_id] if top_id < len(self.loss_) else 0.0
+
+    def Forward(self, bottom, top):                        # layer.hpp:484-521
+        if self.layer_param_.reshape_every_iter:
+            self.Reshape(bottom, top)
+        self.Forward_gpu(bottom, top)
+        loss = 0.0
+        for i, t in enumerate(top):
+            if not self.loss(i):
+                continue
+            loss = loss + (t.data * t.mutable_gpu_diff()).sum()   # caffe_gpu_dot(data, loss_weights)
+        return loss
+
+    def Backward(self, top, propagate_down, bottom):       # layer.hpp:524-537
+        self.Backward_gpu(top, propagate_down, bottom)
+
+
+def _wrap(fn, *a, **k):
+    try:
+        return fn(*a, **k)
+    except Fn2Error as e:      # reference: CHECK / LOG(FATAL)
+        raise CheckError(str(e)) from e
+
+
+class CorrelationLayer(Layer):
+    """include/caffe/layers/correlation_layer.hpp:26-77; correlation_layer.cpp:13-84."""
+
+    def type(self): return "Correlation"
+    def ExactNumBottomBlobs(self): return 2
+    def ExactNumTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        cp = self.layer_param_.correlation_param
+        CHECK("kernel_size" in cp, "Filter kernel_size is not set")                 # cpp:18
+        CHECK("max_displacement" in cp, "Max displacement is required.")            # cpp:19
+        ctype = cp.get("correlation_type", 0)
+        if isinstance(ctype, str):
+            ctype = {"MULTIPLY": 0, "SUBTRACT": 1}[ctype]
+        if int(cp["kernel_size"]) % 2 == 0:
+            raise CheckError("Odd kernel size required")                             # cpp:22
+        self.params_ = ops.corr_params(cp.get("pad", 0), cp["kernel_size"], cp["max_displacement"],
+                                       cp.get("stride_1", 1), cp.get("stride_2", 1), ctype, cp.get("do_abs", False))
+
+    def Reshape(self, bottom, top):
+        CHECK(bottom[0].width() == bottom[1].width(), "Both bottom blobs must have same width")       # cpp:45
+        CHECK(bottom[0].height() == bottom[1].height(), "Both bottom blobs must have same height")    # cpp:46
+        CHECK(bottom[0].channels() == bottom[1].channels(), "Both bottom blobs must have same height")  # cpp:47 (sic)
+        self.num_ = bottom[0].num()
+        tc, th, tw = _wrap(ops.correlation_out_shape, self.params_, bottom[0].channels(), bottom[0].height(), bottom[0].width())
+        self.top_channels_, self.top_height_, self.top_width_ = tc, th, tw
+        top[0].Reshape(self.num_, tc, th, tw)                                        # cpp:73
+
+    def Forward_gpu(self, bottom, top):
+        _wrap(ops.correlation_forward, self.params_, bottom[0].data, bottom[1].data, out=top[0].data)
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        # like the reference (correlation_layer.cu:508-603) both diffs are always written
+        d0, d1 = _wrap(ops.correlation_backward, self.params_, bottom[0].data, bottom[1].data, top[0].mutable_gpu_diff())
+        bottom[0].diff, bottom[1].diff = d0, d1
+
+
+class FlowWarpLayer(Layer):
+    """include/caffe/layers/flow_warp_layer.hpp; flow_warp_layer.cpp:35-52."""
+
+    def type(self): return "FlowWarp"
+
+    def Reshape(self, bottom, top):
+        CHECK(len(bottom) == 2, "FlowWarpLayer takes two input blobs: image and flow.")
+        CHECK(len(top) == 1, "FlowWarpLayer outputs one blob.")
+        CHECK(bottom[0].num() == bottom[1].num(), "Num of the inputs should be the same")
+        CHECK(bottom[1].channels() == 2, "Flow should have 2 channels: x-flow and y-flow")
+        CHECK(bottom[0].width() == bottom[1].width(), "Width of the inputs should be the same")
+        CHECK(bottom[0].height() == bottom[1].height(), "Height of the inputs should be the same")
+        top[0].Reshape(*bottom[0].shape())
+
+    def _fill(self):
+        fv = self.layer_param_.flow_warp_param.get("fill_value", "ZERO")
+        if isinstance(fv, str):
+            fv = {"ZERO": ops.FILL_ZERO, "NOT_A_NUMBER": ops.FILL_NAN}[fv]
+        return int(fv)
+
+    def Forward_gpu(self, bottom, top):
+        top[0].data = _wrap(ops.flow_warp_forward, bottom[0].data, bottom[1].data, self._fill())
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        di, df = _wrap(ops.flow_warp_backward, bottom[0].data, bottom[1].data, top[0].mutable_gpu_diff(),
+                       bool(propagate_down[0]), bool(propagate_down[1]))
+        bottom[0].diff, bottom[1].diff = di, df
+
+
+class ResampleLayer(Layer):
+    """src/caffe/layers/resample_layer.hpp; resample_layer.cpp:14-55.  Forward only."""
+
+    _TYPES = {"NEAREST": ops.NEAREST, "LINEAR": ops.LINEAR, "CUBIC": ops.CUBIC, "AREA": ops.AREA}
+
+    def type(self): return "Resample"
+    def AllowBackward(self): return False                                          # resample_layer.hpp:25
+
+    def _rtype(self):
+        t = self.layer_param_.resample_param.get("type", "LINEAR")
+        return self._TYPES[t] if isinstance(t, str) else int(t)
+
+    def LayerSetUp(self, bottom, top):
+        if self._rtype() not in (ops.CUBIC, ops.LINEAR, ops.NEAREST):
+            raise CheckError("ResampleLayer: only CUBIC, LINEAR and NEAREST interpolation is supported for now")   # cpp:17-20
+
+    def Reshape(self, bottom, top):
+        self.layer_param_.reshape_every_iter = False                                # cpp:27: Reshape only runs on setup
+        CHECK(1 <= len(bottom) <= 2, "ResampleLayer takes one or two bottoms")
+        CHECK(len(top) == 1, "ResampleLayer outputs one blob")
+        rp = self.layer_param_.resample_param
+        if len(bottom) == 1:
+            th, tw = int(rp.get("height", 0)), int(rp.get("width", 0))             # cpp:41-42
+        else:
+            th, tw = bottom[1].height(), bottom[1].width()                          # cpp:44-45
+        CHECK(th >= 1, "ResampleLayer must have top_height > 0")
+        CHECK(tw >= 1, "ResampleLayer must have top_width > 0")
+        self.top_height_, self.top_width_ = th, tw
+        top[0].Reshape(bottom[0].num(), bottom[0].channels(), th, tw)
+
+    def Forward_gpu(self, bottom, top):
+        rp = self.layer_param_.resample_param
+        top[0].data = _wrap(ops.resample_forward, bottom[0].data, self.top_height_, self.top_width_, self._rtype(),
+                            bool(rp.get("antialias", True)))
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        if any(propagate_down):
+            raise CheckError("ResampleLayer cannot do backward.")                    # resample_layer.cu:209-213
+
+
+class L1LossLayer(Layer):
+    """include/caffe/layers/l1_loss_layer.hpp; l1loss_layer.cpp:11-90, l1loss_layer.cu:67-188."""
+
+    def type(self): return "L1Loss"
+    def MinBottomBlobs(self): return 1
+    def MaxBottomBlobs(self): return 2
+    def ExactNumTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        if not self.layer_param_.loss_weight:        # LossLayer::LayerSetUp, loss_layer.cpp:8-13
+            self.layer_param_.loss_weight = [1.0]
+        CHECK(len(bottom) in (1, 2), "L1LossLayer needs one or two input blobs.")
+        lp = self.layer_param_.l1_loss_param
+        self.params_ = ops.l1_params(lp.get("l2_per_location", False), lp.get("l2_prescale_by_channels", False),
+                                     lp.get("normalize_by_num_entries", False), lp.get("epsilon", 1e-2), lp.get("plateau", 0.0))
+        self.ws_ = None
+
+    def Reshape(self, bottom, top):
+        top[0].Reshape()                              # 0-axis scalar, cpp:68-69
+
+    def Forward_gpu(self, bottom, top):
+        b1 = bottom[1].data if len(bottom) > 1 else None
+        loss, self.ws_ = _wrap(ops.l1loss_forward, self.params_, bottom[0].data, b1, self.ws_)
+        top[0].data = loss
+
+    def normalize_coeff(self) -> float:
+        return float(self.ws_[:8].view(torch.float32)[1])
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        prop = bool(propagate_down[0]) or (len(bottom) > 1 and bool(propagate_down[1]))       # cu:150-151
+        if not prop:
+            return
+        top_diff = float(top[0].mutable_gpu_diff())       # top[0]->cpu_diff()[0], cu:155
+        b1 = bottom[1].data if len(bottom) > 1 else None
+        d0, d1 = _wrap(ops.l1loss_backward, self.params_, bottom[0].data, b1, top_diff, self.ws_)
+        if len(bottom) > 1:
+            # Eltwise backward honours propagate_down per bottom (eltwise_layer.cu Backward)
+            if propagate_down[0]: bottom[0].diff = d0
+            if propagate_down[1]: bottom[1].diff = d1
+        else:
+            bottom[0].diff = d0
+
+
+class ChannelNormLayer(Layer):
+    """include/caffe/layers/channel_norm_layer.hpp; channel_norm_layer.cpp:27-40."""
+
+    def type(self): return "ChannelNorm"
+
+    def Reshape(self, bottom, top):
+        CHECK(len(bottom) == 1, "ChannelNormLayer takes one input blob.")
+        CHECK(len(top) == 1, "ChannelNormLayer outputs one blob.")
+        top[0].Reshape(bottom[0].num(), 1, bottom[0].height(), bottom[0].width())
+
+    def Forward_gpu(self, bottom, top):
+        top[0].data = _wrap(ops.channel_norm_forward, bottom[0].data)
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        bottom[0].diff = _wrap(ops.channel_norm_backward, bottom[0].data, top[0].data, top[0].mutable_gpu_diff())
+
+
+class DownsampleLayer(Layer):
+    """include/caffe/layers/downsample_layer.hpp; downsample_layer.cpp:21-57.  Forward only."""
+
+    def type(self): return "Downsample"
+    def AllowBackward(self): return False                                            # downsample_layer.hpp:30
+
+    def Reshape(self, bottom, top):
+        self.layer_param_.reshape_every_iter = False                                 # cpp:24
+        CHECK(1 <= len(bottom) <= 2, "DownsampleLayer takes one or two bottoms")
+        CHECK(len(top) == 1, "DownsampleLayer outputs one blob")
+        dp = self.layer_param_.downsample_param
+        if len(bottom) == 1:
+            th, tw = int(dp.get("top_height", 0)), int(dp.get("top_width", 0))
+        else:
+            th, tw = bottom[1].height(), bottom[1].width()
+        CHECK(th >= 1, "DownsampleLayer must have top_height > 0")
+        CHECK(tw >= 1, "DownsampleLayer must have top_width > 0")
+        self.top_height_, self.top_width_ = th, tw
+        top[0].Reshape(bottom[0].num(), bottom[0].channels(), th, tw)
+
+    def Forward_gpu(self, bottom, top):
+        top[0].data = _wrap(ops.downsample_forward, bottom[0].data, self.top_height_, self.top_width_)
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        if any(propagate_down):
+            raise CheckError("DownsamplingLayer cannot do backward.")                 # downsample_layer.cu:132-138
+
+
+class LayerRegistry:
+    """include/caffe/layer_factory.hpp:53-114."""
+    _registry: Dict[str, Callable[[LayerParameter], Layer]] = {}
+
+    @classmethod
+    def AddCreator(cls, type_: str, creator):
+        CHECK(type_ not in cls._registry, f"Layer type {type_} already registered.")   # layer_factory.hpp:69-70
+        cls._registry[type_] = creator
+
+    @classmethod
+    def CreateLayer(cls, param: LayerParameter) -> Layer:
+        CHECK(param.type in cls._registry,
+              f"Unknown layer type: {param.type} (known types: {', '.join(sorted(cls._registry))})")   # :79-80
+        return cls._registry[param.type](param)
+
+    @classmethod
+    def LayerTypeList(cls):
+        return sorted(cls._registry)
+
+
+def REGISTER_LAYER_CLASS(type_: str, klass):
+    LayerRegistry.AddCreator(type_, klass)
+
+
+REGISTER_LAYER_CLASS("Correlation", CorrelationLayer)      # correlation_layer.cpp:102-103
+REGISTER_LAYER_CLASS("FlowWarp", FlowWarpLayer)            # flow_warp_layer.cpp:259-260
+REGISTER_LAYER_CLASS("Resample", ResampleLayer)            # resample_layer.cpp:71-72
+REGISTER_LAYER_CLASS("L1Loss", L1LossLayer)                # l1loss_layer.cpp:108-109
+REGISTER_LAYER_CLASS("ChannelNorm", ChannelNormLayer)      # channel_norm_layer.cpp:193-194
+REGISTER_LAYER_CLASS("Downsample", DownsampleLayer)        # downsample_layer.cpp:78-79

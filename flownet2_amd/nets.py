@@ -1,0 +1,186 @@
+"""FlowNetC / FlowNetS graphs as the reference's deploy prototxts wire them.
+
+TOPOLOGY CAVEAT: the prototxt templates are NOT in the reference tree (models/download-models.sh:3-10
+fetches them); the graphs below restate them from the FlowNet / FlowNet2 papers and the layer names
+third-party converters use.  Every topology assumption lives in this file.
+
+The custom layers (Correlation, Resample, FlowWarp, ChannelNorm, L1Loss, Downsample) go through
+`backend` = flownet2_amd.functional (HIP kernels).  Convolution / Deconvolution / ReLU / Eltwise /
+Concat are the stock Caffe layers of the reference (conv_layer.cpp:8-40, deconv_layer.cpp:8-45,
+relu_layer.cu:8-14): dense fp32 contractions executed by MIOpen through torch (conv2d /
+conv_transpose2d); Caffe's weight layouts ([Cout,Cin,kh,kw], deconv [Cin,Cout,kh,kw],
+base_conv_layer.cpp:125-139) are torch's, so .caffemodel blobs load without transposition.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+NEG_SLOPE = 0.1          # ReLU negative_slope of every FlowNet conv/deconv
+FLOW_SCALE = 20.0        # deploy multiplies predict_flow2 by 20 (training divides GT by 20)
+LOSS_WEIGHTS = {6: 0.32, 5: 0.08, 4: 0.02, 3: 0.01, 2: 0.005}   # Appendix B (memory)
+
+# name: (kind, Cin, Cout, k, stride, pad)
+_ENC_TAIL = [("conv4", 256, 512, 3, 2, 1), ("conv4_1", 512, 512, 3, 1, 1), ("conv5", 512, 512, 3, 2, 1),
+             ("conv5_1", 512, 512, 3, 1, 1), ("conv6", 512, 1024, 3, 2, 1), ("conv6_1", 1024, 1024, 3, 1, 1)]
+_DEC = [("Convolution1", "conv", 1024, 2), ("deconv5", "deconv", 1024, 512), ("upsample_flow6to5", "deconv", 2, 2),
+        ("Convolution2", "conv", 1026, 2), ("deconv4", "deconv", 1026, 256), ("upsample_flow5to4", "deconv", 2, 2),
+        ("Convolution3", "conv", 770, 2), ("deconv3", "deconv", 770, 128), ("upsample_flow4to3", "deconv", 2, 2),
+        ("Convolution4", "conv", 386, 2), ("deconv2", "deconv", 386, 64), ("upsample_flow3to2", "deconv", 2, 2),
+        ("Convolution5", "conv", 194, 2)]
+
+
+def layer_table(kind: str = "C", in_channels: int = 6):
+    """[(name, 'conv'|'deconv', Cin, Cout, k, stride, pad)] in execution order."""
+    t = []
+    if kind == "C":
+        t += [("conv1", "conv", 3, 64, 7, 2, 3), ("conv2", "conv", 64, 128, 5, 2, 2), ("conv3", "conv", 128, 256, 5, 2, 2),
+              ("conv_redir", "conv", 256, 32, 1, 1, 0), ("conv3_1", "conv", 473, 256, 3, 1, 1)]
+    else:
+        t += [("conv1", "conv", in_channels, 64, 7, 2, 3), ("conv2", "conv", 64, 128, 5, 2, 2), ("conv3", "conv", 128, 256, 5, 2, 2),
+              ("conv3_1", "conv", 256, 256, 3, 1, 1)]
+    t += [(n, "conv", ci, co, k, s, p) for (n, ci, co, k, s, p) in _ENC_TAIL]
+    for (n, k, ci, co) in _DEC:
+        t.append((n, k, ci, co, 3, 1, 1) if k == "conv" else (n, k, ci, co, 4, 2, 1))
+    return t
+
+
+def init_params(kind: str = "C", seed: int = 0, device="cpu", in_channels: int = 6) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights (no .caffemodel can be downloaded here): He-normal for the leaky
+    convs, small predict_flow / upsample heads so flows come out O(1-10 px); biases 0."""
+    g = torch.Generator().manual_seed(seed)
+    params = {}
+    for (name, k, ci, co, ks, s, p) in layer_table(kind, in_channels):
+        shape = (co, ci, ks, ks) if k == "conv" else (ci, co, ks, ks)
+        fan_in = ci * ks * ks if k == "conv" else ci * ks * ks / (s * s)
+        std = math.sqrt(2.0 / ((1 + NEG_SLOPE ** 2) * fan_in))
+        if name.startswith("Convolution"):
+            std *= 0.5
+        if name.startswith("upsample_flow"):
+            std = 0.25
+        params[name + ".w"] = (torch.randn(shape, generator=g) * std).to(device)
+        params[name + ".b"] = torch.zeros(co).to(device)
+    return params
+
+
+def num_params(params) -> int:
+    return sum(int(v.numel()) for v in params.values())
+
+
+def _conv(x, P, name, stride, pad, act=True):
+    y = F.conv2d(x, P[name + ".w"], P[name + ".b"], stride=stride, padding=pad)
+    return F.leaky_relu(y, NEG_SLOPE) if act else y
+
+
+def _deconv(x, P, name, act=True):
+    y = F.conv_transpose2d(x, P[name + ".w"], P[name + ".b"], stride=2, padding=1)
+    return F.leaky_relu(y, NEG_SLOPE) if act else y
+
+
+def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
+    flow6 = _conv(conv6_1, P, "Convolution1", 1, 1, act=False)
+    c5 = torch.cat([conv5_1, _deconv(conv6_1, P, "deconv5"), _deconv(flow6, P, "upsample_flow6to5", act=False)], 1)
+    flow5 = _conv(c5, P, "Convolution2", 1, 1, act=False)
+    c4 = torch.cat([conv4_1, _deconv(c5, P, "deconv4"), _deconv(flow5, P, "upsample_flow5to4", act=False)], 1)
+    flow4 = _conv(c4, P, "Convolution3", 1, 1, act=False)
+    c3 = torch.cat([conv3_1, _deconv(c4, P, "deconv3"), _deconv(flow4, P, "upsample_flow4to3", act=False)], 1)
+    flow3 = _conv(c3, P, "Convolution4", 1, 1, act=False)
+    c2 = torch.cat([conv2, _deconv(c3, P, "deconv2"), _deconv(flow3, P, "upsample_flow3to2", act=False)], 1)
+    flow2 = _conv(c2, P, "Convolution5", 1, 1, act=False)
+    return {2: flow2, 3: flow3, 4: flow4, 5: flow5, 6: flow6}
+
+
+def flownet_c_core(P, img0, img1, backend):
+    """Pre-processed images [N,3,H,W] (H, W multiples of 64) -> {scale: flow prediction /20}."""
+    n = img0.shape[0]
+    x = torch.cat([img0, img1], 0)                 # siamese towers share weights (param { name: } sharing, net.cpp:451-540)
+    c1 = _conv(x, P, "conv1", 2, 3)
+    c2 = _conv(c1, P, "conv2", 2, 2)
+    c3 = _conv(c2, P, "conv3", 2, 2)
+    c3a, c3b = c3[:n], c3[n:]
+    corr = backend.correlation(c3a, c3b, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
+    corr = F.leaky_relu(corr, NEG_SLOPE)
+    redir = _conv(c3a, P, "conv_redir", 1, 0)
+    c31 = _conv(torch.cat([redir, corr], 1), P, "conv3_1", 1, 1)
+    c4 = _conv(c31, P, "conv4", 2, 1)
+    c41 = _conv(c4, P, "conv4_1", 1, 1)
+    c5 = _conv(c41, P, "conv5", 2, 1)
+    c51 = _conv(c5, P, "conv5_1", 1, 1)
+    c6 = _conv(c51, P, "conv6", 2, 1)
+    c61 = _conv(c6, P, "conv6_1", 1, 1)
+    return _decoder(P, c61, c51, c41, c31, c2[:n])
+
+
+def flownet_s_core(P, x, backend=None):
+    c1 = _conv(x, P, "conv1", 2, 3)
+    c2 = _conv(c1, P, "conv2", 2, 2)
+    c3 = _conv(c2, P, "conv3", 2, 2)
+    c31 = _conv(c3, P, "conv3_1", 1, 1)
+    c4 = _conv(c31, P, "conv4", 2, 1)
+    c41 = _conv(c4, P, "conv4_1", 1, 1)
+    c5 = _conv(c41, P, "conv5", 2, 1)
+    c51 = _conv(c5, P, "conv5_1", 1, 1)
+    c6 = _conv(c51, P, "conv6", 2, 1)
+    c61 = _conv(c6, P, "conv6_1", 1, 1)
+    return _decoder(P, c61, c51, c41, c31, c2)
+
+
+def adapted_size(h: int, w: int, divisor: int = 64):
+    """scripts/run-flownet.py:43-45."""
+    return int(math.ceil(h / divisor) * divisor), int(math.ceil(w / divisor) * divisor)
+
+
+def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tensor] = None):
+    """Deploy net: raw 0..255 BGR images [N,3,H,W] -> predict_flow_final [N,2,H,W] in pixels.
+
+    Head/tail as in SURVEY.md Appendix B: Eltwise(1/255) -> Resample(ADAPTED, LINEAR) -> mean
+    subtraction -> net -> x20 -> Resample(TARGET, LINEAR) -> diag(SCALE_WIDTH, SCALE_HEIGHT) 1x1 conv.
+    """
+    N, _, H, W = img0.shape
+    ah, aw = adapted_size(H, W)
+    if mean is None:
+        mean = torch.tensor([0.411, 0.433, 0.45], device=img0.device, dtype=img0.dtype)   # BGR order of a typical RGB mean
+    pre = []
+    for im in (img0, img1):
+        x = im * (1.0 / 255.0)                                                     # Eltwise, coeff 1/255
+        x = backend.resample(x, ah, aw)                                            # Resample to ADAPTED size
+        pre.append(x - mean.view(1, 3, 1, 1))                                      # DataAugmentation mean subtraction (deploy slice)
+    if kind == "C":
+        flows = flownet_c_core(P, pre[0], pre[1], backend)
+    else:
+        flows = flownet_s_core(P, torch.cat(pre, 1), backend)
+    flow = flows[2] * FLOW_SCALE                                                    # Eltwise, coeff 20
+    flow = backend.resample(flow, H, W)                                             # Resample to TARGET size
+    scale = torch.tensor([W / float(aw), H / float(ah)], device=flow.device, dtype=flow.dtype)   # run-flownet.py:47-48
+    return flow * scale.view(1, 2, 1, 1)                                            # 1x1 conv, diagonal filler
+
+
+def multiscale_loss(flows, gt_flow, backend):
+    """Training loss: per scale Downsample(GT * 0.05) -> L1Loss{l2_per_location, normalize_by_num_entries}."""
+    gt = gt_flow * (1.0 / FLOW_SCALE)
+    total = 0.0
+    for s, w in LOSS_WEIGHTS.items():
+        pred = flows[s]
+        tgt = backend.downsample(gt, pred.shape[2], pred.shape[3])
+        total = total + w * backend.l1_loss(pred, tgt, l2_per_location=True, normalize_by_num_entries=True)
+    return total
+
+
+# FLOP model (multiply-add = 2 flops) used by bench.py
+def conv_flops(kind: str, h: int, w: int, in_channels: int = 6) -> float:
+    fl = 0.0
+    size = {}
+    hh, ww = h, w
+    res = {"conv1": 2, "conv2": 4, "conv3": 8, "conv_redir": 8, "conv3_1": 8, "conv4": 16, "conv4_1": 16, "conv5": 32, "conv5_1": 32,
+           "conv6": 64, "conv6_1": 64, "Convolution1": 64, "deconv5": 32, "upsample_flow6to5": 32, "Convolution2": 32,
+           "deconv4": 16, "upsample_flow5to4": 16, "Convolution3": 16, "deconv3": 8, "upsample_flow4to3": 8, "Convolution4": 8,
+           "deconv2": 4, "upsample_flow3to2": 4, "Convolution5": 4}
+    for (name, k, ci, co, ks, s, p) in layer_table(kind, in_channels):
+        oh, ow = hh // res[name], ww // res[name]
+        macs = oh * ow * co * ci * ks * ks if k == "conv" else (oh // 2) * (ow // 2) * ci * co * ks * ks
+        mult = 2 if (kind == "C" and name in ("conv1", "conv2", "conv3")) else 1
+        fl += 2.0 * macs * mult
+    return fl

@@ -1,0 +1,168 @@
+"""Raw operator calls: torch CUDA tensors in, C ABI (libflownet2_hip.so) underneath.
+
+torch is plumbing here (device memory + the current HIP stream); all arithmetic happens in the HIP
+kernels.  Every function validates what the reference's Reshape would CHECK, then forwards to the
+C entry point; there is no PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import CorrParams, L1LossParams, check
+
+MULTIPLY, SUBTRACT = 0, 1
+FILL_ZERO, FILL_NAN = 1, 2
+NEAREST, LINEAR, CUBIC, AREA = 1, 2, 3, 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, ndim: int = 4):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA (HIP) tensor; flownet2_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name}: expected float32 (Dtype=float), got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} axes (NCHW), got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def corr_params(pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1, correlation_type=MULTIPLY, do_abs=False):
+    return CorrParams(int(pad), int(kernel_size), int(max_displacement), int(stride_1), int(stride_2),
+                      int(correlation_type), int(bool(do_abs)))
+
+
+def correlation_out_shape(p: CorrParams, Cc: int, H: int, W: int):
+    tc, th, tw = C.c_int(), C.c_int(), C.c_int()
+    check(_lib.lib().fn2_correlation_out_shape(C.byref(p), Cc, H, W, C.byref(tc), C.byref(th), C.byref(tw)))
+    return tc.value, th.value, tw.value
+
+
+def correlation_forward(p: CorrParams, bottom0: torch.Tensor, bottom1: torch.Tensor, out: torch.Tensor | None = None):
+    b0, b1 = _chk(bottom0, "bottom[0]"), _chk(bottom1, "bottom[1]")
+    if b0.shape != b1.shape:   # correlation_layer.cpp:45-47
+        raise ValueError("Both bottom blobs must have same shape")
+    N, Cc, H, W = b0.shape
+    tc, th, tw = correlation_out_shape(p, Cc, H, W)
+    top = out if out is not None else torch.empty((N, tc, th, tw), device=b0.device, dtype=torch.float32)
+    assert top.is_contiguous() and tuple(top.shape) == (N, tc, th, tw)
+    check(_lib.lib().fn2_correlation_forward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(top), N, Cc, H, W, None, 0, _stream()))
+    return top
+
+
+def correlation_backward(p: CorrParams, bottom0, bottom1, top_diff, need0=True, need1=True):
+    b0, b1, td = _chk(bottom0, "bottom[0]"), _chk(bottom1, "bottom[1]"), _chk(top_diff, "top.diff")
+    N, Cc, H, W = b0.shape
+    d0 = torch.empty_like(b0) if need0 else None
+    d1 = torch.empty_like(b1) if need1 else None
+    check(_lib.lib().fn2_correlation_backward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(td), _ptr(d0), _ptr(d1),
+                                              N, Cc, H, W, None, 0, _stream()))
+    return d0, d1
+
+
+def set_correlation_impl(force_generic: bool):
+    """Test hook: route the forward through the generic kernel instead of the MFMA fast path."""
+    check(_lib.lib().fn2_debug_set_correlation_impl(1 if force_generic else 0))
+
+
+def flow_warp_forward(image, flow, fill_value=FILL_ZERO):
+    im, fl = _chk(image, "bottom[0] (image)"), _chk(flow, "bottom[1] (flow)")
+    N, Cc, H, W = im.shape
+    if fl.shape[0] != N:
+        raise ValueError("Num of the inputs should be the same")               # flow_warp_layer.cpp:45
+    if fl.shape[1] != 2:
+        raise ValueError("Flow should have 2 channels: x-flow and y-flow")     # :46
+    if fl.shape[3] != W or fl.shape[2] != H:
+        raise ValueError("Width/Height of the inputs should be the same")      # :47-48
+    out = torch.empty_like(im)
+    check(_lib.lib().fn2_flow_warp_forward(_ptr(im), _ptr(fl), _ptr(out), N, Cc, H, W, int(fill_value), _stream()))
+    return out
+
+
+def flow_warp_backward(image, flow, warped_diff, propagate_image=True, propagate_flow=True):
+    im, fl, wd = _chk(image, "image"), _chk(flow, "flow"), _chk(warped_diff, "top.diff")
+    N, Cc, H, W = im.shape
+    di, df = torch.empty_like(im), torch.empty_like(fl)
+    check(_lib.lib().fn2_flow_warp_backward(_ptr(im), _ptr(fl), _ptr(wd), _ptr(di), _ptr(df), N, Cc, H, W,
+                                            int(propagate_image), int(propagate_flow), _stream()))
+    return di, df
+
+
+def resample_forward(x, height, width, type=LINEAR, antialias=True):
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    if height < 1 or width < 1:
+        raise ValueError("ResampleLayer must have top_height > 0 and top_width > 0")
+    out = torch.empty((N, Cc, int(height), int(width)), device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_resample_forward(_ptr(x), _ptr(out), N, Cc, H, W, int(height), int(width), int(type), int(bool(antialias)), _stream()))
+    return out
+
+
+def l1_params(l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False, epsilon=1e-2, plateau=0.0):
+    return L1LossParams(int(bool(l2_per_location)), int(bool(l2_prescale_by_channels)), int(bool(normalize_by_num_entries)),
+                        float(epsilon), float(plateau))
+
+
+def l1loss_workspace(x: torch.Tensor) -> torch.Tensor:
+    N, Cc, H, W = x.shape
+    nbytes = _lib.lib().fn2_l1loss_workspace_bytes(N, Cc, H, W)
+    return torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+
+
+def l1loss_forward(p: L1LossParams, bottom0, bottom1=None, workspace=None):
+    """Returns (loss [0-axis device tensor], workspace).  workspace[:8] viewed as float32 = {loss, normalize_coeff}."""
+    b0 = _chk(bottom0, "bottom[0]")
+    b1 = _chk(bottom1, "bottom[1]") if bottom1 is not None else None
+    if b1 is not None and b1.shape != b0.shape:
+        raise ValueError("L1Loss: bottom blobs must have the same shape")
+    N, Cc, H, W = b0.shape
+    ws = workspace if workspace is not None else l1loss_workspace(b0)
+    loss = torch.empty((), device=b0.device, dtype=torch.float32)
+    check(_lib.lib().fn2_l1loss_forward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(loss), N, Cc, H, W, _ptr(ws), ws.numel(), _stream()))
+    return loss, ws
+
+
+def l1loss_backward(p: L1LossParams, bottom0, bottom1, top_diff: float, workspace):
+    b0 = _chk(bottom0, "bottom[0]")
+    b1 = _chk(bottom1, "bottom[1]") if bottom1 is not None else None
+    N, Cc, H, W = b0.shape
+    d0 = torch.empty_like(b0)
+    d1 = torch.empty_like(b0) if b1 is not None else None
+    check(_lib.lib().fn2_l1loss_backward(C.byref(p), _ptr(b0), _ptr(b1), C.c_float(float(top_diff)), _ptr(d0), _ptr(d1),
+                                         N, Cc, H, W, _ptr(workspace), workspace.numel(), _stream()))
+    return d0, d1
+
+
+def channel_norm_forward(x):
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_channel_norm_forward(_ptr(x), _ptr(out), N, Cc, H, W, _stream()))
+    return out
+
+
+def channel_norm_backward(x, top, top_diff):
+    x, top, td = _chk(x, "bottom[0]"), _chk(top, "top"), _chk(top_diff, "top.diff")
+    N, Cc, H, W = x.shape
+    d = torch.empty_like(x)
+    check(_lib.lib().fn2_channel_norm_backward(_ptr(x), _ptr(top), _ptr(td), _ptr(d), N, Cc, H, W, _stream()))
+    return d
+
+
+def downsample_forward(x, top_height, top_width):
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    if top_height < 1 or top_width < 1:
+        raise ValueError("DownsampleLayer must have top_height > 0 and top_width > 0")
+    out = torch.empty((N, Cc, int(top_height), int(top_width)), device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_downsample_forward(_ptr(x), _ptr(out), N, Cc, H, W, int(top_height), int(top_width), _stream()))
+    return out

@@ -1,0 +1,289 @@
+"""GPU parity tests: HIP kernels (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32; north_star: 'EPE within 1e-4 fp32'):
+  * correlation fwd/bwd : |hip - oracle| <= 2e-6 * max(1, |oracle|_inf)  (summation order differs: the
+    oracle keeps the reference's 32 lane-partials, the MFMA kernel accumulates k-ordered fma chains)
+  * flow-warp / resample / channel-norm / downsample forward: <= 1e-6 abs (same op order; fma
+    contraction may differ in the last bit)
+  * flow-warp backward image diff: <= 1e-5 abs (float atomics: order not deterministic)
+  * L1 loss: <= 1e-6 relative (reduction order differs; both accumulate in double)
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from flownet2_amd import layers, ops
+from flownet2_amd.layers import Blob, LayerParameter, LayerRegistry
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def rand(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def assert_close(got, ref, atol, what=""):
+    ref = np.asarray(ref)
+    scale = max(1.0, float(np.abs(ref[np.isfinite(ref)]).max()) if np.isfinite(ref).any() else 1.0)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{what}: NaN pattern differs"
+    err = np.abs(np.nan_to_num(got) - np.nan_to_num(ref)).max()
+    assert err <= atol * scale, f"{what}: max abs err {err:.3e} > {atol * scale:.3e}"
+
+
+CORR_CASES = [
+    # (N, C, H, W, pad, K, md, s1, s2)
+    (2, 5, 9, 11, 4, 1, 4, 1, 2),
+    (1, 7, 8, 10, 3, 3, 2, 2, 1),
+    (2, 3, 7, 9, 3, 1, 3, 1, 1),
+    (1, 4, 10, 9, 5, 3, 4, 1, 2),
+    (1, 33, 6, 7, 2, 1, 2, 1, 1),
+    (1, 2, 6, 6, 6, 1, 4, 1, 2),
+    (1, 16, 13, 17, 20, 1, 20, 1, 2),     # FlowNetC parameters, ragged small map (all displacements hit the border)
+    (2, 64, 24, 40, 20, 1, 20, 1, 2),     # FlowNetC parameters, multi-tile
+    (1, 256, 16, 24, 20, 1, 20, 1, 2),    # FlowNetC channel count
+    (1, 12, 9, 30, 8, 1, 8, 1, 1),        # stride_2 = 1 fast path
+    (1, 6, 11, 13, 7, 1, 6, 1, 3),        # stride_2 = 3
+]
+
+
+@pytest.mark.parametrize("case", CORR_CASES)
+@pytest.mark.parametrize("ctype", [oracle.MULTIPLY, oracle.SUBTRACT])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_correlation_forward(case, ctype, force_generic):
+    N, C, H, W, pad, K, md, s1, s2 = case
+    b0, b1 = rand((N, C, H, W), 1), rand((N, C, H, W), 2)
+    ref = oracle.correlation_forward(oracle.corr_params(pad, K, md, s1, s2, ctype), b0, b1)
+    ops.set_correlation_impl(force_generic)
+    try:
+        top = ops.correlation_forward(ops.corr_params(pad, K, md, s1, s2, ctype), dev(b0), dev(b1))
+    finally:
+        ops.set_correlation_impl(False)
+    assert_close(host(top), ref, 2e-6, "correlation forward")
+
+
+@pytest.mark.parametrize("case", CORR_CASES)
+@pytest.mark.parametrize("ctype", [oracle.MULTIPLY, oracle.SUBTRACT])
+def test_correlation_backward(case, ctype):
+    N, C, H, W, pad, K, md, s1, s2 = case
+    b0, b1 = rand((N, C, H, W), 3), rand((N, C, H, W), 4)
+    po = oracle.corr_params(pad, K, md, s1, s2, ctype)
+    tc, th, tw = oracle.correlation_out_shape(po, C, H, W)
+    g = rand((N, tc, th, tw), 5)
+    r0, r1 = oracle.correlation_backward(po, b0, b1, g)
+    d0, d1 = ops.correlation_backward(ops.corr_params(pad, K, md, s1, s2, ctype), dev(b0), dev(b1), dev(g))
+    assert_close(host(d0), r0, 3e-6, "correlation backward bottom0")
+    assert_close(host(d1), r1, 3e-6, "correlation backward bottom1")
+
+
+def test_correlation_layer_api_forward_backward():
+    """Through the Layer mirror, the way Net::ForwardFromTo / BackwardFromTo drive the reference layer."""
+    N, C, H, W = 2, 8, 12, 14
+    b0, b1 = rand((N, C, H, W), 6), rand((N, C, H, W), 7)
+    lp = LayerParameter(name="corr", type="Correlation",
+                        correlation_param=dict(pad=4, kernel_size=1, max_displacement=4, stride_1=1, stride_2=2))
+    layer = LayerRegistry.CreateLayer(lp)
+    bottom = [Blob.from_tensor(dev(b0)), Blob.from_tensor(dev(b1))]
+    top = [Blob()]
+    layer.SetUp(bottom, top)
+    assert top[0].shape() == [N, 25, H, W]
+    layer.Forward(bottom, top)
+    po = oracle.corr_params(4, 1, 4, 1, 2)
+    assert_close(top[0].cpu_data(), oracle.correlation_forward(po, b0, b1), 2e-6)
+    g = rand((N, 25, H, W), 8)
+    top[0].mutable_gpu_diff().copy_(dev(g))
+    layer.Backward(top, [True, True], bottom)
+    r0, r1 = oracle.correlation_backward(po, b0, b1, g)
+    assert_close(bottom[0].cpu_diff(), r0, 3e-6)
+    assert_close(bottom[1].cpu_diff(), r1, 3e-6)
+
+
+def test_correlation_full_size_properties():
+    """BASELINE config sizes ([8,256,40,56]): size-independent properties instead of the (slow) oracle."""
+    N, C, H, W = 8, 256, 40, 56
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(N, C, H, W, device="cuda", generator=g)
+    b = torch.randn(N, C, H, W, device="cuda", generator=g)
+    top = ops.correlation_forward(p, a, b)
+    assert tuple(top.shape) == (N, 441, H, W)
+    # (1) zero displacement channel (220) is the channel-mean of a*b
+    assert torch.allclose(top[:, 220], (a * b).mean(1), atol=2e-6)
+    # (2) each displacement channel equals the mean product with the shifted second map
+    for q, o in [(-10, -10), (10, 10), (-3, 7), (0, 5), (9, -1)]:
+        ch = (q + 10) * 21 + (o + 10)
+        sh = torch.zeros_like(b)
+        ys, ye = max(0, -2 * q), min(H, H - 2 * q)
+        xs, xe = max(0, -2 * o), min(W, W - 2 * o)
+        sh[:, :, ys:ye, xs:xe] = b[:, :, ys + 2 * q:ye + 2 * q, xs + 2 * o:xe + 2 * o]
+        assert torch.allclose(top[:, ch], (a * sh).mean(1), atol=2e-6), (q, o)
+    # (3) bilinearity
+    top2 = ops.correlation_forward(p, 2 * a, b)
+    assert torch.allclose(top2, 2 * top, atol=1e-6)
+    # (4) swapping the inputs mirrors the displacement grid: corr(b,a)[(q,o)](y,x) = corr(a,b)[(-q,-o)](y+2q, x+2o)
+    topr = ops.correlation_forward(p, b, a)
+    q, o = 4, -6
+    ch, chm = (q + 10) * 21 + (o + 10), (-q + 10) * 21 + (-o + 10)
+    assert torch.allclose(topr[:, ch, 0:H - 2 * q, -2 * o:W], top[:, chm, 2 * q:H, 0:W + 2 * o], atol=2e-6)
+    # (5) generic kernel and MFMA kernel agree on the full size
+    ops.set_correlation_impl(True)
+    try:
+        topg = ops.correlation_forward(p, a, b)
+    finally:
+        ops.set_correlation_impl(False)
+    assert torch.allclose(topg, top, atol=2e-6)
+    # (6) backward is the adjoint of forward: <corr(a,b), g> differentiated w.r.t. a and b
+    gg = torch.randn(top.shape, device="cuda", generator=g)
+    d0, d1 = ops.correlation_backward(p, a, b, gg)
+    da = torch.randn(a.shape, device="cuda", generator=g)
+    lhs = (ops.correlation_forward(p, da, b) * gg).double().sum()
+    rhs = (d0 * da).double().sum()
+    assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
+    lhs = (ops.correlation_forward(p, a, da) * gg).double().sum()
+    rhs = (d1 * da).double().sum()
+    assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 13, 17), (1, 1, 5, 64), (2, 37, 9, 10), (1, 256, 12, 24)])
+@pytest.mark.parametrize("fill", [oracle.FILL_ZERO, oracle.FILL_NAN])
+def test_flow_warp_forward(shape, fill):
+    N, C, H, W = shape
+    img = rand(shape, 10)
+    flow = rand((N, 2, H, W), 11, 4.0)
+    flow[0, :, 0, 0] = 0.0                       # exact integer positions
+    flow[0, 0, 1, 1] = W - 2.0                   # lands in the clamped last column
+    ref = oracle.flow_warp_forward(img, flow, fill)
+    out = ops.flow_warp_forward(dev(img), dev(flow), fill)
+    assert_close(host(out), ref, 1e-6, "flow warp forward")
+    zero = np.zeros_like(flow)
+    assert np.array_equal(host(ops.flow_warp_forward(dev(img), dev(zero))), img)     # zero flow = identity, bit exact
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 13, 17), (1, 8, 9, 10)])
+@pytest.mark.parametrize("prop", [(True, True), (False, True), (True, False)])
+def test_flow_warp_backward(shape, prop):
+    N, C, H, W = shape
+    img, flow, g = rand(shape, 12), rand((N, 2, H, W), 13, 3.0), rand(shape, 14)
+    ri, rf = oracle.flow_warp_backward(img, flow, g, *prop)
+    di, df = ops.flow_warp_backward(dev(img), dev(flow), dev(g), *prop)
+    assert_close(host(di), ri, 1e-5, "flow warp image diff")
+    assert_close(host(df), rf, 1e-5, "flow warp flow diff")
+
+
+@pytest.mark.parametrize("code", [oracle.LINEAR, oracle.CUBIC, oracle.NEAREST])
+@pytest.mark.parametrize("shape", [((6, 8), (24, 32)), ((16, 20), (8, 10)), ((9, 12), (9, 12)), ((12, 16), (7, 9)),
+                                   ((24, 48), (96, 192)), ((80, 112), (20, 28)), ((30, 40), (32, 64))])
+@pytest.mark.parametrize("antialias", [True, False])
+def test_resample(code, shape, antialias):
+    (Hin, Win), (Hout, Wout) = shape
+    x = rand((2, 3, Hin, Win), 15)
+    ref = oracle.resample_forward(x, Hout, Wout, code, antialias)
+    out = ops.resample_forward(dev(x), Hout, Wout, code, antialias)
+    assert_close(host(out), ref, 2e-6, "resample")
+    if (Hin, Win) == (Hout, Wout):
+        assert np.array_equal(host(out), x)
+
+
+def test_resample_rejects_area():
+    import flownet2_amd
+    with pytest.raises(flownet2_amd.Fn2Error):
+        ops.resample_forward(dev(rand((1, 1, 4, 4), 0)), 2, 2, ops.AREA)
+
+
+L1_CASES = [
+    dict(l2_per_location=True, normalize_by_num_entries=True),
+    dict(l2_per_location=True, l2_prescale_by_channels=True, plateau=0.3),
+    dict(l2_per_location=False),
+    dict(l2_per_location=False, plateau=0.2, normalize_by_num_entries=True),
+    dict(l2_per_location=True, epsilon=1e-3),
+]
+
+
+@pytest.mark.parametrize("kw", L1_CASES)
+@pytest.mark.parametrize("two", [True, False])
+@pytest.mark.parametrize("shape", [(3, 2, 7, 9), (8, 2, 80, 112)])
+def test_l1loss(kw, two, shape):
+    b0, b1 = rand(shape, 16), rand(shape, 17)
+    tgt = b1 if two else b0
+    tgt[0, :, 2, 3] = np.nan
+    tgt[1, 0, 4, 4] = np.nan
+    mask = np.random.default_rng(18).random(shape[2:]) < 0.05
+    tgt[2][:, mask] = np.nan
+    po = oracle.l1_params(**kw)
+    rloss, rnorm = oracle.l1loss_forward(po, b0, b1 if two else None)
+    p = ops.l1_params(**kw)
+    loss, ws = ops.l1loss_forward(p, dev(b0), dev(b1) if two else None)
+    wsf = ws[:8].view(torch.float32).cpu().numpy()
+    assert abs(wsf[1] - rnorm) <= 1e-6 * rnorm
+    assert abs(float(loss) - rloss) <= 1e-6 * max(1.0, abs(rloss))
+    assert abs(wsf[0] - float(loss)) == 0
+    r0, r1 = oracle.l1loss_backward(po, b0, b1 if two else None, 0.32, rnorm)
+    d0, d1 = ops.l1loss_backward(p, dev(b0), dev(b1) if two else None, 0.32, ws)
+    assert_close(host(d0), r0, 1e-6, "l1 diff 0")
+    if two:
+        assert_close(host(d1), r1, 1e-6, "l1 diff 1")
+    # determinism: fixed reduction order -> bit-identical loss
+    loss2, _ = ops.l1loss_forward(p, dev(b0), dev(b1) if two else None)
+    assert float(loss2) == float(loss)
+
+
+def test_l1loss_layer_api():
+    shape = (4, 2, 10, 14)
+    pred, gt = rand(shape, 19), rand(shape, 20)
+    gt[0, :, 3, 3] = np.nan
+    lp = LayerParameter(type="L1Loss", loss_weight=[0.32], l1_loss_param=dict(l2_per_location=True, normalize_by_num_entries=True))
+    layer = LayerRegistry.CreateLayer(lp)
+    bottom = [Blob.from_tensor(dev(pred)), Blob.from_tensor(dev(gt))]
+    top = [Blob()]
+    layer.SetUp(bottom, top)
+    total = layer.Forward(bottom, top)
+    po = oracle.l1_params(l2_per_location=True, normalize_by_num_entries=True)
+    rloss, rnorm = oracle.l1loss_forward(po, pred, gt)
+    assert abs(float(top[0].data) - rloss) <= 1e-6
+    assert abs(float(total) - 0.32 * rloss) <= 1e-6            # Layer::Forward: dot(top.data, loss_weight)
+    assert abs(layer.normalize_coeff() - rnorm) <= 1e-6 * rnorm
+    layer.Backward(top, [True, False], bottom)
+    r0, _ = oracle.l1loss_backward(po, pred, gt, 0.32, rnorm)
+    assert_close(bottom[0].cpu_diff(), r0, 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6), (4, 2, 96, 192), (1, 1, 3, 3)])
+def test_channel_norm(shape):
+    x = rand(shape, 21)
+    top = oracle.channel_norm_forward(x)
+    out = ops.channel_norm_forward(dev(x))
+    assert_close(host(out), top, 1e-6)
+    g = rand((shape[0], 1) + shape[2:], 22)
+    ref = oracle.channel_norm_backward(x, top, g)
+    d = ops.channel_norm_backward(dev(x), dev(top), dev(g))
+    assert_close(host(d), ref, 1e-6)
+    z = np.zeros(shape, np.float32)
+    dz = ops.channel_norm_backward(dev(z), ops.channel_norm_forward(dev(z)), dev(g))
+    assert np.array_equal(host(dz), np.zeros(shape, np.float32))       # 0 / (0 + 1e-9) = 0, no NaN
+
+
+@pytest.mark.parametrize("shape", [((16, 24), (4, 6)), ((17, 23), (5, 7)), ((8, 8), (8, 8)), ((320, 448), (80, 112)), ((320, 448), (5, 7))])
+def test_downsample(shape):
+    (Hin, Win), (Hout, Wout) = shape
+    x = rand((2, 2, Hin, Win), 23)
+    x[0, 0, :6, :9] = np.nan
+    x[1, :, Hin // 2:, :] = np.nan
+    ref = oracle.downsample_forward(x, Hout, Wout)
+    out = ops.downsample_forward(dev(x), Hout, Wout)
+    assert_close(host(out), ref, 1e-6, "downsample")
+
+
+def test_empty_batch_is_a_noop():
+    z = torch.empty((0, 3, 4, 4), device="cuda")
+    assert ops.channel_norm_forward(z).shape == (0, 1, 4, 4)
+    assert ops.correlation_forward(ops.corr_params(1, 1, 1, 1, 1), z, z).shape == (0, 9, 4, 4)
+    assert ops.flow_warp_forward(z, torch.empty((0, 2, 4, 4), device="cuda")).shape == (0, 3, 4, 4)
