@@ -78,8 +78,8 @@ using namespace fn2;
 
 FN2_API int fn2_channel_norm_forward(const float* bottom, float* top, int N, int C, int H, int W, void* stream) {
   if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
-  if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
   const size_t hw = (size_t)H * W;
   hipLaunchKernelGGL(channel_norm_fwd, dim3(blocks_for((long long)N * hw, 256)), dim3(256), 0, as_stream(stream), bottom, top, N, C, hw);
   return check_launch("channel_norm_forward");
@@ -88,8 +88,8 @@ FN2_API int fn2_channel_norm_forward(const float* bottom, float* top, int N, int
 FN2_API int fn2_channel_norm_backward(const float* bottom, const float* top, const float* top_diff, float* bottom_diff,
                                       int N, int C, int H, int W, void* stream) {
   if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
-  if (!bottom || !top || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!bottom || !top || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
   const size_t hw = (size_t)H * W;
   hipLaunchKernelGGL(channel_norm_bwd, dim3(blocks_for((long long)N * C * hw, 256)), dim3(256), 0, as_stream(stream), bottom, top,
                      top_diff, bottom_diff, N, C, hw);
@@ -100,8 +100,8 @@ FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C
                                    void* stream) {
   if (N < 0 || C < 1 || Hin < 1 || Win < 1) return fail(FN2_ERR_INVALID_ARG, "downsample: bad bottom shape");
   if (Hout < 1 || Wout < 1) return fail(FN2_ERR_INVALID_ARG, "DownsampleLayer must have top_height > 0 and top_width > 0");
-  if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "downsample: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "downsample: NULL blob pointer");
   hipStream_t st = as_stream(stream);
   if (Hin == Hout && Win == Wout) {   // downsample_layer.cpp:53-56 shares the blob; we copy
     if (bottom != top &&

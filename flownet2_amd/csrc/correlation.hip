@@ -12,18 +12,11 @@
 //       one thread per output element, x fastest (coalesced).  Fallback + cross-check.
 //   corr_fwd_mfma (correlation_mfma.hip)     : the FlowNetC fast path, kernel_size 1, stride_1 1,
 //       MULTIPLY: banded GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
-#include "fn2_common.hpp"
+#include "correlation.hpp"
 
 #include <cmath>
 
 namespace fn2 {
-
-struct CorrGeom {
-  int N, C, H, W;
-  int pad, K, md, s1, s2, kr;
-  int topC, topH, topW, ngr, ngw;
-  int type;
-};
 
 // CorrelationLayer::LayerSetUp + Reshape, correlation_layer.cpp:13-84.
 int corr_geometry(const fn2_corr_params* p, int N, int C, int H, int W, CorrGeom* g) {
@@ -154,10 +147,6 @@ __global__ void __launch_bounds__(256) corr_bwd_generic(const float* __restrict_
   }
 }
 
-// correlation_mfma.hip
-bool corr_fwd_mfma_supported(const CorrGeom& g);
-int corr_fwd_mfma_launch(const CorrGeom& g, const float* b0, const float* b1, float* top, hipStream_t st);
-
 // Set by the tests / bench through fn2_debug_set_correlation_impl: 0 = auto, 1 = force generic.
 static int g_force_generic = 0;
 
@@ -187,8 +176,8 @@ FN2_API int fn2_correlation_forward(const fn2_corr_params* p, const float* botto
   CorrGeom g;
   int rc = corr_geometry(p, N, C, H, W, &g);
   if (rc) return rc;
-  if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation_forward: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation_forward: NULL blob pointer");
   hipStream_t st = as_stream(stream);
   if (!g_force_generic && corr_fwd_mfma_supported(g)) return corr_fwd_mfma_launch(g, bottom0, bottom1, top, st);
   const long long total = (long long)N * g.topC * g.topH * g.topW;
@@ -206,8 +195,8 @@ FN2_API int fn2_correlation_backward(const fn2_corr_params* p, const float* bott
   CorrGeom g;
   int rc = corr_geometry(p, N, C, H, W, &g);
   if (rc) return rc;
-  if (!bottom0 || !bottom1 || !top_diff) return fail(FN2_ERR_INVALID_ARG, "correlation_backward: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!bottom0 || !bottom1 || !top_diff) return fail(FN2_ERR_INVALID_ARG, "correlation_backward: NULL blob pointer");
   hipStream_t st = as_stream(stream);
   const long long total = (long long)N * C * H * W;
   const unsigned blocks = blocks_for(total, 256);

@@ -1,0 +1,17 @@
+// Shared between correlation.hip (generic kernels, C ABI) and correlation_mfma.hip (fast path).
+#pragma once
+#include "fn2_common.hpp"
+
+namespace fn2 {
+
+struct CorrGeom {
+  int N, C, H, W;
+  int pad, K, md, s1, s2, kr;
+  int topC, topH, topW, ngr, ngw;
+  int type;
+};
+
+bool corr_fwd_mfma_supported(const CorrGeom& g);
+int corr_fwd_mfma_launch(const CorrGeom& g, const float* b0, const float* b1, float* top, hipStream_t st);
+
+}  // namespace fn2

@@ -115,8 +115,8 @@ FN2_API int fn2_flow_warp_forward(const float* image, const float* flow, float* 
   if (rc) return rc;
   if (fill_value != FN2_FILL_ZERO && fill_value != FN2_FILL_NAN)
     return fail(FN2_ERR_INVALID_ARG, "flow_warp_forward: fill_value must be ZERO(1) or NOT_A_NUMBER(2)");
-  if (!image || !flow || !warped) return fail(FN2_ERR_INVALID_ARG, "flow_warp_forward: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!image || !flow || !warped) return fail(FN2_ERR_INVALID_ARG, "flow_warp_forward: NULL blob pointer");
   const int cgroups = (C + kWarpChPerThread - 1) / kWarpChPerThread;
   const long long total = (long long)N * cgroups * H * W;
   const float fill = (fill_value == FN2_FILL_ZERO) ? 0.f : __builtin_bit_cast(float, 0xFFE00000u);   // flow_warp_layer.cu:372-375

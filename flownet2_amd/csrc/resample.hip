@@ -86,8 +86,8 @@ FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int 
   if (Hout < 1 || Wout < 1) return fail(FN2_ERR_INVALID_ARG, "ResampleLayer must have top_height > 0 and top_width > 0");
   if (type != FN2_RESAMPLE_NEAREST && type != FN2_RESAMPLE_LINEAR && type != FN2_RESAMPLE_CUBIC)
     return fail(FN2_ERR_UNSUPPORTED, "ResampleLayer: only CUBIC, LINEAR and NEAREST interpolation is supported for now");
-  if (!in || !out) return fail(FN2_ERR_INVALID_ARG, "resample: NULL blob pointer");
   if (N == 0) return FN2_OK;
+  if (!in || !out) return fail(FN2_ERR_INVALID_ARG, "resample: NULL blob pointer");
   ResampleArgs a;
   a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
   a.fx = (float)Win / (float)Wout;                              // :146

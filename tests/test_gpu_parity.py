@@ -51,7 +51,12 @@ CORR_CASES = [
     (1, 16, 13, 17, 20, 1, 20, 1, 2),     # FlowNetC parameters, ragged small map (all displacements hit the border)
     (2, 64, 24, 40, 20, 1, 20, 1, 2),     # FlowNetC parameters, multi-tile
     (1, 256, 16, 24, 20, 1, 20, 1, 2),    # FlowNetC channel count
-    (1, 12, 9, 30, 8, 1, 8, 1, 1),        # stride_2 = 1 fast path
+    (1, 12, 9, 30, 8, 1, 8, 1, 1),        # stride_2 = 1, C not a multiple of 16 -> generic
+    (1, 32, 9, 30, 8, 1, 8, 1, 1),        # MFMA <S2=1,R=8>
+    (1, 16, 11, 13, 8, 1, 8, 1, 2),       # MFMA <S2=2,R=4>, odd sizes
+    (2, 32, 10, 35, 4, 1, 4, 1, 1),       # MFMA <S2=1,R=4>, two x spans
+    (1, 32, 41, 57, 20, 1, 20, 1, 2),     # MFMA <S2=2,R=10>, odd H and W, two x spans
+    (1, 16, 9, 70, 21, 1, 21, 1, 2),      # max_displacement not a multiple of stride_2 (R = 10), three x spans
     (1, 6, 11, 13, 7, 1, 6, 1, 3),        # stride_2 = 3
 ]
 
