@@ -16,15 +16,18 @@
 // Work decomposition.  One workgroup (8 waves) = (sample n, y-parity py, 4 class rows I, one N
 // patch-row a, a 32-pixel x span): wave w owns the M tile (px = w % S2, patch w / S2) and the NB N
 // tiles of patch-row a.  The 4 + 4 image rows a workgroup needs are staged through LDS in chunks of
-// 16 channels (coalesced row reads straight from NCHW, zero fill outside the image = the
-// reference's padding, de-interleaved by x parity so the MFMA operand reads are conflict-free),
-// double-buffered with register staging (loads of chunk k+1 in flight under the MFMAs of chunk k,
-// one barrier per chunk).  The accumulators are scattered into an LDS image of the output and
-// written back as full 128-byte rows.  Two workgroups are resident per CU.
+// 16 channels: coalesced row reads straight from NCHW through a raw buffer descriptor whose
+// out-of-range answer (0.0f) IS the reference's zero padding, de-interleaved by x parity so the
+// MFMA operand reads are bank-conflict free, double-buffered with register staging (loads of chunk
+// k+1 in flight under the MFMAs of chunk k, one barrier per chunk).  The accumulators are scattered
+// into an LDS image of the output and written back as full 128-byte rows.  LDS (52.4 KiB) and VGPRs
+// (<= 80) are sized for THREE resident workgroups per CU = 6 waves per SIMD.
 //
-// HBM traffic: every workgroup reads each input row once per (I, a) pair it participates in; with
-// the sample -> XCD mapping below those re-reads hit the 4 MiB L2, so HBM sees ~ the algorithmic
-// 4*N*H*W*(2C + 441) bytes.
+// Scheduling.  Tasks whose second-map rows are all outside the image ("light": they only write
+// zeros) are ordered after the heavy ones of the same sample, and block b runs logical task
+// (b % 8) * GP + b / 8 so that every XCD (b % 8) walks one contiguous task range = one sample when
+// N is a multiple of 8: the 21x re-reads of a sample's rows stay inside that XCD's 4 MiB L2 and HBM
+// sees ~ the algorithmic 4*N*H*W*(2C + 441) bytes.
 #include "correlation.hpp"
 
 namespace fn2 {
@@ -35,11 +38,14 @@ constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kKC = 16;   // channels per LDS chunk (4 MFMA k-steps)
 
-constexpr int up_4mod8(int v) { return v + ((4 - v % 8) + 8) % 8; }
-constexpr int up_16mod32(int v) { return v + ((16 - v % 32) + 32) % 32; }
+constexpr int up_mod(int v, int r, int m) { return v + ((r - v % m) + m) % m; }   // smallest >= v with == r (mod m)
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// LDS chunk image: B region [row 4][px S2][kc 16][BCS], A region [row 4][px S2][kc 16][ACS].
+// A 16x16x4 operand read has lane (kk, ni, nj) -> address  ni*RS + kk*CS + nj + const; the 32 lanes
+// of a ds_read_b32 half (kk in {0,1}) hit 32 different banks iff {kk*CS + ni*RS} are the 8 multiples
+// of 4 (mod 32):  CS == 4 (mod 8) with RS == 8 (mod 16),  or  CS == 16 (mod 32) with RS == 4 (mod 8).
 template <int S2, int R>
 struct Cfg {
   static constexpr int D = 2 * R + 1;                 // displacements per axis
@@ -48,30 +54,146 @@ struct Cfg {
   static constexpr int SPANC = 4 * PJ;                // class columns per workgroup
   static constexpr int SPANPX = SPANC * S2;           // pixels per workgroup row (32)
   static constexpr int JW = SPANC - 4 + 4 * NB;       // class columns of the second map staged per row
-  static constexpr int JWP = up_4mod8(JW);            // row stride == 4 (mod 8): 16 (i,j) lanes hit 16 banks
-  static constexpr int AWP = up_4mod8(SPANC);
   static constexpr int BPX = JW * S2;                 // staged pixels per row of the second map
-  static constexpr int AOFF = S2 * 4 * JWP;           // first-map region inside one channel slot
-  static constexpr int KS = up_16mod32(AOFF + S2 * 4 * AWP);   // channel slot stride == 16 (mod 32)
-  static constexpr int NBE = cdiv(kKC * 4 * BPX, kThreads);    // staged elements per thread
-  static constexpr int NAE = cdiv(kKC * 4 * SPANPX, kThreads);
-  static constexpr bool B_EXACT = (kKC * 4 * BPX) % kThreads == 0;
-  static constexpr bool A_EXACT = (kKC * 4 * SPANPX) % kThreads == 0;
+  static constexpr int BCS = up_mod(JW, 4, 8);        // channel stride, second map
+  static constexpr int BRS = up_mod(S2 * kKC * BCS, 8, 16);
+  static constexpr bool A16 = (SPANC % 32) == 16;
+  static constexpr int ACS = A16 ? SPANC : up_mod(SPANC, 4, 8);
+  static constexpr int ARS = A16 ? up_mod(S2 * kKC * ACS, 4, 8) : up_mod(S2 * kKC * ACS, 8, 16);
+  static constexpr int AOFF = 4 * BRS;
+  static constexpr int CHUNK = AOFF + 4 * ARS;        // floats per staged chunk
+  static constexpr int BWAVES = cdiv(4 * BPX, 64);    // staging: waves [0,BWAVES) second map, next AWAVES first map
+  static constexpr int AWAVES = cdiv(4 * SPANPX, 64);
   static constexpr int XS = SPANPX + 1;               // output-image row stride in LDS
   static constexpr int OROWS = 16 * D;                // (mi, ni, o) rows of the output image
-  static constexpr int LDS_FLOATS = cmax(2 * kKC * KS, OROWS * XS);
+  static constexpr int LDS_FLOATS = cmax(2 * CHUNK, OROWS * XS);
+  static constexpr int LO_MAX = (NB >= 3) ? 2 : 0;    // specialised N-tile ranges [lo, hi], lo <= LO_MAX, hi >= HI_MIN
+  static constexpr int HI_MIN = (NB >= 3) ? NB - 3 : NB - 1;
   static_assert(kWaves % S2 == 0, "waves must split evenly over x parities");
   static_assert(kThreads % SPANPX == 0, "store phase mapping");
+  static_assert(BWAVES + AWAVES <= kWaves, "staging does not fit the workgroup");
 };
 
 struct MfmaArgs {
   int N, C, H, W;
   int NI, NSPAN;        // M patch rows per y-parity class, x spans
+  int TS, TH;           // tasks per sample, heavy tasks per sample
   int G, GP;            // logical workgroups, workgroups per XCD
 };
 
+// live N patch-rows of M patch-row I: a in [alo, ahi] (may be empty)
 template <int S2, int R>
-__global__ void __launch_bounds__(kThreads, 4)
+__host__ __device__ inline void live_range(int I, int Hc, int& alo, int& ahi) {
+  constexpr int NB = Cfg<S2, R>::NB;
+  // i2_0 = 4I - R + 4a;  live iff i2_0 + 3 >= 0 and i2_0 < Hc
+  const int lo_num = R - 3 - 4 * I;                       // a >= lo_num / 4
+  alo = lo_num <= 0 ? 0 : (lo_num + 3) / 4;
+  const int hi_num = Hc - 1 + R - 4 * I;                  // a <= hi_num / 4
+  ahi = hi_num < 0 ? -1 : hi_num / 4;
+  if (ahi > NB - 1) ahi = NB - 1;
+  if (4 * I >= Hc) { alo = 0; ahi = -1; }
+}
+
+// One channel pass of a workgroup: stage 16-channel chunks of the 4 + 4 image rows through LDS
+// (double buffered, register staged) and run the MFMAs of N tiles [LO, HI] of this wave.
+template <int S2, int R, int LO, int HI, typename Acc>
+__device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
+                                       int tid, int lane, int wave, int px, int Jw, int py, int i0, int i2_0, int jS) {
+  using K = Cfg<S2, R>;
+  const int plane = g.H * g.W;
+  // ---- staging plan: a thread owns ONE pixel position of the 4 + 4 rows and walks the 16 channels
+  // of a chunk with an SGPR channel offset (global side) / an immediate (LDS side).
+  constexpr unsigned OOB = 0x7ffffff0u;
+  const bool isB = wave < K::BWAVES;
+  const int pos = isB ? tid : tid - 64 * K::BWAVES;
+  unsigned voff = OOB;
+  int laddr = -1;
+  if (isB) {
+    const int row = pos / K::BPX, col = pos % K::BPX;
+    if (row < 4) {
+      const int ib = i2_0 + row, yb = S2 * ib + py, xb = S2 * (jS - R) + col;
+      if (ib >= 0 && yb < g.H && xb >= 0 && xb < g.W) voff = 4u * (unsigned)(yb * g.W + xb);
+      laddr = row * K::BRS + (col % S2) * (kKC * K::BCS) + col / S2;
+    }
+  } else {
+    const int row = pos / K::SPANPX, col = pos % K::SPANPX;
+    if (row < 4) {
+      const int ya = S2 * (i0 + row) + py, xa = S2 * jS + col;
+      if (ya < g.H && xa < g.W) voff = 4u * (unsigned)(ya * g.W + xa);
+      laddr = K::AOFF + row * K::ARS + (col % S2) * (kKC * K::ACS) + col / S2;
+    }
+  }
+  const int lcs = isB ? K::BCS : K::ACS;
+  const float* src = isB ? b_n : a_n;        // wave-uniform: one descriptor per wave
+  const unsigned chunk_bytes = 4u * kKC * (unsigned)plane;
+  const unsigned plane_bytes = 4u * (unsigned)plane;
+  float sv[kKC];
+
+  auto load_chunk = [&](int chunk) {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)chunk * kKC * plane), 0, chunk_bytes, 0x00020000);
+    if (laddr >= 0) {
+#pragma unroll
+      for (int kc = 0; kc < kKC; ++kc)
+        sv[kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, kc * plane_bytes, 0));
+    }
+  };
+  auto store_chunk = [&](float* buf) {
+    if (laddr >= 0) {
+#pragma unroll
+      for (int kc = 0; kc < kKC; ++kc) buf[laddr + kc * lcs] = sv[kc];
+    }
+  };
+
+  // operand addresses: lane (kk, ni, nj) of the 16x16x4 fragment reads channel 4*ks + kk of the chunk
+  const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
+  const int aAddr = K::AOFF + ni * K::ARS + px * (kKC * K::ACS) + kk * K::ACS + 4 * Jw + nj;
+  const int bAddr = ni * K::BRS + px * (kKC * K::BCS) + kk * K::BCS + 4 * Jw + nj;
+  constexpr int NT = (LO <= HI) ? HI - LO + 1 : 0;
+  auto compute = [&](const float* buf) {
+    if constexpr (NT > 0) {
+      // explicit operand double buffering: the reads of k-step ks+1 are issued before the MFMAs of ks
+      float av[2], bv[2][NT];
+      av[0] = buf[aAddr];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[0][t] = buf[bAddr + 4 * (LO + t)];
+#pragma unroll
+      for (int ks = 0; ks < kKC / 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < kKC / 4) {
+          av[nxt] = buf[aAddr + 4 * (ks + 1) * K::ACS];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bv[nxt][t] = buf[bAddr + 4 * (ks + 1) * K::BCS + 4 * (LO + t)];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], bv[cur][t], acc[LO + t], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nchunks = g.C / kKC;
+  float* buf0 = smem;
+  float* buf1 = smem + K::CHUNK;
+  load_chunk(0);
+  store_chunk(buf0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    compute(buf0);
+    if (ch + 1 < nchunks) store_chunk(buf1);
+    __syncthreads();
+    if (ch + 1 < nchunks) {
+      if (ch + 2 < nchunks) load_chunk(ch + 2);
+      compute(buf1);
+      if (ch + 2 < nchunks) store_chunk(buf0);
+      __syncthreads();
+    }
+  }
+}
+
+template <int S2, int R>
+__global__ void __launch_bounds__(kThreads, 6)
 corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g) {
   using K = Cfg<S2, R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -79,12 +201,29 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
   // ---- task decode; blocks b, b+8, b+16.. run on one XCD, give them one contiguous task range ----
   const int L = (int)(blockIdx.x % 8) * g.GP + (int)(blockIdx.x / 8);
   if (L >= g.G) return;
-  int t = L;
-  const int span = t % g.NSPAN; t /= g.NSPAN;
-  const int I = t % g.NI; t /= g.NI;
-  const int py = t % S2; t /= S2;
-  const int a = t % K::NB; t /= K::NB;
-  const int n = t;
+  const int n = L / g.TS;
+  int t = L % g.TS;
+  const bool heavy = t < g.TH;
+  if (!heavy) t -= g.TH;
+  const int span = t % g.NSPAN;
+  t /= g.NSPAN;
+  // t-th heavy (or light) (py, I, a) combination, py-major / I / a order; <= S2 * NI scalar iterations
+  int py = 0, I = 0, a = 0;
+  for (int c = 0; c < S2 * g.NI; ++c) {
+    const int cpy = c / g.NI, cI = c % g.NI;
+    const int Hc_c = (g.H - cpy + S2 - 1) / S2;
+    int alo, ahi;
+    live_range<S2, R>(cI, Hc_c, alo, ahi);
+    const int nlive = ahi >= alo ? ahi - alo + 1 : 0;
+    const int cnt = heavy ? nlive : K::NB - nlive;
+    if (t < cnt) {
+      py = cpy; I = cI;
+      if (heavy) a = alo + t;
+      else a = (nlive == 0 || t < alo) ? t : t + nlive;     // light: a in [0, alo) U (ahi, NB)
+      break;
+    }
+    t -= cnt;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,112 +233,51 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const int Wc = (g.W - px + S2 - 1) / S2;      // class cols of this wave's x parity
   if (i0 >= Hc) return;                         // whole workgroup (uniform): no output rows
 
-  const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
+  const int ni = (lane & 15) >> 2, nj = lane & 3;
   const size_t plane = (size_t)g.H * g.W;
   const float* a_n = b0 + (size_t)n * g.C * plane;
   const float* b_n = b1 + (size_t)n * g.C * plane;
-
-  // Which N tiles of this wave can be non-zero (x direction), and is any staged B row inside the image?
-  unsigned bmask = 0;
-  if (jw < Wc) {
-#pragma unroll
-    for (int b = 0; b < K::NB; ++b) {
-      const int j2 = jw - R + 4 * b;
-      if (j2 + 3 >= 0 && j2 < Wc) bmask |= 1u << b;
-    }
-  }
-  bmask = __builtin_amdgcn_readfirstlane(bmask);
   const int i2_0 = i0 - R + 4 * a;
-  const bool rows_live = (i2_0 + 3 >= 0) && (i2_0 < Hc);
 
   f32x4 acc[K::NB];
 #pragma unroll
   for (int b = 0; b < K::NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (rows_live) {
-    // ---- per-thread staging plan (constant over channel chunks) ----
-    int gB[K::NBE], lB[K::NBE], gA[K::NAE], lA[K::NAE];
-    unsigned vB = 0, vA = 0;
+  if (heavy) {
+    // N tiles of this wave that can be non-zero (x direction), widened to one of the 3 x 3 specialised
+    // ranges (an extra tile only multiplies staged zeros).  Straight-line MFMA bodies matter: a branch
+    // per tile serialises every ds_read -> s_waitcnt -> v_mfma triple.
+    int lo = K::NB, hi = -1;
+    if (jw < Wc) {
 #pragma unroll
-    for (int k = 0; k < K::NBE; ++k) {
-      const int e = tid + kThreads * k;
-      const int kc = e / (4 * K::BPX), rem = e % (4 * K::BPX);
-      const int row = rem / K::BPX, col = rem % K::BPX;
-      const int yb = S2 * (i2_0 + row) + py, xb = S2 * (jS - R) + col;
-      const bool ok = (e < kKC * 4 * K::BPX) && yb >= 0 && yb < g.H && (i2_0 + row) >= 0 && xb >= 0 && xb < g.W;
-      gB[k] = ok ? (kc * (int)plane + yb * g.W + xb) : 0;
-      lB[k] = (e < kKC * 4 * K::BPX) ? (kc * K::KS + (col % S2) * (4 * K::JWP) + row * K::JWP + col / S2) : -1;
-      vB |= ok ? (1u << k) : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < K::NAE; ++k) {
-      const int e = tid + kThreads * k;
-      const int kc = e / (4 * K::SPANPX), rem = e % (4 * K::SPANPX);
-      const int row = rem / K::SPANPX, col = rem % K::SPANPX;
-      const int ya = S2 * (i0 + row) + py, xa = S2 * jS + col;
-      const bool ok = (e < kKC * 4 * K::SPANPX) && ya < g.H && xa < g.W;
-      gA[k] = ok ? (kc * (int)plane + ya * g.W + xa) : 0;
-      lA[k] = (e < kKC * 4 * K::SPANPX) ? (kc * K::KS + K::AOFF + (col % S2) * (4 * K::AWP) + row * K::AWP + col / S2) : -1;
-      vA |= ok ? (1u << k) : 0u;
-    }
-    float sB[K::NBE], sA[K::NAE];
-
-    auto load_chunk = [&](int chunk) {
-      const float* pb = b_n + (size_t)chunk * kKC * plane;
-      const float* pa = a_n + (size_t)chunk * kKC * plane;
-#pragma unroll
-      for (int k = 0; k < K::NBE; ++k) sB[k] = pb[gB[k]];      // invalid elements read offset 0 (always mapped) ...
-#pragma unroll
-      for (int k = 0; k < K::NAE; ++k) sA[k] = pa[gA[k]];
-    };
-    auto store_chunk = [&](float* buf) {
-#pragma unroll
-      for (int k = 0; k < K::NBE; ++k)
-        if (K::B_EXACT || lB[k] >= 0) buf[lB[k]] = ((vB >> k) & 1u) ? sB[k] : 0.f;   // ... and become the zero padding here
-#pragma unroll
-      for (int k = 0; k < K::NAE; ++k)
-        if (K::A_EXACT || lA[k] >= 0) buf[lA[k]] = ((vA >> k) & 1u) ? sA[k] : 0.f;
-    };
-
-    // operand addresses: lane (kk, ni, nj) of the 16x16x4 fragment reads channel kk of the k-step
-    const int aAddr = kk * K::KS + K::AOFF + px * (4 * K::AWP) + ni * K::AWP + 4 * Jw + nj;
-    const int bAddr = kk * K::KS + px * (4 * K::JWP) + ni * K::JWP + 4 * Jw + nj;
-    auto compute = [&](const float* buf) {
-#pragma unroll
-      for (int ks = 0; ks < kKC / 4; ++ks) {
-        const float av = buf[aAddr + 4 * ks * K::KS];
-#pragma unroll
-        for (int b = 0; b < K::NB; ++b) {
-          if (bmask & (1u << b)) {
-            const float bv = buf[bAddr + 4 * ks * K::KS + 4 * b];
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[b], 0, 0, 0);
-          }
-        }
-      }
-    };
-
-    const int nchunks = g.C / kKC;
-    float* buf0 = smem;
-    float* buf1 = smem + kKC * K::KS;
-    load_chunk(0);
-    store_chunk(buf0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {
-      if (ch + 1 < nchunks) load_chunk(ch + 1);
-      compute(buf0);
-      if (ch + 1 < nchunks) store_chunk(buf1);
-      __syncthreads();
-      if (ch + 1 < nchunks) {
-        if (ch + 2 < nchunks) load_chunk(ch + 2);
-        compute(buf1);
-        if (ch + 2 < nchunks) store_chunk(buf0);
-        __syncthreads();
+      for (int b = 0; b < K::NB; ++b) {
+        const int j2 = jw - R + 4 * b;
+        if (j2 + 3 >= 0 && j2 < Wc) { lo = min(lo, b); hi = max(hi, b); }
       }
     }
+    int sel = 9;
+    if (hi >= lo) sel = min(lo, K::LO_MAX) * 3 + (max(hi, K::HI_MIN) - K::HI_MIN);
+    sel = __builtin_amdgcn_readfirstlane(sel);
+#define FN2_KLOOP(LO_, HI_) k_loop<S2, R, LO_, HI_>(acc, smem, a_n, b_n, g, tid, lane, wave, px, Jw, py, i0, i2_0, jS)
+    switch (sel) {
+      case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
+      case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
+      case 2: FN2_KLOOP(0, K::HI_MIN + 2); break;
+      case 3: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 0); break;
+      case 4: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 1); break;
+      case 5: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 2); break;
+      case 6: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 0); break;
+      case 7: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 1); break;
+      case 8: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 2); break;
+      default: FN2_KLOOP(1, 0); break;   // wave without a live M tile: staging + barriers only
+    }
+#undef FN2_KLOOP
   }
 
   // ---- epilogue: accumulators -> LDS image [mi][ni][o][x] -> coalesced rows of top ----
   const float sumelems = (float)g.C;      // kernel_size^2 * channels, correlation_layer.cu:108
+  const bool pow2 = (g.C & (g.C - 1)) == 0;   // x / 2^k == x * 2^-k exactly; otherwise keep the true division
+  const float rcp = 1.0f / sumelems;
   const int mi = lane >> 4;               // C/D layout of 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane & 15
 #pragma unroll
   for (int b = 0; b < K::NB; ++b) {
@@ -207,7 +285,7 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
     for (int r = 0; r < 4; ++r) {         // reg r <-> mj
       const int oo = 4 * b + nj - r;      // o + R
       if (oo >= 0 && oo < K::D)
-        smem[((mi * 4 + ni) * K::D + oo) * K::XS + S2 * (4 * Jw + r) + px] = acc[b][r] / sumelems;
+        smem[((mi * 4 + ni) * K::D + oo) * K::XS + S2 * (4 * Jw + r) + px] = pow2 ? acc[b][r] * rcp : acc[b][r] / sumelems;
     }
   }
   __syncthreads();
@@ -233,7 +311,16 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   const int Hc = (cg.H + S2 - 1) / S2, Wc = (cg.W + S2 - 1) / S2;
   g.NI = (Hc + 3) / 4;
   g.NSPAN = (Wc + K::SPANC - 1) / K::SPANC;
-  const long long G = (long long)cg.N * K::NB * S2 * g.NI * g.NSPAN;
+  int nheavy = 0;
+  for (int py = 0; py < S2; ++py)
+    for (int I = 0; I < g.NI; ++I) {
+      int alo, ahi;
+      live_range<S2, R>(I, (cg.H - py + S2 - 1) / S2, alo, ahi);
+      if (ahi >= alo) nheavy += ahi - alo + 1;
+    }
+  g.TH = nheavy * g.NSPAN;
+  g.TS = S2 * g.NI * K::NB * g.NSPAN;
+  const long long G = (long long)cg.N * g.TS;
   if (G > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
   g.G = (int)G;
   g.GP = (g.G + 7) / 8;
@@ -250,7 +337,7 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
 bool corr_fwd_mfma_supported(const CorrGeom& g) {
   if (g.K != 1 || g.s1 != 1 || g.type != FN2_CORR_MULTIPLY || g.pad != g.md) return false;
   if (g.C % kKC != 0) return false;
-  if ((long long)g.C * g.H * g.W >= (1ll << 30)) return false;      // 32-bit staging offsets
+  if ((long long)g.C * g.H * g.W >= (1ll << 28)) return false;      // 32-bit byte offsets in the staging loads
   if (g.s2 == 2 && g.ngr == 10) return true;     // FlowNetC / FlowNet2: max_displacement 20, stride_2 2
   if (g.s2 == 1 && g.ngr == 4) return true;      // 9x9 cost volumes (max_displacement 4, stride_2 1)
   if (g.s2 == 2 && g.ngr == 4) return true;
