@@ -43,6 +43,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-munsafe-fp-atomics",
              "-Wall", "-Wno-unused-function"]
+    if os.environ.get("FN2_ABLATION"):
+        flags.append("-DFN2_ABLATION=1")
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")

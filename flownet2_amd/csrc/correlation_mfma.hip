@@ -24,7 +24,7 @@
 // (<= 80) are sized for THREE resident workgroups per CU = 6 waves per SIMD.
 //
 // Scheduling.  Tasks whose second-map rows are all outside the image ("light": they only write
-// zeros) are ordered after the heavy ones of the same sample, and block b runs logical task
+// zeros) are ordered before the heavy ones of the same sample, and block b runs logical task
 // (b % 8) * GP + b / 8 so that every XCD (b % 8) walks one contiguous task range = one sample when
 // N is a multiple of 8: the 21x re-reads of a sample's rows stay inside that XCD's 4 MiB L2 and HBM
 // sees ~ the algorithmic 4*N*H*W*(2C + 441) bytes.
@@ -42,10 +42,13 @@ constexpr int up_mod(int v, int r, int m) { return v + ((r - v % m) + m) % m; } 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// LDS chunk image: B region [row 4][px S2][kc 16][BCS], A region [row 4][px S2][kc 16][ACS].
-// A 16x16x4 operand read has lane (kk, ni, nj) -> address  ni*RS + kk*CS + nj + const; the 32 lanes
-// of a ds_read_b32 half (kk in {0,1}) hit 32 different banks iff {kk*CS + ni*RS} are the 8 multiples
-// of 4 (mod 32):  CS == 4 (mod 8) with RS == 8 (mod 16),  or  CS == 16 (mod 32) with RS == 4 (mod 8).
+// LDS chunk image: B region [row 4][px S2][jcol JW][16 ch], A region [row 4][px S2][jcol SPANC][16 ch]:
+// the 16 channels of one pixel position are contiguous (64 B).  Lane (kk, ni, nj) of a 16x16x4 fragment
+// reads ONE ds_read_b128 per tile = channels 4kk..4kk+3 of its position, i.e. its operand for all four
+// k-steps of the chunk (k-step r of lane group kk contracts channel 4kk + r; the two maps use the same
+// assignment, and a sum over channels does not care).  ds_read_b128 is serviced in 16-lane groups
+// {(0,0),(0,3),(1,1),(1,2)} / {(0,1),(0,2),(1,0),(1,3)} of (kk, ni) (x 4 nj each); with the row stride
+// == 2 (mod 4) sixteen-byte slots = 8 (mod 16) floats every group covers all 64 banks exactly once.
 template <int S2, int R>
 struct Cfg {
   static constexpr int D = 2 * R + 1;                 // displacements per axis
@@ -55,11 +58,10 @@ struct Cfg {
   static constexpr int SPANPX = SPANC * S2;           // pixels per workgroup row (32)
   static constexpr int JW = SPANC - 4 + 4 * NB;       // class columns of the second map staged per row
   static constexpr int BPX = JW * S2;                 // staged pixels per row of the second map
-  static constexpr int BCS = up_mod(JW, 4, 8);        // channel stride, second map
-  static constexpr int BRS = up_mod(S2 * kKC * BCS, 8, 16);
-  static constexpr bool A16 = (SPANC % 32) == 16;
-  static constexpr int ACS = A16 ? SPANC : up_mod(SPANC, 4, 8);
-  static constexpr int ARS = A16 ? up_mod(S2 * kKC * ACS, 4, 8) : up_mod(S2 * kKC * ACS, 8, 16);
+  static constexpr int BPL = JW * kKC;                // floats per (row, px) plane, second map
+  static constexpr int APL = SPANC * kKC;
+  static constexpr int BRS = up_mod(S2 * BPL, 8, 16); // row strides (floats)
+  static constexpr int ARS = up_mod(S2 * APL, 8, 16);
   static constexpr int AOFF = 4 * BRS;
   static constexpr int CHUNK = AOFF + 4 * ARS;        // floats per staged chunk
   static constexpr int BWAVES = cdiv(4 * BPX, 64);    // staging: waves [0,BWAVES) second map, next AWAVES first map
@@ -69,10 +71,14 @@ struct Cfg {
   static constexpr int LDS_FLOATS = cmax(2 * CHUNK, OROWS * XS);
   static constexpr int LO_MAX = (NB >= 3) ? 2 : 0;    // specialised N-tile ranges [lo, hi], lo <= LO_MAX, hi >= HI_MIN
   static constexpr int HI_MIN = (NB >= 3) ? NB - 3 : NB - 1;
+  static_assert(kKC == 16, "one ds_read_b128 = the 4 k-steps of a 16-channel chunk");
   static_assert(kWaves % S2 == 0, "waves must split evenly over x parities");
   static_assert(kThreads % SPANPX == 0, "store phase mapping");
   static_assert(BWAVES + AWAVES <= kWaves, "staging does not fit the workgroup");
 };
+
+int g_corr_ablation = 0;   // FN2_ABLATION builds only (profiling)
+unsigned long long* g_corr_dbg = nullptr;   // FN2_ABLATION builds: per-workgroup {start, loop end, end, hw id} trace
 
 struct MfmaArgs {
   int N, C, H, W;
@@ -96,9 +102,9 @@ __host__ __device__ inline void live_range(int I, int Hc, int& alo, int& ahi) {
 
 // One channel pass of a workgroup: stage 16-channel chunks of the 4 + 4 image rows through LDS
 // (double buffered, register staged) and run the MFMAs of N tiles [LO, HI] of this wave.
-template <int S2, int R, int LO, int HI, typename Acc>
+template <int S2, int R, int LO, int HI, int ABL, typename Acc>
 __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
-                                       int tid, int lane, int wave, int px, int Jw, int py, int i0, int i2_0, int jS) {
+                                       int tid, int lane, int wave, int px, int Jw, int py, int i0, int i2_0, int jS, unsigned long long (&ph)[4]) {
   using K = Cfg<S2, R>;
   const int plane = g.H * g.W;
   // ---- staging plan: a thread owns ONE pixel position of the 4 + 4 rows and walks the 16 channels
@@ -113,61 +119,73 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
     if (row < 4) {
       const int ib = i2_0 + row, yb = S2 * ib + py, xb = S2 * (jS - R) + col;
       if (ib >= 0 && yb < g.H && xb >= 0 && xb < g.W) voff = 4u * (unsigned)(yb * g.W + xb);
-      laddr = row * K::BRS + (col % S2) * (kKC * K::BCS) + col / S2;
+      laddr = row * K::BRS + (col % S2) * K::BPL + (col / S2) * kKC;
     }
   } else {
     const int row = pos / K::SPANPX, col = pos % K::SPANPX;
     if (row < 4) {
       const int ya = S2 * (i0 + row) + py, xa = S2 * jS + col;
       if (ya < g.H && xa < g.W) voff = 4u * (unsigned)(ya * g.W + xa);
-      laddr = K::AOFF + row * K::ARS + (col % S2) * (kKC * K::ACS) + col / S2;
+      laddr = K::AOFF + row * K::ARS + (col % S2) * K::APL + (col / S2) * kKC;
     }
   }
-  const int lcs = isB ? K::BCS : K::ACS;
   const float* src = isB ? b_n : a_n;        // wave-uniform: one descriptor per wave
   const unsigned chunk_bytes = 4u * kKC * (unsigned)plane;
   const unsigned plane_bytes = 4u * (unsigned)plane;
-  float sv[kKC];
+  const bool stager = laddr >= 0 && !(ABL & 2);
+  float sv[kKC];                     // register staging set (one chunk of this thread's pixel position)
+  constexpr int KSTEPS = kKC / 4;
 
+  // Staging pipeline.  Per chunk c:  MFMAs on LDS buffer c%2  ->  wait for the row loads of chunk c+1
+  // (issued one whole chunk earlier) and write them to buffer (c+1)%2  ->  issue the row loads of
+  // chunk c+2  ->  barrier.  The loads are issued AFTER the LDS write on purpose: hipcc's waitcnt
+  // insertion cannot count loads across the loop back-edge and turns any "wait for the older half
+  // of the loads in flight" into s_waitcnt vmcnt(0), which would expose a full memory round trip
+  // per chunk; with nothing younger in flight vmcnt(0) is the correct wait.
   auto load_chunk = [&](int chunk) {
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)chunk * kKC * plane), 0, chunk_bytes, 0x00020000);
-    if (laddr >= 0) {
+    if (stager) {
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)chunk * kKC * plane), 0, chunk_bytes, 0x00020000);
 #pragma unroll
       for (int kc = 0; kc < kKC; ++kc)
         sv[kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, kc * plane_bytes, 0));
     }
   };
   auto store_chunk = [&](float* buf) {
-    if (laddr >= 0) {
+    if constexpr ((ABL & 8) != 0) {      // profiling: keep the loads alive but store stale registers (no vmcnt wait)
+      if (laddr >= 0) {
 #pragma unroll
-      for (int kc = 0; kc < kKC; ++kc) buf[laddr + kc * lcs] = sv[kc];
+        for (int q = 0; q < kKC / 4; ++q) *reinterpret_cast<f32x4*>(buf + laddr + 4 * q) = f32x4{1.f, 2.f, 3.f, (float)laddr};
+      }
+      return;
+    }
+    if (laddr >= 0) {                    // the 16 channels of this thread's position: 4 x ds_write_b128
+#pragma unroll
+      for (int q = 0; q < kKC / 4; ++q)
+        *reinterpret_cast<f32x4*>(buf + laddr + 4 * q) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
     }
   };
 
-  // operand addresses: lane (kk, ni, nj) of the 16x16x4 fragment reads channel 4*ks + kk of the chunk
+  // operand addresses: lane (kk, ni, nj) reads channels 4kk..4kk+3 of position (ni, 4Jw + 4b + nj)
   const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
-  const int aAddr = K::AOFF + ni * K::ARS + px * (kKC * K::ACS) + kk * K::ACS + 4 * Jw + nj;
-  const int bAddr = ni * K::BRS + px * (kKC * K::BCS) + kk * K::BCS + 4 * Jw + nj;
-  constexpr int NT = (LO <= HI) ? HI - LO + 1 : 0;
+  const int aAddr = K::AOFF + ni * K::ARS + px * K::APL + (4 * Jw + nj) * kKC + 4 * kk;
+  const int bAddr = ni * K::BRS + px * K::BPL + (4 * Jw + nj) * kKC + 4 * kk;
+  constexpr int NT = (LO <= HI && !(ABL & 1)) ? HI - LO + 1 : 0;
+
+  // One chunk = 1 + NT ds_read_b128 and 4 * NT MFMAs per wave.  All reads are issued first; the MFMAs
+  // walk k-step-major / tile-minor so that consecutive MFMAs hit different accumulators (a dependent
+  // 16x16x4 pair would stall 8 cycles) and each only waits for the operands it needs.
   auto compute = [&](const float* buf) {
     if constexpr (NT > 0) {
-      // explicit operand double buffering: the reads of k-step ks+1 are issued before the MFMAs of ks
-      float av[2], bv[2][NT];
-      av[0] = buf[aAddr];
+      const f32x4 av = *reinterpret_cast<const f32x4*>(buf + aAddr);
+      f32x4 bv[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[0][t] = buf[bAddr + 4 * (LO + t)];
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(buf + bAddr + 4 * (LO + t) * kKC);
 #pragma unroll
-      for (int ks = 0; ks < kKC / 4; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < kKC / 4) {
-          av[nxt] = buf[aAddr + 4 * (ks + 1) * K::ACS];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) bv[nxt][t] = buf[bAddr + 4 * (ks + 1) * K::BCS + 4 * (LO + t)];
-        }
+      for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          acc[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], bv[cur][t], acc[LO + t], 0, 0, 0);
+          acc[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[t][r], acc[LO + t], 0, 0, 0);
       }
     }
   };
@@ -177,36 +195,66 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
   float* buf1 = smem + K::CHUNK;
   load_chunk(0);
   store_chunk(buf0);
+  if (nchunks > 1) load_chunk(1);
   __syncthreads();
+#ifdef FN2_ABLATION
+#define FN2_T(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - tprev; tprev = now_; }
+  unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#else
+#define FN2_T(i)
+#endif
   for (int ch = 0; ch < nchunks; ch += 2) {
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
     compute(buf0);
+    FN2_T(0)
     if (ch + 1 < nchunks) store_chunk(buf1);
+    FN2_T(1)
+    if (ch + 2 < nchunks) load_chunk(ch + 2);
+    FN2_T(2)
     __syncthreads();
+    FN2_T(3)
     if (ch + 1 < nchunks) {
-      if (ch + 2 < nchunks) load_chunk(ch + 2);
       compute(buf1);
+      FN2_T(0)
       if (ch + 2 < nchunks) store_chunk(buf0);
+      FN2_T(1)
+      if (ch + 3 < nchunks) load_chunk(ch + 3);
+      FN2_T(2)
       __syncthreads();
+      FN2_T(3)
     }
+  }
+#undef FN2_T
+  if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+    for (int kc = 0; kc < kKC; ++kc) asm volatile("" ::"v"(sv[kc]));
   }
 }
 
-template <int S2, int R>
+template <int S2, int R, int ABL>
 __global__ void __launch_bounds__(kThreads, 6)
-corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g) {
+corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
+              unsigned long long* __restrict__ dbg) {
   using K = Cfg<S2, R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
+#ifdef FN2_ABLATION
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   // ---- task decode; blocks b, b+8, b+16.. run on one XCD, give them one contiguous task range ----
   const int L = (int)(blockIdx.x % 8) * g.GP + (int)(blockIdx.x / 8);
   if (L >= g.G) return;
   const int n = L / g.TS;
   int t = L % g.TS;
-  const bool heavy = t < g.TH;
-  if (!heavy) t -= g.TH;
-  const int span = t % g.NSPAN;
-  t /= g.NSPAN;
+  // Per sample: the light tasks (zero fill only) come FIRST -- their stores go out while the chip is
+  // otherwise still loading, instead of joining the store burst at the end -- then the heavy tasks
+  // with the x span as the slowest index, so that the three workgroups that land on one CU
+  // (tasks c, c+32, c+64 of an XCD) mix full and ragged spans.
+  const int TL = g.TS - g.TH;
+  const bool heavy = t >= TL;
+  if (heavy) t -= TL;
+  const int per_span = (heavy ? g.TH : TL) / g.NSPAN;
+  const int span = t / per_span;
+  t %= per_span;
   // t-th heavy (or light) (py, I, a) combination, py-major / I / a order; <= S2 * NI scalar iterations
   int py = 0, I = 0, a = 0;
   for (int c = 0; c < S2 * g.NI; ++c) {
@@ -243,6 +291,7 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #pragma unroll
   for (int b = 0; b < K::NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  unsigned long long ph[4] = {0, 0, 0, 0};
   if (heavy) {
     // N tiles of this wave that can be non-zero (x direction), widened to one of the 3 x 3 specialised
     // ranges (an extra tile only multiplies staged zeros).  Straight-line MFMA bodies matter: a branch
@@ -258,7 +307,7 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
     int sel = 9;
     if (hi >= lo) sel = min(lo, K::LO_MAX) * 3 + (max(hi, K::HI_MIN) - K::HI_MIN);
     sel = __builtin_amdgcn_readfirstlane(sel);
-#define FN2_KLOOP(LO_, HI_) k_loop<S2, R, LO_, HI_>(acc, smem, a_n, b_n, g, tid, lane, wave, px, Jw, py, i0, i2_0, jS)
+#define FN2_KLOOP(LO_, HI_) k_loop<S2, R, LO_, HI_, ABL>(acc, smem, a_n, b_n, g, tid, lane, wave, px, Jw, py, i0, i2_0, jS, ph)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
       case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
@@ -274,6 +323,9 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #undef FN2_KLOOP
   }
 
+#ifdef FN2_ABLATION
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: accumulators -> LDS image [mi][ni][o][x] -> coalesced rows of top ----
   const float sumelems = (float)g.C;      // kernel_size^2 * channels, correlation_layer.cu:108
   const bool pow2 = (g.C & (g.C - 1)) == 0;   // x / 2^k == x * 2^-k exactly; otherwise keep the true division
@@ -292,7 +344,7 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const int xl = tid % K::SPANPX;
   const int x = S2 * jS + xl;
   const size_t top_n = (size_t)n * K::D * K::D;
-  if (x < g.W) {
+  if (x < g.W && !(ABL & 4)) {
     for (int rowid = tid / K::SPANPX; rowid < K::OROWS; rowid += kThreads / K::SPANPX) {
       const int rmi = rowid / (4 * K::D), rni = (rowid / K::D) % 4, oo = rowid % K::D;
       const int qq = 4 * a + rni - rmi;   // q + R
@@ -301,6 +353,21 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
         top[((top_n + (size_t)qq * K::D + oo) * g.H + y) * g.W + x] = smem[rowid * K::XS + xl];
     }
   }
+#ifdef FN2_ABLATION
+  if (dbg && threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[4 * blockIdx.x + 0] = t_start;
+    dbg[4 * blockIdx.x + 1] = t_loop;
+    dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid | ((unsigned long long)(heavy ? 1 : 0) << 63);
+  }
+  if (dbg && lane == 0) {     // per-wave phase sums: [compute, store(+vmcnt wait), load issue, barrier]
+    unsigned long long* o = dbg + 4 * 1024 + (size_t)(blockIdx.x * kWaves + wave) * 4;
+    o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
+  }
+#endif
 }
 
 template <int S2, int R>
@@ -327,10 +394,25 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   const size_t lds = sizeof(float) * K::LDS_FLOATS;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_mfma<S2, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_mfma<S2, R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((corr_fwd_mfma<S2, R>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g);
+#ifdef FN2_ABLATION
+  // profiling-only builds: bit 0 = no MFMA, bit 1 = no staging loads, bit 2 = no output stores
+  if (S2 == 2 && R == 10 && g_corr_ablation) {
+    switch (g_corr_ablation) {
+      case 1: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 1>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 2: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 2>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 3: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 3>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 4: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 4>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 8: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 8>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 6: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 6>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      default: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 7>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+    }
+    return check_launch("correlation_forward (mfma, ablation)");
+  }
+#endif
+  hipLaunchKernelGGL((corr_fwd_mfma<S2, R, 0>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg);
   return check_launch("correlation_forward (mfma)");
 }
 

@@ -15,6 +15,7 @@ ap.add_argument("--shape", default="8,256,40,56")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--generic", action="store_true")
 ap.add_argument("--backward", action="store_true")
+ap.add_argument("--ablation", type=int, default=0, help="FN2_ABLATION builds: 1 no MFMA, 2 no loads, 4 no stores (bit-or)")
 a = ap.parse_args()
 N, C, H, W = map(int, a.shape.split(","))
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -23,6 +24,9 @@ y = torch.randn(N, C, H, W, device="cuda", generator=g)
 p = ops.corr_params(20, 1, 20, 1, 2)
 out = torch.empty(N, 441, H, W, device="cuda")
 ops.set_correlation_impl(a.generic)
+if a.ablation:
+    from flownet2_amd import _lib
+    _lib.lib().fn2_debug_set_correlation_impl(16 + a.ablation)
 for _ in range(5):
     ops.correlation_forward(p, x, y, out=out)
 torch.cuda.synchronize()

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""FN2_ABLATION builds only: per-workgroup timeline of corr_fwd_mfma (start / K-loop end / end, CU id)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flownet2_amd import ops, _lib
+N, Cc, H, W = 8, 256, 40, 56
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(N, Cc, H, W, device="cuda", generator=g); y = torch.randn(N, Cc, H, W, device="cuda", generator=g)
+p = ops.corr_params(20, 1, 20, 1, 2)
+out = torch.empty(N, 441, H, W, device="cuda")
+for _ in range(3): ops.correlation_forward(p, x, y, out=out)
+dbg = torch.zeros(4 * 1024 + 4 * 8 * 1024, dtype=torch.int64, device="cuda")
+L = _lib.lib(); L.fn2_debug_set_correlation_trace.argtypes = [C.c_void_p]
+L.fn2_debug_set_correlation_trace(C.c_void_p(dbg.data_ptr()))
+ops.correlation_forward(p, x, y, out=out); torch.cuda.synchronize()
+L.fn2_debug_set_correlation_trace(None)
+raw = dbg.cpu().numpy()
+d = raw[:4 * 1024].reshape(-1, 4)
+phases = raw[4 * 1024:].reshape(1024, 8, 4)
+bidx = np.nonzero(d[:, 0] != 0)[0]
+d = d[d[:, 0] != 0]
+hw = d[:, 3] & 0xffffffff; xcc = (d[:, 3] >> 32) & 0xf; heavy = (d[:, 3] >> 63) & 1
+t0 = np.zeros(len(d), dtype=np.int64)
+cu_ = (hw >> 8) & 0xf; sh_ = (hw >> 12) & 1; se_ = (hw >> 13) & 0x7
+grp = (bidx % 8) * 1000 + se_ * 100 + sh_ * 10 + cu_       # one clock domain per CU is the safe assumption
+for k in set(grp.tolist()):
+    t0[grp == k] = d[grp == k, 0].min()
+start, loop, end = (d[:, 0] - t0), (d[:, 1] - t0), (d[:, 2] - t0)
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+key = grp
+print("blocks", len(d), "heavy", int(heavy.sum()), "distinct CUs", len(set(key.tolist())))
+print("span of kernel (max over XCDs)", int(end.max()), "shader cycles")
+for name, arr in [("start", start), ("loop_end", loop), ("end", end)]:
+    print(name, "heavy: min/med/max", int(arr[heavy == 1].min()), int(np.median(arr[heavy == 1])), int(arr[heavy == 1].max()),
+          " light:", int(arr[heavy == 0].min()), int(np.median(arr[heavy == 0])), int(arr[heavy == 0].max()))
+dur = end - start
+print("duration heavy med", int(np.median(dur[heavy == 1])), "light med", int(np.median(dur[heavy == 0])))
+# concurrency per CU at the median time
+from collections import Counter
+c = Counter(key[heavy == 1].tolist())
+print("heavy blocks per CU histogram:", sorted(Counter(c.values()).items()))
+tm = np.median(loop[heavy == 1]) * 0.5
+alive = (start <= tm) & (end >= tm)
+print("blocks alive at t=%d: %d (heavy %d)" % (tm, alive.sum(), (alive & (heavy == 1)).sum()))
+ca = Counter(key[alive].tolist()); print("alive per CU histogram:", sorted(Counter(ca.values()).items()))
+
+for q in (0.25, 0.5, 0.75):
+    tm = end.max() * q
+    alive = (start <= tm) & (end >= tm)
+    ca = Counter(key[alive].tolist())
+    print("t=%d: alive %d (heavy %d); per-CU histogram %s" % (tm, alive.sum(), (alive & (heavy == 1)).sum(), sorted(Counter(ca.values()).items())))
+print("light blocks start: min/med/max", int(start[heavy == 0].min()), int(np.median(start[heavy == 0])), int(start[heavy == 0].max()))
+print("heavy: loop phase med", int(np.median((loop - start)[heavy == 1])), " epilogue med", int(np.median((end - loop)[heavy == 1])))
+print("light: epilogue med", int(np.median((end - loop)[heavy == 0])))
+
+hb = bidx[heavy == 1]
+P = phases[hb]                      # [heavy blocks, waves, 4]
+print("per-wave phase sums over 16 chunks (cycles), median over heavy blocks:")
+for w in range(8):
+    print("  wave", w, "compute %d  store+wait %d  load-issue %d  barrier %d" % tuple(np.median(P[:, w, :], axis=0).astype(int)))
