@@ -1,0 +1,83 @@
+// Stand-in for include/caffe/blob.hpp + syncedmem.hpp: NCHW fp32 tensor with data and diff, lazily mirrored
+// between host and device (the head-state machine of syncedmem.cpp:25-77, reduced to what layers use).
+#pragma once
+#include "caffe/common.hpp"
+
+namespace caffe {
+
+class SyncedMemory {
+ public:
+  explicit SyncedMemory(size_t size) : size_(size) {}
+  ~SyncedMemory() { if (cpu_) std::free(cpu_); if (gpu_) (void)hipFree(gpu_); }
+  const void* cpu_data() { to_cpu(); return cpu_; }
+  const void* gpu_data() { to_gpu(); return gpu_; }
+  void* mutable_cpu_data() { to_cpu(); head_ = HEAD_AT_CPU; return cpu_; }
+  void* mutable_gpu_data() { to_gpu(); head_ = HEAD_AT_GPU; return gpu_; }
+  size_t size() const { return size_; }
+ private:
+  enum Head { UNINITIALIZED, HEAD_AT_CPU, HEAD_AT_GPU, SYNCED };
+  void to_cpu() {
+    if (!cpu_) { cpu_ = std::calloc(size_ ? size_ : 1, 1); }
+    if (head_ == HEAD_AT_GPU) { CUDA_CHECK(hipMemcpy(cpu_, gpu_, size_, hipMemcpyDeviceToHost)); head_ = SYNCED; }
+    if (head_ == UNINITIALIZED) head_ = HEAD_AT_CPU;
+  }
+  void to_gpu() {
+    if (!gpu_) { CUDA_CHECK(hipMalloc(&gpu_, size_ ? size_ : 1)); CUDA_CHECK(hipMemset(gpu_, 0, size_ ? size_ : 1)); }
+    if (head_ == HEAD_AT_CPU) { CUDA_CHECK(hipMemcpy(gpu_, cpu_, size_, hipMemcpyHostToDevice)); head_ = SYNCED; }
+    if (head_ == UNINITIALIZED) head_ = HEAD_AT_GPU;
+  }
+  void* cpu_ = nullptr;
+  void* gpu_ = nullptr;
+  size_t size_;
+  Head head_ = UNINITIALIZED;
+};
+
+template <typename Dtype>
+class Blob {
+ public:
+  Blob() {}
+  Blob(int num, int channels, int height, int width) { Reshape(num, channels, height, width); }
+  explicit Blob(const vector<int>& shape) { Reshape(shape); }
+  void Reshape(int num, int channels, int height, int width) { Reshape(vector<int>{num, channels, height, width}); }
+  void Reshape(const vector<int>& shape) {
+    size_t c = 1;
+    for (int s : shape) { CHECK_GE(s, 0); c *= (size_t)s; }
+    shape_ = shape;
+    count_ = (int)c;
+    if (c > capacity_) {                      // blob.cpp:36-40: reallocate only when growing
+      capacity_ = c;
+      data_.reset(new SyncedMemory(capacity_ * sizeof(Dtype)));
+      diff_.reset(new SyncedMemory(capacity_ * sizeof(Dtype)));
+    }
+  }
+  void ReshapeLike(const Blob& o) { Reshape(o.shape()); }
+  const vector<int>& shape() const { return shape_; }
+  int shape(int i) const { return shape_[i < 0 ? i + (int)shape_.size() : i]; }
+  int num_axes() const { return (int)shape_.size(); }
+  int count() const { return count_; }
+  int LegacyShape(int i) const { CHECK_LE(num_axes(), 4); return i < num_axes() ? shape_[i] : 1; }
+  int num() const { return LegacyShape(0); }
+  int channels() const { return LegacyShape(1); }
+  int height() const { return LegacyShape(2); }
+  int width() const { return LegacyShape(3); }
+  int offset(int n, int c = 0, int h = 0, int w = 0) const { return ((n * channels() + c) * height() + h) * width() + w; }
+  const Dtype* cpu_data() const { CHECK(data_); return (const Dtype*)data_->cpu_data(); }
+  const Dtype* gpu_data() const { CHECK(data_); return (const Dtype*)data_->gpu_data(); }
+  const Dtype* cpu_diff() const { CHECK(diff_); return (const Dtype*)diff_->cpu_data(); }
+  const Dtype* gpu_diff() const { CHECK(diff_); return (const Dtype*)diff_->gpu_data(); }
+  Dtype* mutable_cpu_data() { CHECK(data_); return (Dtype*)data_->mutable_cpu_data(); }
+  Dtype* mutable_gpu_data() { CHECK(data_); return (Dtype*)data_->mutable_gpu_data(); }
+  Dtype* mutable_cpu_diff() { CHECK(diff_); return (Dtype*)diff_->mutable_cpu_data(); }
+  Dtype* mutable_gpu_diff() { CHECK(diff_); return (Dtype*)diff_->mutable_gpu_data(); }
+  Dtype data_at(int n, int c, int h, int w) const { return cpu_data()[offset(n, c, h, w)]; }
+  Dtype diff_at(int n, int c, int h, int w) const { return cpu_diff()[offset(n, c, h, w)]; }
+  void ShareData(const Blob& other) { CHECK_EQ(count_, other.count()); data_ = other.data_; }
+  void ShareDiff(const Blob& other) { CHECK_EQ(count_, other.count()); diff_ = other.diff_; }
+ protected:
+  shared_ptr<SyncedMemory> data_, diff_;
+  vector<int> shape_;
+  int count_ = 0;
+  size_t capacity_ = 0;
+};
+
+}  // namespace caffe

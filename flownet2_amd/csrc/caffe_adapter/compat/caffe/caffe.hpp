@@ -1,0 +1,6 @@
+// Stand-in (nothing from this header is used by the hot-path layers).
+#pragma once
+#include "caffe/common.hpp"
+#include "caffe/blob.hpp"
+#include "caffe/layer.hpp"
+#include "caffe/layer_factory.hpp"

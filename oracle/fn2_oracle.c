@@ -12,9 +12,10 @@
  * by line in plain C.  Two pins exist (see oracle/README.md):
  *   (1) oracle/_ref: the reference's OWN .cu/.cpp sources for Correlation, FlowWarp, Resample,
  *       ChannelNorm and Downsample compiled in place with hipcc against stand-in caffe headers
- *       (oracle/stubs/) and run on the GPU box; tests/golden/ holds vectors it produced.
- *   (2) an independent fp64 numpy re-derivation + numeric gradient checks (tests/).
- * L1Loss is composed from stock Caffe sub-layers in the reference and has no such pin:
+ *       and run on an MI355X; tests/golden/ref_golden.npz holds the outputs they produced and
+ *       tests/test_golden.py checks every function below against them (PINNED for these five).
+ *   (2) an independent fp64 re-derivation + autograd gradient checks (tests/test_oracle.py).
+ * L1Loss is composed from stock Caffe sub-layers in the reference and has only pin (2):
  * "parity unpinned" for L1Loss.
  *
  * All file:line citations are relative to the reference tree.

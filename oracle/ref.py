@@ -1,0 +1,98 @@
+"""ctypes front-end of oracle/_ref/libfn2_ref.so: the REFERENCE's own layer classes (correlation, flow-warp,
+resample, channel-norm, downsample), compiled in place from /root/reference as HIP by oracle/ref_build.sh.
+TEST INFRASTRUCTURE ONLY.  GPU modes need an MI355X; the CPU modes (FlowWarp, ChannelNorm) run anywhere."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_ref", "libfn2_ref.so")
+_lib = None
+
+
+def available() -> bool:
+    return os.path.exists(SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(SO)
+        _lib.fn2ref_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError("reference layer failed: " + lib().fn2ref_last_error().decode())
+
+
+def correlation(b0, b1, pad, kernel_size, max_displacement, stride1, stride2, corr_type=0, top_diff=None):
+    b0, b1 = _f(b0), _f(b1)
+    N, Cc, H, W = b0.shape
+    shape = (C.c_int * 4)()
+    # first call for the shape only (top_out NULL)
+    _chk(lib().fn2ref_correlation(pad, kernel_size, max_displacement, stride1, stride2, corr_type, _p(b0), _p(b1), N, Cc, H, W,
+                                  None, shape, None, None, None))
+    top = np.empty(tuple(shape), np.float32)
+    if top_diff is None:
+        _chk(lib().fn2ref_correlation(pad, kernel_size, max_displacement, stride1, stride2, corr_type, _p(b0), _p(b1), N, Cc, H, W,
+                                      _p(top), shape, None, None, None))
+        return top
+    td = _f(top_diff)
+    d0, d1 = np.empty_like(b0), np.empty_like(b1)
+    _chk(lib().fn2ref_correlation(pad, kernel_size, max_displacement, stride1, stride2, corr_type, _p(b0), _p(b1), N, Cc, H, W,
+                                  _p(top), shape, _p(td), _p(d0), _p(d1)))
+    return top, d0, d1
+
+
+def flow_warp(image, flow, fill_value=1, warped_diff=None, cpu=False):
+    image, flow = _f(image), _f(flow)
+    N, Cc, H, W = image.shape
+    out = np.empty_like(image)
+    if warped_diff is None:
+        _chk(lib().fn2ref_flow_warp(int(cpu), fill_value, _p(image), _p(flow), N, Cc, H, W, _p(out), None, None, None))
+        return out
+    wd = _f(warped_diff)
+    di, df = np.empty_like(image), np.empty_like(flow)
+    _chk(lib().fn2ref_flow_warp(int(cpu), fill_value, _p(image), _p(flow), N, Cc, H, W, _p(out), _p(wd), _p(di), _p(df)))
+    return out, di, df
+
+
+def resample(x, Hout, Wout, type=2, antialias=True):
+    x = _f(x)
+    N, Cc, H, W = x.shape
+    out = np.empty((N, Cc, Hout, Wout), np.float32)
+    _chk(lib().fn2ref_resample(type, int(antialias), _p(x), N, Cc, H, W, Hout, Wout, _p(out)))
+    return out
+
+
+def channel_norm(x, top_diff=None, cpu=False):
+    x = _f(x)
+    N, Cc, H, W = x.shape
+    out = np.empty((N, 1, H, W), np.float32)
+    if top_diff is None:
+        _chk(lib().fn2ref_channel_norm(int(cpu), _p(x), N, Cc, H, W, _p(out), None, None))
+        return out
+    d = np.empty_like(x)
+    _chk(lib().fn2ref_channel_norm(1, _p(x), N, Cc, H, W, _p(out), _p(_f(top_diff)), _p(d)))
+    return out, d
+
+
+def downsample(x, Hout, Wout):
+    x = _f(x)
+    N, Cc, H, W = x.shape
+    out = np.empty((N, Cc, Hout, Wout), np.float32)
+    _chk(lib().fn2ref_downsample(_p(x), N, Cc, H, W, Hout, Wout, _p(out)))
+    return out

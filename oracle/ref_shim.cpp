@@ -1,0 +1,147 @@
+// C API over the REFERENCE's own layer classes (compiled in place from /root/reference by oracle/ref_build.sh
+// against the stand-in Caffe headers).  TEST INFRASTRUCTURE: the resulting oracle/_ref/libfn2_ref.so runs the
+// reference's CUDA kernels -- built as HIP, unchanged -- on the MI355X, and pins the C oracle (tests/test_ref_pin.py).
+// All pointers are HOST pointers; layers are created through the reference's LayerRegistry by their type string.
+#include <cstring>
+
+#include "caffe/blob.hpp"
+#include "caffe/layer.hpp"
+#include "caffe/layer_factory.hpp"
+
+using namespace caffe;
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guard(F&& body) {
+  try { body(); return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+extern "C" __attribute__((visibility("default"))) const char* fn2ref_last_error() { return g_err.c_str(); }
+
+static void fill(Blob<float>& b, const float* src) { std::memcpy(b.mutable_cpu_data(), src, sizeof(float) * b.count()); }
+static void fill_diff(Blob<float>& b, const float* src) { std::memcpy(b.mutable_cpu_diff(), src, sizeof(float) * b.count()); }
+static void fetch(const Blob<float>& b, float* dst) { std::memcpy(dst, b.cpu_data(), sizeof(float) * b.count()); }
+static void fetch_diff(const Blob<float>& b, float* dst) { std::memcpy(dst, b.cpu_diff(), sizeof(float) * b.count()); }
+
+extern "C" __attribute__((visibility("default")))
+int fn2ref_correlation(int pad, int kernel_size, int max_displacement, int stride1, int stride2, int corr_type,
+                       const float* b0, const float* b1, int N, int C, int H, int W,
+                       float* top_out, int* top_shape /* [4] */,
+                       const float* top_diff /* nullable */, float* b0_diff, float* b1_diff) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("Correlation");
+    CorrelationParameter* cp = lp.mutable_correlation_param();
+    cp->set_pad(pad); cp->set_kernel_size(kernel_size); cp->set_max_displacement(max_displacement);
+    cp->set_stride_1(stride1); cp->set_stride_2(stride2);
+    cp->set_correlation_type(corr_type ? CorrelationParameter_CorrelationType_SUBTRACT : CorrelationParameter_CorrelationType_MULTIPLY);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot0(N, C, H, W), bot1(N, C, H, W), top;
+    fill(bot0, b0); fill(bot1, b1);
+    vector<Blob<float>*> bottom{&bot0, &bot1}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 4; ++i) top_shape[i] = top.shape(i);
+    if (top_out) fetch(top, top_out);
+    if (top_diff) {
+      fill_diff(top, top_diff);
+      layer->Backward(tops, vector<bool>{true, true}, bottom);
+      if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+      fetch_diff(bot0, b0_diff); fetch_diff(bot1, b1_diff);
+    }
+  });
+}
+
+// mode: 0 = GPU kernels (flow_warp_layer.cu), 1 = the reference's CPU implementation (flow_warp_layer.cpp:58-199)
+extern "C" __attribute__((visibility("default")))
+int fn2ref_flow_warp(int mode, int fill_value, const float* image, const float* flow, int N, int C, int H, int W,
+                     float* warped, const float* warped_diff /* nullable */, float* image_diff, float* flow_diff) {
+  return guard([&] {
+    Caffe::set_mode(mode ? Caffe::CPU : Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("FlowWarp");
+    lp.mutable_flow_warp_param()->set_fill_value(fill_value == 2 ? FlowWarpParameter_FillParameter_NOT_A_NUMBER : FlowWarpParameter_FillParameter_ZERO);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> img(N, C, H, W), fl(N, 2, H, W), top;
+    fill(img, image); fill(fl, flow);
+    vector<Blob<float>*> bottom{&img, &fl}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+    fetch(top, warped);
+    if (warped_diff) {
+      fill_diff(top, warped_diff);
+      layer->Backward(tops, vector<bool>{true, true}, bottom);
+      if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+      fetch_diff(img, image_diff); fetch_diff(fl, flow_diff);
+    }
+    Caffe::set_mode(Caffe::GPU);
+  });
+}
+
+extern "C" __attribute__((visibility("default")))
+int fn2ref_resample(int type, int antialias, const float* in, int N, int C, int Hin, int Win, int Hout, int Wout, float* out) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("Resample");
+    ResampleParameter* rp = lp.mutable_resample_param();
+    rp->set_type((ResampleParameter_ResampleType)type); rp->set_antialias(antialias != 0); rp->set_width(Wout); rp->set_height(Hout);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot(N, C, Hin, Win), top;
+    fill(bot, in);
+    vector<Blob<float>*> bottom{&bot}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+    fetch(top, out);
+  });
+}
+
+// mode: 0 = GPU forward (channel_norm_layer.cu), 1 = the reference's CPU forward + backward (channel_norm_layer.cpp:43-124).
+// The reference's GPU backward passes host pointers to its kernel (channel_norm_layer.cu:80-83) and is not run.
+extern "C" __attribute__((visibility("default")))
+int fn2ref_channel_norm(int mode, const float* in, int N, int C, int H, int W, float* out,
+                        const float* top_diff /* nullable, CPU mode only */, float* bottom_diff) {
+  return guard([&] {
+    Caffe::set_mode(mode ? Caffe::CPU : Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("ChannelNorm");
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot(N, C, H, W), top;
+    fill(bot, in);
+    vector<Blob<float>*> bottom{&bot}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+    fetch(top, out);
+    if (top_diff && mode) {
+      fill_diff(top, top_diff);
+      layer->Backward(tops, vector<bool>{true}, bottom);
+      fetch_diff(bot, bottom_diff);
+    }
+    Caffe::set_mode(Caffe::GPU);
+  });
+}
+
+extern "C" __attribute__((visibility("default")))
+int fn2ref_downsample(const float* in, int N, int C, int Hin, int Win, int Hout, int Wout, float* out) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("Downsample");
+    lp.mutable_downsample_param()->set_top_height(Hout); lp.mutable_downsample_param()->set_top_width(Wout);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot(N, C, Hin, Win), top;
+    fill(bot, in);
+    vector<Blob<float>*> bottom{&bot}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    if (Caffe::mode() == Caffe::GPU) CUDA_CHECK(hipDeviceSynchronize());
+    fetch(top, out);
+  });
+}

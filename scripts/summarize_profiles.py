@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""gpurun_out/<tag>/ (rocprofv3 CSVs from scripts/profile_round.sh) -> profiles/<tag>_*.{md,json}."""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = os.path.join(ROOT, "gpurun_out", tag)
+OUT = os.path.join(ROOT, "profiles")
+os.makedirs(OUT, exist_ok=True)
+
+
+def kernel_stats(path):
+    return list(csv.DictReader(open(path)))
+
+
+def counters(path, match):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if match in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def short(name, n=100):
+    return name if len(name) <= n else name[: n - 3] + "..."
+
+
+lines = [f"# rocprofv3 summary, round tag {tag}", "",
+         "Source: `bash scripts/profile_round.sh %s` on one MI355X (gfx950), ROCm 7.2; raw CSVs stay in gpurun_out/ (scratch)." % tag, ""]
+
+# --- correlation micro-benchmark: kernel trace
+ks = kernel_stats(os.path.join(R, "corr", "corr_kernel_stats.csv"))
+lines += ["## `rocprofv3 --kernel-trace --stats -- python scripts/corr_microbench.py --iters 200 --backward`", "",
+          "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+corr_avg_us = None
+for r in ks[:6]:
+    lines.append("| `%s` | %s | %.2f | %.2f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                              float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    if "corr_fwd_mfma" in r["Name"]:
+        corr_avg_us = float(r["AverageNs"]) / 1e3
+lines += ["", "stdout of the same run:", "```", open(os.path.join(R, "corr_stdout.txt")).read().strip(), "```", ""]
+
+# --- HBM counters + calibration
+cal_txt = open(os.path.join(R, "cal_stdout.txt")).read().strip().splitlines()
+known = {}
+for l in cal_txt:
+    p = l.split()
+    known[p[0]] = (int(p[2]), int(p[4]))
+cf = {k: counters(os.path.join(R, "cal_fetch", "cal_counter_collection.csv"), k) for k in ("channel_norm_fwd", "flow_warp_fwd")}
+cw = {k: counters(os.path.join(R, "cal_write", "cal_counter_collection.csv"), k) for k in ("channel_norm_fwd", "flow_warp_fwd")}
+fetch_factor = known["channel_norm_fwd"][0] / (cf["channel_norm_fwd"]["FETCH_SIZE"] * 1024.0)
+write_factor = known["flow_warp_fwd"][1] / (cw["flow_warp_fwd"]["WRITE_SIZE"] * 1024.0)
+f = counters(os.path.join(R, "pmc_fetch", "corr_counter_collection.csv"), "corr_fwd_mfma")
+w = counters(os.path.join(R, "pmc_write", "corr_counter_collection.csv"), "corr_fwd_mfma")
+sq = counters(os.path.join(R, "pmc_sq", "corr_counter_collection.csv"), "corr_fwd_mfma")
+fetch_bytes = f["FETCH_SIZE"] * 1024.0 * fetch_factor
+write_bytes = w["WRITE_SIZE"] * 1024.0 * write_factor
+alg = 4.0 * 8 * 40 * 56 * (2 * 256 + 441)
+lines += ["## HBM traffic of `corr_fwd_mfma<2,10>` at [8,256,40,56] (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
+          "Calibration (MI355X_MICROARCH.md, HBM section: FETCH_SIZE/WRITE_SIZE are in KiB and FETCH_SIZE under-reports on gfx950;",
+          "calibrate on a known byte count in the same access width): `scripts/hbm_calibrate.py`", "",
+          "| kernel | known read B | FETCH_SIZE KiB | bytes / (FETCH_SIZE*1024) | known write B | WRITE_SIZE KiB | bytes / (WRITE_SIZE*1024) |", "|---|---|---|---|---|---|---|"]
+for k in ("channel_norm_fwd", "flow_warp_fwd"):
+    lines.append("| %s | %d | %.0f | %.3f | %d | %.0f | %.3f |" % (k, known[k][0], cf[k]["FETCH_SIZE"], known[k][0] / (cf[k]["FETCH_SIZE"] * 1024),
+                                                                   known[k][1], cw[k]["WRITE_SIZE"], known[k][1] / (cw[k]["WRITE_SIZE"] * 1024)))
+lines += ["", "| quantity | value |", "|---|---|",
+          "| FETCH_SIZE (KiB, avg per dispatch) | %.0f |" % f["FETCH_SIZE"],
+          "| WRITE_SIZE (KiB, avg per dispatch) | %.0f |" % w["WRITE_SIZE"],
+          "| read correction factor (4 B/lane coalesced, from channel_norm_fwd) | %.3f |" % fetch_factor,
+          "| write correction factor (from flow_warp_fwd) | %.3f |" % write_factor,
+          "| corrected HBM read bytes / launch | %.2f MB |" % (fetch_bytes / 1e6),
+          "| corrected HBM write bytes / launch | %.2f MB |" % (write_bytes / 1e6),
+          "| **traffic / launch** | **%.2f MB** |" % ((fetch_bytes + write_bytes) / 1e6),
+          "| algorithmic bytes / launch 4*N*H*W*(2C+441) | %.2f MB |" % (alg / 1e6),
+          "| traffic / algorithmic | %.3f |" % ((fetch_bytes + write_bytes) / alg), ""]
+gui = sq.get("GRBM_GUI_ACTIVE", 0) / 8.0
+lines += ["## SQ counters of the same kernel (`--pmc` pass of their own)", "", "| counter | avg per dispatch |", "|---|---|"]
+for k in sorted(sq):
+    lines.append("| %s | %.0f |" % (k, sq[k]))
+if gui:
+    util = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui)
+    lines += ["", "GRBM_GUI_ACTIVE / 8 XCDs = %.0f cycles per launch; matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = **%.1f %%**."
+              % (gui, 100 * util),
+              "MFMA instructions issued: %.0f x 2048 flop = %.2f GFLOP (algorithmic 2*C*441*N*H*W = 4.05 GFLOP counts the products against the zero padding, which the kernel skips)."
+              % (sq["SQ_INSTS_MFMA"], sq["SQ_INSTS_MFMA"] * 2048 / 1e9), ""]
+
+# --- bench kernel table (steady state, find-db warmed)
+ks = kernel_stats(os.path.join(R, "bench", "bench_kernel_stats.csv"))
+lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5` (FlowNetC forward, batch 8 @448x320)", "",
+          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+for r in ks[:28]:
+    lines.append("| `%s` | %s | %.2f | %.2f | %s |" % (short(r["Name"], 90), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+lines += ["", "bench line of the unprofiled run in the same session:", "```", open(os.path.join(R, "bench.json")).read().strip(), "```", ""]
+open(os.path.join(OUT, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
+
+summary = {"tag": tag, "kernel": "corr_fwd_mfma<2,10> [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
+           "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "fetch_correction": fetch_factor,
+           "write_correction": write_factor, "hbm_read_bytes": fetch_bytes, "hbm_write_bytes": write_bytes,
+           "traffic_bytes_per_launch": fetch_bytes + write_bytes, "algorithmic_bytes_per_launch": alg,
+           "mfma_util": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui) if gui else None}
+json.dump(summary, open(os.path.join(OUT, f"{tag}_corr_hbm.json"), "w"), indent=1)
+print(open(os.path.join(OUT, f"{tag}_rocprof_summary.md")).read()[:6000])

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Generates tests/golden/ref_golden.npz: outputs of the REFERENCE's own layer code (oracle/_ref, the
+reference's CUDA kernels built as HIP by oracle/ref_build.sh and executed on an MI355X) on small seeded inputs.
+Run on the GPU box:   python tests/golden/make_golden.py gpurun_out/ref_golden.npz
+then copy the file to tests/golden/.  tests/test_golden.py pins the C oracle (and, on the GPU, the HIP kernels)
+against it; it needs neither the reference tree nor oracle/_ref."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref  # noqa: E402
+
+CORR = [  # (N, C, H, W, pad, K, md, s1, s2, type)
+    (1, 16, 13, 17, 20, 1, 20, 1, 2, 0), (2, 5, 9, 11, 4, 1, 4, 1, 2, 0), (1, 7, 8, 10, 3, 3, 2, 2, 1, 0),
+    (1, 33, 6, 7, 2, 1, 2, 1, 1, 0), (1, 4, 10, 9, 5, 3, 4, 1, 2, 1), (1, 32, 12, 20, 4, 1, 4, 1, 1, 0),
+]
+RESAMPLE = [((6, 8), (24, 32)), ((16, 20), (8, 10)), ((9, 12), (9, 12)), ((12, 16), (7, 9)), ((12, 14), (48, 56))]
+DOWN = [((16, 24), (4, 6)), ((17, 23), (5, 7)), ((40, 56), (10, 14))]
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def main(out):
+    g = {}
+    for i, (N, C, H, W, pad, K, md, s1, s2, t) in enumerate(CORR):
+        b0, b1 = rnd((N, C, H, W), 100 + i), rnd((N, C, H, W), 200 + i)
+        top = ref.correlation(b0, b1, pad, K, md, s1, s2, t)
+        td = rnd(top.shape, 300 + i)
+        top2, d0, d1 = ref.correlation(b0, b1, pad, K, md, s1, s2, t, td)
+        assert np.array_equal(top, top2)
+        g[f"corr{i}_top"], g[f"corr{i}_d0"], g[f"corr{i}_d1"] = top, d0, d1
+    img, flow, wd = rnd((2, 3, 13, 17), 400), rnd((2, 2, 13, 17), 401, 4.0), rnd((2, 3, 13, 17), 402)
+    flow[0, :, 0, 0] = 0
+    for fill in (1, 2):
+        out_, di, df = ref.flow_warp(img, flow, fill, wd, cpu=False)
+        g[f"warp_gpu_fill{fill}"] = out_
+        if fill == 1:
+            g["warp_gpu_di"], g["warp_gpu_df"] = di, df
+    oc, dic, dfc = ref.flow_warp(img, flow, 1, wd, cpu=True)
+    g["warp_cpu"], g["warp_cpu_di"], g["warp_cpu_df"] = oc, dic, dfc
+    for i, ((hi, wi), (ho, wo)) in enumerate(RESAMPLE):
+        x = rnd((2, 2, hi, wi), 500 + i)
+        for t in (1, 2, 3):
+            for aa in (0, 1):
+                g[f"resample{i}_t{t}_aa{aa}"] = ref.resample(x, ho, wo, t, bool(aa))
+    x = rnd((2, 3, 9, 10), 600)
+    g["cnorm_gpu"] = ref.channel_norm(x)
+    tt, dd = ref.channel_norm(x, rnd((2, 1, 9, 10), 601), cpu=True)
+    g["cnorm_cpu"], g["cnorm_cpu_diff"] = tt, dd
+    for i, ((hi, wi), (ho, wo)) in enumerate(DOWN):
+        x = rnd((1, 2, hi, wi), 700 + i)
+        x[0, 0, :5, :7] = np.nan
+        g[f"down{i}"] = ref.downsample(x, ho, wo)
+    np.savez_compressed(out, **g)
+    print("wrote", out, "arrays:", len(g), "bytes:", os.path.getsize(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "ref_golden.npz"))

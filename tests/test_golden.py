@@ -1,0 +1,119 @@
+"""Pins against tests/golden/ref_golden.npz = outputs of the reference's OWN kernels (its CUDA layer sources,
+compiled unchanged as HIP in oracle/_ref and run on an MI355X by tests/golden/make_golden.py).
+CPU part: the C oracle reproduces them.  GPU part: the HIP kernels reproduce them through the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as MG  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "ref_golden.npz")
+pytestmark = pytest.mark.skipif(not os.path.exists(GOLD), reason="golden vectors not generated yet")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def close(a, b, atol):
+    assert a.shape == b.shape
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    s = max(1.0, float(np.nanmax(np.abs(b))) if np.isfinite(b).any() else 1.0)
+    err = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max()
+    assert err <= atol * s, f"max err {err:.3e} > {atol * s:.3e}"
+
+
+def _corr_inputs(i):
+    N, C, H, W, pad, K, md, s1, s2, t = MG.CORR[i]
+    b0, b1 = MG.rnd((N, C, H, W), 100 + i), MG.rnd((N, C, H, W), 200 + i)
+    return b0, b1, (pad, K, md, s1, s2, t)
+
+
+@pytest.mark.parametrize("i", range(len(MG.CORR)))
+def test_oracle_correlation_matches_reference_kernels(gold, i):
+    b0, b1, (pad, K, md, s1, s2, t) = _corr_inputs(i)
+    p = oracle.corr_params(pad, K, md, s1, s2, t)
+    top = oracle.correlation_forward(p, b0, b1)
+    close(top, gold[f"corr{i}_top"], 1e-6)
+    td = MG.rnd(top.shape, 300 + i)
+    d0, d1 = oracle.correlation_backward(p, b0, b1, td)
+    close(d0, gold[f"corr{i}_d0"], 2e-6)
+    close(d1, gold[f"corr{i}_d1"], 2e-6)
+
+
+def test_oracle_flow_warp_matches_reference_gpu_and_cpu_code(gold):
+    img, flow, wd = MG.rnd((2, 3, 13, 17), 400), MG.rnd((2, 2, 13, 17), 401, 4.0), MG.rnd((2, 3, 13, 17), 402)
+    flow[0, :, 0, 0] = 0
+    for fill in (1, 2):
+        close(oracle.flow_warp_forward(img, flow, fill), gold[f"warp_gpu_fill{fill}"], 1e-6)
+    close(oracle.flow_warp_forward(img, flow, 1), gold["warp_cpu"], 1e-6)
+    di, df = oracle.flow_warp_backward(img, flow, wd)
+    close(di, gold["warp_gpu_di"], 1e-5)      # reference GPU uses float atomics
+    close(df, gold["warp_gpu_df"], 1e-6)
+    close(di, gold["warp_cpu_di"], 1e-6)
+    close(df, gold["warp_cpu_df"], 1e-6)
+
+
+@pytest.mark.parametrize("i", range(len(MG.RESAMPLE)))
+def test_oracle_resample_matches_reference_kernels(gold, i):
+    (hi, wi), (ho, wo) = MG.RESAMPLE[i]
+    x = MG.rnd((2, 2, hi, wi), 500 + i)
+    for t in (1, 2, 3):
+        for aa in (0, 1):
+            close(oracle.resample_forward(x, ho, wo, t, bool(aa)), gold[f"resample{i}_t{t}_aa{aa}"], 2e-6)
+
+
+def test_oracle_channel_norm_and_downsample_match_reference(gold):
+    x = MG.rnd((2, 3, 9, 10), 600)
+    top = oracle.channel_norm_forward(x)
+    close(top, gold["cnorm_gpu"], 1e-6)
+    close(top, gold["cnorm_cpu"], 1e-6)
+    close(oracle.channel_norm_backward(x, top, MG.rnd((2, 1, 9, 10), 601)), gold["cnorm_cpu_diff"], 1e-6)
+    for i, ((hi, wi), (ho, wo)) in enumerate(MG.DOWN):
+        x = MG.rnd((1, 2, hi, wi), 700 + i)
+        x[0, 0, :5, :7] = np.nan
+        close(oracle.downsample_forward(x, ho, wo), gold[f"down{i}"], 1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_kernels_match_reference_kernels(gold):
+    import torch
+    from flownet2_amd import ops
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+    for i in range(len(MG.CORR)):
+        b0, b1, (pad, K, md, s1, s2, t) = _corr_inputs(i)
+        p = ops.corr_params(pad, K, md, s1, s2, t)
+        top = ops.correlation_forward(p, dev(b0), dev(b1))
+        close(top.cpu().numpy(), gold[f"corr{i}_top"], 2e-6)
+        td = MG.rnd(tuple(top.shape), 300 + i)
+        d0, d1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        close(d0.cpu().numpy(), gold[f"corr{i}_d0"], 3e-6)
+        close(d1.cpu().numpy(), gold[f"corr{i}_d1"], 3e-6)
+    img, flow, wd = MG.rnd((2, 3, 13, 17), 400), MG.rnd((2, 2, 13, 17), 401, 4.0), MG.rnd((2, 3, 13, 17), 402)
+    flow[0, :, 0, 0] = 0
+    for fill in (1, 2):
+        close(ops.flow_warp_forward(dev(img), dev(flow), fill).cpu().numpy(), gold[f"warp_gpu_fill{fill}"], 1e-6)
+    di, df = ops.flow_warp_backward(dev(img), dev(flow), dev(wd))
+    close(di.cpu().numpy(), gold["warp_gpu_di"], 1e-5)
+    close(df.cpu().numpy(), gold["warp_gpu_df"], 1e-6)
+    for i, ((hi, wi), (ho, wo)) in enumerate(MG.RESAMPLE):
+        x = MG.rnd((2, 2, hi, wi), 500 + i)
+        for t in (1, 2, 3):
+            for aa in (0, 1):
+                close(ops.resample_forward(dev(x), ho, wo, t, bool(aa)).cpu().numpy(), gold[f"resample{i}_t{t}_aa{aa}"], 2e-6)
+    x = MG.rnd((2, 3, 9, 10), 600)
+    close(ops.channel_norm_forward(dev(x)).cpu().numpy(), gold["cnorm_gpu"], 1e-6)
+    for i, ((hi, wi), (ho, wo)) in enumerate(MG.DOWN):
+        x = MG.rnd((1, 2, hi, wi), 700 + i)
+        x[0, 0, :5, :7] = np.nan
+        close(ops.downsample_forward(dev(x), ho, wo).cpu().numpy(), gold[f"down{i}"], 1e-6)

@@ -1,0 +1,78 @@
+"""Direct pins against oracle/_ref (the reference's own layer code compiled in place, oracle/ref_build.sh).
+CPU part: the reference's CPU implementations of FlowWarp / ChannelNorm (flow_warp_layer.cpp:58-199,
+channel_norm_layer.cpp:43-124) against the C oracle on randomised shapes.  GPU part: the reference's kernels
+executed on the MI355X against the oracle and against our HIP kernels, at sizes beyond the golden file."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ref
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference at build time)")
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 13, 17), (1, 1, 5, 9), (1, 8, 24, 32)])
+def test_reference_cpu_flow_warp_equals_oracle(shape):
+    N, C, H, W = shape
+    img, flow, g = rnd(shape, 1), rnd((N, 2, H, W), 2, 5.0), rnd(shape, 3)
+    out, di, df = ref.flow_warp(img, flow, 1, g, cpu=True)
+    np.testing.assert_allclose(oracle.flow_warp_forward(img, flow), out, rtol=0, atol=1e-6)
+    odi, odf = oracle.flow_warp_backward(img, flow, g)
+    np.testing.assert_allclose(odi, di, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(odf, df, rtol=0, atol=1e-6)
+    nan_out = ref.flow_warp(img, flow + 1000, 2, cpu=True)
+    assert np.isnan(nan_out).all() and np.isnan(oracle.flow_warp_forward(img, flow + 1000, 2)).all()
+
+
+def test_reference_cpu_channel_norm_equals_oracle():
+    x, g = rnd((2, 3, 7, 9), 4), rnd((2, 1, 7, 9), 5)
+    top, d = ref.channel_norm(x, g, cpu=True)
+    np.testing.assert_allclose(oracle.channel_norm_forward(x), top, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(oracle.channel_norm_backward(x, top, g), d, rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 24, 40, 20, 1, 20, 1, 2, 0), (1, 256, 16, 24, 20, 1, 20, 1, 2, 0),
+                                  (1, 8, 11, 13, 4, 3, 2, 1, 2, 1), (1, 12, 10, 12, 6, 1, 6, 2, 3, 0)])
+def test_reference_gpu_correlation_equals_oracle_and_hip(case):
+    import torch
+    from flownet2_amd import ops
+    N, C, H, W, pad, K, md, s1, s2, t = case
+    b0, b1 = rnd((N, C, H, W), 6), rnd((N, C, H, W), 7)
+    top = ref.correlation(b0, b1, pad, K, md, s1, s2, t)
+    td = rnd(top.shape, 8)
+    _, d0, d1 = ref.correlation(b0, b1, pad, K, md, s1, s2, t, td)
+    po = oracle.corr_params(pad, K, md, s1, s2, t)
+    np.testing.assert_allclose(oracle.correlation_forward(po, b0, b1), top, rtol=0, atol=2e-6)
+    o0, o1 = oracle.correlation_backward(po, b0, b1, td)
+    np.testing.assert_allclose(o0, d0, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(o1, d1, rtol=0, atol=3e-6)
+    p = ops.corr_params(pad, K, md, s1, s2, t)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    np.testing.assert_allclose(ops.correlation_forward(p, dv(b0), dv(b1)).cpu().numpy(), top, rtol=0, atol=2e-6)
+    h0, h1 = ops.correlation_backward(p, dv(b0), dv(b1), dv(td))
+    np.testing.assert_allclose(h0.cpu().numpy(), d0, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), d1, rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
+def test_reference_gpu_warp_resample_downsample_equal_oracle():
+    img, flow, g = rnd((2, 16, 24, 40), 9), rnd((2, 2, 24, 40), 10, 6.0), rnd((2, 16, 24, 40), 11)
+    out, di, df = ref.flow_warp(img, flow, 1, g)
+    np.testing.assert_allclose(oracle.flow_warp_forward(img, flow), out, rtol=0, atol=1e-6)
+    odi, odf = oracle.flow_warp_backward(img, flow, g)
+    np.testing.assert_allclose(odi, di, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(odf, df, rtol=0, atol=1e-5)
+    x = rnd((2, 2, 20, 28), 12)
+    for t in (1, 2, 3):
+        for (ho, wo) in [(80, 112), (10, 14), (20, 28), (13, 17)]:
+            np.testing.assert_allclose(oracle.resample_forward(x, ho, wo, t, True), ref.resample(x, ho, wo, t, True), rtol=0, atol=5e-6)
+    x = rnd((1, 2, 40, 56), 13)
+    x[0, 1, 10:30, :] = np.nan
+    a, b = oracle.downsample_forward(x, 10, 14), ref.downsample(x, 10, 14)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=0, atol=1e-6)
