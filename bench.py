@@ -25,7 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from flownet2_amd import functional as Fn   # noqa: E402
-from flownet2_amd import nets, ops          # noqa: E402
+from flownet2_amd import nets, ops, parallel   # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6290 measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3    # same table: dense f32-input MFMA peak (= f32 vector peak)
@@ -150,22 +150,16 @@ def main():
         opt = torch.optim.Adam(plist, lr=1e-5)
         gt = torch.randn(B, 2, H, W, device=device) * 5
         gt[torch.rand(B, 1, H, W, device=device).expand(-1, 2, -1, -1) < 0.05] = float("nan")
-        flat = None
+        parallel.broadcast_params(plist, src=0)
 
         def step():
-            nonlocal flat
             opt.zero_grad(set_to_none=False)
             pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
             loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], Fn), gt, Fn)
             loss.backward()
-            if world > 1:
-                # one flat fp32 bucket (39.18 M floats = 156.7 MB): sum over ranks, scale 1/world (parallel.cpp:377)
-                grads = [p.grad for p in plist]
-                flat = torch._utils._flatten_dense_tensors(grads)
-                dist.all_reduce(flat)
-                flat.mul_(1.0 / world)
-                for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                    g.copy_(s)
+            # the ONE exchange of the path: sum-all-reduce of the fp32 gradients (39.18 M floats = 156.7 MB, one
+            # bucket) over RCCL, scaled by 1/world (parallel.cpp:377); identical Adam step on every rank
+            parallel.allreduce_gradients(plist)
             opt.step()
             return loss
     else:
@@ -185,10 +179,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+    elapsed = parallel.max_over_ranks(elapsed, device)
 
     if rank == 0:
         pairs = world * B * args.steps

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Compiles the Caffe adapter against the stand-in headers (compat/) and links it with libflownet2_hip.so and the
+# layer-driving C shim into _build/libfn2_caffe_adapter_test.so -- the "does the plug-in compile and run" check
+# for a box without a Caffe tree (tests/test_caffe_adapter.py).  In a real Caffe tree only fn2_caffe_layers.cpp is
+# used.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$HERE/../../.."
+OUT="$HERE/_build"
+mkdir -p "$OUT"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-parameter -Wno-unused-function -I$HERE/compat -I$ROOT/include"
+$HIPCC $FLAGS -x hip -c "$HERE/fn2_caffe_layers.cpp" -o "$OUT/fn2_caffe_layers.o"
+$HIPCC $FLAGS -DFN2_SHIM_L1LOSS=1 -x hip -c "$ROOT/oracle/ref_shim.cpp" -o "$OUT/shim.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfn2_caffe_adapter_test.so" "$OUT/fn2_caffe_layers.o" "$OUT/shim.o" \
+  -L"$ROOT/flownet2_amd" -lflownet2_hip -Wl,-rpath,'$ORIGIN/../../..'
+echo "built $OUT/libfn2_caffe_adapter_test.so"

@@ -1,0 +1,318 @@
+// Caffe adapter: the FlowNet2 custom layers as `caffe::Layer<float>` plug-ins whose Forward_gpu / Backward_gpu
+// call libflownet2_hip.so (the C ABI in include/flownet2_hip.h) with the Blobs' device pointers.
+//
+// How a maintainer of the reference uses it: drop this file into src/caffe/layers/, REMOVE the
+// reference's correlation_layer.{cpp,cu}, flow_warp_layer.{cpp,cu}, resample_layer.{cpp,cu}, l1loss_layer.{cpp,cu},
+// channel_norm_layer.{cpp,cu}, downsample_layer.{cpp,cu} from the build (a type string can only be registered
+// once, layer_factory.hpp:69-70), build Caffe for ROCm and link -lflownet2_hip.  Prototxts and .caffemodel files
+// are untouched: same `type:` strings, same *_param fields, same blob shapes.
+//
+// In this repository the file is compiled against the stand-in headers in compat/ (no Caffe tree exists here),
+// and the resulting plug-ins are driven through LayerRegistry exactly like the reference's own classes
+// (tests/test_caffe_adapter.py compares the two side by side on the GPU).
+//
+// Class and member names follow the reference headers (include/caffe/layers/correlation_layer.hpp:26-77,
+// flow_warp_layer.hpp, l1_loss_layer.hpp, channel_norm_layer.hpp, downsample_layer.hpp,
+// src/caffe/layers/resample_layer.hpp) so that the class is recognisable; the bodies are new.
+// Only Dtype = float is instantiated: the C ABI is fp32 (the reference's tools use float, tools/caffe.cpp:203).
+#include <cmath>
+#include <type_traits>
+#include <vector>
+
+#include "caffe/blob.hpp"
+#include "caffe/layer.hpp"
+#include "caffe/layer_factory.hpp"
+#include "caffe/proto/caffe.pb.h"
+
+#include "flownet2_hip.h"
+
+namespace caffe {
+
+#define FN2_CALL(expr)                                                                  \
+  do {                                                                                  \
+    const int fn2_rc_ = (expr);                                                         \
+    if (fn2_rc_ != FN2_OK) LOG(FATAL) << #expr << " -> " << fn2_rc_ << ": " << fn2_last_error_string(); \
+  } while (0)
+
+// The C ABI is fp32.  In a real Caffe build INSTANTIATE_CLASS also instantiates Dtype = double
+// (common.hpp:41-66); those instantiations must compile but abort if they are ever run.
+template <typename Dtype> static inline const float* f32(const Dtype* p) {
+  if constexpr (std::is_same<Dtype, float>::value) { return p; }
+  else { LOG(FATAL) << "flownet2_hip layers are fp32 only (Dtype = double requested)"; return nullptr; }
+}
+template <typename Dtype> static inline float* f32(Dtype* p) {
+  if constexpr (std::is_same<Dtype, float>::value) { return p; }
+  else { LOG(FATAL) << "flownet2_hip layers are fp32 only (Dtype = double requested)"; return nullptr; }
+}
+
+// All reference launches go to the legacy default stream (no stream argument anywhere in the fork); so do we.
+static void* const kStream = nullptr;
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Dtype>
+class CorrelationLayer : public Layer<Dtype> {
+ public:
+  explicit CorrelationLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    const CorrelationParameter& cp = this->layer_param_.correlation_param();
+    CHECK(cp.has_kernel_size()) << "Filter kernel_size is not set";
+    CHECK(cp.has_max_displacement()) << "Max displacement is required.";
+    if (cp.kernel_size() % 2 == 0) LOG(FATAL) << "Odd kernel size required";
+    params_.pad = cp.pad();
+    params_.kernel_size = cp.kernel_size();
+    params_.max_displacement = cp.max_displacement();
+    params_.stride1 = cp.stride_1();
+    params_.stride2 = cp.stride_2();
+    params_.corr_type = cp.correlation_type() == CorrelationParameter_CorrelationType_SUBTRACT ? FN2_CORR_SUBTRACT : FN2_CORR_MULTIPLY;
+    params_.do_abs = cp.do_abs();
+  }
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom[0]->width(), bottom[1]->width()) << "Both bottom blobs must have same width";
+    CHECK_EQ(bottom[0]->height(), bottom[1]->height()) << "Both bottom blobs must have same height";
+    CHECK_EQ(bottom[0]->channels(), bottom[1]->channels()) << "Both bottom blobs must have same height";
+    num_ = bottom[0]->num();
+    FN2_CALL(fn2_correlation_out_shape(&params_, bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(),
+                                       &top_channels_, &top_height_, &top_width_));
+    top[0]->Reshape(num_, top_channels_, top_height_, top_width_);
+    // no rbot1_/rbot2_/rtopdiff_ scratch: the kernels read NCHW directly
+  }
+  virtual inline const char* type() const { return "Correlation"; }
+  virtual inline int ExactNumBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom.size(), 2u);
+    CHECK_EQ(top.size(), 1u);
+    FN2_CALL(fn2_correlation_forward(&params_, f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->mutable_gpu_data()),
+                                     bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(),
+                                     nullptr, 0, kStream));
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>&, const vector<Blob<Dtype>*>& bottom) {
+    // like the reference: both diffs are always written, propagate_down is ignored
+    FN2_CALL(fn2_correlation_backward(&params_, f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->gpu_diff()),
+                                      f32(bottom[0]->mutable_gpu_diff()), f32(bottom[1]->mutable_gpu_diff()),
+                                      bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(),
+                                      nullptr, 0, kStream));
+  }
+  fn2_corr_params params_;
+  int num_, top_height_, top_width_, top_channels_;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Dtype>
+class FlowWarpLayer : public Layer<Dtype> {
+ public:
+  explicit FlowWarpLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom.size(), 2u) << "FlowWarpLayer takes two input blobs: image and flow.";
+    CHECK_EQ(top.size(), 1u) << "FlowWarpLayer outputs one blob.";
+    CHECK_EQ(bottom[0]->num(), bottom[1]->num()) << "Num of the inputs should be the same";
+    CHECK_EQ(2, bottom[1]->channels()) << "Flow should have 2 channels: x-flow and y-flow";
+    CHECK_EQ(bottom[0]->width(), bottom[1]->width()) << "Width of the inputs should be the same";
+    CHECK_EQ(bottom[0]->height(), bottom[1]->height()) << "Height of the inputs should be the same";
+    top[0]->Reshape(bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width());
+  }
+  virtual inline const char* type() const { return "FlowWarp"; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    const int fill = this->layer_param_.flow_warp_param().fill_value() == FlowWarpParameter_FillParameter_ZERO ? FN2_FILL_ZERO : FN2_FILL_NAN;
+    FN2_CALL(fn2_flow_warp_forward(f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->mutable_gpu_data()), top[0]->num(),
+                                   top[0]->channels(), top[0]->height(), top[0]->width(), fill, kStream));
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, const vector<Blob<Dtype>*>& bottom) {
+    FN2_CALL(fn2_flow_warp_backward(f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->gpu_diff()), f32(bottom[0]->mutable_gpu_diff()),
+                                    f32(bottom[1]->mutable_gpu_diff()), top[0]->num(), top[0]->channels(), top[0]->height(),
+                                    top[0]->width(), propagate_down[0], propagate_down[1], kStream));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Dtype>
+class ResampleLayer : public Layer<Dtype> {
+ public:
+  explicit ResampleLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) {
+    const ResampleParameter_ResampleType t = this->layer_param().resample_param().type();
+    if (t != ResampleParameter_ResampleType_CUBIC && t != ResampleParameter_ResampleType_LINEAR && t != ResampleParameter_ResampleType_NEAREST)
+      LOG(FATAL) << "ResampleLayer: only CUBIC, LINEAR and NEAREST interpolation is supported for now";
+  }
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    this->layer_param_.set_reshape_every_iter(false);
+    LOG(WARNING) << "ResampleLayer only runs Reshape on setup";
+    CHECK_GE(bottom.size(), 1u);
+    CHECK_LE(bottom.size(), 2u);
+    CHECK_EQ(top.size(), 1u);
+    int top_height, top_width;
+    if (bottom.size() == 1) {
+      top_height = this->layer_param_.resample_param().height();
+      top_width = this->layer_param_.resample_param().width();
+    } else {
+      top_height = bottom[1]->height();
+      top_width = bottom[1]->width();
+    }
+    CHECK_GE(top_height, 1) << "ResampleLayer must have top_height > 0";
+    CHECK_GE(top_width, 1) << "ResampleLayer must have top_width > 0";
+    top[0]->Reshape(bottom[0]->num(), bottom[0]->channels(), top_height, top_width);
+  }
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int MaxBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+  virtual inline bool AllowBackward() const { LOG(WARNING) << "ResampleLayer does not do backward."; return false; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "ResampleLayer: CPU Forward not yet implemented."; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "ResampleLayer cannot do backward."; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(top[0]->channels(), bottom[0]->channels()) << "ResampleLayer top channel count must match bottom channel count";
+    const ResampleParameter& rp = this->layer_param().resample_param();
+    FN2_CALL(fn2_resample_forward(f32(bottom[0]->gpu_data()), f32(top[0]->mutable_gpu_data()), bottom[0]->num(), bottom[0]->channels(),
+                                  bottom[0]->height(), bottom[0]->width(), top[0]->height(), top[0]->width(), (int)rp.type(),
+                                  rp.antialias(), kStream));
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>& propagate_down, const vector<Blob<Dtype>*>&) {
+    for (size_t i = 0; i < propagate_down.size(); i++)
+      if (propagate_down[i]) LOG(FATAL) << "ResampleLayer cannot do backward.";
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Dtype>
+class L1LossLayer : public Layer<Dtype> {
+ public:
+  explicit L1LossLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    if (this->layer_param_.loss_weight_size() == 0) this->layer_param_.add_loss_weight(Dtype(1));   // LossLayer::LayerSetUp, loss_layer.cpp:8-13
+    if (bottom.size() != 1 && bottom.size() != 2) LOG(FATAL) << "L1LossLayer needs one or two input blobs.";
+    const L1LossParameter& lp = this->layer_param_.l1_loss_param();
+    params_.l2_per_location = lp.l2_per_location();
+    params_.l2_prescale_by_channels = lp.l2_prescale_by_channels();
+    params_.normalize_by_num_entries = lp.normalize_by_num_entries();
+    params_.epsilon = lp.epsilon();
+    params_.plateau = lp.plateau();
+  }
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    top[0]->Reshape(vector<int>());   // Loss layers output a scalar; 0 axes.
+    const size_t need = fn2_l1loss_workspace_bytes(bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width());
+    workspace_.Reshape(vector<int>{(int)((need + sizeof(Dtype) - 1) / sizeof(Dtype))});
+    loss_dev_.Reshape(vector<int>{1});
+  }
+  virtual inline const char* type() const { return "L1Loss"; }
+  virtual inline int ExactNumBottomBlobs() const { return -1; }
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int MaxBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+  virtual inline bool AllowForceBackward(const int) const { return true; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    FN2_CALL(fn2_l1loss_forward(&params_, f32(bottom[0]->gpu_data()), bottom.size() > 1 ? f32(bottom[1]->gpu_data()) : nullptr,
+                                f32(loss_dev_.mutable_gpu_data()), bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(),
+                                bottom[0]->width(), f32(workspace_.mutable_gpu_data()), workspace_.count() * sizeof(Dtype), kStream));
+    top[0]->mutable_cpu_data()[0] = loss_dev_.cpu_data()[0];   // the reference also writes the scalar on the host (l1loss_layer.cu:142)
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, const vector<Blob<Dtype>*>& bottom) {
+    bool prop_down = propagate_down[0];
+    if (bottom.size() > 1) prop_down |= propagate_down[1];
+    if (!prop_down) return;
+    FN2_CALL(fn2_l1loss_backward(&params_, f32(bottom[0]->gpu_data()), bottom.size() > 1 ? f32(bottom[1]->gpu_data()) : nullptr,
+                                 top[0]->cpu_diff()[0], f32(bottom[0]->mutable_gpu_diff()),
+                                 bottom.size() > 1 ? f32(bottom[1]->mutable_gpu_diff()) : nullptr, bottom[0]->num(), bottom[0]->channels(),
+                                 bottom[0]->height(), bottom[0]->width(), f32(workspace_.mutable_gpu_data()),
+                                 workspace_.count() * sizeof(Dtype), kStream));
+  }
+  fn2_l1loss_params params_;
+  Blob<Dtype> workspace_, loss_dev_;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Dtype>
+class ChannelNormLayer : public Layer<Dtype> {
+ public:
+  explicit ChannelNormLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom.size(), 1u) << "ChannelNormLayer takes two input blobs: image and flow.";   // (sic) channel_norm_layer.cpp:30
+    CHECK_EQ(top.size(), 1u) << "ChannelNormLayer outputs one blob.";
+    top[0]->Reshape(bottom[0]->num(), 1, bottom[0]->height(), bottom[0]->width());
+  }
+  virtual inline const char* type() const { return "NormLayer"; }   // (sic) channel_norm_layer.hpp:22
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    FN2_CALL(fn2_channel_norm_forward(f32(bottom[0]->gpu_data()), f32(top[0]->mutable_gpu_data()), bottom[0]->num(), bottom[0]->channels(),
+                                      bottom[0]->height(), bottom[0]->width(), kStream));
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>&, const vector<Blob<Dtype>*>& bottom) {
+    FN2_CALL(fn2_channel_norm_backward(f32(bottom[0]->gpu_data()), f32(top[0]->gpu_data()), f32(top[0]->gpu_diff()), f32(bottom[0]->mutable_gpu_diff()),
+                                       bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(), kStream));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename Dtype>
+class DownsampleLayer : public Layer<Dtype> {
+ public:
+  explicit DownsampleLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    this->layer_param_.set_reshape_every_iter(false);
+    LOG(WARNING) << "DownsampleLayer only runs Reshape on setup";
+    CHECK_GE(bottom.size(), 1u);
+    CHECK_LE(bottom.size(), 2u);
+    CHECK_EQ(top.size(), 1u);
+    if (bottom.size() == 1) {
+      top_height_ = this->layer_param_.downsample_param().top_height();
+      top_width_ = this->layer_param_.downsample_param().top_width();
+    } else {
+      top_height_ = bottom[1]->height();
+      top_width_ = bottom[1]->width();
+    }
+    CHECK_GE(top_height_, 1) << "DownsampleLayer must have top_height > 0";
+    CHECK_GE(top_width_, 1) << "DownsampleLayer must have top_width > 0";
+    top[0]->Reshape(bottom[0]->num(), bottom[0]->channels(), top_height_, top_width_);
+    // the reference shares data/diff with the bottom when the sizes agree (downsample_layer.cpp:53-56); we copy in Forward
+  }
+  virtual inline const char* type() const { return "Downsample"; }
+  virtual inline int MinBottomBlobs() const { return 1; }
+  virtual inline int MaxBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+  virtual inline bool AllowBackward() const { return false; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "DownsampleLayer: CPU Forward not yet implemented."; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "DownsampleLayer cannot do backward."; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    FN2_CALL(fn2_downsample_forward(f32(bottom[0]->gpu_data()), f32(top[0]->mutable_gpu_data()), bottom[0]->num(), bottom[0]->channels(),
+                                    bottom[0]->height(), bottom[0]->width(), top_height_, top_width_, kStream));
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>& propagate_down, const vector<Blob<Dtype>*>&) {
+    for (size_t i = 0; i < propagate_down.size(); i++)
+      if (propagate_down[i]) LOG(FATAL) << "DownsamplingLayer cannot do backward.";
+  }
+  int top_width_, top_height_;
+};
+
+INSTANTIATE_CLASS(CorrelationLayer);
+REGISTER_LAYER_CLASS(Correlation);
+INSTANTIATE_CLASS(FlowWarpLayer);
+REGISTER_LAYER_CLASS(FlowWarp);
+INSTANTIATE_CLASS(ResampleLayer);
+REGISTER_LAYER_CLASS(Resample);
+INSTANTIATE_CLASS(L1LossLayer);
+REGISTER_LAYER_CLASS(L1Loss);
+INSTANTIATE_CLASS(ChannelNormLayer);
+REGISTER_LAYER_CLASS(ChannelNorm);
+INSTANTIATE_CLASS(DownsampleLayer);
+REGISTER_LAYER_CLASS(Downsample);
+
+}  // namespace caffe

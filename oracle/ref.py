@@ -10,17 +10,31 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(_HERE, "_ref", "libfn2_ref.so")
+# the same C shim (oracle/ref_shim.cpp) linked with OUR Caffe adapter instead of the reference's layer sources
+ADAPTER_SO = os.path.join(_HERE, "..", "flownet2_amd", "csrc", "caffe_adapter", "_build", "libfn2_caffe_adapter_test.so")
 _lib = None
+_which = SO
 
 
 def available() -> bool:
     return os.path.exists(SO)
 
 
+def adapter_available() -> bool:
+    return os.path.exists(ADAPTER_SO)
+
+
+def use(which: str):
+    """'ref' = the reference's own layers (oracle/_ref), 'adapter' = flownet2_amd's Caffe adapter."""
+    global _lib, _which
+    _which = SO if which == "ref" else ADAPTER_SO
+    _lib = None
+
+
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(SO)
+        _lib = C.CDLL(_which)
         _lib.fn2ref_last_error.restype = C.c_char_p
     return _lib
 
@@ -96,3 +110,20 @@ def downsample(x, Hout, Wout):
     out = np.empty((N, Cc, Hout, Wout), np.float32)
     _chk(lib().fn2ref_downsample(_p(x), N, Cc, H, W, Hout, Wout, _p(out)))
     return out
+
+
+def l1loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False,
+           epsilon=1e-2, plateau=0.0, loss_weight=1.0):
+    """Adapter library only (the reference's L1LossLayer is not part of oracle/_ref)."""
+    b0 = _f(b0)
+    b1 = _f(b1) if b1 is not None else None
+    N, Cc, H, W = b0.shape
+    loss, wl = C.c_float(), C.c_float()
+    d0 = np.empty_like(b0)
+    d1 = np.empty_like(b0) if b1 is not None else None
+    L = lib()
+    L.fn2ref_l1loss.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    _chk(L.fn2ref_l1loss(int(l2_per_location), int(l2_prescale_by_channels), int(normalize_by_num_entries), epsilon, plateau, loss_weight,
+                         _p(b0), _p(b1), N, Cc, H, W, C.byref(loss), C.byref(wl), _p(d0), _p(d1)))
+    return loss.value, wl.value, d0, d1

@@ -145,3 +145,35 @@ int fn2ref_downsample(const float* in, int N, int C, int Hin, int Win, int Hout,
     fetch(top, out);
   });
 }
+
+#ifdef FN2_SHIM_L1LOSS
+// Only for the adapter build (the reference's L1LossLayer is not part of oracle/_ref, see oracle/README.md).
+extern "C" __attribute__((visibility("default")))
+int fn2ref_l1loss(int l2_per_location, int prescale, int normalize, float epsilon, float plateau, float loss_weight,
+                  const float* b0, const float* b1 /* nullable */, int N, int C, int H, int W,
+                  float* loss_out, float* weighted_loss_out, float* b0_diff, float* b1_diff) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("L1Loss");
+    lp.add_loss_weight(loss_weight);
+    L1LossParameter* p = lp.mutable_l1_loss_param();
+    p->set_l2_per_location(l2_per_location); p->set_l2_prescale_by_channels(prescale); p->set_normalize_by_num_entries(normalize);
+    p->set_epsilon(epsilon); p->set_plateau(plateau);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot0(N, C, H, W), bot1(N, C, H, W), top;
+    fill(bot0, b0);
+    vector<Blob<float>*> bottom{&bot0}, tops{&top};
+    if (b1) { fill(bot1, b1); bottom.push_back(&bot1); }
+    layer->SetUp(bottom, tops);
+    const float total = layer->Forward(bottom, tops);
+    CUDA_CHECK(hipDeviceSynchronize());
+    *loss_out = top.cpu_data()[0];
+    *weighted_loss_out = total;
+    layer->Backward(tops, vector<bool>(bottom.size(), true), bottom);
+    CUDA_CHECK(hipDeviceSynchronize());
+    fetch_diff(bot0, b0_diff);
+    if (b1) fetch_diff(bot1, b1_diff);
+  });
+}
+#endif

@@ -1,0 +1,95 @@
+"""The C++ Caffe adapter (flownet2_amd/csrc/caffe_adapter/fn2_caffe_layers.cpp), compiled against the stand-in
+Caffe headers and driven through LayerRegistry<float>::CreateLayer by prototxt type string -- the same way, through
+the same C shim, as the reference's own layer classes in oracle/_ref.  Checks: the plug-in builds, registers the
+six type strings, enforces the reference's CHECKs, and computes what the oracle (and the reference) computes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def test_adapter_builds_and_exports_layer_driver():
+    subprocess.check_call(["bash", os.path.join(ROOT, "flownet2_amd", "csrc", "caffe_adapter", "build_adapter.sh")], stdout=subprocess.DEVNULL)
+    assert ref.adapter_available()
+    out = subprocess.check_output(["nm", "-D", ref.ADAPTER_SO]).decode()
+    for sym in ("fn2ref_correlation", "fn2ref_flow_warp", "fn2ref_resample", "fn2ref_channel_norm", "fn2ref_downsample", "fn2ref_l1loss"):
+        assert sym in out
+    # the adapter must call INTO libflownet2_hip.so (undefined symbols resolved at load time), not re-implement it
+    assert " U fn2_correlation_forward" in out and " U fn2_flow_warp_backward" in out
+
+
+@pytest.fixture()
+def adapter():
+    if not ref.adapter_available():
+        pytest.skip("adapter test library not built")
+    ref.use("adapter")
+    yield ref
+    ref.use("ref")
+
+
+@pytest.mark.gpu
+def test_adapter_layers_match_oracle(adapter):
+    b0, b1 = rnd((2, 32, 12, 20), 1), rnd((2, 32, 12, 20), 2)
+    top = adapter.correlation(b0, b1, 20, 1, 20, 1, 2, 0)
+    td = rnd(top.shape, 3)
+    _, d0, d1 = adapter.correlation(b0, b1, 20, 1, 20, 1, 2, 0, td)
+    po = oracle.corr_params(20, 1, 20, 1, 2)
+    np.testing.assert_allclose(top, oracle.correlation_forward(po, b0, b1), rtol=0, atol=2e-6)
+    o0, o1 = oracle.correlation_backward(po, b0, b1, td)
+    np.testing.assert_allclose(d0, o0, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(d1, o1, rtol=0, atol=3e-6)
+    img, flow, g = rnd((2, 3, 24, 40), 4), rnd((2, 2, 24, 40), 5, 5.0), rnd((2, 3, 24, 40), 6)
+    out, di, df = adapter.flow_warp(img, flow, 1, g)
+    np.testing.assert_allclose(out, oracle.flow_warp_forward(img, flow), rtol=0, atol=1e-6)
+    odi, odf = oracle.flow_warp_backward(img, flow, g)
+    np.testing.assert_allclose(di, odi, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(df, odf, rtol=0, atol=1e-5)
+    x = rnd((2, 2, 20, 28), 7)
+    np.testing.assert_allclose(adapter.resample(x, 80, 112, 2, True), oracle.resample_forward(x, 80, 112, 2, True), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(adapter.channel_norm(x), oracle.channel_norm_forward(x), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(adapter.downsample(x, 5, 7), oracle.downsample_forward(x, 5, 7), rtol=0, atol=1e-6)
+    pred, gt = rnd((4, 2, 10, 14), 8), rnd((4, 2, 10, 14), 9)
+    gt[0, :, 2, 2] = np.nan
+    loss, weighted, l0, l1 = adapter.l1loss(pred, gt, l2_per_location=True, normalize_by_num_entries=True, loss_weight=0.32)
+    po = oracle.l1_params(l2_per_location=True, normalize_by_num_entries=True)
+    rloss, rnorm = oracle.l1loss_forward(po, pred, gt)
+    assert abs(loss - rloss) <= 1e-6 and abs(weighted - 0.32 * rloss) <= 1e-6       # Layer::Forward adds loss_weight * top
+    r0, r1 = oracle.l1loss_backward(po, pred, gt, 0.32, rnorm)
+    np.testing.assert_allclose(l0, r0, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(l1, r1, rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_adapter_enforces_reference_checks(adapter):
+    b = rnd((1, 4, 8, 8), 10)
+    with pytest.raises(RuntimeError, match="Odd kernel size"):
+        adapter.correlation(b, b, 4, 2, 4, 1, 1)
+    with pytest.raises(RuntimeError, match="same width"):
+        adapter.lib()  # make sure the library is loaded
+        adapter.correlation(b, rnd((1, 4, 8, 9), 11), 4, 1, 4, 1, 1)
+    with pytest.raises(RuntimeError, match="only CUBIC, LINEAR and NEAREST"):
+        adapter.resample(b, 4, 4, 4, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_adapter_is_a_drop_in_for_the_reference_layers(adapter):
+    """Same shim, same calls, reference layers vs adapter layers."""
+    b0, b1 = rnd((1, 64, 16, 24), 12), rnd((1, 64, 16, 24), 13)
+    td = rnd((1, 441, 16, 24), 14)
+    a_top, a0, a1 = adapter.correlation(b0, b1, 20, 1, 20, 1, 2, 0, td)
+    ref.use("ref")
+    r_top, r0, r1 = ref.correlation(b0, b1, 20, 1, 20, 1, 2, 0, td)
+    np.testing.assert_allclose(a_top, r_top, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(a0, r0, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(a1, r1, rtol=0, atol=3e-6)
