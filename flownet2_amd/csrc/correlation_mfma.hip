@@ -49,6 +49,10 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // assignment, and a sum over channels does not care).  ds_read_b128 is serviced in 16-lane groups
 // {(0,0),(0,3),(1,1),(1,2)} / {(0,1),(0,2),(1,0),(1,3)} of (kk, ni) (x 4 nj each); with the row stride
 // == 2 (mod 4) sixteen-byte slots = 8 (mod 16) floats every group covers all 64 banks exactly once.
+// The channel quad q of column j (x-parity px) is stored in slot q ^ ((j >> 1) & 3) ^ (2 px): any per-position
+// permutation keeps the reads conflict-free, and this one makes the staging ds_write_b128 (8 consecutive lanes =
+// 4 columns x 2 parities of one row, 32 banks) conflict-free as well -- unswizzled they were 4-way conflicts
+// and 60 % of all LDS cycles.
 template <int S2, int R>
 struct Cfg {
   static constexpr int D = 2 * R + 1;                 // displacements per axis
@@ -114,12 +118,14 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
   const int pos = isB ? tid : tid - 64 * K::BWAVES;
   unsigned voff = OOB;
   int laddr = -1;
+  int wsw = 0;   // quad swizzle of this position: channels 4q..4q+3 live in 16-byte slot q ^ wsw (see Cfg)
   if (isB) {
     const int row = pos / K::BPX, col = pos % K::BPX;
     if (row < 4) {
       const int ib = i2_0 + row, yb = S2 * ib + py, xb = S2 * (jS - R) + col;
       if (ib >= 0 && yb < g.H && xb >= 0 && xb < g.W) voff = 4u * (unsigned)(yb * g.W + xb);
       laddr = row * K::BRS + (col % S2) * K::BPL + (col / S2) * kKC;
+      wsw = (((col / S2) >> 1) & 3) ^ (((col % S2) << 1) & 3);
     }
   } else {
     const int row = pos / K::SPANPX, col = pos % K::SPANPX;
@@ -127,6 +133,7 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
       const int ya = S2 * (i0 + row) + py, xa = S2 * jS + col;
       if (ya < g.H && xa < g.W) voff = 4u * (unsigned)(ya * g.W + xa);
       laddr = K::AOFF + row * K::ARS + (col % S2) * K::APL + (col / S2) * kKC;
+      wsw = (((col / S2) >> 1) & 3) ^ (((col % S2) << 1) & 3);
     }
   }
   const float* src = isB ? b_n : a_n;        // wave-uniform: one descriptor per wave
@@ -162,14 +169,16 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
     if (laddr >= 0) {                    // the 16 channels of this thread's position: 4 x ds_write_b128
 #pragma unroll
       for (int q = 0; q < kKC / 4; ++q)
-        *reinterpret_cast<f32x4*>(buf + laddr + 4 * q) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(buf + laddr + 4 * (q ^ wsw)) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
     }
   };
 
   // operand addresses: lane (kk, ni, nj) reads channels 4kk..4kk+3 of position (ni, 4Jw + 4b + nj)
   const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
-  const int aAddr = K::AOFF + ni * K::ARS + px * K::APL + (4 * Jw + nj) * kKC + 4 * kk;
-  const int bAddr = ni * K::BRS + px * K::BPL + (4 * Jw + nj) * kKC + 4 * kk;
+  const int rsw = ((2 * Jw + (nj >> 1)) & 3) ^ ((px << 1) & 3);          // swizzle of column 4Jw + nj (even tiles; odd tiles: ^ 2)
+  const int aAddr = K::AOFF + ni * K::ARS + px * K::APL + (4 * Jw + nj) * kKC + 4 * (kk ^ rsw);
+  const int bAddr0 = ni * K::BRS + px * K::BPL + (4 * Jw + nj) * kKC + 4 * (kk ^ rsw);
+  const int bAddr1 = ni * K::BRS + px * K::BPL + (4 * Jw + nj) * kKC + 4 * (kk ^ rsw ^ 2);
   constexpr int NT = (LO <= HI && !(ABL & 1)) ? HI - LO + 1 : 0;
 
   // One chunk = 1 + NT ds_read_b128 and 4 * NT MFMAs per wave.  All reads are issued first; the MFMAs
@@ -180,7 +189,7 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
       const f32x4 av = *reinterpret_cast<const f32x4*>(buf + aAddr);
       f32x4 bv[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(buf + bAddr + 4 * (LO + t) * kKC);
+      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(buf + (((LO + t) & 1) ? bAddr1 : bAddr0) + 4 * (LO + t) * kKC);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
