@@ -10,8 +10,8 @@
 // Kernels in this file
 //   corr_fwd_generic / corr_bwd{0,1}_generic : any (kernel_size, stride_1, stride_2, pad, type);
 //       one thread per output element, x fastest (coalesced).  Fallback + cross-check.
-//   corr_fwd_mfma (correlation_mfma.hip)     : the FlowNetC fast path, kernel_size 1, stride_1 1,
-//       MULTIPLY: banded GEMM on v_mfma_f32_16x16x4_f32 (exact fp32).
+//   corr_fwd_mfma (correlation_mfma.hip), corr_bwd_mfma (correlation_bwd_mfma.hip): the FlowNetC fast paths,
+//       kernel_size 1, stride_1 1, MULTIPLY: 2-D banded GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "correlation.hpp"
 
 #include <cmath>
@@ -207,6 +207,11 @@ FN2_API int fn2_correlation_backward(const fn2_corr_params* p, const float* bott
   if (N == 0) return FN2_OK;
   if (!bottom0 || !bottom1 || !top_diff) return fail(FN2_ERR_INVALID_ARG, "correlation_backward: NULL blob pointer");
   hipStream_t st = as_stream(stream);
+  if (!g_force_generic && corr_bwd_mfma_supported(g)) {
+    if (bottom0_diff) { rc = corr_bwd_mfma_launch(g, 0, bottom1, top_diff, bottom0_diff, st); if (rc) return rc; }
+    if (bottom1_diff) { rc = corr_bwd_mfma_launch(g, 1, bottom0, top_diff, bottom1_diff, st); if (rc) return rc; }
+    return FN2_OK;
+  }
   const long long total = (long long)N * C * H * W;
   const unsigned blocks = blocks_for(total, 256);
   const bool sub = (g.type == FN2_CORR_SUBTRACT);

@@ -13,5 +13,7 @@ struct CorrGeom {
 
 bool corr_fwd_mfma_supported(const CorrGeom& g);
 int corr_fwd_mfma_launch(const CorrGeom& g, const float* b0, const float* b1, float* top, hipStream_t st);
+bool corr_bwd_mfma_supported(const CorrGeom& g);
+int corr_bwd_mfma_launch(const CorrGeom& g, int which, const float* other, const float* top_diff, float* out, hipStream_t st);
 
 }  // namespace fn2

@@ -59,7 +59,9 @@ CORR_CASES = [
     (1, 16, 9, 70, 21, 1, 21, 1, 2),      # max_displacement not a multiple of stride_2 (R = 10), three x spans
     (1, 6, 11, 13, 7, 1, 6, 1, 3),        # stride_2 = 3
     (1, 32, 12, 72, 20, 1, 20, 1, 2),     # MFMA <2,10>, W % 4 == 0 (float4 staging), three x spans
-    (1, 16, 8, 64, 4, 1, 4, 1, 1),        # MFMA <1,4>, float4 staging, two x spans
+    (1, 16, 8, 64, 4, 1, 4, 1, 1),        # MFMA <1,4>, two x spans
+    (1, 64, 10, 35, 4, 1, 4, 1, 1),       # MFMA forward AND backward <1,4> (C % 64 == 0), ragged width
+    (1, 128, 13, 17, 20, 1, 20, 1, 2),    # MFMA forward AND backward <2,10>, ragged small map, 2 channel quarters
 ]
 
 
