@@ -19,6 +19,7 @@ EXPORTS = [
     "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
     "fn2_channel_norm_forward", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
+    "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward",
 ]
 
 
@@ -71,6 +72,10 @@ def lib():
     L.fn2_channel_norm_forward.argtypes = [fp, fp, i, i, i, i, vp]
     L.fn2_channel_norm_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]
     L.fn2_downsample_forward.argtypes = [fp, fp, i, i, i, i, i, i, vp]
+    L.fn2_predict_flow_conv_workspace_bytes.argtypes = [i, i, i, i]
+    L.fn2_predict_flow_conv_workspace_bytes.restype = sz
+    L.fn2_predict_flow_conv_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_upsample_flow_deconv_forward.argtypes = [fp, fp, fp, fp, i, i, i, vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
     for name in EXPORTS:

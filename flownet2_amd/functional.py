@@ -95,3 +95,16 @@ def l1_loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, n
             epsilon=1e-2, plateau=0.0):
     p = ops.l1_params(l2_per_location, l2_prescale_by_channels, normalize_by_num_entries, epsilon, plateau)
     return _L1Loss.apply(b0.contiguous(), b1.contiguous() if b1 is not None else None, p)
+
+
+def predict_flow_conv(x, weight, bias=None):
+    """HIP kernel when no gradient is needed (deploy nets); MIOpen conv2d otherwise (training keeps autograd)."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=1)
+    return ops.predict_flow_conv_forward(x.contiguous(), weight.contiguous(), bias)
+
+
+def upsample_flow_deconv(x, weight, bias=None):
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return torch.nn.functional.conv_transpose2d(x, weight, bias, stride=2, padding=1)
+    return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)

@@ -80,16 +80,28 @@ def _deconv(x, P, name, act=True):
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
-def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
-    flow6 = _conv(conv6_1, P, "Convolution1", 1, 1, act=False)
-    c5 = torch.cat([conv5_1, _deconv(conv6_1, P, "deconv5"), _deconv(flow6, P, "upsample_flow6to5", act=False)], 1)
-    flow5 = _conv(c5, P, "Convolution2", 1, 1, act=False)
-    c4 = torch.cat([conv4_1, _deconv(c5, P, "deconv4"), _deconv(flow5, P, "upsample_flow5to4", act=False)], 1)
-    flow4 = _conv(c4, P, "Convolution3", 1, 1, act=False)
-    c3 = torch.cat([conv3_1, _deconv(c4, P, "deconv3"), _deconv(flow4, P, "upsample_flow4to3", act=False)], 1)
-    flow3 = _conv(c3, P, "Convolution4", 1, 1, act=False)
-    c2 = torch.cat([conv2, _deconv(c3, P, "deconv2"), _deconv(flow3, P, "upsample_flow3to2", act=False)], 1)
-    flow2 = _conv(c2, P, "Convolution5", 1, 1, act=False)
+def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
+    # predict_flow (3x3 conv -> 2 ch) and upsample_flow (4x4/2 deconv 2 -> 2) go through the backend's flow-head
+    # kernels when it has them (HIP: flow_head.hip); otherwise the stock conv path
+    def pf(x, name):
+        if backend is not None and hasattr(backend, "predict_flow_conv"):
+            return backend.predict_flow_conv(x, P[name + ".w"], P[name + ".b"])
+        return _conv(x, P, name, 1, 1, act=False)
+
+    def up(x, name):
+        if backend is not None and hasattr(backend, "upsample_flow_deconv"):
+            return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"])
+        return _deconv(x, P, name, act=False)
+
+    flow6 = pf(conv6_1, "Convolution1")
+    c5 = torch.cat([conv5_1, _deconv(conv6_1, P, "deconv5"), up(flow6, "upsample_flow6to5")], 1)
+    flow5 = pf(c5, "Convolution2")
+    c4 = torch.cat([conv4_1, _deconv(c5, P, "deconv4"), up(flow5, "upsample_flow5to4")], 1)
+    flow4 = pf(c4, "Convolution3")
+    c3 = torch.cat([conv3_1, _deconv(c4, P, "deconv3"), up(flow4, "upsample_flow4to3")], 1)
+    flow3 = pf(c3, "Convolution4")
+    c2 = torch.cat([conv2, _deconv(c3, P, "deconv2"), up(flow3, "upsample_flow3to2")], 1)
+    flow2 = pf(c2, "Convolution5")
     return {2: flow2, 3: flow3, 4: flow4, 5: flow5, 6: flow6}
 
 
@@ -111,7 +123,7 @@ def flownet_c_core(P, img0, img1, backend):
     c51 = _conv(c5, P, "conv5_1", 1, 1)
     c6 = _conv(c51, P, "conv6", 2, 1)
     c61 = _conv(c6, P, "conv6_1", 1, 1)
-    return _decoder(P, c61, c51, c41, c31, c2[:n])
+    return _decoder(P, c61, c51, c41, c31, c2[:n], backend)
 
 
 def flownet_s_core(P, x, backend=None):
@@ -125,7 +137,7 @@ def flownet_s_core(P, x, backend=None):
     c51 = _conv(c5, P, "conv5_1", 1, 1)
     c6 = _conv(c51, P, "conv6", 2, 1)
     c61 = _conv(c6, P, "conv6_1", 1, 1)
-    return _decoder(P, c61, c51, c41, c31, c2)
+    return _decoder(P, c61, c51, c41, c31, c2, backend)
 
 
 def adapted_size(h: int, w: int, divisor: int = 64):

@@ -166,3 +166,29 @@ def downsample_forward(x, top_height, top_width):
     out = torch.empty((N, Cc, int(top_height), int(top_width)), device=x.device, dtype=torch.float32)
     check(_lib.lib().fn2_downsample_forward(_ptr(x), _ptr(out), N, Cc, H, W, int(top_height), int(top_width), _stream()))
     return out
+
+
+def predict_flow_conv_forward(x, weight, bias=None):
+    """Convolution{kernel 3, stride 1, pad 1, num_output 2} (the FlowNet predict_flow heads)."""
+    x, w = _chk(x, "bottom[0]"), _chk(weight, "weight")
+    N, Cc, H, W = x.shape
+    if tuple(w.shape) != (2, Cc, 3, 3):
+        raise ValueError(f"predict_flow weight must be [2,{Cc},3,3], got {tuple(w.shape)}")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    out = torch.empty((N, 2, H, W), device=x.device, dtype=torch.float32)
+    nbytes = _lib.lib().fn2_predict_flow_conv_workspace_bytes(N, Cc, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    check(_lib.lib().fn2_predict_flow_conv_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, Cc, H, W, _ptr(ws), nbytes, _stream()))
+    return out
+
+
+def upsample_flow_deconv_forward(x, weight, bias=None):
+    """Deconvolution{kernel 4, stride 2, pad 1, num_output 2} on a 2-channel flow (the upsample_flow heads)."""
+    x, w = _chk(x, "bottom[0]"), _chk(weight, "weight")
+    N, Cc, H, W = x.shape
+    if Cc != 2 or tuple(w.shape) != (2, 2, 4, 4):
+        raise ValueError("upsample_flow expects a 2-channel flow and a [2,2,4,4] weight")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    out = torch.empty((N, 2, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_upsample_flow_deconv_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, H, W, _stream()))
+    return out

@@ -172,6 +172,23 @@ int fn2_channel_norm_backward(const float* bottom, const float* top, const float
 int fn2_downsample_forward(const float* bottom, float* top, int N, int C,
                            int Hin, int Win, int Hout, int Wout, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Flow heads of the FlowNet decoders -- stock Caffe layers in the reference, specialised here because a
+ * 2-output-channel GEMM cannot fill a matrix tile:
+ *   predict_flow*  = Convolution{kernel_size 3, stride 1, pad 1, num_output 2}
+ *                    <- ConvolutionLayer::Forward_gpu, src/caffe/layers/conv_layer.cu:8-23
+ *                       (BaseConvolutionLayer::forward_gpu_gemm, base_conv_layer.cpp:325-341; weight [2,C,3,3])
+ *   upsample_flow* = Deconvolution{kernel_size 4, stride 2, pad 1, num_output 2} on a 2-channel flow
+ *                    <- DeconvolutionLayer::Forward_gpu, src/caffe/layers/deconv_layer.cu (CPU twin deconv_layer.cpp:8-45;
+ *                       weight [Cin=2, Cout=2, 4, 4], base_conv_layer.cpp:125-139)
+ * Forward only (inference); bias may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+size_t fn2_predict_flow_conv_workspace_bytes(int N, int C, int H, int W);   /* channel-split partials of small maps; may be 0 */
+int fn2_predict_flow_conv_forward(const float* in, const float* weight, const float* bias, float* out,
+                                  int N, int C, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const float* bias, float* out,
+                                     int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

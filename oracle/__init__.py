@@ -171,3 +171,23 @@ def downsample_forward(x, Hout, Wout):
     out = np.empty((N, Cc, Hout, Wout), np.float32)
     _check(lib().fn2_downsample_forward_cpu(_p(x), _p(out), N, Cc, H, W, Hout, Wout), "downsample_forward")
     return out
+
+
+def predict_flow_conv_forward(x, weight, bias=None):
+    x, weight = _f32(x), _f32(weight)
+    bias = _f32(bias) if bias is not None else None
+    N, Cc, H, W = x.shape
+    assert weight.shape == (2, Cc, 3, 3)
+    out = np.empty((N, 2, H, W), np.float32)
+    _check(lib().fn2_predict_flow_conv_forward_cpu(_p(x), _p(weight), _p(bias), _p(out), N, Cc, H, W), "predict_flow_conv_forward")
+    return out
+
+
+def upsample_flow_deconv_forward(x, weight, bias=None):
+    x, weight = _f32(x), _f32(weight)
+    bias = _f32(bias) if bias is not None else None
+    N, Cc, H, W = x.shape
+    assert Cc == 2 and weight.shape == (2, 2, 4, 4)
+    out = np.empty((N, 2, 2 * H, 2 * W), np.float32)
+    _check(lib().fn2_upsample_flow_deconv_forward_cpu(_p(x), _p(weight), _p(bias), _p(out), N, H, W), "upsample_flow_deconv_forward")
+    return out

@@ -40,3 +40,11 @@ def l1_loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, n
     p = oracle.l1_params(l2_per_location, l2_prescale_by_channels, normalize_by_num_entries, epsilon, plateau)
     loss, _ = oracle.l1loss_forward(p, _np(b0), _np(b1) if b1 is not None else None)
     return torch.tensor(loss)
+
+
+def predict_flow_conv(x, weight, bias=None):
+    return torch.from_numpy(oracle.predict_flow_conv_forward(_np(x), _np(weight), _np(bias) if bias is not None else None))
+
+
+def upsample_flow_deconv(x, weight, bias=None):
+    return torch.from_numpy(oracle.upsample_flow_deconv_forward(_np(x), _np(weight), _np(bias) if bias is not None else None))

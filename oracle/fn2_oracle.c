@@ -610,3 +610,53 @@ FN2_API int fn2_downsample_forward_cpu(const float* bottom, float* top, int N, i
   }
   return FN2_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Flow heads: stock Caffe Convolution / Deconvolution arithmetic (conv_layer.cpp:8-40 via im2col + GEMM,
+ * deconv_layer.cpp:8-45), restated as direct loops.  The reference sums through cblas_sgemm / cublasSgemm
+ * (order unspecified); tests compare at fp32 tolerance against torch-CPU conv2d / conv_transpose2d too.
+ * ---------------------------------------------------------------------------------------------- */
+FN2_API int fn2_predict_flow_conv_forward_cpu(const float* in, const float* weight, const float* bias, float* out,
+                                              int N, int C, int H, int W) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t plane = (size_t)H * W;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int o = 0; o < 2; ++o)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+          double acc = bias ? bias[o] : 0.0;
+          for (int c = 0; c < C; ++c)
+            for (int dy = 0; dy < 3; ++dy)
+              for (int dx = 0; dx < 3; ++dx) {
+                const int yy = y + dy - 1, xx = x + dx - 1;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                acc += (double)weight[(((size_t)o * C + c) * 3 + dy) * 3 + dx] * in[((size_t)n * C + c) * plane + (size_t)yy * W + xx];
+              }
+          out[((size_t)n * 2 + o) * plane + (size_t)y * W + x] = (float)acc;
+        }
+  return FN2_OK;
+}
+
+FN2_API int fn2_upsample_flow_deconv_forward_cpu(const float* in, const float* weight, const float* bias, float* out,
+                                                 int N, int H, int W) {
+  if (N < 0 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const int Ho = 2 * H, Wo = 2 * W;
+  for (int n = 0; n < N; ++n)
+    for (int o = 0; o < 2; ++o)
+      for (int Y = 0; Y < Ho; ++Y)
+        for (int X = 0; X < Wo; ++X) {
+          double acc = bias ? bias[o] : 0.0;
+          for (int c = 0; c < 2; ++c)
+            for (int ky = 0; ky < 4; ++ky)
+              for (int kx = 0; kx < 4; ++kx) {
+                const int ny = Y + 1 - ky, nx = X + 1 - kx;       /* Y = 2*iy - pad + ky */
+                if (ny < 0 || nx < 0 || (ny & 1) || (nx & 1)) continue;
+                const int iy = ny / 2, ix = nx / 2;
+                if (iy >= H || ix >= W) continue;
+                acc += (double)weight[((c * 2 + o) * 4 + ky) * 4 + kx] * in[(((size_t)n * 2 + c) * H + iy) * W + ix];
+              }
+          out[(((size_t)n * 2 + o) * Ho + Y) * Wo + X] = (float)acc;
+        }
+  return FN2_OK;
+}

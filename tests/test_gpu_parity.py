@@ -296,3 +296,25 @@ def test_empty_batch_is_a_noop():
     assert ops.channel_norm_forward(z).shape == (0, 1, 4, 4)
     assert ops.correlation_forward(ops.corr_params(1, 1, 1, 1, 1), z, z).shape == (0, 9, 4, 4)
     assert ops.flow_warp_forward(z, torch.empty((0, 2, 4, 4), device="cuda")).shape == (0, 3, 4, 4)
+
+
+@pytest.mark.parametrize("shape", [(8, 1024, 5, 7), (8, 1026, 10, 14), (2, 770, 20, 28), (2, 386, 40, 56), (1, 194, 80, 112), (1, 5, 3, 4)])
+def test_predict_flow_conv(shape):
+    """Flow heads vs the oracle's direct loops AND torch-CPU conv2d (the stock Caffe arithmetic)."""
+    N, C, H, W = shape
+    x, w, b = rand(shape, 30), rand((2, C, 3, 3), 31, 0.05), rand((2,), 32)
+    out = host(ops.predict_flow_conv_forward(dev(x), dev(w), dev(b)))
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1).numpy()
+    assert_close(out, ref.astype(np.float32), 3e-6, "predict_flow vs torch fp64")
+    if C <= 400:
+        assert_close(out, oracle.predict_flow_conv_forward(x, w, b), 3e-6, "predict_flow vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(8, 2, 5, 7), (2, 2, 40, 56), (1, 2, 3, 3)])
+def test_upsample_flow_deconv(shape):
+    x, w, b = rand(shape, 33), rand((2, 2, 4, 4), 34), rand((2,), 35)
+    out = host(ops.upsample_flow_deconv_forward(dev(x), dev(w), dev(b)))
+    ref = torch.nn.functional.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                               stride=2, padding=1).numpy()
+    assert_close(out, ref.astype(np.float32), 1e-6, "upsample_flow vs torch fp64")
+    assert_close(out, oracle.upsample_flow_deconv_forward(x, w, b), 1e-6, "upsample_flow vs oracle")
