@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=448)
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
+    ap.add_argument("--net", choices=["C", "2"], default="C", help="C = FlowNetC (headline, configs[1]); 2 = full FlowNet2 stack (configs[2]: use --batch 4 --height 384 --width 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--corr-iters", type=int, default=200)
     return ap.parse_args()
@@ -139,7 +140,7 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     B, H, W = args.batch, args.height, args.width
-    P_cpu = nets.init_params("C", seed=0)                      # same weights on every rank (replicas)
+    P_cpu = nets.init_params("C", seed=0) if args.net == "C" else nets.init_params_flownet2(seed=0)   # same weights on every rank
     P = {k: v.to(device) for k, v in P_cpu.items()}
     img0, img1 = synth_batch(B, H, W, seed=1234 + rank, device=device)
 
@@ -165,6 +166,8 @@ def main():
     else:
         def step():
             with torch.no_grad():
+                if args.net == "2":
+                    return nets.flownet2_deploy_forward(P, img0, img1, Fn)
                 return nets.deploy_forward("C", P, img0, img1, Fn)
 
     for _ in range(args.warmup):
@@ -185,19 +188,19 @@ def main():
         pairs = world * B * args.steps
         conv_gf = nets.conv_flops("C", H, W) * B / 1e9
         res = {
-            "metric": "image-pairs/sec FlowNetC " + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
+            "metric": "image-pairs/sec " + ("FlowNetC " if args.net == "C" else "FlowNet2 (CSS+SD+fusion) ") + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
             "value": round(pairs / elapsed, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FlowNetC %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
-                                   "pairs, seeded random-init weights (39.18 M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H),
+            "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
+                                   "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
                        "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
                        "conv_stack": "MIOpen fp32 via torch (%.1f GFLOP/step/GPU)" % conv_gf},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
         if world == 1:
             res["roofline"] = corr_roofline(device, B, H, W, args.corr_iters)
-            if args.mode == "fwd" and not args.no_cpu_baseline:
+            if args.mode == "fwd" and args.net == "C" and not args.no_cpu_baseline:
                 cb, epe = cpu_baseline(P_cpu, img0, img1, out)
                 res["cpu_baseline"] = cb
                 res["epe_vs_cpu_oracle"] = epe

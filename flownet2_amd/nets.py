@@ -196,3 +196,138 @@ def conv_flops(kind: str, h: int, w: int, in_channels: int = 6) -> float:
         mult = 2 if (kind == "C" and name in ("conv1", "conv2", "conv3")) else 1
         fl += 2.0 * macs * mult
     return fl
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Full FlowNet2 (BASELINE.json configs[2]): FlowNetC -> FlowNetS -> FlowNetS ("CSS") || FlowNet-SD -> fusion net.
+# Topology from SURVEY.md Appendix B (memory of the paper / third-party converters -- the prototxts are not in the
+# reference tree).  Weight names carry the prefixes of the released caffemodels: net2_, net3_, netsd_, fuse_.
+# ------------------------------------------------------------------------------------------------------------------
+_SD_TABLE = [("conv0", "conv", 6, 64, 3, 1, 1), ("conv1", "conv", 64, 64, 3, 2, 1), ("conv1_1", "conv", 64, 128, 3, 1, 1),
+             ("conv2", "conv", 128, 128, 3, 2, 1), ("conv2_1", "conv", 128, 128, 3, 1, 1), ("conv3", "conv", 128, 256, 3, 2, 1),
+             ("conv3_1", "conv", 256, 256, 3, 1, 1), ("conv4", "conv", 256, 512, 3, 2, 1), ("conv4_1", "conv", 512, 512, 3, 1, 1),
+             ("conv5", "conv", 512, 512, 3, 2, 1), ("conv5_1", "conv", 512, 512, 3, 1, 1), ("conv6", "conv", 512, 1024, 3, 2, 1),
+             ("conv6_1", "conv", 1024, 1024, 3, 1, 1),
+             ("Convolution1", "conv", 1024, 2, 3, 1, 1), ("deconv5", "deconv", 1024, 512, 4, 2, 1), ("upsample_flow6to5", "deconv", 2, 2, 4, 2, 1),
+             ("interconv5", "conv", 1026, 512, 3, 1, 1), ("Convolution2", "conv", 512, 2, 3, 1, 1),
+             ("deconv4", "deconv", 1026, 256, 4, 2, 1), ("upsample_flow5to4", "deconv", 2, 2, 4, 2, 1),
+             ("interconv4", "conv", 770, 256, 3, 1, 1), ("Convolution3", "conv", 256, 2, 3, 1, 1),
+             ("deconv3", "deconv", 770, 128, 4, 2, 1), ("upsample_flow4to3", "deconv", 2, 2, 4, 2, 1),
+             ("interconv3", "conv", 386, 128, 3, 1, 1), ("Convolution4", "conv", 128, 2, 3, 1, 1),
+             ("deconv2", "deconv", 386, 64, 4, 2, 1), ("upsample_flow3to2", "deconv", 2, 2, 4, 2, 1),
+             ("interconv2", "conv", 194, 64, 3, 1, 1), ("Convolution5", "conv", 64, 2, 3, 1, 1)]
+_FUSE_TABLE = [("conv0", "conv", 11, 64, 3, 1, 1), ("conv1", "conv", 64, 64, 3, 2, 1), ("conv1_1", "conv", 64, 128, 3, 1, 1),
+               ("conv2", "conv", 128, 128, 3, 2, 1), ("conv2_1", "conv", 128, 128, 3, 1, 1),
+               ("Convolution5", "conv", 128, 2, 3, 1, 1), ("deconv1", "deconv", 128, 32, 4, 2, 1), ("upsample_flow2to1", "deconv", 2, 2, 4, 2, 1),
+               ("interconv1", "conv", 162, 32, 3, 1, 1), ("Convolution6", "conv", 32, 2, 3, 1, 1),
+               ("deconv0", "deconv", 162, 16, 4, 2, 1), ("upsample_flow1to0", "deconv", 2, 2, 4, 2, 1),
+               ("interconv0", "conv", 82, 16, 3, 1, 1), ("Convolution7", "conv", 16, 2, 3, 1, 1)]
+
+
+def _init_table(table, prefix, g, params, device):
+    for (name, k, ci, co, ks, s, p) in table:
+        shape = (co, ci, ks, ks) if k == "conv" else (ci, co, ks, ks)
+        fan_in = ci * ks * ks if k == "conv" else ci * ks * ks / (s * s)
+        std = math.sqrt(2.0 / ((1 + NEG_SLOPE ** 2) * fan_in))
+        if name.startswith("Convolution"):
+            std *= 0.5
+        if name.startswith("upsample_flow"):
+            std = 0.25
+        params[prefix + name + ".w"] = (torch.randn(shape, generator=g) * std).to(device)
+        params[prefix + name + ".b"] = torch.zeros(co).to(device)
+
+
+def init_params_flownet2(seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    P: Dict[str, torch.Tensor] = {}
+    _init_table(layer_table("C"), "", g, P, device)
+    _init_table(layer_table("S", 12), "net2_", g, P, device)
+    _init_table(layer_table("S", 12), "net3_", g, P, device)
+    _init_table(_SD_TABLE, "netsd_", g, P, device)
+    _init_table(_FUSE_TABLE, "fuse_", g, P, device)
+    return P
+
+
+class _Prefixed(dict):
+    """View of a parameter dict under a layer-name prefix."""
+
+    def __init__(self, P, prefix):
+        super().__init__()
+        self.P, self.prefix = P, prefix
+
+    def __getitem__(self, k):
+        return self.P[self.prefix + k]
+
+
+def _pf(P, x, name, backend):
+    if backend is not None and hasattr(backend, "predict_flow_conv"):
+        return backend.predict_flow_conv(x, P[name + ".w"], P[name + ".b"])
+    return _conv(x, P, name, 1, 1, act=False)
+
+
+def _up(P, x, name, backend):
+    if backend is not None and hasattr(backend, "upsample_flow_deconv"):
+        return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"])
+    return _deconv(x, P, name, act=False)
+
+
+def flownet_sd_core(P, x, backend):
+    c0 = _conv(x, P, "conv0", 1, 1)
+    c1 = _conv(_conv(c0, P, "conv1", 2, 1), P, "conv1_1", 1, 1)
+    c2 = _conv(_conv(c1, P, "conv2", 2, 1), P, "conv2_1", 1, 1)
+    c3 = _conv(_conv(c2, P, "conv3", 2, 1), P, "conv3_1", 1, 1)
+    c4 = _conv(_conv(c3, P, "conv4", 2, 1), P, "conv4_1", 1, 1)
+    c5 = _conv(_conv(c4, P, "conv5", 2, 1), P, "conv5_1", 1, 1)
+    c6 = _conv(_conv(c5, P, "conv6", 2, 1), P, "conv6_1", 1, 1)
+    flow6 = _pf(P, c6, "Convolution1", backend)
+    cat5 = torch.cat([c5, _deconv(c6, P, "deconv5"), _up(P, flow6, "upsample_flow6to5", backend)], 1)
+    flow5 = _pf(P, _conv(cat5, P, "interconv5", 1, 1, act=False), "Convolution2", backend)
+    cat4 = torch.cat([c4, _deconv(cat5, P, "deconv4"), _up(P, flow5, "upsample_flow5to4", backend)], 1)
+    flow4 = _pf(P, _conv(cat4, P, "interconv4", 1, 1, act=False), "Convolution3", backend)
+    cat3 = torch.cat([c3, _deconv(cat4, P, "deconv3"), _up(P, flow4, "upsample_flow4to3", backend)], 1)
+    flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False), "Convolution4", backend)
+    cat2 = torch.cat([c2, _deconv(cat3, P, "deconv2"), _up(P, flow3, "upsample_flow3to2", backend)], 1)
+    return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False), "Convolution5", backend)      # 1/4 resolution, units px/20? (SD: px/0.05)
+
+
+def fusion_core(P, x, backend):
+    c0 = _conv(x, P, "conv0", 1, 1)
+    c1 = _conv(_conv(c0, P, "conv1", 2, 1), P, "conv1_1", 1, 1)
+    c2 = _conv(_conv(c1, P, "conv2", 2, 1), P, "conv2_1", 1, 1)
+    flow2 = _pf(P, c2, "Convolution5", backend)
+    cat1 = torch.cat([c1, _deconv(c2, P, "deconv1"), _up(P, flow2, "upsample_flow2to1", backend)], 1)
+    flow1 = _pf(P, _conv(cat1, P, "interconv1", 1, 1, act=False), "Convolution6", backend)
+    cat0 = torch.cat([c0, _deconv(cat1, P, "deconv0"), _up(P, flow1, "upsample_flow1to0", backend)], 1)
+    return _pf(P, _conv(cat0, P, "interconv0", 1, 1, act=False), "Convolution7", backend)        # full resolution, pixels
+
+
+def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor] = None):
+    """Full FlowNet2: raw 0..255 BGR pairs [N,3,H,W] -> flow [N,2,H,W] in pixels.  Four FlowWarp + four ChannelNorm
+    + six Resample calls per forward."""
+    N, _, H, W = img0.shape
+    ah, aw = adapted_size(H, W)
+    if mean is None:
+        mean = torch.tensor([0.411, 0.433, 0.45], device=img0.device, dtype=img0.dtype)
+    a = backend.resample(img0 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
+    b = backend.resample(img1 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
+
+    def refine_input(flow_q):                       # flow_q: 1/4 resolution, units px/20
+        flow = backend.resample(flow_q * FLOW_SCALE, ah, aw)                       # x20, Resample x4 (LINEAR)
+        warped = backend.flow_warp(b, flow)                                          # FlowWarp(img1, flow)
+        err = backend.channel_norm(a - warped)                                       # ChannelNorm(img0 - warped)
+        return flow, warped, err
+
+    flow1_q = flownet_c_core(P, a, b, backend)[2]
+    f1, w1, e1 = refine_input(flow1_q)
+    flow2_q = flownet_s_core(_Prefixed(P, "net2_"), torch.cat([a, b, w1, f1 * (1.0 / FLOW_SCALE), e1], 1), backend)[2]
+    f2, w2, e2 = refine_input(flow2_q)
+    flow3_q = flownet_s_core(_Prefixed(P, "net3_"), torch.cat([a, b, w2, f2 * (1.0 / FLOW_SCALE), e2], 1), backend)[2]
+    flow_css = backend.resample(flow3_q * FLOW_SCALE, ah, aw, type=1)               # NEAREST into the fusion net (Appendix B)
+    flow_sd = backend.resample(flownet_sd_core(_Prefixed(P, "netsd_"), torch.cat([a, b], 1), backend) * 0.05 * FLOW_SCALE, ah, aw, type=1)
+    err_css = backend.channel_norm(a - backend.flow_warp(b, flow_css))
+    err_sd = backend.channel_norm(a - backend.flow_warp(b, flow_sd))
+    fuse_in = torch.cat([a, flow_sd, flow_css, backend.channel_norm(flow_sd), backend.channel_norm(flow_css), err_sd, err_css], 1)
+    flow = fusion_core(_Prefixed(P, "fuse_"), fuse_in, backend)
+    flow = backend.resample(flow, H, W)
+    scale = torch.tensor([W / float(aw), H / float(ah)], device=flow.device, dtype=flow.dtype)
+    return flow * scale.view(1, 2, 1, 1)

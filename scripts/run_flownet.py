@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""py3 re-authoring of the reference's inference driver (scripts/run-flownet.py:1-127) on the MI355X path.
+
+    python scripts/run_flownet.py [--net C|S|2] [--weights w.npz] img0 img1 out.flo
+
+Same behaviour as the reference script: images are read as RGB, fed as BGR raw 0..255 floats, the net runs at the
+ADAPTED (x64) size and the flow is resampled / rescaled back to the TARGET size, and the result is written as .flo.
+Differences: no prototxt template / .caffemodel (neither is in the reference tree; the graph is flownet2_amd/nets.py,
+weights are a name->array .npz in Caffe blob layout or seeded random), and no "retry up to 5x on NaN" loop -- the
+reference needs it for a race in its kernels (run-flownet.py:72-96); these kernels are deterministic."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flownet2_amd import flo, nets  # noqa: E402
+from flownet2_amd import functional as Fn  # noqa: E402
+
+
+def read_image(path):
+    from PIL import Image
+    a = np.asarray(Image.open(path))
+    if a.ndim == 2:
+        return a[np.newaxis, np.newaxis].astype(np.float32)                               # run-flownet.py:30
+    return a[np.newaxis].transpose(0, 3, 1, 2)[:, [2, 1, 0]].astype(np.float32)          # :31 RGB -> BGR
+
+
+def load_params(net, weights, device):
+    P = nets.init_params_flownet2(0) if net == "2" else nets.init_params(net, 0)
+    if weights:
+        blob = np.load(weights)
+        for k in P:
+            if k in blob:
+                assert tuple(blob[k].shape) == tuple(P[k].shape), f"{k}: shape mismatch"      # net.cpp:783-799
+                P[k] = torch.from_numpy(blob[k].astype(np.float32))
+    return {k: v.to(device) for k, v in P.items()}
+
+
+def infer(net, P, img0, img1):
+    with torch.no_grad():
+        if net == "2":
+            return nets.flownet2_deploy_forward(P, img0, img1, Fn)
+        return nets.deploy_forward(net, P, img0, img1, Fn)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("img0"); ap.add_argument("img1"); ap.add_argument("out")
+    ap.add_argument("--net", choices=["C", "S", "2"], default="C")
+    ap.add_argument("--weights", default=None)
+    ap.add_argument("--gpu", type=int, default=0)
+    a = ap.parse_args()
+    for f in (a.img0, a.img1):
+        if not os.path.exists(f):
+            raise SystemExit("image does not exist: " + f)
+    dev = torch.device("cuda", a.gpu)
+    P = load_params(a.net, a.weights, dev)
+    i0, i1 = torch.from_numpy(read_image(a.img0)).to(dev), torch.from_numpy(read_image(a.img1)).to(dev)
+    flow = infer(a.net, P, i0, i1)
+    flo.write_flo(a.out, flow[0].cpu().numpy())                                         # predict_flow_final -> (H,W,2)
+    print("wrote", a.out, tuple(flow.shape[2:]))
+
+
+if __name__ == "__main__":
+    main()
