@@ -30,6 +30,8 @@
 // sees ~ the algorithmic 4*N*H*W*(2C + 441) bytes.
 #include "correlation.hpp"
 
+#include <type_traits>
+
 namespace fn2 {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -87,8 +89,8 @@ unsigned long long* g_corr_dbg = nullptr;   // FN2_ABLATION builds: per-workgrou
 struct MfmaArgs {
   int N, C, H, W;
   int NI, NSPAN;        // M patch rows per y-parity class, x spans
-  int TS, TH;           // tasks per sample, heavy tasks per sample
-  int G, GP;            // logical workgroups, workgroups per XCD
+  int TH, TD;           // live / dead tasks per sample
+  int LP, DP;           // live / dead list entries per XCD
 };
 
 // live N patch-rows of M patch-row I: a in [alo, ahi] (may be empty)
@@ -141,7 +143,6 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
   const unsigned plane_bytes = 4u * (unsigned)plane;
   const bool stager = laddr >= 0 && !(ABL & 2);
   float sv[kKC];                     // register staging set (one chunk of this thread's pixel position)
-  constexpr int KSTEPS = kKC / 4;
 
   // Staging pipeline.  Per chunk c:  MFMAs on LDS buffer c%2  ->  wait for the row loads of chunk c+1
   // (issued one whole chunk earlier) and write them to buffer (c+1)%2  ->  issue the row loads of
@@ -239,6 +240,108 @@ __device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, 
   }
 }
 
+// Task of one workgroup: (sample n, y parity py, M patch-row I, N patch-row a, x span).  live: a is in the live range
+// [alo, ahi] of (py, I), i.e. its second-map rows touch the image; dead tasks only write zeros (12 % of the run
+// time of a live one).
+struct Task { int n, py, I, a, span, alo, ahi; bool live, valid; };
+
+// Task lists.  All live tasks (sample-major; inside a sample the x span is the slowest index, so the workgroups
+// that land on one CU mix full and ragged spans) and all dead tasks form two global lists, each cut into 8 equal
+// contiguous ranges, one per XCD: block b runs on XCD b % 8 and takes entry b / 8 of that XCD's ranges, live
+// entries first.  Long tasks first / short tasks last is the classic LPT order: the dead tasks fill the slots the
+// first finished live workgroups free, and their stores overlap the remaining compute.  A contiguous range of
+// one XCD is (part of) one sample, so the ~9x re-reads of a sample's rows stay in that XCD's L2.
+// (Folding the zero fill into the live workgroups instead measured 8-15 % slower on every shape tried.)
+template <int S2, int R>
+__device__ __forceinline__ Task decode_task(const MfmaArgs& g) {
+  using K = Cfg<S2, R>;
+  Task k{0, 0, 0, 0, 0, 0, -1, false, false};
+  const int xcd = (int)(blockIdx.x % 8), j = (int)(blockIdx.x / 8);
+  int t, per_sample;
+  k.live = j < g.LP;
+  if (k.live) {
+    t = xcd * g.LP + j; per_sample = g.TH;
+    if (t >= g.N * g.TH) return k;
+  } else {
+    t = xcd * g.DP + (j - g.LP); per_sample = g.TD;
+    if (t >= g.N * g.TD) return k;
+  }
+  k.n = t / per_sample;
+  t %= per_sample;
+  const int per_span = per_sample / g.NSPAN;
+  k.span = t / per_span;
+  t %= per_span;
+  // t-th live (or dead) (py, I, a) combination, py-major / I / a order; <= S2 * NI scalar iterations
+  for (int c = 0; c < S2 * g.NI; ++c) {
+    const int cpy = c / g.NI, cI = c % g.NI;
+    int alo, ahi;
+    live_range<S2, R>(cI, (g.H - cpy + S2 - 1) / S2, alo, ahi);
+    const int nlive = ahi >= alo ? ahi - alo + 1 : 0;
+    const int cnt = k.live ? nlive : K::NB - nlive;
+    if (t < cnt) {
+      k.py = cpy; k.I = cI; k.alo = alo; k.ahi = ahi; k.valid = true;
+      if (k.live) k.a = alo + t;
+      else k.a = (nlive == 0 || t < alo) ? t : t + nlive;     // dead: a in [0, alo) U (ahi, NB)
+      break;
+    }
+    t -= cnt;
+  }
+  return k;
+}
+
+// N tiles [lo, hi] of this wave that can be non-zero (x direction), as the index of one of the 3 x 3 specialised
+// ranges (an extra tile only multiplies staged zeros); 9 = wave without a live M tile.
+template <int S2, int R>
+__device__ __forceinline__ int tile_range_sel(int jw, int Wc) {
+  using K = Cfg<S2, R>;
+  int lo = K::NB, hi = -1;
+  if (jw < Wc) {
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) {
+      const int j2 = jw - R + 4 * b;
+      if (j2 + 3 >= 0 && j2 < Wc) { lo = min(lo, b); hi = max(hi, b); }
+    }
+  }
+  int sel = 9;
+  if (hi >= lo) sel = min(lo, K::LO_MAX) * 3 + (max(hi, K::HI_MIN) - K::HI_MIN);
+  return __builtin_amdgcn_readfirstlane(sel);
+}
+
+// Epilogue: accumulators -> LDS image [mi][ni][o][x] -> coalesced 128-byte rows of top.
+template <int S2, int R, bool STORE, typename Acc>
+__device__ __forceinline__ void epilogue(const Acc& acc, float* smem, float* __restrict__ top, const MfmaArgs& g, const Task& k,
+                                         int tid, int lane, int px, int Jw) {
+  using K = Cfg<S2, R>;
+  const int ni = (lane & 15) >> 2, nj = lane & 3;
+  const float sumelems = (float)g.C;      // kernel_size^2 * channels, correlation_layer.cu:108
+  const bool pow2 = (g.C & (g.C - 1)) == 0;   // x / 2^k == x * 2^-k exactly; otherwise keep the true division
+  const float rcp = 1.0f / sumelems;
+  const int mi = lane >> 4;               // C/D layout of 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane & 15
+#pragma unroll
+  for (int b = 0; b < K::NB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {         // reg r <-> mj
+      const int oo = 4 * b + nj - r;      // o + R
+      if (oo >= 0 && oo < K::D)
+        smem[((mi * 4 + ni) * K::D + oo) * K::XS + S2 * (4 * Jw + r) + px] = pow2 ? acc[b][r] * rcp : acc[b][r] / sumelems;
+    }
+  }
+  __syncthreads();
+  const int jS = K::SPANC * k.span, i0 = 4 * k.I;
+  const int xl = tid % K::SPANPX;
+  const int x = S2 * jS + xl;
+  const size_t top_n = (size_t)k.n * K::D * K::D;
+  if (x < g.W && STORE) {
+    for (int rowid = tid / K::SPANPX; rowid < K::OROWS; rowid += kThreads / K::SPANPX) {
+      const int rmi = rowid / (4 * K::D), rni = (rowid / K::D) % 4, oo = rowid % K::D;
+      const int qq = 4 * k.a + rni - rmi;   // q + R
+      const int y = S2 * (i0 + rmi) + k.py;
+      if (qq >= 0 && qq < K::D && y < g.H)
+        top[((top_n + (size_t)qq * K::D + oo) * g.H + y) * g.W + x] = smem[rowid * K::XS + xl];
+    }
+  }
+}
+
 template <int S2, int R, int ABL>
 __global__ void __launch_bounds__(kThreads, 6)
 corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
@@ -249,38 +352,10 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #ifdef FN2_ABLATION
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- task decode; blocks b, b+8, b+16.. run on one XCD, give them one contiguous task range ----
-  const int L = (int)(blockIdx.x % 8) * g.GP + (int)(blockIdx.x / 8);
-  if (L >= g.G) return;
-  const int n = L / g.TS;
-  int t = L % g.TS;
-  // Per sample: the light tasks (zero fill only) come FIRST -- their stores go out while the chip is
-  // otherwise still loading, instead of joining the store burst at the end -- then the heavy tasks
-  // with the x span as the slowest index, so that the three workgroups that land on one CU
-  // (tasks c, c+32, c+64 of an XCD) mix full and ragged spans.
-  const int TL = g.TS - g.TH;
-  const bool heavy = t >= TL;
-  if (heavy) t -= TL;
-  const int per_span = (heavy ? g.TH : TL) / g.NSPAN;
-  const int span = t / per_span;
-  t %= per_span;
-  // t-th heavy (or light) (py, I, a) combination, py-major / I / a order; <= S2 * NI scalar iterations
-  int py = 0, I = 0, a = 0;
-  for (int c = 0; c < S2 * g.NI; ++c) {
-    const int cpy = c / g.NI, cI = c % g.NI;
-    const int Hc_c = (g.H - cpy + S2 - 1) / S2;
-    int alo, ahi;
-    live_range<S2, R>(cI, Hc_c, alo, ahi);
-    const int nlive = ahi >= alo ? ahi - alo + 1 : 0;
-    const int cnt = heavy ? nlive : K::NB - nlive;
-    if (t < cnt) {
-      py = cpy; I = cI;
-      if (heavy) a = alo + t;
-      else a = (nlive == 0 || t < alo) ? t : t + nlive;     // light: a in [0, alo) U (ahi, NB)
-      break;
-    }
-    t -= cnt;
-  }
+  const Task k = decode_task<S2, R>(g);
+  if (!k.valid) return;
+  const int n = k.n, py = k.py, I = k.I, a = k.a, span = k.span;
+  const bool heavy = k.live;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,7 +365,6 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const int Wc = (g.W - px + S2 - 1) / S2;      // class cols of this wave's x parity
   if (i0 >= Hc) return;                         // whole workgroup (uniform): no output rows
 
-  const int ni = (lane & 15) >> 2, nj = lane & 3;
   const size_t plane = (size_t)g.H * g.W;
   const float* a_n = b0 + (size_t)n * g.C * plane;
   const float* b_n = b1 + (size_t)n * g.C * plane;
@@ -302,20 +376,8 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
 
   unsigned long long ph[4] = {0, 0, 0, 0};
   if (heavy) {
-    // N tiles of this wave that can be non-zero (x direction), widened to one of the 3 x 3 specialised
-    // ranges (an extra tile only multiplies staged zeros).  Straight-line MFMA bodies matter: a branch
-    // per tile serialises every ds_read -> s_waitcnt -> v_mfma triple.
-    int lo = K::NB, hi = -1;
-    if (jw < Wc) {
-#pragma unroll
-      for (int b = 0; b < K::NB; ++b) {
-        const int j2 = jw - R + 4 * b;
-        if (j2 + 3 >= 0 && j2 < Wc) { lo = min(lo, b); hi = max(hi, b); }
-      }
-    }
-    int sel = 9;
-    if (hi >= lo) sel = min(lo, K::LO_MAX) * 3 + (max(hi, K::HI_MIN) - K::HI_MIN);
-    sel = __builtin_amdgcn_readfirstlane(sel);
+    // Straight-line MFMA bodies matter: a branch per tile serialises every ds_read -> s_waitcnt -> v_mfma triple.
+    const int sel = tile_range_sel<S2, R>(jw, Wc);
 #define FN2_KLOOP(LO_, HI_) k_loop<S2, R, LO_, HI_, ABL>(acc, smem, a_n, b_n, g, tid, lane, wave, px, Jw, py, i0, i2_0, jS, ph)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
@@ -335,33 +397,7 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #ifdef FN2_ABLATION
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- epilogue: accumulators -> LDS image [mi][ni][o][x] -> coalesced rows of top ----
-  const float sumelems = (float)g.C;      // kernel_size^2 * channels, correlation_layer.cu:108
-  const bool pow2 = (g.C & (g.C - 1)) == 0;   // x / 2^k == x * 2^-k exactly; otherwise keep the true division
-  const float rcp = 1.0f / sumelems;
-  const int mi = lane >> 4;               // C/D layout of 16x16 MFMA: row = 4*(lane>>4) + reg, col = lane & 15
-#pragma unroll
-  for (int b = 0; b < K::NB; ++b) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {         // reg r <-> mj
-      const int oo = 4 * b + nj - r;      // o + R
-      if (oo >= 0 && oo < K::D)
-        smem[((mi * 4 + ni) * K::D + oo) * K::XS + S2 * (4 * Jw + r) + px] = pow2 ? acc[b][r] * rcp : acc[b][r] / sumelems;
-    }
-  }
-  __syncthreads();
-  const int xl = tid % K::SPANPX;
-  const int x = S2 * jS + xl;
-  const size_t top_n = (size_t)n * K::D * K::D;
-  if (x < g.W && !(ABL & 4)) {
-    for (int rowid = tid / K::SPANPX; rowid < K::OROWS; rowid += kThreads / K::SPANPX) {
-      const int rmi = rowid / (4 * K::D), rni = (rowid / K::D) % 4, oo = rowid % K::D;
-      const int qq = 4 * a + rni - rmi;   // q + R
-      const int y = S2 * (i0 + rmi) + py;
-      if (qq >= 0 && qq < K::D && y < g.H)
-        top[((top_n + (size_t)qq * K::D + oo) * g.H + y) * g.W + x] = smem[rowid * K::XS + xl];
-    }
-  }
+  epilogue<S2, R, !(ABL & 4)>(acc, smem, top, g, k, tid, lane, px, Jw);
 #ifdef FN2_ABLATION
   if (dbg && threadIdx.x == 0) {
     unsigned hwid, xcc;
@@ -379,6 +415,261 @@ corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #endif
 }
 
+// =====================================================================================================
+// LDS-DMA variant.  The staged rows go global -> LDS directly (buffer_load_dword ... lds): no staging VGPRs, no
+// ds_write pass, no "wait for loads, then write" phase in front of every barrier -- with three workgroups per CU
+// running in lock step that phase had the matrix pipe idle.  An LDS-DMA instruction writes M0 + lane * 4, i.e.
+// one 64-dword run per wave instruction, so the LDS image is built from runs:
+//   second map: [channel group][channel][row 4][x parity][class column JW]  (a group = GC channels = a whole
+//               number of runs; groups GPADG dwords apart), lane -> pixel de-interleaves the x parities on the
+//               SOURCE side (lane l of a row's parity plane reads pixel S2 * column + parity);
+//   first map:  per channel two runs (rows 0-1, rows 2-3), AHALF apart, channels CSA apart.
+// Operand fetch is one ds_read_b32 per (tile, k-step): lane (kk, ni, nj) contracts channel 4r + kk in k-step r.
+// The paddings make every ds_read_b32 hit 64 distinct banks (brute-forced for all four instantiations).
+// Chunks are KC = 8 channels (2 k-steps), ring of 3 buffers, loads issued two chunks ahead, hand-counted vmcnt
+// (hipcc would drain the queue) and one raw s_barrier per chunk.
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+
+template <int S2, int R>
+struct GCfg {
+  using K = Cfg<S2, R>;
+  static constexpr int KC = 8;                        // channels per chunk
+  static constexpr int NBUF = 3;
+  static constexpr int ROWB = K::BPX;                 // dwords per staged second-map row: [px][jcol]
+  static constexpr int CHB = 4 * ROWB;                // ... per channel
+  static constexpr int GC = 64 / cgcd(64, CHB);       // channels per run-aligned group
+  static constexpr int GROUP = GC * CHB;
+  static constexpr int GS = GROUP + 4;                // group stride (pad 4: conflict-free ds_read_b32)
+  static constexpr int NGRP = KC / GC;
+  static constexpr int BSZ = NGRP * GS;
+  static constexpr int CSA = 136, AHALF = 68;         // first map: channel stride, offset of the rows-2-3 run
+  static constexpr int ASZ = KC * CSA;
+  static constexpr int CHUNK = BSZ + ASZ;             // floats per staged chunk
+  static constexpr int SLOT = CHUNK + 64;             // ring slot = chunk + one scratch run (dummy LDS-DMA destination)
+  static constexpr int NBR = KC * CHB / 64;           // runs per chunk: second map
+  static constexpr int NAR = KC * 2;                  //                 first map
+  static constexpr int NRUN = NBR + NAR;
+  static constexpr int RB = cdiv(NBR, kWaves), RA = cdiv(NAR, kWaves);
+  static constexpr int RPW = RB + RA;                 // LDS-DMA instructions per wave and chunk (dummies included)
+  static constexpr int LDS_FLOATS = cmax(NBUF * SLOT, K::OROWS * K::XS);
+  static_assert(GC == 1 || GC == 2 || GC == 4, "channel 4r + kk must stay group-affine");
+  static_assert(KC % GC == 0 && GROUP % 64 == 0, "a run never straddles a group");
+  static_assert(K::SPANPX == 32, "first-map run = two 32-pixel rows");
+  static_assert(RPW >= 1 && RPW <= 15, "vmcnt immediates below");
+};
+
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 15, "");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int S2, int R, int LO, int HI, typename Acc>
+__device__ __forceinline__ void k_loop_glds(Acc& acc, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
+                                            unsigned lds_base, int lane, int wave, int px, int Jw, int py, int i0, int i2_0, int jS) {
+  using K = Cfg<S2, R>;
+  using G = GCfg<S2, R>;
+  const int plane = g.H * g.W;
+  constexpr unsigned OOB = 0x7ffffff0u;
+
+  // ---- run plan of this wave.  Slot i < RB: second-map run i * 8 + wave, slot RB + i: first-map run i * 8 + wave.
+  // The slot -> map assignment is static so the issue code is straight-line (it is interleaved with MFMAs below);
+  // a slot past the end of its map is a dummy: out-of-range source (reads as 0) into the scratch run that ends every ring slot.
+  unsigned voff[G::RPW];     // per-lane byte offset inside the chunk's channel range
+  int ldst[G::RPW];          // LDS byte offset from the ring slot base; wave-uniform
+#pragma unroll
+  for (int i = 0; i < G::RB; ++i) {
+    const int rho = i * kWaves + wave;
+    voff[i] = OOB; ldst[i] = 4 * G::CHUNK;
+    if (rho < G::NBR) {
+      const int grp = (rho * 64) / G::GROUP;                   // uniform
+      const int rem = rho * 64 - grp * G::GROUP + lane;
+      const int chl = rem / G::CHB, rem2 = rem % G::CHB;
+      const int row = rem2 / G::ROWB, col = rem2 % G::ROWB;
+      const int pxx = col / K::JW, jc = col % K::JW;
+      const int ib = i2_0 + row, yb = S2 * ib + py, xb = S2 * (jS - R + jc) + pxx;
+      if (ib >= 0 && yb < g.H && xb >= 0 && xb < g.W) voff[i] = 4u * (unsigned)((grp * G::GC + chl) * plane + yb * g.W + xb);
+      ldst[i] = 4 * (grp * G::GS + (rho * 64 - grp * G::GROUP));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < G::RA; ++i) {
+    const int ra = i * kWaves + wave;
+    voff[G::RB + i] = OOB; ldst[G::RB + i] = 4 * G::CHUNK;
+    if (ra < G::NAR) {
+      const int ch = ra >> 1, half = ra & 1;
+      const int row = 2 * half + (lane >> 5), col = lane & 31;
+      const int pxx = col / K::SPANC, jc = col % K::SPANC;
+      const int ya = S2 * (i0 + row) + py, xa = S2 * (jS + jc) + pxx;
+      if (ya < g.H && xa < g.W) voff[G::RB + i] = 4u * (unsigned)(ch * plane + ya * g.W + xa);
+      ldst[G::RB + i] = 4 * (G::BSZ + ch * G::CSA + half * G::AHALF);
+    }
+  }
+  const unsigned chunk_bytes = 4u * G::KC * (unsigned)plane;
+  // Descriptors span the whole sample; the chunk is selected by the scalar offset.  OOB (2 GiB - 16) is beyond any
+  // supported sample (C * H * W < 2^28 floats), so such lanes read 0.0f = the zero padding.
+  const unsigned sample_bytes = 4u * (unsigned)g.C * (unsigned)plane;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_n), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_n), 0, sample_bytes, 0x00020000);
+
+  // one LDS-DMA run: M0 = destination, 64 lanes x 4 B
+  auto run = [&](int i, unsigned slot_bytes, unsigned soff) {
+    lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(slot_bytes + (unsigned)ldst[i]);
+    if (i < G::RB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, lp, 4, voff[i], soff, 0, 0);
+    else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lp, 4, voff[i], soff, 0, 0);
+  };
+
+  // ---- operand addresses: lane (kk, ni, nj); k-step r contracts channel 4r + kk ----
+  const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
+  const int bAddr = (kk / G::GC) * G::GS + (kk % G::GC) * G::CHB + ni * G::ROWB + px * K::JW + 4 * Jw + nj;
+  const int aAddr = G::BSZ + kk * G::CSA + (ni >> 1) * G::AHALF + (ni & 1) * 32 + px * K::SPANC + 4 * Jw + nj;
+  constexpr int BSTEP = (4 / G::GC) * G::GS, ASTEP = 4 * G::CSA;     // k-step r -> + r * STEP
+  constexpr int NT = (LO <= HI) ? HI - LO + 1 : 0;
+  constexpr int KS = G::KC / 4;
+  static_assert(KS == 2, "the half-iteration schedule below is written for two k-steps per chunk");
+
+  struct Ops { float a[KS]; float b[KS][NT > 0 ? NT : 1]; };
+  auto read_ops = [&](Ops& o, const float* buf) {
+    if constexpr (NT > 0) {
+#pragma unroll
+      for (int r = 0; r < KS; ++r) {
+        o.a[r] = buf[aAddr + r * ASTEP];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) o.b[r][t] = buf[bAddr + r * BSTEP + 4 * (LO + t)];
+      }
+    }
+  };
+  auto mfma_step = [&](const Ops& o, int r, int t) {
+    if constexpr (NT > 0) acc[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[r], o.b[r][t], acc[LO + t], 0, 0, 0);
+  };
+
+  const int nchunks = g.C / G::KC;
+  // One chunk: [k-step 0 MFMAs with the LDS-DMA issue of chunk c+2 threaded between them] -> wait until chunk c+1
+  // has landed -> barrier -> [operand reads of chunk c+1] -> [k-step 1 MFMAs of chunk c hide the read latency].
+  // sched_barrier(0) pins that order; hipcc otherwise hoists the issue code in front of the MFMAs.
+  // ISSUE / READ are compile-time so the steady-state body is branch-free.
+  auto chunk_step = [&](auto issue_tag, auto read_tag, int c, int slot, Ops& cur, Ops& nxt) {
+    constexpr bool ISSUE = decltype(issue_tag)::value, READ = decltype(read_tag)::value;
+    int s2 = slot + 2; if (s2 >= G::NBUF) s2 -= G::NBUF;
+    int s1 = slot + 1; if (s1 >= G::NBUF) s1 -= G::NBUF;
+    if constexpr (ISSUE) {
+      const unsigned slot2_bytes = lds_base + 4u * (unsigned)(s2 * G::SLOT);
+      const unsigned soff = (unsigned)(c + 2) * chunk_bytes;
+      constexpr int STEPS = NT > G::RPW ? NT : G::RPW;
+#pragma unroll
+      for (int j = 0; j < STEPS; ++j) {
+        if (j < NT) mfma_step(cur, 0, j);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < G::RPW) run(j, slot2_bytes, soff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wait_vmcnt<G::RPW>();
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) mfma_step(cur, 0, j);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (READ) read_ops(nxt, smem + s1 * G::SLOT);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) mfma_step(cur, 1, j);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  // prologue: chunks 0 and 1 in flight, chunk 0 landed and published, its operands in registers
+#pragma unroll
+  for (int i = 0; i < G::RPW; ++i) run(i, lds_base, 0u);
+#pragma unroll
+  for (int i = 0; i < G::RPW; ++i) run(i, lds_base + 4u * G::SLOT, chunk_bytes);
+  wait_vmcnt<G::RPW>();
+  __builtin_amdgcn_s_barrier();
+  Ops o0, o1;
+  read_ops(o0, smem);
+  int slot = 0, c = 0;
+  for (; c + 2 < nchunks; c += 2) {            // nchunks is even and >= 2 (C % 16 == 0)
+    chunk_step(T{}, T{}, c, slot, o0, o1);
+    slot = slot + 1 == G::NBUF ? 0 : slot + 1;
+    chunk_step(T{}, T{}, c + 1, slot, o1, o0);
+    slot = slot + 1 == G::NBUF ? 0 : slot + 1;
+  }
+  chunk_step(F{}, T{}, c, slot, o0, o1);
+  slot = slot + 1 == G::NBUF ? 0 : slot + 1;
+  chunk_step(F{}, F{}, c + 1, slot, o1, o0);
+}
+
+template <int S2, int R>
+__global__ void __launch_bounds__(kThreads, 6)
+corr_fwd_glds(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
+              unsigned long long* __restrict__ dbg) {
+  using K = Cfg<S2, R>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef FN2_ABLATION
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
+  const Task k = decode_task<S2, R>(g);
+  if (!k.valid) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = wave % S2, Jw = wave / S2;
+  const int i0 = 4 * k.I, jS = K::SPANC * k.span, jw = jS + 4 * Jw;
+  const int Hc = (g.H - k.py + S2 - 1) / S2;
+  const int Wc = (g.W - px + S2 - 1) / S2;
+  if (i0 >= Hc) return;
+  const size_t plane = (size_t)g.H * g.W;
+  const float* a_n = b0 + (size_t)k.n * g.C * plane;
+  const float* b_n = b1 + (size_t)k.n * g.C * plane;
+  const int i2_0 = i0 - R + 4 * k.a;
+
+  f32x4 acc[K::NB];
+#pragma unroll
+  for (int b = 0; b < K::NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;     // LDS byte address of the ring
+  if (k.live) {
+    const int sel = tile_range_sel<S2, R>(jw, Wc);
+#define FN2_KLOOP(LO_, HI_) k_loop_glds<S2, R, LO_, HI_>(acc, smem, a_n, b_n, g, lds_base, lane, wave, px, Jw, k.py, i0, i2_0, jS)
+    switch (sel) {
+      case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
+      case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
+      case 2: FN2_KLOOP(0, K::HI_MIN + 2); break;
+      case 3: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 0); break;
+      case 4: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 1); break;
+      case 5: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 2); break;
+      case 6: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 0); break;
+      case 7: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 1); break;
+      case 8: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 2); break;
+      default: FN2_KLOOP(1, 0); break;
+    }
+#undef FN2_KLOOP
+  }
+#ifdef FN2_ABLATION
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  epilogue<S2, R, true>(acc, smem, top, g, k, tid, lane, px, Jw);
+#ifdef FN2_ABLATION
+  if (dbg && threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[4 * blockIdx.x + 0] = t_start;
+    dbg[4 * blockIdx.x + 1] = t_loop;
+    dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid | ((unsigned long long)(k.live ? 1 : 0) << 63);
+    dbg[4 * 1024 + 4 * 8 * 1024 + 2 * blockIdx.x + 0] = rt_start;                             // 100 MHz wall clock
+    dbg[4 * 1024 + 4 * 8 * 1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+int g_corr_stage = 0;   // 0 = LDS-DMA staging (default), 1 = register staging (the first-generation kernel)
+
 template <int S2, int R>
 static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* top, hipStream_t st) {
   using K = Cfg<S2, R>;
@@ -395,11 +686,12 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
       if (ahi >= alo) nheavy += ahi - alo + 1;
     }
   g.TH = nheavy * g.NSPAN;
-  g.TS = S2 * g.NI * K::NB * g.NSPAN;
-  const long long G = (long long)cg.N * g.TS;
-  if (G > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
-  g.G = (int)G;
-  g.GP = (g.G + 7) / 8;
+  g.TD = S2 * g.NI * K::NB * g.NSPAN - g.TH;
+  const long long NL = (long long)cg.N * g.TH, ND = (long long)cg.N * g.TD;
+  if (NL + ND > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
+  g.LP = (int)((NL + 7) / 8);
+  g.DP = (int)((ND + 7) / 8);
+  const unsigned grid = 8u * (unsigned)(g.LP + g.DP);
   const size_t lds = sizeof(float) * K::LDS_FLOATS;
   static bool attr_set = false;
   if (!attr_set) {
@@ -410,18 +702,28 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   // profiling-only builds: bit 0 = no MFMA, bit 1 = no staging loads, bit 2 = no output stores
   if (S2 == 2 && R == 10 && g_corr_ablation) {
     switch (g_corr_ablation) {
-      case 1: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 1>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 2: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 2>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 3: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 3>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 4: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 4>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 8: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 8>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 6: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 6>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      default: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 7>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 1: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 1>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 2: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 2>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 3: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 3>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 4: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 4>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 8: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 8>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      case 6: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 6>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
+      default: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 7>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
     }
     return check_launch("correlation_forward (mfma, ablation)");
   }
 #endif
-  hipLaunchKernelGGL((corr_fwd_mfma<S2, R, 0>), dim3(8 * g.GP), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg);
+  if (g_corr_stage == 0) {
+    const size_t lds2 = sizeof(float) * GCfg<S2, R>::LDS_FLOATS;
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_glds<S2, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      attr2_set = true;
+    }
+    hipLaunchKernelGGL((corr_fwd_glds<S2, R>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg);
+    return check_launch("correlation_forward (mfma, lds-dma)");
+  }
+  hipLaunchKernelGGL((corr_fwd_mfma<S2, R, 0>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg);
   return check_launch("correlation_forward (mfma)");
 }
 

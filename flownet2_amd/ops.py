@@ -69,9 +69,10 @@ def correlation_backward(p: CorrParams, bottom0, bottom1, top_diff, need0=True, 
     return d0, d1
 
 
-def set_correlation_impl(force_generic: bool):
-    """Test hook: route the forward through the generic kernel instead of the MFMA fast path."""
-    check(_lib.lib().fn2_debug_set_correlation_impl(1 if force_generic else 0))
+def set_correlation_impl(impl):
+    """Test hook: 0 / False = automatic choice, 1 / True = generic kernels, 2 = MFMA forward with register staging
+    (the first-generation kernel; the default MFMA forward stages through LDS-DMA)."""
+    check(_lib.lib().fn2_debug_set_correlation_impl(int(impl)))
 
 
 def flow_warp_forward(image, flow, fill_value=FILL_ZERO):

@@ -10,14 +10,19 @@ x = torch.randn(N, Cc, H, W, device="cuda", generator=g); y = torch.randn(N, Cc,
 p = ops.corr_params(20, 1, 20, 1, 2)
 out = torch.empty(N, 441, H, W, device="cuda")
 for _ in range(3): ops.correlation_forward(p, x, y, out=out)
-dbg = torch.zeros(4 * 1024 + 4 * 8 * 1024, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4 * 1024 + 4 * 8 * 1024 + 2 * 1024, dtype=torch.int64, device="cuda")
+if len(sys.argv) > 1: _lib.lib().fn2_debug_set_correlation_impl(int(sys.argv[1]))
 L = _lib.lib(); L.fn2_debug_set_correlation_trace.argtypes = [C.c_void_p]
 L.fn2_debug_set_correlation_trace(C.c_void_p(dbg.data_ptr()))
 ops.correlation_forward(p, x, y, out=out); torch.cuda.synchronize()
 L.fn2_debug_set_correlation_trace(None)
 raw = dbg.cpu().numpy()
 d = raw[:4 * 1024].reshape(-1, 4)
-phases = raw[4 * 1024:].reshape(1024, 8, 4)
+phases = raw[4 * 1024:4 * 1024 + 4 * 8 * 1024].reshape(1024, 8, 4)
+rt = raw[4 * 1024 + 4 * 8 * 1024:].reshape(1024, 2)
+if rt.any():
+    rr = rt[rt[:, 0] != 0]
+    print("wall-clock span of all workgroups: %.2f us (100 MHz ticks)" % ((rr[:, 1].max() - rr[:, 0].min()) / 100.0))
 bidx = np.nonzero(d[:, 0] != 0)[0]
 d = d[d[:, 0] != 0]
 hw = d[:, 3] & 0xffffffff; xcc = (d[:, 3] >> 32) & 0xf; heavy = (d[:, 3] >> 63) & 1
@@ -32,10 +37,9 @@ key = grp
 print("blocks", len(d), "heavy", int(heavy.sum()), "distinct CUs", len(set(key.tolist())))
 print("span of kernel (max over XCDs)", int(end.max()), "shader cycles")
 for name, arr in [("start", start), ("loop_end", loop), ("end", end)]:
-    print(name, "heavy: min/med/max", int(arr[heavy == 1].min()), int(np.median(arr[heavy == 1])), int(arr[heavy == 1].max()),
-          " light:", int(arr[heavy == 0].min()), int(np.median(arr[heavy == 0])), int(arr[heavy == 0].max()))
+    print(name, ": min/med/max", int(arr.min()), int(np.median(arr)), int(arr.max()))
 dur = end - start
-print("duration heavy med", int(np.median(dur[heavy == 1])), "light med", int(np.median(dur[heavy == 0])))
+print("duration med", int(np.median(dur)))
 # concurrency per CU at the median time
 from collections import Counter
 c = Counter(key[heavy == 1].tolist())
@@ -50,9 +54,7 @@ for q in (0.25, 0.5, 0.75):
     alive = (start <= tm) & (end >= tm)
     ca = Counter(key[alive].tolist())
     print("t=%d: alive %d (heavy %d); per-CU histogram %s" % (tm, alive.sum(), (alive & (heavy == 1)).sum(), sorted(Counter(ca.values()).items())))
-print("light blocks start: min/med/max", int(start[heavy == 0].min()), int(np.median(start[heavy == 0])), int(start[heavy == 0].max()))
 print("heavy: loop phase med", int(np.median((loop - start)[heavy == 1])), " epilogue med", int(np.median((end - loop)[heavy == 1])))
-print("light: epilogue med", int(np.median((end - loop)[heavy == 0])))
 
 hb = bidx[heavy == 1]
 P = phases[hb]                      # [heavy blocks, waves, 4]
