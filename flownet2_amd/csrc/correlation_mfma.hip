@@ -91,6 +91,7 @@ struct MfmaArgs {
   int NI, NSPAN;        // M patch rows per y-parity class, x spans
   int TH, TD;           // live / dead tasks per sample
   int LP, DP;           // live / dead list entries per XCD
+  int tune;             // experiment switch (fn2_debug_set_correlation_impl 48 + n)
 };
 
 // live N patch-rows of M patch-row I: a in [alo, ahi] (may be empty)
@@ -466,7 +467,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int S2, int R, int LO, int HI, typename Acc>
+template <int S2, int R, int LO, int HI, int ABL, typename Acc>
 __device__ __forceinline__ void k_loop_glds(Acc& acc, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
                                             unsigned lds_base, int lane, int wave, int px, int Jw, int py, int i0, int i2_0, int jS) {
   using K = Cfg<S2, R>;
@@ -517,6 +518,7 @@ __device__ __forceinline__ void k_loop_glds(Acc& acc, float* smem, const float* 
   // one LDS-DMA run: M0 = destination, 64 lanes x 4 B
   auto run = [&](int i, unsigned slot_bytes, unsigned soff) {
     lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(slot_bytes + (unsigned)ldst[i]);
+    if constexpr ((ABL & 2) != 0) return;      // profiling: no staging traffic
     if (i < G::RB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, lp, 4, voff[i], soff, 0, 0);
     else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lp, 4, voff[i], soff, 0, 0);
   };
@@ -526,7 +528,7 @@ __device__ __forceinline__ void k_loop_glds(Acc& acc, float* smem, const float* 
   const int bAddr = (kk / G::GC) * G::GS + (kk % G::GC) * G::CHB + ni * G::ROWB + px * K::JW + 4 * Jw + nj;
   const int aAddr = G::BSZ + kk * G::CSA + (ni >> 1) * G::AHALF + (ni & 1) * 32 + px * K::SPANC + 4 * Jw + nj;
   constexpr int BSTEP = (4 / G::GC) * G::GS, ASTEP = 4 * G::CSA;     // k-step r -> + r * STEP
-  constexpr int NT = (LO <= HI) ? HI - LO + 1 : 0;
+  constexpr int NT = (LO <= HI && !(ABL & 1)) ? HI - LO + 1 : 0;     // ABL bit 0 (profiling): no operand reads, no MFMAs
   constexpr int KS = G::KC / 4;
   static_assert(KS == 2, "the half-iteration schedule below is written for two k-steps per chunk");
 
@@ -604,7 +606,7 @@ __device__ __forceinline__ void k_loop_glds(Acc& acc, float* smem, const float* 
   chunk_step(F{}, F{}, c + 1, slot, o1, o0);
 }
 
-template <int S2, int R>
+template <int S2, int R, int ABL>
 __global__ void __launch_bounds__(kThreads, 6)
 corr_fwd_glds(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
               unsigned long long* __restrict__ dbg) {
@@ -634,7 +636,9 @@ corr_fwd_glds(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;     // LDS byte address of the ring
   if (k.live) {
     const int sel = tile_range_sel<S2, R>(jw, Wc);
-#define FN2_KLOOP(LO_, HI_) k_loop_glds<S2, R, LO_, HI_>(acc, smem, a_n, b_n, g, lds_base, lane, wave, px, Jw, k.py, i0, i2_0, jS)
+    if (g.tune == 1) { if (k.span == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+    if (g.tune == 2) { if (k.span == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+#define FN2_KLOOP(LO_, HI_) k_loop_glds<S2, R, LO_, HI_, ABL>(acc, smem, a_n, b_n, g, lds_base, lane, wave, px, Jw, k.py, i0, i2_0, jS)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
       case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
@@ -652,7 +656,7 @@ corr_fwd_glds(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #ifdef FN2_ABLATION
   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
-  epilogue<S2, R, true>(acc, smem, top, g, k, tid, lane, px, Jw);
+  epilogue<S2, R, !(ABL & 4)>(acc, smem, top, g, k, tid, lane, px, Jw);
 #ifdef FN2_ABLATION
   if (dbg && threadIdx.x == 0) {
     unsigned hwid, xcc;
@@ -668,7 +672,302 @@ corr_fwd_glds(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #endif
 }
 
-int g_corr_stage = 0;   // 0 = LDS-DMA staging (default), 1 = register staging (the first-generation kernel)
+// =====================================================================================================
+// Paired-parity variant (stride_2 = 2, R = 10, W % 4 == 0): the kernel FlowNetC / FlowNet2 run.
+// A wave owns BOTH x parities of its 4x4 class patch (2 M tiles, 12 accumulator tiles), a workgroup is 4 waves.
+// That makes the staged rows usable in their natural pixel order -- a lane's operand for the two parities is the
+// 8-byte pair (x, x+1) -- so
+//   * the rows arrive by 16-byte LDS-DMA (buffer_load_dwordx4 ... lds), 13 wave instructions per 8-channel chunk
+//     instead of 52 dword ones: the dword kernel spends as long filling LDS (~10 cycles per wave instruction in
+//     the texture path) as it spends in the matrix pipe;
+//   * one ds_read_b64 feeds two MFMAs (7 reads per 12 MFMAs instead of 14), conflict-free: ds_read_b64 is
+//     serviced in two 32-lane halves over 64 banks; in a half, lane group kk = 0/1 takes bank bit 5 (channel
+//     stride 288 = 32 mod 64 dwords) and the 4 x 4 positions spread over rows (72 dwords = 8 mod 64) x pairs;
+//   * twice the MFMA run (24) per barrier, half the waves to synchronise.
+// First-map rows are only 32 dwords, so their 16-byte slots are XOR-swizzled (row bit 1 -> slot bit 2, channel
+// bit 0 -> slot bit 1) on the SOURCE side of the DMA and in the read address alike.
+template <int R>
+struct HCfg {
+  using K = Cfg<2, R>;
+  static constexpr int WAVES = 4, THREADS = 256;
+  static constexpr int KC = 8, NBUF = 3;
+  static constexpr int BQ = K::BPX / 4;               // 16-byte slots per staged second-map row (18)
+  static constexpr int AQ = K::SPANPX / 4;            // ... first-map row (8)
+  static constexpr int CHB = 4 * K::BPX;              // dwords per channel, second map (288)
+  static constexpr int CHA = 4 * K::SPANPX;           //                     first map (128)
+  static constexpr int BSZ = KC * CHB, ASZ = KC * CHA;
+  static constexpr int CHUNK = BSZ + ASZ;             // floats per ring slot (3328)
+  static constexpr int NBR = BSZ / 256, NAR = ASZ / 256, NRUN = NBR + NAR;     // 1 KiB runs per chunk: 9 + 4
+  static constexpr int RPW = cdiv(NRUN, WAVES);       // runs per wave: RPW for waves < NRUN % WAVES (or all), else RPW - 1
+  static constexpr int NFULL = NRUN % WAVES == 0 ? WAVES : NRUN % WAVES;
+  static constexpr int LDS_FLOATS = cmax(NBUF * CHUNK, K::OROWS * K::XS);
+  static_assert(R == 10, "bank analysis above is for 72-pixel rows");
+  static_assert(BSZ % 256 == 0 && ASZ % 256 == 0 && K::BPX % 4 == 0, "whole 1 KiB runs of 16-byte slots");
+  static_assert(CHB % 64 == 32, "channel stride must flip bank bit 5");
+};
+
+template <int R, int LO, int HI, typename Acc>
+__device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
+                                            unsigned lds_base, int lane, int wave, int Jw, int py, int i0, int i2_0, int jS) {
+  using K = Cfg<2, R>;
+  using H = HCfg<R>;
+  const int plane = g.H * g.W;
+  constexpr unsigned OOB = 0x7ffffff0u;
+
+  // ---- run plan: run rho = i * WAVES + wave; lane -> one 16-byte slot (4 pixels of one row and channel) ----
+  unsigned voff[H::RPW];
+  int ldst[H::RPW];
+  bool isB[H::RPW];
+#pragma unroll
+  for (int i = 0; i < H::RPW; ++i) {
+    const int rho = i * H::WAVES + wave;
+    voff[i] = OOB; ldst[i] = 0; isB[i] = rho < H::NBR;
+    if (rho < H::NBR) {
+      const int sl = rho * 64 + lane;                        // slot index in [ch][row][group]
+      const int ch = sl / (4 * H::BQ), rem = sl % (4 * H::BQ);
+      const int row = rem / H::BQ, gq = rem % H::BQ;
+      const int ib = i2_0 + row, yb = 2 * ib + py, xb = 2 * (jS - R) + 4 * gq;
+      if (ib >= 0 && yb < g.H && xb >= 0 && xb < g.W) voff[i] = 4u * (unsigned)(ch * plane + yb * g.W + xb);
+      ldst[i] = rho * 1024;
+    } else if (rho < H::NRUN) {
+      const int sl = (rho - H::NBR) * 64 + lane;             // slot index in [ch][row][swizzled group]
+      const int ch = sl / (4 * H::AQ), rem = sl % (4 * H::AQ);
+      const int row = rem / H::AQ, gs = rem % H::AQ;
+      const int gq = gs ^ ((row >> 1) << 2) ^ ((ch & 1) << 1);
+      const int ya = 2 * (i0 + row) + py, xa = 2 * jS + 4 * gq;
+      if (ya < g.H && xa < g.W) voff[i] = 4u * (unsigned)(ch * plane + ya * g.W + xa);
+      ldst[i] = 4 * H::BSZ + (rho - H::NBR) * 1024;
+    }
+  }
+  const bool full = wave < H::NFULL;                         // this wave issues RPW (else RPW - 1) runs per chunk
+  const unsigned chunk_bytes = 4u * H::KC * (unsigned)plane;
+  const unsigned sample_bytes = 4u * (unsigned)g.C * (unsigned)plane;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_n), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_n), 0, sample_bytes, 0x00020000);
+  auto run = [&](int i, unsigned slot_bytes, unsigned soff) {
+    if (i == H::RPW - 1 && !full) return;                    // wave-uniform
+    lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(slot_bytes + (unsigned)ldst[i]);
+    if (isB[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, lp, 16, voff[i], soff, 0, 0);
+    else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lp, 16, voff[i], soff, 0, 0);
+  };
+  auto wait_landed = [&]() {                                  // everything but the newest chunk's runs has landed
+    if (full) wait_vmcnt<H::RPW>(); else wait_vmcnt<H::RPW - 1>();
+  };
+
+  // ---- operand addresses (dwords): lane (kk, ni, nj); k-step r contracts channel 4r + kk ----
+  const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
+  const int bAddr = kk * H::CHB + ni * K::BPX + 2 * (4 * Jw + nj);
+  const int gA = (2 * Jw + (nj >> 1)) ^ ((ni >> 1) << 2) ^ ((kk & 1) << 1);
+  const int aAddr = H::BSZ + kk * H::CHA + ni * K::SPANPX + 4 * gA + 2 * (nj & 1);
+  constexpr int BSTEP = 4 * H::CHB, ASTEP = 4 * H::CHA;
+  constexpr int NT = (LO <= HI) ? HI - LO + 1 : 0;
+  constexpr int KS = H::KC / 4;
+  static_assert(KS == 2, "half-iteration schedule below");
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+  struct Ops { f32x2 a[KS]; f32x2 b[KS][NT > 0 ? NT : 1]; };
+  auto read_ops = [&](Ops& o, const float* buf) {
+    if constexpr (NT > 0) {
+#pragma unroll
+      for (int r = 0; r < KS; ++r) {
+        o.a[r] = *reinterpret_cast<const f32x2*>(buf + aAddr + r * ASTEP);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) o.b[r][t] = *reinterpret_cast<const f32x2*>(buf + bAddr + r * BSTEP + 8 * (LO + t));
+      }
+    }
+  };
+  // step j of k-step r: tile j / 2, parity j % 2
+  auto mfma_step = [&](const Ops& o, int r, int j) {
+    if constexpr (NT > 0) {
+      const int t = j >> 1;
+      if (j & 1) acc1[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[r].y, o.b[r][t].y, acc1[LO + t], 0, 0, 0);
+      else       acc0[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[r].x, o.b[r][t].x, acc0[LO + t], 0, 0, 0);
+    }
+  };
+
+  const int nchunks = g.C / H::KC;
+  auto chunk_step = [&](auto issue_tag, auto read_tag, int c, int slot, Ops& cur, Ops& nxt) {
+    constexpr bool ISSUE = decltype(issue_tag)::value, READ = decltype(read_tag)::value;
+    int s2 = slot + 2; if (s2 >= H::NBUF) s2 -= H::NBUF;
+    int s1 = slot + 1; if (s1 >= H::NBUF) s1 -= H::NBUF;
+    if constexpr (ISSUE) {
+      const unsigned slot2_bytes = lds_base + 4u * (unsigned)(s2 * H::CHUNK);
+      const unsigned soff = (unsigned)(c + 2) * chunk_bytes;
+      constexpr int GAP = (2 * NT) / (H::RPW + 1) > 0 ? (2 * NT) / (H::RPW + 1) : 1;     // MFMAs between two DMA issues
+      int issued = 0;
+#pragma unroll
+      for (int j = 0; j < 2 * NT; ++j) {
+        mfma_step(cur, 0, j);
+        if ((j + 1) % GAP == 0 && issued < H::RPW) {
+          __builtin_amdgcn_sched_barrier(0);
+          run(issued++, slot2_bytes, soff);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < H::RPW; ++i) if (i >= issued) run(i, slot2_bytes, soff);       // NT == 0 or tiny: issue the rest
+      __builtin_amdgcn_sched_barrier(0);
+      wait_landed();
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2 * NT; ++j) mfma_step(cur, 0, j);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (READ) read_ops(nxt, smem + s1 * H::CHUNK);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2 * NT; ++j) mfma_step(cur, 1, j);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+#pragma unroll
+  for (int i = 0; i < H::RPW; ++i) run(i, lds_base, 0u);
+#pragma unroll
+  for (int i = 0; i < H::RPW; ++i) run(i, lds_base + 4u * H::CHUNK, chunk_bytes);
+  wait_landed();
+  __builtin_amdgcn_s_barrier();
+  Ops o0, o1;
+  read_ops(o0, smem);
+  int slot = 0, c = 0;
+  for (; c + 2 < nchunks; c += 2) {            // nchunks is even and >= 2 (C % 16 == 0)
+    chunk_step(T{}, T{}, c, slot, o0, o1);
+    slot = slot + 1 == H::NBUF ? 0 : slot + 1;
+    chunk_step(T{}, T{}, c + 1, slot, o1, o0);
+    slot = slot + 1 == H::NBUF ? 0 : slot + 1;
+  }
+  chunk_step(F{}, T{}, c, slot, o0, o1);
+  slot = slot + 1 == H::NBUF ? 0 : slot + 1;
+  chunk_step(F{}, F{}, c + 1, slot, o1, o0);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256, 3)
+corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
+              unsigned long long* __restrict__ dbg) {
+  using K = Cfg<2, R>;
+  using H = HCfg<R>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef FN2_ABLATION
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
+  const Task k = decode_task<2, R>(g);
+  if (!k.valid) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int Jw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = 4 * k.I, jS = K::SPANC * k.span, jw = jS + 4 * Jw;
+  const int Hc = (g.H - k.py + 1) / 2;
+  const int Wc = g.W / 2;                          // W % 4 == 0: both x parities have W / 2 class columns
+  if (i0 >= Hc) return;
+  const size_t plane = (size_t)g.H * g.W;
+  const float* a_n = b0 + (size_t)k.n * g.C * plane;
+  const float* b_n = b1 + (size_t)k.n * g.C * plane;
+  const int i2_0 = i0 - R + 4 * k.a;
+  const size_t top_n = (size_t)k.n * K::D * K::D;
+
+  // Output rows of this task: rowid = (rmi * 4 + rni) * D + oo  <->  top[n, (qq = 4a + rni - rmi, oo), y = 2 (4I + rmi) + py,
+  // 32-pixel span].  8 threads x 16 bytes per row, 32 rows per pass; offsets are 32-bit inside the sample's output
+  // (buffer store), the (rmi, rni, oo) decode is carried incrementally: 32 = 21 + 11.
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+      top + top_n * plane, 0, (unsigned)(4u * K::D * K::D * (unsigned)plane), 0x00020000);
+  auto store_rows = [&](auto from_lds) {
+    constexpr bool LDS = decltype(from_lds)::value;
+    const int xq = tid & 7, x = 2 * jS + 4 * xq;
+    if (x >= g.W) return;                                   // W % 4 == 0: a quad is inside or outside as a whole
+    int rowid = tid >> 3;                                   // < 32
+    int rni = rowid >= K::D ? 1 : 0, oo = rowid - rni * K::D, rmi = 0;
+    const unsigned hw4 = 4u * (unsigned)plane, w4 = 4u * (unsigned)g.W;
+#pragma unroll 1
+    for (; rowid < K::OROWS; rowid += H::THREADS / 8) {
+      const int qq = 4 * k.a + rni - rmi, y = 2 * (i0 + rmi) + k.py;
+      if (qq >= 0 && qq < K::D && y < g.H) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LDS) {
+          const float* src = smem + rowid * K::XS + 4 * xq;
+          v = f32x4{src[0], src[1], src[2], src[3]};
+        }
+        const unsigned off = (unsigned)(qq * K::D + oo) * hw4 + (unsigned)y * w4 + 4u * (unsigned)x;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsT, off, 0, 0);
+      }
+      oo += (H::THREADS / 8) - K::D;                        // + 32 rows = one (rmi, rni) block further, + 11
+      ++rni;
+      if (oo >= K::D) { oo -= K::D; ++rni; }
+      if (rni >= 4) { rni -= 4; ++rmi; }
+    }
+  };
+
+  if (!k.live) {          // dead task: zeros, no LDS round trip
+    store_rows(std::false_type{});
+    return;
+  }
+
+  f32x4 acc0[K::NB], acc1[K::NB];
+#pragma unroll
+  for (int b = 0; b < K::NB; ++b) { acc0[b] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  {
+    const int sel = tile_range_sel<2, R>(jw, Wc);
+#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, Jw, Jw, k.py, i0, i2_0, jS)
+    switch (sel) {
+      case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
+      case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
+      case 2: FN2_KLOOP(0, K::HI_MIN + 2); break;
+      case 3: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 0); break;
+      case 4: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 1); break;
+      case 5: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 2); break;
+      case 6: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 0); break;
+      case 7: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 1); break;
+      case 8: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 2); break;
+      default: FN2_KLOOP(1, 0); break;
+    }
+#undef FN2_KLOOP
+  }
+#ifdef FN2_ABLATION
+  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- epilogue: accumulators -> LDS image [mi][ni][o][x] -> coalesced 128-byte rows of top ----
+  {
+    const int ni = (lane & 15) >> 2, nj = lane & 3, mi = lane >> 4;
+    const float sumelems = (float)g.C;
+    const bool pow2 = (g.C & (g.C - 1)) == 0;
+    const float rcp = 1.0f / sumelems;
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oo = 4 * b + nj - r;
+        if (oo >= 0 && oo < K::D) {
+          float* dst = smem + ((mi * 4 + ni) * K::D + oo) * K::XS + 2 * (4 * Jw + r);
+          dst[0] = pow2 ? acc0[b][r] * rcp : acc0[b][r] / sumelems;
+          dst[1] = pow2 ? acc1[b][r] * rcp : acc1[b][r] / sumelems;
+        }
+      }
+    }
+    __syncthreads();
+    store_rows(std::true_type{});
+  }
+#ifdef FN2_ABLATION
+  if (dbg && threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[4 * blockIdx.x + 0] = t_start;
+    dbg[4 * blockIdx.x + 1] = t_loop;
+    dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+    dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid | (1ull << 63);
+    dbg[4 * 1024 + 4 * 8 * 1024 + 2 * blockIdx.x + 0] = rt_start;
+    dbg[4 * 1024 + 4 * 8 * 1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+int g_corr_tune = 0;
+int g_corr_stage = 0;   // 0 = automatic, 1 = register staging (first generation), 2 = dword LDS-DMA kernel even where the paired one applies
 
 template <int S2, int R>
 static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* top, hipStream_t st) {
@@ -687,6 +986,7 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
     }
   g.TH = nheavy * g.NSPAN;
   g.TD = S2 * g.NI * K::NB * g.NSPAN - g.TH;
+  g.tune = g_corr_tune;
   const long long NL = (long long)cg.N * g.TH, ND = (long long)cg.N * g.TD;
   if (NL + ND > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
   g.LP = (int)((NL + 7) / 8);
@@ -713,14 +1013,41 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
     return check_launch("correlation_forward (mfma, ablation)");
   }
 #endif
-  if (g_corr_stage == 0) {
+  if constexpr (S2 == 2 && R == 10) {
+    const bool aligned = cg.W % 4 == 0 && (long long)K::D * K::D * cg.H * cg.W < (1ll << 29) &&      // 32-bit output offsets
+        ((reinterpret_cast<uintptr_t>(b0) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(top)) & 15) == 0;
+    if (g_corr_stage == 0 && aligned) {
+      const size_t lds3 = sizeof(float) * HCfg<R>::LDS_FLOATS;
+      static bool attr3_set = false;
+      if (!attr3_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        attr3_set = true;
+      }
+      hipLaunchKernelGGL((corr_fwd_pair<R>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+      return check_launch("correlation_forward (mfma, paired parities)");
+    }
+  }
+  if (g_corr_stage != 1) {
     const size_t lds2 = sizeof(float) * GCfg<S2, R>::LDS_FLOATS;
     static bool attr2_set = false;
     if (!attr2_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_glds<S2, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_glds<S2, R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       attr2_set = true;
     }
-    hipLaunchKernelGGL((corr_fwd_glds<S2, R>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg);
+#ifdef FN2_ABLATION
+    if (S2 == 2 && R == 10 && g_corr_tune >= 16) {       // impl 64 + bits: 1 no MFMA, 2 no staging loads, 4 no stores
+      switch (g_corr_tune - 16) {
+        case 1: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 1>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+        case 2: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 2>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+        case 3: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 3>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+        case 4: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 4>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+        case 6: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 6>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+        default: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 7>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+      }
+      return check_launch("correlation_forward (mfma, lds-dma, ablation)");
+    }
+#endif
+    hipLaunchKernelGGL((corr_fwd_glds<S2, R, 0>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg);
     return check_launch("correlation_forward (mfma, lds-dma)");
   }
   hipLaunchKernelGGL((corr_fwd_mfma<S2, R, 0>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg);
