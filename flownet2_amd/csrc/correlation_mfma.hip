@@ -328,17 +328,30 @@ __device__ __forceinline__ void epilogue(const Acc& acc, float* smem, float* __r
     }
   }
   __syncthreads();
+  // rowid = (rmi * 4 + rni) * D + oo  <->  top[n, (qq = 4a + rni - rmi, oo), y = S2 (4I + rmi) + py, 32-pixel span];
+  // 16 rows per pass, (rmi, rni, oo) carried incrementally, 32-bit offsets inside the sample's output (buffer store).
   const int jS = K::SPANC * k.span, i0 = 4 * k.I;
   const int xl = tid % K::SPANPX;
   const int x = S2 * jS + xl;
-  const size_t top_n = (size_t)k.n * K::D * K::D;
   if (x < g.W && STORE) {
-    for (int rowid = tid / K::SPANPX; rowid < K::OROWS; rowid += kThreads / K::SPANPX) {
-      const int rmi = rowid / (4 * K::D), rni = (rowid / K::D) % 4, oo = rowid % K::D;
+    const unsigned plane = (unsigned)g.H * (unsigned)g.W;
+    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+        top + (size_t)k.n * K::D * K::D * plane, 0, 4u * K::D * K::D * plane, 0x00020000);
+    const unsigned hw4 = 4u * plane, w4 = 4u * (unsigned)g.W;
+    constexpr int STEP = kThreads / K::SPANPX;
+    int rowid = tid / K::SPANPX, rmi = 0, rni = 0, oo = rowid;
+    while (oo >= K::D) { oo -= K::D; ++rni; }
+#pragma unroll 1
+    for (; rowid < K::OROWS; rowid += STEP) {
       const int qq = 4 * k.a + rni - rmi;   // q + R
       const int y = S2 * (i0 + rmi) + k.py;
-      if (qq >= 0 && qq < K::D && y < g.H)
-        top[((top_n + (size_t)qq * K::D + oo) * g.H + y) * g.W + x] = smem[rowid * K::XS + xl];
+      if (qq >= 0 && qq < K::D && y < g.H) {
+        const unsigned off = (unsigned)(qq * K::D + oo) * hw4 + (unsigned)y * w4 + 4u * (unsigned)x;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, smem[rowid * K::XS + xl]), rsT, off, 0, 0);
+      }
+      oo += STEP;
+      while (oo >= K::D) { oo -= K::D; ++rni; }
+      while (rni >= 4) { rni -= 4; ++rmi; }
     }
   }
 }
@@ -1014,7 +1027,7 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   }
 #endif
   if constexpr (S2 == 2 && R == 10) {
-    const bool aligned = cg.W % 4 == 0 && (long long)K::D * K::D * cg.H * cg.W < (1ll << 29) &&      // 32-bit output offsets
+    const bool aligned = cg.W % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(b0) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(top)) & 15) == 0;
     if (g_corr_stage == 0 && aligned) {
       const size_t lds3 = sizeof(float) * HCfg<R>::LDS_FLOATS;
@@ -1058,6 +1071,7 @@ bool corr_fwd_mfma_supported(const CorrGeom& g) {
   if (g.K != 1 || g.s1 != 1 || g.type != FN2_CORR_MULTIPLY || g.pad != g.md) return false;
   if (g.C % kKC != 0) return false;
   if ((long long)g.C * g.H * g.W >= (1ll << 28)) return false;      // 32-bit byte offsets in the staging loads
+  if ((long long)g.topC * g.H * g.W >= (1ll << 30)) return false;   // ... and in the output stores
   if (g.s2 == 2 && g.ngr == 10) return true;     // FlowNetC / FlowNet2: max_displacement 20, stride_2 2
   if (g.s2 == 1 && g.ngr == 4) return true;      // 9x9 cost volumes (max_displacement 4, stride_2 1)
   if (g.s2 == 2 && g.ngr == 4) return true;
