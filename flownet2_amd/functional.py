@@ -108,3 +108,13 @@ def upsample_flow_deconv(x, weight, bias=None):
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
         return torch.nn.functional.conv_transpose2d(x, weight, bias, stride=2, padding=1)
     return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)
+
+
+def conv_bias_leaky_relu(y, bias, negative_slope=0.1):
+    """Bias term + in-place leaky ReLU on a bias-free convolution output.  One HIP pass when no gradient is needed
+    (deploy nets); stock torch ops otherwise (training keeps autograd)."""
+    if (torch.is_grad_enabled() and (y.requires_grad or (bias is not None and bias.requires_grad))) or not y.is_contiguous():
+        if bias is not None:
+            y = y + bias.view(1, -1, 1, 1)
+        return torch.nn.functional.leaky_relu(y, negative_slope)
+    return ops.bias_leaky_relu_(y, bias, negative_slope)

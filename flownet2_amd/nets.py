@@ -70,12 +70,18 @@ def num_params(params) -> int:
     return sum(int(v.numel()) for v in params.values())
 
 
-def _conv(x, P, name, stride, pad, act=True):
+def _conv(x, P, name, stride, pad, act=True, backend=None):
+    """Convolution (+ ReLU{negative_slope 0.1}).  With a backend that has conv_bias_leaky_relu the library runs the
+    bias-free convolution and bias + activation are one in-place pass (csrc/bias_act.hip) instead of two."""
+    if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
+        return backend.conv_bias_leaky_relu(F.conv2d(x, P[name + ".w"], None, stride=stride, padding=pad), P[name + ".b"], NEG_SLOPE)
     y = F.conv2d(x, P[name + ".w"], P[name + ".b"], stride=stride, padding=pad)
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
-def _deconv(x, P, name, act=True):
+def _deconv(x, P, name, act=True, backend=None):
+    if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
+        return backend.conv_bias_leaky_relu(F.conv_transpose2d(x, P[name + ".w"], None, stride=2, padding=1), P[name + ".b"], NEG_SLOPE)
     y = F.conv_transpose2d(x, P[name + ".w"], P[name + ".b"], stride=2, padding=1)
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
@@ -94,13 +100,13 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
         return _deconv(x, P, name, act=False)
 
     flow6 = pf(conv6_1, "Convolution1")
-    c5 = torch.cat([conv5_1, _deconv(conv6_1, P, "deconv5"), up(flow6, "upsample_flow6to5")], 1)
+    c5 = torch.cat([conv5_1, _deconv(conv6_1, P, "deconv5", backend=backend), up(flow6, "upsample_flow6to5")], 1)
     flow5 = pf(c5, "Convolution2")
-    c4 = torch.cat([conv4_1, _deconv(c5, P, "deconv4"), up(flow5, "upsample_flow5to4")], 1)
+    c4 = torch.cat([conv4_1, _deconv(c5, P, "deconv4", backend=backend), up(flow5, "upsample_flow5to4")], 1)
     flow4 = pf(c4, "Convolution3")
-    c3 = torch.cat([conv3_1, _deconv(c4, P, "deconv3"), up(flow4, "upsample_flow4to3")], 1)
+    c3 = torch.cat([conv3_1, _deconv(c4, P, "deconv3", backend=backend), up(flow4, "upsample_flow4to3")], 1)
     flow3 = pf(c3, "Convolution4")
-    c2 = torch.cat([conv2, _deconv(c3, P, "deconv2"), up(flow3, "upsample_flow3to2")], 1)
+    c2 = torch.cat([conv2, _deconv(c3, P, "deconv2", backend=backend), up(flow3, "upsample_flow3to2")], 1)
     flow2 = pf(c2, "Convolution5")
     return {2: flow2, 3: flow3, 4: flow4, 5: flow5, 6: flow6}
 
@@ -109,34 +115,34 @@ def flownet_c_core(P, img0, img1, backend):
     """Pre-processed images [N,3,H,W] (H, W multiples of 64) -> {scale: flow prediction /20}."""
     n = img0.shape[0]
     x = torch.cat([img0, img1], 0)                 # siamese towers share weights (param { name: } sharing, net.cpp:451-540)
-    c1 = _conv(x, P, "conv1", 2, 3)
-    c2 = _conv(c1, P, "conv2", 2, 2)
-    c3 = _conv(c2, P, "conv3", 2, 2)
+    c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
+    c2 = _conv(c1, P, "conv2", 2, 2, backend=backend)
+    c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
     c3a, c3b = c3[:n], c3[n:]
     corr = backend.correlation(c3a, c3b, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
     corr = F.leaky_relu(corr, NEG_SLOPE)
-    redir = _conv(c3a, P, "conv_redir", 1, 0)
-    c31 = _conv(torch.cat([redir, corr], 1), P, "conv3_1", 1, 1)
-    c4 = _conv(c31, P, "conv4", 2, 1)
-    c41 = _conv(c4, P, "conv4_1", 1, 1)
-    c5 = _conv(c41, P, "conv5", 2, 1)
-    c51 = _conv(c5, P, "conv5_1", 1, 1)
-    c6 = _conv(c51, P, "conv6", 2, 1)
-    c61 = _conv(c6, P, "conv6_1", 1, 1)
+    redir = _conv(c3a, P, "conv_redir", 1, 0, backend=backend)
+    c31 = _conv(torch.cat([redir, corr], 1), P, "conv3_1", 1, 1, backend=backend)
+    c4 = _conv(c31, P, "conv4", 2, 1, backend=backend)
+    c41 = _conv(c4, P, "conv4_1", 1, 1, backend=backend)
+    c5 = _conv(c41, P, "conv5", 2, 1, backend=backend)
+    c51 = _conv(c5, P, "conv5_1", 1, 1, backend=backend)
+    c6 = _conv(c51, P, "conv6", 2, 1, backend=backend)
+    c61 = _conv(c6, P, "conv6_1", 1, 1, backend=backend)
     return _decoder(P, c61, c51, c41, c31, c2[:n], backend)
 
 
 def flownet_s_core(P, x, backend=None):
-    c1 = _conv(x, P, "conv1", 2, 3)
-    c2 = _conv(c1, P, "conv2", 2, 2)
-    c3 = _conv(c2, P, "conv3", 2, 2)
-    c31 = _conv(c3, P, "conv3_1", 1, 1)
-    c4 = _conv(c31, P, "conv4", 2, 1)
-    c41 = _conv(c4, P, "conv4_1", 1, 1)
-    c5 = _conv(c41, P, "conv5", 2, 1)
-    c51 = _conv(c5, P, "conv5_1", 1, 1)
-    c6 = _conv(c51, P, "conv6", 2, 1)
-    c61 = _conv(c6, P, "conv6_1", 1, 1)
+    c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
+    c2 = _conv(c1, P, "conv2", 2, 2, backend=backend)
+    c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
+    c31 = _conv(c3, P, "conv3_1", 1, 1, backend=backend)
+    c4 = _conv(c31, P, "conv4", 2, 1, backend=backend)
+    c41 = _conv(c4, P, "conv4_1", 1, 1, backend=backend)
+    c5 = _conv(c41, P, "conv5", 2, 1, backend=backend)
+    c51 = _conv(c5, P, "conv5_1", 1, 1, backend=backend)
+    c6 = _conv(c51, P, "conv6", 2, 1, backend=backend)
+    c61 = _conv(c6, P, "conv6_1", 1, 1, backend=backend)
     return _decoder(P, c61, c51, c41, c31, c2, backend)
 
 
@@ -158,14 +164,15 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
     pre = []
     for im in (img0, img1):
         x = im * (1.0 / 255.0)                                                     # Eltwise, coeff 1/255
-        x = backend.resample(x, ah, aw)                                            # Resample to ADAPTED size
+        if (ah, aw) != (H, W):                                                     # Resample to ADAPTED size; at equal size the LINEAR
+            x = backend.resample(x, ah, aw)                                        # kernel is the identity (one tap of weight 1): skipped
         pre.append(x - mean.view(1, 3, 1, 1))                                      # DataAugmentation mean subtraction (deploy slice)
     if kind == "C":
         flows = flownet_c_core(P, pre[0], pre[1], backend)
     else:
         flows = flownet_s_core(P, torch.cat(pre, 1), backend)
     flow = flows[2] * FLOW_SCALE                                                    # Eltwise, coeff 20
-    flow = backend.resample(flow, H, W)                                             # Resample to TARGET size
+    flow = backend.resample(flow, H, W)                                             # Resample to TARGET size (x4 up-sampling)
     scale = torch.tensor([W / float(aw), H / float(ah)], device=flow.device, dtype=flow.dtype)   # run-flownet.py:47-48
     return flow * scale.view(1, 2, 1, 1)                                            # 1x1 conv, diagonal filler
 
@@ -272,32 +279,32 @@ def _up(P, x, name, backend):
 
 
 def flownet_sd_core(P, x, backend):
-    c0 = _conv(x, P, "conv0", 1, 1)
-    c1 = _conv(_conv(c0, P, "conv1", 2, 1), P, "conv1_1", 1, 1)
-    c2 = _conv(_conv(c1, P, "conv2", 2, 1), P, "conv2_1", 1, 1)
-    c3 = _conv(_conv(c2, P, "conv3", 2, 1), P, "conv3_1", 1, 1)
-    c4 = _conv(_conv(c3, P, "conv4", 2, 1), P, "conv4_1", 1, 1)
-    c5 = _conv(_conv(c4, P, "conv5", 2, 1), P, "conv5_1", 1, 1)
-    c6 = _conv(_conv(c5, P, "conv6", 2, 1), P, "conv6_1", 1, 1)
+    c0 = _conv(x, P, "conv0", 1, 1, backend=backend)
+    c1 = _conv(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, backend=backend)
+    c2 = _conv(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, backend=backend)
+    c3 = _conv(_conv(c2, P, "conv3", 2, 1, backend=backend), P, "conv3_1", 1, 1, backend=backend)
+    c4 = _conv(_conv(c3, P, "conv4", 2, 1, backend=backend), P, "conv4_1", 1, 1, backend=backend)
+    c5 = _conv(_conv(c4, P, "conv5", 2, 1, backend=backend), P, "conv5_1", 1, 1, backend=backend)
+    c6 = _conv(_conv(c5, P, "conv6", 2, 1, backend=backend), P, "conv6_1", 1, 1, backend=backend)
     flow6 = _pf(P, c6, "Convolution1", backend)
-    cat5 = torch.cat([c5, _deconv(c6, P, "deconv5"), _up(P, flow6, "upsample_flow6to5", backend)], 1)
+    cat5 = torch.cat([c5, _deconv(c6, P, "deconv5", backend=backend), _up(P, flow6, "upsample_flow6to5", backend)], 1)
     flow5 = _pf(P, _conv(cat5, P, "interconv5", 1, 1, act=False), "Convolution2", backend)
-    cat4 = torch.cat([c4, _deconv(cat5, P, "deconv4"), _up(P, flow5, "upsample_flow5to4", backend)], 1)
+    cat4 = torch.cat([c4, _deconv(cat5, P, "deconv4", backend=backend), _up(P, flow5, "upsample_flow5to4", backend)], 1)
     flow4 = _pf(P, _conv(cat4, P, "interconv4", 1, 1, act=False), "Convolution3", backend)
-    cat3 = torch.cat([c3, _deconv(cat4, P, "deconv3"), _up(P, flow4, "upsample_flow4to3", backend)], 1)
+    cat3 = torch.cat([c3, _deconv(cat4, P, "deconv3", backend=backend), _up(P, flow4, "upsample_flow4to3", backend)], 1)
     flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False), "Convolution4", backend)
-    cat2 = torch.cat([c2, _deconv(cat3, P, "deconv2"), _up(P, flow3, "upsample_flow3to2", backend)], 1)
+    cat2 = torch.cat([c2, _deconv(cat3, P, "deconv2", backend=backend), _up(P, flow3, "upsample_flow3to2", backend)], 1)
     return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False), "Convolution5", backend)      # 1/4 resolution, units px/20? (SD: px/0.05)
 
 
 def fusion_core(P, x, backend):
-    c0 = _conv(x, P, "conv0", 1, 1)
-    c1 = _conv(_conv(c0, P, "conv1", 2, 1), P, "conv1_1", 1, 1)
-    c2 = _conv(_conv(c1, P, "conv2", 2, 1), P, "conv2_1", 1, 1)
+    c0 = _conv(x, P, "conv0", 1, 1, backend=backend)
+    c1 = _conv(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, backend=backend)
+    c2 = _conv(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, backend=backend)
     flow2 = _pf(P, c2, "Convolution5", backend)
-    cat1 = torch.cat([c1, _deconv(c2, P, "deconv1"), _up(P, flow2, "upsample_flow2to1", backend)], 1)
+    cat1 = torch.cat([c1, _deconv(c2, P, "deconv1", backend=backend), _up(P, flow2, "upsample_flow2to1", backend)], 1)
     flow1 = _pf(P, _conv(cat1, P, "interconv1", 1, 1, act=False), "Convolution6", backend)
-    cat0 = torch.cat([c0, _deconv(cat1, P, "deconv0"), _up(P, flow1, "upsample_flow1to0", backend)], 1)
+    cat0 = torch.cat([c0, _deconv(cat1, P, "deconv0", backend=backend), _up(P, flow1, "upsample_flow1to0", backend)], 1)
     return _pf(P, _conv(cat0, P, "interconv0", 1, 1, act=False), "Convolution7", backend)        # full resolution, pixels
 
 

@@ -193,3 +193,15 @@ def upsample_flow_deconv_forward(x, weight, bias=None):
     out = torch.empty((N, 2, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
     check(_lib.lib().fn2_upsample_flow_deconv_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, H, W, _stream()))
     return out
+
+
+def bias_leaky_relu_(x, bias=None, negative_slope=0.1):
+    """In place: x[n,c] = leaky_relu(x[n,c] + bias[c]) -- the bias term + ReLU layer that follow every FlowNet conv/deconv."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        raise ValueError("bias_leaky_relu_: expected a contiguous float32 CUDA (HIP) NCHW tensor")
+    N, Cc, H, W = x.shape
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    if b is not None and b.numel() != Cc:
+        raise ValueError(f"bias must have {Cc} entries, got {b.numel()}")
+    check(_lib.lib().fn2_bias_leaky_relu_forward(_ptr(x), _ptr(b), N, Cc, H, W, C.c_float(float(negative_slope)), _stream()))
+    return x

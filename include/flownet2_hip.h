@@ -189,6 +189,16 @@ int fn2_predict_flow_conv_forward(const float* in, const float* weight, const fl
 int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const float* bias, float* out,
                                      int N, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Convolution bias + leaky ReLU, in place (one pass): top[n,c,:,:] = f(top[n,c,:,:] + bias[c]), f(t) = t > 0 ? t : t * negative_slope.
+ *   <- BaseConvolutionLayer::forward_gpu_bias, src/caffe/layers/base_conv_layer.cpp:343-348 (bias term of Convolution /
+ *      Deconvolution) followed by the in-place ReLULayer::Forward_gpu, src/caffe/layers/relu_layer.cu:8-27
+ *      (relu_param.negative_slope = 0.1 in every FlowNet prototxt).  bias may be NULL (plain leaky ReLU).
+ * Forward only; the caller runs the convolution itself without its bias term.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, int C, int H, int W, float negative_slope,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,15 @@ def predict_flow_conv_forward(x, weight, bias=None):
     return out
 
 
+def bias_leaky_relu_forward(x, bias=None, negative_slope=0.1):
+    """Returns leaky_relu(x + bias[c]) (the C twin works in place on a copy)."""
+    out = np.array(_f32(x), copy=True)
+    bias = _f32(bias) if bias is not None else None
+    N, Cc, H, W = out.shape
+    _check(lib().fn2_bias_leaky_relu_forward_cpu(_p(out), _p(bias), N, Cc, H, W, C.c_float(negative_slope)), "bias_leaky_relu_forward")
+    return out
+
+
 def upsample_flow_deconv_forward(x, weight, bias=None):
     x, weight = _f32(x), _f32(weight)
     bias = _f32(bias) if bias is not None else None

@@ -48,3 +48,7 @@ def predict_flow_conv(x, weight, bias=None):
 
 def upsample_flow_deconv(x, weight, bias=None):
     return torch.from_numpy(oracle.upsample_flow_deconv_forward(_np(x), _np(weight), _np(bias) if bias is not None else None))
+
+
+def conv_bias_leaky_relu(y, bias, negative_slope=0.1):
+    return torch.from_numpy(oracle.bias_leaky_relu_forward(_np(y), _np(bias) if bias is not None else None, negative_slope))

@@ -660,3 +660,20 @@ FN2_API int fn2_upsample_flow_deconv_forward_cpu(const float* in, const float* w
         }
   return FN2_OK;
 }
+
+/* Convolution bias term + in-place leaky ReLU (base_conv_layer.cpp:343-348 forward_gpu_bias: top += bias[c];
+ * relu_layer.cu:8-14 ReLUForward: out = in > 0 ? in : in * negative_slope), fp32 like the reference. */
+FN2_API int fn2_bias_leaky_relu_forward_cpu(float* data, const float* bias, int N, int C, int H, int W, float negative_slope) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+#pragma omp parallel for
+  for (long long p = 0; p < (long long)N * C; ++p) {
+    const float b = bias ? bias[p % C] : 0.f;
+    float* d = data + (size_t)p * hw;
+    for (size_t i = 0; i < hw; ++i) {
+      const float t = d[i] + b;
+      d[i] = t > 0.f ? t : t * negative_slope;
+    }
+  }
+  return FN2_OK;
+}

@@ -322,6 +322,28 @@ def test_upsample_flow_deconv(shape):
     assert_close(out, oracle.upsample_flow_deconv_forward(x, w, b), 1e-6, "upsample_flow vs oracle")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 20, 28), (3, 5, 7, 9), (1, 130, 3, 5), (2, 16, 1, 1)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_bias_leaky_relu_inplace(shape, with_bias):
+    """Bias term + in-place leaky ReLU: bit-exact against the oracle (one fp32 add, one compare / multiply)."""
+    x = rand(shape, 40)
+    b = rand((shape[1],), 41) if with_bias else None
+    y = dev(x)
+    out = ops.bias_leaky_relu_(y, dev(b) if with_bias else None, 0.1)
+    assert out.data_ptr() == y.data_ptr()
+    ref = oracle.bias_leaky_relu_forward(x, b, 0.1)
+    np.testing.assert_array_equal(host(out), ref)
+    t = torch.from_numpy(x) + (torch.from_numpy(b).view(1, -1, 1, 1) if with_bias else 0.0)
+    np.testing.assert_allclose(ref, torch.nn.functional.leaky_relu(t, 0.1).numpy(), rtol=0, atol=1e-7)
+
+
+def test_identity_resample_is_exact():
+    """deploy_forward skips the ADAPTED-size Resample when the size does not change: the kernel is then the identity."""
+    x = rand((2, 3, 64, 128), 42)
+    np.testing.assert_array_equal(host(ops.resample_forward(dev(x), 64, 128)), x)
+    np.testing.assert_array_equal(oracle.resample_forward(x, 64, 128), x)
+
+
 def test_flownet2_stack_end_to_end_epe():
     """Full FlowNet2 (C -> S -> S || SD -> fusion; 4 FlowWarp, 4+ ChannelNorm, 7 Resample) on the GPU against the same
     graph on the host (C oracle ops + torch-CPU conv).  north_star tolerance: EPE <= 1e-4 px."""

@@ -226,3 +226,11 @@ def test_downsample_vs_fp64_with_nan_voting(shape):
     ref = R.downsample(x, Hout, Wout)
     assert np.array_equal(np.isnan(out), np.isnan(ref))
     np.testing.assert_allclose(np.nan_to_num(out), np.nan_to_num(ref), atol=2e-6)
+
+
+def test_bias_leaky_relu_oracle_matches_torch():
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((2, 6, 5, 7)).astype(np.float32); b = rng.standard_normal(6).astype(np.float32)
+    ref = torch.nn.functional.leaky_relu(torch.from_numpy(x) + torch.from_numpy(b).view(1, -1, 1, 1), 0.1).numpy()
+    np.testing.assert_allclose(oracle.bias_leaky_relu_forward(x, b, 0.1), ref, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(oracle.bias_leaky_relu_forward(x, None, 0.1), torch.nn.functional.leaky_relu(torch.from_numpy(x), 0.1).numpy(), rtol=0, atol=1e-7)
