@@ -118,3 +118,13 @@ def conv_bias_leaky_relu(y, bias, negative_slope=0.1):
             y = y + bias.view(1, -1, 1, 1)
         return torch.nn.functional.leaky_relu(y, negative_slope)
     return ops.bias_leaky_relu_(y, bias, negative_slope)
+
+
+def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
+    """Stem convolution + bias + leaky ReLU.  Returns None when the fused HIP kernel does not apply (autograd needed or
+    unsupported shape): the caller then runs the library convolution."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return None
+    if not ops.conv_k7s2_relu_supported(x.shape[1], x.shape[2], x.shape[3], weight.shape[0]):
+        return None
+    return ops.conv_k7s2_relu_forward(x.contiguous(), weight.contiguous(), bias, negative_slope)

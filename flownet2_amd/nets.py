@@ -73,9 +73,14 @@ def num_params(params) -> int:
 def _conv(x, P, name, stride, pad, act=True, backend=None):
     """Convolution (+ ReLU{negative_slope 0.1}).  With a backend that has conv_bias_leaky_relu the library runs the
     bias-free convolution and bias + activation are one in-place pass (csrc/bias_act.hip) instead of two."""
+    w = P[name + ".w"]
+    if act and stride == 2 and pad == 3 and w.shape[2] == 7 and backend is not None and hasattr(backend, "conv_k7s2_relu"):
+        y = backend.conv_k7s2_relu(x, w, P[name + ".b"], NEG_SLOPE)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
+        if y is not None:
+            return y
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
-        return backend.conv_bias_leaky_relu(F.conv2d(x, P[name + ".w"], None, stride=stride, padding=pad), P[name + ".b"], NEG_SLOPE)
-    y = F.conv2d(x, P[name + ".w"], P[name + ".b"], stride=stride, padding=pad)
+        return backend.conv_bias_leaky_relu(F.conv2d(x, w, None, stride=stride, padding=pad), P[name + ".b"], NEG_SLOPE)
+    y = F.conv2d(x, w, P[name + ".b"], stride=stride, padding=pad)
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 

@@ -205,3 +205,21 @@ def bias_leaky_relu_(x, bias=None, negative_slope=0.1):
         raise ValueError(f"bias must have {Cc} entries, got {b.numel()}")
     check(_lib.lib().fn2_bias_leaky_relu_forward(_ptr(x), _ptr(b), N, Cc, H, W, C.c_float(float(negative_slope)), _stream()))
     return x
+
+
+def conv_k7s2_relu_supported(Cin, Hin, Win, Cout) -> bool:
+    return bool(_lib.lib().fn2_conv_k7s2_relu_supported(int(Cin), int(Hin), int(Win), int(Cout)))
+
+
+def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
+    """leaky_relu(Convolution{kernel 7, stride 2, pad 3}(x) + bias): conv1 + ReLU1 of the FlowNet encoders, one kernel."""
+    x, w = _chk(x, "bottom[0]"), _chk(weight, "weight")
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 7, 7):
+        raise ValueError(f"stem weight must be [Cout,{Cin},7,7], got {tuple(w.shape)}")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    out = torch.empty((N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_conv_k7s2_relu_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, Cin, H, W, Cout,
+                                                C.c_float(float(negative_slope)), _stream()))
+    return out

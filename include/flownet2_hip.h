@@ -199,6 +199,20 @@ int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const
 int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, int C, int H, int W, float negative_slope,
                                 void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stem convolution of the FlowNet encoders, fused with its bias and ReLU:
+ *   top = leaky_relu(Convolution{kernel_size 7, stride 2, pad 3}(bottom) + bias, negative_slope)
+ *   <- conv1 + ReLU1 of FlowNetC / FlowNetS: ConvolutionLayer::Forward_gpu, src/caffe/layers/conv_layer.cu:8-23
+ *      (forward_gpu_gemm + forward_gpu_bias, base_conv_layer.cpp:325-348; weight [Cout, Cin, 7, 7]) followed by the in-place
+ *      ReLULayer::Forward_gpu, src/caffe/layers/relu_layer.cu:8-27.
+ *   top is [N, Cout, (Hin - 1) / 2 + 1, (Win - 1) / 2 + 1].  fn2_conv_k7s2_relu_supported tells whether this build has a
+ *   kernel for the shape (Cin 3 or 6, Cout % 64 == 0, Win % 8 == 0); callers keep the library convolution otherwise.
+ *   Forward only.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_conv_k7s2_relu_supported(int Cin, int Hin, int Win, int Cout);
+int fn2_conv_k7s2_relu_forward(const float* bottom, const float* weight, const float* bias, float* top,
+                               int N, int Cin, int Hin, int Win, int Cout, float negative_slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -337,6 +337,27 @@ def test_bias_leaky_relu_inplace(shape, with_bias):
     np.testing.assert_allclose(ref, torch.nn.functional.leaky_relu(t, 0.1).numpy(), rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 128, 64), (1, 6, 40, 64, 64), (2, 3, 33, 72, 128), (1, 3, 320, 448, 64), (1, 3, 7, 8, 64)])
+def test_stem_conv_k7s2_relu(shape):
+    """conv1 + bias + ReLU1 fused kernel vs torch fp64 conv2d (the stock Caffe arithmetic) on the CPU."""
+    N, Cin, H, W, Cout = shape
+    x, w, b = rand((N, Cin, H, W), 50), rand((Cout, Cin, 7, 7), 51, 0.1), rand((Cout,), 52)
+    assert ops.conv_k7s2_relu_supported(Cin, H, W, Cout)
+    out = host(ops.conv_k7s2_relu_forward(dev(x), dev(w), dev(b), 0.1))
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(),
+                                                                    torch.from_numpy(b).double(), stride=2, padding=3), 0.1).numpy()
+    assert out.shape == ref.shape
+    assert_close(out, ref.astype(np.float32), 5e-6, "stem conv vs torch fp64")
+
+
+def test_stem_conv_unsupported_shapes_are_reported():
+    assert not ops.conv_k7s2_relu_supported(3, 64, 100, 64)      # width not a multiple of 8
+    assert not ops.conv_k7s2_relu_supported(12, 64, 128, 64)     # stacked FlowNetS inputs keep the library path
+    assert not ops.conv_k7s2_relu_supported(3, 64, 128, 32)
+    with pytest.raises(Exception):
+        ops.conv_k7s2_relu_forward(dev(rand((1, 3, 64, 100), 1)), dev(rand((64, 3, 7, 7), 2)), None)
+
+
 def test_identity_resample_is_exact():
     """deploy_forward skips the ADAPTED-size Resample when the size does not change: the kernel is then the identity."""
     x = rand((2, 3, 64, 128), 42)
