@@ -192,6 +192,18 @@ def bias_leaky_relu_forward(x, bias=None, negative_slope=0.1):
     return out
 
 
+def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
+    x, weight = _f32(x), _f32(weight)
+    bias = _f32(bias) if bias is not None else None
+    N, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    assert weight.shape == (Cout, Cin, 7, 7)
+    out = np.empty((N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1), np.float32)
+    _check(lib().fn2_conv_k7s2_relu_forward_cpu(_p(x), _p(weight), _p(bias), _p(out), N, Cin, H, W, Cout, C.c_float(negative_slope)),
+           "conv_k7s2_relu_forward")
+    return out
+
+
 def upsample_flow_deconv_forward(x, weight, bias=None):
     x, weight = _f32(x), _f32(weight)
     bias = _f32(bias) if bias is not None else None

@@ -677,3 +677,32 @@ FN2_API int fn2_bias_leaky_relu_forward_cpu(float* data, const float* bias, int 
   }
   return FN2_OK;
 }
+
+/* conv1 + ReLU1 of the FlowNet encoders: Convolution{kernel_size 7, stride 2, pad 3} (conv_layer.cpp:25-40 /
+ * base_conv_layer.cpp:255-318: im2col + GEMM + bias) and the in-place ReLU with negative_slope (relu_layer.cpp:23-30).
+ * Direct loops; the contraction is accumulated in double (the reference's SGEMM order is library-defined). */
+FN2_API int fn2_conv_k7s2_relu_forward_cpu(const float* in, const float* weight, const float* bias, float* out,
+                                           int N, int Cin, int Hin, int Win, int Cout, float negative_slope) {
+  if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1) return FN2_ERR_INVALID_ARG;
+  const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co)
+      for (int y = 0; y < Ho; ++y)
+        for (int x = 0; x < Wo; ++x) {
+          double acc = bias ? bias[co] : 0.0;
+          for (int c = 0; c < Cin; ++c)
+            for (int ky = 0; ky < 7; ++ky) {
+              const int yi = 2 * y - 3 + ky;
+              if (yi < 0 || yi >= Hin) continue;
+              for (int kx = 0; kx < 7; ++kx) {
+                const int xi = 2 * x - 3 + kx;
+                if (xi < 0 || xi >= Win) continue;
+                acc += (double)weight[((co * Cin + c) * 7 + ky) * 7 + kx] * in[(((size_t)n * Cin + c) * Hin + yi) * Win + xi];
+              }
+            }
+          const float t = (float)acc;
+          out[(((size_t)n * Cout + co) * Ho + y) * Wo + x] = t > 0.f ? t : t * negative_slope;
+        }
+  return FN2_OK;
+}

@@ -31,7 +31,7 @@ def test_oracle_exports_cpu_twins():
     import oracle
     L = oracle.lib()
     for name in _lib.EXPORTS:
-        if name in ("fn2_version", "fn2_last_error_string") or name.endswith("workspace_bytes"):
+        if name in ("fn2_version", "fn2_last_error_string") or name.endswith("workspace_bytes") or name.endswith("_supported"):
             continue
         assert hasattr(L, name + "_cpu"), name + "_cpu"
 

@@ -348,6 +348,8 @@ def test_stem_conv_k7s2_relu(shape):
                                                                     torch.from_numpy(b).double(), stride=2, padding=3), 0.1).numpy()
     assert out.shape == ref.shape
     assert_close(out, ref.astype(np.float32), 5e-6, "stem conv vs torch fp64")
+    if N * H * W <= 2 * 64 * 128:
+        assert_close(out, oracle.conv_k7s2_relu_forward(x, w, b, 0.1), 5e-6, "stem conv vs oracle")
 
 
 def test_stem_conv_unsupported_shapes_are_reported():

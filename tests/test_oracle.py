@@ -234,3 +234,14 @@ def test_bias_leaky_relu_oracle_matches_torch():
     ref = torch.nn.functional.leaky_relu(torch.from_numpy(x) + torch.from_numpy(b).view(1, -1, 1, 1), 0.1).numpy()
     np.testing.assert_allclose(oracle.bias_leaky_relu_forward(x, b, 0.1), ref, rtol=0, atol=1e-7)
     np.testing.assert_allclose(oracle.bias_leaky_relu_forward(x, None, 0.1), torch.nn.functional.leaky_relu(torch.from_numpy(x), 0.1).numpy(), rtol=0, atol=1e-7)
+
+
+def test_stem_conv_oracle_matches_torch():
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 3, 13, 18)).astype(np.float32); w = (0.1 * rng.standard_normal((4, 3, 7, 7))).astype(np.float32)
+    b = rng.standard_normal(4).astype(np.float32)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(),
+                                                                    torch.from_numpy(b).double(), stride=2, padding=3), 0.1).numpy()
+    got = oracle.conv_k7s2_relu_forward(x, w, b, 0.1)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
