@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profile recipe (run on the GPU box through gpurun):  bash scripts/profile_round.sh r01
 # Writes rocprofv3 CSVs under gpurun_out/<tag>/; scripts/summarize_profiles.py turns them into profiles/<tag>_*.
-# Counters are collected in their own passes (never combined with trace domains other than the kernel trace).
+# Counters are collected in their own passes (never combined with trace domains other than the kernel trace);
+# every pass runs under its own timeout (a counter pass that aborts can otherwise hang until the box limit).
 set -u
 TAG=${1:-r01}
 R=gpurun_out/$TAG
@@ -9,13 +10,13 @@ export TMPDIR=/tmp
 mkdir -p $R
 # warm MIOpen's find-db so the profiled run shows steady-state kernels only
 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_profiled.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/corr -o corr -- python scripts/corr_microbench.py --iters 200 --backward > $R/corr_stdout.txt 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_sq -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_profiled.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/corr -o corr -- python scripts/corr_microbench.py --iters 200 --backward > $R/corr_stdout.txt 2>/dev/null
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_sq -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on streaming kernels of known byte count (dword per lane, like the staging loads)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/cal_fetch -o cal -- python scripts/hbm_calibrate.py > $R/cal_stdout.txt 2>/dev/null
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/cal_write -o cal -- python scripts/hbm_calibrate.py > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/cal_fetch -o cal -- python scripts/hbm_calibrate.py > $R/cal_stdout.txt 2>/dev/null
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/cal_write -o cal -- python scripts/hbm_calibrate.py > /dev/null 2>&1
 python bench.py --steps 30 --warmup 5 > $R/bench.json 2> $R/bench.err
 tail -c 300 $R/bench.json

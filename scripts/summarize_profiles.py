@@ -40,7 +40,7 @@ corr_avg_us = None
 for r in ks[:6]:
     lines.append("| `%s` | %s | %.2f | %.2f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    if "corr_fwd_mfma" in r["Name"]:
+    if ("corr_fwd_pair" in r["Name"] or "corr_fwd_glds" in r["Name"] or "corr_fwd_mfma" in r["Name"]):
         corr_avg_us = float(r["AverageNs"]) / 1e3
 lines += ["", "stdout of the same run:", "```", open(os.path.join(R, "corr_stdout.txt")).read().strip(), "```", ""]
 
@@ -54,13 +54,13 @@ cf = {k: counters(os.path.join(R, "cal_fetch", "cal_counter_collection.csv"), k)
 cw = {k: counters(os.path.join(R, "cal_write", "cal_counter_collection.csv"), k) for k in ("channel_norm_fwd", "flow_warp_fwd")}
 fetch_factor = known["channel_norm_fwd"][0] / (cf["channel_norm_fwd"]["FETCH_SIZE"] * 1024.0)
 write_factor = known["flow_warp_fwd"][1] / (cw["flow_warp_fwd"]["WRITE_SIZE"] * 1024.0)
-f = counters(os.path.join(R, "pmc_fetch", "corr_counter_collection.csv"), "corr_fwd_mfma")
-w = counters(os.path.join(R, "pmc_write", "corr_counter_collection.csv"), "corr_fwd_mfma")
-sq = counters(os.path.join(R, "pmc_sq", "corr_counter_collection.csv"), "corr_fwd_mfma")
+f = counters(os.path.join(R, "pmc_fetch", "corr_counter_collection.csv"), "corr_fwd_")
+w = counters(os.path.join(R, "pmc_write", "corr_counter_collection.csv"), "corr_fwd_")
+sq = counters(os.path.join(R, "pmc_sq", "corr_counter_collection.csv"), "corr_fwd_")
 fetch_bytes = f["FETCH_SIZE"] * 1024.0 * fetch_factor
 write_bytes = w["WRITE_SIZE"] * 1024.0 * write_factor
 alg = 4.0 * 8 * 40 * 56 * (2 * 256 + 441)
-lines += ["## HBM traffic of `corr_fwd_mfma<2,10>` at [8,256,40,56] (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
+lines += ["## HBM traffic of the correlation forward kernel (`corr_fwd_pair<10>`) at [8,256,40,56] (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
           "Calibration (MI355X_MICROARCH.md, HBM section: FETCH_SIZE/WRITE_SIZE are in KiB and FETCH_SIZE under-reports on gfx950;",
           "calibrate on a known byte count in the same access width): `scripts/hbm_calibrate.py`", "",
           "| kernel | known read B | FETCH_SIZE KiB | bytes / (FETCH_SIZE*1024) | known write B | WRITE_SIZE KiB | bytes / (WRITE_SIZE*1024) |", "|---|---|---|---|---|---|---|"]
@@ -97,7 +97,7 @@ for r in ks[:28]:
 lines += ["", "bench line of the unprofiled run in the same session:", "```", open(os.path.join(R, "bench.json")).read().strip(), "```", ""]
 open(os.path.join(OUT, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 
-summary = {"tag": tag, "kernel": "corr_fwd_mfma<2,10> [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
+summary = {"tag": tag, "kernel": "corr_fwd_pair<10> [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
            "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "fetch_correction": fetch_factor,
            "write_correction": write_factor, "hbm_read_bytes": fetch_bytes, "hbm_write_bytes": write_bytes,
            "traffic_bytes_per_launch": fetch_bytes + write_bytes, "algorithmic_bytes_per_launch": alg,
