@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
     ap.add_argument("--net", choices=["C", "2"], default="C", help="C = FlowNetC (headline, configs[1]); 2 = full FlowNet2 stack (configs[2]: use --batch 4 --height 384 --width 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-search", action="store_true", help="let MIOpen's find step time its candidate kernels during warm-up (measured: no gain for this net)")
     ap.add_argument("--corr-iters", type=int, default=200)
     return ap.parse_args()
 
@@ -134,6 +135,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); cuda not available")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = bool(args.conv_search)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
