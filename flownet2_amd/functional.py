@@ -128,3 +128,33 @@ def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
     if not ops.conv_k7s2_relu_supported(x.shape[1], x.shape[2], x.shape[3], weight.shape[0]):
         return None
     return ops.conv_k7s2_relu_forward(x.contiguous(), weight.contiguous(), bias, negative_slope)
+
+
+def _no_grad_needed(*ts):
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts))
+
+
+def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1):
+    """Convolution + bias + leaky ReLU the way the reference computes it -- im2col, one (batched) library GEMM, bias --
+    with our batched im2col and fused bias/activation pass around rocBLAS/hipBLASLt.  Used for the layers where that
+    beats the library's direct convolution on gfx950 (nets._use_gemm_conv).  Returns None if autograd is needed."""
+    if not _no_grad_needed(x, weight, bias):
+        return None
+    N, Cin, H, W = x.shape
+    Cout, k = weight.shape[0], weight.shape[2]
+    Hc, Wc = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    col = ops.im2col_forward(x.contiguous(), k, pad, stride)                   # [N, Cin*k*k, Hc*Wc]
+    y = torch.matmul(weight.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
+    return ops.bias_leaky_relu_(y, bias, negative_slope)
+
+
+def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negative_slope=0.1):
+    """Deconvolution + bias + leaky ReLU as the reference computes it -- weight^T x bottom (one batched library GEMM), then
+    col2im -- with the bias and activation folded into our col2im pass.  weight_t = weight.view(Cin, Cout*k*k).t().contiguous()
+    (cached by the caller).  Returns None if autograd is needed."""
+    if not _no_grad_needed(x, weight_t, bias):
+        return None
+    N, Cin, H, W = x.shape
+    col = torch.matmul(weight_t, x.contiguous().view(N, Cin, H * W))            # [N, Cout*k*k, H*W]
+    Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
+    return ops.col2im_bias_relu_forward(col, bias, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope)

@@ -78,13 +78,42 @@ def _conv(x, P, name, stride, pad, act=True, backend=None):
         y = backend.conv_k7s2_relu(x, w, P[name + ".b"], NEG_SLOPE)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
         if y is not None:
             return y
+    if act and w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
+        y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE)
+        if y is not None:
+            return y
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
         return backend.conv_bias_leaky_relu(F.conv2d(x, w, None, stride=stride, padding=pad), P[name + ".b"], NEG_SLOPE)
     y = F.conv2d(x, w, P[name + ".b"], stride=stride, padding=pad)
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
+_WT_CACHE: Dict[int, tuple] = {}
+
+
+def _transposed_deconv_weight(w):
+    """weight [Cin, Cout, 4, 4] -> [Cout*16, Cin] contiguous (the A operand of the deconvolution GEMM), cached per
+    parameter tensor and rebuilt when the tensor is modified in place (torch bumps `_version`)."""
+    key = w.data_ptr()
+    hit = _WT_CACHE.get(key)
+    if hit is None or hit[0] != w._version or hit[1].shape != (w.shape[1] * 16, w.shape[0]) or hit[1].device != w.device:
+        hit = (w._version, w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous())
+        _WT_CACHE[key] = hit
+    return hit[1]
+
+
+def _use_gemm_conv(x, stride):
+    """3x3 layers for which im2col + one batched fp32 GEMM beats MIOpen's direct kernels on gfx950
+    (profiles/r01_miopen_conv_layer_times.txt vs scripts/im2col_gemm_probe.py): stride 2, and stride 1 on maps of <= 14 x 14."""
+    return stride == 2 or x.shape[2] * x.shape[3] <= 196
+
+
 def _deconv(x, P, name, act=True, backend=None):
+    w = P[name + ".w"]
+    if act and backend is not None and hasattr(backend, "deconv_gemm_relu") and not (torch.is_grad_enabled() and w.requires_grad):
+        y = backend.deconv_gemm_relu(x, _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, NEG_SLOPE)
+        if y is not None:
+            return y
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
         return backend.conv_bias_leaky_relu(F.conv_transpose2d(x, P[name + ".w"], None, stride=2, padding=1), P[name + ".b"], NEG_SLOPE)
     y = F.conv_transpose2d(x, P[name + ".w"], P[name + ".b"], stride=2, padding=1)

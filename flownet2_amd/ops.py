@@ -223,3 +223,27 @@ def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
     check(_lib.lib().fn2_conv_k7s2_relu_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, Cin, H, W, Cout,
                                                 C.c_float(float(negative_slope)), _stream()))
     return out
+
+
+def im2col_forward(x, kernel, pad, stride):
+    """[N,C,H,W] -> col [N, C*k*k, Hc*Wc] (Caffe's im2col row order), batched."""
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    Hc, Wc = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
+    col = torch.empty((N, Cc * kernel * kernel, Hc * Wc), device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_im2col_forward(_ptr(x), _ptr(col), N, Cc, H, W, int(kernel), int(pad), int(stride), _stream()))
+    return col
+
+
+def col2im_bias_relu_forward(col, bias, N, Cc, H, W, kernel, pad, stride, relu=True, negative_slope=0.1):
+    """col [N, C*k*k, Hc*Wc] -> image [N,C,H,W] (+ bias[c], optional leaky ReLU): the tail of a Deconvolution forward."""
+    if not (col.is_cuda and col.dtype == torch.float32 and col.is_contiguous()):
+        raise ValueError("col2im: expected a contiguous float32 CUDA (HIP) column blob")
+    Hc, Wc = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
+    if col.numel() != N * Cc * kernel * kernel * Hc * Wc:
+        raise ValueError(f"col2im: column blob has {col.numel()} entries, expected {N * Cc * kernel * kernel * Hc * Wc}")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    out = torch.empty((N, Cc, H, W), device=col.device, dtype=torch.float32)
+    check(_lib.lib().fn2_col2im_bias_relu_forward(_ptr(col), _ptr(b), _ptr(out), N, Cc, H, W, int(kernel), int(pad), int(stride),
+                                                  int(bool(relu)), C.c_float(float(negative_slope)), _stream()))
+    return out

@@ -213,6 +213,22 @@ int fn2_conv_k7s2_relu_supported(int Cin, int Hin, int Win, int Cout);
 int fn2_conv_k7s2_relu_forward(const float* bottom, const float* weight, const float* bias, float* top,
                                int N, int Cin, int Hin, int Win, int Cout, float negative_slope, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * im2col / col2im of Caffe's GEMM convolution, batched over the mini-batch (square kernel, no dilation):
+ *   fn2_im2col_forward            <- im2col_gpu, src/caffe/util/im2col.cu:8-72, as used by
+ *                                    BaseConvolutionLayer::forward_gpu_gemm (base_conv_layer.cpp:325-341)
+ *       col[n][(c*k + i)*k + j][yc*Wc + xc] = im[n][c][yc*stride - pad + i][xc*stride - pad + j]   (0 outside the image)
+ *       Hc = (H + 2*pad - k) / stride + 1, Wc likewise.  The caller multiplies weight[Cout, C*k*k] with col[n].
+ *   fn2_col2im_bias_relu_forward  <- col2im_gpu, im2col.cu:246-318, as used by the Deconvolution forward
+ *                                    (backward_gpu_gemm, base_conv_layer.cpp:352-368; deconv_layer.cu:8-23), fused with
+ *                                    forward_gpu_bias (:343-348) and, if apply_relu, the in-place ReLU (relu_layer.cu:8-14)
+ *       im[n][c][y][x] = f(bias[c] + sum of the col entries that map onto it), col = weight^T[C*k*k, Cin] x bottom[n];
+ *       (H, W) is the IMAGE (= deconvolution output) size; the column grid is Hc x Wc as above.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_im2col_forward(const float* im, float* col, int N, int C, int H, int W, int kernel, int pad, int stride, void* stream);
+int fn2_col2im_bias_relu_forward(const float* col, const float* bias, float* im, int N, int C, int H, int W,
+                                 int kernel, int pad, int stride, int apply_relu, float negative_slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

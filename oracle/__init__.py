@@ -192,6 +192,24 @@ def bias_leaky_relu_forward(x, bias=None, negative_slope=0.1):
     return out
 
 
+def im2col_forward(x, kernel, pad, stride):
+    x = _f32(x)
+    N, Cc, H, W = x.shape
+    Hc, Wc = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
+    col = np.empty((N, Cc * kernel * kernel, Hc * Wc), np.float32)
+    _check(lib().fn2_im2col_forward_cpu(_p(x), _p(col), N, Cc, H, W, kernel, pad, stride), "im2col_forward")
+    return col
+
+
+def col2im_bias_relu_forward(col, bias, N, Cc, H, W, kernel, pad, stride, relu=True, negative_slope=0.1):
+    col = _f32(col)
+    bias = _f32(bias) if bias is not None else None
+    out = np.empty((N, Cc, H, W), np.float32)
+    _check(lib().fn2_col2im_bias_relu_forward_cpu(_p(col), _p(bias), _p(out), N, Cc, H, W, kernel, pad, stride, int(bool(relu)),
+                                                  C.c_float(negative_slope)), "col2im_bias_relu_forward")
+    return out
+
+
 def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
     x, weight = _f32(x), _f32(weight)
     bias = _f32(bias) if bias is not None else None

@@ -706,3 +706,55 @@ FN2_API int fn2_conv_k7s2_relu_forward_cpu(const float* in, const float* weight,
         }
   return FN2_OK;
 }
+
+
+/* Batched im2col / col2im of Caffe's GEMM convolution (src/caffe/util/im2col.cpp:20-50 im2col_cpu, :168-200 col2im_cpu;
+ * GPU twins im2col.cu:8-72, 246-318).  col2im carries the deconvolution's bias and optional leaky ReLU like the HIP path;
+ * the additions run over the column grid rows ascending, then columns ascending (the reference GPU kernel's order). */
+FN2_API int fn2_im2col_forward_cpu(const float* im, float* col, int N, int C, int H, int W, int kernel, int pad, int stride) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || kernel < 1 || pad < 0 || stride < 1 || H + 2 * pad < kernel || W + 2 * pad < kernel)
+    return FN2_ERR_INVALID_ARG;
+  const int Hc = (H + 2 * pad - kernel) / stride + 1, Wc = (W + 2 * pad - kernel) / stride + 1;
+#pragma omp parallel for
+  for (long long pl = 0; pl < (long long)N * C; ++pl) {
+    const float* src = im + (size_t)pl * H * W;
+    float* dst = col + (size_t)pl * kernel * kernel * Hc * Wc;
+    for (int i = 0; i < kernel; ++i)
+      for (int j = 0; j < kernel; ++j)
+        for (int yc = 0; yc < Hc; ++yc)
+          for (int xc = 0; xc < Wc; ++xc) {
+            const int y = yc * stride - pad + i, x = xc * stride - pad + j;
+            dst[((size_t)(i * kernel + j) * Hc + yc) * Wc + xc] = (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f;
+          }
+  }
+  return FN2_OK;
+}
+
+FN2_API int fn2_col2im_bias_relu_forward_cpu(const float* col, const float* bias, float* im, int N, int C, int H, int W,
+                                             int kernel, int pad, int stride, int apply_relu, float negative_slope) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || kernel < 1 || pad < 0 || stride < 1 || H + 2 * pad < kernel || W + 2 * pad < kernel)
+    return FN2_ERR_INVALID_ARG;
+  const int Hc = (H + 2 * pad - kernel) / stride + 1, Wc = (W + 2 * pad - kernel) / stride + 1;
+#pragma omp parallel for
+  for (long long pl = 0; pl < (long long)N * C; ++pl) {
+    const float* src = col + (size_t)pl * kernel * kernel * Hc * Wc;
+    const float b = bias ? bias[pl % C] : 0.f;
+    for (int yy = 0; yy < H; ++yy)
+      for (int xx = 0; xx < W; ++xx) {
+        const int y = yy + pad, x = xx + pad;
+        float v = 0.f;
+        for (int yc = 0; yc < Hc; ++yc) {
+          const int i = y - yc * stride;
+          if (i < 0 || i >= kernel) continue;
+          for (int xc = 0; xc < Wc; ++xc) {
+            const int j = x - xc * stride;
+            if (j < 0 || j >= kernel) continue;
+            v += src[((size_t)(i * kernel + j) * Hc + yc) * Wc + xc];
+          }
+        }
+        v += b;
+        im[(size_t)pl * H * W + (size_t)yy * W + xx] = (apply_relu && v <= 0.f) ? v * negative_slope : v;
+      }
+  }
+  return FN2_OK;
+}

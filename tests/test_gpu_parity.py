@@ -360,6 +360,46 @@ def test_stem_conv_unsupported_shapes_are_reported():
         ops.conv_k7s2_relu_forward(dev(rand((1, 3, 64, 100), 1)), dev(rand((64, 3, 7, 7), 2)), None)
 
 
+@pytest.mark.parametrize("case", [(2, 5, 9, 11, 3, 1, 1), (2, 4, 10, 14, 3, 1, 2), (1, 3, 7, 8, 4, 1, 2), (1, 2, 6, 6, 5, 2, 1), (3, 6, 5, 7, 1, 0, 1)])
+def test_im2col_matches_oracle_and_unfold(case):
+    N, C, H, W, k, p, s = case
+    x = rand((N, C, H, W), 60)
+    got = host(ops.im2col_forward(dev(x), k, p, s))
+    np.testing.assert_array_equal(got, oracle.im2col_forward(x, k, p, s))
+    np.testing.assert_array_equal(got, torch.nn.functional.unfold(torch.from_numpy(x), k, padding=p, stride=s).numpy())
+
+
+@pytest.mark.parametrize("case", [(2, 6, 5, 5, 7), (1, 130, 3, 10, 14), (2, 16, 8, 20, 28)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_deconv_via_gemm_and_col2im(case, relu):
+    """Deconvolution{4,2,1} forward = weight^T x bottom, then col2im (+ bias, + ReLU): against the oracle's col2im (same
+    addition order: bit-exact) and against torch's conv_transpose2d in fp64."""
+    N, Cin, Cout, H, W = case
+    x, w, b = rand((N, Cin, H, W), 61), rand((Cin, Cout, 4, 4), 62, 0.1), rand((Cout,), 63)
+    col = np.matmul(w.reshape(Cin, Cout * 16).T.astype(np.float64), x.reshape(N, Cin, H * W).astype(np.float64)).astype(np.float32)
+    got = host(ops.col2im_bias_relu_forward(dev(col), dev(b), N, Cout, 2 * H, 2 * W, 4, 1, 2, relu, 0.1))
+    np.testing.assert_array_equal(got, oracle.col2im_bias_relu_forward(col, b, N, Cout, 2 * H, 2 * W, 4, 1, 2, relu, 0.1))
+    ref = torch.nn.functional.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                                               stride=2, padding=1)
+    if relu:
+        ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    assert_close(got, ref.numpy().astype(np.float32), 3e-6, "deconv via col2im vs torch fp64")
+
+
+def test_gemm_conv_paths_match_library_convolutions():
+    """functional.conv_gemm_relu / deconv_gemm_relu (im2col + library GEMM + our passes) vs MIOpen's direct kernels."""
+    from flownet2_amd import functional as Fn
+    x, w, b = dev(rand((2, 64, 10, 14), 64)), dev(rand((96, 64, 3, 3), 65, 0.05)), dev(rand((96,), 66))
+    for stride in (1, 2):
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1), 0.1)
+        got = Fn.conv_gemm_relu(x, w, b, stride, 1, 0.1)
+        assert_close(host(got), host(ref), 1e-5, "conv via im2col + GEMM")
+    wd = dev(rand((64, 32, 4, 4), 67, 0.05)); bd = dev(rand((32,), 68))
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(x, wd, bd, stride=2, padding=1), 0.1)
+    got = Fn.deconv_gemm_relu(x, wd.reshape(64, 32 * 16).t().contiguous(), bd, 32)
+    assert_close(host(got), host(ref), 1e-5, "deconv via GEMM + col2im")
+
+
 def test_identity_resample_is_exact():
     """deploy_forward skips the ADAPTED-size Resample when the size does not change: the kernel is then the identity."""
     x = rand((2, 3, 64, 128), 42)

@@ -245,3 +245,20 @@ def test_stem_conv_oracle_matches_torch():
     got = oracle.conv_k7s2_relu_forward(x, w, b, 0.1)
     assert got.shape == ref.shape
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_im2col_col2im_oracle():
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 3, 6, 7)).astype(np.float32)
+    for k, p, s in ((3, 1, 1), (3, 1, 2), (4, 1, 2), (5, 2, 1)):
+        np.testing.assert_array_equal(oracle.im2col_forward(x, k, p, s), torch.nn.functional.unfold(torch.from_numpy(x), k, padding=p, stride=s).numpy())
+    # deconvolution 4/2/1 through GEMM + col2im against conv_transpose2d
+    w = (0.1 * rng.standard_normal((3, 5, 4, 4))).astype(np.float32); b = rng.standard_normal(5).astype(np.float32)
+    col = np.matmul(w.reshape(3, 80).T.astype(np.float64), x.reshape(2, 3, 42).astype(np.float64)).astype(np.float32)
+    got = oracle.col2im_bias_relu_forward(col, b, 2, 5, 12, 14, 4, 1, 2, relu=False)
+    ref = torch.nn.functional.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=2, padding=1)
+    np.testing.assert_allclose(got, ref.numpy(), rtol=0, atol=3e-6)
+    # col2im is the adjoint-shaped fold: against torch.nn.functional.fold
+    colr = rng.standard_normal((2, 5 * 16, 42)).astype(np.float32)
+    fold = torch.nn.functional.fold(torch.from_numpy(colr).double(), (12, 14), 4, padding=1, stride=2).numpy()
+    np.testing.assert_allclose(oracle.col2im_bias_relu_forward(colr, None, 2, 5, 12, 14, 4, 1, 2, relu=False), fold, rtol=0, atol=2e-6)
