@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
     ap.add_argument("--net", choices=["C", "2"], default="C", help="C = FlowNetC (headline, configs[1]); 2 = full FlowNet2 stack (configs[2]: use --batch 4 --height 384 --width 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture a forward step into a hipGraph and replay it (measured: no gain, the step is not launch-bound)")
     ap.add_argument("--conv-search", action="store_true", help="let MIOpen's find step time its candidate kernels during warm-up (measured: no gain for this net)")
     ap.add_argument("--corr-iters", type=int, default=200)
     return ap.parse_args()
@@ -174,12 +175,26 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    use_graph = args.mode == "fwd" and args.graph
+    if use_graph:
+        # One step = ~130 kernels: captured once (hipGraph through torch's CUDAGraph; same kernels, order and buffers)
+        # and replayed, which removes the host launch path.  The warm-up above has run every lazy initialisation.
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        graph.replay()
+        step_fn = graph.replay
+    else:
+        step_fn = step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        r = step_fn()
+        if r is not None:
+            out = r
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -197,7 +212,8 @@ def main():
             "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
                        "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
-                       "conv_stack": "MIOpen fp32 via torch (%.1f GFLOP/step/GPU)" % conv_gf},
+                       "conv_stack": "stem: own MFMA kernel; 3x3/2, small-map 3x3 and 4x4/2 deconvs: own im2col/col2im + library GEMM; other convolutions: MIOpen fp32 via torch (%.1f GFLOP/step/GPU)" % conv_gf,
+                       "launch": "hipGraph replay" if use_graph else "host launches"},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
         if world == 1:

@@ -88,6 +88,18 @@ def _conv(x, P, name, stride, pad, act=True, backend=None):
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
+_CONSTS: Dict[tuple, torch.Tensor] = {}
+
+
+def _const(device, values):
+    """Small fp32 device constants (mean, output scale), uploaded once: no host-to-device copy inside a step, so a
+    step can be captured into a hipGraph."""
+    key = (str(device), tuple(float(v) for v in values))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(key[1], device=device, dtype=torch.float32)
+    return _CONSTS[key]
+
+
 _WT_CACHE: Dict[int, tuple] = {}
 
 
@@ -104,13 +116,19 @@ def _transposed_deconv_weight(w):
 
 def _use_gemm_conv(x, stride):
     """3x3 layers for which im2col + one batched fp32 GEMM beats MIOpen's direct kernels on gfx950
-    (profiles/r01_miopen_conv_layer_times.txt vs scripts/im2col_gemm_probe.py): stride 2, and stride 1 on maps of <= 14 x 14."""
-    return stride == 2 or x.shape[2] * x.shape[3] <= 196
+    (profiles/r01_miopen_conv_layer_times.txt vs scripts/im2col_gemm_probe.py): stride 2, and stride 1 on maps of
+    <= 14 x 14 -- as long as the column matrix stays small next to the GEMM (<= 64 MB; it is written and read once)."""
+    n, c, h, w = x.shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if 4 * n * c * 9 * ho * wo > (64 << 20) or c < 64:
+        return False
+    return stride == 2 or h * w <= 196
 
 
 def _deconv(x, P, name, act=True, backend=None):
     w = P[name + ".w"]
-    if act and backend is not None and hasattr(backend, "deconv_gemm_relu") and not (torch.is_grad_enabled() and w.requires_grad):
+    if (act and backend is not None and hasattr(backend, "deconv_gemm_relu") and w.shape[0] >= 64
+            and not (torch.is_grad_enabled() and w.requires_grad)):
         y = backend.deconv_gemm_relu(x, _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, NEG_SLOPE)
         if y is not None:
             return y
@@ -194,7 +212,7 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
     N, _, H, W = img0.shape
     ah, aw = adapted_size(H, W)
     if mean is None:
-        mean = torch.tensor([0.411, 0.433, 0.45], device=img0.device, dtype=img0.dtype)   # BGR order of a typical RGB mean
+        mean = _const(img0.device, (0.411, 0.433, 0.45))   # BGR order of a typical RGB mean
     pre = []
     for im in (img0, img1):
         x = im * (1.0 / 255.0)                                                     # Eltwise, coeff 1/255
@@ -207,7 +225,7 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
         flows = flownet_s_core(P, torch.cat(pre, 1), backend)
     flow = flows[2] * FLOW_SCALE                                                    # Eltwise, coeff 20
     flow = backend.resample(flow, H, W)                                             # Resample to TARGET size (x4 up-sampling)
-    scale = torch.tensor([W / float(aw), H / float(ah)], device=flow.device, dtype=flow.dtype)   # run-flownet.py:47-48
+    scale = _const(flow.device, (W / float(aw), H / float(ah)))   # run-flownet.py:47-48
     return flow * scale.view(1, 2, 1, 1)                                            # 1x1 conv, diagonal filler
 
 
@@ -348,7 +366,7 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     N, _, H, W = img0.shape
     ah, aw = adapted_size(H, W)
     if mean is None:
-        mean = torch.tensor([0.411, 0.433, 0.45], device=img0.device, dtype=img0.dtype)
+        mean = _const(img0.device, (0.411, 0.433, 0.45))
     a = backend.resample(img0 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
     b = backend.resample(img1 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
 
@@ -370,5 +388,5 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     fuse_in = torch.cat([a, flow_sd, flow_css, backend.channel_norm(flow_sd), backend.channel_norm(flow_css), err_sd, err_css], 1)
     flow = fusion_core(_Prefixed(P, "fuse_"), fuse_in, backend)
     flow = backend.resample(flow, H, W)
-    scale = torch.tensor([W / float(aw), H / float(ah)], device=flow.device, dtype=flow.dtype)
+    scale = _const(flow.device, (W / float(aw), H / float(ah)))
     return flow * scale.view(1, 2, 1, 1)
