@@ -949,6 +949,14 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
     const float sumelems = (float)g.C;
     const bool pow2 = (g.C & (g.C - 1)) == 0;
     const float rcp = 1.0f / sumelems;
+    // 1 / C is exact for power-of-two channel counts (x / 2^k == x * 2^-k); otherwise keep the reference's true division
+    if (pow2) {
+#pragma unroll
+      for (int b = 0; b < K::NB; ++b) { acc0[b] *= rcp; acc1[b] *= rcp; }
+    } else {
+#pragma unroll
+      for (int b = 0; b < K::NB; ++b) { acc0[b] /= sumelems; acc1[b] /= sumelems; }
+    }
 #pragma unroll
     for (int b = 0; b < K::NB; ++b) {
 #pragma unroll
@@ -956,8 +964,8 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
         const int oo = 4 * b + nj - r;
         if (oo >= 0 && oo < K::D) {
           float* dst = smem + ((mi * 4 + ni) * K::D + oo) * K::XS + 2 * (4 * Jw + r);
-          dst[0] = pow2 ? acc0[b][r] * rcp : acc0[b][r] / sumelems;
-          dst[1] = pow2 ? acc1[b][r] * rcp : acc1[b][r] / sumelems;
+          dst[0] = acc0[b][r];
+          dst[1] = acc1[b][r];
         }
       }
     }
