@@ -94,6 +94,30 @@ lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --
           "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
 for r in ks[:28]:
     lines.append("| `%s` | %s | %.2f | %.2f | %s |" % (short(r["Name"], 90), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+# --- matrix-pipe utilisation of the conv stack (counter pass over the same bench command)
+pmc_path = os.path.join(R, "pmc_bench", "bench_counter_collection.csv")
+if os.path.exists(pmc_path):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for r in csv.DictReader(open(pmc_path)):
+        per[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            cnt[r["Kernel_Name"]] += 1
+    rows = []
+    for name, c in per.items():
+        gui_k = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if gui_k > 0 and c.get("SQ_INSTS_MFMA", 0.0) > 0:
+            rows.append((gui_k, name, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui_k), cnt[name]))
+    rows.sort(reverse=True)
+    tot_gui = sum(r[0] for r in rows)
+    tot_busy = sum(r[0] * r[2] for r in rows)
+    lines += ["", "## Matrix-pipe utilisation of the step's MFMA kernels (`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE`, own pass over the same command)", "",
+              "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); kernels ordered by their share of the MFMA kernels' cycles.", "",
+              "| kernel | dispatches | share of cycles % | MFMA busy % |", "|---|---|---|---|"]
+    for gui_k, name, u, n in rows[:16]:
+        lines.append("| `%s` | %d | %.1f | %.1f |" % (short(name, 90), n, 100 * gui_k / tot_gui, 100 * u))
+    lines += ["", "All MFMA kernels of the run together: **%.1f %%** matrix-pipe utilisation." % (100 * tot_busy / tot_gui)]
+
 lines += ["", "bench line of the unprofiled run in the same session:", "```", open(os.path.join(R, "bench.json")).read().strip(), "```", ""]
 open(os.path.join(OUT, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 
