@@ -9,31 +9,32 @@
 
 namespace fn2 {
 
+// grid: (pixel blocks, n) / (pixel blocks, n * C + c); 32-bit pixel index.
 __global__ void __launch_bounds__(256) channel_norm_fwd(const float* __restrict__ bot, float* __restrict__ top,
-                                                        int N, int C, size_t hw) {
-  const long long total = (long long)N * hw;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const size_t n = idx / hw, s = idx % hw;
-    const float* p = bot + n * C * hw + s;
+                                                        int N, int C, unsigned hw) {
+  const unsigned s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= hw) return;
+  for (unsigned n = blockIdx.y; n < (unsigned)N; n += gridDim.y) {
+    const float* p = bot + (size_t)n * C * hw + s;
     float norm = 0.f;
     for (int c = 0; c < C; ++c) {
       const float v = p[(size_t)c * hw];
       norm = fmaf(v, v, norm);          // :27-28
     }
-    top[idx] = sqrtf(norm);             // :31-32
+    top[(size_t)n * hw + s] = sqrtf(norm);   // :31-32
   }
 }
 
 __global__ void __launch_bounds__(256) channel_norm_bwd(const float* __restrict__ bot, const float* __restrict__ top,
                                                         const float* __restrict__ top_diff, float* __restrict__ bot_diff,
-                                                        int N, int C, size_t hw) {
-  const long long total = (long long)N * C * hw;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const size_t n = idx / (C * hw), s = idx % hw;
+                                                        int N, int C, unsigned hw) {
+  const unsigned s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= hw) return;
+  for (unsigned pl = blockIdx.y; pl < (unsigned)N * C; pl += gridDim.y) {
+    const unsigned n = pl / C;
+    const size_t idx = (size_t)pl * hw + s;
     // :45 -- `top_data + 1e-9` promotes the quotient to double in the reference.
-    bot_diff[idx] = (float)((double)(top_diff[n * hw + s] * bot[idx]) / ((double)top[n * hw + s] + 1e-9));
+    bot_diff[idx] = (float)((double)(top_diff[(size_t)n * hw + s] * bot[idx]) / ((double)top[(size_t)n * hw + s] + 1e-9));
   }
 }
 
@@ -43,11 +44,12 @@ struct DownArgs {
 };
 
 __global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
-  const long long total = (long long)a.NC * a.Hout * a.Wout;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int destx = (int)(idx % a.Wout), desty = (int)((idx / a.Wout) % a.Hout);
-    const long long cn = idx / a.Wout / a.Hout;
+  const unsigned hw_out = (unsigned)a.Hout * a.Wout;
+  const unsigned pd = blockIdx.x * 256u + threadIdx.x;
+  if (pd >= hw_out) return;
+  const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
+  for (unsigned cn = blockIdx.y; cn < (unsigned)a.NC; cn += gridDim.y) {
+    const size_t idx = (size_t)cn * hw_out + pd;
     const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
     const float boty = ((float)desty / (float)(a.Hout - 1)) * (float)(a.Hin - 1);     // :28
     const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                   // :30-31
@@ -80,8 +82,9 @@ FN2_API int fn2_channel_norm_forward(const float* bottom, float* top, int N, int
   if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
   if (N == 0) return FN2_OK;
   if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
-  const size_t hw = (size_t)H * W;
-  hipLaunchKernelGGL(channel_norm_fwd, dim3(blocks_for((long long)N * hw, 256)), dim3(256), 0, as_stream(stream), bottom, top, N, C, hw);
+  if ((long long)H * W >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "channel_norm: plane too large");
+  const unsigned hw = (unsigned)H * W;
+  hipLaunchKernelGGL(channel_norm_fwd, dim3((hw + 255) / 256, (unsigned)(N < 65535 ? N : 65535)), dim3(256), 0, as_stream(stream), bottom, top, N, C, hw);
   return check_launch("channel_norm_forward");
 }
 
@@ -90,9 +93,11 @@ FN2_API int fn2_channel_norm_backward(const float* bottom, const float* top, con
   if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
   if (N == 0) return FN2_OK;
   if (!bottom || !top || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
-  const size_t hw = (size_t)H * W;
-  hipLaunchKernelGGL(channel_norm_bwd, dim3(blocks_for((long long)N * C * hw, 256)), dim3(256), 0, as_stream(stream), bottom, top,
-                     top_diff, bottom_diff, N, C, hw);
+  if ((long long)H * W >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "channel_norm: plane too large");
+  const unsigned hw = (unsigned)H * W;
+  const long long planes = (long long)N * C;
+  hipLaunchKernelGGL(channel_norm_bwd, dim3((hw + 255) / 256, (unsigned)(planes < 65535 ? planes : 65535)), dim3(256), 0, as_stream(stream),
+                     bottom, top, top_diff, bottom_diff, N, C, hw);
   return check_launch("channel_norm_backward");
 }
 
@@ -115,6 +120,7 @@ FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C
   a.heightScale = (float)(Hin - 1) / (float)(Hout - 1);    // :105
   a.wradius = (int)std::ceil(a.widthScale);                // :107
   a.hradius = (int)std::ceil(a.heightScale);               // :108
-  hipLaunchKernelGGL(downsample_fwd, dim3(blocks_for((long long)a.NC * Hout * Wout, 256)), dim3(256), 0, st, bottom, top, a);
+  if ((long long)Hout * Wout >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "downsample: plane too large");
+  hipLaunchKernelGGL(downsample_fwd, dim3(((unsigned)Hout * Wout + 255) / 256, (unsigned)(a.NC < 65535 ? a.NC : 65535)), dim3(256), 0, st, bottom, top, a);
   return check_launch("downsample_forward");
 }

@@ -27,52 +27,96 @@ struct ResampleArgs {
   int NC, Hin, Win, Hout, Wout;
   float fx, fy, ax, ay;
   int rx, ry;
+  int ppt;          // planes per thread (blockIdx.y walks plane groups)
 };
 
+// Indexing of both kernels: blockIdx.x * 256 + tid = output pixel (32-bit), blockIdx.y = group of `ppt` (n, c) planes.
+// Everything that depends on the pixel only -- source position, tap range, coefficients -- is computed once and reused
+// for the planes of the group (the first version decoded a 64-bit flat index per element and re-evaluated the
+// coefficient of every one of the (2r+1)^2 taps: 30 us for a 10 MB up-sampling).
+
 __global__ void __launch_bounds__(256) resample_nearest(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
-  const long long total = (long long)a.NC * a.Hout * a.Wout;
-  const int out_cs = a.Hout * a.Wout;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx / out_cs);
-    const int x_out = (int)(idx % out_cs) % a.Wout, y_out = (int)(idx % out_cs) / a.Wout;
-    const float x_in = x_out * a.fx + a.fy / 2.0f - 0.5f;   // :117
-    const float y_in = y_out * a.fy + a.fx / 2.0f - 0.5f;   // :118
-    int xr = (int)roundf(x_in), yr = (int)roundf(y_in);
-    // The reference reads in_ptr[yr*W+xr] unclamped (:123); clamp instead of faulting.
-    xr = min(max(xr, 0), a.Win - 1);
-    yr = min(max(yr, 0), a.Hin - 1);
-    out[idx] = in[(size_t)c * a.Hin * a.Win + (size_t)yr * a.Win + xr];
-  }
+  const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= hw_out) return;
+  const int y_out = p / a.Wout, x_out = p - y_out * a.Wout;
+  const float x_in = x_out * a.fx + a.fy / 2.0f - 0.5f;   // :117
+  const float y_in = y_out * a.fy + a.fx / 2.0f - 0.5f;   // :118
+  int xr = (int)roundf(x_in), yr = (int)roundf(y_in);
+  // The reference reads in_ptr[yr*W+xr] unclamped (:123); clamp instead of faulting.
+  xr = min(max(xr, 0), a.Win - 1);
+  yr = min(max(yr, 0), a.Hin - 1);
+  const unsigned src = (unsigned)yr * a.Win + xr;
+  for (int c = blockIdx.y * a.ppt; c < min(a.NC, (int)(blockIdx.y + 1) * a.ppt); ++c)
+    out[(size_t)c * hw_out + p] = in[(size_t)c * hw_in + src];
 }
 
-template <bool CUBIC>
+// FAST: tap radius <= 2 on both axes (every up-sampling and same-size call): the 5 + 5 coefficients live in registers.
+template <bool CUBIC, bool FAST>
 __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
-  const long long total = (long long)a.NC * a.Hout * a.Wout;
-  const int out_cs = a.Hout * a.Wout;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx / out_cs);
-    const int x_out = (int)(idx % out_cs) % a.Wout, y_out = (int)(idx % out_cs) / a.Wout;
-    const float x_in = x_out * a.fx + a.fy / 2.0f - 0.5f;   // :62
-    const float y_in = y_out * a.fy + a.fx / 2.0f - 0.5f;   // :63
-    const int xr = (int)roundf(x_in), yr = (int)roundf(y_in);
-    const float* src = in + (size_t)c * a.Hin * a.Win;
-    float sum = 0.f, wsum = 0.f;
+  const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= hw_out) return;
+  const int y_out = p / a.Wout, x_out = p - y_out * a.Wout;
+  const float x_in = x_out * a.fx + a.fy / 2.0f - 0.5f;   // :62
+  const float y_in = y_out * a.fy + a.fx / 2.0f - 0.5f;   // :63
+  const int xr = (int)roundf(x_in), yr = (int)roundf(y_in);
+  const int c_lo = blockIdx.y * a.ppt, c_hi = min(a.NC, c_lo + a.ppt);
+  if constexpr (FAST) {
+    // :87/:89 -- the reference evaluates ((ax*k(ax*dx))*ay)*k(ay*dy); same association: px = (ax*k(ax*dx))*ay per column,
+    // ky per row, taps in the reference's order (rows outer, columns inner).  A tap outside the image is skipped by the
+    // reference; here it gets weight 0 and a 0 sample, which leaves sum and wsum bit-identical.
+    float px[5], ky[5];
+    unsigned xo[5], yo[5], mx = 0u, my = 0u;     // mx / my: which of the 5 columns / rows are taps inside the image
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int x = xr - 2 + i, y = yr - 2 + i;
+      const bool okx = x >= 0 && x < a.Win && (i >= 2 - a.rx && i <= 2 + a.rx);
+      const bool oky = y >= 0 && y < a.Hin && (i >= 2 - a.ry && i <= 2 + a.ry);
+      const float kx = CUBIC ? bicubic_coeff(a.ax * (x_in - x)) : triangle_coeff(a.ax * (x_in - x));
+      const float kyv = CUBIC ? bicubic_coeff(a.ay * (y_in - y)) : triangle_coeff(a.ay * (y_in - y));
+      px[i] = okx ? a.ax * kx * a.ay : 0.f;
+      ky[i] = oky ? kyv : 0.f;
+      xo[i] = okx ? (unsigned)x : 0u;
+      yo[i] = oky ? (unsigned)y * a.Win : 0u;
+      mx |= (okx ? 1u : 0u) << i;
+      my |= (oky ? 1u : 0u) << i;
+    }
+    float wsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) wsum += px[i] * ky[j];
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float* src = in + (size_t)c * hw_in;
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const float w = px[i] * ky[j];
+          // in-image taps are read even when their coefficient is 0: a NaN there poisons the result in the reference too
+          sum = fmaf(w, ((mx >> i) & (my >> j) & 1u) ? src[yo[j] + xo[i]] : 0.f, sum);
+        }
+      out[(size_t)c * hw_out + p] = (!wsum) ? 0.f : (sum / wsum);   // :93
+    }
+  } else {
     const int y0 = max(yr - a.ry, 0), y1 = min(yr + a.ry, a.Hin - 1);
     const int x0 = max(xr - a.rx, 0), x1 = min(xr + a.rx, a.Win - 1);
-    for (int y = y0; y <= y1; ++y) {
-      const float ky = CUBIC ? bicubic_coeff(a.ay * (y_in - y)) : triangle_coeff(a.ay * (y_in - y));
-      for (int x = x0; x <= x1; ++x) {
-        const float dx = x_in - x;
-        // :87/:89 -- the reference evaluates ((ax*k(ax*dx))*ay)*k(ay*dy); same association here,
-        // with k(ay*dy) hoisted out of the x loop.
-        const float w = a.ax * (CUBIC ? bicubic_coeff(a.ax * dx) : triangle_coeff(a.ax * dx)) * a.ay * ky;
-        sum = fmaf(w, src[(size_t)y * a.Win + x], sum);
-        wsum += w;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float* src = in + (size_t)c * hw_in;
+      float sum = 0.f, wsum = 0.f;
+      for (int y = y0; y <= y1; ++y) {
+        const float kyv = CUBIC ? bicubic_coeff(a.ay * (y_in - y)) : triangle_coeff(a.ay * (y_in - y));
+        for (int x = x0; x <= x1; ++x) {
+          const float dx = x_in - x;
+          const float w = a.ax * (CUBIC ? bicubic_coeff(a.ax * dx) : triangle_coeff(a.ax * dx)) * a.ay * kyv;
+          sum = fmaf(w, src[(size_t)y * a.Win + x], sum);
+          wsum += w;
+        }
       }
+      out[(size_t)c * hw_out + p] = (!wsum) ? 0.f : (sum / wsum);   // :93
     }
-    out[idx] = (!wsum) ? 0.f : (sum / wsum);   // :93
   }
 }
 
@@ -99,11 +143,23 @@ FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int 
   a.ay = 1.0f / (antialias ? a.fy : 1.0f);                      // :72
   a.rx = (a.fx < 1.0f) ? 2 : (int)std::ceil((float)kernel_width / a.ax);   // :73
   a.ry = (a.fy < 1.0f) ? 2 : (int)std::ceil((float)kernel_width / a.ay);   // :74
-  const long long total = (long long)a.NC * Hout * Wout;
-  const unsigned blocks = blocks_for(total, 256);
+  if ((long long)Hout * Wout >= (1ll << 31) || (long long)Hin * Win >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "resample: plane too large");
+  const unsigned bx = (unsigned)(((long long)Hout * Wout + 255) / 256);
+  // planes per thread: amortise the per-pixel work, but keep >= ~2k workgroups in flight
+  a.ppt = 1;
+  while (a.ppt < 8 && (long long)bx * ((a.NC + 2 * a.ppt - 1) / (2 * a.ppt)) >= 2048) a.ppt *= 2;
+  const unsigned by = (unsigned)((a.NC + a.ppt - 1) / a.ppt);
+  if (by > 65535u) return fail(FN2_ERR_UNSUPPORTED, "resample: too many planes");
+  const dim3 grid(bx, by);
   hipStream_t st = as_stream(stream);
-  if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, dim3(blocks), dim3(256), 0, st, in, out, a);
-  else if (type == FN2_RESAMPLE_CUBIC) hipLaunchKernelGGL(resample_interp<true>, dim3(blocks), dim3(256), 0, st, in, out, a);
-  else hipLaunchKernelGGL(resample_interp<false>, dim3(blocks), dim3(256), 0, st, in, out, a);
+  const bool fast = a.rx <= 2 && a.ry <= 2;
+  if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, grid, dim3(256), 0, st, in, out, a);
+  else if (type == FN2_RESAMPLE_CUBIC) {
+    if (fast) hipLaunchKernelGGL((resample_interp<true, true>), grid, dim3(256), 0, st, in, out, a);
+    else hipLaunchKernelGGL((resample_interp<true, false>), grid, dim3(256), 0, st, in, out, a);
+  } else {
+    if (fast) hipLaunchKernelGGL((resample_interp<false, true>), grid, dim3(256), 0, st, in, out, a);
+    else hipLaunchKernelGGL((resample_interp<false, false>), grid, dim3(256), 0, st, in, out, a);
+  }
   return check_launch("resample_forward");
 }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the custom layers at the SURVEY section 8(d) sizes: time, algorithmic bytes, achieved GB/s
+(fraction of the 8 TB/s HBM peak).  Inputs are resident in HBM; 20 warm-ups, 100 timed launches, median of 5 rounds."""
+import os, sys, statistics, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flownet2_amd import ops
+dev = "cuda"
+def timeit(f, iters=100, rounds=5):
+    for _ in range(20): f()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): f()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters * 1e3)
+    return statistics.median(ts)
+rows = []
+def add(name, f, nbytes):
+    t = timeit(f)
+    rows.append((name, t, nbytes, nbytes / t / 1e3))
+g = torch.Generator(device=dev).manual_seed(0)
+# FlowWarp: config B images and a 256-channel feature case
+for (N, C, H, W) in [(4, 3, 384, 768), (4, 256, 48, 96)]:
+    img = torch.rand(N, C, H, W, device=dev, generator=g); flow = torch.randn(N, 2, H, W, device=dev, generator=g) * 8
+    gout = torch.randn(N, C, H, W, device=dev, generator=g)
+    add(f"FlowWarp fwd [{N},{C},{H},{W}]", lambda: ops.flow_warp_forward(img, flow), 4 * N * H * W * (2 * C + 2))
+    add(f"FlowWarp bwd [{N},{C},{H},{W}]", lambda: ops.flow_warp_backward(img, flow, gout), 4 * N * H * W * (3 * C + 4))
+# Resample: flow x4 up-sampling (config B), config A final flow, image identity
+for (N, C, H, W, Ho, Wo) in [(4, 2, 96, 192, 384, 768), (8, 2, 80, 112, 320, 448), (4, 3, 384, 768, 384, 768), (4, 3, 436, 1024, 448, 1024)]:
+    x = torch.randn(N, C, H, W, device=dev, generator=g)
+    add(f"Resample LINEAR [{N},{C},{H},{W}]->[{Ho},{Wo}]", lambda: ops.resample_forward(x, Ho, Wo), 4 * N * C * (H * W + Ho * Wo))
+# L1Loss at the training scales of config A, ChannelNorm / Downsample at config B
+for (h, w) in [(80, 112), (5, 7)]:
+    a = torch.randn(8, 2, h, w, device=dev, generator=g); b = torch.randn(8, 2, h, w, device=dev, generator=g)
+    p = ops.l1_params(l2_per_location=True, normalize_by_num_entries=True)
+    ws = ops.l1loss_workspace(a)
+    add(f"L1Loss fwd [8,2,{h},{w}]", lambda: ops.l1loss_forward(p, a, b, ws), 4 * 2 * 8 * 2 * h * w)
+    ops.l1loss_forward(p, a, b, ws)
+    add(f"L1Loss bwd [8,2,{h},{w}]", lambda: ops.l1loss_backward(p, a, b, 1.0, ws), 4 * 4 * 8 * 2 * h * w)
+x = torch.randn(4, 3, 384, 768, device=dev, generator=g)
+add("ChannelNorm fwd [4,3,384,768]", lambda: ops.channel_norm_forward(x), 4 * 4 * 384 * 768 * 4)
+gt = torch.randn(8, 2, 320, 448, device=dev, generator=g)
+add("Downsample [8,2,320,448]->[80,112]", lambda: ops.downsample_forward(gt, 80, 112), 4 * 8 * 2 * (320 * 448 + 80 * 112))
+y = torch.randn(16, 128, 80, 112, device=dev, generator=g); bb = torch.randn(128, device=dev, generator=g)
+add("bias + leaky ReLU in place [16,128,80,112]", lambda: ops.bias_leaky_relu_(y, bb, 0.1), 2 * 4 * y.numel())
+xi = torch.randn(8, 512, 20, 28, device=dev, generator=g)
+add("im2col 3x3/2 [8,512,20,28]", lambda: ops.im2col_forward(xi, 3, 1, 2), 4 * xi.numel() + 4 * 8 * 512 * 9 * 140)
+col = torch.randn(8, 64 * 16, 40 * 56, device=dev, generator=g); b64 = torch.randn(64, device=dev, generator=g)
+add("col2im 4x4/2 + bias + ReLU -> [8,64,80,112]", lambda: ops.col2im_bias_relu_forward(col, b64, 8, 64, 80, 112, 4, 1, 2), 4 * col.numel() + 4 * 8 * 64 * 80 * 112)
+print("| layer | us | algorithmic MB | GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
+for name, t, nb, gbs in rows:
+    print("| %s | %.1f | %.2f | %.0f | %.1f |" % (name, t, nb / 1e6, gbs, gbs / 80.0))
