@@ -1,6 +1,9 @@
 // Stand-in for include/caffe/blob.hpp + syncedmem.hpp: NCHW fp32 tensor with data and diff, lazily mirrored
 // between host and device (the head-state machine of syncedmem.cpp:25-77, reduced to what layers use).
 #pragma once
+#include <sstream>
+#include <string>
+
 #include "caffe/common.hpp"
 
 namespace caffe {
@@ -55,6 +58,29 @@ class Blob {
   int shape(int i) const { return shape_[i < 0 ? i + (int)shape_.size() : i]; }
   int num_axes() const { return (int)shape_.size(); }
   int count() const { return count_; }
+  int count(int start_axis, int end_axis) const {            // blob.hpp:84-98
+    CHECK_LE(start_axis, end_axis); CHECK_GE(start_axis, 0); CHECK_LE(end_axis, num_axes());
+    int c = 1;
+    for (int i = start_axis; i < end_axis; ++i) c *= shape_[i];
+    return c;
+  }
+  int count(int start_axis) const { return count(start_axis, num_axes()); }
+  int CanonicalAxisIndex(int axis_index) const {             // blob.hpp:121-132
+    CHECK_GE(axis_index, -num_axes()); CHECK_LT(axis_index, num_axes());
+    return axis_index < 0 ? axis_index + num_axes() : axis_index;
+  }
+  std::string shape_string() const {
+    std::ostringstream os;
+    for (size_t i = 0; i < shape_.size(); ++i) os << shape_[i] << " ";
+    os << "(" << count_ << ")";
+    return os.str();
+  }
+  const int* gpu_shape() const {                              // device copy of the shape (used by the N-d im2col path only)
+    if (!shape_data_ || shape_data_->size() != shape_.size() * sizeof(int)) shape_data_.reset(new SyncedMemory(shape_.size() * sizeof(int)));
+    int* h = (int*)shape_data_->mutable_cpu_data();
+    for (size_t i = 0; i < shape_.size(); ++i) h[i] = shape_[i];
+    return (const int*)shape_data_->gpu_data();
+  }
   int LegacyShape(int i) const { CHECK_LE(num_axes(), 4); return i < num_axes() ? shape_[i] : 1; }
   int num() const { return LegacyShape(0); }
   int channels() const { return LegacyShape(1); }
@@ -75,6 +101,7 @@ class Blob {
   void ShareDiff(const Blob& other) { CHECK_EQ(count_, other.count()); diff_ = other.diff_; }
  protected:
   shared_ptr<SyncedMemory> data_, diff_;
+  mutable shared_ptr<SyncedMemory> shape_data_;
   vector<int> shape_;
   int count_ = 0;
   size_t capacity_ = 0;

@@ -96,6 +96,85 @@ class DownsampleParameter {
   unsigned top_height_ = 0, top_width_ = 0;
 };
 
+// Messages of the stock layers the reference's L1LossLayer is composed from (l1loss_layer.cpp:19-62): only the oracle/_ref
+// build of that layer reads them (caffe.proto: FillerParameter, EltwiseParameter, PowerParameter, ConvolutionParameter).
+class FillerParameter {
+ public:
+  const std::string& type() const { return type_; }
+  float value() const { return value_; }
+  void set_type(const std::string& v) { type_ = v; }
+  void set_value(float v) { value_ = v; }
+ private:
+  std::string type_ = "constant";
+  float value_ = 0.f;
+};
+
+enum EltwiseParameter_EltwiseOp { EltwiseParameter_EltwiseOp_PROD = 0, EltwiseParameter_EltwiseOp_SUM = 1, EltwiseParameter_EltwiseOp_MAX = 2 };
+class EltwiseParameter {
+ public:
+  typedef EltwiseParameter_EltwiseOp EltwiseOp;
+  EltwiseOp operation() const { return operation_; }
+  void set_operation(EltwiseOp v) { operation_ = v; }
+  int coeff_size() const { return (int)coeff_.size(); }
+  float coeff(int i) const { return coeff_[i]; }
+  void add_coeff(float v) { coeff_.push_back(v); }
+  bool stable_prod_grad() const { return stable_prod_grad_; }
+ private:
+  EltwiseOp operation_ = EltwiseParameter_EltwiseOp_SUM;
+  std::vector<float> coeff_;
+  bool stable_prod_grad_ = true;
+};
+
+class PowerParameter {
+ public:
+  float power() const { return power_; }
+  float scale() const { return scale_; }
+  float shift() const { return shift_; }
+  void set_power(float v) { power_ = v; }
+  void set_scale(float v) { scale_ = v; }
+  void set_shift(float v) { shift_ = v; }
+ private:
+  float power_ = 1.f, scale_ = 1.f, shift_ = 0.f;
+};
+
+enum ConvolutionParameter_Engine { ConvolutionParameter_Engine_DEFAULT = 0, ConvolutionParameter_Engine_CAFFE = 1, ConvolutionParameter_Engine_CUDNN = 2 };
+class ConvolutionParameter {
+ public:
+  typedef ConvolutionParameter_Engine Engine;
+  unsigned num_output() const { return num_output_; }
+  void set_num_output(unsigned v) { num_output_ = v; }
+  bool bias_term() const { return bias_term_; }
+  void set_bias_term(bool v) { bias_term_ = v; }
+#define FN2_REPEATED(name)                                         \
+  int name##_size() const { return (int)name##_.size(); }          \
+  unsigned name(int i) const { return name##_[i]; }                \
+  void add_##name(unsigned v) { name##_.push_back(v); }            \
+  const std::vector<unsigned>& name() const { return name##_; }
+  FN2_REPEATED(pad) FN2_REPEATED(kernel_size) FN2_REPEATED(stride) FN2_REPEATED(dilation)
+#undef FN2_REPEATED
+#define FN2_OPTIONAL(name)                                         \
+  bool has_##name() const { return has_##name##_; }                \
+  unsigned name() const { return name##_; }                        \
+  void set_##name(unsigned v) { name##_ = v; has_##name##_ = true; }
+  FN2_OPTIONAL(pad_h) FN2_OPTIONAL(pad_w) FN2_OPTIONAL(kernel_h) FN2_OPTIONAL(kernel_w) FN2_OPTIONAL(stride_h) FN2_OPTIONAL(stride_w)
+#undef FN2_OPTIONAL
+  unsigned group() const { return group_; }
+  const FillerParameter& weight_filler() const { return weight_filler_; }
+  FillerParameter* mutable_weight_filler() { return &weight_filler_; }
+  const FillerParameter& bias_filler() const { return bias_filler_; }
+  FillerParameter* mutable_bias_filler() { return &bias_filler_; }
+  Engine engine() const { return ConvolutionParameter_Engine_CAFFE; }
+  int axis() const { return 1; }
+  bool force_nd_im2col() const { return false; }
+ private:
+  unsigned num_output_ = 0, group_ = 1;
+  bool bias_term_ = true;
+  std::vector<unsigned> pad_, kernel_size_, stride_, dilation_;
+  unsigned pad_h_ = 0, pad_w_ = 0, kernel_h_ = 0, kernel_w_ = 0, stride_h_ = 1, stride_w_ = 1;
+  bool has_pad_h_ = false, has_pad_w_ = false, has_kernel_h_ = false, has_kernel_w_ = false, has_stride_h_ = false, has_stride_w_ = false;
+  FillerParameter weight_filler_, bias_filler_;
+};
+
 enum Phase { TRAIN = 0, TEST = 1 };
 
 class LayerParameter {
@@ -121,6 +200,12 @@ class LayerParameter {
   DownsampleParameter* mutable_downsample_param() { return &downsample_param_; }
   const FlowWarpParameter& flow_warp_param() const { return flow_warp_param_; }             // = 159
   FlowWarpParameter* mutable_flow_warp_param() { return &flow_warp_param_; }
+  const EltwiseParameter& eltwise_param() const { return eltwise_param_; }                   // stock layers (oracle/_ref only)
+  EltwiseParameter* mutable_eltwise_param() { return &eltwise_param_; }
+  const PowerParameter& power_param() const { return power_param_; }
+  PowerParameter* mutable_power_param() { return &power_param_; }
+  const ConvolutionParameter& convolution_param() const { return convolution_param_; }
+  ConvolutionParameter* mutable_convolution_param() { return &convolution_param_; }
  private:
   std::string name_, type_;
   std::vector<float> loss_weight_;
@@ -131,6 +216,9 @@ class LayerParameter {
   ResampleParameter resample_param_;
   DownsampleParameter downsample_param_;
   FlowWarpParameter flow_warp_param_;
+  EltwiseParameter eltwise_param_;
+  PowerParameter power_param_;
+  ConvolutionParameter convolution_param_;
 };
 
 }  // namespace caffe

@@ -11,12 +11,18 @@
  * CUDA) cannot run in this image.  This file therefore restates the reference's CUDA kernels line
  * by line in plain C.  Two pins exist (see oracle/README.md):
  *   (1) oracle/_ref: the reference's OWN .cu/.cpp sources for Correlation, FlowWarp, Resample,
- *       ChannelNorm and Downsample compiled in place with hipcc against stand-in caffe headers
- *       and run on an MI355X; tests/golden/ref_golden.npz holds the outputs they produced and
- *       tests/test_golden.py checks every function below against them (PINNED for these five).
+ *       ChannelNorm, Downsample and L1Loss compiled in place with hipcc against stand-in caffe
+ *       headers and run on an MI355X; tests/golden/ref_golden.npz holds the outputs they produced
+ *       and tests/test_golden.py checks every reference-layer function below against them
+ *       (PINNED for all six layers).  L1LossLayer instantiates the stock Eltwise / Power /
+ *       Convolution layers (l1loss_layer.cpp:19-62): those sources (+ base_conv_layer.cpp,
+ *       im2col.{cpp,cu}) are compiled in place as well; the only replaced part is the cuBLAS /
+ *       CBLAS calls underneath them (oracle/ref_compat/caffe/util/math_functions.hpp: plain
+ *       dot / gemm / axpby with the textbook meaning).
  *   (2) an independent fp64 re-derivation + autograd gradient checks (tests/test_oracle.py).
- * L1Loss is composed from stock Caffe sub-layers in the reference and has only pin (2):
- * "parity unpinned" for L1Loss.
+ * The stock-layer fast paths at the end of this file (flow heads, bias + ReLU, stem convolution,
+ * im2col / col2im) restate stock Caffe layers whose arithmetic lives in cuBLAS in the reference;
+ * they are checked against torch's fp64 convolutions (tests/test_oracle.py), not against oracle/_ref.
  *
  * All file:line citations are relative to the reference tree.
  * Arithmetic notes: nvcc contracts `sum += a*b` into an FMA by default, so the restatement uses

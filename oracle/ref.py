@@ -114,7 +114,7 @@ def downsample(x, Hout, Wout):
 
 def l1loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False,
            epsilon=1e-2, plateau=0.0, loss_weight=1.0):
-    """Adapter library only (the reference's L1LossLayer is not part of oracle/_ref)."""
+    """L1LossLayer forward + backward: returns (loss, loss * loss_weight, bottom[0] diff, bottom[1] diff or None)."""
     b0 = _f(b0)
     b1 = _f(b1) if b1 is not None else None
     N, Cc, H, W = b0.shape

@@ -147,7 +147,7 @@ int fn2ref_downsample(const float* in, int N, int C, int Hin, int Win, int Hout,
 }
 
 #ifdef FN2_SHIM_L1LOSS
-// Only for the adapter build (the reference's L1LossLayer is not part of oracle/_ref, see oracle/README.md).
+// The reference's L1LossLayer (oracle/_ref: built with its stock sub-layers, see oracle/README.md) or the adapter's.
 extern "C" __attribute__((visibility("default")))
 int fn2ref_l1loss(int l2_per_location, int prescale, int normalize, float epsilon, float plateau, float loss_weight,
                   const float* b0, const float* b1 /* nullable */, int N, int C, int H, int W,

@@ -19,6 +19,21 @@ CORR = [  # (N, C, H, W, pad, K, md, s1, s2, type)
 ]
 RESAMPLE = [((6, 8), (24, 32)), ((16, 20), (8, 10)), ((9, 12), (9, 12)), ((12, 16), (7, 9)), ((12, 14), (48, 56))]
 DOWN = [((16, 24), (4, 6)), ((17, 23), (5, 7)), ((40, 56), (10, 14))]
+# L1Loss: (shape, two bottoms, l2_per_location, l2_prescale_by_channels, normalize_by_num_entries, epsilon, plateau, NaNs in bottom[1], loss_weight)
+L1 = [((2, 2, 9, 11), True, True, False, True, 1e-2, 0.0, True, 0.32), ((2, 2, 9, 11), True, True, True, False, 1e-2, 0.0, False, 1.0),
+      ((1, 3, 6, 7), True, False, False, True, 1e-2, 0.0, True, 0.5), ((1, 3, 6, 7), True, False, False, False, 1e-2, 0.0, False, 1.0),
+      ((2, 2, 9, 11), True, True, False, True, 1e-2, 0.8, True, 1.0), ((2, 2, 5, 7), False, True, False, True, 1e-2, 0.0, False, 1.0),
+      ((1, 4, 8, 8), False, False, False, True, 1e-2, 0.0, False, 0.25), ((2, 2, 20, 28), True, True, False, True, 1e-2, 0.0, True, 0.02)]
+
+
+def l1_inputs(i):
+    shape, two, l2, pre, norm, eps, plateau, nans, lw = L1[i]
+    b0 = rnd(shape, 800 + i, 2.0)
+    b1 = rnd(shape, 900 + i, 2.0) if two else None
+    if nans and b1 is not None:
+        m = np.random.default_rng(950 + i).random((shape[0], 1, shape[2], shape[3])) < 0.15
+        b1[np.broadcast_to(m, shape)] = np.nan          # whole pixels invalid, as in FlyingChairs ground truth
+    return b0, b1
 
 
 def rnd(shape, seed, scale=1.0):
@@ -56,6 +71,13 @@ def main(out):
         x = rnd((1, 2, hi, wi), 700 + i)
         x[0, 0, :5, :7] = np.nan
         g[f"down{i}"] = ref.downsample(x, ho, wo)
+    for i, (shape, two, l2, pre, norm, eps, plateau, nans, lw) in enumerate(L1):
+        b0, b1 = l1_inputs(i)
+        loss, weighted, d0, d1 = ref.l1loss(b0, b1, l2, pre, norm, eps, plateau, lw)
+        g[f"l1_{i}_loss"] = np.array([loss, weighted], np.float32)
+        g[f"l1_{i}_d0"] = d0
+        if d1 is not None:
+            g[f"l1_{i}_d1"] = d1
     np.savez_compressed(out, **g)
     print("wrote", out, "arrays:", len(g), "bytes:", os.path.getsize(out))
 

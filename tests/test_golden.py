@@ -82,6 +82,29 @@ def test_oracle_channel_norm_and_downsample_match_reference(gold):
         close(oracle.downsample_forward(x, ho, wo), gold[f"down{i}"], 1e-6)
 
 
+def _l1_oracle(i):
+    shape, two, l2, pre, norm, eps, plateau, nans, lw = MG.L1[i]
+    b0, b1 = MG.l1_inputs(i)
+    po = oracle.l1_params(l2_per_location=l2, l2_prescale_by_channels=pre, normalize_by_num_entries=norm, epsilon=eps, plateau=plateau)
+    loss, ncoef = oracle.l1loss_forward(po, b0, b1)
+    d0, d1 = oracle.l1loss_backward(po, b0, b1, lw, ncoef)
+    return loss, d0, d1, lw
+
+
+@pytest.mark.parametrize("i", range(len(MG.L1)))
+def test_oracle_l1loss_matches_reference_layer(gold, i):
+    """The reference's L1LossLayer (with its Eltwise / Power / Convolution sub-layers) executed on the MI355X."""
+    if f"l1_{i}_loss" not in gold:
+        pytest.skip("golden file predates the L1Loss vectors")
+    loss, d0, d1, lw = _l1_oracle(i)
+    ref_loss, ref_weighted = gold[f"l1_{i}_loss"]
+    assert abs(loss - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    assert abs(loss * lw - ref_weighted) <= 2e-6 * max(1.0, abs(ref_weighted))
+    close(d0, gold[f"l1_{i}_d0"], 2e-6)
+    if d1 is not None:
+        close(d1, gold[f"l1_{i}_d1"], 2e-6)
+
+
 @pytest.mark.gpu
 def test_hip_kernels_match_reference_kernels(gold):
     import torch
@@ -117,3 +140,15 @@ def test_hip_kernels_match_reference_kernels(gold):
         x = MG.rnd((1, 2, hi, wi), 700 + i)
         x[0, 0, :5, :7] = np.nan
         close(ops.downsample_forward(dev(x), ho, wo).cpu().numpy(), gold[f"down{i}"], 1e-6)
+    for i, (shape, two, l2, pre, norm, eps, plateau, nans, lw) in enumerate(MG.L1):
+        if f"l1_{i}_loss" not in gold:
+            continue
+        b0, b1 = MG.l1_inputs(i)
+        p = ops.l1_params(l2_per_location=l2, l2_prescale_by_channels=pre, normalize_by_num_entries=norm, epsilon=eps, plateau=plateau)
+        loss, ws = ops.l1loss_forward(p, dev(b0), dev(b1) if b1 is not None else None)
+        ref_loss = float(gold[f"l1_{i}_loss"][0])
+        assert abs(float(loss) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), (i, float(loss), ref_loss)
+        d0, d1 = ops.l1loss_backward(p, dev(b0), dev(b1) if b1 is not None else None, lw, ws)
+        close(d0.cpu().numpy(), gold[f"l1_{i}_d0"], 2e-6)
+        if d1 is not None:
+            close(d1.cpu().numpy(), gold[f"l1_{i}_d1"], 2e-6)

@@ -76,3 +76,36 @@ def test_reference_gpu_warp_resample_downsample_equal_oracle():
     a, b = oracle.downsample_forward(x, 10, 14), ref.downsample(x, 10, 14)
     assert np.array_equal(np.isnan(a), np.isnan(b))
     np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(l2_per_location=True, normalize_by_num_entries=True), dict(l2_per_location=True, l2_prescale_by_channels=True),
+                                 dict(normalize_by_num_entries=True), dict(), dict(l2_per_location=True, normalize_by_num_entries=True, plateau=0.5)])
+@pytest.mark.parametrize("two", [True, False])
+def test_reference_gpu_l1loss_equals_oracle_and_hip(cfg, two):
+    """The reference's L1LossLayer -- its own .cpp/.cu plus the stock Eltwise / Power / Convolution layers it instantiates,
+    compiled in place; only the cuBLAS calls underneath are stand-ins -- against the oracle and the fused HIP kernels."""
+    import torch
+    from flownet2_amd import ops
+    shape = (3, 2, 17, 23)
+    b0 = rnd(shape, 20, 3.0)
+    b1 = rnd(shape, 21, 3.0) if two else None
+    if two:
+        m = np.random.default_rng(22).random((3, 1, 17, 23)) < 0.1
+        b1[np.broadcast_to(m, shape)] = np.nan
+    loss, weighted, d0, d1 = ref.l1loss(b0, b1, loss_weight=0.32, **cfg)
+    po = oracle.l1_params(**cfg)
+    ol, ncoef = oracle.l1loss_forward(po, b0, b1)
+    assert abs(ol - loss) <= 2e-6 * max(1.0, abs(loss)) and abs(ol * 0.32 - weighted) <= 2e-6 * max(1.0, abs(weighted))
+    o0, o1 = oracle.l1loss_backward(po, b0, b1, 0.32, ncoef)
+    np.testing.assert_allclose(o0, d0, rtol=0, atol=2e-6)
+    if two:
+        np.testing.assert_allclose(o1, d1, rtol=0, atol=2e-6)
+    dv = lambda a: torch.from_numpy(a).cuda() if a is not None else None
+    p = ops.l1_params(**cfg)
+    hl, ws = ops.l1loss_forward(p, dv(b0), dv(b1))
+    assert abs(float(hl) - loss) <= 2e-6 * max(1.0, abs(loss))
+    h0, h1 = ops.l1loss_backward(p, dv(b0), dv(b1), 0.32, ws)
+    np.testing.assert_allclose(h0.cpu().numpy(), d0, rtol=0, atol=2e-6)
+    if two:
+        np.testing.assert_allclose(h1.cpu().numpy(), d1, rtol=0, atol=2e-6)
