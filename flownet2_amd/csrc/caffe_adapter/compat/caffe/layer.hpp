@@ -48,6 +48,7 @@ class Layer {
   }
 
   const LayerParameter& layer_param() const { return layer_param_; }
+  vector<shared_ptr<Blob<Dtype> > >& blobs() { return blobs_; }          // learnable parameters (layer.hpp:126-128)
   virtual inline const char* type() const { return ""; }
   virtual inline int ExactNumBottomBlobs() const { return -1; }
   virtual inline int MinBottomBlobs() const { return -1; }

@@ -175,6 +175,14 @@ class ConvolutionParameter {
   FillerParameter weight_filler_, bias_filler_;
 };
 
+class ReLUParameter {
+ public:
+  float negative_slope() const { return negative_slope_; }
+  void set_negative_slope(float v) { negative_slope_ = v; }
+ private:
+  float negative_slope_ = 0.f;
+};
+
 enum Phase { TRAIN = 0, TEST = 1 };
 
 class LayerParameter {
@@ -206,6 +214,8 @@ class LayerParameter {
   PowerParameter* mutable_power_param() { return &power_param_; }
   const ConvolutionParameter& convolution_param() const { return convolution_param_; }
   ConvolutionParameter* mutable_convolution_param() { return &convolution_param_; }
+  const ReLUParameter& relu_param() const { return relu_param_; }
+  ReLUParameter* mutable_relu_param() { return &relu_param_; }
  private:
   std::string name_, type_;
   std::vector<float> loss_weight_;
@@ -219,6 +229,7 @@ class LayerParameter {
   EltwiseParameter eltwise_param_;
   PowerParameter power_param_;
   ConvolutionParameter convolution_param_;
+  ReLUParameter relu_param_;
 };
 
 }  // namespace caffe

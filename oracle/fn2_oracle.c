@@ -21,8 +21,9 @@
  *       dot / gemm / axpby with the textbook meaning).
  *   (2) an independent fp64 re-derivation + autograd gradient checks (tests/test_oracle.py).
  * The stock-layer fast paths at the end of this file (flow heads, bias + ReLU, stem convolution,
- * im2col / col2im) restate stock Caffe layers whose arithmetic lives in cuBLAS in the reference;
- * they are checked against torch's fp64 convolutions (tests/test_oracle.py), not against oracle/_ref.
+ * im2col / col2im) restate stock Caffe layers; oracle/_ref also builds the reference's Convolution,
+ * Deconvolution and ReLU layers (same SGEMM stand-in) and the golden file holds their outputs
+ * (stock_* arrays): PINNED as well, in addition to torch's fp64 convolutions (tests/test_oracle.py).
  *
  * All file:line citations are relative to the reference tree.
  * Arithmetic notes: nvcc contracts `sum += a*b` into an FMA by default, so the restatement uses

@@ -127,3 +127,20 @@ def l1loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, no
     _chk(L.fn2ref_l1loss(int(l2_per_location), int(l2_prescale_by_channels), int(normalize_by_num_entries), epsilon, plateau, loss_weight,
                          _p(b0), _p(b1), N, Cc, H, W, C.byref(loss), C.byref(wl), _p(d0), _p(d1)))
     return loss.value, wl.value, d0, d1
+
+
+def convolution(x, weight, bias=None, kernel=3, stride=1, pad=1, deconv=False, relu=False, negative_slope=0.1):
+    """The reference's stock Convolution / Deconvolution layer (+ in-place ReLU) with the given weights."""
+    x, weight = _f(x), _f(weight)
+    bias = _f(bias) if bias is not None else None
+    N, Cc, H, W = x.shape
+    num_output = weight.shape[1] if deconv else weight.shape[0]
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.fn2ref_convolution.argtypes = [C.c_int] * 6 + [C.c_float, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.POINTER(C.c_int)]
+    shape = (C.c_int * 4)()
+    args = (int(deconv), kernel, stride, pad, num_output, int(relu), negative_slope, _p(x), N, Cc, H, W, _p(weight), _p(bias))
+    _chk(L.fn2ref_convolution(*args, None, shape))
+    out = np.empty(tuple(shape), np.float32)
+    _chk(L.fn2ref_convolution(*args, _p(out), shape))
+    return out

@@ -146,7 +146,51 @@ int fn2ref_downsample(const float* in, int N, int C, int Hin, int Win, int Hout,
   });
 }
 
+#ifdef FN2_SHIM_STOCK
+#include "caffe/layers/conv_layer.hpp"
+#include "caffe/layers/deconv_layer.hpp"
+#include "caffe/layers/relu_layer.hpp"
+
+// Stock Convolution / Deconvolution (square kernel, given weights and optional bias), optionally followed by the in-place
+// ReLU{negative_slope}: the reference's own conv_layer / deconv_layer / base_conv_layer / im2col / relu_layer sources; the
+// SGEMM underneath is the plain stand-in of oracle/ref_compat.  Pins the stock-layer fast paths of libflownet2_hip.so.
+extern "C" __attribute__((visibility("default")))
+int fn2ref_convolution(int deconv, int kernel, int stride, int pad, int num_output, int relu, float negative_slope,
+                       const float* x, int N, int C, int H, int W, const float* weight, const float* bias /* nullable */,
+                       float* out /* nullable */, int* out_shape /* [4] */) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    ConvolutionParameter* cp = lp.mutable_convolution_param();
+    cp->set_num_output(num_output); cp->add_kernel_size(kernel); cp->add_stride(stride); cp->add_pad(pad);
+    cp->set_bias_term(bias != nullptr);
+    cp->mutable_weight_filler()->set_type("constant");
+    cp->mutable_bias_filler()->set_type("constant");
+    shared_ptr<Layer<float> > layer;
+    if (deconv) layer.reset(new DeconvolutionLayer<float>(lp)); else layer.reset(new ConvolutionLayer<float>(lp));
+    Blob<float> bot(N, C, H, W), top;
+    fill(bot, x);
+    vector<Blob<float>*> bottom{&bot}, tops{&top};
+    layer->SetUp(bottom, tops);
+    fill(*layer->blobs()[0], weight);
+    if (bias) fill(*layer->blobs()[1], bias);
+    layer->Forward(bottom, tops);
+    if (relu) {
+      LayerParameter rp;
+      rp.mutable_relu_param()->set_negative_slope(negative_slope);
+      ReLULayer<float> act(rp);
+      act.SetUp(tops, tops);            // in place, like the prototxts
+      act.Forward(tops, tops);
+    }
+    CUDA_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 4; ++i) out_shape[i] = top.shape(i);
+    if (out) fetch(top, out);
+  });
+}
+#endif
+
 #ifdef FN2_SHIM_L1LOSS
+
 // The reference's L1LossLayer (oracle/_ref: built with its stock sub-layers, see oracle/README.md) or the adapter's.
 extern "C" __attribute__((visibility("default")))
 int fn2ref_l1loss(int l2_per_location, int prescale, int normalize, float epsilon, float plateau, float loss_weight,

@@ -26,6 +26,18 @@ L1 = [((2, 2, 9, 11), True, True, False, True, 1e-2, 0.0, True, 0.32), ((2, 2, 9
       ((1, 4, 8, 8), False, False, False, True, 1e-2, 0.0, False, 0.25), ((2, 2, 20, 28), True, True, False, True, 1e-2, 0.0, True, 0.02)]
 
 
+def stock_inputs(which):
+    if which == "stem":
+        return rnd((1, 3, 24, 32), 1000), rnd((64, 3, 7, 7), 1001, 0.1), rnd((64,), 1002)
+    if which == "predict_flow":
+        return rnd((2, 34, 9, 11), 1003), rnd((2, 34, 3, 3), 1004, 0.1), rnd((2,), 1005)
+    if which == "upsample_flow":
+        return rnd((2, 2, 5, 7), 1006), rnd((2, 2, 4, 4), 1007), rnd((2,), 1008)
+    if which == "deconv":
+        return rnd((2, 12, 5, 7), 1009), rnd((12, 8, 4, 4), 1010, 0.1), rnd((8,), 1011)
+    return rnd((2, 12, 9, 11), 1012), rnd((16, 12, 3, 3), 1013, 0.1), rnd((16,), 1014)
+
+
 def l1_inputs(i):
     shape, two, l2, pre, norm, eps, plateau, nans, lw = L1[i]
     b0 = rnd(shape, 800 + i, 2.0)
@@ -78,6 +90,18 @@ def main(out):
         g[f"l1_{i}_d0"] = d0
         if d1 is not None:
             g[f"l1_{i}_d1"] = d1
+    # stock layers behind the fast paths (reference Convolution / Deconvolution / ReLU sources, plain SGEMM stand-in)
+    x, w, b = stock_inputs("stem")
+    g["stock_stem"] = ref.convolution(x, w, b, kernel=7, stride=2, pad=3, relu=True)
+    x, w, b = stock_inputs("predict_flow")
+    g["stock_predict_flow"] = ref.convolution(x, w, b, kernel=3, stride=1, pad=1)
+    x, w, b = stock_inputs("upsample_flow")
+    g["stock_upsample_flow"] = ref.convolution(x, w, b, kernel=4, stride=2, pad=1, deconv=True)
+    x, w, b = stock_inputs("deconv")
+    g["stock_deconv_relu"] = ref.convolution(x, w, b, kernel=4, stride=2, pad=1, deconv=True, relu=True)
+    x, w, b = stock_inputs("conv3x3")
+    g["stock_conv3x3s2_relu"] = ref.convolution(x, w, b, kernel=3, stride=2, pad=1, relu=True)
+    g["stock_conv3x3s2_nobias"] = ref.convolution(x, w, None, kernel=3, stride=2, pad=1)
     np.savez_compressed(out, **g)
     print("wrote", out, "arrays:", len(g), "bytes:", os.path.getsize(out))
 

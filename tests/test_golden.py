@@ -105,6 +105,27 @@ def test_oracle_l1loss_matches_reference_layer(gold, i):
         close(d1, gold[f"l1_{i}_d1"], 2e-6)
 
 
+def test_oracle_stock_layer_twins_match_reference_layers(gold):
+    """The oracle twins of the stock-layer fast paths against the reference's Convolution / Deconvolution / ReLU layers."""
+    if "stock_stem" not in gold:
+        pytest.skip("golden file predates the stock-layer vectors")
+    x, w, b = MG.stock_inputs("stem")
+    close(oracle.conv_k7s2_relu_forward(x, w, b, 0.1), gold["stock_stem"], 3e-6)
+    x, w, b = MG.stock_inputs("predict_flow")
+    close(oracle.predict_flow_conv_forward(x, w, b), gold["stock_predict_flow"], 3e-6)
+    x, w, b = MG.stock_inputs("upsample_flow")
+    close(oracle.upsample_flow_deconv_forward(x, w, b), gold["stock_upsample_flow"], 2e-6)
+    x, w, b = MG.stock_inputs("deconv")          # weight^T x bottom in fp64 here, then the oracle's col2im + bias + ReLU
+    N, Cin, H, W = x.shape
+    col = np.matmul(w.reshape(Cin, -1).T.astype(np.float64), x.reshape(N, Cin, H * W).astype(np.float64)).astype(np.float32)
+    close(oracle.col2im_bias_relu_forward(col, b, N, w.shape[1], 2 * H, 2 * W, 4, 1, 2, True, 0.1), gold["stock_deconv_relu"], 3e-6)
+    x, w, b = MG.stock_inputs("conv3x3")         # the oracle's im2col, fp64 GEMM, then the oracle's bias + ReLU
+    col = oracle.im2col_forward(x, 3, 1, 2)
+    y = np.matmul(w.reshape(16, -1).astype(np.float64), col.astype(np.float64)).astype(np.float32).reshape(gold["stock_conv3x3s2_nobias"].shape)
+    close(y, gold["stock_conv3x3s2_nobias"], 3e-6)
+    close(oracle.bias_leaky_relu_forward(gold["stock_conv3x3s2_nobias"], b, 0.1), gold["stock_conv3x3s2_relu"], 1e-6)
+
+
 @pytest.mark.gpu
 def test_hip_kernels_match_reference_kernels(gold):
     import torch
@@ -152,3 +173,17 @@ def test_hip_kernels_match_reference_kernels(gold):
         close(d0.cpu().numpy(), gold[f"l1_{i}_d0"], 2e-6)
         if d1 is not None:
             close(d1.cpu().numpy(), gold[f"l1_{i}_d1"], 2e-6)
+    if "stock_stem" in gold:
+        from flownet2_amd import functional as Fn
+        x, w, b = MG.stock_inputs("stem")
+        close(ops.conv_k7s2_relu_forward(dev(x), dev(w), dev(b), 0.1).cpu().numpy(), gold["stock_stem"], 3e-6)
+        x, w, b = MG.stock_inputs("predict_flow")
+        close(ops.predict_flow_conv_forward(dev(x), dev(w), dev(b)).cpu().numpy(), gold["stock_predict_flow"], 3e-6)
+        x, w, b = MG.stock_inputs("upsample_flow")
+        close(ops.upsample_flow_deconv_forward(dev(x), dev(w), dev(b)).cpu().numpy(), gold["stock_upsample_flow"], 2e-6)
+        x, w, b = MG.stock_inputs("deconv")
+        wt = dev(w).reshape(w.shape[0], -1).t().contiguous()
+        close(Fn.deconv_gemm_relu(dev(x), wt, dev(b), w.shape[1]).cpu().numpy(), gold["stock_deconv_relu"], 1e-5)
+        x, w, b = MG.stock_inputs("conv3x3")
+        close(Fn.conv_gemm_relu(dev(x), dev(w), dev(b), 2, 1, 0.1).cpu().numpy(), gold["stock_conv3x3s2_relu"], 1e-5)
+        close(ops.bias_leaky_relu_(dev(gold["stock_conv3x3s2_nobias"]), dev(b), 0.1).cpu().numpy(), gold["stock_conv3x3s2_relu"], 1e-6)

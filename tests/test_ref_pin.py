@@ -109,3 +109,49 @@ def test_reference_gpu_l1loss_equals_oracle_and_hip(cfg, two):
     np.testing.assert_allclose(h0.cpu().numpy(), d0, rtol=0, atol=2e-6)
     if two:
         np.testing.assert_allclose(h1.cpu().numpy(), d1, rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_reference_stock_layers_pin_the_fast_paths():
+    """conv1 + ReLU1, predict_flow, upsample_flow, the GEMM route and bias + ReLU against the reference's stock
+    Convolution / Deconvolution / ReLU layers (their own sources; plain fp32 SGEMM stand-in underneath)."""
+    import torch
+    from flownet2_amd import functional as Fn, ops
+    dv = lambda a: torch.from_numpy(a).cuda()
+    hv = lambda t: t.cpu().numpy()
+
+    def close(a, b, atol, what):
+        s = max(1.0, float(np.abs(b).max()))
+        err = float(np.abs(a - b).max())
+        assert a.shape == b.shape and err <= atol * s, f"{what}: {err:.3e} > {atol * s:.3e}"
+
+    # stem: Convolution{7,2,3} + ReLU{0.1}
+    for cin in (3, 6):
+        x, w, b = rnd((2, cin, 32, 64), 30, 1.0), rnd((64, cin, 7, 7), 31, 0.1), rnd((64,), 32)
+        want = ref.convolution(x, w, b, kernel=7, stride=2, pad=3, relu=True)
+        close(hv(ops.conv_k7s2_relu_forward(dv(x), dv(w), dv(b), 0.1)), want, 3e-6, "stem")
+        close(oracle.conv_k7s2_relu_forward(x, w, b, 0.1), want, 3e-6, "stem oracle")
+    # predict_flow: Convolution{3,1,1} -> 2 channels, no ReLU
+    x, w, b = rnd((2, 194, 20, 28), 33), rnd((2, 194, 3, 3), 34, 0.05), rnd((2,), 35)
+    want = ref.convolution(x, w, b, kernel=3, stride=1, pad=1)
+    close(hv(ops.predict_flow_conv_forward(dv(x), dv(w), dv(b))), want, 3e-6, "predict_flow")
+    close(oracle.predict_flow_conv_forward(x, w, b), want, 3e-6, "predict_flow oracle")
+    # upsample_flow: Deconvolution{4,2,1} 2 -> 2
+    x, w, b = rnd((2, 2, 10, 14), 36), rnd((2, 2, 4, 4), 37), rnd((2,), 38)
+    want = ref.convolution(x, w, b, kernel=4, stride=2, pad=1, deconv=True)
+    close(hv(ops.upsample_flow_deconv_forward(dv(x), dv(w), dv(b))), want, 2e-6, "upsample_flow")
+    close(oracle.upsample_flow_deconv_forward(x, w, b), want, 2e-6, "upsample_flow oracle")
+    # GEMM route: 3x3 stride 1 / 2 + ReLU, 4x4/2 deconvolution + ReLU
+    x, w, b = rnd((2, 64, 10, 14), 39), rnd((96, 64, 3, 3), 40, 0.05), rnd((96,), 41)
+    for stride in (1, 2):
+        want = ref.convolution(x, w, b, kernel=3, stride=stride, pad=1, relu=True)
+        close(hv(Fn.conv_gemm_relu(dv(x), dv(w), dv(b), stride, 1, 0.1)), want, 1e-5, "conv via im2col + GEMM")
+        col = oracle.im2col_forward(x, 3, 1, stride)
+        np.testing.assert_array_equal(hv(ops.im2col_forward(dv(x), 3, 1, stride)), col)
+    wd, bd = rnd((64, 32, 4, 4), 42, 0.05), rnd((32,), 43)
+    want = ref.convolution(x, wd, bd, kernel=4, stride=2, pad=1, deconv=True, relu=True)
+    close(hv(Fn.deconv_gemm_relu(dv(x), dv(wd).reshape(64, 512).t().contiguous(), dv(bd), 32)), want, 1e-5, "deconv via GEMM + col2im")
+    # bias + ReLU alone: the reference's bias-free convolution, then our pass
+    nob = ref.convolution(x, w, None, kernel=3, stride=1, pad=1)
+    close(hv(ops.bias_leaky_relu_(dv(nob), dv(b), 0.1)), ref.convolution(x, w, b, kernel=3, stride=1, pad=1, relu=True), 1e-6, "bias + ReLU")
+    close(oracle.bias_leaky_relu_forward(nob, b, 0.1), ref.convolution(x, w, b, kernel=3, stride=1, pad=1, relu=True), 1e-6, "bias + ReLU oracle")
