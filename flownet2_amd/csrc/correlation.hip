@@ -154,22 +154,19 @@ static int g_force_generic = 0;
 
 using namespace fn2;
 
-namespace fn2 { extern int g_corr_ablation; extern int g_corr_stage; extern int g_corr_tune; extern unsigned long long* g_corr_dbg; }
+namespace fn2 { extern int g_corr_ablation; extern int g_corr_force_dword; extern unsigned long long* g_corr_dbg; }
 
 FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   fn2::g_corr_dbg = reinterpret_cast<unsigned long long*>(device_buffer);
   return FN2_OK;
 }
 
-// impl: 0 = auto, 1 = force the generic kernel, 2 = MFMA kernel with register staging (first generation),
-// 3 = dword LDS-DMA MFMA kernel even where the paired-parity kernel applies,
-// 16 + bits = ablation of the register-staged MFMA kernel (FN2_ABLATION builds)
+// impl: 0 = automatic, 1 = generic kernels, 3 = general (dword LDS-DMA) MFMA forward even where the paired-parity kernel
+// applies, 64 + bits = ablation of the general MFMA forward (FN2_ABLATION builds: 1 no MFMA, 2 no staging loads, 4 no stores)
 FN2_API int fn2_debug_set_correlation_impl(int impl) {
   g_force_generic = (impl == 1);
-  fn2::g_corr_stage = (impl == 2 || (impl >= 16 && impl < 32)) ? 1 : (impl == 3 ? 2 : 0);
-  fn2::g_corr_ablation = (impl >= 16 && impl < 32) ? impl - 16 : 0;
-  fn2::g_corr_tune = impl >= 48 ? impl - 48 : 0;
-
+  fn2::g_corr_force_dword = (impl == 3);
+  fn2::g_corr_ablation = impl >= 64 ? impl - 64 : 0;
   return FN2_OK;
 }
 

@@ -1,4 +1,4 @@
-// Correlation forward fast path for gfx950: kernel_size 1, stride_1 1, MULTIPLY, pad == max_displacement
+// Correlation forward fast paths for gfx950: kernel_size 1, stride_1 1, MULTIPLY, pad == max_displacement
 // (the FlowNetC instance: max_displacement 20, stride_2 2 -> 21x21 = 441 displacement channels).
 //
 // Replaces blob_rearrange_kernel2 + CorrelateData (reference: src/caffe/layers/correlation_layer.cu:23-114).
@@ -13,21 +13,18 @@
 // (1-D) banding.  Each tile product runs on v_mfma_f32_16x16x4_f32: exact fp32 (a k-ordered fma
 // chain), 64 flop/clk/SIMD = the fp32 peak of the chip (157.3 TFLOP/s).
 //
-// Work decomposition.  One workgroup (8 waves) = (sample n, y-parity py, 4 class rows I, one N
-// patch-row a, a 32-pixel x span): wave w owns the M tile (px = w % S2, patch w / S2) and the NB N
-// tiles of patch-row a.  The 4 + 4 image rows a workgroup needs are staged through LDS in chunks of
-// 16 channels: coalesced row reads straight from NCHW through a raw buffer descriptor whose
-// out-of-range answer (0.0f) IS the reference's zero padding, de-interleaved by x parity so the
-// MFMA operand reads are bank-conflict free, double-buffered with register staging (loads of chunk
-// k+1 in flight under the MFMAs of chunk k, one barrier per chunk).  The accumulators are scattered
-// into an LDS image of the output and written back as full 128-byte rows.  LDS (52.4 KiB) and VGPRs
-// (<= 80) are sized for THREE resident workgroups per CU = 6 waves per SIMD.
+// Task = (sample n, y-parity py, 4 class rows I, one N patch-row a, a 32-pixel x span).  The 4 + 4 image rows a
+// task needs are staged through LDS in 8-channel chunks by LDS-DMA (buffer_load ... lds) straight from NCHW through
+// a raw buffer descriptor whose out-of-range answer (0.0f) IS the reference's zero padding; ring of 3 slots, issue
+// two chunks ahead, hand-counted vmcnt, one raw s_barrier per chunk.  The accumulators are scattered into an LDS
+// image of the output and written back as full 128-byte rows.  Two kernels share this skeleton:
+//   corr_fwd_pair<R>      stride_2 2, R 10, W % 4 == 0 (FlowNetC / FlowNet2): 4 waves, a wave owns both x parities of
+//                         its patch, 16-byte DMA, ds_read_b64 operands (second half of this file);
+//   corr_fwd_glds<S2,R>   everything else the MFMA path covers: 8 waves (parity x patch), dword DMA with the x
+//                         parities de-interleaved on the source side, ds_read_b32 operands.
+// (A first generation with register staging and ds_read_b128 operands ran 62 us where these run 51 / 42 us; DESIGN.md.)
 //
-// Scheduling.  Tasks whose second-map rows are all outside the image ("light": they only write
-// zeros) are ordered before the heavy ones of the same sample, and block b runs logical task
-// (b % 8) * GP + b / 8 so that every XCD (b % 8) walks one contiguous task range = one sample when
-// N is a multiple of 8: the 21x re-reads of a sample's rows stay inside that XCD's 4 MiB L2 and HBM
-// sees ~ the algorithmic 4*N*H*W*(2C + 441) bytes.
+// Scheduling: decode_task below (live tasks first, dead tasks last, lists balanced over the 8 XCDs).
 #include "correlation.hpp"
 
 #include <type_traits>
@@ -38,23 +35,12 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
-constexpr int kKC = 16;   // channels per LDS chunk (4 MFMA k-steps)
+constexpr int kKC = 16;   // channel granularity of the MFMA paths (two 8-channel chunks per loop trip)
 
 constexpr int up_mod(int v, int r, int m) { return v + ((r - v % m) + m) % m; }   // smallest >= v with == r (mod m)
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-// LDS chunk image: B region [row 4][px S2][jcol JW][16 ch], A region [row 4][px S2][jcol SPANC][16 ch]:
-// the 16 channels of one pixel position are contiguous (64 B).  Lane (kk, ni, nj) of a 16x16x4 fragment
-// reads ONE ds_read_b128 per tile = channels 4kk..4kk+3 of its position, i.e. its operand for all four
-// k-steps of the chunk (k-step r of lane group kk contracts channel 4kk + r; the two maps use the same
-// assignment, and a sum over channels does not care).  ds_read_b128 is serviced in 16-lane groups
-// {(0,0),(0,3),(1,1),(1,2)} / {(0,1),(0,2),(1,0),(1,3)} of (kk, ni) (x 4 nj each); with the row stride
-// == 2 (mod 4) sixteen-byte slots = 8 (mod 16) floats every group covers all 64 banks exactly once.
-// The channel quad q of column j (x-parity px) is stored in slot q ^ ((j >> 1) & 3) ^ (2 px): any per-position
-// permutation keeps the reads conflict-free, and this one makes the staging ds_write_b128 (8 consecutive lanes =
-// 4 columns x 2 parities of one row, 32 banks) conflict-free as well -- unswizzled they were 4-way conflicts
-// and 60 % of all LDS cycles.
 template <int S2, int R>
 struct Cfg {
   static constexpr int D = 2 * R + 1;                 // displacements per axis
@@ -64,26 +50,15 @@ struct Cfg {
   static constexpr int SPANPX = SPANC * S2;           // pixels per workgroup row (32)
   static constexpr int JW = SPANC - 4 + 4 * NB;       // class columns of the second map staged per row
   static constexpr int BPX = JW * S2;                 // staged pixels per row of the second map
-  static constexpr int BPL = JW * kKC;                // floats per (row, px) plane, second map
-  static constexpr int APL = SPANC * kKC;
-  static constexpr int BRS = up_mod(S2 * BPL, 8, 16); // row strides (floats)
-  static constexpr int ARS = up_mod(S2 * APL, 8, 16);
-  static constexpr int AOFF = 4 * BRS;
-  static constexpr int CHUNK = AOFF + 4 * ARS;        // floats per staged chunk
-  static constexpr int BWAVES = cdiv(4 * BPX, 64);    // staging: waves [0,BWAVES) second map, next AWAVES first map
-  static constexpr int AWAVES = cdiv(4 * SPANPX, 64);
   static constexpr int XS = SPANPX + 1;               // output-image row stride in LDS
   static constexpr int OROWS = 16 * D;                // (mi, ni, o) rows of the output image
-  static constexpr int LDS_FLOATS = cmax(2 * CHUNK, OROWS * XS);
   static constexpr int LO_MAX = (NB >= 3) ? 2 : 0;    // specialised N-tile ranges [lo, hi], lo <= LO_MAX, hi >= HI_MIN
   static constexpr int HI_MIN = (NB >= 3) ? NB - 3 : NB - 1;
-  static_assert(kKC == 16, "one ds_read_b128 = the 4 k-steps of a 16-channel chunk");
   static_assert(kWaves % S2 == 0, "waves must split evenly over x parities");
   static_assert(kThreads % SPANPX == 0, "store phase mapping");
-  static_assert(BWAVES + AWAVES <= kWaves, "staging does not fit the workgroup");
 };
 
-int g_corr_ablation = 0;   // FN2_ABLATION builds only (profiling)
+int g_corr_ablation = 0;   // FN2_ABLATION builds only (profiling): bit 0 no MFMA, bit 1 no staging loads, bit 2 no stores
 unsigned long long* g_corr_dbg = nullptr;   // FN2_ABLATION builds: per-workgroup {start, loop end, end, hw id} trace
 
 struct MfmaArgs {
@@ -91,7 +66,6 @@ struct MfmaArgs {
   int NI, NSPAN;        // M patch rows per y-parity class, x spans
   int TH, TD;           // live / dead tasks per sample
   int LP, DP;           // live / dead list entries per XCD
-  int tune;             // experiment switch (fn2_debug_set_correlation_impl 48 + n)
 };
 
 // live N patch-rows of M patch-row I: a in [alo, ahi] (may be empty)
@@ -105,140 +79,6 @@ __host__ __device__ inline void live_range(int I, int Hc, int& alo, int& ahi) {
   ahi = hi_num < 0 ? -1 : hi_num / 4;
   if (ahi > NB - 1) ahi = NB - 1;
   if (4 * I >= Hc) { alo = 0; ahi = -1; }
-}
-
-// One channel pass of a workgroup: stage 16-channel chunks of the 4 + 4 image rows through LDS
-// (double buffered, register staged) and run the MFMAs of N tiles [LO, HI] of this wave.
-template <int S2, int R, int LO, int HI, int ABL, typename Acc>
-__device__ __forceinline__ void k_loop(Acc& acc, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
-                                       int tid, int lane, int wave, int px, int Jw, int py, int i0, int i2_0, int jS, unsigned long long (&ph)[4]) {
-  using K = Cfg<S2, R>;
-  const int plane = g.H * g.W;
-  // ---- staging plan: a thread owns ONE pixel position of the 4 + 4 rows and walks the 16 channels
-  // of a chunk with an SGPR channel offset (global side) / an immediate (LDS side).
-  constexpr unsigned OOB = 0x7ffffff0u;
-  const bool isB = wave < K::BWAVES;
-  const int pos = isB ? tid : tid - 64 * K::BWAVES;
-  unsigned voff = OOB;
-  int laddr = -1;
-  int wsw = 0;   // quad swizzle of this position: channels 4q..4q+3 live in 16-byte slot q ^ wsw (see Cfg)
-  if (isB) {
-    const int row = pos / K::BPX, col = pos % K::BPX;
-    if (row < 4) {
-      const int ib = i2_0 + row, yb = S2 * ib + py, xb = S2 * (jS - R) + col;
-      if (ib >= 0 && yb < g.H && xb >= 0 && xb < g.W) voff = 4u * (unsigned)(yb * g.W + xb);
-      laddr = row * K::BRS + (col % S2) * K::BPL + (col / S2) * kKC;
-      wsw = (((col / S2) >> 1) & 3) ^ (((col % S2) << 1) & 3);
-    }
-  } else {
-    const int row = pos / K::SPANPX, col = pos % K::SPANPX;
-    if (row < 4) {
-      const int ya = S2 * (i0 + row) + py, xa = S2 * jS + col;
-      if (ya < g.H && xa < g.W) voff = 4u * (unsigned)(ya * g.W + xa);
-      laddr = K::AOFF + row * K::ARS + (col % S2) * K::APL + (col / S2) * kKC;
-      wsw = (((col / S2) >> 1) & 3) ^ (((col % S2) << 1) & 3);
-    }
-  }
-  const float* src = isB ? b_n : a_n;        // wave-uniform: one descriptor per wave
-  const unsigned chunk_bytes = 4u * kKC * (unsigned)plane;
-  const unsigned plane_bytes = 4u * (unsigned)plane;
-  const bool stager = laddr >= 0 && !(ABL & 2);
-  float sv[kKC];                     // register staging set (one chunk of this thread's pixel position)
-
-  // Staging pipeline.  Per chunk c:  MFMAs on LDS buffer c%2  ->  wait for the row loads of chunk c+1
-  // (issued one whole chunk earlier) and write them to buffer (c+1)%2  ->  issue the row loads of
-  // chunk c+2  ->  barrier.  The loads are issued AFTER the LDS write on purpose: hipcc's waitcnt
-  // insertion cannot count loads across the loop back-edge and turns any "wait for the older half
-  // of the loads in flight" into s_waitcnt vmcnt(0), which would expose a full memory round trip
-  // per chunk; with nothing younger in flight vmcnt(0) is the correct wait.
-  auto load_chunk = [&](int chunk) {
-    if (stager) {
-      const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (size_t)chunk * kKC * plane), 0, chunk_bytes, 0x00020000);
-#pragma unroll
-      for (int kc = 0; kc < kKC; ++kc)
-        sv[kc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, kc * plane_bytes, 0));
-    }
-  };
-  auto store_chunk = [&](float* buf) {
-    if constexpr ((ABL & 8) != 0) {      // profiling: keep the loads alive but store stale registers (no vmcnt wait)
-      if (laddr >= 0) {
-#pragma unroll
-        for (int q = 0; q < kKC / 4; ++q) *reinterpret_cast<f32x4*>(buf + laddr + 4 * q) = f32x4{1.f, 2.f, 3.f, (float)laddr};
-      }
-      return;
-    }
-    if (laddr >= 0) {                    // the 16 channels of this thread's position: 4 x ds_write_b128
-#pragma unroll
-      for (int q = 0; q < kKC / 4; ++q)
-        *reinterpret_cast<f32x4*>(buf + laddr + 4 * (q ^ wsw)) = f32x4{sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]};
-    }
-  };
-
-  // operand addresses: lane (kk, ni, nj) reads channels 4kk..4kk+3 of position (ni, 4Jw + 4b + nj)
-  const int kk = lane >> 4, ni = (lane & 15) >> 2, nj = lane & 3;
-  const int rsw = ((2 * Jw + (nj >> 1)) & 3) ^ ((px << 1) & 3);          // swizzle of column 4Jw + nj (even tiles; odd tiles: ^ 2)
-  const int aAddr = K::AOFF + ni * K::ARS + px * K::APL + (4 * Jw + nj) * kKC + 4 * (kk ^ rsw);
-  const int bAddr0 = ni * K::BRS + px * K::BPL + (4 * Jw + nj) * kKC + 4 * (kk ^ rsw);
-  const int bAddr1 = ni * K::BRS + px * K::BPL + (4 * Jw + nj) * kKC + 4 * (kk ^ rsw ^ 2);
-  constexpr int NT = (LO <= HI && !(ABL & 1)) ? HI - LO + 1 : 0;
-
-  // One chunk = 1 + NT ds_read_b128 and 4 * NT MFMAs per wave.  All reads are issued first; the MFMAs
-  // walk k-step-major / tile-minor so that consecutive MFMAs hit different accumulators (a dependent
-  // 16x16x4 pair would stall 8 cycles) and each only waits for the operands it needs.
-  auto compute = [&](const float* buf) {
-    if constexpr (NT > 0) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(buf + aAddr);
-      f32x4 bv[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const f32x4*>(buf + (((LO + t) & 1) ? bAddr1 : bAddr0) + 4 * (LO + t) * kKC);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-          acc[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[t][r], acc[LO + t], 0, 0, 0);
-      }
-    }
-  };
-
-  const int nchunks = g.C / kKC;
-  float* buf0 = smem;
-  float* buf1 = smem + K::CHUNK;
-  load_chunk(0);
-  store_chunk(buf0);
-  if (nchunks > 1) load_chunk(1);
-  __syncthreads();
-#ifdef FN2_ABLATION
-#define FN2_T(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - tprev; tprev = now_; }
-  unsigned long long tprev = __builtin_amdgcn_s_memtime();
-#else
-#define FN2_T(i)
-#endif
-  for (int ch = 0; ch < nchunks; ch += 2) {
-    compute(buf0);
-    FN2_T(0)
-    if (ch + 1 < nchunks) store_chunk(buf1);
-    FN2_T(1)
-    if (ch + 2 < nchunks) load_chunk(ch + 2);
-    FN2_T(2)
-    __syncthreads();
-    FN2_T(3)
-    if (ch + 1 < nchunks) {
-      compute(buf1);
-      FN2_T(0)
-      if (ch + 2 < nchunks) store_chunk(buf0);
-      FN2_T(1)
-      if (ch + 3 < nchunks) load_chunk(ch + 3);
-      FN2_T(2)
-      __syncthreads();
-      FN2_T(3)
-    }
-  }
-#undef FN2_T
-  if constexpr ((ABL & 8) != 0) {
-#pragma unroll
-    for (int kc = 0; kc < kKC; ++kc) asm volatile("" ::"v"(sv[kc]));
-  }
 }
 
 // Task of one workgroup: (sample n, y parity py, M patch-row I, N patch-row a, x span).  live: a is in the live range
@@ -356,83 +196,10 @@ __device__ __forceinline__ void epilogue(const Acc& acc, float* smem, float* __r
   }
 }
 
-template <int S2, int R, int ABL>
-__global__ void __launch_bounds__(kThreads, 6)
-corr_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
-              unsigned long long* __restrict__ dbg) {
-  using K = Cfg<S2, R>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-#ifdef FN2_ABLATION
-  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-#endif
-  const Task k = decode_task<S2, R>(g);
-  if (!k.valid) return;
-  const int n = k.n, py = k.py, I = k.I, a = k.a, span = k.span;
-  const bool heavy = k.live;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int px = wave % S2, Jw = wave / S2;
-  const int i0 = 4 * I, jS = K::SPANC * span, jw = jS + 4 * Jw;
-  const int Hc = (g.H - py + S2 - 1) / S2;      // class rows of this y parity
-  const int Wc = (g.W - px + S2 - 1) / S2;      // class cols of this wave's x parity
-  if (i0 >= Hc) return;                         // whole workgroup (uniform): no output rows
-
-  const size_t plane = (size_t)g.H * g.W;
-  const float* a_n = b0 + (size_t)n * g.C * plane;
-  const float* b_n = b1 + (size_t)n * g.C * plane;
-  const int i2_0 = i0 - R + 4 * a;
-
-  f32x4 acc[K::NB];
-#pragma unroll
-  for (int b = 0; b < K::NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  unsigned long long ph[4] = {0, 0, 0, 0};
-  if (heavy) {
-    // Straight-line MFMA bodies matter: a branch per tile serialises every ds_read -> s_waitcnt -> v_mfma triple.
-    const int sel = tile_range_sel<S2, R>(jw, Wc);
-#define FN2_KLOOP(LO_, HI_) k_loop<S2, R, LO_, HI_, ABL>(acc, smem, a_n, b_n, g, tid, lane, wave, px, Jw, py, i0, i2_0, jS, ph)
-    switch (sel) {
-      case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
-      case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
-      case 2: FN2_KLOOP(0, K::HI_MIN + 2); break;
-      case 3: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 0); break;
-      case 4: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 1); break;
-      case 5: FN2_KLOOP(K::LO_MAX / 2, K::HI_MIN + 2); break;
-      case 6: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 0); break;
-      case 7: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 1); break;
-      case 8: FN2_KLOOP(K::LO_MAX, K::HI_MIN + 2); break;
-      default: FN2_KLOOP(1, 0); break;   // wave without a live M tile: staging + barriers only
-    }
-#undef FN2_KLOOP
-  }
-
-#ifdef FN2_ABLATION
-  const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
-#endif
-  epilogue<S2, R, !(ABL & 4)>(acc, smem, top, g, k, tid, lane, px, Jw);
-#ifdef FN2_ABLATION
-  if (dbg && threadIdx.x == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    dbg[4 * blockIdx.x + 0] = t_start;
-    dbg[4 * blockIdx.x + 1] = t_loop;
-    dbg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-    dbg[4 * blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hwid | ((unsigned long long)(heavy ? 1 : 0) << 63);
-  }
-  if (dbg && lane == 0) {     // per-wave phase sums: [compute, store(+vmcnt wait), load issue, barrier]
-    unsigned long long* o = dbg + 4 * 1024 + (size_t)(blockIdx.x * kWaves + wave) * 4;
-    o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
-  }
-#endif
-}
-
 // =====================================================================================================
-// LDS-DMA variant.  The staged rows go global -> LDS directly (buffer_load_dword ... lds): no staging VGPRs, no
-// ds_write pass, no "wait for loads, then write" phase in front of every barrier -- with three workgroups per CU
-// running in lock step that phase had the matrix pipe idle.  An LDS-DMA instruction writes M0 + lane * 4, i.e.
+// General LDS-DMA kernel (8 waves, dword DMA).  The staged rows go global -> LDS directly (buffer_load_dword ... lds):
+// no staging VGPRs, no ds_write pass, no "wait for loads, then write" phase in front of every barrier -- with three
+// workgroups per CU running in lock step that phase had the matrix pipe idle.  An LDS-DMA instruction writes M0 + lane * 4, i.e.
 // one 64-dword run per wave instruction, so the LDS image is built from runs:
 //   second map: [channel group][channel][row 4][x parity][class column JW]  (a group = GC channels = a whole
 //               number of runs; groups GPADG dwords apart), lane -> pixel de-interleaves the x parities on the
@@ -649,8 +416,6 @@ corr_fwd_glds(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;     // LDS byte address of the ring
   if (k.live) {
     const int sel = tile_range_sel<S2, R>(jw, Wc);
-    if (g.tune == 1) { if (k.span == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
-    if (g.tune == 2) { if (k.span == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
 #define FN2_KLOOP(LO_, HI_) k_loop_glds<S2, R, LO_, HI_, ABL>(acc, smem, a_n, b_n, g, lds_base, lane, wave, px, Jw, k.py, i0, i2_0, jS)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
@@ -987,8 +752,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #endif
 }
 
-int g_corr_tune = 0;
-int g_corr_stage = 0;   // 0 = automatic, 1 = register staging (first generation), 2 = dword LDS-DMA kernel even where the paired one applies
+int g_corr_force_dword = 0;   // test hook: run the general (dword LDS-DMA) kernel even where the paired one applies
 
 template <int S2, int R>
 static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* top, hipStream_t st) {
@@ -998,46 +762,24 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   const int Hc = (cg.H + S2 - 1) / S2, Wc = (cg.W + S2 - 1) / S2;
   g.NI = (Hc + 3) / 4;
   g.NSPAN = (Wc + K::SPANC - 1) / K::SPANC;
-  int nheavy = 0;
+  int nlive = 0;
   for (int py = 0; py < S2; ++py)
     for (int I = 0; I < g.NI; ++I) {
       int alo, ahi;
       live_range<S2, R>(I, (cg.H - py + S2 - 1) / S2, alo, ahi);
-      if (ahi >= alo) nheavy += ahi - alo + 1;
+      if (ahi >= alo) nlive += ahi - alo + 1;
     }
-  g.TH = nheavy * g.NSPAN;
+  g.TH = nlive * g.NSPAN;
   g.TD = S2 * g.NI * K::NB * g.NSPAN - g.TH;
-  g.tune = g_corr_tune;
   const long long NL = (long long)cg.N * g.TH, ND = (long long)cg.N * g.TD;
   if (NL + ND > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
   g.LP = (int)((NL + 7) / 8);
   g.DP = (int)((ND + 7) / 8);
   const unsigned grid = 8u * (unsigned)(g.LP + g.DP);
-  const size_t lds = sizeof(float) * K::LDS_FLOATS;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_mfma<S2, R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-#ifdef FN2_ABLATION
-  // profiling-only builds: bit 0 = no MFMA, bit 1 = no staging loads, bit 2 = no output stores
-  if (S2 == 2 && R == 10 && g_corr_ablation) {
-    switch (g_corr_ablation) {
-      case 1: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 1>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 2: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 2>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 3: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 3>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 4: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 4>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 8: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 8>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      case 6: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 6>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-      default: hipLaunchKernelGGL((corr_fwd_mfma<2, 10, 7>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg); break;
-    }
-    return check_launch("correlation_forward (mfma, ablation)");
-  }
-#endif
   if constexpr (S2 == 2 && R == 10) {
     const bool aligned = cg.W % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(b0) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(top)) & 15) == 0;
-    if (g_corr_stage == 0 && aligned) {
+    if (!g_corr_force_dword && !g_corr_ablation && aligned) {
       const size_t lds3 = sizeof(float) * HCfg<R>::LDS_FLOATS;
       static bool attr3_set = false;
       if (!attr3_set) {
@@ -1048,31 +790,27 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
       return check_launch("correlation_forward (mfma, paired parities)");
     }
   }
-  if (g_corr_stage != 1) {
-    const size_t lds2 = sizeof(float) * GCfg<S2, R>::LDS_FLOATS;
-    static bool attr2_set = false;
-    if (!attr2_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_glds<S2, R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      attr2_set = true;
-    }
-#ifdef FN2_ABLATION
-    if (S2 == 2 && R == 10 && g_corr_tune >= 16) {       // impl 64 + bits: 1 no MFMA, 2 no staging loads, 4 no stores
-      switch (g_corr_tune - 16) {
-        case 1: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 1>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
-        case 2: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 2>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
-        case 3: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 3>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
-        case 4: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 4>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
-        case 6: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 6>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
-        default: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 7>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
-      }
-      return check_launch("correlation_forward (mfma, lds-dma, ablation)");
-    }
-#endif
-    hipLaunchKernelGGL((corr_fwd_glds<S2, R, 0>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg);
-    return check_launch("correlation_forward (mfma, lds-dma)");
+  const size_t lds2 = sizeof(float) * GCfg<S2, R>::LDS_FLOATS;
+  static bool attr2_set = false;
+  if (!attr2_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_glds<S2, R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    attr2_set = true;
   }
-  hipLaunchKernelGGL((corr_fwd_mfma<S2, R, 0>), dim3(grid), dim3(kThreads), lds, st, b0, b1, top, g, g_corr_dbg);
-  return check_launch("correlation_forward (mfma)");
+#ifdef FN2_ABLATION
+  if (S2 == 2 && R == 10 && g_corr_ablation) {     // profiling builds, fn2_debug_set_correlation_impl(64 + bits)
+    switch (g_corr_ablation) {
+      case 1: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 1>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+      case 2: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 2>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+      case 3: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 3>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+      case 4: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 4>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+      case 6: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 6>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+      default: hipLaunchKernelGGL((corr_fwd_glds<2, 10, 7>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg); break;
+    }
+    return check_launch("correlation_forward (mfma, lds-dma, ablation)");
+  }
+#endif
+  hipLaunchKernelGGL((corr_fwd_glds<S2, R, 0>), dim3(grid), dim3(kThreads), lds2, st, b0, b1, top, g, g_corr_dbg);
+  return check_launch("correlation_forward (mfma, lds-dma)");
 }
 
 bool corr_fwd_mfma_supported(const CorrGeom& g) {

@@ -70,8 +70,8 @@ def correlation_backward(p: CorrParams, bottom0, bottom1, top_diff, need0=True, 
 
 
 def set_correlation_impl(impl):
-    """Test hook: 0 / False = automatic choice, 1 / True = generic kernels, 2 = MFMA forward with register staging
-    (the first-generation kernel; the default MFMA forward stages through LDS-DMA)."""
+    """Test hook: 0 / False = automatic choice, 1 / True = generic kernels, 3 = the general (dword LDS-DMA) MFMA forward
+    even where the paired-parity kernel applies."""
     check(_lib.lib().fn2_debug_set_correlation_impl(int(impl)))
 
 

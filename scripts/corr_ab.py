@@ -4,7 +4,7 @@ boxes and DVFS state differ between runs, so only within-run, interleaved compar
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flownet2_amd import ops, _lib
-impls = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 2]
+impls = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 3]
 shape = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (8, 256, 40, 56)
 N, C, H, W = shape
 g = torch.Generator(device="cuda").manual_seed(0)

@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="8,256,40,56")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--generic", action="store_true")
-ap.add_argument("--impl", type=int, default=0, help="fn2_debug_set_correlation_impl value (2 = register-staged MFMA kernel)")
+ap.add_argument("--impl", type=int, default=0, help="fn2_debug_set_correlation_impl value (3 = general dword LDS-DMA MFMA kernel)")
 ap.add_argument("--backward", action="store_true")
 ap.add_argument("--ablation", type=int, default=0, help="FN2_ABLATION builds: 1 no MFMA, 2 no loads, 4 no stores (bit-or)")
 a = ap.parse_args()
@@ -27,7 +27,7 @@ out = torch.empty(N, 441, H, W, device="cuda")
 ops.set_correlation_impl(a.generic)
 if a.ablation:
     from flownet2_amd import _lib
-    _lib.lib().fn2_debug_set_correlation_impl(16 + a.ablation)
+    _lib.lib().fn2_debug_set_correlation_impl(64 + a.ablation)
 elif a.impl:
     from flownet2_amd import _lib
     _lib.lib().fn2_debug_set_correlation_impl(a.impl)

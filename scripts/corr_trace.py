@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""FN2_ABLATION builds only: per-workgroup timeline of corr_fwd_mfma (start / K-loop end / end, CU id)."""
+"""FN2_ABLATION builds only: per-workgroup timeline of the MFMA correlation kernels (start / K-loop end / end, CU id).
+usage: corr_trace.py [impl]   (impl 0 = automatic, 3 = general kernel, 64 + bits = its ablations)"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +19,6 @@ ops.correlation_forward(p, x, y, out=out); torch.cuda.synchronize()
 L.fn2_debug_set_correlation_trace(None)
 raw = dbg.cpu().numpy()
 d = raw[:4 * 1024].reshape(-1, 4)
-phases = raw[4 * 1024:4 * 1024 + 4 * 8 * 1024].reshape(1024, 8, 4)
 rt = raw[4 * 1024 + 4 * 8 * 1024:].reshape(1024, 2)
 if rt.any():
     rr = rt[rt[:, 0] != 0]
@@ -56,8 +56,3 @@ for q in (0.25, 0.5, 0.75):
     print("t=%d: alive %d (heavy %d); per-CU histogram %s" % (tm, alive.sum(), (alive & (heavy == 1)).sum(), sorted(Counter(ca.values()).items())))
 print("heavy: loop phase med", int(np.median((loop - start)[heavy == 1])), " epilogue med", int(np.median((end - loop)[heavy == 1])))
 
-hb = bidx[heavy == 1]
-P = phases[hb]                      # [heavy blocks, waves, 4]
-print("per-wave phase sums over 16 chunks (cycles), median over heavy blocks:")
-for w in range(8):
-    print("  wave", w, "compute %d  store+wait %d  load-issue %d  barrier %d" % tuple(np.median(P[:, w, :], axis=0).astype(int)))

@@ -69,7 +69,7 @@ CORR_CASES = [
 
 @pytest.mark.parametrize("case", CORR_CASES)
 @pytest.mark.parametrize("ctype", [oracle.MULTIPLY, oracle.SUBTRACT])
-@pytest.mark.parametrize("force_generic", [0, 1, 2, 3])  # automatic (paired-parity / LDS-DMA MFMA kernels where they apply), generic, register-staged MFMA, dword LDS-DMA MFMA
+@pytest.mark.parametrize("force_generic", [0, 1, 3])  # automatic (paired-parity / general MFMA kernels where they apply), generic, general (dword LDS-DMA) MFMA
 def test_correlation_forward(case, ctype, force_generic):
     N, C, H, W, pad, K, md, s1, s2 = case
     b0, b1 = rand((N, C, H, W), 1), rand((N, C, H, W), 2)
