@@ -14,6 +14,7 @@ base_conv_layer.cpp:125-139) are torch's, so .caffemodel blobs load without tran
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, Optional
 
 import torch
@@ -100,18 +101,20 @@ def _const(device, values):
     return _CONSTS[key]
 
 
-_WT_CACHE: Dict[int, tuple] = {}
+_WT_CACHE: Dict[int, tuple] = {}      # id(weight tensor) -> (weak reference to it, its _version, transposed copy)
 
 
 def _transposed_deconv_weight(w):
-    """weight [Cin, Cout, 4, 4] -> [Cout*16, Cin] contiguous (the A operand of the deconvolution GEMM), cached per
-    parameter tensor and rebuilt when the tensor is modified in place (torch bumps `_version`)."""
-    key = w.data_ptr()
+    """weight [Cin, Cout, 4, 4] -> [Cout*16, Cin] contiguous (the A operand of the deconvolution GEMM).  Cached per
+    parameter tensor OBJECT (the entry dies with the tensor, so a new tensor that reuses the id or the storage address
+    never sees it) and rebuilt when the tensor is modified in place (torch bumps `_version`)."""
+    key = id(w)
     hit = _WT_CACHE.get(key)
-    if hit is None or hit[0] != w._version or hit[1].shape != (w.shape[1] * 16, w.shape[0]) or hit[1].device != w.device:
-        hit = (w._version, w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous())
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        hit = (weakref.ref(w, lambda _r, k=key: _WT_CACHE.pop(k, None)), w._version,
+               w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous())
         _WT_CACHE[key] = hit
-    return hit[1]
+    return hit[2]
 
 
 def _use_gemm_conv(x, stride):

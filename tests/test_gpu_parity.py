@@ -400,6 +400,19 @@ def test_gemm_conv_paths_match_library_convolutions():
     assert_close(host(got), host(ref), 1e-5, "deconv via GEMM + col2im")
 
 
+def test_deconv_weight_cache_follows_the_parameter():
+    """nets caches the transposed deconvolution weight per tensor object and rebuilds it after in-place updates."""
+    from flownet2_amd import nets
+    w = dev(rand((64, 8, 4, 4), 70))
+    t0 = nets._transposed_deconv_weight(w)
+    assert nets._transposed_deconv_weight(w) is t0
+    w.mul_(2.0)
+    t1 = nets._transposed_deconv_weight(w)
+    assert t1 is not t0 and torch.equal(t1, w.reshape(64, 128).t())
+    w2 = dev(rand((64, 8, 4, 4), 71))
+    assert torch.equal(nets._transposed_deconv_weight(w2), w2.reshape(64, 128).t())
+
+
 def test_identity_resample_is_exact():
     """deploy_forward skips the ADAPTED-size Resample when the size does not change: the kernel is then the identity."""
     x = rand((2, 3, 64, 128), 42)
