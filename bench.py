@@ -82,21 +82,22 @@ def corr_roofline(device, batch, h, w, iters):
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
     # calibrated -- profiles/rNN_rocprof_summary.md).  Counters cannot be read from inside this process, so
     # the figure comes from the newest committed profile of exactly this kernel and shape.
-    traffic = None
+    traffic, traffic_detail = None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corr_hbm.json")), reverse=True):
         try:
             pj = json.load(open(f))
             if pj.get("kernel", "").endswith("[%d,%d,%d,%d]" % (batch, C, H, W)):
-                traffic = {"bytes_per_launch": round(pj["traffic_bytes_per_launch"]), "source": os.path.basename(f),
-                           "vs_algorithmic": round(pj["traffic_bytes_per_launch"] / alg_bytes, 3)}
+                traffic = round(pj["traffic_bytes_per_launch"])
+                traffic_detail = {"unit": "bytes per launch", "source": "profiles/" + os.path.basename(f),
+                                  "vs_algorithmic": round(pj["traffic_bytes_per_launch"] / alg_bytes, 3)}
                 break
         except Exception:
             pass
     return {
         "kernel": "corr_fwd (K=1,md=20,s2=2) [%d,%d,%d,%d]" % (batch, C, H, W),
         "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
         "us_per_launch": round(t * 1e6, 2),
         "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
         "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
