@@ -14,7 +14,7 @@ SO_PATH = os.path.join(_HERE, "libflownet2_hip.so")
 EXPORTS = [
     "fn2_version", "fn2_last_error_string",
     "fn2_correlation_out_shape", "fn2_correlation_workspace_bytes", "fn2_correlation_forward", "fn2_correlation_backward",
-    "fn2_flow_warp_forward", "fn2_flow_warp_backward",
+    "fn2_flow_warp_forward", "fn2_flow_warp_backward_workspace_bytes", "fn2_flow_warp_backward",
     "fn2_resample_forward",
     "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
     "fn2_channel_norm_forward", "fn2_channel_norm_backward",
@@ -66,7 +66,9 @@ def lib():
     L.fn2_correlation_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_correlation_backward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_flow_warp_forward.argtypes = [fp, fp, fp, i, i, i, i, i, vp]
-    L.fn2_flow_warp_backward.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, i, i, vp]
+    L.fn2_flow_warp_backward_workspace_bytes.argtypes = [i, i, i, i]
+    L.fn2_flow_warp_backward_workspace_bytes.restype = sz
+    L.fn2_flow_warp_backward.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, i, i, vp, sz, vp]
     L.fn2_resample_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, i, vp]
     L.fn2_l1loss_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_l1loss_workspace_bytes.restype = sz

@@ -126,10 +126,15 @@ class FlowWarpLayer : public Layer<Dtype> {
                                    top[0]->channels(), top[0]->height(), top[0]->width(), fill, kStream));
   }
   virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, const vector<Blob<Dtype>*>& bottom) {
+    // scratch for the inverted scatter (replaces the reference's transposed_image_ blob, flow_warp_layer.cpp:50)
+    const size_t ws_bytes = fn2_flow_warp_backward_workspace_bytes(top[0]->num(), top[0]->channels(), top[0]->height(), top[0]->width());
+    workspace_.Reshape(vector<int>{(int)((ws_bytes + sizeof(Dtype) - 1) / sizeof(Dtype))});
     FN2_CALL(fn2_flow_warp_backward(f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->gpu_diff()), f32(bottom[0]->mutable_gpu_diff()),
                                     f32(bottom[1]->mutable_gpu_diff()), top[0]->num(), top[0]->channels(), top[0]->height(),
-                                    top[0]->width(), propagate_down[0], propagate_down[1], kStream));
+                                    top[0]->width(), propagate_down[0], propagate_down[1], workspace_.mutable_gpu_data(),
+                                    workspace_.count() * sizeof(Dtype), kStream));
   }
+  Blob<Dtype> workspace_;
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -93,8 +93,10 @@ def flow_warp_backward(image, flow, warped_diff, propagate_image=True, propagate
     im, fl, wd = _chk(image, "image"), _chk(flow, "flow"), _chk(warped_diff, "top.diff")
     N, Cc, H, W = im.shape
     di, df = torch.empty_like(im), torch.empty_like(fl)
+    nbytes = _lib.lib().fn2_flow_warp_backward_workspace_bytes(N, Cc, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=im.device)
     check(_lib.lib().fn2_flow_warp_backward(_ptr(im), _ptr(fl), _ptr(wd), _ptr(di), _ptr(df), N, Cc, H, W,
-                                            int(propagate_image), int(propagate_flow), _stream()))
+                                            int(propagate_image), int(propagate_flow), _ptr(ws), nbytes, _stream()))
     return di, df
 
 

@@ -100,14 +100,17 @@ enum { FN2_FILL_ZERO = 1, FN2_FILL_NAN = 2 };
 /* image [N,C,H,W], flow [N,2,H,W] (channel 0 = x/u, 1 = y/v), warped [N,C,H,W]. */
 int fn2_flow_warp_forward(const float* image, const float* flow, float* warped,
                           int N, int C, int H, int W, int fill_value, void* stream);
-/* image_diff [N,C,H,W] and flow_diff [N,2,H,W] are both overwritten.  propagate_* == 0 zeroes the
- * corresponding diff after the pass exactly as flow_warp_layer.cu:507-508 does.  image_diff is
- * accumulated with float atomics (as the reference, :197-200): summation order is not
- * deterministic. */
+/* image_diff [N,C,H,W] and flow_diff [N,2,H,W] are both overwritten.  propagate_* == 0 leaves the
+ * corresponding diff zero, as flow_warp_layer.cu:507-508 does.  The reference accumulates image_diff with
+ * float atomics (:197-200: order not deterministic); here the scatter is inverted through per-pixel
+ * linked lists in the workspace (2 ints per pixel) and summed in a fixed order (bit-reproducible wherever
+ * at most 24 source pixels land on one cell). */
+size_t fn2_flow_warp_backward_workspace_bytes(int N, int C, int H, int W);
 int fn2_flow_warp_backward(const float* image, const float* flow, const float* warped_diff,
                            float* image_diff, float* flow_diff,
                            int N, int C, int H, int W,
-                           int propagate_image, int propagate_flow, void* stream);
+                           int propagate_image, int propagate_flow,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Resample  (type: "Resample")  -- forward only (resample_layer.cu:209-213 is LOG(FATAL))

@@ -25,8 +25,13 @@ g = torch.Generator(device=dev).manual_seed(0)
 for (N, C, H, W) in [(4, 3, 384, 768), (4, 256, 48, 96)]:
     img = torch.rand(N, C, H, W, device=dev, generator=g); flow = torch.randn(N, 2, H, W, device=dev, generator=g) * 8
     gout = torch.randn(N, C, H, W, device=dev, generator=g)
-    add(f"FlowWarp fwd [{N},{C},{H},{W}]", lambda: ops.flow_warp_forward(img, flow), 4 * N * H * W * (2 * C + 2))
-    add(f"FlowWarp bwd [{N},{C},{H},{W}]", lambda: ops.flow_warp_backward(img, flow, gout), 4 * N * H * W * (3 * C + 4))
+    add(f"FlowWarp fwd [{N},{C},{H},{W}] iid flow", lambda: ops.flow_warp_forward(img, flow), 4 * N * H * W * (2 * C + 2))
+    add(f"FlowWarp bwd [{N},{C},{H},{W}] iid flow", lambda: ops.flow_warp_backward(img, flow, gout), 4 * N * H * W * (3 * C + 4))
+    # a smooth field of the same magnitude (what a network predicts): neighbouring pixels sample neighbouring addresses
+    sm = torch.nn.functional.interpolate(torch.randn(N, 2, max(H // 64, 2), max(W // 64, 2), device=dev, generator=g) * 8, size=(H, W),
+                                         mode="bilinear", align_corners=True).contiguous()
+    add(f"FlowWarp fwd [{N},{C},{H},{W}] smooth flow", lambda: ops.flow_warp_forward(img, sm), 4 * N * H * W * (2 * C + 2))
+    add(f"FlowWarp bwd [{N},{C},{H},{W}] smooth flow", lambda: ops.flow_warp_backward(img, sm, gout), 4 * N * H * W * (3 * C + 4))
 # Resample: flow x4 up-sampling (config B), config A final flow, image identity
 for (N, C, H, W, Ho, Wo) in [(4, 2, 96, 192, 384, 768), (8, 2, 80, 112, 320, 448), (4, 3, 384, 768, 384, 768), (4, 3, 436, 1024, 448, 1024)]:
     x = torch.randn(N, C, H, W, device=dev, generator=g)
