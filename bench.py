@@ -74,6 +74,20 @@ def corr_roofline(device, batch, h, w, iters):
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / iters                       # seconds per launch
+    # cold caches: the 68 MB working set fits the 256 MiB Infinity Cache, so back-to-back launches (and the launch inside
+    # the net, whose inputs conv3 has just written) find their inputs on chip; with a 1 GiB fill in between they come from HBM
+    flush = torch.empty(256 << 20, dtype=torch.float32, device=device)
+    cold = []
+    for _ in range(8):
+        flush.fill_(1.0)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        ops.correlation_forward(p, a, b, out=out)
+        c1.record()
+        torch.cuda.synchronize()
+        cold.append(c0.elapsed_time(c1) * 1e3)
+    del flush
+    cold_us = sorted(cold)[len(cold) // 2]
     # per-launch events (includes launch gaps) vs back-to-back average: take the back-to-back average
     alg_bytes = 4.0 * batch * H * W * (2 * C + D2)               # read both maps once + write top once
     alg_flops = 2.0 * C * D2 * batch * H * W
@@ -98,7 +112,7 @@ def corr_roofline(device, batch, h, w, iters):
         "kernel": "corr_fwd (K=1,md=20,s2=2) [%d,%d,%d,%d]" % (batch, C, H, W),
         "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
-        "us_per_launch": round(t * 1e6, 2),
+        "us_per_launch": round(t * 1e6, 2), "us_per_launch_cold_caches": round(cold_us, 2),
         "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
         "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
         "note": "exact-fp32 correlation is FMA-bound (59 flop/B > machine balance); hbm = algorithmic bytes / time",
