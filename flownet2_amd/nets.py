@@ -119,7 +119,7 @@ def _transposed_deconv_weight(w):
 
 def _use_gemm_conv(x, stride):
     """3x3 layers for which im2col + one batched fp32 GEMM beats MIOpen's direct kernels on gfx950
-    (profiles/r01_miopen_conv_layer_times.txt vs scripts/im2col_gemm_probe.py): stride 2, and stride 1 on maps of
+    (profiles/r01_miopen_conv_layer_times.txt vs scripts/probes/im2col_gemm_probe.py): stride 2, and stride 1 on maps of
     <= 14 x 14 -- as long as the column matrix stays small next to the GEMM (<= 64 MB; it is written and read once)."""
     n, c, h, w = x.shape
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1

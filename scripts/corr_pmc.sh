@@ -1,13 +1,14 @@
+#!/bin/bash
+# SQ counter passes over the correlation micro-benchmark (each in its own rocprofv3 run, each under a timeout: a TCC_* pass
+# aborted inside rocprofv3 once and then sat until the box limit).  Prints the per-launch averages of the correlation kernel.
 export TMPDIR=/tmp
 R=gpurun_out/pmc2
 mkdir -p $R
-rocprofv3 --list-avail > $R/avail.txt 2>&1
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" \
            "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU" \
-           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SMEM" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TA_BUSY_avr"; do
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_INSTS_SMEM"; do
   n=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --output-format csv -d $R/$n -o c -- python scripts/corr_microbench.py --iters 10 > /dev/null 2> $R/$n.err
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d $R/$n -o c -- python scripts/corr_microbench.py --iters 10 > /dev/null 2> $R/$n.err
 done
 python - <<'PY'
 import csv, glob, collections

@@ -1,5 +1,5 @@
 import torch, torch.nn.functional as F, sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flownet2_amd import ops
 def t(f, n=20):
     for _ in range(3): f()

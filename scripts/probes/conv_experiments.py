@@ -2,7 +2,7 @@
 """Conv-stack experiments for the FlowNetC forward (memory formats)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flownet2_amd import functional as Fn, nets
 import numpy as np
 

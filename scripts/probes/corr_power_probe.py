@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Is the correlation kernel running against the power budget?  Same launch, inputs of different toggle activity."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flownet2_amd import ops, _lib
 N, C, H, W = 8, 256, 40, 56
 p = ops.corr_params(20, 1, 20, 1, 2)

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flownet2_amd import ops
 for (N, C, H, W) in [(8,1024,5,7),(8,1026,10,14),(8,770,20,28),(8,386,40,56),(8,194,80,112)]:
     x = torch.randn(N,C,H,W,device="cuda"); w = torch.randn(2,C,3,3,device="cuda")*0.01; b = torch.zeros(2,device="cuda")

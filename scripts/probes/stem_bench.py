@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """conv1 (7x7/2, 3 -> 64) + bias + leaky ReLU at batch 16 @448x320: fused HIP kernel vs MIOpen conv + the fused bias/activation pass."""
 import os, sys, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flownet2_amd import ops
 x = torch.randn(16, 3, 320, 448, device="cuda"); w = torch.randn(64, 3, 7, 7, device="cuda") * 0.05; b = torch.randn(64, device="cuda")
 def t(f, n=30):
