@@ -186,7 +186,7 @@ int fn2_downsample_forward(const float* bottom, float* top, int N, int C,
  *                       weight [Cin=2, Cout=2, 4, 4], base_conv_layer.cpp:125-139)
  * Forward only (inference); bias may be NULL.
  * ---------------------------------------------------------------------------------------------- */
-size_t fn2_predict_flow_conv_workspace_bytes(int N, int C, int H, int W);   /* channel-split partials of small maps; may be 0 */
+size_t fn2_predict_flow_conv_workspace_bytes(int N, int C, int H, int W);   /* the per-tap partial image (18 planes per channel split) */
 int fn2_predict_flow_conv_forward(const float* in, const float* weight, const float* bias, float* out,
                                   int N, int C, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const float* bias, float* out,
