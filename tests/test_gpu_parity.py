@@ -468,3 +468,66 @@ def test_runner_writes_flo_and_is_batch_invariant(tmp_path):
     assert f1.shape == (96, 136, 2) and np.isfinite(f1).all()
     # per-sample kernels + MIOpen conv picked per batch size: equal to fp32 rounding, not necessarily bitwise
     np.testing.assert_allclose(flo.read_flo(str(tmp_path / "out1.flo")), f1, rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Randomised shape sweeps (seeded): every kernel against its oracle twin on ragged sizes the fixed cases do not hit.
+def _rng_shapes(seed, n, lo, hi):
+    r = np.random.default_rng(seed)
+    return [tuple(int(v) for v in r.integers(lo, hi, size=len(lo))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("shape", _rng_shapes(101, 8, (1, 1, 2, 2), (3, 9, 23, 29)))
+def test_sweep_warp_resample_downsample_norm(shape):
+    N, C, H, W = shape
+    img, flow, g = rand(shape, 200), rand((N, 2, H, W), 201, 3.0), rand(shape, 202)
+    assert_close(host(ops.flow_warp_forward(dev(img), dev(flow))), oracle.flow_warp_forward(img, flow), 1e-6, "warp fwd")
+    di, df = ops.flow_warp_backward(dev(img), dev(flow), dev(g))
+    odi, odf = oracle.flow_warp_backward(img, flow, g)
+    assert_close(host(di), odi, 1e-5, "warp image diff")
+    assert_close(host(df), odf, 1e-5, "warp flow diff")
+    di2, _ = ops.flow_warp_backward(dev(img), dev(flow), dev(g))
+    assert torch.equal(di, di2), "warp backward must be bit-reproducible"
+    r = np.random.default_rng(203 + H * W)
+    ho, wo = int(r.integers(1, 2 * H + 2)), int(r.integers(1, 2 * W + 2))
+    for t in (ops.NEAREST, ops.LINEAR, ops.CUBIC):
+        # CUBIC has negative lobes: a 1-ulp difference in the source coordinate (fma contraction) is amplified more than for LINEAR
+        assert_close(host(ops.resample_forward(dev(img), ho, wo, t)), oracle.resample_forward(img, ho, wo, t),
+                     8e-6 if t == ops.CUBIC else 3e-6, f"resample type {t}")
+    if H >= 4 and W >= 4:
+        hd, wd = max(2, H // 3), max(2, W // 3)
+        assert_close(host(ops.downsample_forward(dev(img), hd, wd)), oracle.downsample_forward(img, hd, wd), 1e-6, "downsample")
+    assert_close(host(ops.channel_norm_forward(dev(img))), oracle.channel_norm_forward(img), 1e-6, "channel norm")
+
+
+@pytest.mark.parametrize("case", _rng_shapes(102, 8, (1, 1, 3, 3, 1, 0, 1), (3, 7, 14, 17, 6, 3, 4)))
+def test_sweep_im2col_col2im(case):
+    N, C, H, W, k, p, s = case
+    if H + 2 * p < k or W + 2 * p < k:
+        pytest.skip("kernel larger than the padded image")
+    x = rand((N, C, H, W), 210)
+    col = oracle.im2col_forward(x, k, p, s)
+    np.testing.assert_array_equal(host(ops.im2col_forward(dev(x), k, p, s)), col)
+    # col2im on an image of the size im2col came from (the Deconvolution direction), random columns
+    colr = rand(col.shape, 211)
+    b = rand((C,), 212)
+    got = host(ops.col2im_bias_relu_forward(dev(colr), dev(b), N, C, H, W, k, p, s, True, 0.1))
+    np.testing.assert_array_equal(got, oracle.col2im_bias_relu_forward(colr, b, N, C, H, W, k, p, s, True, 0.1))
+
+
+@pytest.mark.parametrize("shape", _rng_shapes(103, 6, (1, 1, 1, 1), (3, 40, 12, 15)))
+def test_sweep_flow_heads_and_bias(shape):
+    N, C, H, W = shape
+    x, w, b = rand(shape, 220), rand((2, C, 3, 3), 221, 0.2), rand((2,), 222)
+    assert_close(host(ops.predict_flow_conv_forward(dev(x), dev(w), dev(b))), oracle.predict_flow_conv_forward(x, w, b), 3e-6, "predict_flow")
+    f, wu = rand((N, 2, H, W), 223), rand((2, 2, 4, 4), 224)
+    assert_close(host(ops.upsample_flow_deconv_forward(dev(f), dev(wu), dev(b))), oracle.upsample_flow_deconv_forward(f, wu, b), 2e-6, "upsample_flow")
+    bc = rand((C,), 225)
+    np.testing.assert_array_equal(host(ops.bias_leaky_relu_(dev(x), dev(bc), 0.1)), oracle.bias_leaky_relu_forward(x, bc, 0.1))
+
+
+@pytest.mark.parametrize("case", [(1, 3, 16, 24, 64), (2, 6, 23, 40, 64), (1, 3, 9, 8, 128), (1, 3, 50, 136, 64)])
+def test_sweep_stem_conv(case):
+    N, Cin, H, W, Cout = case
+    x, w, b = rand((N, Cin, H, W), 230), rand((Cout, Cin, 7, 7), 231, 0.1), rand((Cout,), 232)
+    assert_close(host(ops.conv_k7s2_relu_forward(dev(x), dev(w), dev(b), 0.1)), oracle.conv_k7s2_relu_forward(x, w, b, 0.1), 3e-6, "stem")
