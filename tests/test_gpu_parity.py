@@ -531,3 +531,23 @@ def test_sweep_stem_conv(case):
     N, Cin, H, W, Cout = case
     x, w, b = rand((N, Cin, H, W), 230), rand((Cout, Cin, 7, 7), 231, 0.1), rand((Cout,), 232)
     assert_close(host(ops.conv_k7s2_relu_forward(dev(x), dev(w), dev(b), 0.1)), oracle.conv_k7s2_relu_forward(x, w, b, 0.1), 3e-6, "stem")
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 5, 8), (2, 48, 11, 12), (1, 32, 33, 64), (3, 16, 2, 4), (1, 80, 17, 36), (2, 16, 40, 56), (1, 16, 9, 132)])
+def test_sweep_correlation_mfma_kernels_agree_with_generic(shape):
+    """FlowNetC parameters on ragged maps with W % 4 == 0 (paired-parity kernel) -- against the generic kernel, whose
+    channel sum is the same sequential fma chain: agreement to the last bits, for both MFMA kernels."""
+    N, C, H, W = shape
+    b0, b1 = dev(rand(shape, 240)), dev(rand(shape, 241))
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    outs = {}
+    for impl in (1, 0, 3):
+        ops.set_correlation_impl(impl)
+        try:
+            outs[impl] = ops.correlation_forward(p, b0, b1)
+        finally:
+            ops.set_correlation_impl(0)
+    scale = max(1.0, float(outs[1].abs().max()))
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-7 * scale
+    assert float((outs[3] - outs[1]).abs().max()) <= 2e-7 * scale
+    assert_close(host(outs[0]), oracle.correlation_forward(oracle.corr_params(20, 1, 20, 1, 2), host(b0), host(b1)), 2e-6, "vs oracle")
