@@ -119,13 +119,12 @@ def _transposed_deconv_weight(w):
 
 def _use_gemm_conv(x, stride):
     """3x3 layers for which im2col + one batched fp32 GEMM beats MIOpen's direct kernels on gfx950
-    (profiles/r01_miopen_conv_layer_times.txt vs scripts/probes/im2col_gemm_probe.py): stride 2, and stride 1 on maps of
-    <= 14 x 14 -- as long as the column matrix stays small next to the GEMM (<= 64 MB; it is written and read once)."""
+    (scripts/probes/im2col_gemm_probe.py, gemm_route_shapes_probe.py: FlowNetC and FlowNet2 shapes): every layer with at
+    least 64 input channels whose column matrix (written and read once) stays below 128 MB -- the GEMM runs at 85-125
+    TFLOP/s against 35-95 for the direct kernels; at 170 MB it is a tie, at 300 MB the column traffic loses."""
     n, c, h, w = x.shape
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-    if 4 * n * c * 9 * ho * wo > (64 << 20) or c < 64:
-        return False
-    return stride == 2 or h * w <= 196
+    return c >= 64 and 4 * n * c * 9 * ho * wo <= (128 << 20)
 
 
 def _deconv(x, P, name, act=True, backend=None):
