@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from . import tuning
 
 
 class _Correlation(torch.autograd.Function):
@@ -140,6 +141,7 @@ def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1):
     beats the library's direct convolution on gfx950 (nets._use_gemm_conv).  Returns None if autograd is needed."""
     if not _no_grad_needed(x, weight, bias):
         return None
+    tuning.enable()
     N, Cin, H, W = x.shape
     Cout, k = weight.shape[0], weight.shape[2]
     Hc, Wc = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
@@ -154,6 +156,7 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     (cached by the caller).  Returns None if autograd is needed."""
     if not _no_grad_needed(x, weight_t, bias):
         return None
+    tuning.enable()
     N, Cin, H, W = x.shape
     col = torch.matmul(weight_t, x.contiguous().view(N, Cin, H * W))            # [N, Cout*k*k, H*W]
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel

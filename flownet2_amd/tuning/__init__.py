@@ -1,0 +1,38 @@
+"""Tuned library-GEMM selections for the GEMM route (nets._use_gemm_conv, deconvolutions).
+
+rocBLAS / hipBLASLt pick a kernel per GEMM shape from a heuristic; PyTorch's TunableOp can time the candidates once and
+record the winner.  `gemm_gfx950.csv` holds the winners for the GEMM shapes of FlowNetC (batch 8 @448x320) and FlowNet2
+(batch 4 @768x384) on an MI355X -- 10-35 % faster than the heuristic choice for the deconvolution GEMMs -- and
+`enable()` switches TunableOp to look-up-only mode on that file (no tuning at run time; shapes that are not in the file keep
+the library default; a file recorded with other library versions is rejected by TunableOp's own validators and ignored).
+Regenerate with scripts/tune_gemms.py on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_gfx950.csv")
+_done = False
+
+
+def enable() -> bool:
+    """Idempotent.  Returns True when the tuned selections are active."""
+    global _done
+    if _done:
+        return True
+    if os.environ.get("FN2_NO_TUNED_GEMM") == "1" or not os.path.exists(CSV) or not torch.cuda.is_available():
+        return False
+    try:
+        import torch.cuda.tunable as tn
+        if os.environ.get("PYTORCH_TUNABLEOP_TUNING") == "1":      # somebody is recording: do not interfere
+            return False
+        tn.enable(True)
+        tn.tuning_enable(False)
+        tn.set_filename(CSV, insert_device_ordinal=False)
+        tn.read_file(CSV)
+        _done = True
+    except Exception:                                               # TunableOp unavailable in this torch build: library defaults
+        return False
+    return True
