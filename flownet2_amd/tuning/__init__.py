@@ -28,10 +28,16 @@ def enable() -> bool:
         import torch.cuda.tunable as tn
         if os.environ.get("PYTORCH_TUNABLEOP_TUNING") == "1":      # somebody is recording: do not interfere
             return False
+        # TunableOp rewrites "its" file when the process exits: give every process a private copy, so that the table in the
+        # tree is never touched and the ranks of a multi-GPU job do not write one file
+        import shutil
+        import tempfile
+        private = os.path.join(tempfile.gettempdir(), "fn2_gemm_gfx950_%d.csv" % os.getpid())
+        shutil.copyfile(CSV, private)
         tn.enable(True)
         tn.tuning_enable(False)
-        tn.set_filename(CSV, insert_device_ordinal=False)
-        tn.read_file(CSV)
+        tn.set_filename(private, insert_device_ordinal=False)
+        tn.read_file(private)
         _done = True
     except Exception:                                               # TunableOp unavailable in this torch build: library defaults
         return False
