@@ -119,6 +119,12 @@ def corr_roofline(device, batch, h, w, iters):
     }
 
 
+def step_percentiles(marks):
+    ts = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
+    pick = lambda q: round(ts[min(len(ts) - 1, int(q * len(ts)))], 4)
+    return [pick(0.1), pick(0.5), pick(0.9)]
+
+
 def cpu_baseline(P_cpu, img0, img1, flow_gpu, budget_s=20.0):
     """Oracle leg: the same graph on the host (C oracle ops + torch-CPU fp32 conv), bounded sample."""
     import oracle
@@ -205,11 +211,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         r = step_fn()
         if r is not None:
             out = r
+        marks[i + 1].record()                  # per-step spread (device time); the headline stays the host clock around all K steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,7 +231,8 @@ def main():
         res = {
             "metric": "image-pairs/sec " + ("FlowNetC " if args.net == "C" else "FlowNet2 (CSS+SD+fusion) ") + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
             "value": round(pairs / elapsed, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_p10_p50_p90": step_percentiles(marks), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
