@@ -14,6 +14,7 @@ for _ in range(3): ops.correlation_forward(p, x, y, out=out)
 dbg = torch.zeros(4 * 1024 + 4 * 8 * 1024 + 2 * 1024, dtype=torch.int64, device="cuda")
 if len(sys.argv) > 1: _lib.lib().fn2_debug_set_correlation_impl(int(sys.argv[1]))
 L = _lib.lib(); L.fn2_debug_set_correlation_trace.argtypes = [C.c_void_p]
+for _ in range(50): ops.correlation_forward(p, x, y, out=out)      # steady state: clocks ramped, inputs in the Infinity Cache
 L.fn2_debug_set_correlation_trace(C.c_void_p(dbg.data_ptr()))
 ops.correlation_forward(p, x, y, out=out); torch.cuda.synchronize()
 L.fn2_debug_set_correlation_trace(None)
