@@ -413,6 +413,16 @@ def test_deconv_weight_cache_follows_the_parameter():
     assert torch.equal(nets._transposed_deconv_weight(w2), w2.reshape(64, 128).t())
 
 
+@pytest.mark.parametrize("case", [((2, 2, 320, 448), (5, 7)), ((1, 2, 320, 448), (10, 14)), ((1, 3, 97, 130), (3, 4))])
+def test_downsample_large_factors(case):
+    """Coarse scales of the multi-scale loss: hundreds to thousands of taps per output (wave-per-output kernel), with NaN
+    ground truth; the sum order differs from the oracle's sequential loop, hence 3e-6."""
+    shape, (ho, wo) = case
+    x = rand(shape, 80, 5.0)
+    x[:, :, : shape[2] // 3, : shape[3] // 2] = np.nan
+    assert_close(host(ops.downsample_forward(dev(x), ho, wo)), oracle.downsample_forward(x, ho, wo), 3e-6, "downsample, large factor")
+
+
 def test_identity_resample_is_exact():
     """deploy_forward skips the ADAPTED-size Resample when the size does not change: the kernel is then the identity."""
     x = rand((2, 3, 64, 128), 42)
