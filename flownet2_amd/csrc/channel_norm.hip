@@ -109,14 +109,25 @@ __global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restri
     const int nx = x1 - x0 + 1, ntap = nx * (y1 - y0 + 1);
     const float* p = src + (size_t)cn * a.Hin * a.Win;
     float accum_value = 0.f, accum_weight = 0.f, accum_nan = 0.f;
-    for (int t = (int)lane; t < ntap; t += 64) {
-      const int by = y0 + t / nx, bx = x0 + t % nx;
-      float sample = p[(size_t)by * a.Win + bx];
-      float weight = fmaxf(0.0f, 1.0f - (fabsf((float)bx - botx) / a.widthScale)) *
-                     fmaxf(0.0f, 1.0f - (fabsf((float)by - boty) / a.heightScale));   // :52
-      if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }     // :53-57
-      accum_value = fmaf(sample, weight, accum_value);
-      accum_weight += weight;
+    for (int t0 = (int)lane; t0 < ntap; t0 += 256) {           // four taps per lane in flight
+      float sm[4];
+      int tby[4], tbx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = min(t0 + 64 * j, ntap - 1);
+        tby[j] = y0 + t / nx; tbx[j] = x0 + t % nx;
+        sm[j] = p[(size_t)tby[j] * a.Win + tbx[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t0 + 64 * j >= ntap) break;
+        float sample = sm[j];
+        float weight = fmaxf(0.0f, 1.0f - (fabsf((float)tbx[j] - botx) / a.widthScale)) *
+                       fmaxf(0.0f, 1.0f - (fabsf((float)tby[j] - boty) / a.heightScale));   // :52
+        if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }           // :53-57
+        accum_value = fmaf(sample, weight, accum_value);
+        accum_weight += weight;
+      }
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
