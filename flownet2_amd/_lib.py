@@ -20,7 +20,7 @@ EXPORTS = [
     "fn2_channel_norm_forward", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward",
-    "fn2_bias_leaky_relu_forward",
+    "fn2_bias_leaky_relu_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
 ]
@@ -82,6 +82,9 @@ def lib():
     L.fn2_predict_flow_conv_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_upsample_flow_deconv_forward.argtypes = [fp, fp, fp, fp, i, i, i, vp]
     L.fn2_bias_leaky_relu_forward.argtypes = [fp, fp, i, i, i, i, C.c_float, vp]
+    L.fn2_bias_leaky_relu_backward_workspace_bytes.argtypes = [i, i, i, i]
+    L.fn2_bias_leaky_relu_backward_workspace_bytes.restype = sz
+    L.fn2_bias_leaky_relu_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, C.c_float, vp, sz, vp]
     L.fn2_conv_k7s2_relu_supported.argtypes = [i, i, i, i]
     L.fn2_im2col_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, vp]
     L.fn2_col2im_bias_relu_forward.argtypes = [fp, fp, fp, i, i, i, i, i, i, i, i, C.c_float, vp]

@@ -33,9 +33,69 @@ __global__ void __launch_bounds__(256) bias_leaky_relu(float* __restrict__ data,
   }
 }
 
+// ---- backward ---------------------------------------------------------------------------------------------------------
+// bottom_diff = top_diff * (top_data > 0 ? 1 : slope)   (ReLUBackward on the in-place blob, relu_layer.cu:33-43: the sign of
+// the output is the sign of the input for slope > 0) and bias_diff[c] = sum over n, h, w of bottom_diff (backward_gpu_bias,
+// base_conv_layer.cpp:389-393: a GEMV with a vector of ones per sample) in one pass: every block reduces its chunk of one
+// (n, c) plane (wave shuffles + LDS), a second small kernel adds the partials of a channel in a fixed order.
+constexpr int kBwdChunks = 8;      // blocks per (n, c) plane
+
+__global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restrict__ top_data, const float* __restrict__ top_diff,
+                                                           float* __restrict__ bottom_diff, float* __restrict__ partial,
+                                                           unsigned hw, float slope) {
+  __shared__ float red[4];
+  const unsigned plane = blockIdx.y;
+  const size_t base = (size_t)plane * hw;
+  float acc = 0.f;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < hw; i += gridDim.x * 256u) {
+    const float g = top_diff[base + i] * (top_data[base + i] > 0.f ? 1.f : slope);
+    bottom_diff[base + i] = g;
+    acc += g;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)plane * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(64) bias_diff_finalize(const float* __restrict__ partial, float* __restrict__ bias_diff,
+                                                         int N, int C, int chunks) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < chunks; ++k) acc += partial[((size_t)n * C + c) * chunks + k];
+  bias_diff[c] = acc;
+}
+
 }  // namespace fn2
 
 using namespace fn2;
+
+FN2_API size_t fn2_bias_leaky_relu_backward_workspace_bytes(int N, int C, int H, int W) {
+  (void)H; (void)W;
+  if (N <= 0 || C <= 0) return 0;
+  return sizeof(float) * (size_t)N * C * kBwdChunks;
+}
+
+FN2_API int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
+                                         int N, int C, int H, int W, float negative_slope, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: bad shape [%d,%d,%d,%d]", N, C, H, W);
+  if (N == 0) return FN2_OK;
+  if (!top_data || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: null blob");
+  const long long planes = (long long)N * C, hw = (long long)H * W;
+  if (planes > 65535 || hw >= (1ll << 32)) return fail(FN2_ERR_UNSUPPORTED, "bias_leaky_relu_backward: blob too large");
+  const size_t need = fn2_bias_leaky_relu_backward_workspace_bytes(N, C, H, W);
+  if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "bias_leaky_relu_backward: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(bias_leaky_relu_bwd, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
+                     (unsigned)hw, negative_slope);
+  if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 63) / 64), dim3(64), 0, st, partial, bias_diff, N, C, kBwdChunks);
+  return check_launch("bias_leaky_relu_backward");
+}
 
 FN2_API int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, int C, int H, int W, float negative_slope,
                                         void* stream) {

@@ -111,13 +111,34 @@ def upsample_flow_deconv(x, weight, bias=None):
     return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)
 
 
+class _BiasLeakyReLU(torch.autograd.Function):
+    """y -> leaky_relu(y + bias) in place on the convolution output (conv2d's backward does not need its output), with the
+    fused backward: one pass for the activation gradient and the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, y, bias, negative_slope):
+        ctx.mark_dirty(y)
+        ops.bias_leaky_relu_(y, bias, negative_slope)
+        ctx.slope = negative_slope
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        d, db = ops.bias_leaky_relu_backward(y, g.contiguous(), ctx.slope, ctx.has_bias and ctx.needs_input_grad[1])
+        return d, db, None
+
+
 def conv_bias_leaky_relu(y, bias, negative_slope=0.1):
-    """Bias term + in-place leaky ReLU on a bias-free convolution output.  One HIP pass when no gradient is needed
-    (deploy nets); stock torch ops otherwise (training keeps autograd)."""
-    if (torch.is_grad_enabled() and (y.requires_grad or (bias is not None and bias.requires_grad))) or not y.is_contiguous():
+    """Bias term + in-place leaky ReLU on a bias-free convolution output: one HIP pass forward, one backward."""
+    if not y.is_contiguous():
         if bias is not None:
             y = y + bias.view(1, -1, 1, 1)
         return torch.nn.functional.leaky_relu(y, negative_slope)
+    if torch.is_grad_enabled() and (y.requires_grad or (bias is not None and bias.requires_grad)):
+        return _BiasLeakyReLU.apply(y, bias, negative_slope)
     return ops.bias_leaky_relu_(y, bias, negative_slope)
 
 

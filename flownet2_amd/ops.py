@@ -249,3 +249,18 @@ def col2im_bias_relu_forward(col, bias, N, Cc, H, W, kernel, pad, stride, relu=T
     check(_lib.lib().fn2_col2im_bias_relu_forward(_ptr(col), _ptr(b), _ptr(out), N, Cc, H, W, int(kernel), int(pad), int(stride),
                                                   int(bool(relu)), C.c_float(float(negative_slope)), _stream()))
     return out
+
+
+def bias_leaky_relu_backward(top_data, top_diff, negative_slope=0.1, need_bias_diff=True):
+    """(bottom_diff, bias_diff): gradient of x -> leaky_relu(x + bias) given the OUTPUT blob and its gradient."""
+    y, g = _chk(top_data, "top.data"), _chk(top_diff, "top.diff")
+    if y.shape != g.shape:
+        raise ValueError("top.data and top.diff must have the same shape")
+    N, Cc, H, W = y.shape
+    d = torch.empty_like(g)
+    db = torch.empty(Cc, device=y.device, dtype=torch.float32) if need_bias_diff else None
+    nbytes = _lib.lib().fn2_bias_leaky_relu_backward_workspace_bytes(N, Cc, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=y.device)
+    check(_lib.lib().fn2_bias_leaky_relu_backward(_ptr(y), _ptr(g), _ptr(d), _ptr(db), N, Cc, H, W, C.c_float(float(negative_slope)),
+                                                  _ptr(ws), nbytes, _stream()))
+    return d, db

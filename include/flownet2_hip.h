@@ -201,6 +201,14 @@ int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const
  * ---------------------------------------------------------------------------------------------- */
 int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, int C, int H, int W, float negative_slope,
                                 void* stream);
+/* Backward of the same pair: bottom_diff = top_diff * (top_data > 0 ? 1 : negative_slope)
+ *   <- ReLULayer::Backward_gpu, src/caffe/layers/relu_layer.cu:33-60 (in-place blob: the output's sign is the input's),
+ * and bias_diff[c] = sum over n, h, w of bottom_diff  <- backward_gpu_bias, base_conv_layer.cpp:389-393 (bias_diff may be
+ * NULL).  bottom_diff may alias top_diff.  Deterministic (fixed-order partial sums in the workspace). */
+size_t fn2_bias_leaky_relu_backward_workspace_bytes(int N, int C, int H, int W);
+int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
+                                 int N, int C, int H, int W, float negative_slope, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stem convolution of the FlowNet encoders, fused with its bias and ReLU:

@@ -192,6 +192,14 @@ def bias_leaky_relu_forward(x, bias=None, negative_slope=0.1):
     return out
 
 
+def bias_leaky_relu_backward(top_data, top_diff, negative_slope=0.1):
+    y, g = _f32(top_data), _f32(top_diff)
+    N, Cc, H, W = y.shape
+    d, db = np.empty_like(g), np.empty(Cc, np.float32)
+    _check(lib().fn2_bias_leaky_relu_backward_cpu(_p(y), _p(g), _p(d), _p(db), N, Cc, H, W, C.c_float(negative_slope)), "bias_leaky_relu_backward")
+    return d, db
+
+
 def im2col_forward(x, kernel, pad, stride):
     x = _f32(x)
     N, Cc, H, W = x.shape

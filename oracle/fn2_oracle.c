@@ -765,3 +765,25 @@ FN2_API int fn2_col2im_bias_relu_forward_cpu(const float* col, const float* bias
   }
   return FN2_OK;
 }
+
+
+/* Backward of bias + leaky ReLU: relu_layer.cpp:33-45 (bottom_diff = top_diff * ((data > 0) + slope * (data <= 0)), evaluated on
+ * the in-place blob) and backward_cpu_bias (base_conv_layer.cpp:319-323: bias_diff += top_diff summed over the positions). */
+FN2_API int fn2_bias_leaky_relu_backward_cpu(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
+                                             int N, int C, int H, int W, float negative_slope) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  for (int c = 0; c < C; ++c) {
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const size_t base = ((size_t)n * C + c) * hw;
+      for (size_t i = 0; i < hw; ++i) {
+        const float g = top_diff[base + i] * (top_data[base + i] > 0.f ? 1.f : negative_slope);
+        bottom_diff[base + i] = g;
+        acc += g;
+      }
+    }
+    if (bias_diff) bias_diff[c] = (float)acc;
+  }
+  return FN2_OK;
+}

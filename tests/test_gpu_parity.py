@@ -423,6 +423,28 @@ def test_downsample_large_factors(case):
     assert_close(host(ops.downsample_forward(dev(x), ho, wo)), oracle.downsample_forward(x, ho, wo), 3e-6, "downsample, large factor")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 20, 28), (3, 5, 7, 9), (1, 130, 3, 5), (16, 64, 40, 56)])
+def test_bias_leaky_relu_backward_and_autograd(shape):
+    y, g = rand(shape, 90), rand(shape, 91)
+    d, db = ops.bias_leaky_relu_backward(dev(y), dev(g), 0.1)
+    od, odb = oracle.bias_leaky_relu_backward(y, g, 0.1)
+    np.testing.assert_array_equal(host(d), od)
+    assert_close(host(db), odb, 2e-6 * np.sqrt(shape[0] * shape[2] * shape[3]), "bias diff")
+    d2, db2 = ops.bias_leaky_relu_backward(dev(y), dev(g), 0.1)
+    assert torch.equal(db, db2), "bias gradient must be bit-reproducible"
+    # through autograd, against the stock ops
+    from flownet2_amd import functional as Fn
+    x = dev(rand(shape, 92)).requires_grad_(True)
+    b = dev(rand((shape[1],), 93)).requires_grad_(True)
+    out = Fn.conv_bias_leaky_relu(x * 1.0, b, 0.1)
+    (out * dev(g)).sum().backward()
+    xr = dev(rand(shape, 92)).requires_grad_(True)
+    br = dev(rand((shape[1],), 93)).requires_grad_(True)
+    (torch.nn.functional.leaky_relu(xr + br.view(1, -1, 1, 1), 0.1) * dev(g)).sum().backward()
+    assert_close(host(x.grad), host(xr.grad), 1e-6, "input gradient")
+    assert_close(host(b.grad), host(br.grad), 2e-6 * np.sqrt(shape[0] * shape[2] * shape[3]), "bias gradient")
+
+
 def test_identity_resample_is_exact():
     """deploy_forward skips the ADAPTED-size Resample when the size does not change: the kernel is then the identity."""
     x = rand((2, 3, 64, 128), 42)
@@ -561,3 +583,35 @@ def test_sweep_correlation_mfma_kernels_agree_with_generic(shape):
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-7 * scale
     assert float((outs[3] - outs[1]).abs().max()) <= 2e-7 * scale
     assert_close(host(outs[0]), oracle.correlation_forward(oracle.corr_params(20, 1, 20, 1, 2), host(b0), host(b1)), 2e-6, "vs oracle")
+
+
+def test_training_gradients_fused_path_matches_stock_ops():
+    """One FlowNetC training loss (multi-scale L1, NaN ground truth) differentiated twice: with the fused bias + leaky ReLU
+    autograd function, and with the stock torch ops in its place.  Every parameter gradient must agree."""
+    from flownet2_amd import functional as Fn, nets
+    P = nets.init_params("C", seed=3)
+    g = torch.Generator().manual_seed(5)
+    im0, im1 = (torch.rand(1, 3, 128, 192, generator=g) - 0.5 for _ in range(2))
+    gt = torch.randn(1, 2, 128, 192, generator=g) * 4
+    gt[:, :, :10, :20] = float("nan")
+
+    def grads(stock):
+        Pd = {k: v.cuda().clone().requires_grad_(True) for k, v in P.items()}
+        keep = Fn.conv_bias_leaky_relu
+        if stock:
+            Fn.conv_bias_leaky_relu = lambda y, b, s=0.1: torch.nn.functional.leaky_relu(y + b.view(1, -1, 1, 1), s)
+        try:
+            loss = nets.multiscale_loss(nets.flownet_c_core(Pd, im0.cuda(), im1.cuda(), Fn), gt.cuda(), Fn)
+            loss.backward()
+        finally:
+            Fn.conv_bias_leaky_relu = keep
+        return float(loss.detach()), {k: v.grad.detach().cpu() for k, v in Pd.items() if v.grad is not None}
+
+    l_fused, g_fused = grads(False)
+    l_stock, g_stock = grads(True)
+    assert abs(l_fused - l_stock) <= 1e-5 * max(1.0, abs(l_stock))
+    assert g_fused.keys() == g_stock.keys() and len(g_fused) > 40
+    for k in g_stock:
+        scale = max(float(g_stock[k].abs().max()), 1e-12)
+        err = float((g_fused[k] - g_stock[k]).abs().max())
+        assert err <= 2e-4 * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
