@@ -11,7 +11,8 @@
 //     is one ds_read_b32 at  lane base + immediate;  the 8th tap has weight 0;
 //   * the input rows of a workgroup (2 RB + 5 rows x CIN channels x (32 tiles + 8) columns) are staged once by 16-byte
 //     LDS-DMA in natural pixel order; out-of-image rows / columns come back 0 from the buffer descriptor = zero padding;
-//   * the MFMA result layout gives every lane 4 consecutive x of one output channel: bias + leaky ReLU + one 16-byte store.
+//   * the MFMA result layout gives every lane 4 consecutive x of one output channel: bias + leaky ReLU + one 16-byte store;
+//   * 12 input channels (the stems of FlowNet2's stacked nets) run as two 6-channel passes over the same output.
 #include "fn2_common.hpp"
 
 #include <type_traits>
@@ -23,12 +24,16 @@ using lds_ptr_t = __attribute__((address_space(3))) void*;
 
 struct StemArgs {
   int N, Hin, Win, Hout, Wout, Cout;
+  int Ctot, c0;     // channels of the bottom blob / first channel of this pass (CIN channels per pass)
   int ntx;          // x blocks per output row
   int nyb;          // row blocks
   float slope;
 };
 
-template <int CIN, int RB, int XT>     // XT: 16-pixel tiles per workgroup row
+// PASS: 0 = the whole contraction in one launch; 1 = first half of a two-pass contraction (raw partial sums are stored);
+// 2 = second half (adds the stored partial sums, then bias and ReLU).  Two passes serve the 12-channel stems of FlowNet2's
+// stacked FlowNetS nets: their weight slice (168 values per lane) does not fit the register file, 84 per pass do.
+template <int CIN, int RB, int XT, int PASS>     // XT: 16-pixel tiles per workgroup row
 __global__ void __launch_bounds__(256, 2)
 conv_k7s2_relu(const float* __restrict__ in, const float* __restrict__ weight, const float* __restrict__ bias,
                float* __restrict__ out, StemArgs a) {
@@ -51,7 +56,7 @@ conv_k7s2_relu(const float* __restrict__ in, const float* __restrict__ weight, c
   // ---- stage the input window: slot s -> (c, row, group of 4 columns) ----
   const size_t plane = (size_t)a.Hin * a.Win;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(in + (size_t)n * CIN * plane), 0, (unsigned)(4u * CIN * plane), 0x00020000);
+      const_cast<float*>(in + ((size_t)n * a.Ctot + a.c0) * plane), 0, (unsigned)(4u * CIN * plane), 0x00020000);
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
 #pragma unroll
   for (int i = 0; i < (NRUN + 3) / 4; ++i) {
@@ -73,7 +78,7 @@ conv_k7s2_relu(const float* __restrict__ in, const float* __restrict__ weight, c
   const int kk = lane >> 4, nn = lane & 15;
   float w[CIN][7][2];
   {
-    const float* wp = weight + (size_t)(co0 + nn) * CIN * 49;
+    const float* wp = weight + ((size_t)(co0 + nn) * a.Ctot + a.c0) * 49;
 #pragma unroll
     for (int c = 0; c < CIN; ++c)
 #pragma unroll
@@ -110,8 +115,11 @@ conv_k7s2_relu(const float* __restrict__ in, const float* __restrict__ weight, c
       const int x = x0 + 16 * (t + u) + xq;
       if (x < a.Wout) {                            // Wout % 4 == 0: a quad is inside or outside as a whole
         f32x4 v = acc[u];
+        if constexpr (PASS == 2) v += *reinterpret_cast<const f32x4*>(orow + x);
+        if constexpr (PASS != 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float s = v[j] + bv; v[j] = s > 0.f ? s : s * a.slope; }
+          for (int j = 0; j < 4; ++j) { const float s = v[j] + bv; v[j] = s > 0.f ? s : s * a.slope; }
+        }
         *reinterpret_cast<f32x4*>(orow + x) = v;
       }
     }
@@ -129,12 +137,12 @@ conv_k7s2_relu(const float* __restrict__ in, const float* __restrict__ weight, c
   }
 }
 
-template <int CIN>
-static int launch_stem(const float* in, const float* weight, const float* bias, float* out, int N, int Hin, int Win, int Cout,
-                       float slope, hipStream_t st) {
+template <int CIN, int PASS>
+static int launch_stem(const float* in, const float* weight, const float* bias, float* out, int N, int Ctot, int c0, int Hin, int Win,
+                       int Cout, float slope, hipStream_t st) {
   constexpr int RB = 2, XT = 7;
   StemArgs a;
-  a.N = N; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.slope = slope;
+  a.N = N; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.slope = slope; a.Ctot = Ctot; a.c0 = c0;
   a.Hout = (Hin + 6 - 7) / 2 + 1; a.Wout = (Win + 6 - 7) / 2 + 1;
   a.ntx = (a.Wout + 16 * XT - 1) / (16 * XT);
   a.nyb = (a.Hout + RB - 1) / RB;
@@ -143,10 +151,10 @@ static int launch_stem(const float* in, const float* weight, const float* bias, 
   constexpr size_t lds = sizeof(float) * CIN * (2 * RB + 5) * (32 * XT + 8) + 1024;     // + the tail of the last (partial) run
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_k7s2_relu<CIN, RB, XT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_k7s2_relu<CIN, RB, XT, PASS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_k7s2_relu<CIN, RB, XT>), dim3((unsigned)grid), dim3(256), lds, st, in, weight, bias, out, a);
+  hipLaunchKernelGGL((conv_k7s2_relu<CIN, RB, XT, PASS>), dim3((unsigned)grid), dim3(256), lds, st, in, weight, bias, out, a);
   return check_launch("conv_k7s2_relu_forward");
 }
 
@@ -155,7 +163,7 @@ static int launch_stem(const float* in, const float* weight, const float* bias, 
 using namespace fn2;
 
 FN2_API int fn2_conv_k7s2_relu_supported(int Cin, int Hin, int Win, int Cout) {
-  return (Cin == 3 || Cin == 6) && Cout % 64 == 0 && Cout > 0 && Hin >= 1 && Win >= 8 && Win % 8 == 0 &&
+  return (Cin == 3 || Cin == 6 || Cin == 12) && Cout % 64 == 0 && Cout > 0 && Hin >= 1 && Win >= 8 && Win % 8 == 0 &&
          (long long)Cin * Hin * Win < (1ll << 28);
 }
 
@@ -165,10 +173,13 @@ FN2_API int fn2_conv_k7s2_relu_forward(const float* in, const float* weight, con
   if (N == 0) return FN2_OK;
   if (!in || !weight || !out) return fail(FN2_ERR_INVALID_ARG, "conv_k7s2_relu: null blob");
   if (!fn2_conv_k7s2_relu_supported(Cin, Hin, Win, Cout))
-    return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_relu: needs Cin in {3,6}, Cout %% 64 == 0, width %% 8 == 0 (got Cin %d, Cout %d, W %d)", Cin, Cout, Win);
+    return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_relu: needs Cin in {3,6,12}, Cout %% 64 == 0, width %% 8 == 0 (got Cin %d, Cout %d, W %d)", Cin, Cout, Win);
   if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0)
     return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_relu: blobs must be 16-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (Cin == 3) return launch_stem<3>(in, weight, bias, out, N, Hin, Win, Cout, negative_slope, st);
-  return launch_stem<6>(in, weight, bias, out, N, Hin, Win, Cout, negative_slope, st);
+  if (Cin == 3) return launch_stem<3, 0>(in, weight, bias, out, N, 3, 0, Hin, Win, Cout, negative_slope, st);
+  if (Cin == 6) return launch_stem<6, 0>(in, weight, bias, out, N, 6, 0, Hin, Win, Cout, negative_slope, st);
+  const int rc = launch_stem<6, 1>(in, weight, bias, out, N, 12, 0, Hin, Win, Cout, negative_slope, st);     // channels 0-5: partial sums
+  if (rc) return rc;
+  return launch_stem<6, 2>(in, weight, bias, out, N, 12, 6, Hin, Win, Cout, negative_slope, st);            // channels 6-11, bias, ReLU
 }

@@ -217,7 +217,7 @@ int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, f
  *      (forward_gpu_gemm + forward_gpu_bias, base_conv_layer.cpp:325-348; weight [Cout, Cin, 7, 7]) followed by the in-place
  *      ReLULayer::Forward_gpu, src/caffe/layers/relu_layer.cu:8-27.
  *   top is [N, Cout, (Hin - 1) / 2 + 1, (Win - 1) / 2 + 1].  fn2_conv_k7s2_relu_supported tells whether this build has a
- *   kernel for the shape (Cin 3 or 6, Cout % 64 == 0, Win % 8 == 0); callers keep the library convolution otherwise.
+ *   kernel for the shape (Cin 3, 6 or 12, Cout % 64 == 0, Win % 8 == 0); callers keep the library convolution otherwise.
  *   Forward only.
  * ---------------------------------------------------------------------------------------------- */
 int fn2_conv_k7s2_relu_supported(int Cin, int Hin, int Win, int Cout);

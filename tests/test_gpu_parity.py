@@ -354,7 +354,8 @@ def test_stem_conv_k7s2_relu(shape):
 
 def test_stem_conv_unsupported_shapes_are_reported():
     assert not ops.conv_k7s2_relu_supported(3, 64, 100, 64)      # width not a multiple of 8
-    assert not ops.conv_k7s2_relu_supported(12, 64, 128, 64)     # stacked FlowNetS inputs keep the library path
+    assert ops.conv_k7s2_relu_supported(12, 64, 128, 64)         # stacked FlowNetS inputs: two 6-channel passes
+    assert not ops.conv_k7s2_relu_supported(5, 64, 128, 64)
     assert not ops.conv_k7s2_relu_supported(3, 64, 128, 32)
     with pytest.raises(Exception):
         ops.conv_k7s2_relu_forward(dev(rand((1, 3, 64, 100), 1)), dev(rand((64, 3, 7, 7), 2)), None)
@@ -558,7 +559,7 @@ def test_sweep_flow_heads_and_bias(shape):
     np.testing.assert_array_equal(host(ops.bias_leaky_relu_(dev(x), dev(bc), 0.1)), oracle.bias_leaky_relu_forward(x, bc, 0.1))
 
 
-@pytest.mark.parametrize("case", [(1, 3, 16, 24, 64), (2, 6, 23, 40, 64), (1, 3, 9, 8, 128), (1, 3, 50, 136, 64)])
+@pytest.mark.parametrize("case", [(1, 3, 16, 24, 64), (2, 6, 23, 40, 64), (1, 3, 9, 8, 128), (1, 3, 50, 136, 64), (2, 12, 21, 48, 64), (1, 12, 64, 128, 128)])
 def test_sweep_stem_conv(case):
     N, Cin, H, W, Cout = case
     x, w, b = rand((N, Cin, H, W), 230), rand((Cout, Cin, 7, 7), 231, 0.1), rand((Cout,), 232)
