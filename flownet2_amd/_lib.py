@@ -14,6 +14,7 @@ SO_PATH = os.path.join(_HERE, "libflownet2_hip.so")
 EXPORTS = [
     "fn2_version", "fn2_last_error_string",
     "fn2_correlation_out_shape", "fn2_correlation_workspace_bytes", "fn2_correlation_forward", "fn2_correlation_backward",
+    "fn2_correlation1d_out_shape", "fn2_correlation1d_forward", "fn2_correlation1d_backward",
     "fn2_flow_warp_forward", "fn2_flow_warp_backward_workspace_bytes", "fn2_flow_warp_backward",
     "fn2_resample_forward",
     "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
@@ -36,7 +37,8 @@ class Fn2Error(RuntimeError):
 
 class CorrParams(C.Structure):
     _fields_ = [("pad", C.c_int), ("kernel_size", C.c_int), ("max_displacement", C.c_int),
-                ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int)]
+                ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int),
+                ("single_direction", C.c_int)]
 
 
 class L1LossParams(C.Structure):
@@ -65,6 +67,9 @@ def lib():
     L.fn2_correlation_workspace_bytes.restype = sz
     L.fn2_correlation_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_correlation_backward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_correlation1d_out_shape.argtypes = [C.POINTER(CorrParams), i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.fn2_correlation1d_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp]
+    L.fn2_correlation1d_backward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, fp, fp, i, i, i, i, vp]
     L.fn2_flow_warp_forward.argtypes = [fp, fp, fp, i, i, i, i, i, vp]
     L.fn2_flow_warp_backward_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_flow_warp_backward_workspace_bytes.restype = sz

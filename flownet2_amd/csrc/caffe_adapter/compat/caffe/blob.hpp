@@ -11,7 +11,7 @@ namespace caffe {
 class SyncedMemory {
  public:
   explicit SyncedMemory(size_t size) : size_(size) {}
-  ~SyncedMemory() { if (cpu_) std::free(cpu_); if (gpu_) (void)hipFree(gpu_); }
+  ~SyncedMemory() { if (cpu_) std::free(cpu_); if (gpu_) (void)hipFree(static_cast<char*>(gpu_) - kFrontGuard); }
   const void* cpu_data() { to_cpu(); return cpu_; }
   const void* gpu_data() { to_gpu(); return gpu_; }
   void* mutable_cpu_data() { to_cpu(); head_ = HEAD_AT_CPU; return cpu_; }
@@ -25,10 +25,20 @@ class SyncedMemory {
     if (head_ == UNINITIALIZED) head_ = HEAD_AT_CPU;
   }
   void to_gpu() {
-    if (!gpu_) { CUDA_CHECK(hipMalloc(&gpu_, size_ ? size_ : 1)); CUDA_CHECK(hipMemset(gpu_, 0, size_ ? size_ : 1)); }
+    if (!gpu_) {
+      void* base = nullptr;
+      CUDA_CHECK(hipMalloc(&base, kFrontGuard + (size_ ? size_ : 1)));
+      CUDA_CHECK(hipMemset(base, 0, kFrontGuard + (size_ ? size_ : 1)));
+      gpu_ = static_cast<char*>(base) + kFrontGuard;
+    }
     if (head_ == HEAD_AT_CPU) { CUDA_CHECK(hipMemcpy(gpu_, cpu_, size_, hipMemcpyHostToDevice)); head_ = SYNCED; }
     if (head_ == UNINITIALIZED) head_ = HEAD_AT_GPU;
   }
+  // Zeroed bytes in front of every device buffer.  The reference's Correlation1D with single_direction = -1 reads up to
+  // stride_2 * channels floats in FRONT of its scratch blob (correlation_layer1d.cu:89 with x_shift = -grid_width, :467-468).
+  // With cudaMalloc's sub-allocator that is readable neighbouring memory; a bare hipMalloc block here starts a mapping and the
+  // read faults.  The guard makes that read defined (zeros) so the layer can be run and pinned.
+  static constexpr size_t kFrontGuard = 16384;
   void* cpu_ = nullptr;
   void* gpu_ = nullptr;
   size_t size_;

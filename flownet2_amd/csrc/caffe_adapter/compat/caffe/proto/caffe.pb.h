@@ -30,6 +30,7 @@ class CorrelationParameter {
   void set_stride_1(unsigned v) { stride_1_ = v; }
   void set_stride_2(unsigned v) { stride_2_ = v; }
   void set_do_abs(bool v) { do_abs_ = v; }
+  void set_single_direction(int v) { single_direction_ = v; }
   void set_correlation_type(CorrelationType v) { correlation_type_ = v; }
  private:
   unsigned pad_ = 0, kernel_size_ = 0, max_displacement_ = 0, stride_1_ = 1, stride_2_ = 1;

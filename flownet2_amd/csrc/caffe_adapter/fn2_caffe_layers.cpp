@@ -65,6 +65,7 @@ class CorrelationLayer : public Layer<Dtype> {
     params_.stride2 = cp.stride_2();
     params_.corr_type = cp.correlation_type() == CorrelationParameter_CorrelationType_SUBTRACT ? FN2_CORR_SUBTRACT : FN2_CORR_MULTIPLY;
     params_.do_abs = cp.do_abs();
+    params_.single_direction = 0;   // Correlation1D only
   }
   virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
     CHECK_EQ(bottom[0]->width(), bottom[1]->width()) << "Both bottom blobs must have same width";
@@ -99,6 +100,56 @@ class CorrelationLayer : public Layer<Dtype> {
   }
   fn2_corr_params params_;
   int num_, top_height_, top_width_, top_channels_;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Correlation1D (horizontal displacements; correlation_layer1d.cpp / .cu of the reference)
+template <typename Dtype>
+class Correlation1DLayer : public Layer<Dtype> {
+ public:
+  explicit Correlation1DLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    const CorrelationParameter& cp = this->layer_param_.correlation_param();
+    CHECK(cp.has_kernel_size()) << "Filter kernel_size is not set";
+    CHECK(cp.has_max_displacement()) << "Max displacement is required.";
+    if (cp.kernel_size() % 2 == 0) LOG(FATAL) << "Odd kernel size required";
+    if (cp.single_direction() < -1 || cp.single_direction() > 1) LOG(FATAL) << "single_direction must be -1 (left), 0 (off), or 1 (right)";
+    params_.pad = cp.pad();
+    params_.kernel_size = cp.kernel_size();
+    params_.max_displacement = cp.max_displacement();
+    params_.stride1 = cp.stride_1();
+    params_.stride2 = cp.stride_2();
+    params_.corr_type = cp.correlation_type() == CorrelationParameter_CorrelationType_SUBTRACT ? FN2_CORR_SUBTRACT : FN2_CORR_MULTIPLY;
+    params_.do_abs = cp.do_abs();
+    params_.single_direction = cp.single_direction();
+  }
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom[0]->width(), bottom[1]->width()) << "Both bottom blobs must have same width";
+    CHECK_EQ(bottom[0]->height(), bottom[1]->height()) << "Both bottom blobs must have same height";
+    CHECK_EQ(bottom[0]->channels(), bottom[1]->channels()) << "Both bottom blobs must have same number of channels";
+    int tc, th, tw;
+    FN2_CALL(fn2_correlation1d_out_shape(&params_, bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(), &tc, &th, &tw));
+    top[0]->Reshape(bottom[0]->num(), tc, th, tw);
+  }
+  virtual inline const char* type() const { return "Correlation1D"; }
+  virtual inline int ExactNumBottomBlobs() const { return 2; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom.size(), 2u);
+    CHECK_EQ(top.size(), 1u);
+    FN2_CALL(fn2_correlation1d_forward(&params_, f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->mutable_gpu_data()),
+                                       bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(), kStream));
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>&, const vector<Blob<Dtype>*>& bottom) {
+    FN2_CALL(fn2_correlation1d_backward(&params_, f32(bottom[0]->gpu_data()), f32(bottom[1]->gpu_data()), f32(top[0]->gpu_diff()),
+                                        f32(bottom[0]->mutable_gpu_diff()), f32(bottom[1]->mutable_gpu_diff()),
+                                        bottom[0]->num(), bottom[0]->channels(), bottom[0]->height(), bottom[0]->width(), kStream));
+  }
+  fn2_corr_params params_;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -309,6 +360,8 @@ class DownsampleLayer : public Layer<Dtype> {
 
 INSTANTIATE_CLASS(CorrelationLayer);
 REGISTER_LAYER_CLASS(Correlation);
+INSTANTIATE_CLASS(Correlation1DLayer);
+REGISTER_LAYER_CLASS(Correlation1D);
 INSTANTIATE_CLASS(FlowWarpLayer);
 REGISTER_LAYER_CLASS(FlowWarp);
 INSTANTIATE_CLASS(ResampleLayer);

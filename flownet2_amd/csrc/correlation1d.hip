@@ -1,0 +1,185 @@
+// Correlation1D (horizontal cost volume) for gfx950.
+//
+// Replaces Correlation1DLayer::Forward_gpu / Backward_gpu (reference: src/caffe/layers/correlation_layer1d.cu:429-616)
+// behind fn2_correlation1d_{forward,backward}.  As for the 2-D layer there is no padded NHWC scratch copy: the kernels read
+// the NCHW blobs and treat the horizontal padding as zeros.  The reference addresses its scratch blob [N, H, W+2p, C] with a
+// flat index and no bounds check; with single_direction = -1 the first displacement lies one grid step beyond the radius
+// (x_shift = -grid_width, correlation_layer1d.cu:466-471), so columns left of a padded row are read: that is the end of the
+// previous row of the flat blob.  padded_flat() reproduces exactly that (memory in front of the blob reads as 0).
+//
+// One thread per output element, x fastest (coalesced along rows); gather formulation of the backward passes, no atomics.
+#include "fn2_common.hpp"
+
+#include <cmath>
+
+namespace fn2 {
+
+struct Corr1dGeom {
+  int N, C, H, W;
+  int pad, K, md, s1, s2, kr, pW;
+  int topC, topH, topW, ngr, ngw, xshift;
+  int type;
+};
+
+// Correlation1DLayer::LayerSetUp + Reshape, correlation_layer1d.cpp:12-92.
+static int corr1d_geometry(const fn2_corr_params* p, int N, int C, int H, int W, Corr1dGeom* g) {
+  if (!p) return fail(FN2_ERR_INVALID_ARG, "correlation1d: params == NULL");
+  if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "correlation1d: bad bottom shape [%d,%d,%d,%d]", N, C, H, W);
+  if (p->kernel_size < 1 || p->kernel_size % 2 == 0)
+    return fail(FN2_ERR_INVALID_ARG, "correlation1d: Odd kernel size required (got %d)", p->kernel_size);
+  if (p->stride1 < 1 || p->stride2 < 1) return fail(FN2_ERR_INVALID_ARG, "correlation1d: strides must be >= 1");
+  if (p->max_displacement < 0 || p->pad < 0) return fail(FN2_ERR_INVALID_ARG, "correlation1d: negative pad / max_displacement");
+  if (p->single_direction < -1 || p->single_direction > 1)
+    return fail(FN2_ERR_INVALID_ARG, "correlation1d: single_direction must be -1 (left), 0 (off), or 1 (right)");
+  if (p->corr_type != FN2_CORR_MULTIPLY && p->corr_type != FN2_CORR_SUBTRACT)
+    return fail(FN2_ERR_INVALID_ARG, "correlation1d: unknown correlation_type %d", p->corr_type);
+  g->N = N; g->C = C; g->H = H; g->W = W;
+  g->pad = p->pad; g->K = p->kernel_size; g->md = p->max_displacement; g->s1 = p->stride1; g->s2 = p->stride2;
+  g->type = p->corr_type;
+  g->kr = (g->K - 1) / 2;
+  g->pW = W + 2 * g->pad;
+  const int border = g->md + g->kr;
+  g->topW = (int)std::ceil((float)(g->pW - border * 2) / (float)g->s1);
+  g->topH = (int)std::ceil((float)(H - g->kr * 2) / (float)g->s1);
+  if (g->topW < 1 || g->topH < 1)
+    return fail(FN2_ERR_INVALID_ARG, "Correlation cannot be done with current settings. Neighborhood and kernel don't fit in blob");
+  g->ngr = g->md / g->s2;
+  g->ngw = p->single_direction != 0 ? g->ngr + 1 : 2 * g->ngr + 1;
+  g->topC = g->ngw;
+  g->xshift = p->single_direction == -1 ? -g->ngw : (p->single_direction == 1 ? 0 : -g->ngr);   // correlation_layer1d.cu:466-471
+  return FN2_OK;
+}
+
+// Element (n, m, q, c) of the reference's flat zero-padded scratch blob [N, H, pW, C], q possibly outside [0, pW).
+__device__ __forceinline__ float padded_flat(const float* __restrict__ b, int n, int c, int m, int q, const Corr1dGeom& g) {
+  if (q < 0 || q >= g.pW) {
+    const long long f = ((long long)n * g.H + m) * g.pW + q;
+    if (f < 0 || f >= (long long)g.N * g.H * g.pW) return 0.f;   // outside the blob: undefined in the reference
+    const long long row = f / g.pW;
+    q = (int)(f - row * g.pW);
+    n = (int)(row / g.H);
+    m = (int)(row - (long long)n * g.H);
+  }
+  const int x = q - g.pad;
+  return (x >= 0 && x < g.W) ? b[(((size_t)n * g.C + c) * g.H + m) * g.W + x] : 0.f;
+}
+
+template <bool SUB>
+__global__ void __launch_bounds__(256) corr1d_fwd(const float* __restrict__ b0, const float* __restrict__ b1,
+                                                  float* __restrict__ top, Corr1dGeom g) {
+  const long long total = (long long)g.N * g.topC * g.topH * g.topW;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % g.topW);
+    const int y = (int)((idx / g.topW) % g.topH);
+    const int tc = (int)((idx / g.topW / g.topH) % g.topC);
+    const int n = (int)(idx / g.topW / g.topH / g.topC);
+    const int s2o = (tc + g.xshift) * g.s2;
+    float sum = 0.f;
+    for (int j = 0; j < g.K; ++j) {
+      const int m = y * g.s1 + j;
+      for (int i = 0; i < g.K; ++i) {
+        const int qa = x * g.s1 + g.md + i, qb = qa + s2o;
+        for (int c = 0; c < g.C; ++c) {
+          const float av = padded_flat(b0, n, c, m, qa, g);
+          const float bv = padded_flat(b1, n, c, m, qb, g);
+          sum = SUB ? sum + fabsf(av - bv) : fmaf(av, bv, sum);
+        }
+      }
+    }
+    top[idx] = sum / (float)(g.K * g.K * g.C);
+  }
+}
+
+__device__ __forceinline__ int ceil_div1(int a, int s) { return (a >= 0) ? (a + s - 1) / s : -((-a) / s); }
+__device__ __forceinline__ int floor_div1(int a, int s) { return (a >= 0) ? a / s : -((-a + s - 1) / s); }
+
+// WHICH = 0: bottom0 diff (CorrelateDataBackward0[Subtract], correlation_layer1d.cu:117-181, :295-359);
+// WHICH = 1: bottom1 diff (CorrelateDataBackward1[Subtract], :183-249, :361-423).
+template <bool SUB, int WHICH>
+__global__ void __launch_bounds__(256) corr1d_bwd(const float* __restrict__ b0, const float* __restrict__ b1,
+                                                  const float* __restrict__ top_diff, float* __restrict__ bdiff, Corr1dGeom g) {
+  const long long total = (long long)g.N * g.C * g.H * g.W;
+  const size_t tplane = (size_t)g.topH * g.topW;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % g.W);
+    const int m = (int)((idx / g.W) % g.H);
+    const int c = (int)((idx / g.W / g.H) % g.C);
+    const int n = (int)(idx / g.W / g.H / g.C);
+    const int l = x + g.pad;
+    const float* td = top_diff + (size_t)n * g.topC * tplane;
+    int ymin = ceil_div1(m - 2 * g.kr, g.s1);
+    int ymax = floor_div1(m, g.s1);
+    float sum = 0.f;
+    for (int o = g.xshift; o < g.xshift + g.ngw; ++o) {
+      const int s2o = g.s2 * o;
+      const int sx = (WHICH == 0) ? 0 : s2o;
+      int xmin = ceil_div1(l - 2 * g.kr - g.md - sx, g.s1);
+      int xmax = floor_div1(l - g.md - sx, g.s1);
+      if (!(xmax >= 0 && ymax >= 0 && xmin <= g.topW - 1 && ymin <= g.topH - 1)) continue;
+      xmin = max(0, xmin); xmax = min(g.topW - 1, xmax);
+      const int y0 = max(0, ymin), y1 = min(g.topH - 1, ymax);
+      const int q = (WHICH == 0) ? l + s2o : l - s2o;
+      float coef;
+      if (!SUB) {
+        coef = padded_flat((WHICH == 0) ? b1 : b0, n, c, m, q, g);
+      } else {
+        const float v0 = padded_flat(b0, n, c, m, q, g), v1 = padded_flat(b1, n, c, m, q, g);
+        coef = (WHICH == 0) ? ((v0 >= v1) ? 1.f : -1.f) : ((v0 >= v1) ? -1.f : 1.f);
+      }
+      const float* t = td + (size_t)(o - g.xshift) * tplane;
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = xmin; xx <= xmax; ++xx) sum = fmaf(t[(size_t)yy * g.topW + xx], coef, sum);
+    }
+    bdiff[idx] = sum / (float)((g.kr * 2 + 1) * (g.kr * 2 + 1) * g.C);
+  }
+}
+
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API int fn2_correlation1d_out_shape(const fn2_corr_params* p, int C, int H, int W, int* topC, int* topH, int* topW) {
+  Corr1dGeom g;
+  int rc = corr1d_geometry(p, 1, C, H, W, &g);
+  if (rc) return rc;
+  if (topC) *topC = g.topC;
+  if (topH) *topH = g.topH;
+  if (topW) *topW = g.topW;
+  return FN2_OK;
+}
+
+FN2_API int fn2_correlation1d_forward(const fn2_corr_params* p, const float* bottom0, const float* bottom1, float* top,
+                                      int N, int C, int H, int W, void* stream) {
+  Corr1dGeom g;
+  int rc = corr1d_geometry(p, N, C, H, W, &g);
+  if (rc) return rc;
+  if (N == 0) return FN2_OK;
+  if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation1d_forward: NULL blob pointer");
+  const unsigned blocks = blocks_for((long long)N * g.topC * g.topH * g.topW, 256);
+  if (g.type == FN2_CORR_MULTIPLY)
+    hipLaunchKernelGGL(corr1d_fwd<false>, dim3(blocks), dim3(256), 0, as_stream(stream), bottom0, bottom1, top, g);
+  else
+    hipLaunchKernelGGL(corr1d_fwd<true>, dim3(blocks), dim3(256), 0, as_stream(stream), bottom0, bottom1, top, g);
+  return check_launch("correlation1d_forward");
+}
+
+FN2_API int fn2_correlation1d_backward(const fn2_corr_params* p, const float* bottom0, const float* bottom1, const float* top_diff,
+                                       float* bottom0_diff, float* bottom1_diff, int N, int C, int H, int W, void* stream) {
+  Corr1dGeom g;
+  int rc = corr1d_geometry(p, N, C, H, W, &g);
+  if (rc) return rc;
+  if (N == 0) return FN2_OK;
+  if (!bottom0 || !bottom1 || !top_diff) return fail(FN2_ERR_INVALID_ARG, "correlation1d_backward: NULL blob pointer");
+  hipStream_t st = as_stream(stream);
+  const unsigned blocks = blocks_for((long long)N * C * H * W, 256);
+  const bool sub = (g.type == FN2_CORR_SUBTRACT);
+  if (bottom0_diff) {
+    if (!sub) hipLaunchKernelGGL((corr1d_bwd<false, 0>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom0_diff, g);
+    else hipLaunchKernelGGL((corr1d_bwd<true, 0>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom0_diff, g);
+  }
+  if (bottom1_diff) {
+    if (!sub) hipLaunchKernelGGL((corr1d_bwd<false, 1>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom1_diff, g);
+    else hipLaunchKernelGGL((corr1d_bwd<true, 1>), dim3(blocks), dim3(256), 0, st, bottom0, bottom1, top_diff, bottom1_diff, g);
+  }
+  return check_launch("correlation1d_backward");
+}

@@ -235,6 +235,44 @@ class CorrelationLayer(Layer):
         bottom[0].diff, bottom[1].diff = d0, d1
 
 
+class Correlation1DLayer(Layer):
+    """include/caffe/layers/correlation_1d_layer.hpp; correlation_layer1d.cpp:12-92 (horizontal displacements only)."""
+
+    def type(self): return "Correlation1D"
+    def ExactNumBottomBlobs(self): return 2
+    def ExactNumTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        cp = self.layer_param_.correlation_param
+        CHECK("kernel_size" in cp, "Filter kernel_size is not set")                 # cpp:19
+        CHECK("max_displacement" in cp, "Max displacement is required.")            # cpp:20
+        ctype = cp.get("correlation_type", 0)
+        if isinstance(ctype, str):
+            ctype = {"MULTIPLY": 0, "SUBTRACT": 1}[ctype]
+        if int(cp["kernel_size"]) % 2 == 0:
+            raise CheckError("Odd kernel size required")                             # cpp:23
+        sd = int(cp.get("single_direction", 0))
+        if sd < -1 or sd > 1:
+            raise CheckError("single_direction must be -1 (left), 0 (off), or 1 (right)")   # cpp:30
+        self.params_ = ops.corr_params(cp.get("pad", 0), cp["kernel_size"], cp["max_displacement"], cp.get("stride_1", 1),
+                                       cp.get("stride_2", 1), ctype, cp.get("do_abs", False), sd)
+
+    def Reshape(self, bottom, top):
+        CHECK(bottom[0].width() == bottom[1].width(), "Both bottom blobs must have same width")       # cpp:48
+        CHECK(bottom[0].height() == bottom[1].height(), "Both bottom blobs must have same height")    # cpp:49
+        CHECK(bottom[0].channels() == bottom[1].channels(), "Both bottom blobs must have same number of channels")  # cpp:50
+        tc, th, tw = _wrap(ops.correlation1d_out_shape, self.params_, bottom[0].channels(), bottom[0].height(), bottom[0].width())
+        top[0].Reshape(bottom[0].num(), tc, th, tw)                                  # cpp:81
+
+    def Forward_gpu(self, bottom, top):
+        top[0].data = _wrap(ops.correlation1d_forward, self.params_, bottom[0].data, bottom[1].data)
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        # like the reference (correlation_layer1d.cu:513-616) both diffs are always written
+        d0, d1 = _wrap(ops.correlation1d_backward, self.params_, bottom[0].data, bottom[1].data, top[0].mutable_gpu_diff())
+        bottom[0].diff, bottom[1].diff = d0, d1
+
+
 class FlowWarpLayer(Layer):
     """include/caffe/layers/flow_warp_layer.hpp; flow_warp_layer.cpp:35-52."""
 
@@ -417,6 +455,7 @@ def REGISTER_LAYER_CLASS(type_: str, klass):
 
 
 REGISTER_LAYER_CLASS("Correlation", CorrelationLayer)      # correlation_layer.cpp:102-103
+REGISTER_LAYER_CLASS("Correlation1D", Correlation1DLayer)  # correlation_layer1d.cpp:108-109
 REGISTER_LAYER_CLASS("FlowWarp", FlowWarpLayer)            # flow_warp_layer.cpp:259-260
 REGISTER_LAYER_CLASS("Resample", ResampleLayer)            # resample_layer.cpp:71-72
 REGISTER_LAYER_CLASS("L1Loss", L1LossLayer)                # l1loss_layer.cpp:108-109

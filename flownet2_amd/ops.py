@@ -36,9 +36,10 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def corr_params(pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1, correlation_type=MULTIPLY, do_abs=False):
+def corr_params(pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1, correlation_type=MULTIPLY, do_abs=False,
+                single_direction=0):
     return CorrParams(int(pad), int(kernel_size), int(max_displacement), int(stride_1), int(stride_2),
-                      int(correlation_type), int(bool(do_abs)))
+                      int(correlation_type), int(bool(do_abs)), int(single_direction))
 
 
 def correlation_out_shape(p: CorrParams, Cc: int, H: int, W: int):
@@ -66,6 +67,32 @@ def correlation_backward(p: CorrParams, bottom0, bottom1, top_diff, need0=True, 
     d1 = torch.empty_like(b1) if need1 else None
     check(_lib.lib().fn2_correlation_backward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(td), _ptr(d0), _ptr(d1),
                                               N, Cc, H, W, None, 0, _stream()))
+    return d0, d1
+
+
+def correlation1d_out_shape(p: CorrParams, Cc: int, H: int, W: int):
+    tc, th, tw = C.c_int(), C.c_int(), C.c_int()
+    check(_lib.lib().fn2_correlation1d_out_shape(C.byref(p), Cc, H, W, C.byref(tc), C.byref(th), C.byref(tw)))
+    return tc.value, th.value, tw.value
+
+
+def correlation1d_forward(p: CorrParams, bottom0: torch.Tensor, bottom1: torch.Tensor):
+    b0, b1 = _chk(bottom0, "bottom[0]"), _chk(bottom1, "bottom[1]")
+    if b0.shape != b1.shape:   # correlation_layer1d.cpp:48-50
+        raise ValueError("Both bottom blobs must have same shape")
+    N, Cc, H, W = b0.shape
+    tc, th, tw = correlation1d_out_shape(p, Cc, H, W)
+    top = torch.empty((N, tc, th, tw), device=b0.device, dtype=torch.float32)
+    check(_lib.lib().fn2_correlation1d_forward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(top), N, Cc, H, W, _stream()))
+    return top
+
+
+def correlation1d_backward(p: CorrParams, bottom0, bottom1, top_diff, need0=True, need1=True):
+    b0, b1, td = _chk(bottom0, "bottom[0]"), _chk(bottom1, "bottom[1]"), _chk(top_diff, "top.diff")
+    N, Cc, H, W = b0.shape
+    d0 = torch.empty_like(b0) if need0 else None
+    d1 = torch.empty_like(b1) if need1 else None
+    check(_lib.lib().fn2_correlation1d_backward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(td), _ptr(d0), _ptr(d1), N, Cc, H, W, _stream()))
     return d0, d1
 
 

@@ -65,6 +65,7 @@ typedef struct fn2_corr_params {
   int stride2;           /* stride_2         = 6  [default 1]  */
   int corr_type;         /* correlation_type = 15 [default MULTIPLY] */
   int do_abs;            /* do_abs = 7: parsed but never used by the reference (correlation_layer.cpp:29); ignored */
+  int single_direction;  /* single_direction = 8 [default 0]: Correlation1D only (-1 left, 0 both, 1 right); the 2-D layer never reads it */
 } fn2_corr_params;
 
 /* Reshape: top = [N, topC, topH, topW].  Errors: even kernel_size, stride <= 0, top dims < 1
@@ -86,6 +87,25 @@ int fn2_correlation_backward(const fn2_corr_params* p,
                              float* bottom0_diff, float* bottom1_diff,
                              int N, int C, int H, int W,
                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation1D  (type: "Correlation1D"; horizontal displacements only -- the DispNet variant of the layer)
+ *   params  <- the same CorrelationParameter + single_direction, Correlation1DLayer::LayerSetUp, src/caffe/layers/correlation_layer1d.cpp:12-40
+ *   shapes  <- Correlation1DLayer::Reshape, correlation_layer1d.cpp:42-92: zero padding in x only; topW = ceil((W+2p-2(md+kr))/s1),
+ *              topH = ceil((H-2kr)/s1); topC = md/s2 + 1 (single_direction != 0) or 2(md/s2) + 1
+ *   forward <- Correlation1DLayer::Forward_gpu, src/caffe/layers/correlation_layer1d.cu:429-510 (CorrelateData :47-113, ...Subtract :251-293);
+ *              displacement of top channel c is (c + x_shift) * s2 with x_shift = -md/s2 (both), 0 (right), -topC (left, :466-471)
+ *   backward<- Correlation1DLayer::Backward_gpu, correlation_layer1d.cu:513-616 (kernels :117-249, :295-423)
+ * single_direction = -1 makes the reference read up to s2 elements before the start of a padded row (x_shift = -topC, one more than
+ * the grid radius): in its flat [N,H,W+2p,C] scratch blob that is the end of the previous row (zero padding when p > 0), and for the
+ * first row of the first sample memory in front of the blob (undefined; read as 0 here).  The kernels reproduce the flat indexing.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_correlation1d_out_shape(const fn2_corr_params* p, int C, int H, int W, int* topC, int* topH, int* topW);
+int fn2_correlation1d_forward(const fn2_corr_params* p, const float* bottom0, const float* bottom1, float* top,
+                              int N, int C, int H, int W, void* stream);
+/* Overwrites both bottom diffs (propagate_down is ignored, correlation_layer1d.cu:513-616); either may be NULL to skip that half. */
+int fn2_correlation1d_backward(const fn2_corr_params* p, const float* bottom0, const float* bottom1, const float* top_diff,
+                               float* bottom0_diff, float* bottom1_diff, int N, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FlowWarp  (type: "FlowWarp")

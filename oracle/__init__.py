@@ -4,8 +4,7 @@ TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.
 leg, never by flownet2_amd/.  All arrays are host numpy float32, C-contiguous NCHW.
 
 Parity status: see the header of fn2_oracle.c (pinned against the reference's own kernels through
-oracle/_ref + tests/golden for Correlation / FlowWarp / Resample / ChannelNorm / Downsample;
-"parity unpinned" for L1Loss).
+oracle/_ref + tests/golden for every layer restated there).
 """
 from __future__ import annotations
 
@@ -25,7 +24,8 @@ NEAREST, LINEAR, CUBIC, AREA = 1, 2, 3, 4
 
 class CorrParams(C.Structure):
     _fields_ = [("pad", C.c_int), ("kernel_size", C.c_int), ("max_displacement", C.c_int),
-                ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int)]
+                ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int),
+                ("single_direction", C.c_int)]
 
 
 class L1Params(C.Structure):
@@ -70,8 +70,8 @@ def num_threads() -> int:
     return lib().fn2_oracle_num_threads()
 
 
-def corr_params(pad=0, kernel_size=1, max_displacement=0, stride1=1, stride2=1, corr_type=MULTIPLY, do_abs=0):
-    return CorrParams(pad, kernel_size, max_displacement, stride1, stride2, corr_type, do_abs)
+def corr_params(pad=0, kernel_size=1, max_displacement=0, stride1=1, stride2=1, corr_type=MULTIPLY, do_abs=0, single_direction=0):
+    return CorrParams(pad, kernel_size, max_displacement, stride1, stride2, corr_type, do_abs, single_direction)
 
 
 def correlation_out_shape(p: CorrParams, Cc, H, W):
@@ -94,6 +94,29 @@ def correlation_backward(p: CorrParams, b0, b1, top_diff):
     N, Cc, H, W = b0.shape
     d0, d1 = np.empty_like(b0), np.empty_like(b1)
     _check(lib().fn2_correlation_backward_cpu(C.byref(p), _p(b0), _p(b1), _p(top_diff), _p(d0), _p(d1), N, Cc, H, W), "correlation_backward")
+    return d0, d1
+
+
+def correlation1d_out_shape(p: CorrParams, Cc, H, W):
+    tc, th, tw = C.c_int(), C.c_int(), C.c_int()
+    _check(lib().fn2_correlation1d_out_shape_cpu(C.byref(p), Cc, H, W, C.byref(tc), C.byref(th), C.byref(tw)), "correlation1d_out_shape")
+    return tc.value, th.value, tw.value
+
+
+def correlation1d_forward(p: CorrParams, b0, b1):
+    b0, b1 = _f32(b0), _f32(b1)
+    N, Cc, H, W = b0.shape
+    tc, th, tw = correlation1d_out_shape(p, Cc, H, W)
+    top = np.empty((N, tc, th, tw), np.float32)
+    _check(lib().fn2_correlation1d_forward_cpu(C.byref(p), _p(b0), _p(b1), _p(top), N, Cc, H, W), "correlation1d_forward")
+    return top
+
+
+def correlation1d_backward(p: CorrParams, b0, b1, top_diff):
+    b0, b1, top_diff = _f32(b0), _f32(b1), _f32(top_diff)
+    N, Cc, H, W = b0.shape
+    d0, d1 = np.empty_like(b0), np.empty_like(b1)
+    _check(lib().fn2_correlation1d_backward_cpu(C.byref(p), _p(b0), _p(b1), _p(top_diff), _p(d0), _p(d1), N, Cc, H, W), "correlation1d_backward")
     return d0, d1
 
 

@@ -10,11 +10,11 @@
  * any FlowNet2 layer (src/caffe/test/ is stock BVLC), and its build (boost/glog/protobuf/BLAS/
  * CUDA) cannot run in this image.  This file therefore restates the reference's CUDA kernels line
  * by line in plain C.  Two pins exist (see oracle/README.md):
- *   (1) oracle/_ref: the reference's OWN .cu/.cpp sources for Correlation, FlowWarp, Resample,
+ *   (1) oracle/_ref: the reference's OWN .cu/.cpp sources for Correlation, Correlation1D, FlowWarp, Resample,
  *       ChannelNorm, Downsample and L1Loss compiled in place with hipcc against stand-in caffe
  *       headers and run on an MI355X; tests/golden/ref_golden.npz holds the outputs they produced
  *       and tests/test_golden.py checks every reference-layer function below against them
- *       (PINNED for all six layers).  L1LossLayer instantiates the stock Eltwise / Power /
+ *       (PINNED for all seven layers).  L1LossLayer instantiates the stock Eltwise / Power /
  *       Convolution layers (l1loss_layer.cpp:19-62): those sources (+ base_conv_layer.cpp,
  *       im2col.{cpp,cu}) are compiled in place as well; the only replaced part is the cuBLAS /
  *       CBLAS calls underneath them (oracle/ref_compat/caffe/util/math_functions.hpp: plain
@@ -257,6 +257,197 @@ FN2_API int fn2_correlation_backward_cpu(const fn2_corr_params* p, const float* 
                 }
               }
             bottom1_diff[(size_t)item * bottomcount + ((size_t)n * H + yy) * W + xx] = sum / (float)sumelems;   /* :245-246 */
+          }
+        }
+  }
+  free(r0);
+  free(r1);
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation1D: correlation_layer1d.cpp:12-92 (LayerSetUp, Reshape), correlation_layer1d.cu:23-616.
+ * Horizontal displacements only; the scratch blob is [N, H, W+2p, C] (padding in x only, :26-44).
+ * The kernels address it with a flat index and no bounds check.  With single_direction = -1 the first
+ * displacement is x_shift = -grid_width (:466-471), one step beyond the grid radius, so columns left of a
+ * row start are read: in the flat blob that is the tail of the previous row.  flat_at() keeps the flat
+ * indexing; an index outside the blob (undefined in the reference) reads as 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct corr1d_geom {
+  int kr, pW, topH, topW, ngr, ngw, topC, xshift;
+} corr1d_geom;
+
+static int corr1d_geometry(const fn2_corr_params* p, int C, int H, int W, corr1d_geom* g) {
+  if (!p || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  if (p->kernel_size < 1 || p->kernel_size % 2 == 0) return FN2_ERR_INVALID_ARG;            /* cpp:22 */
+  if (p->stride1 < 1 || p->stride2 < 1 || p->max_displacement < 0 || p->pad < 0) return FN2_ERR_INVALID_ARG;
+  if (p->single_direction < -1 || p->single_direction > 1) return FN2_ERR_INVALID_ARG;       /* cpp:29 */
+  if (p->corr_type != FN2_CORR_MULTIPLY && p->corr_type != FN2_CORR_SUBTRACT) return FN2_ERR_INVALID_ARG;
+  g->kr = (p->kernel_size - 1) / 2;                                                          /* cpp:58 */
+  const int border = p->max_displacement + g->kr;                                            /* cpp:59 */
+  g->pW = W + 2 * p->pad;                                                                    /* cpp:55 */
+  g->topW = (int)ceilf((float)(g->pW - border * 2) / (float)p->stride1);                     /* cpp:61 */
+  g->topH = (int)ceilf((float)(H - g->kr * 2) / (float)p->stride1);                          /* cpp:62 */
+  if (g->topW < 1 || g->topH < 1) return FN2_ERR_INVALID_ARG;                                /* cpp:64-65 */
+  g->ngr = p->max_displacement / p->stride2;                                                 /* cpp:68 */
+  g->ngw = p->single_direction != 0 ? g->ngr + 1 : g->ngr * 2 + 1;                           /* cpp:70-74 */
+  g->topC = g->ngw;                                                                          /* cpp:78 */
+  g->xshift = -g->ngr;                                                                       /* cu:466 */
+  if (p->single_direction == -1) g->xshift = -g->ngw;                                        /* cu:467-468 */
+  else if (p->single_direction == 1) g->xshift = 0;                                          /* cu:469-470 */
+  return FN2_OK;
+}
+
+FN2_API int fn2_correlation1d_out_shape_cpu(const fn2_corr_params* p, int C, int H, int W,
+                                            int* topC, int* topH, int* topW) {
+  corr1d_geom g;
+  int rc = corr1d_geometry(p, C, H, W, &g);
+  if (rc) return rc;
+  if (topC) *topC = g.topC;
+  if (topH) *topH = g.topH;
+  if (topW) *topW = g.topW;
+  return FN2_OK;
+}
+
+/* corr1d::blob_rearrange_kernel2, correlation_layer1d.cu:25-44 + the cudaMemsets :447-448: NCHW -> N H (W+2p) C */
+static float* rearrange_padded_x(const float* in, int N, int C, int H, int W, int pad) {
+  const int pW = W + 2 * pad;
+  float* out = (float*)calloc((size_t)N * H * pW * C + 1, sizeof(float));
+  if (!out) return NULL;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < N; ++n)
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x)
+        for (int ch = 0; ch < C; ++ch)
+          out[(((size_t)n * H + y) * pW + (x + pad)) * C + ch] = in[(((size_t)n * C + ch) * H + y) * W + x];
+  return out;
+}
+
+static inline float flat_at(const float* r, long long idx, long long count) { return (idx < 0 || idx >= count) ? 0.f : r[idx]; }
+
+FN2_API int fn2_correlation1d_forward_cpu(const fn2_corr_params* p, const float* bottom0, const float* bottom1,
+                                          float* top, int N, int C, int H, int W) {
+  corr1d_geom g;
+  int rc = corr1d_geometry(p, C, H, W, &g);
+  if (rc) return rc;
+  float* r0 = rearrange_padded_x(bottom0, N, C, H, W, p->pad);
+  float* r1 = rearrange_padded_x(bottom1, N, C, H, W, p->pad);
+  if (!r0 || !r1) { free(r0); free(r1); return FN2_ERR_WORKSPACE; }
+  const int K = p->kernel_size, md = p->max_displacement, s1 = p->stride1, s2 = p->stride2, kr = g.kr;
+  const long long pW = g.pW, count = (long long)N * H * pW * C;
+  const size_t topcount = (size_t)g.topC * g.topH * g.topW;
+  const int sumelems = K * K * C;                                                            /* :107 / :288 */
+  const int sub = (p->corr_type == FN2_CORR_SUBTRACT);
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int item = 0; item < N; ++item)
+    for (int by = 0; by < g.topH; ++by)
+      for (int bx = 0; bx < g.topW; ++bx) {
+        const int x1 = bx * s1 + md;                                                         /* :56 (MULTIPLY); :267 = x*s1+kr+md with i from -kr */
+        const int y1 = by * s1;                                                              /* :57 / :268 */
+        for (int tc = 0; tc < g.topC; ++tc) {
+          const int s2o = (tc % g.ngw + g.xshift) * s2;                                      /* :80 / :263 */
+          float total = 0.f;
+          if (!sub) {
+            float lane[32];                                                                  /* :75, lanes as in the 2-D kernel */
+            for (int t = 0; t < 32; ++t) lane[t] = 0.f;
+            for (int j = 0; j < K; ++j)
+              for (int i = 0; i < K; ++i) {
+                const long long ia = (((long long)item * H + y1 + j) * pW + x1 + i) * C;          /* :66 */
+                const long long ib = (((long long)item * H + y1 + j) * pW + x1 + s2o + i) * C;    /* :89 */
+                for (int ch = 0; ch < C; ++ch)
+                  lane[ch & 31] = fmaf(flat_at(r0, ia + ch, count), flat_at(r1, ib + ch, count), lane[ch & 31]);   /* :91 */
+              }
+            for (int t = 0; t < 32; ++t) total += lane[t];                                   /* :100-103 */
+          } else {
+            for (int j = -kr; j <= kr; ++j)
+              for (int i = -kr; i <= kr; ++i) {
+                const long long ia = (((long long)item * H + y1 + kr + j) * pW + x1 + kr + i) * C;        /* :280 */
+                const long long ib = (((long long)item * H + y1 + kr + j) * pW + x1 + kr + s2o + i) * C;  /* :281 */
+                for (int l = 0; l < C; ++l) total += fabsf(flat_at(r0, ia + l, count) - flat_at(r1, ib + l, count));   /* :284 */
+              }
+          }
+          top[(size_t)item * topcount + ((size_t)tc * g.topH + by) * g.topW + bx] = total / (float)sumelems;   /* :106 / :289 */
+        }
+      }
+  free(r0);
+  free(r1);
+  return FN2_OK;
+}
+
+FN2_API int fn2_correlation1d_backward_cpu(const fn2_corr_params* p, const float* bottom0, const float* bottom1,
+                                           const float* top_diff, float* bottom0_diff, float* bottom1_diff,
+                                           int N, int C, int H, int W) {
+  corr1d_geom g;
+  int rc = corr1d_geometry(p, C, H, W, &g);
+  if (rc) return rc;
+  float* r0 = rearrange_padded_x(bottom0, N, C, H, W, p->pad);
+  float* r1 = rearrange_padded_x(bottom1, N, C, H, W, p->pad);
+  if (!r0 || !r1) { free(r0); free(r1); return FN2_ERR_WORKSPACE; }
+  const int md = p->max_displacement, s1 = p->stride1, s2 = p->stride2, pad = p->pad, kr = g.kr;
+  const int topH = g.topH, topW = g.topW, topC = g.topC;
+  const long long pW = g.pW, count = (long long)N * H * pW * C;
+  const int sumelems = (kr * 2 + 1) * (kr * 2 + 1) * C;
+  const size_t bottomcount = (size_t)C * H * W;
+  const int sub = (p->corr_type == FN2_CORR_SUBTRACT);
+
+  if (bottom0_diff) {
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int item = 0; item < N; ++item)
+      for (int m = 0; m < H; ++m)
+        for (int xx = 0; xx < W; ++xx) {
+          const int l = xx + pad;                                                            /* :124 */
+          int xmin = ceil_div_ro(l - 2 * kr - md, s1);                                       /* :134 */
+          int ymin = ceil_div_ro(m - 2 * kr, s1);                                            /* :135 */
+          int xmax = floor_div_ro(l - md, s1);                                               /* :138 */
+          int ymax = floor_div_ro(m, s1);                                                    /* :139 */
+          const int live = (xmax >= 0 && ymax >= 0 && xmin <= topW - 1 && ymin <= topH - 1); /* :143 */
+          if (live) { xmin = imax(0, xmin); xmax = imin(topW - 1, xmax); ymin = imax(0, ymin); ymax = imin(topH - 1, ymax); }
+          for (int n = 0; n < C; ++n) {
+            float sum = 0.f;
+            if (live)
+              for (int o = g.xshift; o < g.xshift + g.ngw; ++o) {                            /* :152 */
+                const int s2o = s2 * o;
+                const long long idx = (((long long)item * H + m) * pW + (l + s2o)) * C + n;  /* :156 / :332 */
+                float coef;
+                if (!sub) coef = flat_at(r1, idx, count);                                    /* :157 */
+                else coef = (flat_at(r0, idx, count) >= flat_at(r1, idx, count)) ? 1.f : -1.f;   /* :333-335 */
+                const size_t off = (size_t)item * topC + (o - g.xshift);                     /* :160-161 */
+                for (int y = ymin; y <= ymax; ++y)
+                  for (int x = xmin; x <= xmax; ++x)
+                    sum = fmaf(top_diff[(off * topH + y) * topW + x], coef, sum);            /* :166 */
+              }
+            bottom0_diff[(size_t)item * bottomcount + ((size_t)n * H + m) * W + xx] = sum / (float)sumelems;   /* :173-175 */
+          }
+        }
+  }
+  if (bottom1_diff) {
+#pragma omp parallel for collapse(3) schedule(static)
+    for (int item = 0; item < N; ++item)
+      for (int m = 0; m < H; ++m)
+        for (int xx = 0; xx < W; ++xx) {
+          const int l = xx + pad;
+          for (int n = 0; n < C; ++n) {
+            float sum = 0.f;
+            for (int o = g.xshift; o < g.xshift + g.ngw; ++o) {                              /* :204 */
+              const int s2o = s2 * o;
+              int xmin = ceil_div_ro(l - 2 * kr - md - s2o, s1);                             /* :210 */
+              int ymin = ceil_div_ro(m - 2 * kr, s1);                                        /* :211 */
+              int xmax = floor_div_ro(l - md - s2o, s1);                                     /* :214 */
+              int ymax = floor_div_ro(m, s1);                                                /* :215 */
+              if (xmax >= 0 && ymax >= 0 && xmin <= topW - 1 && ymin <= topH - 1) {          /* :217 */
+                xmin = imax(0, xmin); xmax = imin(topW - 1, xmax);
+                ymin = imax(0, ymin); ymax = imin(topH - 1, ymax);
+                const long long idx = (((long long)item * H + m) * pW + (l - s2o)) * C + n;  /* :226 / :397 */
+                float coef;
+                if (!sub) coef = flat_at(r0, idx, count);                                    /* :227 */
+                else coef = (flat_at(r0, idx, count) >= flat_at(r1, idx, count)) ? -1.f : 1.f;   /* :398-400 */
+                const size_t off = (size_t)item * topC + (o - g.xshift);
+                for (int y = ymin; y <= ymax; ++y)
+                  for (int x = xmin; x <= xmax; ++x)
+                    sum = fmaf(top_diff[(off * topH + y) * topW + x], coef, sum);            /* :236 */
+              }
+            }
+            bottom1_diff[(size_t)item * bottomcount + ((size_t)n * H + m) * W + xx] = sum / (float)sumelems;   /* :243-245 */
           }
         }
   }

@@ -71,6 +71,23 @@ def correlation(b0, b1, pad, kernel_size, max_displacement, stride1, stride2, co
     return top, d0, d1
 
 
+def correlation1d(b0, b1, pad, kernel_size, max_displacement, stride1, stride2, corr_type=0, single_direction=0, top_diff=None):
+    """Correlation1DLayer of the reference (correlation_layer1d.cpp/.cu); returns top, or (top, b0_diff, b1_diff)."""
+    b0, b1 = _f(b0), _f(b1)
+    N, Cc, H, W = b0.shape
+    shape = (C.c_int * 4)()
+    args = (pad, kernel_size, max_displacement, stride1, stride2, corr_type, single_direction, _p(b0), _p(b1), N, Cc, H, W)
+    _chk(lib().fn2ref_correlation1d(*args, None, shape, None, None, None))
+    top = np.empty(tuple(shape), np.float32)
+    if top_diff is None:
+        _chk(lib().fn2ref_correlation1d(*args, _p(top), shape, None, None, None))
+        return top
+    td = _f(top_diff)
+    d0, d1 = np.empty_like(b0), np.empty_like(b1)
+    _chk(lib().fn2ref_correlation1d(*args, _p(top), shape, _p(td), _p(d0), _p(d1)))
+    return top, d0, d1
+
+
 def flow_warp(image, flow, fill_value=1, warped_diff=None, cpu=False):
     image, flow = _f(image), _f(flow)
     N, Cc, H, W = image.shape

@@ -15,10 +15,10 @@ COMPAT="$HERE/../flownet2_amd/csrc/caffe_adapter/compat"
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fvisibility=hidden -w -I$HERE/ref_compat -I$COMPAT -I$HERE/stubs -I$REF/include -I$REF/src -DFN2_REF_INC=$REF/include -fopenmp"
-# the five custom layers, then L1LossLayer and the stock layers it is composed from (l1loss_layer.cpp:19-62), plus the stock
+# the five custom layers (+ Correlation1D, the horizontal variant), then L1LossLayer and the stock layers it is composed from (l1loss_layer.cpp:19-62), plus the stock
 # Deconvolution and ReLU layers (pins of the stock-layer fast paths: stem, flow heads, GEMM route, bias + ReLU); cuBLAS/CBLAS
 # are replaced by the plain stand-ins of oracle/ref_compat/caffe/util/math_functions.hpp
-LAYERS="correlation_layer flow_warp_layer resample_layer channel_norm_layer downsample_layer l1loss_layer eltwise_layer power_layer conv_layer deconv_layer relu_layer"
+LAYERS="correlation_layer correlation_layer1d flow_warp_layer resample_layer channel_norm_layer downsample_layer l1loss_layer eltwise_layer power_layer conv_layer deconv_layer relu_layer"
 EXTRA="layers/base_conv_layer.cpp layers/loss_layer.cpp layers/neuron_layer.cpp util/im2col.cpp util/im2col.cu"
 # newest stand-in header: an object older than it is rebuilt (the stand-ins define Blob / Layer layouts)
 NEWEST_HDR=$(find "$COMPAT" "$HERE/ref_compat" "$HERE/stubs" -type f -printf '%T@ %p\n' | sort -n | tail -1 | cut -d' ' -f2-)

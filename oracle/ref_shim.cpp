@@ -56,6 +56,37 @@ int fn2ref_correlation(int pad, int kernel_size, int max_displacement, int strid
   });
 }
 
+extern "C" __attribute__((visibility("default")))
+int fn2ref_correlation1d(int pad, int kernel_size, int max_displacement, int stride1, int stride2, int corr_type, int single_direction,
+                         const float* b0, const float* b1, int N, int C, int H, int W,
+                         float* top_out, int* top_shape /* [4] */,
+                         const float* top_diff /* nullable */, float* b0_diff, float* b1_diff) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("Correlation1D");
+    CorrelationParameter* cp = lp.mutable_correlation_param();
+    cp->set_pad(pad); cp->set_kernel_size(kernel_size); cp->set_max_displacement(max_displacement);
+    cp->set_stride_1(stride1); cp->set_stride_2(stride2); cp->set_single_direction(single_direction);
+    cp->set_correlation_type(corr_type ? CorrelationParameter_CorrelationType_SUBTRACT : CorrelationParameter_CorrelationType_MULTIPLY);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot0(N, C, H, W), bot1(N, C, H, W), top;
+    fill(bot0, b0); fill(bot1, b1);
+    vector<Blob<float>*> bottom{&bot0, &bot1}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    CUDA_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 4; ++i) top_shape[i] = top.shape(i);
+    if (top_out) fetch(top, top_out);
+    if (top_diff) {
+      fill_diff(top, top_diff);
+      layer->Backward(tops, vector<bool>{true, true}, bottom);
+      CUDA_CHECK(hipDeviceSynchronize());
+      fetch_diff(bot0, b0_diff); fetch_diff(bot1, b1_diff);
+    }
+  });
+}
+
 // mode: 0 = GPU kernels (flow_warp_layer.cu), 1 = the reference's CPU implementation (flow_warp_layer.cpp:58-199)
 extern "C" __attribute__((visibility("default")))
 int fn2ref_flow_warp(int mode, int fill_value, const float* image, const float* flow, int N, int C, int H, int W,

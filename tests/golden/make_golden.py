@@ -2,7 +2,8 @@
 """Generates tests/golden/ref_golden.npz: outputs of the REFERENCE's own layer code (oracle/_ref, the
 reference's CUDA kernels built as HIP by oracle/ref_build.sh and executed on an MI355X) on small seeded inputs.
 Run on the GPU box:   python tests/golden/make_golden.py gpurun_out/ref_golden.npz
-then copy the file to tests/golden/.  tests/test_golden.py pins the C oracle (and, on the GPU, the HIP kernels)
+then copy the file to tests/golden/.  `--only corr1d --base tests/golden/ref_golden.npz` generates one section and keeps the
+other arrays of an existing file (sections: main, corr1d, corr1d_left).  tests/test_golden.py pins the C oracle (and, on the GPU, the HIP kernels)
 against it; it needs neither the reference tree nor oracle/_ref."""
 import os
 import sys
@@ -17,6 +18,17 @@ CORR = [  # (N, C, H, W, pad, K, md, s1, s2, type)
     (1, 16, 13, 17, 20, 1, 20, 1, 2, 0), (2, 5, 9, 11, 4, 1, 4, 1, 2, 0), (1, 7, 8, 10, 3, 3, 2, 2, 1, 0),
     (1, 33, 6, 7, 2, 1, 2, 1, 1, 0), (1, 4, 10, 9, 5, 3, 4, 1, 2, 1), (1, 32, 12, 20, 4, 1, 4, 1, 1, 0),
 ]
+# Correlation1D: (N, C, H, W, pad, K, md, s1, s2, type, single_direction)
+CORR1D = [
+    (2, 5, 7, 19, 4, 1, 4, 1, 2, 0, 0), (1, 7, 9, 14, 3, 3, 2, 2, 1, 0, 1), (1, 4, 8, 15, 5, 3, 4, 1, 2, 1, 0),
+    (1, 33, 5, 30, 8, 1, 8, 1, 1, 0, 1), (2, 3, 6, 9, 0, 1, 2, 1, 1, 0, 0), (1, 6, 6, 13, 3, 1, 3, 1, 1, 1, 1),
+]
+# single_direction = -1: the reference reads up to s2 pixels in FRONT of its scratch blob for the first row of the first sample
+# (undefined memory; corr1d_undefined_mask() marks the outputs that depend on it).  Generated as a section of its own.
+CORR1D_LEFT = [
+    (2, 16, 5, 24, 10, 1, 10, 1, 1, 0, -1), (2, 33, 4, 12, 6, 1, 6, 1, 2, 0, -1), (2, 3, 5, 11, 0, 1, 3, 1, 2, 0, -1),
+    (2, 6, 6, 13, 3, 1, 3, 1, 1, 1, -1),
+]
 RESAMPLE = [((6, 8), (24, 32)), ((16, 20), (8, 10)), ((9, 12), (9, 12)), ((12, 16), (7, 9)), ((12, 14), (48, 56))]
 DOWN = [((16, 24), (4, 6)), ((17, 23), (5, 7)), ((40, 56), (10, 14))]
 # L1Loss: (shape, two bottoms, l2_per_location, l2_prescale_by_channels, normalize_by_num_entries, epsilon, plateau, NaNs in bottom[1], loss_weight)
@@ -24,6 +36,31 @@ L1 = [((2, 2, 9, 11), True, True, False, True, 1e-2, 0.0, True, 0.32), ((2, 2, 9
       ((1, 3, 6, 7), True, False, False, True, 1e-2, 0.0, True, 0.5), ((1, 3, 6, 7), True, False, False, False, 1e-2, 0.0, False, 1.0),
       ((2, 2, 9, 11), True, True, False, True, 1e-2, 0.8, True, 1.0), ((2, 2, 5, 7), False, True, False, True, 1e-2, 0.0, False, 1.0),
       ((1, 4, 8, 8), False, False, False, True, 1e-2, 0.0, False, 0.25), ((2, 2, 20, 28), True, True, False, True, 1e-2, 0.0, True, 0.02)]
+
+
+def corr1d_inputs(i, left=False):
+    N, C, H, W, pad, K, md, s1, s2, t, sd = (CORR1D_LEFT if left else CORR1D)[i]
+    base = 1300 if left else 1100
+    return rnd((N, C, H, W), base + i), rnd((N, C, H, W), base + 50 + i), (pad, K, md, s1, s2, t, sd)
+
+
+def corr1d_undefined_mask(case, top_shape):
+    """(top mask, bottom0-diff mask) of elements for which the reference reads in front of its scratch blob
+    (sample 0, row 0, padded column < 0; correlation_layer1d.cu:89 / :156 with x_shift = -grid_width)."""
+    N, C, H, W, pad, K, md, s1, s2, t, sd = case
+    ngr = md // s2
+    ngw = ngr + 1 if sd != 0 else 2 * ngr + 1
+    xshift = -ngw if sd == -1 else (0 if sd == 1 else -ngr)
+    mt = np.zeros(top_shape, bool)
+    for c in range(top_shape[1]):
+        for x in range(top_shape[3]):
+            if x * s1 + md + (c + xshift) * s2 < 0:
+                mt[0, c, 0, x] = True
+    m0 = np.zeros((N, C, H, W), bool)
+    for x in range(W):
+        if x + pad + xshift * s2 < 0:
+            m0[0, :, 0, x] = True
+    return mt, m0
 
 
 def stock_inputs(which):
@@ -52,8 +89,32 @@ def rnd(shape, seed, scale=1.0):
     return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
 
 
-def main(out):
+def corr1d_section(g, left):
+    cases = CORR1D_LEFT if left else CORR1D
+    tag = "corr1dL" if left else "corr1d"
+    for i in range(len(cases)):
+        b0, b1, (pad, K, md, s1, s2, t, sd) = corr1d_inputs(i, left)
+        top = ref.correlation1d(b0, b1, pad, K, md, s1, s2, t, sd)
+        td = rnd(top.shape, (1400 if left else 1200) + i)
+        _, d0, d1 = ref.correlation1d(b0, b1, pad, K, md, s1, s2, t, sd, td)
+        g[f"{tag}{i}_top"], g[f"{tag}{i}_d0"], g[f"{tag}{i}_d1"] = top, d0, d1
+
+
+def main(out, only=None, base=None):
     g = {}
+    if base:
+        g.update(np.load(base))
+    if only in (None, "corr1d"):
+        corr1d_section(g, False)
+    if only == "corr1d_left":
+        corr1d_section(g, True)
+    if only in (None, "main"):
+        main_section(g)
+    np.savez_compressed(out, **g)
+    print("wrote", out, "arrays:", len(g), "bytes:", os.path.getsize(out))
+
+
+def main_section(g):
     for i, (N, C, H, W, pad, K, md, s1, s2, t) in enumerate(CORR):
         b0, b1 = rnd((N, C, H, W), 100 + i), rnd((N, C, H, W), 200 + i)
         top = ref.correlation(b0, b1, pad, K, md, s1, s2, t)
@@ -102,9 +163,13 @@ def main(out):
     x, w, b = stock_inputs("conv3x3")
     g["stock_conv3x3s2_relu"] = ref.convolution(x, w, b, kernel=3, stride=2, pad=1, relu=True)
     g["stock_conv3x3s2_nobias"] = ref.convolution(x, w, None, kernel=3, stride=2, pad=1)
-    np.savez_compressed(out, **g)
-    print("wrote", out, "arrays:", len(g), "bytes:", os.path.getsize(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(__file__), "ref_golden.npz"))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out", nargs="?", default=os.path.join(os.path.dirname(__file__), "ref_golden.npz"))
+    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left"], default=None)
+    ap.add_argument("--base", default=None, help="existing .npz whose arrays are kept")
+    a = ap.parse_args()
+    main(a.out, a.only, a.base)

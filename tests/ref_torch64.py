@@ -42,6 +42,34 @@ def correlation(b0: torch.Tensor, b1: torch.Tensor, pad, K, md, s1, s2, subtract
     return torch.stack(outs, 1)
 
 
+def correlation1d(b0: torch.Tensor, b1: torch.Tensor, pad, K, md, s1, s2, single_direction=0, subtract=False) -> torch.Tensor:
+    """Horizontal cost volume: top[n,c,y,x] = 1/(K*K*C) * sum_{j,i,ch} P0[n,ch,y*s1+j,x1+i] (*|-) P1[n,ch,y*s1+j,x1+i+(c+x_shift)*s2],
+    x1 = x*s1 + md in x-PADDED coordinates (padding in x only); x_shift = -md//s2 (both), 0 (right), -(md//s2 + 1) (left).
+    Positions outside the padded row count as zeros (what the reference's flat indexing reads whenever pad >= the overshoot)."""
+    N, C, H, W = b0.shape
+    kr = (K - 1) // 2
+    ngr = md // s2
+    ngw = ngr + 1 if single_direction != 0 else 2 * ngr + 1
+    xshift = -ngw if single_direction == -1 else (0 if single_direction == 1 else -ngr)
+    topW = math.ceil((W + 2 * pad - 2 * (md + kr)) / s1)
+    topH = math.ceil((H - 2 * kr) / s1)
+    extra = max(0, -(md + xshift * s2))          # left mode starts one grid step beyond the radius
+    P0 = F.pad(b0, (pad + extra, pad, 0, 0))
+    P1 = F.pad(b1, (pad + extra, pad, 0, 0))
+    outs = []
+    for c in range(ngw):
+        d = (c + xshift) * s2
+        acc = 0
+        for j in range(K):
+            for i in range(K):
+                xs = md + i + extra
+                a = P0[:, :, j: j + (topH - 1) * s1 + 1: s1, xs: xs + (topW - 1) * s1 + 1: s1]
+                b = P1[:, :, j: j + (topH - 1) * s1 + 1: s1, xs + d: xs + d + (topW - 1) * s1 + 1: s1]
+                acc = acc + ((a - b).abs().sum(1) if subtract else (a * b).sum(1))
+        outs.append(acc / (K * K * C))
+    return torch.stack(outs, 1)
+
+
 def flow_warp(image: torch.Tensor, flow: torch.Tensor, fill=0.0) -> torch.Tensor:
     """Appendix A.3: bilinear sample at (x+u, y+v), right/bottom neighbour clamped, fill outside."""
     N, C, H, W = image.shape

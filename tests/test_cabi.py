@@ -51,6 +51,25 @@ def test_shape_function_matches_reference_reshape_and_rejects_bad_params():
             oracle.correlation_out_shape(oracle.corr_params(pad, K, md, s1, s2), C, H, W)
 
 
+def test_correlation1d_shape_function_matches_reference_reshape():
+    import oracle
+    # DispNetCorr1D parameters: correlation_layer1d.cpp:55-78 with K=1, md=40, pad=40, s1=1, s2=1, left only
+    assert ops.correlation1d_out_shape(ops.corr_params(40, 1, 40, 1, 1, single_direction=-1), 256, 48, 96) == (41, 48, 96)
+    assert ops.correlation1d_out_shape(ops.corr_params(40, 1, 40, 1, 1), 256, 48, 96) == (81, 48, 96)
+    assert ops.correlation1d_out_shape(ops.corr_params(3, 3, 2, 2, 1, single_direction=1), 7, 9, 14) == (3, 4, 7)   # no padding in y
+    for bad in [ops.corr_params(4, 2, 4, 1, 1), ops.corr_params(4, 1, 4, 1, 1, single_direction=2), ops.corr_params(0, 1, 0, 0, 1),
+                ops.corr_params(0, 1, 4, 1, 1)]:
+        with pytest.raises(flownet2_amd.Fn2Error):
+            ops.correlation1d_out_shape(bad, 3, 8, 8)
+    for args in [(40, 1, 40, 1, 1, -1, 8, 6, 30), (3, 3, 2, 2, 1, 1, 7, 9, 14), (5, 3, 4, 1, 2, 0, 4, 8, 15), (0, 1, 2, 1, 1, 0, 3, 6, 9)]:
+        pad, K, md, s1, s2, sd, C, H, W = args
+        assert ops.correlation1d_out_shape(ops.corr_params(pad, K, md, s1, s2, single_direction=sd), C, H, W) == \
+            oracle.correlation1d_out_shape(oracle.corr_params(pad, K, md, s1, s2, 0, 0, sd), C, H, W)
+    x = torch.zeros(1, 3, 4, 4)
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.correlation1d_forward(ops.corr_params(1, 1, 1, 1, 1), x, x)
+
+
 def test_ops_refuse_cpu_tensors_no_fallback():
     x = torch.zeros(1, 3, 4, 4)
     with pytest.raises(ValueError, match="no CPU path"):
@@ -60,7 +79,7 @@ def test_ops_refuse_cpu_tensors_no_fallback():
 
 
 def test_layer_registry_and_blob_count_checks():
-    assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Correlation", "Downsample", "FlowWarp", "L1Loss", "Resample"]
+    assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Correlation", "Correlation1D", "Downsample", "FlowWarp", "L1Loss", "Resample"]
     with pytest.raises(CheckError, match="Unknown layer type"):
         LayerRegistry.CreateLayer(LayerParameter(type="Nope"))
     with pytest.raises(CheckError, match="already registered"):

@@ -1,7 +1,7 @@
 """The C++ Caffe adapter (flownet2_amd/csrc/caffe_adapter/fn2_caffe_layers.cpp), compiled against the stand-in
 Caffe headers and driven through LayerRegistry<float>::CreateLayer by prototxt type string -- the same way, through
 the same C shim, as the reference's own layer classes in oracle/_ref.  Checks: the plug-in builds, registers the
-six type strings, enforces the reference's CHECKs, and computes what the oracle (and the reference) computes."""
+seven type strings, enforces the reference's CHECKs, and computes what the oracle (and the reference) computes."""
 import os
 import subprocess
 
@@ -22,7 +22,7 @@ def test_adapter_builds_and_exports_layer_driver():
     subprocess.check_call(["bash", os.path.join(ROOT, "flownet2_amd", "csrc", "caffe_adapter", "build_adapter.sh")], stdout=subprocess.DEVNULL)
     assert ref.adapter_available()
     out = subprocess.check_output(["nm", "-D", ref.ADAPTER_SO]).decode()
-    for sym in ("fn2ref_correlation", "fn2ref_flow_warp", "fn2ref_resample", "fn2ref_channel_norm", "fn2ref_downsample", "fn2ref_l1loss"):
+    for sym in ("fn2ref_correlation", "fn2ref_correlation1d", "fn2ref_flow_warp", "fn2ref_resample", "fn2ref_channel_norm", "fn2ref_downsample", "fn2ref_l1loss"):
         assert sym in out
     # the adapter must call INTO libflownet2_hip.so (undefined symbols resolved at load time), not re-implement it
     assert " U fn2_correlation_forward" in out and " U fn2_flow_warp_backward" in out
@@ -48,6 +48,16 @@ def test_adapter_layers_match_oracle(adapter):
     o0, o1 = oracle.correlation_backward(po, b0, b1, td)
     np.testing.assert_allclose(d0, o0, rtol=0, atol=3e-6)
     np.testing.assert_allclose(d1, o1, rtol=0, atol=3e-6)
+    # Correlation1D, DispNetCorr1D-style (left only) and both directions
+    for sd in (-1, 0):
+        top = adapter.correlation1d(b0, b1, 8, 1, 8, 1, 1, 0, sd)
+        td = rnd(top.shape, 30)
+        _, d0, d1 = adapter.correlation1d(b0, b1, 8, 1, 8, 1, 1, 0, sd, td)
+        po = oracle.corr_params(8, 1, 8, 1, 1, 0, 0, sd)
+        np.testing.assert_allclose(top, oracle.correlation1d_forward(po, b0, b1), rtol=0, atol=2e-6)
+        o0, o1 = oracle.correlation1d_backward(po, b0, b1, td)
+        np.testing.assert_allclose(d0, o0, rtol=0, atol=3e-6)
+        np.testing.assert_allclose(d1, o1, rtol=0, atol=3e-6)
     img, flow, g = rnd((2, 3, 24, 40), 4), rnd((2, 2, 24, 40), 5, 5.0), rnd((2, 3, 24, 40), 6)
     out, di, df = adapter.flow_warp(img, flow, 1, g)
     np.testing.assert_allclose(out, oracle.flow_warp_forward(img, flow), rtol=0, atol=1e-6)
@@ -76,6 +86,8 @@ def test_adapter_enforces_reference_checks(adapter):
         adapter.correlation(b, b, 4, 2, 4, 1, 1)
     with pytest.raises(RuntimeError, match="pad .* < max_displacement"):     # C-ABI error surfaces as LOG(FATAL)
         adapter.correlation(b, b, 1, 1, 4, 1, 1)
+    with pytest.raises(RuntimeError, match="single_direction must be"):
+        adapter.correlation1d(b, b, 4, 1, 4, 1, 1, 0, 2)
     with pytest.raises(RuntimeError, match="only CUBIC, LINEAR and NEAREST"):
         adapter.resample(b, 4, 4, 4, True)
 

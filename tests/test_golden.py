@@ -48,6 +48,57 @@ def test_oracle_correlation_matches_reference_kernels(gold, i):
     close(d1, gold[f"corr{i}_d1"], 2e-6)
 
 
+def _corr1d_cases():
+    return [(False, i) for i in range(len(MG.CORR1D))] + [(True, i) for i in range(len(MG.CORR1D_LEFT))]
+
+
+def _corr1d_check(gold, left, i, fwd, bwd, tol):
+    """fwd / bwd are callables (params tuple, b0, b1[, td]) -> numpy; compared with the reference kernels' outputs outside
+    the elements for which the reference reads in front of its scratch blob (left mode, sample 0, row 0)."""
+    tag = f"corr1dL{i}" if left else f"corr1d{i}"
+    if f"{tag}_top" not in gold:
+        pytest.skip("golden arrays for this Correlation1D case not generated")
+    case = (MG.CORR1D_LEFT if left else MG.CORR1D)[i]
+    b0, b1, prm = MG.corr1d_inputs(i, left)
+    want = gold[f"{tag}_top"]
+    mt, m0 = MG.corr1d_undefined_mask(case, want.shape)
+    assert mt.any() == (left and True)
+    top = fwd(prm, b0, b1)
+    close(np.where(mt, 0, top), np.where(mt, 0, want), tol)
+    td = MG.rnd(want.shape, (1400 if left else 1200) + i)
+    d0, d1 = bwd(prm, b0, b1, td)
+    close(np.where(m0, 0, d0), np.where(m0, 0, gold[f"{tag}_d0"]), 2 * tol)
+    close(d1, gold[f"{tag}_d1"], 2 * tol)
+
+
+@pytest.mark.parametrize("left,i", _corr1d_cases())
+def test_oracle_correlation1d_matches_reference_kernels(gold, left, i):
+    def P(prm):
+        pad, K, md, s1, s2, t, sd = prm
+        return oracle.corr_params(pad, K, md, s1, s2, t, 0, sd)
+    _corr1d_check(gold, left, i, lambda prm, a, b: oracle.correlation1d_forward(P(prm), a, b),
+                  lambda prm, a, b, td: oracle.correlation1d_backward(P(prm), a, b, td), 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("left,i", _corr1d_cases())
+def test_hip_correlation1d_matches_reference_kernels(gold, left, i):
+    import torch
+    from flownet2_amd import ops
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+    def P(prm):
+        pad, K, md, s1, s2, t, sd = prm
+        return ops.corr_params(pad, K, md, s1, s2, t, False, sd)
+
+    def bwd(prm, a, b, td):
+        d0, d1 = ops.correlation1d_backward(P(prm), dev(a), dev(b), dev(td))
+        return d0.cpu().numpy(), d1.cpu().numpy()
+    _corr1d_check(gold, left, i, lambda prm, a, b: ops.correlation1d_forward(P(prm), dev(a), dev(b)).cpu().numpy(), bwd, 2e-6)
+
+
 def test_oracle_flow_warp_matches_reference_gpu_and_cpu_code(gold):
     img, flow, wd = MG.rnd((2, 3, 13, 17), 400), MG.rnd((2, 2, 13, 17), 401, 4.0), MG.rnd((2, 3, 13, 17), 402)
     flow[0, :, 0, 0] = 0

@@ -96,6 +96,78 @@ def test_correlation_backward(case, ctype):
     assert_close(host(d1), r1, 3e-6, "correlation backward bottom1")
 
 
+CORR1D_CASES = [
+    # (N, C, H, W, pad, K, md, s1, s2, single_direction)
+    (2, 5, 7, 19, 4, 1, 4, 1, 2, 0),
+    (1, 7, 9, 14, 3, 3, 2, 2, 1, 1),
+    (2, 16, 5, 24, 10, 1, 10, 1, 1, -1),    # DispNetCorr1D-like: left only
+    (2, 33, 4, 12, 6, 1, 6, 1, 2, -1),      # left, stride_2 2: the overshoot lands in the zero padding
+    (2, 3, 5, 11, 0, 1, 3, 1, 2, -1),       # left without padding: the overshoot lands on DATA of the previous row / sample
+    (1, 4, 8, 15, 5, 3, 4, 1, 2, 0),
+    (2, 3, 6, 9, 0, 1, 2, 1, 1, 0),         # no padding: top narrower than bottom
+    (1, 64, 24, 96, 40, 1, 40, 1, 1, -1),   # DispNetCorr1D parameters (md 40, left) on a conv3-sized map
+]
+
+
+@pytest.mark.parametrize("case", CORR1D_CASES)
+@pytest.mark.parametrize("ctype", [oracle.MULTIPLY, oracle.SUBTRACT])
+def test_correlation1d_forward_backward(case, ctype):
+    N, C, H, W, pad, K, md, s1, s2, sd = case
+    b0, b1 = rand((N, C, H, W), 41), rand((N, C, H, W), 42)
+    po = oracle.corr_params(pad, K, md, s1, s2, ctype, 0, sd)
+    p = ops.corr_params(pad, K, md, s1, s2, ctype, False, sd)
+    shape = oracle.correlation1d_out_shape(po, C, H, W)
+    assert ops.correlation1d_out_shape(p, C, H, W) == shape
+    top = ops.correlation1d_forward(p, dev(b0), dev(b1))
+    assert_close(host(top), oracle.correlation1d_forward(po, b0, b1), 2e-6, "correlation1d forward")
+    g = rand((N,) + shape, 43)
+    r0, r1 = oracle.correlation1d_backward(po, b0, b1, g)
+    d0, d1 = ops.correlation1d_backward(p, dev(b0), dev(b1), dev(g))
+    assert_close(host(d0), r0, 3e-6, "correlation1d backward bottom0")
+    assert_close(host(d1), r1, 3e-6, "correlation1d backward bottom1")
+    only1 = ops.correlation1d_backward(p, dev(b0), dev(b1), dev(g), need0=False)
+    assert only1[0] is None and torch.equal(only1[1], d1)
+
+
+def test_correlation1d_layer_api_and_errors():
+    N, C, H, W = 2, 8, 6, 30
+    b0, b1 = rand((N, C, H, W), 44), rand((N, C, H, W), 45)
+    lp = LayerParameter(name="corr1d", type="Correlation1D",
+                        correlation_param=dict(pad=8, kernel_size=1, max_displacement=8, stride_1=1, stride_2=1, single_direction=-1))
+    layer = LayerRegistry.CreateLayer(lp)
+    bottom = [Blob.from_tensor(dev(b0)), Blob.from_tensor(dev(b1))]
+    top = [Blob()]
+    layer.SetUp(bottom, top)
+    assert top[0].shape() == [N, 9, H, W]
+    layer.Forward(bottom, top)
+    po = oracle.corr_params(8, 1, 8, 1, 1, oracle.MULTIPLY, 0, -1)
+    assert_close(top[0].cpu_data(), oracle.correlation1d_forward(po, b0, b1), 2e-6)
+    g = rand((N, 9, H, W), 46)
+    top[0].mutable_gpu_diff().copy_(dev(g))
+    layer.Backward(top, [True, True], bottom)
+    r0, r1 = oracle.correlation1d_backward(po, b0, b1, g)
+    assert_close(bottom[0].cpu_diff(), r0, 3e-6)
+    assert_close(bottom[1].cpu_diff(), r1, 3e-6)
+    for bad in [dict(pad=8, kernel_size=2, max_displacement=8), dict(pad=8, kernel_size=1, max_displacement=8, single_direction=2),
+                dict(pad=0, kernel_size=1, max_displacement=20), dict(pad=8, max_displacement=8)]:
+        with pytest.raises(layers.CheckError):
+            LayerRegistry.CreateLayer(LayerParameter(name="x", type="Correlation1D", correlation_param=bad)).SetUp(bottom, [Blob()])
+    z = torch.zeros((0, 4, 5, 9), device="cuda")
+    assert ops.correlation1d_forward(ops.corr_params(2, 1, 2, 1, 1), z, z).shape == (0, 5, 5, 9)
+
+
+def test_correlation1d_centre_channel_is_the_row_of_the_2d_cost_volume():
+    """With both directions the 1-D layer is the zero-vertical-displacement row of the 2-D layer (same parameters)."""
+    N, C, H, W, md, s2 = 2, 32, 12, 40, 8, 2
+    a, b = dev(rand((N, C, H, W), 47)), dev(rand((N, C, H, W), 48))
+    top1 = ops.correlation1d_forward(ops.corr_params(md, 1, md, 1, s2), a, b)
+    top2 = ops.correlation_forward(ops.corr_params(md, 1, md, 1, s2), a, b)
+    ngw = 2 * (md // s2) + 1
+    row = top2[:, (ngw // 2) * ngw:(ngw // 2 + 1) * ngw]
+    assert top1.shape == row.shape
+    assert float((top1 - row).abs().max()) <= 2e-6 * float(row.abs().max())
+
+
 def test_correlation_layer_api_forward_backward():
     """Through the Layer mirror, the way Net::ForwardFromTo / BackwardFromTo drive the reference layer."""
     N, C, H, W = 2, 8, 12, 14

@@ -103,6 +103,100 @@ def test_correlation_self_peak_and_shape_errors():
         oracle.correlation_out_shape(oracle.corr_params(0, 1, 0, 0, 1), 3, 8, 8)     # stride 0
 
 
+CORR1D_CASES = [
+    # (N, C, H, W, pad, K, md, s1, s2, single_direction)
+    (2, 5, 7, 19, 4, 1, 4, 1, 2, 0),
+    (1, 7, 9, 14, 3, 3, 2, 2, 1, 1),
+    (1, 16, 5, 24, 10, 1, 10, 1, 1, -1),   # DispNetCorr1D-like: left only
+    (1, 33, 4, 12, 6, 1, 6, 1, 2, -1),     # left, stride_2 2: overshoot of 2 columns lands in the zero padding
+    (1, 4, 8, 15, 5, 3, 4, 1, 2, 0),
+    (2, 3, 6, 9, 0, 1, 2, 1, 1, 0),        # no padding at all: top narrower than bottom
+]
+
+
+@pytest.mark.parametrize("case", CORR1D_CASES)
+@pytest.mark.parametrize("ctype", [oracle.MULTIPLY, oracle.SUBTRACT])
+def test_correlation1d_forward_vs_fp64(case, ctype):
+    N, C, H, W, pad, K, md, s1, s2, sd = case
+    b0, b1 = _rand((N, C, H, W), 21), _rand((N, C, H, W), 22)
+    p = oracle.corr_params(pad, K, md, s1, s2, ctype, 0, sd)
+    top = oracle.correlation1d_forward(p, b0, b1)
+    ref = R.correlation1d(torch.from_numpy(b0).double(), torch.from_numpy(b1).double(), pad, K, md, s1, s2, sd,
+                          subtract=(ctype == oracle.SUBTRACT)).numpy()
+    assert top.shape == ref.shape == (N,) + oracle.correlation1d_out_shape(p, C, H, W)
+    np.testing.assert_allclose(top, ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CORR1D_CASES)
+def test_correlation1d_backward_is_gradient(case):
+    N, C, H, W, pad, K, md, s1, s2, sd = case
+    b0, b1 = _rand((N, C, H, W), 23), _rand((N, C, H, W), 24)
+    p = oracle.corr_params(pad, K, md, s1, s2, oracle.MULTIPLY, 0, sd)
+    g = _rand((N,) + oracle.correlation1d_out_shape(p, C, H, W), 25)
+    d0, d1 = oracle.correlation1d_backward(p, b0, b1, g)
+    t0 = torch.from_numpy(b0).double().requires_grad_()
+    t1 = torch.from_numpy(b1).double().requires_grad_()
+    R.correlation1d(t0, t1, pad, K, md, s1, s2, sd).backward(torch.from_numpy(g).double())
+    np.testing.assert_allclose(d0, t0.grad.numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(d1, t1.grad.numpy(), rtol=0, atol=5e-6)
+
+
+def _flat_padded(b, pad):
+    """The reference's scratch blob [N, H, W+2p, C] as one flat array of pixels (correlation_layer1d.cu:25-44)."""
+    return np.pad(b, ((0, 0), (0, 0), (0, 0), (pad, pad))).transpose(0, 2, 3, 1).reshape(-1, b.shape[1]).astype(np.float64)
+
+
+def test_correlation1d_left_mode_wraps_into_the_previous_row_like_the_flat_blob():
+    """single_direction = -1 with pad < overshoot: the reference's flat index lands on DATA of the previous row
+    (correlation_layer1d.cu:89 with x_shift = -grid_width, :467-468); positions in front of the blob read as 0."""
+    N, C, H, W, pad, K, md, s1, s2 = 2, 3, 5, 11, 0, 1, 3, 1, 2
+    b0, b1 = _rand((N, C, H, W), 26), _rand((N, C, H, W), 27)
+    p = oracle.corr_params(pad, K, md, s1, s2, oracle.MULTIPLY, 0, -1)
+    tc, th, tw = oracle.correlation1d_out_shape(p, C, H, W)
+    assert (tc, th, tw) == (2, 5, 5)
+    top = oracle.correlation1d_forward(p, b0, b1)
+    pW = W + 2 * pad
+    F0, F1 = _flat_padded(b0, pad), _flat_padded(b1, pad)
+    exp = np.zeros((N, tc, th, tw))
+    wrapped = 0
+    for n in range(N):
+        for c in range(tc):
+            for y in range(th):
+                for x in range(tw):
+                    fa = (n * H + y) * pW + x + md
+                    fb = fa + (c - tc) * s2
+                    wrapped += (x + md + (c - tc) * s2) < 0
+                    exp[n, c, y, x] = (F0[fa] * (F1[fb] if fb >= 0 else 0.0)).sum() / C
+    assert wrapped > 0
+    np.testing.assert_allclose(top, exp, rtol=0, atol=2e-6)
+    assert np.abs(top[1, 0, 0, 0]) > 0          # first row of sample 1 reads the last row of sample 0
+    # backward of bottom0 reads bottom1 through the same flat index (:156)
+    g = _rand((N, tc, th, tw), 28)
+    d0, d1 = oracle.correlation1d_backward(p, b0, b1, g)
+    e0 = np.zeros((N, C, H, W))
+    for n in range(N):
+        for y in range(H):
+            for x in range(W):
+                l = x + pad
+                xt = l - md                       # K = 1, s1 = 1: the one top column whose patch covers l
+                if 0 <= xt < tw:
+                    for c in range(tc):
+                        f = (n * H + y) * pW + l + (c - tc) * s2
+                        e0[n, :, y, x] += g[n, c, y, xt] * (F1[f] if f >= 0 else 0.0)
+    np.testing.assert_allclose(d0, e0 / C, rtol=0, atol=5e-6)
+
+
+def test_correlation1d_shape_errors():
+    with pytest.raises(ValueError):
+        oracle.correlation1d_out_shape(oracle.corr_params(4, 2, 4, 1, 1), 3, 8, 8)                 # even kernel
+    with pytest.raises(ValueError):
+        oracle.correlation1d_out_shape(oracle.corr_params(4, 1, 4, 1, 1, 0, 0, 2), 3, 8, 8)        # single_direction out of range
+    with pytest.raises(ValueError):
+        oracle.correlation1d_out_shape(oracle.corr_params(0, 1, 4, 1, 1), 3, 8, 8)                 # neighbourhood does not fit
+    assert oracle.correlation1d_out_shape(oracle.corr_params(40, 1, 40, 1, 1, 0, 0, -1), 8, 6, 30) == (41, 6, 30)
+    assert oracle.correlation1d_out_shape(oracle.corr_params(40, 1, 40, 1, 1), 8, 6, 30) == (81, 6, 30)
+
+
 def test_flow_warp_forward_vs_fp64_and_identity():
     N, C, H, W = 2, 3, 13, 17
     img = _rand((N, C, H, W), 10)

@@ -60,6 +60,30 @@ def test_reference_gpu_correlation_equals_oracle_and_hip(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 32, 12, 48, 16, 1, 16, 1, 1, 0, 1), (1, 64, 8, 40, 20, 1, 20, 1, 2, 0, 0),
+                                  (1, 8, 11, 21, 4, 3, 2, 1, 2, 1, 0), (1, 12, 10, 25, 6, 1, 6, 2, 3, 0, 1)])
+def test_reference_gpu_correlation1d_equals_oracle_and_hip(case):
+    import torch
+    from flownet2_amd import ops
+    N, C, H, W, pad, K, md, s1, s2, t, sd = case
+    b0, b1 = rnd((N, C, H, W), 16), rnd((N, C, H, W), 17)
+    top = ref.correlation1d(b0, b1, pad, K, md, s1, s2, t, sd)
+    td = rnd(top.shape, 18)
+    _, d0, d1 = ref.correlation1d(b0, b1, pad, K, md, s1, s2, t, sd, td)
+    po = oracle.corr_params(pad, K, md, s1, s2, t, 0, sd)
+    np.testing.assert_allclose(oracle.correlation1d_forward(po, b0, b1), top, rtol=0, atol=2e-6)
+    o0, o1 = oracle.correlation1d_backward(po, b0, b1, td)
+    np.testing.assert_allclose(o0, d0, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(o1, d1, rtol=0, atol=3e-6)
+    p = ops.corr_params(pad, K, md, s1, s2, t, False, sd)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    np.testing.assert_allclose(ops.correlation1d_forward(p, dv(b0), dv(b1)).cpu().numpy(), top, rtol=0, atol=2e-6)
+    h0, h1 = ops.correlation1d_backward(p, dv(b0), dv(b1), dv(td))
+    np.testing.assert_allclose(h0.cpu().numpy(), d0, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(h1.cpu().numpy(), d1, rtol=0, atol=3e-6)
+
+
+@pytest.mark.gpu
 def test_reference_gpu_warp_resample_downsample_equal_oracle():
     img, flow, g = rnd((2, 16, 24, 40), 9), rnd((2, 2, 24, 40), 10, 6.0), rnd((2, 16, 24, 40), 11)
     out, di, df = ref.flow_warp(img, flow, 1, g)
