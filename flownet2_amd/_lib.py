@@ -24,6 +24,8 @@ EXPORTS = [
     "fn2_bias_leaky_relu_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
+    "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
+    "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_decode_forward",
 ]
 
 
@@ -39,6 +41,11 @@ class CorrParams(C.Structure):
     _fields_ = [("pad", C.c_int), ("kernel_size", C.c_int), ("max_displacement", C.c_int),
                 ("stride1", C.c_int), ("stride2", C.c_int), ("corr_type", C.c_int), ("do_abs", C.c_int),
                 ("single_direction", C.c_int)]
+
+
+class DatumView(C.Structure):
+    _fields_ = [("channels", C.c_int), ("height", C.c_int), ("width", C.c_int), ("label", C.c_int), ("encoded", C.c_int),
+                ("data", C.c_void_p), ("data_bytes", C.c_size_t), ("float_data_count", C.c_size_t)]
 
 
 class L1LossParams(C.Structure):
@@ -94,6 +101,15 @@ def lib():
     L.fn2_im2col_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, vp]
     L.fn2_col2im_bias_relu_forward.argtypes = [fp, fp, fp, i, i, i, i, i, i, i, i, C.c_float, vp]
     L.fn2_conv_k7s2_relu_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, i, C.c_float, vp]
+    ip = C.POINTER(C.c_int)
+    L.fn2_datum_parse.argtypes = [vp, sz, C.POINTER(DatumView)]
+    L.fn2_datum_float_data.argtypes = [vp, sz, fp, sz]
+    L.fn2_datum_serialize.argtypes = [i, i, i, vp, sz, i, vp, sz]
+    L.fn2_datum_serialize.restype = C.c_longlong
+    L.fn2_custom_data_sample_bytes.argtypes = [i, i, i, ip, i, ip, i]
+    L.fn2_custom_data_sample_bytes.restype = sz
+    L.fn2_custom_data_encode_sample.argtypes = [vp, vp, vp, vp, i, i, vp, sz]
+    L.fn2_custom_data_decode_forward.argtypes = [vp, sz, i, i, i, i, ip, i, ip, i, i, fp, C.c_float, C.POINTER(C.c_void_p), vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
     for name in EXPORTS:

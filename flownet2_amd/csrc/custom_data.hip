@@ -1,0 +1,313 @@
+// CustomData sample format: Datum wire format, the writer's packing and the decode of a batch of samples on the GPU.
+//
+// Reference: Datum (src/caffe/proto/caffe.proto:30-41), ImagePair::read_data (tools/convert_imageset_and_flow.cpp:142-206),
+// DecodeData + CustomDataLayerPrefetch (src/caffe/layers/custom_data_layer.cpp:44-136, :209-300).  The reference decodes on one
+// host thread into fp32 blobs and uploads those; here the packed bytes stay packed until they are in HBM:
+//   per pixel 10.125 B are read (6 B images, 4 B flow, 1 bit occlusion) and 36 B written (9 fp32 planes) -- HBM-bound streaming,
+//   one kernel per slice, 4 outputs per thread for the byte / int16 planes and 8 per thread for the bit plane.
+#include "fn2_common.hpp"
+
+#include <cstdint>
+#include <cstring>
+#include <limits>
+
+namespace fn2 {
+
+// ---------------------------------------------------------------------------------------------------------
+// Protobuf wire format (proto2), the subset Datum needs: varint (0), 64-bit (1), length-delimited (2), 32-bit (5).
+// ---------------------------------------------------------------------------------------------------------
+struct Reader {
+  const unsigned char* p;
+  const unsigned char* end;
+  bool varint(uint64_t* v) {
+    uint64_t r = 0;
+    for (int shift = 0; shift < 64 && p < end; shift += 7) {
+      const unsigned char b = *p++;
+      r |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) { *v = r; return true; }
+    }
+    return false;
+  }
+  bool skip(size_t n) { if ((size_t)(end - p) < n) return false; p += n; return true; }
+};
+
+// Walks the message once; float_dst (may be NULL) receives up to float_cap values of field 6.
+static int walk_datum(const void* buf, size_t len, fn2_datum_view* out, float* float_dst, size_t float_cap) {
+  if (!buf && len) return fail(FN2_ERR_INVALID_ARG, "datum: NULL buffer");
+  Reader r{static_cast<const unsigned char*>(buf), static_cast<const unsigned char*>(buf) + len};
+  fn2_datum_view v;
+  std::memset(&v, 0, sizeof(v));
+  while (r.p < r.end) {
+    uint64_t key;
+    if (!r.varint(&key)) return fail(FN2_ERR_INVALID_ARG, "datum: truncated field key");
+    const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    if (field == 0) return fail(FN2_ERR_INVALID_ARG, "datum: field number 0");
+    uint64_t x = 0;
+    switch (wt) {
+      case 0:
+        if (!r.varint(&x)) return fail(FN2_ERR_INVALID_ARG, "datum: truncated varint (field %u)", field);
+        if (field == 1) v.channels = (int)(int64_t)x;
+        else if (field == 2) v.height = (int)(int64_t)x;
+        else if (field == 3) v.width = (int)(int64_t)x;
+        else if (field == 5) v.label = (int)(int64_t)x;
+        else if (field == 7) v.encoded = x != 0;
+        break;
+      case 1:
+        if (!r.skip(8)) return fail(FN2_ERR_INVALID_ARG, "datum: truncated 64-bit field %u", field);
+        break;
+      case 2: {
+        if (!r.varint(&x) || (uint64_t)(r.end - r.p) < x) return fail(FN2_ERR_INVALID_ARG, "datum: truncated length-delimited field %u", field);
+        if (field == 4) { v.data = r.p; v.data_bytes = (size_t)x; }
+        else if (field == 6) {                       // packed repeated float
+          if (x % 4) return fail(FN2_ERR_INVALID_ARG, "datum: packed float_data of %llu bytes", (unsigned long long)x);
+          for (uint64_t i = 0; i < x / 4; ++i, ++v.float_data_count)
+            if (float_dst && v.float_data_count < float_cap) std::memcpy(float_dst + v.float_data_count, r.p + 4 * i, 4);
+        }
+        r.p += x;
+        break;
+      }
+      case 5:
+        if ((size_t)(r.end - r.p) < 4) return fail(FN2_ERR_INVALID_ARG, "datum: truncated 32-bit field %u", field);
+        if (field == 6) {
+          if (float_dst && v.float_data_count < float_cap) std::memcpy(float_dst + v.float_data_count, r.p, 4);
+          ++v.float_data_count;
+        }
+        r.p += 4;
+        break;
+      default:
+        return fail(FN2_ERR_INVALID_ARG, "datum: unsupported wire type %u (field %u)", wt, field);
+    }
+  }
+  if (out) *out = v;
+  return FN2_OK;
+}
+
+static size_t varint_size(uint64_t v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
+static unsigned char* put_varint(unsigned char* p, uint64_t v) {
+  while (v >= 0x80) { *p++ = (unsigned char)(v | 0x80); v >>= 7; }
+  *p++ = (unsigned char)v;
+  return p;
+}
+// int32 fields are sign-extended to 64 bits on the wire
+static uint64_t int32_wire(int v) { return (uint64_t)(int64_t)v; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Slicing of a sample (DecodeData :66-86)
+// ---------------------------------------------------------------------------------------------------------
+struct Slice { int c0, cc, enc; size_t offset; };
+constexpr int kMaxSlices = 32;
+
+static int make_slices(int channels, int H, int W, const int* sp, int nsp, const int* enc, int nenc, int float_data,
+                       Slice* out, size_t* total) {
+  if (channels < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "custom_data: bad datum shape [%d,%d,%d]", channels, H, W);
+  if (nsp < 0 || nsp + 1 > kMaxSlices || nenc < 0 || (nsp && !sp) || (nenc && !enc)) return fail(FN2_ERR_INVALID_ARG, "custom_data: bad slice arrays");
+  if (float_data && nenc) return fail(FN2_ERR_INVALID_ARG, "Encoded layers must be stored as uint8 in LMDB.");          // :55
+  const size_t hw = (size_t)H * W;
+  int prev = 0;
+  size_t off = 0;
+  for (int s = 0; s <= nsp; ++s) {
+    const int end = (s == nsp) ? channels : sp[s];
+    if (end <= prev || end > channels) return fail(FN2_ERR_INVALID_ARG, "custom_data: slice point %d not in (%d, %d]", end, prev, channels);   // CHECK_GT :519
+    const int e = float_data ? 0 : (s < nenc ? enc[s] : FN2_ENC_UINT8);                                                  // :80-83
+    out[s] = Slice{prev, end - prev, e, off};
+    if (float_data) off += 4 * hw * (end - prev);
+    else if (e == FN2_ENC_UINT8) off += hw * (end - prev);
+    else if (e == FN2_ENC_UINT16FLOW) off += 2 * hw * (end - prev);
+    else if (e == FN2_ENC_BOOL1) {
+      if (end - prev != 1) return fail(FN2_ERR_INVALID_ARG, "custom_data: BOOL1 slice with %d channels (the reference decodes H*W bits per slice, assert :135)", end - prev);
+      off += (hw - 1) / 8 + 1;
+    } else return fail(FN2_ERR_INVALID_ARG, "Invalid format for slice %d", s);                                            // :130
+    prev = end;
+  }
+  *total = off;
+  return FN2_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Decode kernels.  grid.y = sample; each thread produces 4 (8 for bits) consecutive elements of the slice.
+// ---------------------------------------------------------------------------------------------------------
+struct DecodeArgs {
+  const unsigned char* samples;
+  size_t stride, offset;       // sample stride, byte offset of the slice inside a sample
+  const float* mean;           // already offset to the slice's first channel, or NULL
+  float* top;
+  size_t count;                // cc * H * W elements of the slice per sample
+  float scale;
+};
+
+__device__ __forceinline__ float finish(float v, const float* mean, size_t i, float scale) {
+  return (v - (mean ? mean[i] : 0.f)) * scale;                                                // :282
+}
+
+__global__ void __launch_bounds__(256) decode_u8(DecodeArgs a) {
+  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + a.offset;
+  float* dst = a.top + (size_t)blockIdx.y * a.count;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= a.count) return;
+  if (i + 4 <= a.count) {
+    unsigned char b[4];
+    if ((reinterpret_cast<uintptr_t>(src + i) & 3) == 0) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(src + i);
+      b[0] = w & 0xff; b[1] = (w >> 8) & 0xff; b[2] = (w >> 16) & 0xff; b[3] = w >> 24;
+    } else {
+      b[0] = src[i]; b[1] = src[i + 1]; b[2] = src[i + 2]; b[3] = src[i + 3];
+    }
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = finish((float)b[k], a.mean, i + k, a.scale);            // :88-92
+    if ((reinterpret_cast<uintptr_t>(dst + i) & 15) == 0) *reinterpret_cast<float4*>(dst + i) = make_float4(o[0], o[1], o[2], o[3]);
+    else { dst[i] = o[0]; dst[i + 1] = o[1]; dst[i + 2] = o[2]; dst[i + 3] = o[3]; }
+  } else {
+    for (size_t k = i; k < a.count; ++k) dst[k] = finish((float)src[k], a.mean, k, a.scale);
+  }
+}
+
+__device__ __forceinline__ float flow_value(unsigned lo, unsigned hi) {
+  const short v = (short)(unsigned short)(lo | (hi << 8));                                     // :99-101 (little-endian host)
+  // signaling NaN in the reference (:104-105), quieted by the subtraction of the mean: 0x7fe00000 on x86 SSE
+  return v == 32767 ? __uint_as_float(0x7fa00000u) : (float)v / 32.0f;                         // :107
+}
+
+__global__ void __launch_bounds__(256) decode_i16flow(DecodeArgs a) {
+  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + a.offset;
+  float* dst = a.top + (size_t)blockIdx.y * a.count;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= a.count) return;
+  const size_t n = (i + 4 <= a.count) ? 4 : a.count - i;
+  float o[4];
+  if (n == 4 && (reinterpret_cast<uintptr_t>(src + 2 * i) & 7) == 0) {
+    const uint2 w = *reinterpret_cast<const uint2*>(src + 2 * i);
+    o[0] = flow_value(w.x & 0xff, (w.x >> 8) & 0xff); o[1] = flow_value((w.x >> 16) & 0xff, w.x >> 24);
+    o[2] = flow_value(w.y & 0xff, (w.y >> 8) & 0xff); o[3] = flow_value((w.y >> 16) & 0xff, w.y >> 24);
+  } else {
+    for (size_t k = 0; k < n; ++k) o[k] = flow_value(src[2 * (i + k)], src[2 * (i + k) + 1]);
+  }
+  for (size_t k = 0; k < n; ++k) o[k] = finish(o[k], a.mean, i + k, a.scale);
+  if (n == 4 && (reinterpret_cast<uintptr_t>(dst + i) & 15) == 0) *reinterpret_cast<float4*>(dst + i) = make_float4(o[0], o[1], o[2], o[3]);
+  else for (size_t k = 0; k < n; ++k) dst[i + k] = o[k];
+}
+
+__global__ void __launch_bounds__(256) decode_bool1(DecodeArgs a) {
+  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + a.offset;
+  float* dst = a.top + (size_t)blockIdx.y * a.count;
+  const size_t byte = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = byte * 8;
+  if (i >= a.count) return;
+  const unsigned d = src[byte];
+  for (int k = 0; k < 8; ++k)                                                                 // :117-126, LSB first
+    if (i + k < a.count) dst[i + k] = finish(((d >> k) & 1u) ? 1.f : 0.f, a.mean, i + k, a.scale);
+}
+
+__global__ void __launch_bounds__(256) decode_f32(DecodeArgs a) {
+  const float* src = reinterpret_cast<const float*>(a.samples + (size_t)blockIdx.y * a.stride + a.offset);
+  float* dst = a.top + (size_t)blockIdx.y * a.count;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.count) dst[i] = finish(src[i], a.mean, i, a.scale);                               // :57-58
+}
+
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API int fn2_datum_parse(const void* buf, size_t len, fn2_datum_view* out) {
+  if (!out) return fail(FN2_ERR_INVALID_ARG, "datum_parse: out == NULL");
+  return walk_datum(buf, len, out, nullptr, 0);
+}
+
+FN2_API int fn2_datum_float_data(const void* buf, size_t len, float* dst, size_t count) {
+  if (!dst && count) return fail(FN2_ERR_INVALID_ARG, "datum_float_data: dst == NULL");
+  fn2_datum_view v;
+  int rc = walk_datum(buf, len, &v, dst, count);
+  if (rc) return rc;
+  if (v.float_data_count != count) return fail(FN2_ERR_INVALID_ARG, "datum_float_data: datum holds %zu floats, %zu requested", v.float_data_count, count);
+  return FN2_OK;
+}
+
+FN2_API long long fn2_datum_serialize(int channels, int height, int width, const void* data, size_t data_bytes, int label,
+                                      void* dst, size_t dst_bytes) {
+  if (!data && data_bytes) return fail(FN2_ERR_INVALID_ARG, "datum_serialize: NULL data");
+  const size_t need = 1 + varint_size(int32_wire(channels)) + 1 + varint_size(int32_wire(height)) + 1 + varint_size(int32_wire(width)) +
+                      1 + varint_size(data_bytes) + data_bytes + 1 + varint_size(int32_wire(label));
+  if (!dst) return (long long)need;
+  if (dst_bytes < need) return fail(FN2_ERR_WORKSPACE, "datum_serialize: %zu bytes needed, %zu given", need, dst_bytes);
+  unsigned char* p = static_cast<unsigned char*>(dst);
+  *p++ = 0x08; p = put_varint(p, int32_wire(channels));     // field 1, varint
+  *p++ = 0x10; p = put_varint(p, int32_wire(height));       // field 2
+  *p++ = 0x18; p = put_varint(p, int32_wire(width));        // field 3
+  *p++ = 0x22; p = put_varint(p, data_bytes);               // field 4, length-delimited
+  if (data_bytes) std::memcpy(p, data, data_bytes);
+  p += data_bytes;
+  *p++ = 0x28; p = put_varint(p, int32_wire(label));        // field 5
+  return (long long)need;
+}
+
+FN2_API size_t fn2_custom_data_sample_bytes(int channels, int H, int W, const int* slice_points, int n_slice_points,
+                                            const int* encodings, int n_encodings) {
+  Slice sl[kMaxSlices];
+  size_t total = 0;
+  if (make_slices(channels, H, W, slice_points, n_slice_points, encodings, n_encodings, 0, sl, &total)) return 0;
+  return total;
+}
+
+FN2_API int fn2_custom_data_encode_sample(const unsigned char* img0, const unsigned char* img1, const float* flow,
+                                          const unsigned char* occ, int H, int W, unsigned char* dst, size_t dst_bytes) {
+  if (H < 1 || W < 1 || !img0 || !img1 || !dst) return fail(FN2_ERR_INVALID_ARG, "custom_data_encode_sample: bad arguments");
+  const size_t hw = (size_t)H * W, need = 10 * hw + (hw - 1) / 8 + 1;                          // :142-145
+  if (dst_bytes < need) return fail(FN2_ERR_WORKSPACE, "custom_data_encode_sample: %zu bytes needed, %zu given", need, dst_bytes);
+  std::memset(dst, 0, need);                                                                  // :147
+  unsigned char* p = dst;
+  for (const unsigned char* img : {img0, img1})                                               // :151-166
+    for (int c = 0; c < 3; ++c)
+      for (size_t i = 0; i < hw; ++i) *p++ = img[i * 3 + c];
+  for (size_t j = 0; j < 2 * hw; ++j) {                                                       // :169-181
+    short value = 0;
+    if (flow) {
+      if (flow[j] != flow[j]) value = std::numeric_limits<short>::max();
+      else {
+        // `short value = flo*32`: conversion toward zero; out-of-range products are undefined in C++ -- clamped here
+        const float t = flow[j] * 32;
+        value = t >= 32767.f ? (short)32767 : (t <= -32768.f ? (short)-32768 : (short)t);
+      }
+    }
+    *p++ = (unsigned char)((unsigned short)value & 0xff);
+    *p++ = (unsigned char)((unsigned short)value >> 8);
+  }
+  unsigned char current = 0;                                                                  // :185-203
+  int idx = 0;
+  for (size_t i = 0; i < hw; ++i) {
+    if (occ && occ[i] > 0) current |= (unsigned char)(1u << idx);
+    if (++idx == 8) { *p++ = current; idx = 0; current = 0; }
+  }
+  if (idx > 0) *p++ = current;
+  return FN2_OK;
+}
+
+FN2_API int fn2_custom_data_decode_forward(const void* samples, size_t sample_stride, int N, int channels, int H, int W,
+                                           const int* slice_points, int n_slice_points, const int* encodings, int n_encodings,
+                                           int float_data, const float* mean, float scale, float* const* tops, void* stream) {
+  Slice sl[kMaxSlices];
+  size_t total = 0;
+  int rc = make_slices(channels, H, W, slice_points, n_slice_points, encodings, n_encodings, float_data, sl, &total);
+  if (rc) return rc;
+  if (N < 0) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: N < 0");
+  if (N == 0) return FN2_OK;
+  if (!samples || !tops) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: NULL pointer");
+  if (sample_stride < total) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: sample stride %zu < sample size %zu", sample_stride, total);
+  if (float_data && sample_stride % 4) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: float samples need a stride that is a multiple of 4");
+  if (N > 65535) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: batch of %d samples (max 65535)", N);
+  const size_t hw = (size_t)H * W;
+  hipStream_t st = as_stream(stream);
+  for (int s = 0; s <= n_slice_points; ++s) {
+    if (!tops[s]) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: top[%d] == NULL", s);
+    DecodeArgs a{static_cast<const unsigned char*>(samples), sample_stride, sl[s].offset,
+                 mean ? mean + (size_t)sl[s].c0 * hw : nullptr, tops[s], (size_t)sl[s].cc * hw, scale};
+    const size_t per_thread = float_data ? 1 : (sl[s].enc == FN2_ENC_BOOL1 ? 8 : 4);
+    const size_t threads = (a.count + per_thread - 1) / per_thread;
+    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)N);
+    if (float_data) hipLaunchKernelGGL(decode_f32, grid, dim3(256), 0, st, a);
+    else if (sl[s].enc == FN2_ENC_UINT8) hipLaunchKernelGGL(decode_u8, grid, dim3(256), 0, st, a);
+    else if (sl[s].enc == FN2_ENC_UINT16FLOW) hipLaunchKernelGGL(decode_i16flow, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(decode_bool1, grid, dim3(256), 0, st, a);
+  }
+  return check_launch("custom_data_decode_forward");
+}

@@ -260,6 +260,58 @@ int fn2_im2col_forward(const float* im, float* col, int N, int C, int H, int W, 
 int fn2_col2im_bias_relu_forward(const float* col, const float* bias, float* im, int N, int C, int H, int W,
                                  int kernel, int pad, int stride, int apply_relu, float negative_slope, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * CustomData sample format  (type: "CustomData"; SURVEY.md 8f row 4: the on-disk format of the training sets)
+ *   An LMDB value is a serialized `Datum` (src/caffe/proto/caffe.proto:30-41) whose `data` bytes hold, plane after plane,
+ *   the slices named by DataParameter.slice_point / .encoding (caffe.proto:923-927, :979-980).  The FlyingChairs sets written by
+ *   tools/convert_imageset_and_flow.cpp:142-206 have channels = 9, slice_point 3,6,8, encoding UINT8,UINT8,UINT16FLOW,BOOL1:
+ *     image 0, image 1 : [3,H,W] uint8, planar, OpenCV channel order (B,G,R)
+ *     flow             : [2,H,W] int16 little-endian = (short)(flow * 32) (C conversion: toward zero); SHRT_MAX marks NaN
+ *     occlusions       : H*W bits, LSB first, (H*W - 1)/8 + 1 bytes
+ *   decode  <- DecodeData, src/caffe/layers/custom_data_layer.cpp:44-136, followed by the per-slice copy of
+ *              CustomDataLayerPrefetch (:209-300): top = (decoded - mean[data_index]) * scale.  The reference does this on ONE host
+ *              thread and uploads the fp32 blobs (Forward_gpu = Forward_cpu, custom_data_layer.cu:19-23); here the raw bytes are
+ *              uploaded (3.6x fewer) and decoded by a kernel.  crop_size > 0 is LOG(FATAL) in the reference (:503-506): no crop/mirror.
+ *   The storage engine (LMDB's B-tree file) is out of scope: records arrive as (pointer, length) from whatever reads them.
+ * ---------------------------------------------------------------------------------------------- */
+enum { FN2_ENC_UINT8 = 1, FN2_ENC_UINT16FLOW = 2, FN2_ENC_BOOL1 = 3 };   /* DataParameter.CHANNELENCODING */
+
+typedef struct fn2_datum_view {     /* Datum, caffe.proto:30-41; pointers point INTO the parsed buffer */
+  int channels, height, width;      /* fields 1-3 (0 when absent)                                   */
+  int label;                        /* field 5                                                      */
+  int encoded;                      /* field 7                                                      */
+  const unsigned char* data;        /* field 4, NULL when absent                                    */
+  size_t data_bytes;
+  size_t float_data_count;          /* field 6 (repeated float, packed or not); fetch with fn2_datum_float_data */
+} fn2_datum_view;
+
+/* HOST functions (no GPU work).  Protobuf wire format, proto2: unknown fields are skipped, the last occurrence of a scalar wins. */
+int fn2_datum_parse(const void* buf, size_t len, fn2_datum_view* out);
+int fn2_datum_float_data(const void* buf, size_t len, float* dst, size_t count);
+/* Serializes {channels, height, width, data, label} the way Datum::SerializeToString does for the writer tool
+ * (convert_imageset_and_flow.cpp:231-236: fields in number order, all five present).  Returns the size; writes when dst != NULL
+ * and dst_bytes suffices, else FN2_ERR_WORKSPACE (as a negative size). */
+long long fn2_datum_serialize(int channels, int height, int width, const void* data, size_t data_bytes, int label,
+                              void* dst, size_t dst_bytes);
+
+/* Bytes of one sample's `data` for the given slicing; 0 if the slicing is invalid (slice points not increasing / beyond channels,
+ * unknown encoding, BOOL1 slice with more than one channel -- DecodeData walks H*W bits once per BOOL1 slice, :113-128). */
+size_t fn2_custom_data_sample_bytes(int channels, int H, int W, const int* slice_points, int n_slice_points,
+                                    const int* encodings, int n_encodings);
+/* HOST: the writer (ImagePair::read_data, tools/convert_imageset_and_flow.cpp:142-206).  img0/img1: [H,W,3] uint8 interleaved as
+ * cv::imread returns them; flow: [2,H,W] float planar as readFloFile returns it (util/output.cpp:31-37), NULL = zeros;
+ * occlusion: [H,W] uint8 (non-zero = occluded), NULL = none.  dst must hold 10*H*W + (H*W-1)/8 + 1 bytes. */
+int fn2_custom_data_encode_sample(const unsigned char* img0_hwc, const unsigned char* img1_hwc, const float* flow_chw,
+                                  const unsigned char* occlusion, int H, int W, unsigned char* dst, size_t dst_bytes);
+/* DEVICE: samples = N `data` payloads in device memory, sample_stride bytes apart (>= the sample size).  mean: device
+ * [channels*H*W] floats or NULL (= 0, data_mean_ without mean_file / subtract, :612-615).  tops: HOST array of n_slice_points + 1
+ * device pointers, top[s] = [N, slice channels, H, W].  float_data != 0: samples are channels*H*W floats each (Datum.float_data,
+ * :53-61; encodings must then be empty, CHECK :55).  NaN flow decodes to a quiet NaN (the reference's signaling NaN is quieted by
+ * the mean subtraction, :104-108, :282). */
+int fn2_custom_data_decode_forward(const void* samples, size_t sample_stride, int N, int channels, int H, int W,
+                                   const int* slice_points, int n_slice_points, const int* encodings, int n_encodings,
+                                   int float_data, const float* mean, float scale, float* const* tops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,3 +261,84 @@ def upsample_flow_deconv_forward(x, weight, bias=None):
     out = np.empty((N, 2, 2 * H, 2 * W), np.float32)
     _check(lib().fn2_upsample_flow_deconv_forward_cpu(_p(x), _p(weight), _p(bias), _p(out), N, H, W), "upsample_flow_deconv_forward")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# CustomData sample format (Datum wire format, writer packing, decode) -- host arrays throughout
+# ------------------------------------------------------------------------------------------------
+class DatumView(C.Structure):
+    _fields_ = [("channels", C.c_int), ("height", C.c_int), ("width", C.c_int), ("label", C.c_int), ("encoded", C.c_int),
+                ("data", C.c_void_p), ("data_bytes", C.c_size_t), ("float_data_count", C.c_size_t)]
+
+
+def _ints(v):
+    return (C.c_int * max(1, len(v)))(*[int(x) for x in v]), len(v)
+
+
+def datum_parse(record: bytes):
+    """-> dict(channels, height, width, label, encoded, data (bytes or None), float_data (array or None))"""
+    a = np.frombuffer(record, dtype=np.uint8)
+    v = DatumView()
+    L = lib()
+    L.fn2_datum_parse_cpu.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(DatumView)]
+    _check(L.fn2_datum_parse_cpu(C.c_void_p(a.ctypes.data), a.size, C.byref(v)), "datum_parse")
+    data = bytes(a[v.data - a.ctypes.data: v.data - a.ctypes.data + v.data_bytes]) if v.data else None
+    fl = None
+    if v.float_data_count:
+        fl = np.empty(v.float_data_count, np.float32)
+        L.fn2_datum_float_data_cpu.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _check(L.fn2_datum_float_data_cpu(C.c_void_p(a.ctypes.data), a.size, C.c_void_p(fl.ctypes.data), fl.size), "datum_float_data")
+    return dict(channels=v.channels, height=v.height, width=v.width, label=v.label, encoded=bool(v.encoded), data=data, float_data=fl)
+
+
+def datum_serialize(channels, height, width, data: bytes, label=0) -> bytes:
+    a = np.frombuffer(data, dtype=np.uint8)
+    L = lib()
+    L.fn2_datum_serialize_cpu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+    L.fn2_datum_serialize_cpu.restype = C.c_longlong
+    need = L.fn2_datum_serialize_cpu(channels, height, width, C.c_void_p(a.ctypes.data), a.size, label, None, 0)
+    _check(min(need, 0), "datum_serialize")
+    out = np.empty(need, np.uint8)
+    _check(min(L.fn2_datum_serialize_cpu(channels, height, width, C.c_void_p(a.ctypes.data), a.size, label, C.c_void_p(out.ctypes.data), out.size), 0),
+           "datum_serialize")
+    return out.tobytes()
+
+
+def custom_data_sample_bytes(channels, H, W, slice_points, encodings) -> int:
+    sp, nsp = _ints(slice_points)
+    en, nen = _ints(encodings)
+    L = lib()
+    L.fn2_custom_data_sample_bytes_cpu.restype = C.c_size_t
+    return L.fn2_custom_data_sample_bytes_cpu(channels, H, W, sp, nsp, en, nen)
+
+
+def custom_data_encode_sample(img0_hwc, img1_hwc, flow_chw=None, occlusion=None) -> bytes:
+    a, b = np.ascontiguousarray(img0_hwc, np.uint8), np.ascontiguousarray(img1_hwc, np.uint8)
+    H, W = a.shape[:2]
+    f = np.ascontiguousarray(flow_chw, np.float32) if flow_chw is not None else None
+    o = np.ascontiguousarray(occlusion).astype(np.uint8) if occlusion is not None else None
+    out = np.empty(10 * H * W + (H * W - 1) // 8 + 1, np.uint8)
+    p = lambda x: C.c_void_p(x.ctypes.data) if x is not None else None
+    L = lib()
+    L.fn2_custom_data_encode_sample_cpu.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    _check(L.fn2_custom_data_encode_sample_cpu(p(a), p(b), p(f), p(o), H, W, p(out), out.size), "custom_data_encode_sample")
+    return out.tobytes()
+
+
+def custom_data_decode(samples: np.ndarray, channels, H, W, slice_points=(), encodings=(), mean=None, scale=1.0, float_data=False):
+    """samples: [N, stride] uint8 (or float32 with float_data) host array -> list of float32 [N, slice channels, H, W]."""
+    samples = np.ascontiguousarray(samples)
+    N = samples.shape[0]
+    stride = samples.shape[1] * samples.itemsize
+    bounds = [0] + [int(s) for s in slice_points] + [channels]
+    tops = [np.empty((N, max(b - a, 0), H, W), np.float32) for a, b in zip(bounds, bounds[1:])]
+    sp, nsp = _ints(slice_points)
+    en, nen = _ints(encodings)
+    ptrs = (C.c_void_p * len(tops))(*[t.ctypes.data for t in tops])
+    m = np.ascontiguousarray(mean, np.float32) if mean is not None else None
+    L = lib()
+    L.fn2_custom_data_decode_forward_cpu.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                                     C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]
+    _check(L.fn2_custom_data_decode_forward_cpu(C.c_void_p(samples.ctypes.data), stride, N, channels, H, W, sp, nsp, en, nen, int(float_data),
+                                                C.c_void_p(m.ctypes.data) if m is not None else None, float(scale), ptrs), "custom_data_decode")
+    return tops

@@ -978,3 +978,268 @@ FN2_API int fn2_bias_leaky_relu_backward_cpu(const float* top_data, const float*
   }
   return FN2_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CustomData sample format.
+ *   Datum: src/caffe/proto/caffe.proto:30-41, encoded by libprotobuf (third-party, version unpinned by the reference's
+ *   Makefile); the wire format is the published proto2 encoding: key = (field << 3) | wire_type as a base-128 varint, wire types
+ *   0 varint, 1 fixed64, 2 length-delimited, 5 fixed32; int32 values are sign-extended to 64 bits; repeated scalars may arrive
+ *   packed.  tests/test_sample_format.py pins these functions against the protobuf runtime installed here.
+ *   Writer: ImagePair::read_data, tools/convert_imageset_and_flow.cpp:142-206.
+ *   Reader: DecodeData (src/caffe/layers/custom_data_layer.cpp:44-136) + the slice copy of CustomDataLayerPrefetch (:209-300).
+ * ---------------------------------------------------------------------------------------------- */
+static int pb_varint(const unsigned char** p, const unsigned char* end, uint64_t* v) {
+  uint64_t r = 0;
+  int shift = 0;
+  while (*p < end && shift < 64) {
+    const unsigned char b = *(*p)++;
+    r |= (uint64_t)(b & 0x7f) << shift;
+    if (!(b & 0x80)) { *v = r; return 1; }
+    shift += 7;
+  }
+  return 0;
+}
+
+static int datum_walk_cpu(const void* buf, size_t len, fn2_datum_view* out, float* fdst, size_t fcap) {
+  const unsigned char* p = (const unsigned char*)buf;
+  const unsigned char* end = p + len;
+  fn2_datum_view v;
+  memset(&v, 0, sizeof(v));
+  if (!buf && len) return FN2_ERR_INVALID_ARG;
+  while (p < end) {
+    uint64_t key, x;
+    if (!pb_varint(&p, end, &key)) return FN2_ERR_INVALID_ARG;
+    const unsigned field = (unsigned)(key >> 3), wt = (unsigned)(key & 7);
+    if (field == 0) return FN2_ERR_INVALID_ARG;
+    if (wt == 0) {
+      if (!pb_varint(&p, end, &x)) return FN2_ERR_INVALID_ARG;
+      switch (field) {
+        case 1: v.channels = (int)(int64_t)x; break;
+        case 2: v.height = (int)(int64_t)x; break;
+        case 3: v.width = (int)(int64_t)x; break;
+        case 5: v.label = (int)(int64_t)x; break;
+        case 7: v.encoded = x != 0; break;
+        default: break;
+      }
+    } else if (wt == 1) {
+      if ((size_t)(end - p) < 8) return FN2_ERR_INVALID_ARG;
+      p += 8;
+    } else if (wt == 2) {
+      if (!pb_varint(&p, end, &x) || (uint64_t)(end - p) < x) return FN2_ERR_INVALID_ARG;
+      if (field == 4) { v.data = p; v.data_bytes = (size_t)x; }
+      if (field == 6) {
+        if (x % 4) return FN2_ERR_INVALID_ARG;
+        for (uint64_t i = 0; i < x / 4; ++i) {
+          if (fdst && v.float_data_count < fcap) memcpy(fdst + v.float_data_count, p + 4 * i, 4);
+          v.float_data_count++;
+        }
+      }
+      p += x;
+    } else if (wt == 5) {
+      if ((size_t)(end - p) < 4) return FN2_ERR_INVALID_ARG;
+      if (field == 6) {
+        if (fdst && v.float_data_count < fcap) memcpy(fdst + v.float_data_count, p, 4);
+        v.float_data_count++;
+      }
+      p += 4;
+    } else {
+      return FN2_ERR_INVALID_ARG;       /* groups (3, 4) do not occur in Datum */
+    }
+  }
+  if (out) *out = v;
+  return FN2_OK;
+}
+
+FN2_API int fn2_datum_parse_cpu(const void* buf, size_t len, fn2_datum_view* out) {
+  if (!out) return FN2_ERR_INVALID_ARG;
+  return datum_walk_cpu(buf, len, out, NULL, 0);
+}
+
+FN2_API int fn2_datum_float_data_cpu(const void* buf, size_t len, float* dst, size_t count) {
+  fn2_datum_view v;
+  int rc = datum_walk_cpu(buf, len, &v, dst, count);
+  if (rc) return rc;
+  return v.float_data_count == count ? FN2_OK : FN2_ERR_INVALID_ARG;
+}
+
+static size_t pb_put(unsigned char* dst, size_t pos, uint64_t v) {      /* appends a varint; counts only when dst == NULL */
+  do {
+    unsigned char b = (unsigned char)(v & 0x7f);
+    v >>= 7;
+    if (v) b |= 0x80;
+    if (dst) dst[pos] = b;
+    pos++;
+  } while (v);
+  return pos;
+}
+
+FN2_API long long fn2_datum_serialize_cpu(int channels, int height, int width, const void* data, size_t data_bytes, int label,
+                                          void* dst, size_t dst_bytes) {
+  if (!data && data_bytes) return FN2_ERR_INVALID_ARG;
+  for (int pass = 0; pass < 2; ++pass) {
+    unsigned char* d = pass ? (unsigned char*)dst : NULL;
+    size_t pos = 0;
+    pos = pb_put(d, pos, (1u << 3) | 0); pos = pb_put(d, pos, (uint64_t)(int64_t)channels);
+    pos = pb_put(d, pos, (2u << 3) | 0); pos = pb_put(d, pos, (uint64_t)(int64_t)height);
+    pos = pb_put(d, pos, (3u << 3) | 0); pos = pb_put(d, pos, (uint64_t)(int64_t)width);
+    pos = pb_put(d, pos, (4u << 3) | 2); pos = pb_put(d, pos, (uint64_t)data_bytes);
+    if (d && data_bytes) memcpy(d + pos, data, data_bytes);
+    pos += data_bytes;
+    pos = pb_put(d, pos, (5u << 3) | 0); pos = pb_put(d, pos, (uint64_t)(int64_t)label);
+    if (!dst) return (long long)pos;
+    if (!pass && dst_bytes < pos) return FN2_ERR_WORKSPACE;
+    if (pass) return (long long)pos;
+  }
+  return FN2_ERR_INVALID_ARG;
+}
+
+/* byte size and channel range of every slice, custom_data_layer.cpp:66-86; returns the number of slices or a negative status */
+typedef struct cd_slice { int c0, cc, enc; size_t off; } cd_slice;
+static int cd_slices(int channels, int H, int W, const int* sp, int nsp, const int* enc, int nenc, int float_data,
+                     cd_slice* out, size_t* total) {
+  if (channels < 1 || H < 1 || W < 1 || nsp < 0 || nsp >= 32 || nenc < 0) return FN2_ERR_INVALID_ARG;
+  if (float_data && nenc) return FN2_ERR_INVALID_ARG;                                            /* :55 */
+  const size_t hw = (size_t)H * W;
+  int channel_end = 0;
+  size_t off = 0;
+  for (int slice = 0; slice <= nsp; ++slice) {
+    const int channel_start = channel_end;                                                       /* :70 */
+    channel_end = (slice == nsp) ? channels : sp[slice];                                         /* :72-75 */
+    const int channel_count = channel_end - channel_start;                                       /* :77 */
+    if (channel_count < 1 || channel_end > channels) return FN2_ERR_INVALID_ARG;                 /* CHECK_GT :519 */
+    const int format = float_data ? 0 : (nenc <= slice ? FN2_ENC_UINT8 : enc[slice]);            /* :79-83 */
+    out[slice].c0 = channel_start; out[slice].cc = channel_count; out[slice].enc = format; out[slice].off = off;
+    if (float_data) off += 4 * hw * channel_count;
+    else if (format == FN2_ENC_UINT8) off += hw * channel_count;
+    else if (format == FN2_ENC_UINT16FLOW) off += 2 * hw * channel_count;
+    else if (format == FN2_ENC_BOOL1) { if (channel_count != 1) return FN2_ERR_INVALID_ARG; off += (hw - 1) / 8 + 1; }   /* :116, assert :135 */
+    else return FN2_ERR_INVALID_ARG;                                                             /* :129-131 */
+  }
+  *total = off;
+  return nsp + 1;
+}
+
+FN2_API size_t fn2_custom_data_sample_bytes_cpu(int channels, int H, int W, const int* slice_points, int n_slice_points,
+                                                const int* encodings, int n_encodings) {
+  cd_slice sl[32];
+  size_t total = 0;
+  return cd_slices(channels, H, W, slice_points, n_slice_points, encodings, n_encodings, 0, sl, &total) < 0 ? 0 : total;
+}
+
+FN2_API int fn2_custom_data_encode_sample_cpu(const unsigned char* img0, const unsigned char* img1, const float* flow,
+                                              const unsigned char* occ, int H, int W, unsigned char* dst, size_t dst_bytes) {
+  if (H < 1 || W < 1 || !img0 || !img1 || !dst) return FN2_ERR_INVALID_ARG;
+  const int width = W, height = H;
+  const size_t data_size = (size_t)3 * width * height + (size_t)3 * width * height + (size_t)2 * 2 * width * height +
+                           ((size_t)width * height - 1) / 8 + 1;                                 /* tool :142-145 */
+  if (dst_bytes < data_size) return FN2_ERR_WORKSPACE;
+  memset(dst, 0, data_size);                                                                     /* :147 */
+  unsigned char* ptr = dst;
+  for (int c = 0; c < 3; ++c)                                                                    /* :151-156 */
+    for (int y = 0; y < height; ++y)
+      for (int x = 0; x < width; ++x) *(ptr++) = img0[((size_t)y * width + x) * 3 + c];          /* cv::Vec3b at(y,x)[c] */
+  for (int c = 0; c < 3; ++c)                                                                    /* :160-165 */
+    for (int y = 0; y < height; ++y)
+      for (int x = 0; x < width; ++x) *(ptr++) = img1[((size_t)y * width + x) * 3 + c];
+  for (size_t j = 0; j < (size_t)2 * width * height; j++) {                                      /* :169-181 */
+    short value = 0;
+    if (flow) {
+      if (isnan(flow[j])) value = 32767;                                                         /* numeric_limits<short>::max() */
+      else {
+        /* `value = flo_data[j]*32`: float -> short conversion truncates toward zero; outside the range of short it is undefined
+         * behaviour in C++ (flows beyond +-1024 px do not occur in the data sets): saturate */
+        const float t = flow[j] * 32;
+        value = t >= 32767.f ? 32767 : (t <= -32768.f ? -32768 : (short)t);
+      }
+    }
+    *(ptr++) = *((unsigned char*)&value);                                                        /* host byte order (little-endian) */
+    *(ptr++) = *((unsigned char*)&value + 1);
+  }
+  unsigned char current = 0;                                                                     /* :185-203 */
+  int current_idx = 0;
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      unsigned char value = 0;
+      if (occ) value = occ[(size_t)y * width + x] > 0;
+      if (value) current |= 1 << current_idx;
+      current_idx++;
+      if (current_idx == 8) { *(ptr++) = current; current_idx = 0; current = 0; }
+    }
+  if (current_idx > 0) *(ptr++) = current;
+  return (size_t)(ptr - dst) == data_size ? FN2_OK : FN2_ERR_INVALID_ARG;                        /* assert :204 */
+}
+
+/* All pointers are HOST pointers here.  Restates DecodeData (whole datum -> floats, :44-136) and then the slice copy with the mean
+ * and the scale (:209-300, the crop_size == 0 branch :274-284). */
+FN2_API int fn2_custom_data_decode_forward_cpu(const void* samples, size_t sample_stride, int N, int channels, int H, int W,
+                                               const int* slice_points, int n_slice_points, const int* encodings, int n_encodings,
+                                               int float_data, const float* mean, float scale, float* const* tops) {
+  cd_slice sl[32];
+  size_t total = 0;
+  const int ns = cd_slices(channels, H, W, slice_points, n_slice_points, encodings, n_encodings, float_data, sl, &total);
+  if (ns < 0) return ns;
+  if (N < 0 || (N && (!samples || !tops)) || sample_stride < total) return FN2_ERR_INVALID_ARG;
+  const int width = W, height = H;
+  const size_t heightwidth = (size_t)H * W, count = heightwidth * channels;
+  float* decoded = (float*)malloc(count * sizeof(float));
+  float* zero_mean = (float*)calloc(count, sizeof(float));                                       /* data_mean_ "all-empty", :612-615 */
+  if (!decoded || !zero_mean) { free(decoded); free(zero_mean); return FN2_ERR_WORKSPACE; }
+  const float* mean_data = mean ? mean : zero_mean;
+  for (int item_id = 0; item_id < N; ++item_id) {
+    const unsigned char* srcptr = (const unsigned char*)samples + (size_t)item_id * sample_stride;
+    float* destptr = decoded;
+    if (float_data) {
+      memcpy(decoded, srcptr, count * sizeof(float));                                            /* :57-58 */
+    } else {
+      for (int slice = 0; slice < ns; ++slice) {
+        const int channel_count = sl[slice].cc;
+        switch (sl[slice].enc) {
+          case FN2_ENC_UINT8:                                                                    /* :88-92 */
+            for (int c = 0; c < channel_count; c++)
+              for (int y = 0; y < height; y++)
+                for (int x = 0; x < width; x++) *(destptr++) = (float)(*(srcptr++));
+            break;
+          case FN2_ENC_UINT16FLOW:                                                               /* :94-111 */
+            for (int c = 0; c < channel_count; c++)
+              for (int y = 0; y < height; y++)
+                for (int x = 0; x < width; x++) {
+                  short v;
+                  *((unsigned char*)&v) = *(srcptr++);
+                  *((unsigned char*)&v + 1) = *(srcptr++);
+                  float value;
+                  if (v == 32767) { const uint32_t snan = 0x7fa00000u; memcpy(&value, &snan, 4); }   /* signaling_NaN(), :105 */
+                  else value = ((float)v) / 32.0f;                                               /* :107 */
+                  *(destptr++) = value;
+                }
+            break;
+          default: {                                                                             /* BOOL1, :113-128 */
+            size_t j = 0;
+            for (size_t i = 0; i < (heightwidth - 1) / 8 + 1; i++) {
+              const unsigned char data = *(srcptr++);
+              for (int k = 0; k < 8; k++) {
+                const float value = (data & (1 << k)) == (1 << k);
+                if (j < heightwidth) *(destptr++) = value ? 1.0f : 0.f;
+                j++;
+              }
+            }
+          }
+        }
+      }
+      if (destptr != decoded + count) { free(decoded); free(zero_mean); return FN2_ERR_INVALID_ARG; }   /* assert :135 */
+    }
+    for (int slice = 0; slice < ns; ++slice) {                                                   /* :216-284 */
+      float* top_data = tops[slice];
+      const int slice_channel_count = sl[slice].cc, src_channel_start = sl[slice].c0;
+      for (int c = 0; c < slice_channel_count; ++c)
+        for (size_t hw = 0; hw < heightwidth; ++hw) {
+          const size_t top_index = ((size_t)item_id * slice_channel_count + c) * heightwidth + hw;   /* :278 */
+          const size_t data_index = (size_t)(src_channel_start + c) * heightwidth + hw;              /* :279 */
+          volatile float datum_element = decoded[data_index];                                       /* keeps the sNaN -> qNaN subtraction */
+          top_data[top_index] = (datum_element - mean_data[data_index]) * scale;                    /* :282 */
+        }
+    }
+  }
+  free(decoded);
+  free(zero_mean);
+  return FN2_OK;
+}
