@@ -5,6 +5,7 @@
 #include <string>
 
 #include "caffe/common.hpp"
+#include "caffe/proto/caffe.pb.h"
 
 namespace caffe {
 
@@ -51,6 +52,7 @@ class Blob {
   Blob() {}
   Blob(int num, int channels, int height, int width) { Reshape(num, channels, height, width); }
   explicit Blob(const vector<int>& shape) { Reshape(shape); }
+  void FromProto(const BlobProto&) { LOG(FATAL) << "Blob::FromProto: not part of the stand-in (mean_file is not used by the pins)"; }
   void Reshape(int num, int channels, int height, int width) { Reshape(vector<int>{num, channels, height, width}); }
   void Reshape(const vector<int>& shape) {
     size_t c = 1;

@@ -5,6 +5,7 @@
 // reference sources use are mapped onto their HIP twins here (test scaffolding only -- the product kernels
 // never see these macros).
 #pragma once
+#include <random>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -32,7 +33,10 @@ class LogMessage {
  public:
   LogMessage(const char* file, int line, bool fatal, bool silent) : fatal_(fatal), silent_(silent) { s_ << file << ":" << line << "] "; }
   ~LogMessage() noexcept(false) {
-    if (fatal_) throw Fatal(s_.str());
+    if (fatal_) {
+      if (std::getenv("FN2_CAFFE_LOG")) std::cerr << "FATAL " << s_.str() << std::endl;
+      throw Fatal(s_.str());
+    }
     if (!silent_ && std::getenv("FN2_CAFFE_LOG")) std::cerr << s_.str() << std::endl;
   }
   std::ostream& stream() { return s_; }
@@ -89,6 +93,15 @@ class Caffe {
   static Brew& mode_ref() { static thread_local Brew m = GPU; return m; }
   static Brew mode() { return mode_ref(); }
   static void set_mode(Brew m) { mode_ref() = m; }
+  // common.hpp:118-130 of the reference: a seeded generator handed out as void* (data layers only)
+  class RNG {
+   public:
+    RNG() : g_(1) {}
+    explicit RNG(unsigned int seed) : g_(seed) {}
+    void* generator() { return &g_; }
+   private:
+    std::mt19937 g_;
+  };
 };
 
 // ---- util/device_alternate.hpp:40-90 (CUDA names -> HIP) ---------------------------------------------------

@@ -184,6 +184,123 @@ class ReLUParameter {
   float negative_slope_ = 0.f;
 };
 
+// ---- data layers (oracle/_ref only: the reference's CustomData layer is compiled in place to pin the sample format) ----------
+// Datum, caffe.proto:30-41.  ParseFromArray is a plain proto2 wire reader (harness code: the product's reader is
+// fn2_datum_parse, pinned against the protobuf runtime by tests/test_sample_format.py).
+class Datum {
+ public:
+  int channels() const { return channels_; }
+  int height() const { return height_; }
+  int width() const { return width_; }
+  int label() const { return label_; }
+  bool encoded() const { return encoded_; }
+  const std::string& data() const { return data_; }
+  int float_data_size() const { return (int)float_data_.size(); }
+  float float_data(int i) const { return float_data_[i]; }
+  bool ParseFromArray(const void* buf, int size) {
+    *this = Datum();
+    const unsigned char* p = static_cast<const unsigned char*>(buf);
+    const unsigned char* end = p + size;
+    auto varint = [&](unsigned long long* v) {
+      *v = 0;
+      for (int sh = 0; sh < 64 && p < end; sh += 7) { const unsigned char b = *p++; *v |= (unsigned long long)(b & 0x7f) << sh; if (!(b & 0x80)) return true; }
+      return false;
+    };
+    auto f32 = [&](const unsigned char* q) { float f; __builtin_memcpy(&f, q, 4); return f; };
+    while (p < end) {
+      unsigned long long key, x;
+      if (!varint(&key)) return false;
+      const unsigned field = (unsigned)(key >> 3), wt = (unsigned)(key & 7);
+      if (wt == 0) {
+        if (!varint(&x)) return false;
+        if (field == 1) channels_ = (int)x; else if (field == 2) height_ = (int)x; else if (field == 3) width_ = (int)x;
+        else if (field == 5) label_ = (int)x; else if (field == 7) encoded_ = x != 0;
+      } else if (wt == 2) {
+        if (!varint(&x) || (unsigned long long)(end - p) < x) return false;
+        if (field == 4) data_.assign(reinterpret_cast<const char*>(p), (size_t)x);
+        if (field == 6) for (unsigned long long i = 0; i + 4 <= x; i += 4) float_data_.push_back(f32(p + i));
+        p += x;
+      } else if (wt == 5) {
+        if (end - p < 4) return false;
+        if (field == 6) float_data_.push_back(f32(p));
+        p += 4;
+      } else if (wt == 1) {
+        if (end - p < 8) return false;
+        p += 8;
+      } else return false;
+    }
+    return true;
+  }
+ private:
+  int channels_ = 0, height_ = 0, width_ = 0, label_ = 0;
+  bool encoded_ = false;
+  std::string data_;
+  std::vector<float> float_data_;
+};
+class BlobProto {};
+
+template <typename T>
+class RepeatedField {
+ public:
+  typename std::vector<T>::const_iterator begin() const { return v_.begin(); }
+  typename std::vector<T>::const_iterator end() const { return v_.end(); }
+  int size() const { return (int)v_.size(); }
+  T Get(int i) const { return v_[i]; }
+  void Add(T x) { v_.push_back(x); }
+ private:
+  std::vector<T> v_;
+};
+
+enum DataParameter_DB { DataParameter_DB_LEVELDB = 0, DataParameter_DB_LMDB = 1 };
+enum DataParameter_CHANNELENCODING { DataParameter_CHANNELENCODING_UINT8 = 1, DataParameter_CHANNELENCODING_UINT16FLOW = 2, DataParameter_CHANNELENCODING_BOOL1 = 3 };
+enum DataParameter_RANDPERMORDER { DataParameter_RANDPERMORDER_FIRST_PERMUTE_THEN_RANGE = 0, DataParameter_RANDPERMORDER_FIRST_RANGE_THEN_PERMUTE = 1 };
+class DataParameter {           // caffe.proto:918-986, the fields CustomDataLayer reads, with the proto defaults
+ public:
+  const std::string& source() const { return source_; }
+  void set_source(const std::string& v) { source_ = v; }
+  unsigned batch_size() const { return batch_size_; }
+  void set_batch_size(unsigned v) { batch_size_ = v; }
+  unsigned rand_skip() const { return 0; }
+  DataParameter_DB backend() const { return backend_; }
+  void set_backend(DataParameter_DB v) { backend_ = v; }
+  float scale() const { return scale_; }
+  void set_scale(float v) { scale_ = v; }
+  bool has_mean_file() const { return false; }
+  const std::string& mean_file() const { return mean_file_; }
+  unsigned crop_size() const { return crop_size_; }
+  void set_crop_size(unsigned v) { crop_size_ = v; }
+  bool mirror() const { return false; }
+  bool has_preselection_file() const { return false; }
+  const std::string& preselection_file() const { return mean_file_; }
+  bool has_preselection_label() const { return false; }
+  int preselection_label() const { return 0; }
+  int range_start() const { return range_start_; }
+  void set_range_start(int v) { range_start_ = v; }
+  int range_end() const { return range_end_; }
+  void set_range_end(int v) { range_end_ = v; }
+  bool rand_permute() const { return false; }
+  DataParameter_RANDPERMORDER rand_permute_order() const { return DataParameter_RANDPERMORDER_FIRST_PERMUTE_THEN_RANGE; }
+  unsigned rand_permute_seed() const { return 0; }
+  const RepeatedField<unsigned>& slice_point() const { return slice_point_; }
+  void add_slice_point(unsigned v) { slice_point_.Add(v); }
+  const RepeatedField<int>& encoding() const { return encoding_; }
+  void add_encoding(int v) { encoding_.Add(v); }
+  bool verbose() const { return false; }
+  const RepeatedField<float>& subtract() const { return subtract_; }
+  void add_subtract(float v) { subtract_.Add(v); }
+  unsigned permute_every_iter() const { return 0; }
+  unsigned block_size() const { return 0; }
+ private:
+  std::string source_, mean_file_;
+  unsigned batch_size_ = 1, crop_size_ = 0;
+  DataParameter_DB backend_ = DataParameter_DB_LEVELDB;
+  float scale_ = 1.f;
+  int range_start_ = 0, range_end_ = -1;
+  RepeatedField<unsigned> slice_point_;
+  RepeatedField<int> encoding_;
+  RepeatedField<float> subtract_;
+};
+
 enum Phase { TRAIN = 0, TEST = 1 };
 
 class LayerParameter {
@@ -217,7 +334,10 @@ class LayerParameter {
   ConvolutionParameter* mutable_convolution_param() { return &convolution_param_; }
   const ReLUParameter& relu_param() const { return relu_param_; }
   ReLUParameter* mutable_relu_param() { return &relu_param_; }
+  const DataParameter& data_param() const { return data_param_; }                            // CustomData (oracle/_ref only)
+  DataParameter* mutable_data_param() { return &data_param_; }
  private:
+  DataParameter data_param_;
   std::string name_, type_;
   std::vector<float> loss_weight_;
   bool reshape_every_iter_ = true;

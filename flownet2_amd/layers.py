@@ -105,7 +105,7 @@ class Blob:
 class LayerParameter:
     """The subset of caffe.proto's LayerParameter (:312-425) these layers read.  The *_param dicts
     use the proto field names (correlation_param: caffe.proto:628-644, flow_warp_param :553-560,
-    resample_param :665-677, l1_loss_param :619-625, downsample_param :646-649)."""
+    resample_param :665-677, l1_loss_param :619-625, downsample_param :646-649, data_param :918-986)."""
     name: str = ""
     type: str = ""
     bottom: List[str] = field(default_factory=list)
@@ -117,6 +117,7 @@ class LayerParameter:
     resample_param: Dict = field(default_factory=dict)
     l1_loss_param: Dict = field(default_factory=dict)
     downsample_param: Dict = field(default_factory=dict)
+    data_param: Dict = field(default_factory=dict)      # DataParameter, caffe.proto:918-986 (CustomData)
 
 
 class Layer:
@@ -430,6 +431,120 @@ class DownsampleLayer(Layer):
             raise CheckError("DownsamplingLayer cannot do backward.")                 # downsample_layer.cu:132-138
 
 
+class CustomDataLayer(Layer):
+    """include/caffe/layers/custom_data_layer.hpp; custom_data_layer.cpp: LayerSetUp :326-633, the prefetch :138-303, Forward :664-699.
+
+    `data_param.source` is, in the reference, the path of an LMDB environment.  The storage engine is out of scope here: `source`
+    is the sequence of (key, value) records such an environment holds (any iterable of pairs or a dict); the layer sorts them by key
+    and positions its cursor with the same "%08d" lower-bound lookup (MDB_SET_RANGE, :181-186).  The values are parsed on the host
+    (Datum header only), their packed `data` bytes go to the GPU and fn2_custom_data_decode_forward produces the tops; the
+    reference decodes on one prefetch thread and uploads fp32 blobs.  Not reproduced: rand_permute (std::random_shuffle seeded with
+    std::srand, :29-42 -- the order depends on the C library), mean_file (a BlobProto on disk), preselection files."""
+
+    def type(self): return "CustomData"
+    def ExactNumBottomBlobs(self): return 0
+    def MinTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        import bisect
+        from . import sample_format as SF
+        dp = self.layer_param_.data_param
+        enc_names = {"UINT8": SF.UINT8, "UINT16FLOW": SF.UINT16FLOW, "BOOL1": SF.BOOL1}
+        self.slice_point_ = [int(s) for s in dp.get("slice_point", [])]
+        self.channel_encoding_ = [enc_names.get(e, e) for e in dp.get("encoding", [])]
+        self.iter_ = 0
+        n_slices = len(self.slice_point_) + 1
+        if len(top) == n_slices:                                                               # :340-346
+            self.output_labels_ = False
+        elif len(top) == n_slices + 1:
+            self.output_labels_ = True
+        else:
+            raise CheckError(f"CustomDataLayer has {len(top)} top blobs, but {n_slices} slices.")
+        backend = dp.get("backend", "LEVELDB")                                                 # proto default, caffe.proto:945
+        CHECK(backend in ("LMDB", 1), "LevelDB not supported by CustomData" if backend in ("LEVELDB", 0) else "Unknown database backend")
+        for unsupported in ("rand_permute", "mean_file", "preselection_file"):
+            CHECK(not dp.get(unsupported), f"CustomData: {unsupported} is not reproduced by flownet2_amd (see the class docstring)")
+        src = dp.get("source")
+        CHECK(src is not None and len(src) > 0, "mdb_env_open failed")                         # :359-361
+        items = src.items() if isinstance(src, dict) else src
+        recs = sorted(((k.encode() if isinstance(k, str) else bytes(k)), v) for k, v in items)
+        self.keys_ = [k for k, _ in recs]
+        self.values_ = [v for _, v in recs]
+        self.bisect_ = bisect.bisect_left
+        self.database_entries_ = len(recs)
+        perm = list(range(self.database_entries_))                                             # :415-418
+        self.range_start_ = int(dp.get("range_start", 0))
+        self.range_end_ = int(dp.get("range_end", -1))
+        if self.range_start_ < 0: self.range_start_ = 0                                        # :424-430
+        if self.range_start_ >= len(perm): self.range_start_ = len(perm) - 1
+        if self.range_end_ < 0 or self.range_end_ >= len(perm): self.range_end_ = len(perm) - 1
+        CHECK(self.range_end_ >= self.range_start_, "Range end is before start.")
+        self.range_size_ = self.range_end_ - self.range_start_ + 1
+        self.permutation_vector_ = perm[self.range_start_: self.range_end_ + 1]                # :446-452
+        CHECK(not dp.get("rand_skip"), "No rand_skip for CustomData layer")                    # :486-488
+        self.datum_index_ = 0
+        d = SF.parse_datum(self.values_[0])                                                    # first record shapes the tops, :490-499
+        CHECK(int(dp.get("crop_size", 0)) == 0, "Cropping currently not supported")            # :503-506
+        batch = int(dp.get("batch_size", 1))
+        self.batch_size_ = batch
+        if self.slice_point_:                                                                  # :512-546
+            CHECK(len(self.slice_point_) == len(top) - 1, f"Check failed: slice_point_.size() == top.size() - 1 ({len(self.slice_point_)} vs. {len(top) - 1})")
+            CHECK(len(top) <= d.channels, "Check failed: top.size() <= datum.channels()")
+            prev, slices = 0, []
+            for sp in self.slice_point_:
+                CHECK(sp > prev, f"Check failed: slice_point_[i] > prev ({sp} vs. {prev})")
+                slices.append(sp - prev)
+                prev = sp
+            slices.append(d.channels - prev)
+            for i in range(len(top)):
+                top[i].Reshape(batch, slices[i], d.height, d.width)
+        else:
+            top[0].Reshape(batch, d.channels, d.height, d.width)                               # :558-560
+        if self.output_labels_:
+            top[len(self.slice_point_) + 1].Reshape(batch, 1, 1, 1)                            # :569-571
+        self.datum_channels_, self.datum_height_, self.datum_width_ = d.channels, d.height, d.width
+        CHECK(SF.sample_bytes(d.channels, d.height, d.width, self.slice_point_, self.channel_encoding_) > 0, "unreachable")
+        sub = [float(x) for x in dp.get("subtract", [])]                                       # :591-610: one constant plane per listed channel
+        self.mean_host_ = None
+        if sub:
+            CHECK(len(sub) <= d.channels, "more subtract values than channels")
+            self.mean_host_ = torch.zeros(d.channels, d.height * d.width)
+            for i, m in enumerate(sub):
+                self.mean_host_[i] = m
+        self.mean_ = None
+        self.scale_ = float(dp.get("scale", 1.0))
+
+    def Reshape(self, bottom, top):                                                            # :636-639: empty in the reference
+        pass
+
+    def _next_record(self):
+        """CustomDataLayerPrefetch, :170-189: wrap around, permuted index -> "%08d" key -> first record with key >= it."""
+        if self.datum_index_ >= self.range_size_:
+            self.datum_index_ = 0
+        db_index = self.permutation_vector_[self.datum_index_]
+        pos = self.bisect_(self.keys_, b"%08d" % db_index)
+        CHECK(pos < len(self.keys_), f"Internal data fetch error: Tried to fetch element {self.datum_index_} of {self.range_size_} which is in DB: {db_index}")
+        self.datum_index_ += 1
+        return self.values_[pos]
+
+    def Forward_gpu(self, bottom, top):
+        from . import sample_format as SF
+        records = [self._next_record() for _ in range(self.batch_size_)]
+        samples, shape, labels = _wrap(SF.stage_records, records, top[0].device)
+        CHECK(shape == (self.datum_channels_, self.datum_height_, self.datum_width_), "records of different shapes in one database")
+        if self.mean_host_ is not None and self.mean_ is None:
+            self.mean_ = self.mean_host_.to(top[0].device)
+        tops = _wrap(SF.decode_batch, samples, *shape, self.slice_point_, self.channel_encoding_, self.mean_, self.scale_)
+        for i, t in enumerate(tops):
+            top[i].data = t
+        if self.output_labels_:
+            top[len(self.slice_point_) + 1].data = torch.tensor(labels, dtype=torch.float32, device=top[0].device).view(-1, 1, 1, 1)
+        self.iter_ += 1
+
+    def Backward_gpu(self, top, propagate_down, bottom):                                       # hpp:49-52: empty
+        pass
+
+
 class LayerRegistry:
     """include/caffe/layer_factory.hpp:53-114."""
     _registry: Dict[str, Callable[[LayerParameter], Layer]] = {}
@@ -461,3 +576,4 @@ REGISTER_LAYER_CLASS("Resample", ResampleLayer)            # resample_layer.cpp:
 REGISTER_LAYER_CLASS("L1Loss", L1LossLayer)                # l1loss_layer.cpp:108-109
 REGISTER_LAYER_CLASS("ChannelNorm", ChannelNormLayer)      # channel_norm_layer.cpp:193-194
 REGISTER_LAYER_CLASS("Downsample", DownsampleLayer)        # downsample_layer.cpp:78-79
+REGISTER_LAYER_CLASS("CustomData", CustomDataLayer)        # custom_data_layer.cpp:712-713

@@ -161,3 +161,36 @@ def convolution(x, weight, bias=None, kernel=3, stride=1, pad=1, deconv=False, r
     out = np.empty(tuple(shape), np.float32)
     _chk(L.fn2ref_convolution(*args, _p(out), shape))
     return out
+
+
+def custom_data(records, batch_size, slice_points=(), encodings=(), scale=1.0, subtract=(), range_start=0, range_end=-1,
+                n_forward=1, with_labels=False):
+    """The reference's CustomDataLayer (custom_data_layer.cpp) over an in-memory stand-in for LMDB.  records: list of (key, value
+    bytes) = serialized Datums.  Runs on the CPU path (the layer has no other).  Returns (tops, labels): tops[s] is
+    [n_forward * batch, slice channels, H, W]."""
+    n = len(records)
+    keys = (C.c_char_p * n)(*[k.encode() if isinstance(k, str) else k for k, _ in records])
+    bufs = [np.frombuffer(v, dtype=np.uint8) for _, v in records]
+    vals = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    sp = (C.c_int * max(1, len(slice_points)))(*slice_points)
+    en = (C.c_int * max(1, len(encodings)))(*encodings)
+    sub = (C.c_float * max(1, len(subtract)))(*subtract)
+    ntop = len(slice_points) + 1
+    shapes = (C.c_int * (4 * ntop))()
+    L = lib()
+    L.fn2ref_custom_data.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                     C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.POINTER(C.c_float), C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_int)]
+    # the top shapes come from the first datum (custom_data_layer.cpp:527-536); size the outputs from the record itself
+    from . import datum_parse
+    d = datum_parse(records[0][1])
+    bounds = [0] + list(slice_points) + [d["channels"]]
+    tops = [np.empty((n_forward * batch_size, max(b - a, 0), d["height"], d["width"]), np.float32) for a, b in zip(bounds, bounds[1:])]
+    ptrs = (C.c_void_p * ntop)(*[t.ctypes.data for t in tops])
+    labels = np.empty(n_forward * batch_size, np.float32) if with_labels else None
+    _chk(L.fn2ref_custom_data(keys, vals, lens, n, batch_size, sp, len(slice_points), en, len(encodings), scale, sub, len(subtract),
+                              range_start, range_end, n_forward, ptrs, C.c_void_p(labels.ctypes.data) if with_labels else None, shapes))
+    for s, t in enumerate(tops):
+        assert tuple(shapes[4 * s:4 * s + 4]) == (batch_size,) + t.shape[1:], (tuple(shapes[4 * s:4 * s + 4]), t.shape)
+    return tops, labels

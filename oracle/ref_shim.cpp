@@ -252,3 +252,50 @@ int fn2ref_l1loss(int l2_per_location, int prescale, int normalize, float epsilo
   });
 }
 #endif
+
+#ifdef FN2_SHIM_DATA
+// The reference's CustomDataLayer (custom_data_layer.cpp, compiled in place) over the in-memory LMDB stand-in: registers the given
+// (key, value) records as a database, creates the layer through the registry, runs n_forward batches on the CPU path (the layer has
+// no other: Forward_gpu calls Forward_cpu) and copies every top out.  tops_out[s] receives n_forward * batch * slice_channels * H * W
+// floats; labels_out (nullable) n_forward * batch.
+#include "lmdb.h"
+extern "C" __attribute__((visibility("default")))
+int fn2ref_custom_data(const char* const* keys, const unsigned char* const* values, const size_t* value_bytes, int n_records,
+                       int batch_size, const int* slice_points, int n_slice_points, const int* encodings, int n_encodings,
+                       float scale, const float* subtract, int n_subtract, int range_start, int range_end, int n_forward,
+                       float* const* tops_out, float* labels_out, int* top_shapes /* [(n_slice_points + 1) * 4] */) {
+  return guard([&] {
+    static int counter = 0;
+    const std::string source = "mem:" + std::to_string(counter++);
+    fn2_fake_db& db = fn2_fake_lmdb_sources()[source];
+    for (int i = 0; i < n_records; ++i) db[keys[i]] = std::string(reinterpret_cast<const char*>(values[i]), value_bytes[i]);
+    Caffe::set_mode(Caffe::CPU);
+    {
+      LayerParameter lp;
+      lp.set_type("CustomData");
+      DataParameter* dp = lp.mutable_data_param();
+      dp->set_source(source); dp->set_backend(DataParameter_DB_LMDB); dp->set_batch_size(batch_size); dp->set_scale(scale);
+      dp->set_range_start(range_start); dp->set_range_end(range_end);
+      for (int i = 0; i < n_slice_points; ++i) dp->add_slice_point(slice_points[i]);
+      for (int i = 0; i < n_encodings; ++i) dp->add_encoding(encodings[i]);
+      for (int i = 0; i < n_subtract; ++i) dp->add_subtract(subtract[i]);
+      shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+      const int ntop = n_slice_points + 1 + (labels_out ? 1 : 0);
+      std::vector<Blob<float> > blobs(ntop);
+      vector<Blob<float>*> bottom, tops;
+      for (auto& b : blobs) tops.push_back(&b);
+      layer->SetUp(bottom, tops);
+      for (int s = 0; s <= n_slice_points; ++s)
+        for (int a = 0; a < 4; ++a) top_shapes[s * 4 + a] = blobs[s].shape(a);
+      for (int f = 0; f < n_forward; ++f) {
+        layer->Forward(bottom, tops);
+        for (int s = 0; s <= n_slice_points; ++s)
+          std::memcpy(tops_out[s] + (size_t)f * blobs[s].count(), blobs[s].cpu_data(), sizeof(float) * blobs[s].count());
+        if (labels_out) std::memcpy(labels_out + (size_t)f * batch_size, blobs[n_slice_points + 1].cpu_data(), sizeof(float) * batch_size);
+      }
+    }   // the layer joins its prefetch thread and closes the "database" here
+    fn2_fake_lmdb_sources().erase(source);
+    Caffe::set_mode(Caffe::GPU);
+  });
+}
+#endif

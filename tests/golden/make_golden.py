@@ -3,7 +3,7 @@
 reference's CUDA kernels built as HIP by oracle/ref_build.sh and executed on an MI355X) on small seeded inputs.
 Run on the GPU box:   python tests/golden/make_golden.py gpurun_out/ref_golden.npz
 then copy the file to tests/golden/.  `--only corr1d --base tests/golden/ref_golden.npz` generates one section and keeps the
-other arrays of an existing file (sections: main, corr1d, corr1d_left).  tests/test_golden.py pins the C oracle (and, on the GPU, the HIP kernels)
+other arrays of an existing file (sections: main, corr1d, corr1d_left, custom_data -- the last one needs no GPU).  tests/test_golden.py pins the C oracle (and, on the GPU, the HIP kernels)
 against it; it needs neither the reference tree nor oracle/_ref."""
 import os
 import sys
@@ -63,6 +63,36 @@ def corr1d_undefined_mask(case, top_shape):
     return mt, m0
 
 
+# CustomData: (H, W, records, batch, slice_point, encoding, scale, subtract, range_start, range_end, forwards)
+CUSTOM_DATA = [
+    (6, 10, 5, 2, (3, 6, 8), (1, 1, 2, 3), 1.0, (), 0, -1, 4),                                   # wraps around after 5 records
+    (7, 13, 4, 3, (3, 6, 8), (1, 1, 2, 3), 1.0 / 255, (104, 117, 123, 104, 117, 123), 0, -1, 2),  # H*W % 8 != 0, per-channel means, scale
+    (5, 9, 6, 2, (6,), (1, 2), 0.5, (1, 2, 3, 4, 5, 6, 0.25, 0.5), 1, 4, 3),                      # 2 slices (images | flow), range [1,4]
+    (4, 8, 3, 2, (), (), 1.0, (), 0, -1, 2),                                                      # no slicing: one top, everything UINT8
+]
+
+
+def custom_data_records(i):
+    """LMDB (key, value) pairs of case i: keys as the writer tool makes them ("%08d_<name>", convert_imageset_and_flow.cpp:416), values =
+    serialized Datums packed by the oracle's restatement of the writer."""
+    import oracle
+    H, W, n, batch, sp, enc, scale, sub, r0, r1, fw = CUSTOM_DATA[i]
+    recs = []
+    for r in range(n):
+        rng = np.random.default_rng(2000 + 10 * i + r)
+        a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        b = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        f = (rng.standard_normal((2, H, W)) * 12).astype(np.float32)
+        f[rng.random((2, H, W)) < 0.1] = np.nan
+        o = rng.random((H, W)) < 0.3
+        channels = 9 if len(sp) != 1 else 8                # case 2 stores images + flow only
+        data = oracle.custom_data_encode_sample(a, b, f, o)
+        if channels == 8:
+            data = data[:10 * H * W]
+        recs.append(("%08d_pair%d" % (r, r), oracle.datum_serialize(channels, H, W, data, 100 + r)))
+    return recs
+
+
 def stock_inputs(which):
     if which == "stem":
         return rnd((1, 3, 24, 32), 1000), rnd((64, 3, 7, 7), 1001, 0.1), rnd((64,), 1002)
@@ -108,6 +138,11 @@ def main(out, only=None, base=None):
         corr1d_section(g, False)
     if only == "corr1d_left":
         corr1d_section(g, True)
+    if only in (None, "custom_data"):          # the reference's CustomData layer runs on the CPU: no GPU needed for this section
+        for i, (H, W, n, batch, sp, enc, scale, sub, r0, r1, fw) in enumerate(CUSTOM_DATA):
+            tops, _ = ref.custom_data(custom_data_records(i), batch, sp, enc, scale, sub, r0, r1, fw)
+            for s_, t in enumerate(tops):
+                g[f"cdata{i}_top{s_}"] = t.view(np.uint32)     # bit patterns (NaN payloads included)
     if only in (None, "main"):
         main_section(g)
     np.savez_compressed(out, **g)
@@ -169,7 +204,7 @@ if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("out", nargs="?", default=os.path.join(os.path.dirname(__file__), "ref_golden.npz"))
-    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left"], default=None)
+    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left", "custom_data"], default=None)
     ap.add_argument("--base", default=None, help="existing .npz whose arrays are kept")
     a = ap.parse_args()
     main(a.out, a.only, a.base)

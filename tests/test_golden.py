@@ -99,6 +99,65 @@ def test_hip_correlation1d_matches_reference_kernels(gold, left, i):
     _corr1d_check(gold, left, i, lambda prm, a, b: ops.correlation1d_forward(P(prm), dev(a), dev(b)).cpu().numpy(), bwd, 2e-6)
 
 
+def _cdata_expected_order(i):
+    """Record index of every decoded sample: the cursor walks [range_start, range_end] and wraps (custom_data_layer.cpp:170-189)."""
+    H, W, n, batch, sp, enc, scale, sub, r0, r1, fw = MG.CUSTOM_DATA[i]
+    r1 = n - 1 if (r1 < 0 or r1 >= n) else r1
+    span = list(range(max(r0, 0), r1 + 1))
+    return [span[k % len(span)] for k in range(batch * fw)]
+
+
+def _cdata_inputs(i):
+    H, W, n, batch, sp, enc, scale, sub, r0, r1, fw = MG.CUSTOM_DATA[i]
+    recs = MG.custom_data_records(i)
+    datums = [oracle.datum_parse(v) for _, v in recs]
+    channels = datums[0]["channels"]
+    samples = np.stack([np.frombuffer(datums[k]["data"], np.uint8) for k in _cdata_expected_order(i)])
+    mean = None
+    if sub:
+        mean = np.zeros((channels, H * W), np.float32)
+        mean[:len(sub)] = np.asarray(sub, np.float32)[:, None]
+    return recs, samples, channels, mean
+
+
+@pytest.mark.parametrize("i", range(len(MG.CUSTOM_DATA)))
+def test_oracle_custom_data_decode_matches_the_reference_layer(gold, i):
+    """Golden = tops of the reference's CustomDataLayer (compiled in place, in-memory LMDB stand-in) over n_forward batches."""
+    H, W, n, batch, sp, enc, scale, sub, r0, r1, fw = MG.CUSTOM_DATA[i]
+    recs, samples, channels, mean = _cdata_inputs(i)
+    tops = oracle.custom_data_decode(samples, channels, H, W, sp, enc, mean=mean, scale=scale)
+    assert len(tops) == len(sp) + 1
+    for s_, t in enumerate(tops):
+        assert np.array_equal(t.view(np.uint32), gold[f"cdata{i}_top{s_}"]), (i, s_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(MG.CUSTOM_DATA)))
+def test_hip_custom_data_layer_matches_the_reference_layer(gold, i):
+    import torch
+    from flownet2_amd import sample_format as SF
+    from flownet2_amd.layers import Blob, LayerParameter, LayerRegistry
+    H, W, n, batch, sp, enc, scale, sub, r0, r1, fw = MG.CUSTOM_DATA[i]
+    recs, samples, channels, mean = _cdata_inputs(i)
+    got = SF.decode_batch(torch.from_numpy(samples).cuda(), channels, H, W, sp, enc,
+                          mean=torch.from_numpy(mean).cuda() if mean is not None else None, scale=scale)
+    for s_, t in enumerate(got):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), gold[f"cdata{i}_top{s_}"]), (i, s_)
+    # the same through the Layer mirror, batch by batch, the way Net::Forward drives the reference layer
+    lp = LayerParameter(name="data", type="CustomData",
+                        data_param=dict(source=recs, backend="LMDB", batch_size=batch, slice_point=list(sp), encoding=list(enc), scale=scale,
+                                        subtract=list(sub), range_start=r0, range_end=r1))
+    layer = LayerRegistry.CreateLayer(lp)
+    top = [Blob() for _ in range(len(sp) + 1)]
+    layer.SetUp([], top)
+    for f in range(fw):
+        layer.Forward([], top)
+        for s_, t in enumerate(top):
+            want = gold[f"cdata{i}_top{s_}"][f * batch:(f + 1) * batch]
+            assert t.shape() == list(want.shape)
+            assert np.array_equal(t.cpu_data().view(np.uint32), want), (i, f, s_)
+
+
 def test_oracle_flow_warp_matches_reference_gpu_and_cpu_code(gold):
     img, flow, wd = MG.rnd((2, 3, 13, 17), 400), MG.rnd((2, 2, 13, 17), 401, 4.0), MG.rnd((2, 3, 13, 17), 402)
     flow[0, :, 0, 0] = 0

@@ -35,6 +35,38 @@ def test_reference_cpu_channel_norm_equals_oracle():
     np.testing.assert_allclose(oracle.channel_norm_backward(x, top, g), d, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", [(12, 20, 7, 3, 5), (5, 7, 3, 2, 4), (1, 1, 2, 1, 3), (9, 1, 4, 4, 2), (24, 32, 3, 2, 1)])
+def test_reference_custom_data_layer_equals_oracle(case):
+    """The reference's CustomDataLayer runs on the CPU (Forward_gpu = Forward_cpu, custom_data_layer.cu:19-23): records packed by the
+    oracle's writer restatement, served by the in-memory LMDB stand-in, decoded by the reference, against the oracle's decode."""
+    H, W, n, batch, fw = case
+    rng = np.random.default_rng(H * 1000 + W)
+    recs, datas = [], []
+    for r in range(n):
+        a = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        b = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        f = (rng.standard_normal((2, H, W)) * 30).astype(np.float32)
+        f[rng.random((2, H, W)) < 0.1] = np.nan
+        o = rng.random((H, W)) < 0.5
+        datas.append(oracle.custom_data_encode_sample(a, b, f, o))
+        recs.append(("%08d_x" % r, oracle.datum_serialize(9, H, W, datas[-1], r)))
+    sp, enc = (3, 6, 8), (1, 1, 2, 3)
+    sub = (10.5, 20.25, 30, 40, 50, 60, 0.5, -0.5, 0.25)
+    order = [k % n for k in range(batch * fw)]
+    samples = np.stack([np.frombuffer(datas[k], np.uint8) for k in order])
+    mean = np.repeat(np.asarray(sub, np.float32), H * W)
+    for scale, subtract, m in [(1.0, (), None), (0.00390625, sub, mean), (3.0, sub[:3], np.concatenate([mean[:3 * H * W], np.zeros(6 * H * W, np.float32)]))]:
+        tops, _ = ref.custom_data(recs, batch, sp, enc, scale, subtract, 0, -1, fw)
+        want = oracle.custom_data_decode(samples, 9, H, W, sp, enc, mean=m, scale=scale)
+        for t, w in zip(tops, want):
+            assert np.array_equal(t.view(np.uint32), w.view(np.uint32))
+    # labels only without slicing (with slice points the reference CHECK-fails when a label top is requested, :513)
+    tops, labels = ref.custom_data(recs, batch, (), (), 1.0, (), 0, -1, fw, with_labels=True)
+    assert labels.tolist() == [float(k) for k in order]
+    want = oracle.custom_data_decode(np.stack([np.frombuffer(datas[k], np.uint8)[:9 * H * W] for k in order]), 9, H, W)
+    assert np.array_equal(tops[0], want[0])          # default encoding: every channel UINT8 (only the first 9*H*W bytes are read)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(2, 64, 24, 40, 20, 1, 20, 1, 2, 0), (1, 256, 16, 24, 20, 1, 20, 1, 2, 0),
                                   (1, 8, 11, 13, 4, 3, 2, 1, 2, 1), (1, 12, 10, 12, 6, 1, 6, 2, 3, 0)])

@@ -260,6 +260,40 @@ def test_records_round_trip_through_the_datum_container():
     assert (p.channels, p.height, p.width, p.label, p.data) == (9, H, W, 42, d.data)
 
 
+def test_custom_data_layer_mirror_setup_and_checks():
+    """Host logic of the Layer mirror (no GPU work in SetUp): top shapes from the first record, the reference's CHECKs, the cursor."""
+    from flownet2_amd.layers import Blob, CheckError, LayerParameter, LayerRegistry
+    H, W = 6, 10
+    recs = [("%08d_p%d" % (i, i), SF.make_record(*_sample_inputs(H, W, i), label=i)) for i in range(5)]
+
+    def make(ntop, **dp):
+        base = dict(source=recs, backend="LMDB", batch_size=2, slice_point=list(SP), encoding=["UINT8", "UINT8", "UINT16FLOW", "BOOL1"])
+        base.update(dp)
+        layer = LayerRegistry.CreateLayer(LayerParameter(name="data", type="CustomData", data_param=base))
+        top = [Blob(device="cpu") for _ in range(ntop)]
+        layer.SetUp([], top)
+        return layer, top
+    layer, top = make(4)
+    assert [t.shape() for t in top] == [[2, 3, H, W], [2, 3, H, W], [2, 2, H, W], [2, 1, H, W]]
+    assert layer.channel_encoding_ == list(ENC)
+    order = [SF.parse_datum(layer._next_record()).label for _ in range(12)]
+    assert order == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 0, 1]                      # wraps around (:177)
+    layer, top = make(4, range_start=1, range_end=3, source=dict(reversed(recs)))   # any record order: the environment is sorted by key
+    assert [SF.parse_datum(layer._next_record()).label for _ in range(5)] == [1, 2, 3, 1, 2]
+    layer, top = make(2, slice_point=[], encoding=[])
+    assert [t.shape() for t in top] == [[2, 9, H, W], [2, 1, 1, 1]] and layer.output_labels_
+    for ntop, dp, msg in [(3, {}, "has 3 top blobs, but 4 slices"), (4, dict(backend="LEVELDB"), "LevelDB not supported"),
+                          (4, dict(crop_size=4), "Cropping currently not supported"), (4, dict(rand_skip=3), "No rand_skip"),
+                          (5, {}, "slice_point_.size\\(\\) == top.size\\(\\) - 1"),           # labels + slicing: the reference's own CHECK (:513)
+                          (4, dict(range_start=3, range_end=1), "Range end is before start"),
+                          (4, dict(slice_point=[3, 3, 8]), "slice_point_\\[i\\] > prev"), (4, dict(rand_permute=True), "rand_permute is not reproduced"),
+                          (4, dict(source=[]), "mdb_env_open failed")]:
+        with pytest.raises(CheckError, match=msg):
+            make(ntop, **dp)
+    with pytest.raises(CheckError):                                             # bottoms are not allowed (ExactNumBottomBlobs = 0)
+        LayerRegistry.CreateLayer(LayerParameter(type="CustomData", data_param=dict(source=recs, backend="LMDB"))).SetUp([Blob(device="cpu")], [Blob(device="cpu")])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # GPU: decode kernels vs the oracle, bit for bit
 # ---------------------------------------------------------------------------------------------------------
