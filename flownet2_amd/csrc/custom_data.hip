@@ -4,7 +4,7 @@
 // DecodeData + CustomDataLayerPrefetch (src/caffe/layers/custom_data_layer.cpp:44-136, :209-300).  The reference decodes on one
 // host thread into fp32 blobs and uploads those; here the packed bytes stay packed until they are in HBM:
 //   per pixel 10.125 B are read (6 B images, 4 B flow, 1 bit occlusion) and 36 B written (9 fp32 planes) -- HBM-bound streaming,
-//   one kernel per slice, 4 outputs per thread for the byte / int16 planes and 8 per thread for the bit plane.
+//   one launch for the whole batch, 4 outputs per thread for the byte / int16 planes and 8 per thread for the bit plane.
 #include "fn2_common.hpp"
 
 #include <cstdint>
@@ -124,42 +124,26 @@ static int make_slices(int channels, int H, int W, const int* sp, int nsp, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Decode kernels.  grid.y = sample; each thread produces 4 (8 for bits) consecutive elements of the slice.
+// Decode kernel: ONE launch for all slices of all samples (a batch of eight 512x384 samples is 72 MB of traffic; four separate
+// launches of 6-9 us each spend most of their time ramping up and draining).  grid = (blocks of the largest slice, sample, slice);
+// a block works on one slice only, so the format switch is uniform.  Each thread produces 4 consecutive elements (8 for bits).
 // ---------------------------------------------------------------------------------------------------------
-struct DecodeArgs {
-  const unsigned char* samples;
-  size_t stride, offset;       // sample stride, byte offset of the slice inside a sample
+struct SliceArgs {
+  size_t offset;               // byte offset of the slice inside a sample
+  size_t count;                // cc * H * W elements of the slice per sample
   const float* mean;           // already offset to the slice's first channel, or NULL
   float* top;
-  size_t count;                // cc * H * W elements of the slice per sample
+  int enc;                     // FN2_ENC_*, 0 = fp32 payload
+};
+struct DecodeArgs {
+  const unsigned char* samples;
+  size_t stride;
   float scale;
+  SliceArgs slice[kMaxSlices];
 };
 
 __device__ __forceinline__ float finish(float v, const float* mean, size_t i, float scale) {
   return (v - (mean ? mean[i] : 0.f)) * scale;                                                // :282
-}
-
-__global__ void __launch_bounds__(256) decode_u8(DecodeArgs a) {
-  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + a.offset;
-  float* dst = a.top + (size_t)blockIdx.y * a.count;
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= a.count) return;
-  if (i + 4 <= a.count) {
-    unsigned char b[4];
-    if ((reinterpret_cast<uintptr_t>(src + i) & 3) == 0) {
-      const uint32_t w = *reinterpret_cast<const uint32_t*>(src + i);
-      b[0] = w & 0xff; b[1] = (w >> 8) & 0xff; b[2] = (w >> 16) & 0xff; b[3] = w >> 24;
-    } else {
-      b[0] = src[i]; b[1] = src[i + 1]; b[2] = src[i + 2]; b[3] = src[i + 3];
-    }
-    float o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = finish((float)b[k], a.mean, i + k, a.scale);            // :88-92
-    if ((reinterpret_cast<uintptr_t>(dst + i) & 15) == 0) *reinterpret_cast<float4*>(dst + i) = make_float4(o[0], o[1], o[2], o[3]);
-    else { dst[i] = o[0]; dst[i + 1] = o[1]; dst[i + 2] = o[2]; dst[i + 3] = o[3]; }
-  } else {
-    for (size_t k = i; k < a.count; ++k) dst[k] = finish((float)src[k], a.mean, k, a.scale);
-  }
 }
 
 __device__ __forceinline__ float flow_value(unsigned lo, unsigned hi) {
@@ -168,41 +152,58 @@ __device__ __forceinline__ float flow_value(unsigned lo, unsigned hi) {
   return v == 32767 ? __uint_as_float(0x7fa00000u) : (float)v / 32.0f;                         // :107
 }
 
-__global__ void __launch_bounds__(256) decode_i16flow(DecodeArgs a) {
-  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + a.offset;
-  float* dst = a.top + (size_t)blockIdx.y * a.count;
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= a.count) return;
-  const size_t n = (i + 4 <= a.count) ? 4 : a.count - i;
-  float o[4];
-  if (n == 4 && (reinterpret_cast<uintptr_t>(src + 2 * i) & 7) == 0) {
-    const uint2 w = *reinterpret_cast<const uint2*>(src + 2 * i);
-    o[0] = flow_value(w.x & 0xff, (w.x >> 8) & 0xff); o[1] = flow_value((w.x >> 16) & 0xff, w.x >> 24);
-    o[2] = flow_value(w.y & 0xff, (w.y >> 8) & 0xff); o[3] = flow_value((w.y >> 16) & 0xff, w.y >> 24);
-  } else {
-    for (size_t k = 0; k < n; ++k) o[k] = flow_value(src[2 * (i + k)], src[2 * (i + k) + 1]);
-  }
-  for (size_t k = 0; k < n; ++k) o[k] = finish(o[k], a.mean, i + k, a.scale);
+__device__ __forceinline__ void store4(float* dst, size_t i, size_t n, const float* o) {
   if (n == 4 && (reinterpret_cast<uintptr_t>(dst + i) & 15) == 0) *reinterpret_cast<float4*>(dst + i) = make_float4(o[0], o[1], o[2], o[3]);
   else for (size_t k = 0; k < n; ++k) dst[i + k] = o[k];
 }
 
-__global__ void __launch_bounds__(256) decode_bool1(DecodeArgs a) {
-  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + a.offset;
-  float* dst = a.top + (size_t)blockIdx.y * a.count;
-  const size_t byte = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i = byte * 8;
-  if (i >= a.count) return;
-  const unsigned d = src[byte];
-  for (int k = 0; k < 8; ++k)                                                                 // :117-126, LSB first
-    if (i + k < a.count) dst[i + k] = finish(((d >> k) & 1u) ? 1.f : 0.f, a.mean, i + k, a.scale);
-}
-
-__global__ void __launch_bounds__(256) decode_f32(DecodeArgs a) {
-  const float* src = reinterpret_cast<const float*>(a.samples + (size_t)blockIdx.y * a.stride + a.offset);
-  float* dst = a.top + (size_t)blockIdx.y * a.count;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < a.count) dst[i] = finish(src[i], a.mean, i, a.scale);                               // :57-58
+__global__ void __launch_bounds__(256) decode_samples(DecodeArgs a) {
+  const SliceArgs& s = a.slice[blockIdx.z];
+  const unsigned char* src = a.samples + (size_t)blockIdx.y * a.stride + s.offset;
+  float* dst = s.top + (size_t)blockIdx.y * s.count;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s.enc == FN2_ENC_BOOL1) {                                                               // :113-128, LSB first
+    const size_t i = t * 8;
+    if (i >= s.count) return;
+    const unsigned d = src[t];
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = ((d >> k) & 1u) ? 1.f : 0.f;
+    for (int h = 0; h < 2; ++h) {
+      const size_t j = i + 4 * h;
+      if (j >= s.count) break;
+      const size_t n = (j + 4 <= s.count) ? 4 : s.count - j;
+      float q[4];
+      for (size_t k = 0; k < n; ++k) q[k] = finish(o[4 * h + k], s.mean, j + k, a.scale);
+      store4(dst, j, n, q);
+    }
+    return;
+  }
+  const size_t i = t * 4;
+  if (i >= s.count) return;
+  const size_t n = (i + 4 <= s.count) ? 4 : s.count - i;
+  float o[4];
+  if (s.enc == FN2_ENC_UINT8) {                                                               // :88-92
+    if (n == 4 && (reinterpret_cast<uintptr_t>(src + i) & 3) == 0) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(src + i);
+      o[0] = (float)(w & 0xff); o[1] = (float)((w >> 8) & 0xff); o[2] = (float)((w >> 16) & 0xff); o[3] = (float)(w >> 24);
+    } else {
+      for (size_t k = 0; k < n; ++k) o[k] = (float)src[i + k];
+    }
+  } else if (s.enc == FN2_ENC_UINT16FLOW) {                                                   // :94-111
+    if (n == 4 && (reinterpret_cast<uintptr_t>(src + 2 * i) & 7) == 0) {
+      const uint2 w = *reinterpret_cast<const uint2*>(src + 2 * i);
+      o[0] = flow_value(w.x & 0xff, (w.x >> 8) & 0xff); o[1] = flow_value((w.x >> 16) & 0xff, w.x >> 24);
+      o[2] = flow_value(w.y & 0xff, (w.y >> 8) & 0xff); o[3] = flow_value((w.y >> 16) & 0xff, w.y >> 24);
+    } else {
+      for (size_t k = 0; k < n; ++k) o[k] = flow_value(src[2 * (i + k)], src[2 * (i + k) + 1]);
+    }
+  } else {                                                                                    // fp32 payload (Datum.float_data, :57-58)
+    const float* f = reinterpret_cast<const float*>(src);
+    for (size_t k = 0; k < n; ++k) o[k] = f[i + k];
+  }
+  for (size_t k = 0; k < n; ++k) o[k] = finish(o[k], s.mean, i + k, a.scale);
+  store4(dst, i, n, o);
 }
 
 }  // namespace fn2
@@ -296,18 +297,20 @@ FN2_API int fn2_custom_data_decode_forward(const void* samples, size_t sample_st
   if (float_data && sample_stride % 4) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: float samples need a stride that is a multiple of 4");
   if (N > 65535) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: batch of %d samples (max 65535)", N);
   const size_t hw = (size_t)H * W;
-  hipStream_t st = as_stream(stream);
+  DecodeArgs a{};
+  a.samples = static_cast<const unsigned char*>(samples);
+  a.stride = sample_stride;
+  a.scale = scale;
+  size_t max_threads = 0;
   for (int s = 0; s <= n_slice_points; ++s) {
     if (!tops[s]) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: top[%d] == NULL", s);
-    DecodeArgs a{static_cast<const unsigned char*>(samples), sample_stride, sl[s].offset,
-                 mean ? mean + (size_t)sl[s].c0 * hw : nullptr, tops[s], (size_t)sl[s].cc * hw, scale};
-    const size_t per_thread = float_data ? 1 : (sl[s].enc == FN2_ENC_BOOL1 ? 8 : 4);
-    const size_t threads = (a.count + per_thread - 1) / per_thread;
-    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)N);
-    if (float_data) hipLaunchKernelGGL(decode_f32, grid, dim3(256), 0, st, a);
-    else if (sl[s].enc == FN2_ENC_UINT8) hipLaunchKernelGGL(decode_u8, grid, dim3(256), 0, st, a);
-    else if (sl[s].enc == FN2_ENC_UINT16FLOW) hipLaunchKernelGGL(decode_i16flow, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(decode_bool1, grid, dim3(256), 0, st, a);
+    a.slice[s] = SliceArgs{sl[s].offset, (size_t)sl[s].cc * hw, mean ? mean + (size_t)sl[s].c0 * hw : nullptr, tops[s], sl[s].enc};
+    const size_t per_thread = sl[s].enc == FN2_ENC_BOOL1 ? 8 : 4;
+    const size_t threads = (a.slice[s].count + per_thread - 1) / per_thread;
+    if (threads > max_threads) max_threads = threads;
   }
+  const size_t blocks = (max_threads + 255) / 256;
+  if (blocks > 0x7fffffffu) return fail(FN2_ERR_INVALID_ARG, "custom_data_decode: slice of %zu elements is too large", max_threads * 4);
+  hipLaunchKernelGGL(decode_samples, dim3((unsigned)blocks, (unsigned)N, (unsigned)(n_slice_points + 1)), dim3(256), 0, as_stream(stream), a);
   return check_launch("custom_data_decode_forward");
 }

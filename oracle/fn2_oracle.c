@@ -25,6 +25,10 @@
  * Deconvolution and ReLU layers (same SGEMM stand-in) and the golden file holds their outputs
  * (stock_* arrays): PINNED as well, in addition to torch's fp64 convolutions (tests/test_oracle.py).
  *
+ * The CustomData sample format at the end of this file is PINNED too: decode against the reference's custom_data_layer.cpp compiled
+ * in place over an in-memory LMDB stand-in (cdata* golden arrays), the Datum wire format against the protobuf runtime; the writer's
+ * packing (the tool needs OpenCV) is restated and checked through the pinned reader.
+ *
  * All file:line citations are relative to the reference tree.
  * Arithmetic notes: nvcc contracts `sum += a*b` into an FMA by default, so the restatement uses
  * fmaf() where the reference has that pattern; summation ORDER follows the reference kernels.

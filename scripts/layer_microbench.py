@@ -54,6 +54,34 @@ xi = torch.randn(8, 512, 20, 28, device=dev, generator=g)
 add("im2col 3x3/2 [8,512,20,28]", lambda: ops.im2col_forward(xi, 3, 1, 2), 4 * xi.numel() + 4 * 8 * 512 * 9 * 140)
 col = torch.randn(8, 64 * 16, 40 * 56, device=dev, generator=g); b64 = torch.randn(64, device=dev, generator=g)
 add("col2im 4x4/2 + bias + ReLU -> [8,64,80,112]", lambda: ops.col2im_bias_relu_forward(col, b64, 8, 64, 80, 112, 4, 1, 2), 4 * col.numel() + 4 * 8 * 64 * 80 * 112)
+# CustomData sample decode: a batch of 8 FlyingChairs samples (512x384): 10.125 B/pixel of packed bytes in, 9 fp32 planes out
+from flownet2_amd import sample_format as SF
+Hs, Ws, Ns = 384, 512, 8
+nb = SF.sample_bytes(9, Hs, Ws, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS)
+packed = torch.randint(0, 256, (Ns, (nb + 15) // 16 * 16), device=dev, dtype=torch.uint8, generator=g)
+add(f"CustomData decode [{Ns} x 9ch {Ws}x{Hs}] (one launch)", lambda: SF.decode_batch(packed, 9, Hs, Ws, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS),
+    Ns * (nb + 4 * 9 * Hs * Ws))
+mean_t = torch.randn(9 * Hs * Ws, device=dev, generator=g)
+add(f"CustomData decode [{Ns} x 9ch {Ws}x{Hs}] with a mean blob", lambda: SF.decode_batch(packed, 9, Hs, Ws, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS, mean=mean_t, scale=1 / 255.),
+    Ns * (nb + 4 * 9 * Hs * Ws) + 4 * 9 * Hs * Ws)
 print("| layer | us | algorithmic MB | GB/s | % of 8 TB/s |\n|---|---|---|---|---|")
 for name, t, nb, gbs in rows:
     print("| %s | %.1f | %.2f | %.0f | %.1f |" % (name, t, nb / 1e6, gbs, gbs / 80.0))
+
+# CPU side of the sample decode on this box: the oracle's restatement (one thread, like the reference's prefetch thread) and, when
+# oracle/_ref is present, the reference's own CustomDataLayer (compiled in place, in-memory LMDB stand-in), 4 batches of 8
+import time
+import numpy as np
+import oracle
+from oracle import ref
+host = packed.cpu().numpy()
+t0 = time.time(); oracle.custom_data_decode(host, 9, Hs, Ws, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS); t_or = time.time() - t0
+print("\nCPU decode of the same batch: oracle restatement %.1f ms (%.0f samples/s, 1 thread)" % (t_or * 1e3, Ns / t_or))
+if ref.available():
+    recs = [("%08d" % i, oracle.datum_serialize(9, Hs, Ws, host[i, :nb].tobytes(), i)) for i in range(Ns)]
+    t0 = time.time(); ref.custom_data(recs, Ns, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS, n_forward=4); t_ref = (time.time() - t0) / 5   # SetUp prefetches one batch too
+    print("reference CustomDataLayer (oracle/_ref, host prefetch thread): %.1f ms per batch of %d (%.0f samples/s)" % (t_ref * 1e3, Ns, Ns / t_ref))
+t0 = time.time()
+for _ in range(5):
+    dev_copy = torch.from_numpy(host).pin_memory().to(dev, non_blocking=True); torch.cuda.synchronize()
+print("host -> device copy of the packed batch (%.1f MB, incl. pinning): %.2f ms" % (host.nbytes / 1e6, (time.time() - t0) / 5 * 1e3))
