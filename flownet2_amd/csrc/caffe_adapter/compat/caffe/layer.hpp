@@ -3,6 +3,7 @@
 // unless reshape_every_iter is false, :484-521), including the fork's additions (AllowBackward :322-324).
 #pragma once
 #include "caffe/blob.hpp"
+#include "caffe/util/math_functions.hpp"   // layer.hpp:13 of the reference
 #include "caffe/layer_factory.hpp"
 #include "caffe/proto/caffe.pb.h"
 

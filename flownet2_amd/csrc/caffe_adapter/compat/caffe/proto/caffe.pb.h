@@ -4,6 +4,7 @@
 // names protoc would generate.  Plain structs -- there is no protobuf runtime in this image.
 #pragma once
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace caffe {
@@ -301,6 +302,112 @@ class DataParameter {           // caffe.proto:918-986, the fields CustomDataLay
   RepeatedField<float> subtract_;
 };
 
+// ---- augmentation messages (FlowAugmentation adapter + oracle/_ref) ------------------------------------------
+// AugmentationCoeff, caffe.proto:436-486: 42 optional floats.  The layers move coefficients around as arrays through the
+// protobuf reflection API (augmentation_layer_base.cpp:338-380): index = declaration order, value stored as log() when the field's
+// default is non-zero.  The stand-in keeps the same order, defaults and has-bits behind a minimal Reflection / Descriptor.
+#define FN2_AUG_COEFF_FIELDS(X)                                                                                              \
+  X(mirror, 0) X(dx, 0) X(dy, 0) X(angle, 0) X(zoom_x, 1) X(zoom_y, 1)                                                        \
+  X(gamma, 1) X(brightness, 0) X(contrast, 1) X(color1, 1) X(color2, 1) X(color3, 1)                                          \
+  X(pow_nomean0, 1) X(pow_nomean1, 1) X(pow_nomean2, 1) X(add_nomean0, 0) X(add_nomean1, 0) X(add_nomean2, 0)                 \
+  X(mult_nomean0, 1) X(mult_nomean1, 1) X(mult_nomean2, 1) X(pow_withmean0, 1) X(pow_withmean1, 1) X(pow_withmean2, 1)        \
+  X(add_withmean0, 0) X(add_withmean1, 0) X(add_withmean2, 0) X(mult_withmean0, 1) X(mult_withmean1, 1) X(mult_withmean2, 1)  \
+  X(lmult_pow, 1) X(lmult_add, 0) X(lmult_mult, 1) X(col_angle, 0)                                                            \
+  X(fog_amount, 0) X(fog_size, 0) X(motion_blur_angle, 0) X(motion_blur_size, 0)                                              \
+  X(shadow_angle, 0) X(shadow_distance, 0) X(shadow_strength, 0) X(noise, 0)
+}  // namespace caffe
+namespace google { namespace protobuf {
+class FieldDescriptor {
+ public:
+  FieldDescriptor(int index, float def) : index_(index), default_(def) {}
+  float default_value_float() const { return default_; }
+  int index() const { return index_; }
+ private:
+  int index_;
+  float default_;
+};
+class Descriptor {
+ public:
+  explicit Descriptor(std::vector<FieldDescriptor> f) : fields_(std::move(f)) {}
+  int field_count() const { return (int)fields_.size(); }
+  const FieldDescriptor* field(int i) const { return &fields_[i]; }
+ private:
+  std::vector<FieldDescriptor> fields_;
+};
+class Reflection {
+ public:
+  template <typename M> float GetFloat(const M& m, const FieldDescriptor* f) const { return m.has_[f->index()] ? m.value_[f->index()] : f->default_value_float(); }
+  template <typename M> void SetFloat(M* m, const FieldDescriptor* f, float v) const { m->value_[f->index()] = v; m->has_[f->index()] = true; }
+  template <typename M> void ClearField(M* m, const FieldDescriptor* f) const { m->has_[f->index()] = false; m->value_[f->index()] = f->default_value_float(); }
+};
+} }  // namespace google::protobuf
+namespace caffe {
+class AugmentationCoeff {
+ public:
+  enum { kNumFields = 42 };
+  AugmentationCoeff() {
+    int i = 0;
+#define X(name, def) value_[i] = def; has_[i] = false; ++i;
+    FN2_AUG_COEFF_FIELDS(X)
+#undef X
+  }
+#define X(name, def)                                                                 \
+  float name() const { return value_[k_##name]; }                                    \
+  bool has_##name() const { return has_[k_##name]; }                                 \
+  void set_##name(float v) { value_[k_##name] = v; has_[k_##name] = true; }          \
+  void clear_##name() { value_[k_##name] = def; has_[k_##name] = false; }
+  FN2_AUG_COEFF_FIELDS(X)
+#undef X
+  static const AugmentationCoeff& default_instance() { static const AugmentationCoeff d; return d; }
+  const google::protobuf::Reflection* GetReflection() const { static const google::protobuf::Reflection r; return &r; }
+  const google::protobuf::Descriptor* GetDescriptor() const {
+    static const google::protobuf::Descriptor d([] {
+      std::vector<google::protobuf::FieldDescriptor> f;
+      int i = 0;
+#define X(name, def) f.emplace_back(i++, (float)def);
+      FN2_AUG_COEFF_FIELDS(X)
+#undef X
+      return f;
+    }());
+    return &d;
+  }
+ private:
+  friend class google::protobuf::Reflection;
+  enum {
+#define X(name, def) k_##name,
+    FN2_AUG_COEFF_FIELDS(X)
+#undef X
+    kCount
+  };
+  static_assert(kCount == kNumFields, "AugmentationCoeff has 42 fields");
+  float value_[kNumFields];
+  bool has_[kNumFields];
+};
+
+class CoeffScheduleParameter {};     // caffe.proto:693-697: a member of DataAugmentationLayer, whose header flow_augmentation_layer.cu includes
+class RandomGeneratorParameter {};   // caffe.proto:607-616: only handed to caffe_rng_generate, which the pins never reach
+// AugmentationParameter, caffe.proto:489-546: crop size (read by the layers) and the generator sub-messages (named by
+// augmentation_layer_base.cpp's generate_* functions, absent here: has_*() is false)
+#define FN2_AUG_PARAM_GENERATORS(X)                                                                                         \
+  X(mirror) X(translate) X(rotate) X(zoom) X(squeeze) X(translate_x) X(translate_y) X(gamma) X(brightness) X(contrast) X(color) \
+  X(lmult_pow) X(lmult_mult) X(lmult_add) X(sat_pow) X(sat_mult) X(sat_add) X(col_pow) X(col_mult) X(col_add)                 \
+  X(ladd_pow) X(ladd_mult) X(ladd_add) X(col_rotate) X(fog_amount) X(fog_size) X(motion_blur_angle) X(motion_blur_size)       \
+  X(shadow_angle) X(shadow_distance) X(shadow_strength) X(noise)
+class AugmentationParameter {
+ public:
+  unsigned crop_width() const { return crop_width_; }
+  unsigned crop_height() const { return crop_height_; }
+  void set_crop_width(unsigned v) { crop_width_ = v; }
+  void set_crop_height(unsigned v) { crop_height_ = v; }
+#define X(name)                                                                                   \
+  bool has_##name() const { return false; }                                                       \
+  const RandomGeneratorParameter& name() const { static const RandomGeneratorParameter r; return r; }
+  FN2_AUG_PARAM_GENERATORS(X)
+#undef X
+ private:
+  unsigned crop_width_ = 0, crop_height_ = 0;
+};
+
 enum Phase { TRAIN = 0, TEST = 1 };
 
 class LayerParameter {
@@ -334,10 +441,13 @@ class LayerParameter {
   ConvolutionParameter* mutable_convolution_param() { return &convolution_param_; }
   const ReLUParameter& relu_param() const { return relu_param_; }
   ReLUParameter* mutable_relu_param() { return &relu_param_; }
+  const AugmentationParameter& augmentation_param() const { return augmentation_param_; }     // = 149 (FlowAugmentation)
+  AugmentationParameter* mutable_augmentation_param() { return &augmentation_param_; }
   const DataParameter& data_param() const { return data_param_; }                            // CustomData (oracle/_ref only)
   DataParameter* mutable_data_param() { return &data_param_; }
  private:
   DataParameter data_param_;
+  AugmentationParameter augmentation_param_;
   std::string name_, type_;
   std::vector<float> loss_weight_;
   bool reshape_every_iter_ = true;

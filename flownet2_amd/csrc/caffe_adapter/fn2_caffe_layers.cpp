@@ -153,6 +153,42 @@ class Correlation1DLayer : public Layer<Dtype> {
 };
 
 // ---------------------------------------------------------------------------------------------------------
+// FlowAugmentation (flow_augmentation_layer.cpp / .cu of the reference): the coefficient blobs are read on the host, as there.
+template <typename Dtype>
+class FlowAugmentationLayer : public Layer<Dtype> {
+ public:
+  explicit FlowAugmentationLayer(const LayerParameter& param) : Layer<Dtype>(param) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_GT(this->layer_param_.augmentation_param().crop_width(), 0u) << "Please enter crop width if you want to perform augmentation";
+    CHECK_GT(this->layer_param_.augmentation_param().crop_height(), 0u) << "Please enter crop height if you want to perform augmentation";
+    this->layer_param_.set_reshape_every_iter(false);
+  }
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom.size(), 3u) << "Flow augmentation layer takes three input blobs: FlowField, Img1TransfParams, Img2TransfParams";
+    CHECK_EQ(top.size(), 1u) << "Flow augmentation layer outputs one output blob: Augmented Flow";
+    CHECK_EQ(bottom[0]->channels(), 2) << "Flow data must have two channels";
+    cropped_width_ = this->layer_param_.augmentation_param().crop_width();
+    cropped_height_ = this->layer_param_.augmentation_param().crop_height();
+    top[0]->Reshape(bottom[0]->num(), 2, cropped_height_, cropped_width_);
+  }
+  virtual inline const char* type() const { return "FlowAugmentation"; }
+  virtual inline bool AllowBackward() const { return false; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "Forward CPU Augmentation not implemented."; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "FlowAugmentationLayer cannot do backward."; }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { LOG(FATAL) << "FlowAugmentationLayer cannot do backward."; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom[1]->count() / bottom[0]->num(), FN2_AUG_NUM_PARAMS) << "coefficient blob does not hold one AugmentationCoeff per sample";
+    CHECK_EQ(bottom[2]->count(), bottom[1]->count());
+    FN2_CALL(fn2_flow_augmentation_forward(f32(bottom[0]->gpu_data()), f32(bottom[1]->cpu_data()), f32(bottom[2]->cpu_data()),
+                                           f32(top[0]->mutable_gpu_data()), bottom[0]->num(), bottom[0]->height(), bottom[0]->width(),
+                                           cropped_height_, cropped_width_, kStream));
+  }
+  int cropped_height_, cropped_width_;
+};
+
+// ---------------------------------------------------------------------------------------------------------
 template <typename Dtype>
 class FlowWarpLayer : public Layer<Dtype> {
  public:
@@ -362,6 +398,8 @@ INSTANTIATE_CLASS(CorrelationLayer);
 REGISTER_LAYER_CLASS(Correlation);
 INSTANTIATE_CLASS(Correlation1DLayer);
 REGISTER_LAYER_CLASS(Correlation1D);
+INSTANTIATE_CLASS(FlowAugmentationLayer);
+REGISTER_LAYER_CLASS(FlowAugmentation);
 INSTANTIATE_CLASS(FlowWarpLayer);
 REGISTER_LAYER_CLASS(FlowWarp);
 INSTANTIATE_CLASS(ResampleLayer);

@@ -118,6 +118,7 @@ class LayerParameter:
     l1_loss_param: Dict = field(default_factory=dict)
     downsample_param: Dict = field(default_factory=dict)
     data_param: Dict = field(default_factory=dict)      # DataParameter, caffe.proto:918-986 (CustomData)
+    augmentation_param: Dict = field(default_factory=dict)   # AugmentationParameter, caffe.proto:489-546 (crop_width / crop_height)
 
 
 class Layer:
@@ -431,6 +432,36 @@ class DownsampleLayer(Layer):
             raise CheckError("DownsamplingLayer cannot do backward.")                 # downsample_layer.cu:132-138
 
 
+class FlowAugmentationLayer(Layer):
+    """include/caffe/layers/flow_augmentation_layer.hpp; flow_augmentation_layer.cpp:30-72, .cu:92-160.
+    bottom = [flow, coefficient blob of image 1, coefficient blob of image 2] (the `params` outputs of the two DataAugmentation layers)."""
+
+    def type(self): return "FlowAugmentation"
+    def AllowBackward(self): return False                                            # hpp:28
+
+    def LayerSetUp(self, bottom, top):
+        ap = self.layer_param_.augmentation_param
+        CHECK(int(ap.get("crop_width", 0)) > 0, "Please enter crop width if you want to perform augmentation")     # cpp:33
+        CHECK(int(ap.get("crop_height", 0)) > 0, "Please enter crop height if you want to perform augmentation")   # cpp:34
+        self.layer_param_.reshape_every_iter = False                                  # cpp:35
+
+    def Reshape(self, bottom, top):
+        CHECK(len(bottom) == 3, "Flow augmentation layer takes three input blobs: FlowField, Img1TransfParams, Img2TransfParams")   # cpp:43
+        CHECK(len(top) == 1, "Flow augmentation layer outputs one output blob: Augmented Flow")                                       # cpp:44
+        CHECK(bottom[0].channels() == 2, "Flow data must have two channels")                                                          # cpp:52
+        ap = self.layer_param_.augmentation_param
+        self.cropped_width_, self.cropped_height_ = int(ap["crop_width"]), int(ap["crop_height"])
+        top[0].Reshape(bottom[0].num(), 2, self.cropped_height_, self.cropped_width_)                                                 # cpp:57
+        self.num_params_ = ops.AUG_NUM_PARAMS
+
+    def Forward_gpu(self, bottom, top):
+        top[0].data = _wrap(ops.flow_augmentation_forward, bottom[0].data, bottom[1].data, bottom[2].data,
+                            self.cropped_height_, self.cropped_width_)
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        raise CheckError("FlowAugmentationLayer cannot do backward.")                 # hpp:38-41
+
+
 class CustomDataLayer(Layer):
     """include/caffe/layers/custom_data_layer.hpp; custom_data_layer.cpp: LayerSetUp :326-633, the prefetch :138-303, Forward :664-699.
 
@@ -576,4 +607,5 @@ REGISTER_LAYER_CLASS("Resample", ResampleLayer)            # resample_layer.cpp:
 REGISTER_LAYER_CLASS("L1Loss", L1LossLayer)                # l1loss_layer.cpp:108-109
 REGISTER_LAYER_CLASS("ChannelNorm", ChannelNormLayer)      # channel_norm_layer.cpp:193-194
 REGISTER_LAYER_CLASS("Downsample", DownsampleLayer)        # downsample_layer.cpp:78-79
+REGISTER_LAYER_CLASS("FlowAugmentation", FlowAugmentationLayer)   # flow_augmentation_layer.cpp:88-89
 REGISTER_LAYER_CLASS("CustomData", CustomDataLayer)        # custom_data_layer.cpp:712-713

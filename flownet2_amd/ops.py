@@ -291,3 +291,39 @@ def bias_leaky_relu_backward(top_data, top_diff, negative_slope=0.1, need_bias_d
     check(_lib.lib().fn2_bias_leaky_relu_backward(_ptr(y), _ptr(g), _ptr(d), _ptr(db), N, Cc, H, W, C.c_float(float(negative_slope)),
                                                   _ptr(ws), nbytes, _stream()))
     return d, db
+
+
+AUG_NUM_PARAMS = 42      # AugmentationCoeff fields, caffe.proto:436-486
+
+
+def augmentation_matrix(coeffs, crop_width, crop_height, bottom_width, bottom_height, invert=False):
+    """HOST: one coefficient array (coeff_to_array layout) -> (t0, t1, t2, t3, t4, t5) of tTransMat::fromCoeff (optionally inverted)."""
+    import numpy as np
+    c = np.ascontiguousarray(coeffs, np.float32)
+    if c.shape != (AUG_NUM_PARAMS,):
+        raise ValueError(f"coefficient array must have {AUG_NUM_PARAMS} entries")
+    out = np.empty(6, np.float32)
+    check(_lib.lib().fn2_augmentation_matrix(C.c_void_p(c.ctypes.data), crop_width, crop_height, bottom_width, bottom_height, int(invert),
+                                             C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def flow_augmentation_forward(flow, coeffs1, coeffs2, crop_height, crop_width):
+    """flow: CUDA [N,2,H,W]; coeffs1 / coeffs2: [N,42] coefficient arrays of image 1 / image 2 (read on the host, like the reference's
+    cpu_data(), flow_augmentation_layer.cu:123-124).  Returns [N,2,crop_height,crop_width]."""
+    import numpy as np
+    fl = _chk(flow, "bottom[0] (flow)")
+    N, Cc, H, W = fl.shape
+    if Cc != 2:
+        raise ValueError("Flow data must have two channels")                      # flow_augmentation_layer.cpp:52
+    host = []
+    for c in (coeffs1, coeffs2):
+        a = c.detach().cpu().numpy() if isinstance(c, torch.Tensor) else np.asarray(c)
+        a = np.ascontiguousarray(a, np.float32).reshape(N, -1)
+        if a.shape[1] != AUG_NUM_PARAMS:
+            raise ValueError(f"coefficient blobs must hold {AUG_NUM_PARAMS} values per sample")
+        host.append(a)
+    top = torch.empty((N, 2, int(crop_height), int(crop_width)), device=fl.device, dtype=torch.float32)
+    check(_lib.lib().fn2_flow_augmentation_forward(_ptr(fl), C.c_void_p(host[0].ctypes.data), C.c_void_p(host[1].ctypes.data), _ptr(top),
+                                                   N, H, W, int(crop_height), int(crop_width), _stream()))
+    return top

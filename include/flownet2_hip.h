@@ -312,6 +312,26 @@ int fn2_custom_data_decode_forward(const void* samples, size_t sample_stride, in
                                    const int* slice_points, int n_slice_points, const int* encodings, int n_encodings,
                                    int float_data, const float* mean, float scale, float* const* tops, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FlowAugmentation  (type: "FlowAugmentation"; SURVEY.md 8f row 3: the ground-truth flow under the spatial augmentation of both images)
+ *   coefficient arrays <- AugmentationLayerBase::coeff_to_array / array_to_coeff, src/caffe/layers/augmentation_layer_base.cpp:352-380:
+ *                         one AugmentationCoeff (caffe.proto:436-486, 42 float fields) per sample, index = declaration order, fields
+ *                         with a non-zero default stored as log(value); only mirror, dx, dy, angle, zoom_x, zoom_y (0..5) matter here
+ *   matrix             <- tTransMat::toIdentity / leftMultiply / fromCoeff / inverse, augmentation_layer_base.cpp:14-68
+ *                         ( t0 t2 t4 ; t1 t3 t5 ), crop-centred mirror, rotation, translation by (dx*crop_w, dy*crop_h), 1/zoom, bottom-centred
+ *   forward            <- FlowAugmentationLayer::Forward_gpu + WarpData, src/caffe/layers/flow_augmentation_layer.cu:23-88, :92-160:
+ *                         p1 = M1 (x,y); f = flow at round-half-up(p1) (flat index, no bounds check); p3 = M2^-1 (p1 + f); top = p3 - (x,y)
+ *   shapes             <- FlowAugmentationLayer::Reshape, flow_augmentation_layer.cpp:40-72: top [N,2,crop_height,crop_width]
+ * The coefficient blobs are read on the HOST by the reference (cpu_data(), :123-124); they are host pointers here as well.
+ * A flat source index outside the flow blob (the reference clamps only from above, to one element PAST the end, :50-56) reads 0.
+ * ---------------------------------------------------------------------------------------------- */
+#define FN2_AUG_NUM_PARAMS 42
+/* HOST.  mat6 = {t0, t1, t2, t3, t4, t5}; invert != 0 returns tTransMat::inverse() of it (what the layer does for image 2). */
+int fn2_augmentation_matrix(const float* coeffs, int crop_width, int crop_height, int bottom_width, int bottom_height,
+                            int invert, float* mat6);
+int fn2_flow_augmentation_forward(const float* flow, const float* coeffs1_host, const float* coeffs2_host, float* top,
+                                  int N, int H, int W, int crop_height, int crop_width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

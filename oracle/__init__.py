@@ -342,3 +342,19 @@ def custom_data_decode(samples: np.ndarray, channels, H, W, slice_points=(), enc
     _check(L.fn2_custom_data_decode_forward_cpu(C.c_void_p(samples.ctypes.data), stride, N, channels, H, W, sp, nsp, en, nen, int(float_data),
                                                 C.c_void_p(m.ctypes.data) if m is not None else None, float(scale), ptrs), "custom_data_decode")
     return tops
+
+
+def augmentation_matrix(coeffs, crop_width, crop_height, bottom_width, bottom_height, invert=False):
+    c = np.ascontiguousarray(coeffs, np.float32)
+    out = np.empty(6, np.float32)
+    _check(lib().fn2_augmentation_matrix_cpu(_p(c), crop_width, crop_height, bottom_width, bottom_height, int(invert), _p(out)), "augmentation_matrix")
+    return out
+
+
+def flow_augmentation_forward(flow, coeffs1, coeffs2, crop_height, crop_width):
+    flow = _f32(flow)
+    N, _, H, W = flow.shape
+    c1, c2 = _f32(coeffs1).reshape(N, 42), _f32(coeffs2).reshape(N, 42)
+    top = np.empty((N, 2, crop_height, crop_width), np.float32)
+    _check(lib().fn2_flow_augmentation_forward_cpu(_p(flow), _p(c1), _p(c2), _p(top), N, H, W, crop_height, crop_width), "flow_augmentation_forward")
+    return top

@@ -1247,3 +1247,94 @@ FN2_API int fn2_custom_data_decode_forward_cpu(const void* samples, size_t sampl
   free(zero_mean);
   return FN2_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * FlowAugmentation: flow_augmentation_layer.cpp:30-72, flow_augmentation_layer.cu:23-160; matrix helpers
+ * augmentation_layer_base.cpp:14-68; coefficient arrays :352-380 (index = field order of AugmentationCoeff, caffe.proto:436-486;
+ * fields with a non-zero default are stored as log and come back through exp()).
+ * Number types follow the reference: tTransMat holds floats, leftMultiply takes floats, its call sites compute in double
+ * (.5 * float, cos(double), 1.0 / float) and convert.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct aug_mat { float t0, t2, t4, t1, t3, t5; } aug_mat;
+
+static void aug_left_multiply(aug_mat* m, float u0, float u1, float u2, float u3, float u4, float u5) {   /* cpp:22-35 */
+  const float t0 = m->t0, t2 = m->t2, t4 = m->t4;
+  const float t1 = m->t1, t3 = m->t3, t5 = m->t5;
+  m->t0 = t0 * u0 + t1 * u2;
+  m->t1 = t0 * u1 + t1 * u3;
+  m->t2 = t2 * u0 + t3 * u2;
+  m->t3 = t2 * u1 + t3 * u3;
+  m->t4 = t4 * u0 + t5 * u2 + u4;
+  m->t5 = t4 * u1 + t5 * u3 + u5;
+}
+
+static aug_mat aug_from_array(const float* in, int width, int height, int bottomwidth, int bottomheight) {
+  /* array_to_coeff, cpp:368-380: defaults of mirror, dx, dy, angle are 0 (copied), of zoom_x, zoom_y 1 (exp) */
+  const float mirror = in[0], dx = in[1], dy = in[2], angle = in[3];
+  const float zoom_x = (float)exp((double)in[4]), zoom_y = (float)exp((double)in[5]);
+  aug_mat m;
+  m.t0 = 1; m.t2 = 0; m.t4 = 0; m.t1 = 0; m.t3 = 1; m.t5 = 0;                                                    /* toIdentity, cpp:15-19 */
+  /* fromCoeff, cpp:38-49 (every has_*() is true after array_to_coeff) */
+  if (mirror) aug_left_multiply(&m, -1, 0, 0, 1, (float)(.5 * (float)width), (float)(-.5 * (float)height));
+  else aug_left_multiply(&m, 1, 0, 0, 1, (float)(-.5 * (float)width), (float)(-.5 * (float)height));
+  aug_left_multiply(&m, (float)cos(angle), (float)sin(angle), (float)-sin(angle), (float)cos(angle), 0, 0);
+  aug_left_multiply(&m, 1, 0, 0, 1, dx * (float)width, dy * (float)height);
+  aug_left_multiply(&m, (float)(1.0 / zoom_x), 0, 0, (float)(1.0 / zoom_y), 0, 0);
+  aug_left_multiply(&m, 1, 0, 0, 1, (float)(.5 * (float)bottomwidth), (float)(.5 * (float)bottomheight));
+  return m;
+}
+
+static aug_mat aug_inverse(aug_mat s) {                                                                           /* cpp:52-68 */
+  const float a = s.t0, c = s.t2, e = s.t4;
+  const float b = s.t1, d = s.t3, f = s.t5;
+  const float denom = a * d - b * c;
+  aug_mat r;
+  r.t0 = d / denom;
+  r.t1 = -b / denom;
+  r.t2 = -c / denom;
+  r.t3 = a / denom;
+  r.t4 = (c * f - d * e) / denom;
+  r.t5 = (b * e - a * f) / denom;
+  return r;
+}
+
+FN2_API int fn2_augmentation_matrix_cpu(const float* coeffs, int crop_width, int crop_height, int bottom_width, int bottom_height,
+                                        int invert, float* mat6) {
+  if (!coeffs || !mat6 || crop_width < 1 || crop_height < 1 || bottom_width < 1 || bottom_height < 1) return FN2_ERR_INVALID_ARG;
+  aug_mat m = aug_from_array(coeffs, crop_width, crop_height, bottom_width, bottom_height);
+  if (invert) m = aug_inverse(m);
+  mat6[0] = m.t0; mat6[1] = m.t1; mat6[2] = m.t2; mat6[3] = m.t3; mat6[4] = m.t4; mat6[5] = m.t5;
+  return FN2_OK;
+}
+
+/* WarpData, flow_augmentation_layer.cu:23-88; all pointers are host pointers here. */
+FN2_API int fn2_flow_augmentation_forward_cpu(const float* flow, const float* coeffs1, const float* coeffs2, float* top,
+                                              int N, int H, int W, int crop_height, int crop_width) {
+  if (crop_width < 1 || crop_height < 1 || N < 0 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;               /* cpp:33-34 */
+  if (N && (!flow || !coeffs1 || !coeffs2 || !top)) return FN2_ERR_INVALID_ARG;
+  const int width = W, height = H, dest_width = crop_width, dest_height = crop_height;
+  const long long src_count = (long long)N * 2 * H * W;
+  for (int n = 0; n < N; ++n) {
+    const aug_mat m1 = aug_from_array(coeffs1 + (size_t)n * FN2_AUG_NUM_PARAMS, crop_width, crop_height, W, H);             /* cu:131-137 */
+    const aug_mat m2 = aug_inverse(aug_from_array(coeffs2 + (size_t)n * FN2_AUG_NUM_PARAMS, crop_width, crop_height, W, H)); /* cu:139-142 */
+    for (int yi = 0; yi < dest_height; ++yi)
+      for (int xi = 0; xi < dest_width; ++xi) {
+        const float x = (float)xi, y = (float)yi;
+        /* the device compiler contracts a*b + c*d + e into fma(a, b, fma(c, d, e)) (AMDGPU fuses aggressively; the position decides
+         * which source pixel is read, so the rounding is kept) */
+        const float xpos1 = fmaf(x, m1.t0, fmaf(y, m1.t2, m1.t4));                                            /* :41 */
+        const float ypos1 = fmaf(x, m1.t1, fmaf(y, m1.t3, m1.t5));                                            /* :42 */
+        const long long ix = (long long)width * ((long long)height * (2 * n + 0) + (int)(ypos1 + 0.5f)) + (int)(xpos1 + 0.5f);   /* :45-47 */
+        const long long iy = (long long)width * ((long long)height * (2 * n + 1) + (int)(ypos1 + 0.5f)) + (int)(xpos1 + 0.5f);   /* :48-50 */
+        /* the reference reads src_data[min(idx, src_count)]: unchecked below 0 and one element past the end above; both read 0 here */
+        const float u = (ix >= 0 && ix < src_count) ? flow[ix] : 0.f;
+        const float v = (iy >= 0 && iy < src_count) ? flow[iy] : 0.f;
+        const float xpos2 = xpos1 + u, ypos2 = ypos1 + v;                                                     /* :52-53 */
+        const float xpos3 = fmaf(xpos2, m2.t0, fmaf(ypos2, m2.t2, m2.t4));                                    /* :56 */
+        const float ypos3 = fmaf(xpos2, m2.t1, fmaf(ypos2, m2.t3, m2.t5));                                    /* :57 */
+        top[(size_t)dest_width * ((size_t)dest_height * (2 * n + 0) + yi) + xi] = xpos3 - x;                  /* :60 */
+        top[(size_t)dest_width * ((size_t)dest_height * (2 * n + 1) + yi) + xi] = ypos3 - y;                  /* :61 */
+      }
+  }
+  return FN2_OK;
+}

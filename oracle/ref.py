@@ -194,3 +194,13 @@ def custom_data(records, batch_size, slice_points=(), encodings=(), scale=1.0, s
     for s, t in enumerate(tops):
         assert tuple(shapes[4 * s:4 * s + 4]) == (batch_size,) + t.shape[1:], (tuple(shapes[4 * s:4 * s + 4]), t.shape)
     return tops, labels
+
+
+def flow_augmentation(flow, coeffs1, coeffs2, crop_height, crop_width):
+    """FlowAugmentationLayer of the reference (flow_augmentation_layer.cpp/.cu + augmentation_layer_base.cpp); GPU only."""
+    flow = _f(flow)
+    N, _, H, W = flow.shape
+    c1, c2 = _f(coeffs1).reshape(N, -1), _f(coeffs2).reshape(N, -1)
+    top = np.empty((N, 2, crop_height, crop_width), np.float32)
+    _chk(lib().fn2ref_flow_augmentation(_p(flow), _p(c1), _p(c2), c1.shape[1], N, H, W, crop_height, crop_width, _p(top)))
+    return top

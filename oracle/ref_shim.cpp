@@ -87,6 +87,28 @@ int fn2ref_correlation1d(int pad, int kernel_size, int max_displacement, int str
   });
 }
 
+// FlowAugmentation through the registry: bottom = {flow, coefficient blob of image 1, coefficient blob of image 2}
+extern "C" __attribute__((visibility("default")))
+int fn2ref_flow_augmentation(const float* flow, const float* coeffs1, const float* coeffs2, int num_params, int N, int H, int W,
+                             int crop_height, int crop_width, float* top_out) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("FlowAugmentation");
+    lp.mutable_augmentation_param()->set_crop_width(crop_width);
+    lp.mutable_augmentation_param()->set_crop_height(crop_height);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> fl(N, 2, H, W), c1(N, num_params, 1, 1), c2(N, num_params, 1, 1), top;
+    fill(fl, flow); fill(c1, coeffs1); fill(c2, coeffs2);
+    vector<Blob<float>*> bottom{&fl, &c1, &c2}, tops{&top};
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    CUDA_CHECK(hipDeviceSynchronize());
+    CHECK_EQ(top.count(), N * 2 * crop_height * crop_width);
+    fetch(top, top_out);
+  });
+}
+
 // mode: 0 = GPU kernels (flow_warp_layer.cu), 1 = the reference's CPU implementation (flow_warp_layer.cpp:58-199)
 extern "C" __attribute__((visibility("default")))
 int fn2ref_flow_warp(int mode, int fill_value, const float* image, const float* flow, int N, int C, int H, int W,

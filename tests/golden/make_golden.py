@@ -93,6 +93,34 @@ def custom_data_records(i):
     return recs
 
 
+# FlowAugmentation: (N, H, W, crop_h, crop_w)
+FLOW_AUG = [(2, 48, 64, 32, 44), (3, 96, 128, 64, 96), (2, 40, 56, 40, 56)]
+
+
+def flow_aug_inputs(i):
+    """Smooth flow (bilinear up-sampling of a coarse random field) + coefficient arrays in coeff_to_array layout (42 floats per sample:
+    mirror, dx, dy, angle, log zoom_x, log zoom_y, then the chromatic / effect fields at their defaults = 0)."""
+    N, H, W, ch, cw = FLOW_AUG[i]
+    rng = np.random.default_rng(3000 + i)
+    coarse = rng.standard_normal((N, 2, 4, 5)) * 6
+    ys, xs = np.linspace(0, 3, H), np.linspace(0, 4, W)
+    y0, x0 = np.minimum(ys.astype(int), 2), np.minimum(xs.astype(int), 3)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    a, b = coarse[:, :, y0][:, :, :, x0], coarse[:, :, y0][:, :, :, x0 + 1]
+    c, d = coarse[:, :, y0 + 1][:, :, :, x0], coarse[:, :, y0 + 1][:, :, :, x0 + 1]
+    flow = ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy).astype(np.float32)
+
+    def coeffs():
+        out = np.zeros((N, 42), np.float32)
+        for n in range(N):
+            out[n, :6] = [float(rng.random() < 0.5), rng.uniform(-0.04, 0.04), rng.uniform(-0.04, 0.04), rng.uniform(-0.15, 0.15),
+                          np.log(rng.uniform(0.95, 1.25)), np.log(rng.uniform(0.95, 1.25))]
+        return out
+    if i == 2:                                   # identity transforms, crop = image
+        return flow, np.zeros((N, 42), np.float32), np.zeros((N, 42), np.float32), ch, cw
+    return flow, coeffs(), coeffs(), ch, cw
+
+
 def stock_inputs(which):
     if which == "stem":
         return rnd((1, 3, 24, 32), 1000), rnd((64, 3, 7, 7), 1001, 0.1), rnd((64,), 1002)
@@ -143,6 +171,10 @@ def main(out, only=None, base=None):
             tops, _ = ref.custom_data(custom_data_records(i), batch, sp, enc, scale, sub, r0, r1, fw)
             for s_, t in enumerate(tops):
                 g[f"cdata{i}_top{s_}"] = t.view(np.uint32)     # bit patterns (NaN payloads included)
+    if only in (None, "flow_aug"):
+        for i in range(len(FLOW_AUG)):
+            flow, c1, c2, ch, cw = flow_aug_inputs(i)
+            g[f"flowaug{i}"] = ref.flow_augmentation(flow, c1, c2, ch, cw)
     if only in (None, "main"):
         main_section(g)
     np.savez_compressed(out, **g)
@@ -204,7 +236,7 @@ if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("out", nargs="?", default=os.path.join(os.path.dirname(__file__), "ref_golden.npz"))
-    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left", "custom_data"], default=None)
+    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left", "custom_data", "flow_aug"], default=None)
     ap.add_argument("--base", default=None, help="existing .npz whose arrays are kept")
     a = ap.parse_args()
     main(a.out, a.only, a.base)

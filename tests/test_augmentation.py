@@ -1,0 +1,204 @@
+"""FlowAugmentation: the coefficient-array -> matrix helpers and the flow warp.
+
+CPU part: the C oracle and the host function of libflownet2_hip.so against an independent fp64 composition of the affine maps.
+GPU part (-m gpu): HIP kernel vs oracle, vs the reference's own layer (oracle/_ref, live and through the golden file) and through
+the Layer mirror."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import flownet2_amd
+import oracle
+from flownet2_amd import ops
+from oracle import ref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as MG  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "ref_golden.npz")
+
+
+def coeff_array(mirror=0.0, dx=0.0, dy=0.0, angle=0.0, zoom_x=1.0, zoom_y=1.0):
+    """One AugmentationCoeff as coeff_to_array writes it (augmentation_layer_base.cpp:352-365): declaration order, log() for the
+    fields whose default is 1.  Everything but the six spatial fields stays at its default (0, or log 1 = 0)."""
+    a = np.zeros(42, np.float32)
+    a[:6] = [mirror, dx, dy, angle, np.log(zoom_x), np.log(zoom_y)]
+    return a
+
+
+def matrix64(mirror, dx, dy, angle, zx, zy, cw, ch, W, H):
+    """fp64 composition of tTransMat::fromCoeff (augmentation_layer_base.cpp:38-49) as 3x3 homogeneous matrices, applied left to right."""
+    def T(tx, ty): return np.array([[1, 0, tx], [0, 1, ty], [0, 0, 1.0]])
+    M = np.eye(3)
+    M = (np.array([[-1, 0, .5 * cw], [0, 1, -.5 * ch], [0, 0, 1.0]]) if mirror else T(-.5 * cw, -.5 * ch)) @ M
+    c, s = np.cos(angle), np.sin(angle)
+    M = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]]) @ M
+    M = T(dx * cw, dy * ch) @ M
+    M = np.diag([1 / zx, 1 / zy, 1.0]) @ M
+    return T(.5 * W, .5 * H) @ M
+
+
+def as6(M):
+    return np.array([M[0, 0], M[1, 0], M[0, 1], M[1, 1], M[0, 2], M[1, 2]])     # t0 t1 t2 t3 t4 t5
+
+
+CASES = [  # mirror, dx, dy, angle, zoom_x, zoom_y, crop_w, crop_h, W, H
+    (0, 0, 0, 0, 1, 1, 64, 48, 64, 48), (0, 0.05, -0.1, 0.2, 1.2, 0.9, 56, 40, 64, 48), (1, -0.08, 0.03, -0.35, 0.8, 1.1, 448, 320, 512, 384),
+    (1, 0, 0, 0, 1, 1, 30, 20, 31, 21), (0, 0.2, 0.2, 3.0, 2.0, 2.0, 16, 16, 40, 24),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_augmentation_matrix_matches_fp64_composition(case):
+    mirror, dx, dy, angle, zx, zy, cw, ch, W, H = case
+    arr = coeff_array(mirror, dx, dy, angle, zx, zy)
+    want = matrix64(mirror, dx, dy, angle, zx, zy, cw, ch, W, H)
+    for impl in (oracle.augmentation_matrix, ops.augmentation_matrix):
+        m = impl(arr, cw, ch, W, H)
+        np.testing.assert_allclose(m, as6(want), rtol=2e-6, atol=2e-4)
+        inv = impl(arr, cw, ch, W, H, invert=True)
+        np.testing.assert_allclose(inv, as6(np.linalg.inv(want)), rtol=2e-5, atol=5e-4)
+    # the product's host function and the oracle agree to the bit (same operation order, same number types)
+    assert np.array_equal(oracle.augmentation_matrix(arr, cw, ch, W, H).view(np.uint32), ops.augmentation_matrix(arr, cw, ch, W, H).view(np.uint32))
+    assert np.array_equal(oracle.augmentation_matrix(arr, cw, ch, W, H, True).view(np.uint32), ops.augmentation_matrix(arr, cw, ch, W, H, True).view(np.uint32))
+
+
+def smooth_flow(N, H, W, seed, mag=6.0):
+    g = torch.Generator().manual_seed(seed)
+    coarse = torch.randn(N, 2, 4, 5, generator=g) * mag
+    return torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=True).numpy().astype(np.float32)
+
+
+def flow_aug64(flow, c1, c2, ch, cw):
+    """fp64 statement of flow_augmentation_layer.cu:36-61 with nearest-source sampling (round half up, as (int)(p + 0.5) for p >= -0.5)."""
+    N, _, H, W = flow.shape
+    out = np.zeros((N, 2, ch, cw))
+    ys, xs = np.mgrid[0:ch, 0:cw].astype(np.float64)
+    for n in range(N):
+        M1 = matrix64(c1[n][0], c1[n][1], c1[n][2], c1[n][3], np.exp(np.float64(c1[n][4])), np.exp(np.float64(c1[n][5])), cw, ch, W, H)
+        M2 = np.linalg.inv(matrix64(c2[n][0], c2[n][1], c2[n][2], c2[n][3], np.exp(np.float64(c2[n][4])), np.exp(np.float64(c2[n][5])), cw, ch, W, H))
+        x1 = M1[0, 0] * xs + M1[0, 1] * ys + M1[0, 2]
+        y1 = M1[1, 0] * xs + M1[1, 1] * ys + M1[1, 2]
+        xi, yi = np.trunc(x1 + 0.5).astype(int), np.trunc(y1 + 0.5).astype(int)
+        assert xi.min() >= 0 and yi.min() >= 0 and xi.max() < W and yi.max() < H, "test transform leaves the image"
+        x2, y2 = x1 + flow[n, 0][yi, xi], y1 + flow[n, 1][yi, xi]
+        out[n, 0] = M2[0, 0] * x2 + M2[0, 1] * y2 + M2[0, 2] - xs
+        out[n, 1] = M2[1, 0] * x2 + M2[1, 1] * y2 + M2[1, 2] - ys
+    return out
+
+
+def aug_inputs(N, H, W, ch, cw, seed):
+    rng = np.random.default_rng(seed)
+    def coeffs():
+        return np.stack([coeff_array(float(rng.random() < 0.5), rng.uniform(-0.04, 0.04), rng.uniform(-0.04, 0.04), rng.uniform(-0.15, 0.15),
+                                     rng.uniform(0.95, 1.25), rng.uniform(0.95, 1.25)) for _ in range(N)])
+    return smooth_flow(N, H, W, seed), coeffs(), coeffs()
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 64, 32, 44), (3, 96, 128, 64, 96)])
+def test_oracle_flow_augmentation_vs_fp64(shape):
+    N, H, W, ch, cw = shape
+    flow, c1, c2 = aug_inputs(N, H, W, ch, cw, 5)
+    got = oracle.flow_augmentation_forward(flow, c1, c2, ch, cw)
+    want = flow_aug64(flow, c1, c2, ch, cw)
+    # a float rounding of the sampling position can pick the neighbouring source pixel; the flow is smooth, so that costs < 0.5 px
+    err = np.abs(got - want)
+    assert np.quantile(err, 0.999) < 2e-3 and err.max() < 0.6
+
+
+def test_flow_augmentation_invariants_and_errors():
+    N, H, W = 2, 40, 56
+    flow = smooth_flow(N, H, W, 7)
+    ident = np.stack([coeff_array()] * N)
+    # identity coefficients, crop = image: the flow comes back (up to the rounding of (x + u) - x)
+    top = oracle.flow_augmentation_forward(flow, ident, ident, H, W)
+    assert np.abs(top - flow).max() < 1e-4
+    # the same transform on both images and no motion: no flow
+    c = np.stack([coeff_array(1, 0.03, -0.02, 0.1, 1.1, 1.2)] * N)
+    top = oracle.flow_augmentation_forward(np.zeros_like(flow), c, c, 30, 40)
+    assert np.abs(top).max() < 1e-3
+    # a centred crop without any transform: the window of the flow field
+    top = oracle.flow_augmentation_forward(flow, ident, ident, 20, 30)
+    assert np.abs(top - flow[:, :, 10:30, 13:43]).max() < 1e-4
+    with pytest.raises(ValueError):
+        oracle.flow_augmentation_forward(flow, ident, ident, 0, 10)
+    with pytest.raises(flownet2_amd.Fn2Error):
+        ops.augmentation_matrix(coeff_array(), 0, 10, 10, 10)
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.flow_augmentation_forward(torch.zeros(1, 2, 4, 4), ident[:1], ident[:1], 2, 2)
+
+
+def test_flow_augmentation_layer_mirror_checks():
+    from flownet2_amd.layers import Blob, CheckError, LayerParameter, LayerRegistry
+    b = [Blob(2, 2, 8, 8, device="cpu"), Blob(2, 42, 1, 1, device="cpu"), Blob(2, 42, 1, 1, device="cpu")]
+    layer = LayerRegistry.CreateLayer(LayerParameter(type="FlowAugmentation", augmentation_param=dict(crop_width=6, crop_height=4)))
+    top = [Blob(device="cpu")]
+    layer.SetUp(b, top)
+    assert top[0].shape() == [2, 2, 4, 6] and not layer.AllowBackward() and not layer.layer_param_.reshape_every_iter
+    for bottoms, ap, msg in [(b, dict(crop_height=4), "Please enter crop width"), (b, dict(crop_width=6), "Please enter crop height"),
+                             (b[:2], dict(crop_width=6, crop_height=4), "takes three input blobs"),
+                             ([Blob(2, 3, 8, 8, device="cpu")] + b[1:], dict(crop_width=6, crop_height=4), "two channels")]:
+        with pytest.raises(CheckError, match=msg):
+            LayerRegistry.CreateLayer(LayerParameter(type="FlowAugmentation", augmentation_param=ap)).SetUp(bottoms, [Blob(device="cpu")])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------------
+def _close_flow(a, b, what):
+    """Positions are compared in pixels: identical arithmetic up to the contraction of a*b + c*d + e, which may pick the neighbouring
+    source pixel for a handful of outputs of a smooth field."""
+    err = np.abs(a - b)
+    assert np.quantile(err, 0.999) <= 2e-4 and err.max() < 0.6, (what, float(np.quantile(err, 0.999)), float(err.max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 48, 64, 32, 44), (3, 96, 128, 64, 96), (70, 24, 32, 16, 20), (8, 384, 512, 320, 448)])
+def test_hip_flow_augmentation_matches_oracle(shape):
+    N, H, W, ch, cw = shape
+    flow, c1, c2 = aug_inputs(N, H, W, ch, cw, 11)
+    got = ops.flow_augmentation_forward(torch.from_numpy(flow).cuda(), c1, torch.from_numpy(c2).cuda(), ch, cw).cpu().numpy()
+    _close_flow(got, oracle.flow_augmentation_forward(flow, c1, c2, ch, cw), "hip vs oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("shape", [(2, 48, 64, 32, 44), (4, 96, 128, 64, 96)])
+def test_reference_flow_augmentation_equals_oracle_and_hip(shape):
+    N, H, W, ch, cw = shape
+    flow, c1, c2 = aug_inputs(N, H, W, ch, cw, 13)
+    want = ref.flow_augmentation(flow, c1, c2, ch, cw)
+    _close_flow(oracle.flow_augmentation_forward(flow, c1, c2, ch, cw), want, "oracle vs reference")
+    got = ops.flow_augmentation_forward(torch.from_numpy(flow).cuda(), c1, c2, ch, cw).cpu().numpy()
+    _close_flow(got, want, "hip vs reference")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="golden vectors not generated yet")
+@pytest.mark.parametrize("i", range(len(MG.FLOW_AUG)))
+def test_hip_flow_augmentation_layer_matches_reference_golden(i):
+    from flownet2_amd.layers import Blob, LayerParameter, LayerRegistry
+    gold = np.load(GOLD)
+    if f"flowaug{i}" not in gold:
+        pytest.skip("golden arrays for FlowAugmentation not generated")
+    flow, c1, c2, ch, cw = MG.flow_aug_inputs(i)
+    layer = LayerRegistry.CreateLayer(LayerParameter(type="FlowAugmentation", augmentation_param=dict(crop_width=cw, crop_height=ch)))
+    bottom = [Blob.from_tensor(torch.from_numpy(x).cuda()) for x in (flow, c1.reshape(len(c1), 42, 1, 1), c2.reshape(len(c2), 42, 1, 1))]
+    top = [Blob()]
+    layer.SetUp(bottom, top)
+    layer.Forward(bottom, top)
+    _close_flow(top[0].cpu_data(), gold[f"flowaug{i}"], "layer mirror vs reference golden")
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="golden vectors not generated yet")
+@pytest.mark.parametrize("i", range(len(MG.FLOW_AUG)))
+def test_oracle_flow_augmentation_matches_reference_golden(i):
+    gold = np.load(GOLD)
+    if f"flowaug{i}" not in gold:
+        pytest.skip("golden arrays for FlowAugmentation not generated")
+    flow, c1, c2, ch, cw = MG.flow_aug_inputs(i)
+    _close_flow(oracle.flow_augmentation_forward(flow, c1, c2, ch, cw), gold[f"flowaug{i}"], "oracle vs reference golden")

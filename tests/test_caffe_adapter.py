@@ -1,7 +1,7 @@
 """The C++ Caffe adapter (flownet2_amd/csrc/caffe_adapter/fn2_caffe_layers.cpp), compiled against the stand-in
 Caffe headers and driven through LayerRegistry<float>::CreateLayer by prototxt type string -- the same way, through
 the same C shim, as the reference's own layer classes in oracle/_ref.  Checks: the plug-in builds, registers the
-seven type strings, enforces the reference's CHECKs, and computes what the oracle (and the reference) computes."""
+eight type strings, enforces the reference's CHECKs, and computes what the oracle (and the reference) computes."""
 import os
 import subprocess
 
@@ -22,7 +22,7 @@ def test_adapter_builds_and_exports_layer_driver():
     subprocess.check_call(["bash", os.path.join(ROOT, "flownet2_amd", "csrc", "caffe_adapter", "build_adapter.sh")], stdout=subprocess.DEVNULL)
     assert ref.adapter_available()
     out = subprocess.check_output(["nm", "-D", ref.ADAPTER_SO]).decode()
-    for sym in ("fn2ref_correlation", "fn2ref_correlation1d", "fn2ref_flow_warp", "fn2ref_resample", "fn2ref_channel_norm", "fn2ref_downsample", "fn2ref_l1loss"):
+    for sym in ("fn2ref_correlation", "fn2ref_correlation1d", "fn2ref_flow_augmentation", "fn2ref_flow_warp", "fn2ref_resample", "fn2ref_channel_norm", "fn2ref_downsample", "fn2ref_l1loss"):
         assert sym in out
     # the adapter must call INTO libflownet2_hip.so (undefined symbols resolved at load time), not re-implement it
     assert " U fn2_correlation_forward" in out and " U fn2_flow_warp_backward" in out
@@ -58,6 +58,14 @@ def test_adapter_layers_match_oracle(adapter):
         o0, o1 = oracle.correlation1d_backward(po, b0, b1, td)
         np.testing.assert_allclose(d0, o0, rtol=0, atol=3e-6)
         np.testing.assert_allclose(d1, o1, rtol=0, atol=3e-6)
+    # FlowAugmentation: coefficient blobs in coeff_to_array layout (mirror, dx, dy, angle, log zoom_x, log zoom_y, defaults)
+    fl = rnd((2, 2, 24, 40), 31, 3.0)
+    c1, c2 = np.zeros((2, 42), np.float32), np.zeros((2, 42), np.float32)
+    c1[:, :6] = [[0, 0.02, -0.03, 0.1, 0.1, 0.05], [1, 0, 0.01, -0.05, 0, 0.08]]
+    c2[:, :6] = [[0, -0.01, 0.02, 0.05, 0.05, 0.1], [1, 0.03, 0, 0, 0.1, 0.1]]
+    got = adapter.flow_augmentation(fl, c1, c2, 16, 28)
+    err = np.abs(got - oracle.flow_augmentation_forward(fl, c1, c2, 16, 28))
+    assert np.quantile(err, 0.99) < 1e-4       # an i.i.d. flow: a rounding flip of the sampled pixel changes an output completely
     img, flow, g = rnd((2, 3, 24, 40), 4), rnd((2, 2, 24, 40), 5, 5.0), rnd((2, 3, 24, 40), 6)
     out, di, df = adapter.flow_warp(img, flow, 1, g)
     np.testing.assert_allclose(out, oracle.flow_warp_forward(img, flow), rtol=0, atol=1e-6)
