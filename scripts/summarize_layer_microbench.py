@@ -18,6 +18,9 @@ if os.path.exists(txt):
     out += ["", "Per-workload table of the same script, timed from the host with HIP events around 100 back-to-back calls (FlowWarp backward = 3 kernels + 2",
             "memsets; blobs of a few MB are bounded below by the ~10-15 us Python launch path, not by the kernel):", ""]
     out += [l.rstrip() for l in open(txt) if l.startswith("|")]
+    extra = [l.rstrip() for l in open(txt) if l.startswith(("CPU decode", "reference CustomDataLayer", "host -> device"))]
+    if extra:
+        out += ["", "Host side of the sample decode on the same box (`oracle/_ref` = the reference's own CustomData layer compiled in place):", ""] + ["* " + l for l in extra]
 out += ["", "Notes: FlowWarp with an i.i.d. random flow makes every lane touch its own cache line (texture-path bound); the smooth field",
         "(bilinear up-sampling of a coarse random field, same magnitude) is what a network predicts.  Resample keeps the reference's 25 taps",
         "per output including the zero-weight ones (a NaN there poisons the output in the reference too)."]
