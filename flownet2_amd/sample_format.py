@@ -154,7 +154,23 @@ def stage_records(records: Sequence[bytes], device="cuda"):
         if (d.channels, d.height, d.width) != (d0.channels, d0.height, d0.width) or d.data is None or len(d.data) != len(d0.data):
             raise ValueError("records of one batch must share channels / height / width and hold `data` bytes")
     stride = (len(d0.data) + 15) // 16 * 16                     # keeps every sample 16-byte aligned
-    host = torch.zeros((len(datums), stride), dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.zeros((len(datums), stride), dtype=torch.uint8)
+    host = _staging(len(datums), stride)
     for i, d in enumerate(datums):
         host[i, :len(d.data)] = torch.frombuffer(bytearray(d.data), dtype=torch.uint8)
-    return host.to(device, non_blocking=True), (d0.channels, d0.height, d0.width), [d.label for d in datums]
+    out = host.to(device, non_blocking=True)
+    if out.is_cuda:
+        torch.cuda.current_stream().synchronize()                 # the staging buffer is reused by the next batch
+    return out, (d0.channels, d0.height, d0.width), [d.label for d in datums]
+
+
+_STAGING = {}
+
+
+def _staging(n: int, stride: int) -> torch.Tensor:
+    """Page-locked host buffer for one batch of packed samples, kept between batches (pinning 16 MB costs ~20 ms, copying it ~0.3 ms)."""
+    key = (n, stride)
+    if key not in _STAGING:
+        _STAGING.clear()
+        buf = torch.zeros((n, stride), dtype=torch.uint8)
+        _STAGING[key] = buf.pin_memory() if torch.cuda.is_available() else buf
+    return _STAGING[key]

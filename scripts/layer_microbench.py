@@ -54,6 +54,14 @@ xi = torch.randn(8, 512, 20, 28, device=dev, generator=g)
 add("im2col 3x3/2 [8,512,20,28]", lambda: ops.im2col_forward(xi, 3, 1, 2), 4 * xi.numel() + 4 * 8 * 512 * 9 * 140)
 col = torch.randn(8, 64 * 16, 40 * 56, device=dev, generator=g); b64 = torch.randn(64, device=dev, generator=g)
 add("col2im 4x4/2 + bias + ReLU -> [8,64,80,112]", lambda: ops.col2im_bias_relu_forward(col, b64, 8, 64, 80, 112, 4, 1, 2), 4 * col.numel() + 4 * 8 * 64 * 80 * 112)
+# FlowAugmentation at the training crop of config A (FlyingChairs 512x384 -> 448x320), Correlation1D with DispNetCorr1D's parameters
+import numpy as np
+flow_a = torch.randn(8, 2, 384, 512, device=dev, generator=g) * 8
+c_id = np.zeros((8, 42), np.float32); c_id[:, :6] = [0, 0.01, -0.02, 0.05, 0.1, 0.08]
+add("FlowAugmentation [8,2,384,512]->[320,448]", lambda: ops.flow_augmentation_forward(flow_a, c_id, c_id, 320, 448), 8 * 320 * 448 * 16)
+a1 = torch.randn(4, 256, 48, 96, device=dev, generator=g); b1 = torch.randn(4, 256, 48, 96, device=dev, generator=g)
+p1d = ops.corr_params(40, 1, 40, 1, 1, single_direction=-1)
+add("Correlation1D fwd [4,256,48,96] md 40 left (generic kernel)", lambda: ops.correlation1d_forward(p1d, a1, b1), 4 * 4 * 48 * 96 * (2 * 256 + 41))
 # CustomData sample decode: a batch of 8 FlyingChairs samples (512x384): 10.125 B/pixel of packed bytes in, 9 fp32 planes out
 from flownet2_amd import sample_format as SF
 Hs, Ws, Ns = 384, 512, 8
@@ -81,7 +89,9 @@ if ref.available():
     recs = [("%08d" % i, oracle.datum_serialize(9, Hs, Ws, host[i, :nb].tobytes(), i)) for i in range(Ns)]
     t0 = time.time(); ref.custom_data(recs, Ns, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS, n_forward=4); t_ref = (time.time() - t0) / 5   # SetUp prefetches one batch too
     print("reference CustomDataLayer (oracle/_ref, host prefetch thread): %.1f ms per batch of %d (%.0f samples/s)" % (t_ref * 1e3, Ns, Ns / t_ref))
+pinned = torch.from_numpy(host).pin_memory()
+src = torch.from_numpy(host)
 t0 = time.time()
-for _ in range(5):
-    dev_copy = torch.from_numpy(host).pin_memory().to(dev, non_blocking=True); torch.cuda.synchronize()
-print("host -> device copy of the packed batch (%.1f MB, incl. pinning): %.2f ms" % (host.nbytes / 1e6, (time.time() - t0) / 5 * 1e3))
+for _ in range(20):
+    pinned.copy_(src); dev_copy = pinned.to(dev, non_blocking=True); torch.cuda.synchronize()
+print("host -> device copy of the packed batch through a persistent pinned buffer (%.1f MB): %.2f ms" % (host.nbytes / 1e6, (time.time() - t0) / 20 * 1e3))
