@@ -27,6 +27,7 @@ EXPORTS = [
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_decode_forward",
     "fn2_augmentation_matrix", "fn2_flow_augmentation_forward",
+    "fn2_data_augmentation_workspace_bytes", "fn2_data_augmentation_forward",
 ]
 
 
@@ -47,6 +48,11 @@ class CorrParams(C.Structure):
 class DatumView(C.Structure):
     _fields_ = [("channels", C.c_int), ("height", C.c_int), ("width", C.c_int), ("label", C.c_int), ("encoded", C.c_int),
                 ("data", C.c_void_p), ("data_bytes", C.c_size_t), ("float_data_count", C.c_size_t)]
+
+
+class DataAugParams(C.Structure):
+    _fields_ = [("crop_width", C.c_int), ("crop_height", C.c_int), ("max_multiplier", C.c_float), ("has_chromatic_eigvec", C.c_int),
+                ("chromatic_eigvec", C.c_float * 9), ("mean_mode", C.c_int)]
 
 
 class L1LossParams(C.Structure):
@@ -113,6 +119,9 @@ def lib():
     L.fn2_custom_data_decode_forward.argtypes = [vp, sz, i, i, i, i, ip, i, ip, i, i, fp, C.c_float, C.POINTER(C.c_void_p), vp]
     L.fn2_augmentation_matrix.argtypes = [fp, i, i, i, i, i, fp]
     L.fn2_flow_augmentation_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, i, vp]
+    L.fn2_data_augmentation_workspace_bytes.argtypes = [i]
+    L.fn2_data_augmentation_workspace_bytes.restype = sz
+    L.fn2_data_augmentation_forward.argtypes = [C.POINTER(DataAugParams), fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
     for name in EXPORTS:

@@ -5,54 +5,17 @@
 // matrices on the host from the coefficient blobs, uploads them through two SyncedMemory buffers and launches WarpData; here the
 // matrices travel as kernel arguments (12 floats per sample, 64 samples per launch): no workspace, no copy.
 // HBM-bound: one gathered read of (u, v) and one coalesced write of (u', v') per output pixel.
-#include "fn2_common.hpp"
-
-#include <cmath>
+#include "augmentation.hpp"
 
 namespace fn2 {
 
-// tTransMat, include/caffe/layers/augmentation_layer_base.hpp:20-35:  | t0 t2 t4 |
-//                                                                     | t1 t3 t5 |
-struct TransMat {
-  float t0, t1, t2, t3, t4, t5;
-  void identity() { t0 = 1; t2 = 0; t4 = 0; t1 = 0; t3 = 1; t5 = 0; }                        // cpp:15-19
-  void left_multiply(float u0, float u1, float u2, float u3, float u4, float u5) {           // cpp:22-35
-    const float a0 = t0, a2 = t2, a4 = t4, a1 = t1, a3 = t3, a5 = t5;
-    t0 = a0 * u0 + a1 * u2;
-    t1 = a0 * u1 + a1 * u3;
-    t2 = a2 * u0 + a3 * u2;
-    t3 = a2 * u1 + a3 * u3;
-    t4 = a4 * u0 + a5 * u2 + u4;
-    t5 = a4 * u1 + a5 * u3 + u5;
-  }
-  TransMat inverse() const {                                                                 // cpp:52-68
-    const float a = t0, c = t2, e = t4, b = t1, d = t3, f = t5;
-    const float denom = a * d - b * c;
-    TransMat r;
-    r.t0 = d / denom;
-    r.t1 = -b / denom;
-    r.t2 = -c / denom;
-    r.t3 = a / denom;
-    r.t4 = (c * f - d * e) / denom;
-    r.t5 = (b * e - a * f) / denom;
-    return r;
-  }
-};
-
-// array_to_coeff (cpp:368-380: fields with a non-zero default come back through exp) followed by fromCoeff (cpp:38-49).  After
-// array_to_coeff every field is "set", so each factor is applied.  The double -> float conversions are the reference's: the
-// arguments of leftMultiply are floats, its call sites compute them in double.
+// FlowAugmentationLayer::Forward_gpu, flow_augmentation_layer.cu:126-143: array_to_coeff (every field set) -> toIdentity -> fromCoeff
 static TransMat matrix_from_coeffs(const float* in, int width, int height, int bottomwidth, int bottomheight) {
-  const float mirror = in[0], dx = in[1], dy = in[2], angle = in[3];
-  const float zoom_x = (float)std::exp((double)in[4]), zoom_y = (float)std::exp((double)in[5]);   // exp(Dtype) resolves to ::exp(double), cpp:376
+  AugCoeff c;
+  c.from_array(in);
   TransMat m;
   m.identity();
-  if (mirror) m.left_multiply(-1, 0, 0, 1, (float)(.5 * (double)(float)width), (float)(-.5 * (double)(float)height));
-  else m.left_multiply(1, 0, 0, 1, (float)(-.5 * (double)(float)width), (float)(-.5 * (double)(float)height));
-  m.left_multiply((float)std::cos((double)angle), (float)std::sin((double)angle), (float)-std::sin((double)angle), (float)std::cos((double)angle), 0, 0);
-  m.left_multiply(1, 0, 0, 1, dx * (float)width, dy * (float)height);
-  m.left_multiply((float)(1.0 / (double)zoom_x), 0, 0, (float)(1.0 / (double)zoom_y), 0, 0);
-  m.left_multiply(1, 0, 0, 1, (float)(.5 * (double)(float)bottomwidth), (float)(.5 * (double)(float)bottomheight));
+  m.from_coeff(c, width, height, bottomwidth, bottomheight);
   return m;
 }
 

@@ -1,6 +1,7 @@
 // Stand-in for include/caffe/blob.hpp + syncedmem.hpp: NCHW fp32 tensor with data and diff, lazily mirrored
 // between host and device (the head-state machine of syncedmem.cpp:25-77, reduced to what layers use).
 #pragma once
+#include <cstring>
 #include <sstream>
 #include <string>
 
@@ -66,6 +67,14 @@ class Blob {
     }
   }
   void ReshapeLike(const Blob& o) { Reshape(o.shape()); }
+  void CopyFrom(const Blob& source, bool copy_diff = false, bool reshape = false) {      // blob.cpp:421-457, host copy
+    if (source.count() != count_ || source.shape() != shape_) {
+      if (reshape) ReshapeLike(source);
+      else LOG(FATAL) << "Trying to copy blobs of different sizes.";
+    }
+    if (copy_diff) std::memcpy(mutable_cpu_diff(), source.cpu_diff(), sizeof(Dtype) * count_);
+    else std::memcpy(mutable_cpu_data(), source.cpu_data(), sizeof(Dtype) * count_);
+  }
   const vector<int>& shape() const { return shape_; }
   int shape(int i) const { return shape_[i < 0 ? i + (int)shape_.size() : i]; }
   int num_axes() const { return (int)shape_.size(); }

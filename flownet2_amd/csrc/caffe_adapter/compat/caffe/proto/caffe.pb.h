@@ -384,7 +384,21 @@ class AugmentationCoeff {
   bool has_[kNumFields];
 };
 
-class CoeffScheduleParameter {};     // caffe.proto:693-697: a member of DataAugmentationLayer, whose header flow_augmentation_layer.cu includes
+class CoeffScheduleParameter {       // caffe.proto:693-697
+ public:
+  float half_life() const { return half_life_; }
+  float initial_coeff() const { return initial_coeff_; }
+  float final_coeff() const { return final_coeff_; }
+ private:
+  float half_life_ = 1, initial_coeff_ = 1, final_coeff_ = 1;
+};
+class ParamSpec {                    // caffe.proto:284-308, the two setters DataAugmentationLayer::LayerSetUp calls
+ public:
+  void set_lr_mult(float v) { lr_mult_ = v; }
+  void set_decay_mult(float v) { decay_mult_ = v; }
+ private:
+  float lr_mult_ = 1, decay_mult_ = 1;
+};
 class RandomGeneratorParameter {};   // caffe.proto:607-616: only handed to caffe_rng_generate, which the pins never reach
 // AugmentationParameter, caffe.proto:489-546: crop size (read by the layers) and the generator sub-messages (named by
 // augmentation_layer_base.cpp's generate_* functions, absent here: has_*() is false)
@@ -397,15 +411,34 @@ class AugmentationParameter {
  public:
   unsigned crop_width() const { return crop_width_; }
   unsigned crop_height() const { return crop_height_; }
-  void set_crop_width(unsigned v) { crop_width_ = v; }
-  void set_crop_height(unsigned v) { crop_height_ = v; }
+  bool has_crop_width() const { return has_crop_width_; }
+  bool has_crop_height() const { return has_crop_height_; }
+  void set_crop_width(unsigned v) { crop_width_ = v; has_crop_width_ = true; }
+  void set_crop_height(unsigned v) { crop_height_ = v; has_crop_height_ = true; }
+  // the fields DataAugmentationLayer reads (defaults of caffe.proto:492-505)
+  bool has_write_augmented() const { return false; }
+  const std::string& write_augmented() const { static const std::string e; return e; }
+  float max_multiplier() const { return max_multiplier_; }
+  void set_max_multiplier(float v) { max_multiplier_ = v; }
+  bool augment_during_test() const { return false; }
+  unsigned recompute_mean() const { return recompute_mean_; }
+  void set_recompute_mean(unsigned v) { recompute_mean_ = v; }
+  bool mean_per_pixel() const { return mean_per_pixel_; }
+  void set_mean_per_pixel(bool v) { mean_per_pixel_ = v; }
+  const RepeatedField<float>& mean() const { return mean_; }
+  void add_mean(float v) { mean_.Add(v); }
+  const RepeatedField<float>& chromatic_eigvec() const { return chromatic_eigvec_; }
+  void add_chromatic_eigvec(float v) { chromatic_eigvec_.Add(v); }
 #define X(name)                                                                                   \
   bool has_##name() const { return false; }                                                       \
   const RandomGeneratorParameter& name() const { static const RandomGeneratorParameter r; return r; }
   FN2_AUG_PARAM_GENERATORS(X)
 #undef X
  private:
-  unsigned crop_width_ = 0, crop_height_ = 0;
+  unsigned crop_width_ = 0, crop_height_ = 0, recompute_mean_ = 0;
+  bool has_crop_width_ = false, has_crop_height_ = false, mean_per_pixel_ = true;
+  float max_multiplier_ = 255.f;
+  RepeatedField<float> mean_, chromatic_eigvec_;
 };
 
 enum Phase { TRAIN = 0, TEST = 1 };
@@ -441,6 +474,10 @@ class LayerParameter {
   ConvolutionParameter* mutable_convolution_param() { return &convolution_param_; }
   const ReLUParameter& relu_param() const { return relu_param_; }
   ReLUParameter* mutable_relu_param() { return &relu_param_; }
+  const CoeffScheduleParameter& coeff_schedule_param() const { return coeff_schedule_param_; }   // = 148 (DataAugmentation, oracle/_ref only)
+  ParamSpec* add_param() { param_.emplace_back(); return &param_.back(); }
+  ParamSpec* mutable_param(int i) { return &param_[i]; }
+  int param_size() const { return (int)param_.size(); }
   const AugmentationParameter& augmentation_param() const { return augmentation_param_; }     // = 149 (FlowAugmentation)
   AugmentationParameter* mutable_augmentation_param() { return &augmentation_param_; }
   const DataParameter& data_param() const { return data_param_; }                            // CustomData (oracle/_ref only)
@@ -448,6 +485,8 @@ class LayerParameter {
  private:
   DataParameter data_param_;
   AugmentationParameter augmentation_param_;
+  CoeffScheduleParameter coeff_schedule_param_;
+  std::vector<ParamSpec> param_;
   std::string name_, type_;
   std::vector<float> loss_weight_;
   bool reshape_every_iter_ = true;

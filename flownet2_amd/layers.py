@@ -432,6 +432,64 @@ class DownsampleLayer(Layer):
             raise CheckError("DownsamplingLayer cannot do backward.")                 # downsample_layer.cu:132-138
 
 
+class DataAugmentationLayer(Layer):
+    """include/caffe/layers/data_augmentation_layer.hpp; data_augmentation_layer.cpp:32-160, .cu:320-637 -- for GIVEN coefficients.
+    bottom = [images] or [images, coefficient blob] (`input_params_`); top = [augmented] or [augmented, coefficient blob].
+    Without bottom[1] every sample gets the default coefficients (what the reference does outside the training phase, .cu:375-387:
+    centre crop, no colour change); drawing random coefficients (generate_*_coeffs, boost generators) is not reproduced.
+    Mean: `augmentation_param.mean` (3 values) with `mean_per_pixel: false` (.cpp:142-151), or the blobs a trained model carries
+    (`set_mean(per_channel=...)` = blobs_[2], `set_mean(per_pixel=...)` = blobs_[1], .cu:592-621); the running re-computation of the
+    mean over the first `recompute_mean` iterations is training-time state of the reference layer and is not reproduced."""
+
+    def type(self): return "DataAugmentation"
+    def AllowBackward(self): return False                                            # hpp:29
+
+    def LayerSetUp(self, bottom, top):
+        self.layer_param_.reshape_every_iter = False                                  # cpp:38
+        self.mean_ = None
+        self.mean_mode_ = ops.MEAN_NONE
+
+    def set_mean(self, per_channel=None, per_pixel=None):
+        CHECK((per_channel is None) != (per_pixel is None), "give exactly one of per_channel / per_pixel")
+        self.mean_ = (per_channel if per_channel is not None else per_pixel).contiguous().float()
+        self.mean_mode_ = ops.MEAN_PER_CHANNEL if per_channel is not None else ops.MEAN_PER_PIXEL
+
+    def Reshape(self, bottom, top):
+        CHECK(1 <= len(bottom) <= 2, "Data augmentation layer takes one or two input blobs.")          # cpp:78-79
+        CHECK(1 <= len(top) <= 2, "Data augmentation layer outputs one or two output blobs.")          # cpp:80-81
+        ap = self.layer_param_.augmentation_param
+        num, channels, height, width = bottom[0].num(), bottom[0].channels(), bottom[0].height(), bottom[0].width()
+        self.output_params_, self.input_params_ = len(top) > 1, len(bottom) > 1
+        self.do_cropping_ = "crop_width" in ap and "crop_height" in ap                                 # cpp:94
+        if self.do_cropping_:
+            self.cropped_width_, self.cropped_height_ = int(ap["crop_width"]), int(ap["crop_height"])
+            CHECK(width >= self.cropped_width_, "crop width greater than original")                     # cpp:103
+            CHECK(height >= self.cropped_height_, "crop height greater than original")                  # cpp:104
+        else:
+            self.cropped_width_, self.cropped_height_ = width, height
+        top[0].Reshape(num, channels, self.cropped_height_, self.cropped_width_)                        # cpp:108
+        if self.output_params_:
+            top[1].Reshape(num, ops.AUG_NUM_PARAMS, 1, 1)                                               # cpp:121-126
+        mean = list(ap.get("mean", []))
+        if len(mean) == 3 and not ap.get("mean_per_pixel", True):                                       # cpp:142-151
+            self.mean_host_ = [float(v) for v in mean]
+            self.mean_mode_ = ops.MEAN_PER_CHANNEL
+        self.params_ = ops.data_aug_params(self.cropped_width_ if self.do_cropping_ else 0, self.cropped_height_ if self.do_cropping_ else 0,
+                                           ap.get("max_multiplier", 255.0), ap.get("chromatic_eigvec") or None, self.mean_mode_)
+
+    def Forward_gpu(self, bottom, top):
+        if self.mean_ is None and getattr(self, "mean_host_", None) is not None:
+            self.mean_ = torch.tensor(self.mean_host_, dtype=torch.float32, device=bottom[0].data.device)
+        self.params_.mean_mode = self.mean_mode_
+        coeffs = bottom[1].data if self.input_params_ else None
+        top[0].data = _wrap(ops.data_augmentation_forward, self.params_, bottom[0].data, coeffs, self.mean_)
+        if self.output_params_:                                                                         # .cu:346-347: the same blob
+            top[1].data = bottom[1].data if self.input_params_ else torch.zeros_like(top[1].data)
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        CHECK(not any(propagate_down), "DataAugmentationLayer cannot do backward.")                    # hpp:38-41
+
+
 class FlowAugmentationLayer(Layer):
     """include/caffe/layers/flow_augmentation_layer.hpp; flow_augmentation_layer.cpp:30-72, .cu:92-160.
     bottom = [flow, coefficient blob of image 1, coefficient blob of image 2] (the `params` outputs of the two DataAugmentation layers)."""
@@ -607,5 +665,6 @@ REGISTER_LAYER_CLASS("Resample", ResampleLayer)            # resample_layer.cpp:
 REGISTER_LAYER_CLASS("L1Loss", L1LossLayer)                # l1loss_layer.cpp:108-109
 REGISTER_LAYER_CLASS("ChannelNorm", ChannelNormLayer)      # channel_norm_layer.cpp:193-194
 REGISTER_LAYER_CLASS("Downsample", DownsampleLayer)        # downsample_layer.cpp:78-79
+REGISTER_LAYER_CLASS("DataAugmentation", DataAugmentationLayer)   # data_augmentation_layer.cpp:218-219
 REGISTER_LAYER_CLASS("FlowAugmentation", FlowAugmentationLayer)   # flow_augmentation_layer.cpp:88-89
 REGISTER_LAYER_CLASS("CustomData", CustomDataLayer)        # custom_data_layer.cpp:712-713

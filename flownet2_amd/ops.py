@@ -327,3 +327,44 @@ def flow_augmentation_forward(flow, coeffs1, coeffs2, crop_height, crop_width):
     check(_lib.lib().fn2_flow_augmentation_forward(_ptr(fl), C.c_void_p(host[0].ctypes.data), C.c_void_p(host[1].ctypes.data), _ptr(top),
                                                    N, H, W, int(crop_height), int(crop_width), _stream()))
     return top
+
+
+MEAN_NONE, MEAN_PER_CHANNEL, MEAN_PER_PIXEL = 0, 1, 2
+
+
+def data_aug_params(crop_width=0, crop_height=0, max_multiplier=255.0, chromatic_eigvec=None, mean_mode=MEAN_NONE):
+    p = _lib.DataAugParams(int(crop_width), int(crop_height), float(max_multiplier), int(chromatic_eigvec is not None))
+    if chromatic_eigvec is not None:
+        if len(chromatic_eigvec) != 9:
+            raise ValueError("chromatic_eigvec must have 9 entries")
+        p.chromatic_eigvec = (C.c_float * 9)(*[float(v) for v in chromatic_eigvec])
+    p.mean_mode = int(mean_mode)
+    return p
+
+
+def data_augmentation_forward(p, bottom, coeffs=None, mean=None):
+    """bottom: CUDA [N,C,H,W]; coeffs: [N,42] coefficient arrays (host side, like the reference's cpu_data()) or None = defaults;
+    mean: CUDA tensor of C (per channel) or C*crop_h*crop_w (per pixel) values, as p.mean_mode says.  Returns [N,C,crop_h,crop_w]."""
+    import numpy as np
+    x = _chk(bottom, "bottom[0]")
+    N, Cc, H, W = x.shape
+    crop = p.crop_width > 0 and p.crop_height > 0
+    ch, cw = (p.crop_height, p.crop_width) if crop else (H, W)
+    host = None
+    if coeffs is not None:
+        host = coeffs.detach().cpu().numpy() if isinstance(coeffs, torch.Tensor) else np.asarray(coeffs)
+        host = np.ascontiguousarray(host, np.float32).reshape(N, -1)
+        if host.shape[1] != AUG_NUM_PARAMS:
+            raise ValueError(f"coefficient blob must hold {AUG_NUM_PARAMS} values per sample")
+    m = None
+    if p.mean_mode != MEAN_NONE:
+        m = _chk(mean, "mean", ndim=None)
+        want = Cc if p.mean_mode == MEAN_PER_CHANNEL else Cc * ch * cw
+        if m.numel() != want:
+            raise ValueError(f"mean: expected {want} values")
+    top = torch.empty((N, Cc, max(ch, 0), max(cw, 0)), device=x.device, dtype=torch.float32)
+    nws = _lib.lib().fn2_data_augmentation_workspace_bytes(N)
+    ws = torch.empty(nws, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().fn2_data_augmentation_forward(C.byref(p), _ptr(x), C.c_void_p(host.ctypes.data) if host is not None else None, _ptr(m),
+                                                   _ptr(top), N, Cc, H, W, _ptr(ws), nws, _stream()))
+    return top

@@ -332,6 +332,37 @@ int fn2_augmentation_matrix(const float* coeffs, int crop_width, int crop_height
 int fn2_flow_augmentation_forward(const float* flow, const float* coeffs1_host, const float* coeffs2_host, float* top,
                                   int N, int H, int W, int crop_height, int crop_width, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DataAugmentation  (type: "DataAugmentation"; the image half of the augmentation, applied for GIVEN coefficients)
+ *   forward <- DataAugmentationLayer::Forward_gpu, src/caffe/layers/data_augmentation_layer.cu:320-637, the part after the coefficient
+ *              blob exists (:452-637): per sample array_to_coeff + clear_defaults (a field within 1e-3 of its default is dropped,
+ *              augmentation_layer_base.cpp:340-350) -> tTransMat / tChromaticCoeffs / tChromaticEigenCoeffs / tEffectCoeffs, then
+ *                SpatialAugmentation        :24-69   bilinear sample of the source at M (x, y), clamped to [0, W-1.05] x [0, H-1.05]
+ *                ChromaticEigenAugmentation :192-291 (with ComputeChromaticEigenspace :147-187 over the SOURCE batch)
+ *                ColorContrastAugmentation  :72-116  colour, brightness compensation, gamma, brightness, contrast
+ *                ApplyEffects               :295-317 half-plane shadow
+ *              and the mean subtraction :592-635 (per pixel :613-616, per channel :617-634).  One kernel does all of it per pixel.
+ *   shapes  <- DataAugmentationLayer::Reshape, data_augmentation_layer.cpp:74-160: top [N,C,crop_height,crop_width]; without a crop size
+ *              the layer copies the bottom (:590) and only the mean is applied.
+ * Not part of this entry point: drawing the coefficients (generate_*_coeffs use boost generators: their stream cannot be reproduced),
+ * the noise effect (cuRAND, :578-587: a coefficient array with noise > 0 is refused), fog / motion blur (coefficients exist, the
+ * reference has no kernel for them either), the running re-computation of the mean over the first iterations (:597-606; state of the
+ * layer object -- pass the mean in).  Colour transforms need 3 channels (CHECKs :489,:540,:548,:556).
+ * ---------------------------------------------------------------------------------------------- */
+enum { FN2_MEAN_NONE = 0, FN2_MEAN_PER_CHANNEL = 1, FN2_MEAN_PER_PIXEL = 2 };
+typedef struct fn2_data_aug_params {
+  int crop_width, crop_height;     /* AugmentationParameter.crop_width = 33 / crop_height = 34; both 0 = no cropping, no augmentation */
+  float max_multiplier;            /* max_multiplier = 3 [default 255] */
+  int has_chromatic_eigvec;        /* chromatic_eigvec = 83 (9 floats), needed when a sample has chromatic-eigen coefficients */
+  float chromatic_eigvec[9];
+  int mean_mode;                   /* FN2_MEAN_*: what `mean` holds: C floats, or C*crop_height*crop_width floats */
+} fn2_data_aug_params;
+/* Device scratch for the chromatic-eigen statistics of the batch. */
+size_t fn2_data_augmentation_workspace_bytes(int N);
+/* bottom [N,C,H,W] device; coeffs_host [N,42] HOST (coeff_to_array layout) or NULL = all defaults; mean device or NULL. */
+int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const float* bottom, const float* coeffs_host, const float* mean,
+                                  float* top, int N, int C, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

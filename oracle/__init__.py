@@ -358,3 +358,24 @@ def flow_augmentation_forward(flow, coeffs1, coeffs2, crop_height, crop_width):
     top = np.empty((N, 2, crop_height, crop_width), np.float32)
     _check(lib().fn2_flow_augmentation_forward_cpu(_p(flow), _p(c1), _p(c2), _p(top), N, H, W, crop_height, crop_width), "flow_augmentation_forward")
     return top
+
+
+class DataAugParams(C.Structure):
+    _fields_ = [("crop_width", C.c_int), ("crop_height", C.c_int), ("max_multiplier", C.c_float), ("has_chromatic_eigvec", C.c_int),
+                ("chromatic_eigvec", C.c_float * 9), ("mean_mode", C.c_int)]
+
+
+def data_augmentation_forward(bottom, coeffs=None, crop_height=0, crop_width=0, mean=None, mean_mode=0, max_multiplier=255.0, chromatic_eigvec=None):
+    bottom = _f32(bottom)
+    N, Cc, H, W = bottom.shape
+    crop = crop_width > 0 and crop_height > 0
+    ch, cw = (crop_height, crop_width) if crop else (H, W)
+    p = DataAugParams(crop_width, crop_height, max_multiplier, int(chromatic_eigvec is not None))
+    if chromatic_eigvec is not None:
+        p.chromatic_eigvec = (C.c_float * 9)(*[float(v) for v in chromatic_eigvec])
+    p.mean_mode = mean_mode
+    co = _f32(coeffs).reshape(N, 42) if coeffs is not None else None
+    m = _f32(mean) if mean is not None else None
+    top = np.empty((N, Cc, max(ch, 1), max(cw, 1)), np.float32)
+    _check(lib().fn2_data_augmentation_forward_cpu(C.byref(p), _p(bottom), _p(co), _p(m), _p(top), N, Cc, H, W), "data_augmentation_forward")
+    return top

@@ -37,6 +37,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <float.h>
 
 #include "../include/flownet2_hip.h"
 
@@ -1336,5 +1337,244 @@ FN2_API int fn2_flow_augmentation_forward_cpu(const float* flow, const float* co
         top[(size_t)dest_width * ((size_t)dest_height * (2 * n + 1) + yi) + xi] = ypos3 - y;                  /* :61 */
       }
   }
+  return FN2_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * DataAugmentation for given coefficients: data_augmentation_layer.cu:320-637 from the point where the coefficient blob exists
+ * (:452), kernels :24-317, coefficient structs include/caffe/layers/augmentation_layer_base.hpp:37-127, clear_defaults
+ * augmentation_layer_base.cpp:340-350.  The passes run one after the other over the whole batch, as in the reference.
+ * ---------------------------------------------------------------------------------------------- */
+enum { OA_MIRROR, OA_DX, OA_DY, OA_ANGLE, OA_ZOOM_X, OA_ZOOM_Y, OA_GAMMA, OA_BRIGHTNESS, OA_CONTRAST, OA_COLOR1, OA_COLOR2, OA_COLOR3,
+       OA_POW_NOMEAN0, OA_ADD_NOMEAN0 = OA_POW_NOMEAN0 + 3, OA_MULT_NOMEAN0 = OA_ADD_NOMEAN0 + 3, OA_POW_WITHMEAN0 = OA_MULT_NOMEAN0 + 3,
+       OA_ADD_WITHMEAN0 = OA_POW_WITHMEAN0 + 3, OA_MULT_WITHMEAN0 = OA_ADD_WITHMEAN0 + 3, OA_LMULT_POW = OA_MULT_WITHMEAN0 + 3, OA_LMULT_ADD,
+       OA_LMULT_MULT, OA_COL_ANGLE, OA_FOG_AMOUNT, OA_FOG_SIZE, OA_MOTION_BLUR_ANGLE, OA_MOTION_BLUR_SIZE, OA_SHADOW_ANGLE,
+       OA_SHADOW_DISTANCE, OA_SHADOW_STRENGTH, OA_NOISE, OA_COUNT };
+static const float oa_default[42] = {0, 0, 0, 0, 1, 1,  1, 0, 1, 1, 1, 1,  1, 1, 1, 0, 0, 0,  1, 1, 1, 1, 1, 1,
+                                     0, 0, 0, 1, 1, 1,  1, 0, 1, 0,  0, 0, 0, 0, 0, 0, 0, 0};   /* caffe.proto:436-486 */
+
+typedef struct oa_coeff { float v[42]; int has[42]; } oa_coeff;
+
+static void oa_from_array(const float* in, oa_coeff* c) {                       /* array_to_coeff, cpp:368-380 */
+  for (int fn = 0; fn < 42; ++fn) {
+    if (fabs(oa_default[fn]) < 1e-3) c->v[fn] = in[fn];
+    else c->v[fn] = (float)exp((double)in[fn]);
+    c->has[fn] = 1;
+  }
+}
+
+static void oa_clear_defaults(oa_coeff* c) {                                    /* cpp:340-350 */
+  for (int fn = 0; fn < 42; ++fn)
+    if (fabs(oa_default[fn] - c->v[fn]) < 1e-3) { c->v[fn] = oa_default[fn]; c->has[fn] = 0; }
+}
+
+static aug_mat oa_matrix(const oa_coeff* c, int width, int height, int bottomwidth, int bottomheight) {   /* toIdentity + fromCoeff, cpp:15-49 */
+  aug_mat m;
+  m.t0 = 1; m.t2 = 0; m.t4 = 0; m.t1 = 0; m.t3 = 1; m.t5 = 0;
+  if (c->v[OA_MIRROR]) aug_left_multiply(&m, -1, 0, 0, 1, (float)(.5 * (float)width), (float)(-.5 * (float)height));
+  else aug_left_multiply(&m, 1, 0, 0, 1, (float)(-.5 * (float)width), (float)(-.5 * (float)height));
+  if (c->has[OA_ANGLE]) aug_left_multiply(&m, (float)cos(c->v[OA_ANGLE]), (float)sin(c->v[OA_ANGLE]), (float)-sin(c->v[OA_ANGLE]), (float)cos(c->v[OA_ANGLE]), 0, 0);
+  if (c->has[OA_DX] || c->has[OA_DY]) aug_left_multiply(&m, 1, 0, 0, 1, c->v[OA_DX] * (float)width, c->v[OA_DY] * (float)height);
+  if (c->has[OA_ZOOM_X] || c->has[OA_ZOOM_Y]) aug_left_multiply(&m, (float)(1.0 / c->v[OA_ZOOM_X]), 0, 0, (float)(1.0 / c->v[OA_ZOOM_Y]), 0, 0);
+  aug_left_multiply(&m, 1, 0, 0, 1, (float)(.5 * (float)bottomwidth), (float)(.5 * (float)bottomheight));
+  return m;
+}
+
+static inline float oa_clamp(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }               /* cu:20-22 */
+
+typedef struct oa_eigenspace { float mean_eig[3], mean_rgb[3], max_abs_eig[3], max_rgb[3], min_rgb[3], max_l, eigvec[9]; } oa_eigenspace;
+
+FN2_API int fn2_data_augmentation_forward_cpu(const fn2_data_aug_params* p, const float* bottom, const float* coeffs, const float* mean,
+                                              float* top, int N, int C, int H, int W) {
+  if (!p || N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const int do_cropping = p->crop_width > 0 && p->crop_height > 0;                                      /* cpp:94 */
+  const int cw = do_cropping ? p->crop_width : W, ch = do_cropping ? p->crop_height : H;
+  if (W < cw || H < ch) return FN2_ERR_INVALID_ARG;                                                     /* cpp:103-104 */
+  if (p->mean_mode < FN2_MEAN_NONE || p->mean_mode > FN2_MEAN_PER_PIXEL) return FN2_ERR_INVALID_ARG;
+  if (N == 0) return FN2_OK;
+  if (!bottom || !top || (p->mean_mode != FN2_MEAN_NONE && !mean)) return FN2_ERR_INVALID_ARG;
+  const int width = W, height = H, channels = C;
+  const long long src_count = (long long)N * C * H * W;
+  const size_t area = (size_t)ch * cw, count = area * C;
+  const float max_multiplier = p->max_multiplier;
+  static const float zeros[42] = {0};
+
+  if (!do_cropping) {
+    memcpy(top, bottom, sizeof(float) * (size_t)src_count);                                             /* :590 */
+  } else {
+    oa_coeff* co = (oa_coeff*)malloc(sizeof(oa_coeff) * (size_t)N);
+    aug_mat* mats = (aug_mat*)malloc(sizeof(aug_mat) * (size_t)N);
+    if (!co || !mats) { free(co); free(mats); return FN2_ERR_WORKSPACE; }
+    int has_chromatic = 0, has_eigen = 0, has_effect = 0;
+    for (int n = 0; n < N; ++n) {                                                                       /* :452-476 */
+      oa_from_array(coeffs ? coeffs + (size_t)n * 42 : zeros, &co[n]);
+      oa_clear_defaults(&co[n]);
+      mats[n] = oa_matrix(&co[n], cw, ch, W, H);
+      const float* v = co[n].v;
+      if (v[OA_GAMMA] != 1 || v[OA_BRIGHTNESS] != 0 || v[OA_CONTRAST] != 1 || v[OA_COLOR1] != 1 || v[OA_COLOR2] != 1 || v[OA_COLOR3] != 1) has_chromatic = 1;   /* hpp:48 */
+      for (int f = OA_POW_NOMEAN0; f <= OA_COL_ANGLE; ++f) if (v[f] != oa_default[f]) has_eigen = 1;  /* hpp:86-94 */
+      if (v[OA_NOISE] > 0) { free(co); free(mats); return FN2_ERR_UNSUPPORTED; }                        /* cuRAND noise, :578-587 */
+      if ((v[OA_FOG_AMOUNT] != 0 && v[OA_FOG_SIZE] != 0) || v[OA_MOTION_BLUR_SIZE] > 0 || v[OA_SHADOW_STRENGTH] > 0) has_effect = 1;   /* hpp:111 */
+    }
+    if ((has_chromatic || has_eigen || has_effect) && C != 3) { free(co); free(mats); return FN2_ERR_INVALID_ARG; }   /* :489,:548,:556 */
+    if (has_eigen && !p->has_chromatic_eigvec) { free(co); free(mats); return FN2_ERR_INVALID_ARG; }   /* :493-494 (LOG(ERROR), then reads an empty list) */
+
+    oa_eigenspace es;
+    if (has_eigen) {                                                                                    /* :488-536 + ComputeChromaticEigenspace :147-187 */
+      memset(&es, 0, sizeof(es));
+      for (int i = 0; i < 9; ++i) es.eigvec[i] = p->chromatic_eigvec[i];
+      for (int c = 0; c < 3; ++c) es.min_rgb[c] = FLT_MAX;
+      for (int n = 0; n < N; ++n)
+        for (size_t px = 0; px < (size_t)H * W; ++px) {
+          float rgb[3];
+          for (int c = 0; c < 3; ++c) rgb[c] = bottom[((size_t)n * 3 + c) * H * W + px];
+          for (int c = 0; c < 3; ++c) {
+            const float eig = es.eigvec[3 * c] * rgb[0] + es.eigvec[3 * c + 1] * rgb[1] + es.eigvec[3 * c + 2] * rgb[2];
+            if (fabsf(eig) > es.max_abs_eig[c]) es.max_abs_eig[c] = fabsf(eig);
+            if (rgb[c] > es.max_rgb[c]) es.max_rgb[c] = rgb[c];
+            if (rgb[c] < es.min_rgb[c]) es.min_rgb[c] = rgb[c];
+            es.mean_rgb[c] += rgb[c] / width / height;                                                  /* atomicAdd of per-thread terms, :176-179 */
+          }
+        }
+      for (int c = 0; c < 3; ++c) es.mean_rgb[c] = es.mean_rgb[c] / N;                                  /* :517-518 */
+      for (int c = 0; c < 3; ++c) {
+        es.mean_eig[c] = es.eigvec[3 * c] * es.mean_rgb[0] + es.eigvec[3 * c + 1] * es.mean_rgb[1] + es.eigvec[3 * c + 2] * es.mean_rgb[2];
+        if (es.max_abs_eig[c] > 1e-2) es.mean_eig[c] = es.mean_eig[c] / es.max_abs_eig[c];
+      }
+      es.max_l = sqrtf(es.max_abs_eig[0] * es.max_abs_eig[0] + es.max_abs_eig[1] * es.max_abs_eig[1] + es.max_abs_eig[2] * es.max_abs_eig[2]);
+    }
+
+    /* SpatialAugmentation, :24-69 */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int cn = 0; cn < N * C; ++cn)
+      for (int y = 0; y < ch; ++y)
+        for (int x = 0; x < cw; ++x) {
+          const int n = cn / channels;
+          const aug_mat* m = &mats[n];
+          float xpos = fmaf((float)x, m->t0, fmaf((float)y, m->t2, m->t4));                             /* :41, contracted on the device */
+          float ypos = fmaf((float)x, m->t1, fmaf((float)y, m->t3, m->t5));                             /* :42 */
+          xpos = oa_clamp(xpos, 0.0f, (float)(width) - 1.05f);                                          /* :44 */
+          ypos = oa_clamp(ypos, 0.0f, (float)(height) - 1.05f);                                         /* :45 */
+          const float tlx = floorf(xpos), tly = floorf(ypos);
+          const long long off = (long long)width * ((long long)height * cn + (long long)tly) + (long long)tlx;   /* :51 */
+          const long long last = src_count - 1;          /* the reference clamps to src_count, one past the end; unreachable inside the image */
+          const float sTL = bottom[off];
+          const float sTR = bottom[off + 1 <= last ? off + 1 : last];
+          const float sBL = bottom[off + width <= last ? off + width : last];
+          const float sBR = bottom[off + 1 + width <= last ? off + 1 + width : last];
+          const float xdist = xpos - tlx, ydist = ypos - tly;
+          /* (1-xd)(1-yd) TL + xd yd BR + (1-xd) yd BL + xd (1-yd) TR, :61-64.  The device compiler contracts the sum of products
+           * into an fma chain: the second product is rounded, the others are fused */
+          float sample = xdist * ydist * sBR;
+          sample = fmaf((1 - xdist) * (1 - ydist), sTL, sample);
+          sample = fmaf((1 - xdist) * ydist, sBL, sample);
+          sample = fmaf(xdist * (1 - ydist), sTR, sample);
+          top[((size_t)cn * ch + y) * cw + x] = sample;                                                 /* :67 */
+        }
+
+    if (has_eigen) {                                                                                    /* ChromaticEigenAugmentation, :192-291 */
+      for (int n = 0; n < N; ++n) {
+        const float* k = co[n].v;
+        for (size_t px = 0; px < area; ++px) {
+          float rgb[3], eig[3], s, s1, l = 0, l1 = 0;
+          for (int c = 0; c < 3; ++c) rgb[c] = top[((size_t)n * 3 + c) * area + px] - es.mean_rgb[c];
+          for (int c = 0; c < 3; ++c) {
+            eig[c] = es.eigvec[3 * c] * rgb[0] + es.eigvec[3 * c + 1] * rgb[1] + es.eigvec[3 * c + 2] * rgb[2];
+            if (es.max_abs_eig[c] > 1e-2f) {
+              eig[c] = eig[c] / es.max_abs_eig[c];
+              eig[c] = copysignf(powf(fabsf(eig[c]), k[OA_POW_NOMEAN0 + c]), eig[c]);
+              eig[c] = eig[c] + k[OA_ADD_NOMEAN0 + c];
+              eig[c] = eig[c] * k[OA_MULT_NOMEAN0 + c];
+            }
+          }
+          for (int c = 0; c < 3; ++c) eig[c] = eig[c] + es.mean_eig[c];
+          if (es.max_abs_eig[0] > 1e-2f) {
+            eig[0] = copysignf(powf(fabsf(eig[0]), k[OA_POW_WITHMEAN0]), eig[0]);
+            eig[0] = eig[0] + k[OA_ADD_WITHMEAN0];
+            eig[0] = eig[0] * k[OA_MULT_WITHMEAN0];
+          }
+          s = sqrtf(eig[1] * eig[1] + eig[2] * eig[2]);
+          s1 = s;
+          if (s > 1e-2f) {
+            s1 = powf(s1, k[OA_POW_WITHMEAN0 + 1]);
+            s1 = fmaxf(s1 + k[OA_ADD_WITHMEAN0 + 1], 0.f);
+            s1 = s1 * k[OA_MULT_WITHMEAN0 + 1];
+          }
+          if (k[OA_COL_ANGLE] != 0) {
+            const float t1 = cosf(k[OA_COL_ANGLE]) * eig[1] - sinf(k[OA_COL_ANGLE]) * eig[2];
+            const float t2 = sinf(k[OA_COL_ANGLE]) * eig[1] + cosf(k[OA_COL_ANGLE]) * eig[2];
+            eig[1] = t1;
+            eig[2] = t2;
+          }
+          for (int c = 0; c < 3; ++c) if (es.max_abs_eig[c] > 1e-2f) eig[c] = eig[c] * es.max_abs_eig[c];
+          if (es.max_l > 1e-2f) { l1 = sqrtf(eig[0] * eig[0] + eig[1] * eig[1] + eig[2] * eig[2]); l1 = l1 / es.max_l; }
+          if (s > 1e-2f) { eig[1] = eig[1] / s * s1; eig[2] = eig[2] / s * s1; }
+          if (es.max_l > 1e-2f) {
+            l = sqrtf(eig[0] * eig[0] + eig[1] * eig[1] + eig[2] * eig[2]);
+            l1 = powf(l1, k[OA_LMULT_POW]);
+            l1 = fmaxf(l1 + k[OA_LMULT_ADD], 0.f);
+            l1 = l1 * k[OA_LMULT_MULT];
+            l1 = l1 * es.max_l;
+            if (l > 1e-2f)
+              for (int c = 0; c < 3; ++c) {
+                eig[c] = eig[c] / l * l1;
+                if (eig[c] > es.max_abs_eig[c]) eig[c] = es.max_abs_eig[c];
+              }
+          }
+          for (int c = 0; c < 3; ++c) {
+            float v = es.eigvec[c] * eig[0] + es.eigvec[3 + c] * eig[1] + es.eigvec[6 + c] * eig[2];
+            v = v < max_multiplier ? v : max_multiplier;
+            v = v > 0 ? v : 0;
+            top[((size_t)n * 3 + c) * area + px] = v;
+          }
+        }
+      }
+    }
+
+    if (has_chromatic) {                                                                                /* ColorContrastAugmentation, :72-116 */
+      for (int n = 0; n < N; ++n) {
+        const float* k = co[n].v;
+        for (size_t px = 0; px < area; ++px) {
+          float rgb[3], mean_in = 0, mean_out = 0;
+          for (int c = 0; c < 3; ++c) {
+            rgb[c] = top[((size_t)n * 3 + c) * area + px];
+            mean_in += rgb[c];
+            rgb[c] *= k[OA_COLOR1 + c];
+            mean_out += rgb[c];
+          }
+          const float brightness_coeff = mean_in / (mean_out + 0.01f);
+          for (int c = 0; c < 3; ++c) {
+            rgb[c] = oa_clamp(rgb[c] * brightness_coeff, 0.f, 1.f);
+            rgb[c] = powf(rgb[c], k[OA_GAMMA]);
+            rgb[c] = rgb[c] + k[OA_BRIGHTNESS];
+            rgb[c] = 0.5f + (rgb[c] - 0.5f) * k[OA_CONTRAST];
+            top[((size_t)n * 3 + c) * area + px] = oa_clamp(rgb[c], 0.f, max_multiplier);
+          }
+        }
+      }
+    }
+
+    if (has_effect) {                                                                                   /* ApplyEffects, :295-317 */
+      for (int n = 0; n < N; ++n) {
+        const float nx = (float)cos(co[n].v[OA_SHADOW_ANGLE]), ny = (float)sin(co[n].v[OA_SHADOW_ANGLE]);   /* hpp:110 */
+        for (int c = 0; c < C; ++c)
+          for (int y = 0; y < ch; ++y)
+            for (int x = 0; x < cw; ++x) {
+              float sample = top[(((size_t)n * C + c) * ch + y) * cw + x];
+              if ((x - cw / 2) * nx + (y - ch / 2) * ny - co[n].v[OA_SHADOW_DISTANCE] > 0) sample -= co[n].v[OA_SHADOW_STRENGTH];
+              top[(((size_t)n * C + c) * ch + y) * cw + x] = oa_clamp(sample, 0.f, max_multiplier);
+            }
+      }
+    }
+    free(co);
+    free(mats);
+  }
+
+  /* mean subtraction, :592-635: per pixel (axpy with -1, :613-616) or per channel (rank-1 gemm with -1, :617-634) */
+  if (p->mean_mode != FN2_MEAN_NONE)
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < C; ++c)
+        for (size_t px = 0; px < area; ++px)
+          top[(size_t)n * count + (size_t)c * area + px] -= (p->mean_mode == FN2_MEAN_PER_PIXEL) ? mean[(size_t)c * area + px] : mean[c];
   return FN2_OK;
 }

@@ -204,3 +204,17 @@ def flow_augmentation(flow, coeffs1, coeffs2, crop_height, crop_width):
     top = np.empty((N, 2, crop_height, crop_width), np.float32)
     _chk(lib().fn2ref_flow_augmentation(_p(flow), _p(c1), _p(c2), c1.shape[1], N, H, W, crop_height, crop_width, _p(top)))
     return top
+
+
+def data_augmentation(bottom, coeffs=None, crop_height=0, crop_width=0, max_multiplier=255.0, chromatic_eigvec=None, mean3=None):
+    """DataAugmentationLayer of the reference with the coefficient blob given as bottom[1] (or absent: defaults).  GPU only."""
+    bottom = _f(bottom)
+    N, Cc, H, W = bottom.shape
+    crop = crop_width > 0 and crop_height > 0
+    top = np.empty((N, Cc, crop_height if crop else H, crop_width if crop else W), np.float32)
+    co = _f(coeffs).reshape(N, -1) if coeffs is not None else None
+    ev = _f(chromatic_eigvec) if chromatic_eigvec is not None else None
+    m3 = _f(mean3) if mean3 is not None else None
+    _chk(lib().fn2ref_data_augmentation(_p(bottom), _p(co), co.shape[1] if co is not None else 42, N, Cc, H, W, crop_height, crop_width,
+                                        C.c_float(max_multiplier), _p(ev), _p(m3), _p(top)))
+    return top

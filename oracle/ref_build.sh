@@ -19,7 +19,7 @@ FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fvisibility=hidden -w -I$HERE
 # Deconvolution and ReLU layers (pins of the stock-layer fast paths: stem, flow heads, GEMM route, bias + ReLU); cuBLAS/CBLAS
 # are replaced by the plain stand-ins of oracle/ref_compat/caffe/util/math_functions.hpp.  custom_data_layer (the LMDB data layer whose
 # DecodeData defines the sample format) is built against an in-memory stand-in for liblmdb (oracle/stubs/lmdb.h)
-LAYERS="correlation_layer correlation_layer1d flow_warp_layer resample_layer channel_norm_layer downsample_layer l1loss_layer eltwise_layer power_layer conv_layer deconv_layer relu_layer custom_data_layer flow_augmentation_layer"
+LAYERS="correlation_layer correlation_layer1d flow_warp_layer resample_layer channel_norm_layer downsample_layer l1loss_layer eltwise_layer power_layer conv_layer deconv_layer relu_layer custom_data_layer flow_augmentation_layer data_augmentation_layer"
 EXTRA="layers/augmentation_layer_base.cpp layers/base_conv_layer.cpp layers/loss_layer.cpp layers/neuron_layer.cpp util/im2col.cpp util/im2col.cu"
 # newest stand-in header: an object older than it is rebuilt (the stand-ins define Blob / Layer layouts)
 NEWEST_HDR=$(find "$COMPAT" "$HERE/ref_compat" "$HERE/stubs" -type f -printf '%T@ %p\n' | sort -n | tail -1 | cut -d' ' -f2-)

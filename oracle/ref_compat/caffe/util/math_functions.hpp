@@ -16,6 +16,9 @@ namespace caffe {
 // ---------------------------------------------------------------- host
 inline void caffe_memset(const size_t N, const int alpha, void* X) { std::memset(X, alpha, N); }
 inline void caffe_gpu_memset(const size_t N, const int alpha, void* X) { CUDA_CHECK(hipMemset(X, alpha, N)); }
+// cuRAND in the reference (math_functions.cu:395-406); the pins never enable the noise effect
+template <typename Dtype> inline void caffe_gpu_rng_gaussian(const int, const Dtype, const Dtype, Dtype*) { LOG(FATAL) << "caffe_gpu_rng_gaussian is not part of the pin harness"; }
+inline void caffe_gpu_memcpy(const size_t N, const void* X, void* Y) { if (X != Y) CUDA_CHECK(hipMemcpy(Y, X, N, hipMemcpyDefault)); }   // math_functions.cu:94-98
 template <typename Dtype> inline void caffe_set(const int N, const Dtype alpha, Dtype* X) { for (int i = 0; i < N; ++i) X[i] = alpha; }
 template <typename Dtype> inline void caffe_copy(const int N, const Dtype* X, Dtype* Y) {   // math_functions.cpp:86-98
   if (X == Y) return;

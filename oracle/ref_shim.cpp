@@ -109,6 +109,33 @@ int fn2ref_flow_augmentation(const float* flow, const float* coeffs1, const floa
   });
 }
 
+// DataAugmentation with the coefficients given as bottom[1] (input_params_, data_augmentation_layer.cpp:87): the deterministic part of
+// the layer.  mean3: per-channel mean from the proto (AugmentationParameter.mean, mean_per_pixel = false) or NULL.
+extern "C" __attribute__((visibility("default")))
+int fn2ref_data_augmentation(const float* bottom0, const float* coeffs /* nullable */, int num_params, int N, int C, int H, int W,
+                             int crop_height, int crop_width, float max_multiplier, const float* chromatic_eigvec /* [9] or NULL */,
+                             const float* mean3 /* [3] or NULL */, float* top_out) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_type("DataAugmentation");
+    AugmentationParameter* ap = lp.mutable_augmentation_param();
+    if (crop_width > 0 && crop_height > 0) { ap->set_crop_width(crop_width); ap->set_crop_height(crop_height); }
+    ap->set_max_multiplier(max_multiplier);
+    if (chromatic_eigvec) for (int i = 0; i < 9; ++i) ap->add_chromatic_eigvec(chromatic_eigvec[i]);
+    if (mean3) { for (int i = 0; i < 3; ++i) ap->add_mean(mean3[i]); ap->set_mean_per_pixel(false); }
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> img(N, C, H, W), co(N, num_params, 1, 1), top;
+    fill(img, bottom0);
+    vector<Blob<float>*> bottom{&img}, tops{&top};
+    if (coeffs) { fill(co, coeffs); bottom.push_back(&co); }
+    layer->SetUp(bottom, tops);
+    layer->Forward(bottom, tops);
+    CUDA_CHECK(hipDeviceSynchronize());
+    fetch(top, top_out);
+  });
+}
+
 // mode: 0 = GPU kernels (flow_warp_layer.cu), 1 = the reference's CPU implementation (flow_warp_layer.cpp:58-199)
 extern "C" __attribute__((visibility("default")))
 int fn2ref_flow_warp(int mode, int fill_value, const float* image, const float* flow, int N, int C, int H, int W,

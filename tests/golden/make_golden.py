@@ -121,6 +121,54 @@ def flow_aug_inputs(i):
     return flow, coeffs(), coeffs(), ch, cw
 
 
+# DataAugmentation with given coefficients: (N, C, H, W, crop_h, crop_w, kind); images in [0,1] (the nets scale by 1/255 first)
+DATA_AUG = [(2, 3, 48, 64, 32, 44, "spatial"), (3, 3, 40, 56, 32, 40, "chromatic"), (2, 3, 36, 48, 28, 40, "eigen"),
+            (2, 3, 40, 40, 32, 32, "shadow"), (3, 3, 48, 64, 40, 56, "all"), (2, 2, 24, 32, 16, 20, "spatial"), (2, 3, 24, 32, 0, 0, "none"),
+            (3, 3, 20, 24, 16, 20, "eigen_const"), (2, 3, 16, 16, 12, 12, "eigen_const")]
+# The reference's batch statistics for the chromatic-eigen transform are racy: fatomicMax / fatomicMin (data_augmentation_layer.cu:119-145)
+# assign the unsigned result of atomicCAS to a float (a numeric conversion, not the bit pattern), so a thread whose first
+# compare-and-swap loses never retries with the right value and maxima are lost depending on timing.  Kinds whose reference output is
+# therefore not reproducible are not pinned; "eigen_const" uses one constant colour for the whole batch, where every thread proposes the
+# same maximum and the per-pixel arithmetic of the transform can be pinned.
+DATA_AUG_UNPINNED = ("eigen", "all")
+EIGVEC = (0.51, 0.56, 0.65, 0.79, 0.01, -0.62, 0.35, -0.83, 0.44)      # the chromatic_eigvec of the FlowNet2 training prototxts (memory)
+
+
+def data_aug_inputs(i):
+    """Smooth images in [0,1] (so that a one-pixel difference of a sampling position is small) + [N,42] coefficient arrays in
+    coeff_to_array layout (fields with default 1 as log), + the per-channel mean (None for some cases)."""
+    N, C, H, W, ch, cw, kind = DATA_AUG[i]
+    rng = np.random.default_rng(4000 + i)
+    coarse = rng.random((N, C, 5, 6))
+    ys, xs = np.linspace(0, 4, H), np.linspace(0, 5, W)
+    y0, x0 = np.minimum(ys.astype(int), 3), np.minimum(xs.astype(int), 4)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    g = lambda dy, dx: coarse[:, :, y0 + dy][:, :, :, x0 + dx]
+    img = ((g(0, 0) * (1 - fx) + g(0, 1) * fx) * (1 - fy) + (g(1, 0) * (1 - fx) + g(1, 1) * fx) * fy).astype(np.float32)
+    if kind == "eigen_const":
+        img = np.broadcast_to(rng.uniform(0.2, 0.8, 3).astype(np.float32).reshape(1, 3, 1, 1), (N, C, H, W)).copy()
+    co = np.zeros((N, 42), np.float32)
+    for n in range(N):
+        if kind in ("spatial", "all", "eigen", "shadow", "chromatic", "eigen_const"):
+            co[n, :6] = [float(rng.random() < 0.5), rng.uniform(-0.03, 0.03), rng.uniform(-0.03, 0.03), rng.uniform(-0.12, 0.12),
+                         np.log(rng.uniform(1.0, 1.2)), np.log(rng.uniform(1.0, 1.2))]
+        if kind in ("chromatic", "all") and n != 1:              # sample 1 keeps default colour coefficients: the batch kernel still runs on it
+            co[n, 6:12] = [np.log(rng.uniform(0.7, 1.5)), rng.uniform(-0.1, 0.1), np.log(rng.uniform(0.6, 1.4)),
+                           np.log(rng.uniform(0.8, 1.2)), np.log(rng.uniform(0.8, 1.2)), np.log(rng.uniform(0.8, 1.2))]
+        if kind in ("eigen", "all", "eigen_const") and n != 1:
+            v = np.zeros(22, np.float32)
+            v[0:3] = np.log(rng.uniform(0.8, 1.25, 3)); v[3:6] = rng.uniform(-0.05, 0.05, 3); v[6:9] = np.log(rng.uniform(0.8, 1.25, 3))
+            v[9:12] = np.log(rng.uniform(0.8, 1.25, 3)); v[12:15] = rng.uniform(-0.05, 0.05, 3); v[15:18] = np.log(rng.uniform(0.8, 1.25, 3))
+            v[18] = np.log(rng.uniform(0.8, 1.25)); v[19] = rng.uniform(-0.05, 0.05); v[20] = np.log(rng.uniform(0.8, 1.25)); v[21] = rng.uniform(-0.3, 0.3)
+            co[n, 12:34] = v
+        if kind in ("shadow", "all") and n == 0:
+            co[n, 38:41] = [rng.uniform(0, 6.28), rng.uniform(-5, 5), rng.uniform(0.1, 0.4)]      # shadow_angle, _distance, _strength
+    mean3 = None if i % 2 else np.array([0.41, 0.43, 0.45], np.float32)
+    if C != 3:
+        mean3 = None
+    return img, (None if kind == "none" else co), mean3, ch, cw
+
+
 def stock_inputs(which):
     if which == "stem":
         return rnd((1, 3, 24, 32), 1000), rnd((64, 3, 7, 7), 1001, 0.1), rnd((64,), 1002)
@@ -175,6 +223,13 @@ def main(out, only=None, base=None):
         for i in range(len(FLOW_AUG)):
             flow, c1, c2, ch, cw = flow_aug_inputs(i)
             g[f"flowaug{i}"] = ref.flow_augmentation(flow, c1, c2, ch, cw)
+    if only in (None, "data_aug"):
+        for i in range(len(DATA_AUG)):
+            g.pop(f"dataaug{i}", None)
+            if DATA_AUG[i][6] in DATA_AUG_UNPINNED:
+                continue
+            img, co, mean3, ch, cw = data_aug_inputs(i)
+            g[f"dataaug{i}"] = ref.data_augmentation(img, co, ch, cw, 255.0, EIGVEC, mean3)
     if only in (None, "main"):
         main_section(g)
     np.savez_compressed(out, **g)
@@ -236,7 +291,7 @@ if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("out", nargs="?", default=os.path.join(os.path.dirname(__file__), "ref_golden.npz"))
-    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left", "custom_data", "flow_aug"], default=None)
+    ap.add_argument("--only", choices=["main", "corr1d", "corr1d_left", "custom_data", "flow_aug", "data_aug"], default=None)
     ap.add_argument("--base", default=None, help="existing .npz whose arrays are kept")
     a = ap.parse_args()
     main(a.out, a.only, a.base)

@@ -202,3 +202,137 @@ def test_oracle_flow_augmentation_matches_reference_golden(i):
         pytest.skip("golden arrays for FlowAugmentation not generated")
     flow, c1, c2, ch, cw = MG.flow_aug_inputs(i)
     _close_flow(oracle.flow_augmentation_forward(flow, c1, c2, ch, cw), gold[f"flowaug{i}"], "oracle vs reference golden")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DataAugmentation (for given coefficients)
+# ---------------------------------------------------------------------------------------------------------
+def _close_img(a, b, what, q=2e-5, worst=0.05):
+    """Image values are in [0,1]; the sampling position may differ by an ulp (contraction), which for a smooth image is invisible;
+    the colour transforms go through powf, which differs by an ulp between libm and the device library."""
+    err = np.abs(a - b)
+    assert a.shape == b.shape and np.quantile(err, 0.999) <= q and err.max() < worst, (what, float(np.quantile(err, 0.999)), float(err.max()))
+
+
+def _oracle_data_aug(i):
+    img, co, mean3, ch, cw = MG.data_aug_inputs(i)
+    return oracle.data_augmentation_forward(img, co, ch, cw, mean=mean3, mean_mode=1 if mean3 is not None else 0, max_multiplier=255.0,
+                                            chromatic_eigvec=MG.EIGVEC)
+
+
+def test_oracle_spatial_augmentation_vs_fp64_bilinear():
+    img, co, mean3, ch, cw = MG.data_aug_inputs(0)
+    N, C, H, W = img.shape
+    got = oracle.data_augmentation_forward(img, co, ch, cw)
+    ys, xs = np.mgrid[0:ch, 0:cw].astype(np.float64)
+    for n in range(N):
+        c = co[n]
+        M = matrix64(c[0], c[1], c[2], c[3], np.exp(np.float64(c[4])), np.exp(np.float64(c[5])), cw, ch, W, H)
+        xp = np.clip(M[0, 0] * xs + M[0, 1] * ys + M[0, 2], 0, W - 1.05)
+        yp = np.clip(M[1, 0] * xs + M[1, 1] * ys + M[1, 2], 0, H - 1.05)
+        x0, y0 = np.floor(xp).astype(int), np.floor(yp).astype(int)
+        fx, fy = xp - x0, yp - y0
+        for ch_ in range(C):
+            p = img[n, ch_].astype(np.float64)
+            want = (1 - fx) * (1 - fy) * p[y0, x0] + fx * fy * p[y0 + 1, x0 + 1] + (1 - fx) * fy * p[y0 + 1, x0] + fx * (1 - fy) * p[y0, x0 + 1]
+            assert np.abs(got[n, ch_] - want).max() < 2e-4
+
+
+def test_data_augmentation_invariants_and_errors():
+    img, co, mean3, ch, cw = MG.data_aug_inputs(1)
+    N, C, H, W = img.shape
+    ident = np.zeros((N, 42), np.float32)
+    # default coefficients: a centred crop (bilinear at integer + 0.0 offsets when the margins are even), no colour change
+    top = oracle.data_augmentation_forward(img, ident, 32, 40)
+    assert np.abs(top - img[:, :, 4:36, 8:48]).max() < 1e-6
+    assert np.array_equal(oracle.data_augmentation_forward(img, None, 32, 40), top)
+    # no crop size: the bottom is copied whatever the coefficients say; then the mean
+    m = np.array([0.1, 0.2, 0.3], np.float32)
+    out = oracle.data_augmentation_forward(img, co, 0, 0, mean=m, mean_mode=1)
+    assert np.array_equal(out, img - m.reshape(1, 3, 1, 1))
+    pm = np.random.default_rng(0).random((3, 32, 40)).astype(np.float32)
+    assert np.array_equal(oracle.data_augmentation_forward(img, ident, 32, 40, mean=pm, mean_mode=2), top - pm[None])
+    # one sample with colour coefficients drags the whole batch through the colour kernel (batch flags, .cu:456-476): the sample with
+    # DEFAULT colour coefficients changes too (brightness compensation mean_in / (mean_out + 0.01), clamp to [0,1])
+    with_col = oracle.data_augmentation_forward(img, co, ch, cw)
+    only_spatial = co.copy(); only_spatial[:, 6:] = 0
+    without = oracle.data_augmentation_forward(img, only_spatial, ch, cw)
+    assert np.abs(with_col[1] - without[1]).max() > 1e-4 and np.abs(with_col[1] - without[1]).max() < 0.02
+    noisy = co.copy(); noisy[0, 41] = 0.1
+    with pytest.raises(ValueError):                      # the noise effect needs cuRAND's stream
+        oracle.data_augmentation_forward(img, noisy, ch, cw)
+    with pytest.raises(ValueError):                      # crop greater than original
+        oracle.data_augmentation_forward(img, co, H + 1, W)
+    with pytest.raises(ValueError):                      # colour transforms need 3 channels
+        oracle.data_augmentation_forward(img[:, :2], co, ch, cw)
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.data_augmentation_forward(ops.data_aug_params(8, 8), torch.zeros(1, 3, 16, 16))
+
+
+def test_data_augmentation_layer_mirror_checks():
+    from flownet2_amd.layers import Blob, CheckError, LayerParameter, LayerRegistry
+    img, co = Blob(2, 3, 16, 24, device="cpu"), Blob(2, 42, 1, 1, device="cpu")
+    layer = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=dict(crop_width=20, crop_height=12, mean=[1, 2, 3], mean_per_pixel=False)))
+    top = [Blob(device="cpu"), Blob(device="cpu")]
+    layer.SetUp([img, co], top)
+    assert top[0].shape() == [2, 3, 12, 20] and top[1].shape() == [2, 42, 1, 1] and layer.mean_mode_ == ops.MEAN_PER_CHANNEL and not layer.AllowBackward()
+    layer = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation"))
+    top = [Blob(device="cpu")]
+    layer.SetUp([img], top)
+    assert top[0].shape() == [2, 3, 16, 24] and not layer.do_cropping_
+    for bottoms, ntop, ap, msg in [([img, co, co], 1, {}, "one or two input blobs"), ([img], 3, {}, "one or two output blobs"),
+                                   ([img], 1, dict(crop_width=30, crop_height=8), "crop width greater"), ([img], 1, dict(crop_width=8, crop_height=30), "crop height greater")]:
+        with pytest.raises(CheckError, match=msg):
+            LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=ap)).SetUp(bottoms, [Blob(device="cpu") for _ in range(ntop)])
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="golden vectors not generated yet")
+@pytest.mark.parametrize("i", range(len(MG.DATA_AUG)))
+def test_oracle_data_augmentation_matches_reference_golden(i):
+    gold = np.load(GOLD)
+    if f"dataaug{i}" not in gold:
+        pytest.skip("golden arrays for DataAugmentation not generated")
+    _close_img(_oracle_data_aug(i), gold[f"dataaug{i}"], "oracle vs reference golden")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(MG.DATA_AUG)))
+def test_hip_data_augmentation_matches_oracle_and_reference_golden(i):
+    from flownet2_amd.layers import Blob, LayerParameter, LayerRegistry
+    img, co, mean3, ch, cw = MG.data_aug_inputs(i)
+    ap = dict(max_multiplier=255.0, chromatic_eigvec=list(MG.EIGVEC))
+    if ch:
+        ap.update(crop_width=cw, crop_height=ch)
+    if mean3 is not None:
+        ap.update(mean=mean3.tolist(), mean_per_pixel=False)
+    layer = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=ap))
+    bottom = [Blob.from_tensor(torch.from_numpy(img).cuda())]
+    if co is not None:
+        bottom.append(Blob.from_tensor(torch.from_numpy(co.reshape(len(co), 42, 1, 1)).cuda()))
+    top = [Blob()]
+    layer.SetUp(bottom, top)
+    layer.Forward(bottom, top)
+    got = top[0].cpu_data()
+    _close_img(got, _oracle_data_aug(i), "hip vs oracle")
+    if os.path.exists(GOLD) and f"dataaug{i}" in np.load(GOLD):
+        _close_img(got, np.load(GOLD)[f"dataaug{i}"], "hip vs reference golden", q=5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built")
+def test_reference_data_augmentation_equals_oracle_and_hip_at_training_size():
+    """A FlyingChairs batch: 8 x [3,384,512] -> 320x448 with spatial + colour + shadow coefficients."""
+    rng = np.random.default_rng(77)
+    N, H, W, ch, cw = 8, 384, 512, 320, 448
+    img = torch.nn.functional.interpolate(torch.from_numpy(rng.random((N, 3, 13, 17)).astype(np.float32)), size=(H, W), mode="bilinear", align_corners=True).numpy()
+    co = np.zeros((N, 42), np.float32)
+    co[:, :6] = np.stack([[float(rng.random() < 0.5), rng.uniform(-0.03, 0.03), rng.uniform(-0.03, 0.03), rng.uniform(-0.1, 0.1),
+                           np.log(rng.uniform(1.0, 1.2)), np.log(rng.uniform(1.0, 1.2))] for _ in range(N)])
+    co[:, 6:12] = rng.uniform(-0.1, 0.1, (N, 6))
+    co[0, 38:41] = [1.0, 3.0, 0.2]            # (no chromatic-eigen coefficients: the reference's batch statistics are racy, see make_golden.py)
+    mean3 = np.array([0.41, 0.43, 0.45], np.float32)
+    want = ref.data_augmentation(img, co, ch, cw, 255.0, MG.EIGVEC, mean3)
+    _close_img(oracle.data_augmentation_forward(img, co, ch, cw, mean=mean3, mean_mode=1, chromatic_eigvec=MG.EIGVEC), want, "oracle vs reference")
+    p = ops.data_aug_params(cw, ch, 255.0, MG.EIGVEC, ops.MEAN_PER_CHANNEL)
+    got = ops.data_augmentation_forward(p, torch.from_numpy(img).cuda(), co, torch.from_numpy(mean3).cuda()).cpu().numpy()
+    _close_img(got, want, "hip vs reference", q=5e-6)
