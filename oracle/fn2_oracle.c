@@ -14,7 +14,7 @@
  *       ChannelNorm, Downsample and L1Loss compiled in place with hipcc against stand-in caffe
  *       headers and run on an MI355X; tests/golden/ref_golden.npz holds the outputs they produced
  *       and tests/test_golden.py checks every reference-layer function below against them
- *       (PINNED for all seven layers; FlowAugmentation, added later, likewise).  L1LossLayer instantiates the stock Eltwise / Power /
+ *       (PINNED for all seven layers; FlowAugmentation and DataAugmentation for given coefficients, added later, likewise).  L1LossLayer instantiates the stock Eltwise / Power /
  *       Convolution layers (l1loss_layer.cpp:19-62): those sources (+ base_conv_layer.cpp,
  *       im2col.{cpp,cu}) are compiled in place as well; the only replaced part is the cuBLAS /
  *       CBLAS calls underneath them (oracle/ref_compat/caffe/util/math_functions.hpp: plain
