@@ -1,0 +1,225 @@
+"""Drawing augmentation coefficients: the host logic in front of DataAugmentation / FlowAugmentation.
+
+Restates AugmentationLayerBase::generate_*_coeffs / generate_valid_spatial_coeffs (src/caffe/layers/augmentation_layer_base.cpp:72-170,
+:250-336), caffe_rng_generate (src/caffe/util/rng.cpp:8-114), the discount schedule (data_augmentation_layer.cu:366-368) and the
+modes of GenerateAugmentationParametersLayer::Forward_gpu (src/caffe/layers/generate_augmentation_parameters_layer.cu:20-112).
+
+PARITY: the control flow, distributions and array layout follow the reference; the random STREAM does not -- the reference draws from
+boost generators seeded per thread (caffe_rng_*), whose sequence cannot be reproduced here, so drawn values are "unpinned" by
+construction.  What is deterministic (coeff_to_array / array_to_coeff / add_coeff_to_array, the four-corner validity test) is tested
+against the pinned matrix helpers (tests/test_augmentation.py).  Consumers: ops.data_augmentation_forward, ops.flow_augmentation_forward.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+
+# AugmentationCoeff, caffe.proto:436-486: (name, default) in declaration order = array layout
+FIELDS = [("mirror", 0), ("dx", 0), ("dy", 0), ("angle", 0), ("zoom_x", 1), ("zoom_y", 1),
+          ("gamma", 1), ("brightness", 0), ("contrast", 1), ("color1", 1), ("color2", 1), ("color3", 1),
+          ("pow_nomean0", 1), ("pow_nomean1", 1), ("pow_nomean2", 1), ("add_nomean0", 0), ("add_nomean1", 0), ("add_nomean2", 0),
+          ("mult_nomean0", 1), ("mult_nomean1", 1), ("mult_nomean2", 1), ("pow_withmean0", 1), ("pow_withmean1", 1), ("pow_withmean2", 1),
+          ("add_withmean0", 0), ("add_withmean1", 0), ("add_withmean2", 0), ("mult_withmean0", 1), ("mult_withmean1", 1), ("mult_withmean2", 1),
+          ("lmult_pow", 1), ("lmult_add", 0), ("lmult_mult", 1), ("col_angle", 0),
+          ("fog_amount", 0), ("fog_size", 0), ("motion_blur_angle", 0), ("motion_blur_size", 0),
+          ("shadow_angle", 0), ("shadow_distance", 0), ("shadow_strength", 0), ("noise", 0)]
+NUM_PARAMS = len(FIELDS)
+DEFAULT = {k: float(v) for k, v in FIELDS}
+SPATIAL = ("mirror", "dx", "dy", "angle", "zoom_x", "zoom_y")
+
+
+def default_coeff() -> Dict[str, float]:
+    return dict(DEFAULT)
+
+
+def coeff_to_array(coeff: Dict[str, float]) -> np.ndarray:            # cpp:352-365: log() where the default is non-zero
+    return np.array([coeff[k] if abs(d) < 1e-3 else math.log(coeff[k]) for k, d in FIELDS], np.float32)
+
+
+def array_to_coeff(arr) -> Dict[str, float]:                           # cpp:368-380
+    return {k: float(arr[i]) if abs(d) < 1e-3 else float(np.float32(math.exp(float(arr[i])))) for i, (k, d) in enumerate(FIELDS)}
+
+
+def add_coeff_to_array(coeff: Dict[str, float], out: np.ndarray) -> None:   # cpp:172-179: sums in the array (= log) domain
+    out += coeff_to_array(coeff)
+
+
+def discount_coeff(num_iter: int, schedule: Optional[dict] = None) -> float:
+    """CoeffScheduleParameter (caffe.proto:693-697), data_augmentation_layer.cu:366-368."""
+    s = dict(half_life=1.0, initial_coeff=1.0, final_coeff=1.0)
+    s.update(schedule or {})
+    return s["initial_coeff"] + (s["final_coeff"] - s["initial_coeff"]) * (2.0 / (1.0 + math.exp(-1.0986 * num_iter / s["half_life"])) - 1.0)
+
+
+def rng_generate(rng: np.random.Generator, param: dict, discount: float = 1.0, prob0_value: float = float("nan"), as_bool: bool = False):
+    """caffe_rng_generate, rng.cpp:8-114.  param = RandomGeneratorParameter as a dict (caffe.proto:607-616 defaults)."""
+    p = dict(rand_type="uniform", exp=False, mean=0.0, spread=0.0, prob=1.0, apply_schedule=True, discretize=False, multiplier=1.0)
+    p.update(param)
+    spread = p["spread"] * discount if p["apply_schedule"] else p["spread"]
+
+    def uniform():
+        return rng.uniform(p["mean"] - spread, p["mean"] + spread) if spread > 0 else p["mean"]
+
+    def gaussian():
+        return rng.normal(p["mean"], spread) if spread > 0 else p["mean"]
+    t = p["rand_type"]
+    if t in ("uniform", "gaussian"):
+        v = uniform() if t == "uniform" else gaussian()
+        if p["exp"]:
+            v = math.exp(v)
+    elif t == "bernoulli":
+        v = float(rng.random() < p["prob"]) if p["prob"] > 0 else 0.0
+    elif t in ("uniform_bernoulli", "gaussian_bernoulli"):
+        on = (rng.random() < p["prob"]) if p["prob"] > 0 else False
+        if not on:
+            if not math.isnan(prob0_value):
+                return bool(prob0_value) if as_bool else prob0_value      # returned as is: no exp / discretize / multiplier (:58-60)
+            v = 0.0
+        else:
+            v = uniform() if t == "uniform_bernoulli" else gaussian()
+        if p["exp"]:
+            v = math.exp(v)
+    else:
+        raise ValueError(f"Unknown random type {t}")
+    if as_bool:
+        v = float(bool(v))
+    if p["discretize"]:
+        v = float(round(v))
+    v = p["multiplier"] * v
+    return bool(v) if as_bool else float(np.float32(v))
+
+
+def generate_spatial_coeffs(rng, aug: dict, coeff: dict, discount: float) -> None:       # cpp:72-97
+    if "mirror" in aug:
+        coeff["mirror"] = float(rng_generate(rng, aug["mirror"], 1.0, DEFAULT["mirror"], as_bool=True))
+    if "translate" in aug:
+        coeff["dx"] = rng_generate(rng, aug["translate"], discount, DEFAULT["dx"])
+        coeff["dy"] = rng_generate(rng, aug["translate"], discount, DEFAULT["dy"])
+    if "translate_x" in aug:
+        coeff["dx"] = rng_generate(rng, aug["translate_x"], discount, DEFAULT["dx"])
+    if "translate_y" in aug:
+        coeff["dy"] = rng_generate(rng, aug["translate_y"], discount, DEFAULT["dy"])
+    if "rotate" in aug:
+        coeff["angle"] = rng_generate(rng, aug["rotate"], discount, DEFAULT["angle"])
+    if "zoom" in aug:
+        coeff["zoom_x"] = rng_generate(rng, aug["zoom"], discount, DEFAULT["zoom_x"])
+        coeff["zoom_y"] = coeff["zoom_x"]
+    if "squeeze" in aug:
+        sq = rng_generate(rng, aug["squeeze"], discount, 1.0)
+        coeff["zoom_x"] *= sq
+        coeff["zoom_y"] /= sq
+
+
+def corners_inside(coeff: dict, width: int, height: int, cw: int, ch: int) -> bool:
+    """The four corners of the crop, transformed, must fall inside the source image (cpp:133-160)."""
+    good = 0
+    for x in (0, cw - 1):
+        for y in (0, ch - 1):
+            x1 = (-x + .5 * cw) if coeff["mirror"] else (x - .5 * cw)
+            y1 = y - .5 * ch
+            x2 = math.cos(coeff["angle"]) * x1 - math.sin(coeff["angle"]) * y1 + coeff["dx"] * cw
+            y2 = math.sin(coeff["angle"]) * x1 + math.cos(coeff["angle"]) * y1 + coeff["dy"] * ch
+            x2, y2 = x2 / coeff["zoom_x"] + .5 * width, y2 / coeff["zoom_y"] + .5 * height
+            if not (math.floor(x2) < 0 or math.floor(x2) > width - 2 or math.floor(y2) < 0 or math.floor(y2) > height - 2):
+                good += 1
+    return good == 4
+
+
+def generate_valid_spatial_coeffs(rng, aug: dict, coeff: dict, discount: float, width: int, height: int, cw: int, ch: int, max_tries: int = 50) -> None:
+    """cpp:101-169: draw on top of the incoming coefficients (sum in the array domain) until the crop stays inside the image."""
+    incoming = coeff_to_array(coeff)
+    for _ in range(max_tries):
+        fresh = default_coeff()
+        generate_spatial_coeffs(rng, aug, fresh, discount)
+        cand = array_to_coeff(coeff_to_array(fresh) + incoming)
+        if corners_inside(cand, width, height, cw, ch):
+            coeff.update(cand)
+            return
+    coeff.update(array_to_coeff(incoming))                 # "Exceeded maximum tries in finding spatial coeffs."
+
+
+def generate_chromatic_coeffs(rng, aug, coeff, discount):                                  # cpp:251-262
+    for name in ("gamma", "brightness", "contrast"):
+        if name in aug:
+            coeff[name] = rng_generate(rng, aug[name], discount)
+    if "color" in aug:
+        for k in ("color1", "color2", "color3"):
+            coeff[k] = rng_generate(rng, aug["color"], discount)
+
+
+def generate_chromatic_eigen_coeffs(rng, aug, coeff, discount):                            # cpp:264-311
+    def g(name):
+        return rng_generate(rng, aug[name], discount)
+    for src, dst in (("ladd_pow", ["pow_nomean0"]), ("col_pow", ["pow_nomean1", "pow_nomean2"]), ("ladd_add", ["add_nomean0"]),
+                     ("col_add", ["add_nomean1", "add_nomean2"]), ("ladd_mult", ["mult_nomean0"]), ("col_mult", ["mult_nomean1", "mult_nomean2"])):
+        if src in aug:
+            for d in dst:
+                coeff[d] = g(src)
+    for src, a, b in (("sat_pow", "pow_withmean1", "pow_withmean2"), ("sat_add", "add_withmean1", "add_withmean2"), ("sat_mult", "mult_withmean1", "mult_withmean2")):
+        if src in aug:
+            coeff[a] = g(src)
+            coeff[b] = coeff[a]
+    for src, dst in (("lmult_pow", "lmult_pow"), ("lmult_mult", "lmult_mult"), ("lmult_add", "lmult_add"), ("col_rotate", "col_angle")):
+        if src in aug:
+            coeff[dst] = g(src)
+
+
+def generate_effect_coeffs(rng, aug, coeff, discount):                                     # cpp:313-336
+    groups = (("fog_amount", "fog_size"), ("motion_blur_angle", "motion_blur_size"), ("shadow_angle", "shadow_distance", "shadow_strength"))
+    for grp in groups:
+        if any(k in aug for k in grp):
+            for k in grp:
+                coeff[k] = rng_generate(rng, aug.get(k, {}), discount, DEFAULT[k])
+    if "noise" in aug:
+        coeff["noise"] = rng_generate(rng, aug["noise"], discount)
+
+
+_SPATIAL_KEYS = ("mirror", "rotate", "zoom", "translate", "squeeze", "translate_x", "translate_y")
+_CHROMATIC_KEYS = ("brightness", "gamma", "contrast", "color")
+_EFFECT_KEYS = ("fog_size", "fog_amount", "motion_blur_angle", "motion_blur_size", "shadow_angle", "shadow_distance", "shadow_strength", "noise")
+_EIGEN_KEYS = ("lmult_pow", "lmult_mult", "lmult_add", "sat_pow", "sat_mult", "sat_add", "col_pow", "col_mult", "col_add", "ladd_pow", "ladd_mult", "ladd_add", "col_rotate")
+
+
+def draw_batch(rng, aug: dict, num: int, width: int, height: int, cw: int, ch: int, discount: float = 1.0,
+               in_params: Optional[np.ndarray] = None, mode: str = "add") -> np.ndarray:
+    """[num, 42] coefficient blob.  in_params = None: what DataAugmentationLayer draws for itself in the training phase
+    (data_augmentation_layer.cu:375-450).  With in_params: GenerateAugmentationParametersLayer (modes "add" / "replace" / "regenerate",
+    generate_augmentation_parameters_layer.cu:58-108): coefficients of the second image relative to those of the first."""
+    spatial = any(k in aug for k in _SPATIAL_KEYS)
+    chromatic = any(k in aug for k in _CHROMATIC_KEYS)
+    effect = any(k in aug for k in _EFFECT_KEYS)
+    eigen = any(k in aug for k in _EIGEN_KEYS)
+    out = np.zeros((num, NUM_PARAMS), np.float32)
+    for n in range(num):
+        if in_params is None:
+            coeff = default_coeff()
+            if spatial:
+                generate_valid_spatial_coeffs(rng, aug, coeff, discount, width, height, cw, ch)
+            if chromatic:
+                generate_chromatic_coeffs(rng, aug, coeff, discount)
+            if eigen:
+                generate_chromatic_eigen_coeffs(rng, aug, coeff, discount)
+            if effect:
+                generate_effect_coeffs(rng, aug, coeff, discount)
+            out[n] = coeff_to_array(coeff)
+            continue
+        coeff = array_to_coeff(in_params[n]) if mode in ("add", "replace") else default_coeff()
+        if spatial:
+            if mode == "replace":
+                for k in SPATIAL:
+                    coeff[k] = DEFAULT[k]
+            generate_valid_spatial_coeffs(rng, aug, coeff, discount, width, height, cw, ch)
+        out[n] = coeff_to_array(coeff)
+        for on, gen in ((chromatic, generate_chromatic_coeffs), (eigen, generate_chromatic_eigen_coeffs), (effect, generate_effect_coeffs)):
+            if not on:
+                continue
+            if mode in ("regenerate", "replace"):
+                gen(rng, aug, coeff, discount)
+                out[n] = coeff_to_array(coeff)
+            else:
+                tmp = default_coeff()
+                gen(rng, aug, tmp, discount)
+                add_coeff_to_array(tmp, out[n])
+    return out

@@ -336,3 +336,62 @@ def test_reference_data_augmentation_equals_oracle_and_hip_at_training_size():
     p = ops.data_aug_params(cw, ch, 255.0, MG.EIGVEC, ops.MEAN_PER_CHANNEL)
     got = ops.data_augmentation_forward(p, torch.from_numpy(img).cuda(), co, torch.from_numpy(mean3).cuda()).cpu().numpy()
     _close_img(got, want, "hip vs reference", q=5e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Drawing coefficients (host logic; the random stream itself is numpy's, not boost's: see flownet2_amd/augment.py)
+# ---------------------------------------------------------------------------------------------------------
+TRAIN_AUG = dict(   # the shape of the FlowNet2 training prototxts' augmentation_param (memory): first image, then the relative one
+    mirror=dict(rand_type="bernoulli", prob=0.5), translate=dict(rand_type="uniform_bernoulli", exp=False, mean=0, spread=0.4, prob=1.0),
+    rotate=dict(rand_type="uniform_bernoulli", exp=False, mean=0, spread=0.4, prob=1.0), zoom=dict(rand_type="uniform_bernoulli", exp=True, mean=0.2, spread=0.4, prob=1.0),
+    squeeze=dict(rand_type="uniform_bernoulli", exp=True, mean=0, spread=0.3, prob=1.0), gamma=dict(rand_type="uniform_bernoulli", exp=True, mean=0, spread=0.02, prob=1.0),
+    brightness=dict(rand_type="gaussian_bernoulli", exp=False, mean=0, spread=0.02, prob=1.0), contrast=dict(rand_type="uniform_bernoulli", exp=True, mean=0, spread=0.4, prob=1.0),
+    color=dict(rand_type="gaussian_bernoulli", exp=True, mean=0, spread=0.02, prob=1.0), lmult_pow=dict(rand_type="uniform_bernoulli", exp=True, mean=-0.2, spread=0.4, prob=1.0),
+    col_rotate=dict(rand_type="uniform_bernoulli", exp=False, mean=0, spread=1.0, prob=1.0))
+REL_AUG = dict(translate=dict(rand_type="gaussian_bernoulli", exp=False, mean=0, spread=0.03, prob=1.0), rotate=dict(rand_type="gaussian_bernoulli", exp=False, mean=0, spread=0.03, prob=1.0),
+               zoom=dict(rand_type="gaussian_bernoulli", exp=True, mean=0, spread=0.03, prob=1.0), gamma=dict(rand_type="gaussian_bernoulli", exp=True, mean=0, spread=0.02, prob=1.0))
+
+
+def test_coefficient_arrays_round_trip_and_compose_in_the_log_domain():
+    from flownet2_amd import augment as A
+    assert A.NUM_PARAMS == ops.AUG_NUM_PARAMS == 42
+    c = A.default_coeff()
+    assert np.array_equal(A.coeff_to_array(c), np.zeros(42, np.float32))           # defaults: 0, or log 1
+    c.update(mirror=1.0, dx=0.05, angle=-0.2, zoom_x=1.3, zoom_y=0.8, gamma=1.1, col_angle=0.3, shadow_strength=0.2)
+    arr = A.coeff_to_array(c)
+    assert np.array_equal(arr[:6], coeff_array(1.0, 0.05, 0.0, -0.2, 1.3, 0.8)[:6])   # the layout the pinned C functions read
+    back = A.array_to_coeff(arr)
+    assert all(abs(back[k] - c[k]) < 1e-6 for k in c)
+    # add_coeff_to_array sums arrays: additive fields add, multiplicative (log-stored) fields multiply
+    out = arr.copy()
+    A.add_coeff_to_array(dict(A.default_coeff(), dx=0.01, zoom_x=1.1, gamma=0.9), out)
+    z = A.array_to_coeff(out)
+    assert abs(z["dx"] - 0.06) < 1e-6 and abs(z["zoom_x"] - 1.43) < 1e-5 and abs(z["gamma"] - 0.99) < 1e-5 and z["mirror"] == 1.0
+
+
+def test_drawn_spatial_coefficients_keep_the_crop_inside_the_image():
+    """generate_valid_spatial_coeffs (augmentation_layer_base.cpp:101-169): every accepted draw maps the four crop corners into the
+    image -- checked with the PINNED matrix helper, not with the generator's own test."""
+    from flownet2_amd import augment as A
+    rng = np.random.default_rng(3)
+    W, H, cw, ch = 512, 384, 448, 320
+    first = A.draw_batch(rng, TRAIN_AUG, 64, W, H, cw, ch, discount=A.discount_coeff(10 ** 6))
+    second = A.draw_batch(rng, REL_AUG, 64, W, H, cw, ch, in_params=first, mode="add")
+    assert first.shape == second.shape == (64, 42) and np.isfinite(first).all() and np.isfinite(second).all()
+    assert 10 < first[:, 0].sum() < 54                                                    # mirror: Bernoulli(0.5)
+    assert np.array_equal(second[:, 0], first[:, 0])                                      # the relative draw has no mirror: it is inherited
+    assert np.abs(second[:, 1:6] - first[:, 1:6]).max() < 0.2 and np.abs(second[:, 1:6] - first[:, 1:6]).max() > 0
+    for blob in (first, second):
+        for n in range(64):
+            if np.array_equal(blob[n, :6], np.zeros(6)):                                  # 50 failed tries: falls back to the incoming values
+                continue
+            m = oracle.augmentation_matrix(blob[n], cw, ch, W, H)
+            for x in (0, cw - 1):
+                for y in (0, ch - 1):
+                    xs, ys = m[0] * x + m[2] * y + m[4], m[1] * x + m[3] * y + m[5]
+                    assert -1e-3 <= xs <= W - 1 + 1e-3 and -1e-3 <= ys <= H - 1 + 1e-3, (n, x, y, xs, ys)
+    # schedule: spread grows from 0 with the iteration count (data_augmentation_layer.cu:366-368)
+    assert A.discount_coeff(0, dict(half_life=50000, initial_coeff=0.5, final_coeff=1)) == 0.5
+    assert abs(A.discount_coeff(50000, dict(half_life=50000, initial_coeff=0.5, final_coeff=1)) - 0.75) < 1e-3
+    zero = A.draw_batch(rng, dict(translate=dict(rand_type="uniform", spread=0.3)), 4, W, H, cw, ch, discount=0.0)
+    assert np.array_equal(zero, np.zeros((4, 42), np.float32))
