@@ -146,21 +146,31 @@ def decode_batch(samples: torch.Tensor, channels: int, H: int, W: int, slice_poi
 
 
 def stage_records(records: Sequence[bytes], device="cuda"):
-    """Parses a batch of LMDB values on the host and uploads their raw `data` payloads: returns (samples uint8 [N, stride] on the
-    device, the first Datum's (channels, H, W), labels).  All records must have the same shape (the layer CHECKs that, :545)."""
-    datums = [parse_datum(r) for r in records]
-    d0 = datums[0]
-    for d in datums:
-        if (d.channels, d.height, d.width) != (d0.channels, d0.height, d0.width) or d.data is None or len(d.data) != len(d0.data):
-            raise ValueError("records of one batch must share channels / height / width and hold `data` bytes")
-    stride = (len(d0.data) + 15) // 16 * 16                     # keeps every sample 16-byte aligned
-    host = _staging(len(datums), stride)
-    for i, d in enumerate(datums):
-        host[i, :len(d.data)] = torch.frombuffer(bytearray(d.data), dtype=torch.uint8)
+    """Parses a batch of LMDB values on the host (header walk only) and uploads their raw `data` payloads: returns (samples uint8
+    [N, stride] on the device, the first Datum's (channels, H, W), labels).  All records must have the same shape (the layer CHECKs
+    that, :545).  One host copy per record: from the record into the page-locked staging buffer."""
+    L = _lib.lib()
+    views = []
+    for r in records:
+        addr, n, keep = _buf(r)
+        v = DatumView()
+        check(L.fn2_datum_parse(addr, n, C.byref(v)))
+        if not v.data:
+            raise ValueError("records of one batch must hold `data` bytes")
+        views.append((v, v.data - addr.value, keep))
+    v0 = views[0][0]
+    for v, _, _ in views:
+        if (v.channels, v.height, v.width, v.data_bytes) != (v0.channels, v0.height, v0.width, v0.data_bytes):
+            raise ValueError("records of one batch must share channels / height / width")
+    stride = (v0.data_bytes + 15) // 16 * 16                    # keeps every sample 16-byte aligned
+    host = _staging(len(views), stride)
+    host_np = host.numpy()
+    for i, (v, off, keep) in enumerate(views):
+        host_np[i, :v.data_bytes] = keep[off: off + v.data_bytes]
     out = host.to(device, non_blocking=True)
     if out.is_cuda:
         torch.cuda.current_stream().synchronize()                 # the staging buffer is reused by the next batch
-    return out, (d0.channels, d0.height, d0.width), [d.label for d in datums]
+    return out, (v0.channels, v0.height, v0.width), [v.label for v, _, _ in views]
 
 
 _STAGING = {}
