@@ -6,7 +6,7 @@
 // the whole chain: per output pixel C bilinear samples (4 reads each, neighbouring lanes read neighbouring addresses for the mild
 // transforms the generator draws) and C coalesced writes -- HBM-bound, bytes = 4 * N * C * (H*W read at most once + crop_h*crop_w).
 // The chromatic-eigen transform needs batch statistics of the SOURCE images first (ComputeChromaticEigenspace, :147-187): a reduction
-// kernel (wave shuffles -> LDS -> one atomic per block) in front.
+// kernel (wave shuffles -> LDS -> one atomic per block; 256 blocks: the atomics on the 12 statistics serialise) in front.
 #include "augmentation.hpp"
 
 #include <cfloat>
@@ -89,6 +89,23 @@ __global__ void __launch_bounds__(256) eigenspace_stats(const float* __restrict_
       old = __uint_as_float(prev);
     }
   }
+}
+
+struct EigVec { float v[9]; };
+
+__global__ void eigenspace_init(EigenSpace* es, EigVec ev) {                                              // :491-500
+  for (int c = 0; c < 3; ++c) { es->mean_eig[c] = 0; es->mean_rgb[c] = 0; es->max_abs_eig[c] = 0; es->max_rgb[c] = 0; es->min_rgb[c] = FLT_MAX; }
+  es->max_l = 0;
+  for (int i = 0; i < 9; ++i) es->eigvec[i] = ev.v[i];
+}
+
+__global__ void eigenspace_finish(EigenSpace* es, int num) {                                              // :517-534 (host code in the reference)
+  for (int c = 0; c < 3; ++c) es->mean_rgb[c] = es->mean_rgb[c] / num;
+  for (int c = 0; c < 3; ++c) {
+    es->mean_eig[c] = es->eigvec[3 * c] * es->mean_rgb[0] + es->eigvec[3 * c + 1] * es->mean_rgb[1] + es->eigvec[3 * c + 2] * es->mean_rgb[2];
+    if (es->max_abs_eig[c] > 1e-2f) es->mean_eig[c] = es->mean_eig[c] / es->max_abs_eig[c];
+  }
+  es->max_l = sqrtf(es->max_abs_eig[0] * es->max_abs_eig[0] + es->max_abs_eig[1] * es->max_abs_eig[1] + es->max_abs_eig[2] * es->max_abs_eig[2]);
 }
 
 // ChromaticEigenAugmentation, :192-291, on one pixel
@@ -294,24 +311,13 @@ FN2_API int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const fl
   if (any_eigen) {
     if (!p->has_chromatic_eigvec) return fail(FN2_ERR_INVALID_ARG, "You need to specify chromatic eigenvectors for Chromatic-Eigen augementation");   // :494
     if (!workspace || workspace_bytes < sizeof(EigenSpace)) return fail(FN2_ERR_WORKSPACE, "data_augmentation: workspace of %zu bytes needed", sizeof(EigenSpace));
-    EigenSpace es;
-    std::memset(&es, 0, sizeof(es));                                                                      // :491
-    for (int i = 0; i < 9; ++i) es.eigvec[i] = p->chromatic_eigvec[i];                                    // :496-497
-    for (int c = 0; c < 3; ++c) es.min_rgb[c] = FLT_MAX;                                                  // :499-500
-    if (hipMemcpyAsync(workspace, &es, sizeof(es), hipMemcpyHostToDevice, st) != hipSuccess) return check_launch("data_augmentation (eigenspace upload)");
-    hipLaunchKernelGGL(eigenspace_stats, dim3(blocks_for((long long)N * H * W, 256, 2048)), dim3(256), 0, st, bottom, N, H, W,
-                       static_cast<EigenSpace*>(workspace));
-    // the host finishes the statistics (:514-534): it needs them back
-    if (hipMemcpyAsync(&es, workspace, sizeof(es), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return check_launch("data_augmentation (eigenspace download)");
-    for (int c = 0; c < 3; ++c) es.mean_rgb[c] = es.mean_rgb[c] / N;
-    for (int c = 0; c < 3; ++c) {
-      es.mean_eig[c] = es.eigvec[3 * c] * es.mean_rgb[0] + es.eigvec[3 * c + 1] * es.mean_rgb[1] + es.eigvec[3 * c + 2] * es.mean_rgb[2];
-      if (es.max_abs_eig[c] > 1e-2) es.mean_eig[c] = es.mean_eig[c] / es.max_abs_eig[c];
-    }
-    es.max_l = std::sqrt(es.max_abs_eig[0] * es.max_abs_eig[0] + es.max_abs_eig[1] * es.max_abs_eig[1] + es.max_abs_eig[2] * es.max_abs_eig[2]);
-    if (hipMemcpyAsync(workspace, &es, sizeof(es), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return check_launch("data_augmentation (eigenspace upload)");
+    // :488-536 without the reference's two device <-> host round trips: initialise, reduce and finish on the device
+    EigVec ev;
+    for (int i = 0; i < 9; ++i) ev.v[i] = p->chromatic_eigvec[i];                                         // :496-497
+    EigenSpace* es = static_cast<EigenSpace*>(workspace);
+    hipLaunchKernelGGL(eigenspace_init, dim3(1), dim3(1), 0, st, es, ev);
+    hipLaunchKernelGGL(eigenspace_stats, dim3(blocks_for((long long)N * H * W, 256, 256)), dim3(256), 0, st, bottom, N, H, W, es);
+    hipLaunchKernelGGL(eigenspace_finish, dim3(1), dim3(1), 0, st, es, N);
   }
   for (int n0 = 0; n0 < N; n0 += kItemChunk) {
     a.n0 = n0;

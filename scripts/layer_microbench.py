@@ -64,7 +64,7 @@ c_col = c_id.copy(); c_col[:, 6:12] = 0.05; c_col[:, 12:34] = 0.02
 mean_a = torch.tensor([0.41, 0.43, 0.45], device=dev)
 pa = ops.data_aug_params(448, 320, 255.0, (0.51, 0.56, 0.65, 0.79, 0.01, -0.62, 0.35, -0.83, 0.44), ops.MEAN_PER_CHANNEL)
 add("DataAugmentation spatial + mean [8,3,384,512]->[320,448]", lambda: ops.data_augmentation_forward(pa, img_a, c_id, mean_a), 4 * 8 * 3 * (384 * 512 + 320 * 448))
-add("DataAugmentation spatial + eigen + colour + mean (stats pass + host round trip)", lambda: ops.data_augmentation_forward(pa, img_a, c_col, mean_a), 4 * 8 * 3 * (2 * 384 * 512 + 320 * 448))
+add("DataAugmentation spatial + eigen + colour + mean (statistics pass first)", lambda: ops.data_augmentation_forward(pa, img_a, c_col, mean_a), 4 * 8 * 3 * (2 * 384 * 512 + 320 * 448))
 a1 = torch.randn(4, 256, 48, 96, device=dev, generator=g); b1 = torch.randn(4, 256, 48, 96, device=dev, generator=g)
 p1d = ops.corr_params(40, 1, 40, 1, 1, single_direction=-1)
 add("Correlation1D fwd [4,256,48,96] md 40 left (generic kernel)", lambda: ops.correlation1d_forward(p1d, a1, b1), 4 * 4 * 48 * 96 * (2 * 256 + 41))
