@@ -82,19 +82,9 @@ print("| layer | us | algorithmic MB | GB/s | % of 8 TB/s |\n|---|---|---|---|--
 for name, t, nb, gbs in rows:
     print("| %s | %.1f | %.2f | %.0f | %.1f |" % (name, t, nb / 1e6, gbs, gbs / 80.0))
 
-# CPU side of the sample decode on this box: the oracle's restatement (one thread, like the reference's prefetch thread) and, when
-# oracle/_ref is present, the reference's own CustomDataLayer (compiled in place, in-memory LMDB stand-in), 4 batches of 8
+# host -> device leg of the sample decode (the CPU decode baselines live in tests/cpu_baselines.py: only tests/ may use the oracle)
 import time
-import numpy as np
-import oracle
-from oracle import ref
 host = packed.cpu().numpy()
-t0 = time.time(); oracle.custom_data_decode(host, 9, Hs, Ws, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS); t_or = time.time() - t0
-print("\nCPU decode of the same batch: oracle restatement %.1f ms (%.0f samples/s, 1 thread)" % (t_or * 1e3, Ns / t_or))
-if ref.available():
-    recs = [("%08d" % i, oracle.datum_serialize(9, Hs, Ws, host[i, :nb].tobytes(), i)) for i in range(Ns)]
-    t0 = time.time(); ref.custom_data(recs, Ns, SF.FLOW_SAMPLE_SLICE_POINTS, SF.FLOW_SAMPLE_ENCODINGS, n_forward=4); t_ref = (time.time() - t0) / 5   # SetUp prefetches one batch too
-    print("reference CustomDataLayer (oracle/_ref, host prefetch thread): %.1f ms per batch of %d (%.0f samples/s)" % (t_ref * 1e3, Ns, Ns / t_ref))
 pinned = torch.from_numpy(host).pin_memory()
 src = torch.from_numpy(host)
 t0 = time.time()
