@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile recipe (run on the GPU box through gpurun):  bash scripts/profile_round.sh r01
-# Writes rocprofv3 CSVs under gpurun_out/<tag>/; scripts/summarize_profiles.py turns them into profiles/<tag>_*.
+# Writes rocprofv3 CSVs under gpurun_out/<tag>/; scripts/summarize_profiles.py and scripts/summarize_layer_microbench.py turn them into profiles/<tag>_*.
 # Counters are collected in their own passes (never combined with trace domains other than the kernel trace);
 # every pass runs under its own timeout (a counter pass that aborts can otherwise hang until the box limit).
 set -u
@@ -19,5 +19,10 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTI
 # calibration of FETCH_SIZE / WRITE_SIZE on streaming kernels of known byte count (dword per lane, like the staging loads)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/cal_fetch -o cal -- python scripts/hbm_calibrate.py > $R/cal_stdout.txt 2>/dev/null
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/cal_write -o cal -- python scripts/hbm_calibrate.py > /dev/null 2>&1
+# custom-layer micro-benchmarks (own kernel trace), their host baselines, and the training input pipeline
+python scripts/layer_microbench.py > gpurun_out/layer_microbench.txt 2>/dev/null
+python tests/cpu_baselines.py >> gpurun_out/layer_microbench.txt 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/layers -o lay -- python scripts/layer_microbench.py > /dev/null 2>&1
+timeout 300 python scripts/train_pipeline.py --iters 8 2>/dev/null | tail -11 > gpurun_out/train_pipeline.txt
 python bench.py --steps 30 --warmup 5 > $R/bench.json 2> $R/bench.err
 tail -c 300 $R/bench.json
