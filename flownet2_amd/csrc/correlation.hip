@@ -154,7 +154,7 @@ static int g_force_generic = 0;
 
 using namespace fn2;
 
-namespace fn2 { extern int g_corr_ablation; extern int g_corr_force_dword; extern unsigned long long* g_corr_dbg; }
+namespace fn2 { extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; }
 
 FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   fn2::g_corr_dbg = reinterpret_cast<unsigned long long*>(device_buffer);
@@ -165,6 +165,7 @@ FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
 // applies, 64 + bits = ablation of the general MFMA forward (FN2_ABLATION builds: 1 no MFMA, 2 no staging loads, 4 no stores)
 FN2_API int fn2_debug_set_correlation_impl(int impl) {
   g_force_generic = (impl == 1);
+  fn2::g_corr1d_force_generic = (impl == 1);
   fn2::g_corr_force_dword = (impl == 3);
   fn2::g_corr_ablation = impl >= 64 ? impl - 64 : 0;
   return FN2_OK;

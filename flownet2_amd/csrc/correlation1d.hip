@@ -7,7 +7,8 @@
 // (x_shift = -grid_width, correlation_layer1d.cu:466-471), so columns left of a padded row are read: that is the end of the
 // previous row of the flat blob.  padded_flat() reproduces exactly that (memory in front of the blob reads as 0).
 //
-// One thread per output element, x fastest (coalesced along rows); gather formulation of the backward passes, no atomics.
+// Generic kernels: one thread per output element, x fastest (coalesced along rows); gather formulation of the backward passes, no
+// atomics.  The forward of the configuration the networks use (kernel_size 1, stride_1 1, MULTIPLY) has an LDS-tiled kernel.
 #include "fn2_common.hpp"
 
 #include <cmath>
@@ -90,6 +91,79 @@ __global__ void __launch_bounds__(256) corr1d_fwd(const float* __restrict__ b0, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Tiled forward for the layer as the networks use it: kernel_size 1, stride_1 1, MULTIPLY, and a padding that covers the overshoot
+// of the left mode (then everything outside a row reads zero and the flat indexing never reaches data).
+// Workgroup = one image row x 32 output columns; 8 groups of 32 lanes, group g owns the displacements g, g+8, g+16, ...; channels are
+// staged through LDS 16 at a time (the 32 values of map 0 and the 32 + span values of map 1 the tile needs), so every value is
+// read from memory once per tile instead of once per output, and the map-0 value is reused across a lane's displacements.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kC1Tile = 32, kC1Groups = 256 / kC1Tile, kC1Chunk = 16;
+
+template <int NO>
+__global__ void __launch_bounds__(256) corr1d_fwd_tiled(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, Corr1dGeom g,
+                                                        int bw /* columns of map 1 staged per tile */) {
+  extern __shared__ float lds[];
+  float* As = lds;                              // [kC1Chunk][kC1Tile]
+  float* Bs = lds + kC1Chunk * kC1Tile;         // [kC1Chunk][bw]
+  const int lane = threadIdx.x % kC1Tile, grp = threadIdx.x / kC1Tile;
+  const int x0 = blockIdx.x * kC1Tile;
+  const int y = blockIdx.y % g.H, n = blockIdx.y / g.H;
+  const int xa0 = x0 + g.md - g.pad;            // first map-0 column of the tile (unpadded coordinates)
+  const int xb0 = xa0 + g.xshift * g.s2;        // first map-1 column any displacement of the tile reads
+  const size_t plane = (size_t)g.H * g.W;
+  const float* a_row = b0 + (size_t)n * g.C * plane + (size_t)y * g.W;
+  const float* b_row = b1 + (size_t)n * g.C * plane + (size_t)y * g.W;
+  float acc[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) acc[j] = 0.f;
+  for (int c0 = 0; c0 < g.C; c0 += kC1Chunk) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kC1Chunk * kC1Tile; i += 256) {
+      const int c = i / kC1Tile, x = xa0 + i % kC1Tile;
+      As[i] = (c0 + c < g.C && x >= 0 && x < g.W) ? a_row[(size_t)(c0 + c) * plane + x] : 0.f;
+    }
+    for (int i = threadIdx.x; i < kC1Chunk * bw; i += 256) {
+      const int c = i / bw, x = xb0 + i % bw;
+      Bs[i] = (c0 + c < g.C && x >= 0 && x < g.W) ? b_row[(size_t)(c0 + c) * plane + x] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kC1Chunk; ++c) {
+      const float a = As[c * kC1Tile + lane];
+      const float* brow = Bs + c * bw + lane + grp * g.s2;
+#pragma unroll
+      for (int j = 0; j < NO; ++j) acc[j] = fmaf(a, brow[kC1Groups * j * g.s2], acc[j]);
+    }
+  }
+  const int x = x0 + lane;
+  if (x < g.topW) {
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      const int o = grp + kC1Groups * j;
+      if (o < g.topC) top[(((size_t)n * g.topC + o) * g.topH + y) * g.topW + x] = acc[j] / (float)g.C;
+    }
+  }
+}
+
+static bool corr1d_tiled_supported(const Corr1dGeom& g, int* no, int* bw) {
+  if (g.K != 1 || g.s1 != 1 || g.type != FN2_CORR_MULTIPLY) return false;
+  const int overshoot = -(g.md + g.xshift * g.s2);               // > 0 only in the left mode
+  if (overshoot > g.pad) return false;                           // the flat index would reach data of the previous row
+  const int need = (g.topC + kC1Groups - 1) / kC1Groups;
+  *no = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 16 ? 16 : 0;
+  if (!*no) return false;
+  *bw = kC1Tile + kC1Groups * (*no) * g.s2;                      // covers lane + (grp + 8 j) * s2 for every j < NO
+  return (size_t)kC1Chunk * (kC1Tile + *bw) * sizeof(float) <= 60 * 1024 && (long long)g.N * g.H <= 65535;
+}
+
+template <int NO>
+static void corr1d_tiled_launch(const Corr1dGeom& g, const float* b0, const float* b1, float* top, int bw, hipStream_t st) {
+  const size_t lds = (size_t)kC1Chunk * (kC1Tile + bw) * sizeof(float);
+  hipLaunchKernelGGL(corr1d_fwd_tiled<NO>, dim3((g.topW + kC1Tile - 1) / kC1Tile, g.N * g.H), dim3(256), lds, st, b0, b1, top, g, bw);
+}
+
 __device__ __forceinline__ int ceil_div1(int a, int s) { return (a >= 0) ? (a + s - 1) / s : -((-a) / s); }
 __device__ __forceinline__ int floor_div1(int a, int s) { return (a >= 0) ? a / s : -((-a + s - 1) / s); }
 
@@ -138,6 +212,9 @@ __global__ void __launch_bounds__(256) corr1d_bwd(const float* __restrict__ b0, 
 
 using namespace fn2;
 
+// test hook (fn2_debug_set_correlation_impl(1) also forces the generic 1-D kernels)
+namespace fn2 { int g_corr1d_force_generic = 0; }
+
 FN2_API int fn2_correlation1d_out_shape(const fn2_corr_params* p, int C, int H, int W, int* topC, int* topH, int* topW) {
   Corr1dGeom g;
   int rc = corr1d_geometry(p, 1, C, H, W, &g);
@@ -155,6 +232,19 @@ FN2_API int fn2_correlation1d_forward(const fn2_corr_params* p, const float* bot
   if (rc) return rc;
   if (N == 0) return FN2_OK;
   if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation1d_forward: NULL blob pointer");
+  int no = 0, bw = 0;
+  if (!g_corr1d_force_generic && corr1d_tiled_supported(g, &no, &bw)) {
+    hipStream_t st = as_stream(stream);
+    switch (no) {
+      case 2: corr1d_tiled_launch<2>(g, bottom0, bottom1, top, bw, st); break;
+      case 4: corr1d_tiled_launch<4>(g, bottom0, bottom1, top, bw, st); break;
+      case 6: corr1d_tiled_launch<6>(g, bottom0, bottom1, top, bw, st); break;
+      case 8: corr1d_tiled_launch<8>(g, bottom0, bottom1, top, bw, st); break;
+      case 12: corr1d_tiled_launch<12>(g, bottom0, bottom1, top, bw, st); break;
+      default: corr1d_tiled_launch<16>(g, bottom0, bottom1, top, bw, st); break;
+    }
+    return check_launch("correlation1d_forward");
+  }
   const unsigned blocks = blocks_for((long long)N * g.topC * g.topH * g.topW, 256);
   if (g.type == FN2_CORR_MULTIPLY)
     hipLaunchKernelGGL(corr1d_fwd<false>, dim3(blocks), dim3(256), 0, as_stream(stream), bottom0, bottom1, top, g);

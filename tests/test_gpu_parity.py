@@ -129,6 +129,24 @@ def test_correlation1d_forward_backward(case, ctype):
     assert only1[0] is None and torch.equal(only1[1], d1)
 
 
+@pytest.mark.parametrize("case", [(1, 32, 6, 150, 40, 1, 40, 1, 1, 0), (2, 48, 5, 97, 12, 1, 12, 1, 3, 1), (1, 256, 12, 96, 40, 1, 40, 1, 1, -1),
+                                  (3, 7, 9, 64, 127, 1, 127, 1, 1, 1), (1, 16, 4, 70, 9, 1, 8, 1, 2, -1)])
+def test_correlation1d_tiled_forward_agrees_with_generic_and_oracle(case):
+    """The LDS-tiled forward (kernel_size 1, stride_1 1, MULTIPLY) against the thread-per-output kernel and the oracle: several x tiles,
+    ragged widths, up to 128 displacements, stride_2 > 1, all three directions."""
+    N, C, H, W, pad, K, md, s1, s2, sd = case
+    b0, b1 = rand((N, C, H, W), 51), rand((N, C, H, W), 52)
+    p = ops.corr_params(pad, K, md, s1, s2, oracle.MULTIPLY, False, sd)
+    tiled = ops.correlation1d_forward(p, dev(b0), dev(b1))
+    ops.set_correlation_impl(1)
+    try:
+        generic = ops.correlation1d_forward(p, dev(b0), dev(b1))
+    finally:
+        ops.set_correlation_impl(0)
+    assert_close(host(tiled), host(generic), 2e-6, "tiled vs generic")
+    assert_close(host(tiled), oracle.correlation1d_forward(oracle.corr_params(pad, K, md, s1, s2, oracle.MULTIPLY, 0, sd), b0, b1), 2e-6, "tiled vs oracle")
+
+
 def test_correlation1d_layer_api_and_errors():
     N, C, H, W = 2, 8, 6, 30
     b0, b1 = rand((N, C, H, W), 44), rand((N, C, H, W), 45)
