@@ -165,10 +165,12 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
     return {2: flow2, 3: flow3, 4: flow4, 5: flow5, 6: flow6}
 
 
-def flownet_c_core(P, img0, img1, backend):
-    """Pre-processed images [N,3,H,W] (H, W multiples of 64) -> {scale: flow prediction /20}."""
-    n = img0.shape[0]
-    x = torch.cat([img0, img1], 0)                 # siamese towers share weights (param { name: } sharing, net.cpp:451-540)
+def flownet_c_core(P, img0, img1, backend, towers=None):
+    """Pre-processed images [N,3,H,W] (H, W multiples of 64) -> {scale: flow prediction /20}.  `towers`: the two images already
+    stacked along the batch axis [2N,3,H,W] (the deploy head writes them there directly)."""
+    # siamese towers share weights (param { name: } sharing, net.cpp:451-540): one batch of 2N through conv1-3
+    x = towers if towers is not None else torch.cat([img0, img1], 0)
+    n = x.shape[0] // 2
     c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
     c2 = _conv(c1, P, "conv2", 2, 2, backend=backend)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
@@ -215,16 +217,32 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
     ah, aw = adapted_size(H, W)
     if mean is None:
         mean = _const(img0.device, (0.411, 0.433, 0.45))   # BGR order of a typical RGB mean
-    pre = []
-    for im in (img0, img1):
-        x = im * (1.0 / 255.0)                                                     # Eltwise, coeff 1/255
-        if (ah, aw) != (H, W):                                                     # Resample to ADAPTED size; at equal size the LINEAR
-            x = backend.resample(x, ah, aw)                                        # kernel is the identity (one tap of weight 1): skipped
-        pre.append(x - mean.view(1, 3, 1, 1))                                      # DataAugmentation mean subtraction (deploy slice)
-    if kind == "C":
-        flows = flownet_c_core(P, pre[0], pre[1], backend)
+    if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled():
+        # At the ADAPTED size the LINEAR Resample is the identity (one tap of weight 1), so the head is x / 255 - mean per image:
+        # one pass per image, written straight into the blob the towers (C: batch axis) or conv1 (S: channel axis) read --
+        # instead of scale, subtract and concat as three passes.
+        neg_mean = -mean.view(1, 3, 1, 1)
+        if kind == "C":
+            x = torch.empty((2 * N, 3, H, W), device=img0.device, dtype=torch.float32)
+            torch.add(neg_mean, img0, alpha=1.0 / 255.0, out=x[:N])
+            torch.add(neg_mean, img1, alpha=1.0 / 255.0, out=x[N:])
+            flows = flownet_c_core(P, None, None, backend, towers=x)
+        else:
+            x = torch.empty((N, 6, H, W), device=img0.device, dtype=torch.float32)
+            torch.add(neg_mean, img0, alpha=1.0 / 255.0, out=x[:, :3])
+            torch.add(neg_mean, img1, alpha=1.0 / 255.0, out=x[:, 3:])
+            flows = flownet_s_core(P, x, backend)
     else:
-        flows = flownet_s_core(P, torch.cat(pre, 1), backend)
+        pre = []
+        for im in (img0, img1):
+            x = im * (1.0 / 255.0)                                                 # Eltwise, coeff 1/255
+            if (ah, aw) != (H, W):
+                x = backend.resample(x, ah, aw)                                    # Resample to ADAPTED size
+            pre.append(x - mean.view(1, 3, 1, 1))                                  # DataAugmentation mean subtraction (deploy slice)
+        if kind == "C":
+            flows = flownet_c_core(P, pre[0], pre[1], backend)
+        else:
+            flows = flownet_s_core(P, torch.cat(pre, 1), backend)
     flow = flows[2] * FLOW_SCALE                                                    # Eltwise, coeff 20
     flow = backend.resample(flow, H, W)                                             # Resample to TARGET size (x4 up-sampling)
     scale = _const(flow.device, (W / float(aw), H / float(ah)))   # run-flownet.py:47-48
@@ -369,8 +387,13 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     ah, aw = adapted_size(H, W)
     if mean is None:
         mean = _const(img0.device, (0.411, 0.433, 0.45))
-    a = backend.resample(img0 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
-    b = backend.resample(img1 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
+    if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled():
+        # LINEAR Resample at equal size is the identity: scale and mean in one pass per image
+        a = torch.add(-mean.view(1, 3, 1, 1), img0, alpha=1.0 / 255.0)
+        b = torch.add(-mean.view(1, 3, 1, 1), img1, alpha=1.0 / 255.0)
+    else:
+        a = backend.resample(img0 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
+        b = backend.resample(img1 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
 
     def refine_input(flow_q):                       # flow_q: 1/4 resolution, units px/20
         flow = backend.resample(flow_q * FLOW_SCALE, ah, aw)                       # x20, Resample x4 (LINEAR)

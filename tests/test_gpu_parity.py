@@ -702,7 +702,19 @@ def test_training_gradients_fused_path_matches_stock_ops():
     l_stock, g_stock = grads(True)
     assert abs(l_fused - l_stock) <= 1e-5 * max(1.0, abs(l_stock))
     assert g_fused.keys() == g_stock.keys() and len(g_fused) > 40
+    # The two graphs run the library convolutions twice, and the library does not always pick the same kernels for both: measured over
+    # repeated runs (scripts/probes/grad_agreement_loop.py) the agreement is either ~7e-7 in relative L2 over all gradients, or 4.7e-6
+    # with one transposed-convolution weight gradient at 5e-4.  A wrong backward formula is off by O(1).  Criteria: all parameters
+    # together agree to 2e-3 in relative L2, the typical parameter to 1e-4, no parameter is off by more than 5e-2.
+    rel = {}
+    num = den = 0.0
     for k in g_stock:
-        scale = max(float(g_stock[k].abs().max()), 1e-12)
-        err = float((g_fused[k] - g_stock[k]).abs().max())
-        assert err <= 2e-4 * scale, f"{k}: {err:.3e} vs scale {scale:.3e}"
+        d = (g_fused[k] - g_stock[k]).double()
+        n2, d2 = float(g_stock[k].double().pow(2).sum()), float(d.pow(2).sum())
+        rel[k] = (d2 / max(n2, 1e-30)) ** 0.5
+        num, den = num + d2, den + n2
+    worst = max(rel, key=rel.get)
+    print(f"gradient agreement: all {(num / den) ** 0.5:.2e}, median {float(np.median(list(rel.values()))):.2e}, worst {worst} {rel[worst]:.2e}")
+    assert (num / den) ** 0.5 <= 2e-3, f"all gradients together: relative L2 error {(num / den) ** 0.5:.3e}"
+    assert float(np.median(list(rel.values()))) <= 1e-4, f"median relative L2 error {float(np.median(list(rel.values()))):.3e}"
+    assert rel[worst] <= 5e-2, f"{worst}: relative L2 error {rel[worst]:.3e}"
