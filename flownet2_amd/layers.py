@@ -527,7 +527,10 @@ class CustomDataLayer(Layer):
     is the sequence of (key, value) records such an environment holds (any iterable of pairs or a dict); the layer sorts them by key
     and positions its cursor with the same "%08d" lower-bound lookup (MDB_SET_RANGE, :181-186).  The values are parsed on the host
     (Datum header only), their packed `data` bytes go to the GPU and fn2_custom_data_decode_forward produces the tops; the
-    reference decodes on one prefetch thread and uploads fp32 blobs.  Not reproduced: rand_permute (std::random_shuffle seeded with
+    reference decodes on one prefetch thread and uploads fp32 blobs.  Data-parallel training: the reference SHARES this layer between the
+    solver threads of one process (`ShareInParallel()`, custom_data_layer.hpp:37: successive batches go to successive solvers); with one
+    process per GPU the same assignment is `data_param.world` / `data_param.rank` (ours, default 1 / 0): rank r takes batches
+    r, r + world, r + 2 world, ... of the single cursor.  Not reproduced: rand_permute (std::random_shuffle seeded with
     std::srand, :29-42 -- the order depends on the C library), mean_file (a BlobProto on disk), preselection files."""
 
     def type(self): return "CustomData"
@@ -572,6 +575,8 @@ class CustomDataLayer(Layer):
         self.permutation_vector_ = perm[self.range_start_: self.range_end_ + 1]                # :446-452
         CHECK(not dp.get("rand_skip"), "No rand_skip for CustomData layer")                    # :486-488
         self.datum_index_ = 0
+        self.world_, self.rank_ = int(dp.get("world", 1)), int(dp.get("rank", 0))
+        CHECK(self.world_ >= 1 and 0 <= self.rank_ < self.world_, "data_param.rank must be in [0, world)")
         d = SF.parse_datum(self.values_[0])                                                    # first record shapes the tops, :490-499
         CHECK(int(dp.get("crop_size", 0)) == 0, "Cropping currently not supported")            # :503-506
         batch = int(dp.get("batch_size", 1))
@@ -616,9 +621,15 @@ class CustomDataLayer(Layer):
         self.datum_index_ += 1
         return self.values_[pos]
 
+    def _next_batch(self):
+        """The batch this rank owns: the shared cursor hands batch b to solver b % world (layer.hpp:484-490 with ShareInParallel)."""
+        for _ in range(self.rank_ * self.batch_size_ if self.iter_ == 0 else (self.world_ - 1) * self.batch_size_):
+            self._next_record()
+        return [self._next_record() for _ in range(self.batch_size_)]
+
     def Forward_gpu(self, bottom, top):
         from . import sample_format as SF
-        records = [self._next_record() for _ in range(self.batch_size_)]
+        records = self._next_batch()
         samples, shape, labels = _wrap(SF.stage_records, records, top[0].device)
         CHECK(shape == (self.datum_channels_, self.datum_height_, self.datum_width_), "records of different shapes in one database")
         if self.mean_host_ is not None and self.mean_ is None:

@@ -290,6 +290,19 @@ def test_custom_data_layer_mirror_setup_and_checks():
                           (4, dict(source=[]), "mdb_env_open failed")]:
         with pytest.raises(CheckError, match=msg):
             make(ntop, **dp)
+    # data-parallel ranks: rank r owns batches r, r + world, ... of the one cursor the reference shares between its solver threads
+    single, _ = make(4, batch_size=2)
+    want = [[SF.parse_datum(r).label for r in single._next_batch()] for _ in range(9)]
+    for world in (2, 3):
+        got = {}
+        for rank in range(world):
+            layer, _ = make(4, batch_size=2, world=world, rank=rank)
+            for it in range(9 // world):
+                got[it * world + rank] = [SF.parse_datum(r).label for r in layer._next_batch()]
+                layer.iter_ += 1
+        assert [got[b] for b in sorted(got)] == want[:len(got)]
+    with pytest.raises(CheckError, match="rank must be in"):
+        make(4, world=2, rank=2)
     with pytest.raises(CheckError):                                             # bottoms are not allowed (ExactNumBottomBlobs = 0)
         LayerRegistry.CreateLayer(LayerParameter(type="CustomData", data_param=dict(source=recs, backend="LMDB"))).SetUp([Blob(device="cpu")], [Blob(device="cpu")])
 
