@@ -14,7 +14,7 @@
 namespace fn2 {
 
 // ---------------------------------------------------------------------------------------------------------
-// Protobuf wire format (proto2), the subset Datum needs: varint (0), 64-bit (1), length-delimited (2), 32-bit (5).
+// Protobuf wire format (proto2): varint (0), 64-bit (1), length-delimited (2), groups (3 / 4, only ever unknown fields here), 32-bit (5).
 // ---------------------------------------------------------------------------------------------------------
 struct Reader {
   const unsigned char* p;
@@ -31,6 +31,26 @@ struct Reader {
   bool skip(size_t n) { if ((size_t)(end - p) < n) return false; p += n; return true; }
 };
 
+// Skips the body of an unknown group (wire type 3) up to its END_GROUP key (wire type 4, same field number); groups nest.
+static bool skip_group(Reader& r, uint32_t field, int depth) {
+  if (depth > 100) return false;                       // libprotobuf's recursion limit
+  while (r.p < r.end) {
+    uint64_t key, x;
+    if (!r.varint(&key) || key > 0xffffffffull || (key >> 3) == 0) return false;
+    const uint32_t f = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+    switch (wt) {
+      case 0: if (!r.varint(&x)) return false; break;
+      case 1: if (!r.skip(8)) return false; break;
+      case 2: if (!r.varint(&x) || (uint64_t)(r.end - r.p) < x) return false; r.p += x; break;
+      case 3: if (!skip_group(r, f, depth + 1)) return false; break;
+      case 4: return f == field;
+      case 5: if (!r.skip(4)) return false; break;
+      default: return false;
+    }
+  }
+  return false;                                        // ran out of bytes inside the group
+}
+
 // Walks the message once; float_dst (may be NULL) receives up to float_cap values of field 6.
 static int walk_datum(const void* buf, size_t len, fn2_datum_view* out, float* float_dst, size_t float_cap) {
   if (!buf && len) return fail(FN2_ERR_INVALID_ARG, "datum: NULL buffer");
@@ -40,6 +60,7 @@ static int walk_datum(const void* buf, size_t len, fn2_datum_view* out, float* f
   while (r.p < r.end) {
     uint64_t key;
     if (!r.varint(&key)) return fail(FN2_ERR_INVALID_ARG, "datum: truncated field key");
+    if (key > 0xffffffffull) return fail(FN2_ERR_INVALID_ARG, "datum: field key does not fit 32 bits");
     const uint32_t field = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
     if (field == 0) return fail(FN2_ERR_INVALID_ARG, "datum: field number 0");
     uint64_t x = 0;
@@ -66,6 +87,9 @@ static int walk_datum(const void* buf, size_t len, fn2_datum_view* out, float* f
         r.p += x;
         break;
       }
+      case 3:                                        // an unknown group: skipped as a whole
+        if (!skip_group(r, field, 1)) return fail(FN2_ERR_INVALID_ARG, "datum: malformed group (field %u)", field);
+        break;
       case 5:
         if ((size_t)(r.end - r.p) < 4) return fail(FN2_ERR_INVALID_ARG, "datum: truncated 32-bit field %u", field);
         if (field == 6) {
@@ -74,8 +98,8 @@ static int walk_datum(const void* buf, size_t len, fn2_datum_view* out, float* f
         }
         r.p += 4;
         break;
-      default:
-        return fail(FN2_ERR_INVALID_ARG, "datum: unsupported wire type %u (field %u)", wt, field);
+      default:                                       // 4 = END_GROUP without a group, 6 / 7 = undefined
+        return fail(FN2_ERR_INVALID_ARG, "datum: unexpected wire type %u (field %u)", wt, field);
     }
   }
   if (out) *out = v;

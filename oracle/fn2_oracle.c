@@ -1005,6 +1005,24 @@ static int pb_varint(const unsigned char** p, const unsigned char* end, uint64_t
   return 0;
 }
 
+/* unknown group: everything up to the END_GROUP key (wire type 4) of the same field number; groups nest (recursion limit 100) */
+static int pb_skip_group(const unsigned char** p, const unsigned char* end, unsigned field, int depth) {
+  if (depth > 100) return 0;
+  while (*p < end) {
+    uint64_t key, x;
+    if (!pb_varint(p, end, &key) || key > 0xffffffffu || (key >> 3) == 0) return 0;
+    const unsigned f = (unsigned)(key >> 3), wt = (unsigned)(key & 7);
+    if (wt == 0) { if (!pb_varint(p, end, &x)) return 0; }
+    else if (wt == 1) { if ((size_t)(end - *p) < 8) return 0; *p += 8; }
+    else if (wt == 2) { if (!pb_varint(p, end, &x) || (uint64_t)(end - *p) < x) return 0; *p += x; }
+    else if (wt == 3) { if (!pb_skip_group(p, end, f, depth + 1)) return 0; }
+    else if (wt == 4) return f == field;
+    else if (wt == 5) { if ((size_t)(end - *p) < 4) return 0; *p += 4; }
+    else return 0;
+  }
+  return 0;
+}
+
 static int datum_walk_cpu(const void* buf, size_t len, fn2_datum_view* out, float* fdst, size_t fcap) {
   const unsigned char* p = (const unsigned char*)buf;
   const unsigned char* end = p + len;
@@ -1013,7 +1031,7 @@ static int datum_walk_cpu(const void* buf, size_t len, fn2_datum_view* out, floa
   if (!buf && len) return FN2_ERR_INVALID_ARG;
   while (p < end) {
     uint64_t key, x;
-    if (!pb_varint(&p, end, &key)) return FN2_ERR_INVALID_ARG;
+    if (!pb_varint(&p, end, &key) || key > 0xffffffffu) return FN2_ERR_INVALID_ARG;     /* a key is a 32-bit varint */
     const unsigned field = (unsigned)(key >> 3), wt = (unsigned)(key & 7);
     if (field == 0) return FN2_ERR_INVALID_ARG;
     if (wt == 0) {
@@ -1047,8 +1065,10 @@ static int datum_walk_cpu(const void* buf, size_t len, fn2_datum_view* out, floa
         v.float_data_count++;
       }
       p += 4;
+    } else if (wt == 3) {
+      if (!pb_skip_group(&p, end, field, 1)) return FN2_ERR_INVALID_ARG;                 /* an unknown group, skipped as a whole */
     } else {
-      return FN2_ERR_INVALID_ARG;       /* groups (3, 4) do not occur in Datum */
+      return FN2_ERR_INVALID_ARG;       /* END_GROUP without a group, wire types 6 / 7 */
     }
   }
   if (out) *out = v;

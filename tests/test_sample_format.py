@@ -158,11 +158,86 @@ def test_truncated_and_malformed_records_fail_exactly_where_protobuf_fails():
             with pytest.raises(ValueError):
                 oracle.datum_parse(part)
     assert n_bad > 200                                    # every cut inside the data bytes or inside a varint / fixed32
-    for bad in [b"\x00\x01", b"\x0b", b"\x0c", b"\x0e\x00", b"\x32\x03abc", b"\x08" + b"\xff" * 11]:   # field 0, groups, wire type 6, ragged packed floats, endless varint
+    for bad in [b"\x00\x01", b"\x0b", b"\x0c", b"\x0e\x00", b"\x32\x03abc", b"\x08" + b"\xff" * 11]:   # field 0, open / stray group, wire type 6, ragged packed floats, endless varint
         with pytest.raises(flownet2_amd.Fn2Error):
             SF.parse_datum(bad)
         with pytest.raises(ValueError):
             oracle.datum_parse(bad)
+
+
+def _protobuf_view(D, rec):
+    from google.protobuf.message import DecodeError
+    try:
+        d = D()
+        d.ParseFromString(rec)
+    except DecodeError:
+        return None
+    return (d.channels, d.height, d.width, d.label, bool(d.encoded), d.data if d.HasField("data") else None,
+            np.asarray(list(d.float_data), np.float32).view(np.uint32).tolist())
+
+
+def _our_views(rec):
+    out = []
+    try:
+        g = SF.parse_datum(rec)
+        out.append((g.channels, g.height, g.width, g.label, g.encoded, g.data, [] if g.float_data is None else g.float_data.view(np.uint32).tolist()))
+    except flownet2_amd.Fn2Error:
+        out.append(None)
+    try:
+        o = oracle.datum_parse(rec)
+        out.append((o["channels"], o["height"], o["width"], o["label"], o["encoded"], o["data"], [] if o["float_data"] is None else o["float_data"].view(np.uint32).tolist()))
+    except ValueError:
+        out.append(None)
+    return out
+
+
+def test_edge_cases_of_the_wire_format_follow_protobuf():
+    """Groups (skipped when well formed), 10-byte varints, int32 truncation, keys beyond 32 bits, known fields with a foreign wire type
+    (treated as unknown), bool from any non-zero varint."""
+    D = _datum_class()
+    cases = [b"\x0b\x08\x01\x0c", b"\x0b\x08\x01", b"\x0b\x14", b"\x0c", b"\x0b\x13\x2a\x02hi\x14\x0c\x08\x07", b"\x0b\x13\x0c\x14",
+             b"\x08" + b"\xff" * 9 + b"\x01", b"\x08" + b"\xff" * 9 + b"\x7f", b"\x08" + b"\xff" * 10 + b"\x01", b"\x08\x85\x80\x80\x80\x10",
+             b"\x0a\x01\x05", b"\x20\x05", b"\x31" + b"\x00" * 8, b"\x2d\x01\x00\x00\x00", b"\xf8\xff\xff\xff\x0f\x01", b"\xf8\xff\xff\xff\x1f\x01",
+             b"\x38\x02", b"\x22\x00", b"\x22\x03abc\x22\x02xy", b"\x0b" * 101 + b"\x0c" * 101, b"\x0b" * 99 + b"\x0c" * 99]
+    for rec in cases:
+        want = _protobuf_view(D, rec)
+        for got in _our_views(rec):
+            assert got == want, (rec, got, want)
+
+
+def test_fuzzed_records_parse_like_protobuf():
+    """20,000 byte strings: random bytes biased towards plausible keys, and mutations (bit flips, cuts, splices) of valid Datums."""
+    D = _datum_class()
+    rng = np.random.default_rng(2024)
+    d = D()
+    d.channels, d.height, d.width, d.label, d.data, d.encoded = 9, 24, 32, -3, bytes(range(40)), True
+    d.float_data.extend([1.5, -2.25])
+    valid = d.SerializeToString()
+    keys = np.array([0x08, 0x10, 0x18, 0x22, 0x28, 0x32, 0x35, 0x38, 0x0b, 0x0c, 0x09, 0x0d, 0x00, 0x0e, 0x4a, 0xf8], np.uint8)
+    accepted = 0
+    for it in range(20000):
+        kind = it % 4
+        if kind == 0:
+            rec = rng.integers(0, 256, int(rng.integers(0, 24)), dtype=np.uint8)
+            pos = rng.random(rec.size) < 0.3
+            rec[pos] = rng.choice(keys, int(pos.sum()))
+        else:
+            rec = np.frombuffer(valid, np.uint8).copy()
+            if kind == 1:
+                for _ in range(int(rng.integers(1, 4))):
+                    rec[int(rng.integers(0, rec.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            elif kind == 2:
+                a, b = sorted(rng.integers(0, rec.size + 1, 2))
+                rec = np.concatenate([rec[:a], rec[b:]])
+            else:
+                a = int(rng.integers(0, rec.size + 1))
+                rec = np.concatenate([rec[:a], rng.choice(keys, int(rng.integers(1, 4))), rec[a:]])
+        rec = rec.tobytes()
+        want = _protobuf_view(D, rec)
+        accepted += want is not None
+        for got in _our_views(rec):
+            assert got == want, (rec, got, want)
+    assert 2000 < accepted < 19000
 
 
 # ---------------------------------------------------------------------------------------------------------
