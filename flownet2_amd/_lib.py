@@ -25,7 +25,7 @@ EXPORTS = [
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
-    "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_decode_forward",
+    "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
     "fn2_augmentation_matrix", "fn2_flow_augmentation_forward",
     "fn2_data_augmentation_workspace_bytes", "fn2_data_augmentation_forward",
 ]
@@ -116,6 +116,7 @@ def lib():
     L.fn2_custom_data_sample_bytes.argtypes = [i, i, i, ip, i, ip, i]
     L.fn2_custom_data_sample_bytes.restype = sz
     L.fn2_custom_data_encode_sample.argtypes = [vp, vp, vp, vp, i, i, vp, sz]
+    L.fn2_custom_data_stage_records.argtypes = [C.POINTER(C.c_void_p), C.POINTER(sz), i, vp, sz, ip, ip, ip, C.POINTER(sz), ip]
     L.fn2_custom_data_decode_forward.argtypes = [vp, sz, i, i, i, i, ip, i, ip, i, i, fp, C.c_float, C.POINTER(C.c_void_p), vp]
     L.fn2_augmentation_matrix.argtypes = [fp, i, i, i, i, i, fp]
     L.fn2_flow_augmentation_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, i, vp]

@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <thread>
+#include <vector>
 
 namespace fn2 {
 
@@ -304,6 +306,37 @@ FN2_API int fn2_custom_data_encode_sample(const unsigned char* img0, const unsig
     if (++idx == 8) { *p++ = current; idx = 0; current = 0; }
   }
   if (idx > 0) *p++ = current;
+  return FN2_OK;
+}
+
+FN2_API int fn2_custom_data_stage_records(const void* const* records, const size_t* record_bytes, int N, void* staging, size_t sample_stride,
+                                          int* channels, int* height, int* width, size_t* sample_bytes, int* labels) {
+  if (N < 1 || !records || !record_bytes) return fail(FN2_ERR_INVALID_ARG, "custom_data_stage_records: no records");
+  std::vector<fn2_datum_view> v((size_t)N);
+  for (int i = 0; i < N; ++i) {
+    int rc = walk_datum(records[i], record_bytes[i], &v[i], nullptr, 0);
+    if (rc) return rc;
+    if (!v[i].data) return fail(FN2_ERR_INVALID_ARG, "custom_data_stage_records: record %d holds no data bytes", i);
+    if (v[i].channels != v[0].channels || v[i].height != v[0].height || v[i].width != v[0].width || v[i].data_bytes != v[0].data_bytes)
+      return fail(FN2_ERR_INVALID_ARG, "custom_data_stage_records: record %d is [%d,%d,%d] with %zu bytes, record 0 is [%d,%d,%d] with %zu",
+                  i, v[i].channels, v[i].height, v[i].width, v[i].data_bytes, v[0].channels, v[0].height, v[0].width, v[0].data_bytes);
+  }
+  if (channels) *channels = v[0].channels;
+  if (height) *height = v[0].height;
+  if (width) *width = v[0].width;
+  if (sample_bytes) *sample_bytes = v[0].data_bytes;
+  if (labels) for (int i = 0; i < N; ++i) labels[i] = v[i].label;
+  if (!staging) return FN2_OK;
+  if (sample_stride < v[0].data_bytes) return fail(FN2_ERR_WORKSPACE, "custom_data_stage_records: stride %zu < sample size %zu", sample_stride, v[0].data_bytes);
+  auto copy = [&](int i) { std::memcpy(static_cast<unsigned char*>(staging) + (size_t)i * sample_stride, v[i].data, v[i].data_bytes); };
+  if ((size_t)N * v[0].data_bytes < (1u << 20) || N == 1) {
+    for (int i = 0; i < N; ++i) copy(i);
+  } else {                                             // a few MB per record: one thread per record (up to 8) saturates the host memory better
+    const int nt = N < 8 ? N : 8;
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { for (int i = t; i < N; i += nt) copy(i); });
+    for (auto& x : th) x.join();
+  }
   return FN2_OK;
 }
 

@@ -148,29 +148,22 @@ def decode_batch(samples: torch.Tensor, channels: int, H: int, W: int, slice_poi
 def stage_records(records: Sequence[bytes], device="cuda"):
     """Parses a batch of LMDB values on the host (header walk only) and uploads their raw `data` payloads: returns (samples uint8
     [N, stride] on the device, the first Datum's (channels, H, W), labels).  All records must have the same shape (the layer CHECKs
-    that, :545).  One host copy per record: from the record into the page-locked staging buffer."""
+    that, :545).  One host copy per record, from the record into the page-locked staging buffer (fn2_custom_data_stage_records)."""
     L = _lib.lib()
-    views = []
-    for r in records:
-        addr, n, keep = _buf(r)
-        v = DatumView()
-        check(L.fn2_datum_parse(addr, n, C.byref(v)))
-        if not v.data:
-            raise ValueError("records of one batch must hold `data` bytes")
-        views.append((v, v.data - addr.value, keep))
-    v0 = views[0][0]
-    for v, _, _ in views:
-        if (v.channels, v.height, v.width, v.data_bytes) != (v0.channels, v0.height, v0.width, v0.data_bytes):
-            raise ValueError("records of one batch must share channels / height / width")
-    stride = (v0.data_bytes + 15) // 16 * 16                    # keeps every sample 16-byte aligned
-    host = _staging(len(views), stride)
-    host_np = host.numpy()
-    for i, (v, off, keep) in enumerate(views):
-        host_np[i, :v.data_bytes] = keep[off: off + v.data_bytes]
+    n = len(records)
+    bufs = [np.frombuffer(r, dtype=np.uint8) for r in records]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    ch, h, w, nb = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    labels = (C.c_int * n)()
+    check(L.fn2_custom_data_stage_records(ptrs, lens, n, None, 0, C.byref(ch), C.byref(h), C.byref(w), C.byref(nb), labels))
+    stride = (nb.value + 15) // 16 * 16                         # keeps every sample 16-byte aligned
+    host = _staging(n, stride)
+    check(L.fn2_custom_data_stage_records(ptrs, lens, n, C.c_void_p(host.data_ptr()), stride, None, None, None, None, None))
     out = host.to(device, non_blocking=True)
     if out.is_cuda:
         torch.cuda.current_stream().synchronize()                 # the staging buffer is reused by the next batch
-    return out, (v0.channels, v0.height, v0.width), [v.label for v, _, _ in views]
+    return out, (ch.value, h.value, w.value), list(labels)
 
 
 _STAGING = {}

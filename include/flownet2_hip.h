@@ -303,6 +303,13 @@ size_t fn2_custom_data_sample_bytes(int channels, int H, int W, const int* slice
  * occlusion: [H,W] uint8 (non-zero = occluded), NULL = none.  dst must hold 10*H*W + (H*W-1)/8 + 1 bytes. */
 int fn2_custom_data_encode_sample(const unsigned char* img0_hwc, const unsigned char* img1_hwc, const float* flow_chw,
                                   const unsigned char* occlusion, int H, int W, unsigned char* dst, size_t dst_bytes);
+/* HOST: the staging step of a batch -- walks N serialized Datums (LMDB values), CHECKs that they share channels / height / width and
+ * payload size (custom_data_layer.cpp:545 assumes it), copies every `data` payload to staging + i * sample_stride (a page-locked buffer
+ * the caller uploads with one copy) and returns the labels (Datum.label, :297).  staging == NULL: only reports the shape and
+ * *sample_bytes of the first record, so that the caller can size the buffer.  Records without `data` bytes (float_data datums) are
+ * refused here. */
+int fn2_custom_data_stage_records(const void* const* records, const size_t* record_bytes, int N, void* staging, size_t sample_stride,
+                                  int* channels, int* height, int* width, size_t* sample_bytes, int* labels);
 /* DEVICE: samples = N `data` payloads in device memory, sample_stride bytes apart (>= the sample size).  mean: device
  * [channels*H*W] floats or NULL (= 0, data_mean_ without mean_file / subtract, :612-615).  tops: HOST array of n_slice_points + 1
  * device pointers, top[s] = [N, slice channels, H, W].  float_data != 0: samples are channels*H*W floats each (Datum.float_data,

@@ -379,3 +379,20 @@ def data_augmentation_forward(bottom, coeffs=None, crop_height=0, crop_width=0, 
     top = np.empty((N, Cc, max(ch, 1), max(cw, 1)), np.float32)
     _check(lib().fn2_data_augmentation_forward_cpu(C.byref(p), _p(bottom), _p(co), _p(m), _p(top), N, Cc, H, W), "data_augmentation_forward")
     return top
+
+
+def custom_data_stage_records(records):
+    """-> (samples uint8 [N, sample_bytes], (channels, H, W), labels) through the oracle's staging restatement."""
+    n = len(records)
+    bufs = [np.frombuffer(r, dtype=np.uint8) for r in records]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    ch, h, w, nb = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+    labels = (C.c_int * n)()
+    L = lib()
+    L.fn2_custom_data_stage_records_cpu.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    _check(L.fn2_custom_data_stage_records_cpu(ptrs, lens, n, None, 0, C.byref(ch), C.byref(h), C.byref(w), C.byref(nb), labels), "custom_data_stage_records")
+    out = np.zeros((n, nb.value), np.uint8)
+    _check(L.fn2_custom_data_stage_records_cpu(ptrs, lens, n, C.c_void_p(out.ctypes.data), nb.value, None, None, None, None, None), "custom_data_stage_records")
+    return out, (ch.value, h.value, w.value), list(labels)

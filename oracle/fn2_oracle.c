@@ -1194,6 +1194,32 @@ FN2_API int fn2_custom_data_encode_sample_cpu(const unsigned char* img0, const u
   return (size_t)(ptr - dst) == data_size ? FN2_OK : FN2_ERR_INVALID_ARG;                        /* assert :204 */
 }
 
+/* The staging step in front of the decode: what CustomDataLayerPrefetch does per item before DecodeData (custom_data_layer.cpp:170-207:
+ * fetch the value, Datum::ParseFromArray) plus the label (:297), with the payload copied out instead of decoded. */
+FN2_API int fn2_custom_data_stage_records_cpu(const void* const* records, const size_t* record_bytes, int N, void* staging, size_t sample_stride,
+                                              int* channels, int* height, int* width, size_t* sample_bytes, int* labels) {
+  if (N < 1 || !records || !record_bytes) return FN2_ERR_INVALID_ARG;
+  fn2_datum_view first;
+  for (int item_id = 0; item_id < N; ++item_id) {
+    fn2_datum_view d;
+    int rc = datum_walk_cpu(records[item_id], record_bytes[item_id], &d, NULL, 0);
+    if (rc) return rc;
+    if (!d.data) return FN2_ERR_INVALID_ARG;
+    if (item_id == 0) first = d;
+    if (d.channels != first.channels || d.height != first.height || d.width != first.width || d.data_bytes != first.data_bytes) return FN2_ERR_INVALID_ARG;
+    if (labels) labels[item_id] = d.label;
+    if (staging) {
+      if (sample_stride < d.data_bytes) return FN2_ERR_WORKSPACE;
+      memcpy((unsigned char*)staging + (size_t)item_id * sample_stride, d.data, d.data_bytes);
+    }
+  }
+  if (channels) *channels = first.channels;
+  if (height) *height = first.height;
+  if (width) *width = first.width;
+  if (sample_bytes) *sample_bytes = first.data_bytes;
+  return FN2_OK;
+}
+
 /* All pointers are HOST pointers here.  Restates DecodeData (whole datum -> floats, :44-136) and then the slice copy with the mean
  * and the scale (:209-300, the crop_size == 0 branch :274-284). */
 FN2_API int fn2_custom_data_decode_forward_cpu(const void* samples, size_t sample_stride, int N, int channels, int H, int W,

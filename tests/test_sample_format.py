@@ -323,6 +323,31 @@ def test_slicing_defaults_float_data_and_invalid_slicings():
         SF.decode_batch(torch.zeros(1, 10, dtype=torch.uint8), 1, 2, 5)
 
 
+def test_stage_records_host_function_matches_the_oracle_and_checks_shapes():
+    H, W = 12, 20
+    recs = [SF.make_record(*_sample_inputs(H, W, 70 + i), label=5 - i) for i in range(5)]
+    got, shape, labels = SF.stage_records(recs, "cpu")
+    want, wshape, wlabels = oracle.custom_data_stage_records(recs)
+    nb = SF.sample_bytes(9, H, W, SP, ENC)
+    assert shape == wshape == (9, H, W) and labels == wlabels == [5, 4, 3, 2, 1]
+    assert got.shape[1] % 16 == 0 and np.array_equal(got.numpy()[:, :nb], want) and want.shape == (5, nb)
+    for i, r in enumerate(recs):
+        assert want[i].tobytes() == SF.parse_datum(r).data
+    big = [SF.make_record(*_sample_inputs(128, 160, 80 + i)) for i in range(6)]          # > 1 MB in total: the threaded copy
+    g2, _, _ = SF.stage_records(big, "cpu")
+    w2, _, _ = oracle.custom_data_stage_records(big)
+    assert np.array_equal(g2.numpy()[:, :w2.shape[1]], w2)
+    other = SF.make_record(*_sample_inputs(H, W + 1, 3))
+    fl = _datum_class()()
+    fl.channels, fl.height, fl.width = 1, 1, 2
+    fl.float_data.extend([1.0, 2.0])
+    for bad in ([recs[0], other], [recs[0], recs[1][:-7]], [fl.SerializeToString()]):
+        with pytest.raises(flownet2_amd.Fn2Error):
+            SF.stage_records(bad, "cpu")
+        with pytest.raises(ValueError):
+            oracle.custom_data_stage_records(bad)
+
+
 def test_records_round_trip_through_the_datum_container():
     H, W = 6, 10
     a, b, f, o = _sample_inputs(H, W, 11)
