@@ -118,7 +118,9 @@ class LayerParameter:
     l1_loss_param: Dict = field(default_factory=dict)
     downsample_param: Dict = field(default_factory=dict)
     data_param: Dict = field(default_factory=dict)      # DataParameter, caffe.proto:918-986 (CustomData)
-    augmentation_param: Dict = field(default_factory=dict)   # AugmentationParameter, caffe.proto:489-546 (crop_width / crop_height)
+    augmentation_param: Dict = field(default_factory=dict)   # AugmentationParameter, caffe.proto:489-546 (crop sizes, mean, generators as dicts)
+    coeff_schedule_param: Dict = field(default_factory=dict)  # CoeffScheduleParameter, caffe.proto:693-697
+    phase: str = "TEST"                                       # TRAIN / TEST (caffe.proto:311); the augmentation layers draw only in TRAIN
 
 
 class Layer:
@@ -435,8 +437,10 @@ class DownsampleLayer(Layer):
 class DataAugmentationLayer(Layer):
     """include/caffe/layers/data_augmentation_layer.hpp; data_augmentation_layer.cpp:32-160, .cu:320-637 -- for GIVEN coefficients.
     bottom = [images] or [images, coefficient blob] (`input_params_`); top = [augmented] or [augmented, coefficient blob].
-    Without bottom[1] every sample gets the default coefficients (what the reference does outside the training phase, .cu:375-387:
-    centre crop, no colour change); drawing random coefficients (generate_*_coeffs, boost generators) is not reproduced.
+    Without bottom[1]: outside the training phase every sample gets the default coefficients (.cu:375-387: centre crop, no colour
+    change); in the training phase (or with `augment_during_test`) the layer draws them from the generator sub-messages of
+    `augmentation_param` (dicts: rand_type / exp / mean / spread / prob ...) through flownet2_amd/augment.py -- the reference's control
+    flow with numpy's random stream (`augmentation_param.seed`, ours), since boost's cannot be reproduced.
     Mean: `augmentation_param.mean` (3 values) with `mean_per_pixel: false` (.cpp:142-151), or the blobs a trained model carries
     (`set_mean(per_channel=...)` = blobs_[2], `set_mean(per_pixel=...)` = blobs_[1], .cu:592-621); the running re-computation of the
     mean over the first `recompute_mean` iterations is training-time state of the reference layer and is not reproduced."""
@@ -445,9 +449,25 @@ class DataAugmentationLayer(Layer):
     def AllowBackward(self): return False                                            # hpp:29
 
     def LayerSetUp(self, bottom, top):
+        import numpy as np
         self.layer_param_.reshape_every_iter = False                                  # cpp:38
         self.mean_ = None
         self.mean_mode_ = ops.MEAN_NONE
+        self.num_iter_ = 0                                                            # blobs_[0], .cu:349-351
+        self.rng_ = np.random.default_rng(self.layer_param_.augmentation_param.get("seed", 0))
+
+    def _generators(self):
+        return {k: v for k, v in self.layer_param_.augmentation_param.items() if isinstance(v, dict)}
+
+    def _draw(self, bottom):
+        """.cu:364-450: only with a crop size, only in TRAIN (or augment_during_test), only the groups that have generators."""
+        from . import augment
+        ap = self.layer_param_.augmentation_param
+        if not self.do_cropping_ or not (self.layer_param_.phase == "TRAIN" or ap.get("augment_during_test", False)) or not self._generators():
+            return None
+        disc = augment.discount_coeff(self.num_iter_, self.layer_param_.coeff_schedule_param)
+        return augment.draw_batch(self.rng_, self._generators(), bottom[0].num(), bottom[0].width(), bottom[0].height(),
+                                  self.cropped_width_, self.cropped_height_, discount=disc)
 
     def set_mean(self, per_channel=None, per_pixel=None):
         CHECK((per_channel is None) != (per_pixel is None), "give exactly one of per_channel / per_pixel")
@@ -481,13 +501,79 @@ class DataAugmentationLayer(Layer):
         if self.mean_ is None and getattr(self, "mean_host_", None) is not None:
             self.mean_ = torch.tensor(self.mean_host_, dtype=torch.float32, device=bottom[0].data.device)
         self.params_.mean_mode = self.mean_mode_
-        coeffs = bottom[1].data if self.input_params_ else None
+        self.num_iter_ += 1                                                                             # .cu:350
+        coeffs = bottom[1].data if self.input_params_ else self._draw(bottom)
         top[0].data = _wrap(ops.data_augmentation_forward, self.params_, bottom[0].data, coeffs, self.mean_)
         if self.output_params_:                                                                         # .cu:346-347: the same blob
-            top[1].data = bottom[1].data if self.input_params_ else torch.zeros_like(top[1].data)
+            if self.input_params_:
+                top[1].data = bottom[1].data
+            else:                                                                                       # coefficient blobs are read on the host
+                top[1].data = torch.zeros(top[1].shape()) if coeffs is None else torch.from_numpy(coeffs).view(-1, ops.AUG_NUM_PARAMS, 1, 1)
 
     def Backward_gpu(self, top, propagate_down, bottom):
         CHECK(not any(propagate_down), "DataAugmentationLayer cannot do backward.")                    # hpp:38-41
+
+
+class GenerateAugmentationParametersLayer(Layer):
+    """include/caffe/layers/generate_augmentation_parameters_layer.hpp; generate_augmentation_parameters_layer.cpp:32-105, .cu:14-112.
+    bottom = [any blob] (num and, if it is an image, the source size) or [coefficient blob, original images, augmented images];
+    top = [coefficient blob].  Modes "add" / "replace" / "regenerate" (augmentation_param.mode, forced to "regenerate" when the single
+    bottom is an image, cpp:56-60).  Host logic throughout (the reference's Forward_gpu runs on the host too); numpy's random stream."""
+
+    def type(self): return "GenerateAugmentationParameters"
+    def AllowBackward(self): return False
+
+    def LayerSetUp(self, bottom, top):
+        import numpy as np
+        self.layer_param_.reshape_every_iter = False                                  # cpp:35
+        self.rng_ = np.random.default_rng(self.layer_param_.augmentation_param.get("seed", 0))
+
+    def Reshape(self, bottom, top):
+        ap = self.layer_param_.augmentation_param
+        CHECK(len(bottom) in (1, 3), "Generate augmentation parameters layer takes one (any blob from which it can take num and potentially "
+              "original image size) or three (aug params, orig data, augmented data) input blobs.")                                         # cpp:50
+        CHECK(len(top) == 1, "Generate augmentation parameters layer outputs one output blob.")                                             # cpp:51
+        self.mode_ = ap.get("mode", "add")                                                                                                   # caffe.proto:498
+        if len(bottom) == 1 and (bottom[0].width() > 1 or bottom[0].height() > 1):
+            self.mode_ = "regenerate"                                                                                                        # cpp:58-60
+        self.num_ = bottom[0].num()
+        if len(bottom) == 3:
+            self.cropped_width_, self.cropped_height_ = bottom[2].width(), bottom[2].height()                                                # cpp:74-77
+            self.bottomwidth_, self.bottomheight_ = bottom[1].width(), bottom[1].height()
+        else:
+            CHECK("crop_width" in ap and "crop_height" in ap, "Need crop_width and crop_height if there is no blob specifying these")        # cpp:79
+            self.cropped_width_, self.cropped_height_ = int(ap["crop_width"]), int(ap["crop_height"])
+            if bottom[0].width() > 1 or bottom[0].height() > 1:
+                self.bottomwidth_, self.bottomheight_ = bottom[0].width(), bottom[0].height()
+            else:
+                CHECK("bottomwidth" in ap and "bottomheight" in ap, "Need bottomwidth and bottomheight if there is no blob specifying these")   # cpp:87
+                self.bottomwidth_, self.bottomheight_ = int(ap["bottomwidth"]), int(ap["bottomheight"])
+        CHECK(self.num_ >= 1, "Must provide num with a bottom blob or in the prototxt")                                                      # cpp:95
+        top[0].Reshape(self.num_, ops.AUG_NUM_PARAMS, 1, 1)
+        self.num_iter_ = 0
+
+    def Forward_gpu(self, bottom, top):
+        import numpy as np
+        from . import augment
+        ap = self.layer_param_.augmentation_param
+        self.num_iter_ += 1                                                                                                                  # .cu:20
+        gens = {k: v for k, v in ap.items() if isinstance(v, dict)}
+        if not (self.layer_param_.phase == "TRAIN" or ap.get("augment_during_test", False)):
+            gens = {}                                                                                                                        # .cu:35-36
+        in_params = None
+        if self.mode_ in ("add", "replace"):
+            in_params = bottom[0].data.detach().cpu().numpy().reshape(self.num_, ops.AUG_NUM_PARAMS).astype(np.float32)
+        disc = augment.discount_coeff(self.num_iter_, self.layer_param_.coeff_schedule_param)
+        if in_params is None:
+            out = augment.draw_batch(self.rng_, gens, self.num_, self.bottomwidth_, self.bottomheight_, self.cropped_width_, self.cropped_height_, disc,
+                                     in_params=np.zeros((self.num_, ops.AUG_NUM_PARAMS), np.float32), mode="regenerate")
+        else:
+            out = augment.draw_batch(self.rng_, gens, self.num_, self.bottomwidth_, self.bottomheight_, self.cropped_width_, self.cropped_height_, disc,
+                                     in_params=in_params, mode=self.mode_)
+        top[0].data = torch.from_numpy(out).view(self.num_, ops.AUG_NUM_PARAMS, 1, 1)          # read on the host by the consumers
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        pass
 
 
 class FlowAugmentationLayer(Layer):
@@ -677,5 +763,6 @@ REGISTER_LAYER_CLASS("L1Loss", L1LossLayer)                # l1loss_layer.cpp:10
 REGISTER_LAYER_CLASS("ChannelNorm", ChannelNormLayer)      # channel_norm_layer.cpp:193-194
 REGISTER_LAYER_CLASS("Downsample", DownsampleLayer)        # downsample_layer.cpp:78-79
 REGISTER_LAYER_CLASS("DataAugmentation", DataAugmentationLayer)   # data_augmentation_layer.cpp:218-219
+REGISTER_LAYER_CLASS("GenerateAugmentationParameters", GenerateAugmentationParametersLayer)   # generate_augmentation_parameters_layer.cpp:118-119
 REGISTER_LAYER_CLASS("FlowAugmentation", FlowAugmentationLayer)   # flow_augmentation_layer.cpp:88-89
 REGISTER_LAYER_CLASS("CustomData", CustomDataLayer)        # custom_data_layer.cpp:712-713

@@ -395,3 +395,44 @@ def test_drawn_spatial_coefficients_keep_the_crop_inside_the_image():
     assert abs(A.discount_coeff(50000, dict(half_life=50000, initial_coeff=0.5, final_coeff=1)) - 0.75) < 1e-3
     zero = A.draw_batch(rng, dict(translate=dict(rand_type="uniform", spread=0.3)), 4, W, H, cw, ch, discount=0.0)
     assert np.array_equal(zero, np.zeros((4, 42), np.float32))
+
+
+def test_augmentation_layer_mirrors_draw_only_in_the_training_phase():
+    from flownet2_amd.layers import Blob, CheckError, LayerParameter, LayerRegistry
+    img, aug_img = Blob(4, 3, 384, 512, device="cpu"), Blob(4, 3, 320, 448, device="cpu")
+    ap = dict(TRAIN_AUG, crop_width=448, crop_height=320, seed=7)
+    # DataAugmentation draws its own coefficients in TRAIN, keeps the defaults in TEST (data_augmentation_layer.cu:375-387)
+    for phase, drawn in (("TEST", False), ("TRAIN", True)):
+        layer = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", phase=phase, augmentation_param=ap,
+                                                         coeff_schedule_param=dict(half_life=50000, initial_coeff=0.5, final_coeff=1.0)))
+        layer.SetUp([img], [Blob(device="cpu"), Blob(device="cpu")])
+        layer.num_iter_ = 1
+        co = layer._draw([img])
+        assert (co is not None) == drawn
+        if drawn:
+            assert co.shape == (4, 42) and np.isfinite(co).all() and np.abs(co[:, 1:12]).max() > 0 and np.array_equal(co[:, 34:], np.zeros((4, 8), np.float32))
+    # GenerateAugmentationParameters, three bottoms, mode add: relative coefficients on top of the given ones
+    params0 = Blob.from_tensor(torch.from_numpy(co).view(4, 42, 1, 1))
+    gen = LayerRegistry.CreateLayer(LayerParameter(type="GenerateAugmentationParameters", phase="TRAIN", augmentation_param=dict(REL_AUG, mode="add", seed=9)))
+    top = [Blob(device="cpu")]
+    gen.SetUp([params0, img, aug_img], top)
+    assert top[0].shape() == [4, 42, 1, 1] and (gen.cropped_width_, gen.cropped_height_, gen.bottomwidth_, gen.bottomheight_) == (448, 320, 512, 384)
+    gen.Forward_gpu([params0, img, aug_img], top)
+    out = top[0].data.numpy().reshape(4, 42)
+    assert np.array_equal(out[:, 0], co[:, 0]) and 0 < np.abs(out[:, 1:6] - co[:, 1:6]).max() < 0.3
+    assert np.abs(out[:, 7:12] - co[:, 7:12]).max() < 1e-6 and np.abs(out[:, 6] - co[:, 6]).max() > 0          # only gamma is re-drawn
+    # outside the training phase nothing is drawn: the coefficients pass through (exp / log round trip of the multiplicative fields)
+    gen_test = LayerRegistry.CreateLayer(LayerParameter(type="GenerateAugmentationParameters", phase="TEST", augmentation_param=dict(REL_AUG, mode="add")))
+    gen_test.SetUp([params0, img, aug_img], top)
+    gen_test.Forward_gpu([params0, img, aug_img], top)
+    assert np.abs(top[0].data.numpy().reshape(4, 42) - co).max() < 1e-6
+    # one image bottom: mode forced to "regenerate", sizes from the blob and the prototxt
+    gen1 = LayerRegistry.CreateLayer(LayerParameter(type="GenerateAugmentationParameters", phase="TRAIN", augmentation_param=dict(TRAIN_AUG, crop_width=448, crop_height=320)))
+    gen1.SetUp([img], top)
+    assert gen1.mode_ == "regenerate" and (gen1.bottomwidth_, gen1.bottomheight_) == (512, 384)
+    gen1.Forward_gpu([img], top)
+    assert np.isfinite(top[0].data.numpy()).all()
+    for bottoms, apx, msg in [([img, img], dict(crop_width=4, crop_height=4), "takes one .* or three"), ([params0], dict(crop_width=4, crop_height=4), "Need bottomwidth"),
+                              ([img], {}, "Need crop_width")]:
+        with pytest.raises(CheckError, match=msg):
+            LayerRegistry.CreateLayer(LayerParameter(type="GenerateAugmentationParameters", augmentation_param=apx)).SetUp(bottoms, [Blob(device="cpu")])

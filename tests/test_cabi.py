@@ -79,7 +79,7 @@ def test_ops_refuse_cpu_tensors_no_fallback():
 
 
 def test_layer_registry_and_blob_count_checks():
-    assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Correlation", "Correlation1D", "CustomData", "DataAugmentation", "Downsample", "FlowAugmentation", "FlowWarp", "L1Loss", "Resample"]
+    assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Correlation", "Correlation1D", "CustomData", "DataAugmentation", "Downsample", "FlowAugmentation", "FlowWarp", "GenerateAugmentationParameters", "L1Loss", "Resample"]
     with pytest.raises(CheckError, match="Unknown layer type"):
         LayerRegistry.CreateLayer(LayerParameter(type="Nope"))
     with pytest.raises(CheckError, match="already registered"):
