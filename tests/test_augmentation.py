@@ -436,3 +436,34 @@ def test_augmentation_layer_mirrors_draw_only_in_the_training_phase():
                               ([img], {}, "Need crop_width")]:
         with pytest.raises(CheckError, match=msg):
             LayerRegistry.CreateLayer(LayerParameter(type="GenerateAugmentationParameters", augmentation_param=apx)).SetUp(bottoms, [Blob(device="cpu")])
+
+
+def test_rng_generate_follows_caffe_rng_generate_semantics():
+    """rng.cpp:8-114: spread scaled by the schedule only with apply_schedule, zero spread returns the mean, exp after the draw,
+    *_bernoulli returns prob0_value untouched when the coin fails, discretize rounds, multiplier applies last."""
+    from flownet2_amd import augment as A
+    rng = np.random.default_rng(11)
+    g = lambda p, **k: A.rng_generate(rng, p, **k)
+    xs = np.array([g(dict(rand_type="uniform", mean=2.0, spread=0.5)) for _ in range(4000)])
+    assert 1.5 <= xs.min() < 1.55 and 2.45 < xs.max() <= 2.5 and abs(xs.mean() - 2.0) < 0.02
+    xs = np.array([g(dict(rand_type="uniform", mean=2.0, spread=0.5), discount=0.1) for _ in range(500)])
+    assert 1.95 <= xs.min() and xs.max() <= 2.05
+    xs = np.array([g(dict(rand_type="uniform", mean=2.0, spread=0.5, apply_schedule=False), discount=0.1) for _ in range(2000)])
+    assert xs.min() < 1.6 and xs.max() > 2.4
+    assert g(dict(rand_type="gaussian", mean=0.3, spread=0.0)) == np.float32(0.3) and g(dict(rand_type="uniform", mean=0.0, spread=0.0, exp=True)) == 1.0
+    xs = np.array([g(dict(rand_type="gaussian", mean=-1.0, spread=0.2)) for _ in range(4000)])
+    assert abs(xs.mean() + 1.0) < 0.02 and abs(xs.std() - 0.2) < 0.02
+    xs = np.array([g(dict(rand_type="gaussian", mean=0.0, spread=0.3, exp=True)) for _ in range(4000)])
+    assert xs.min() > 0 and abs(np.log(xs).mean()) < 0.03
+    bs = [g(dict(rand_type="bernoulli", prob=0.25), as_bool=True) for _ in range(4000)]
+    assert all(isinstance(b, bool) for b in bs) and abs(np.mean(bs) - 0.25) < 0.03
+    assert g(dict(rand_type="bernoulli", prob=0.0)) == 0.0
+    # the coin of *_bernoulli: failing returns prob0_value as is (no exp, no multiplier); without one it continues from 0
+    assert g(dict(rand_type="uniform_bernoulli", mean=5.0, spread=1.0, prob=0.0, exp=True, multiplier=3.0), prob0_value=1.0) == 1.0
+    assert g(dict(rand_type="gaussian_bernoulli", mean=5.0, spread=1.0, prob=0.0, exp=True, multiplier=3.0)) == 3.0       # exp(0) * 3
+    xs = np.array([g(dict(rand_type="uniform_bernoulli", mean=5.0, spread=1.0, prob=0.5), prob0_value=0.0) for _ in range(2000)])
+    assert abs((xs == 0).mean() - 0.5) < 0.05 and xs[xs != 0].min() >= 4.0
+    xs = np.array([g(dict(rand_type="uniform", mean=0.0, spread=3.0, discretize=True, multiplier=0.5)) for _ in range(500)])
+    assert np.all(np.abs(xs * 2 - np.round(xs * 2)) < 1e-6) and set(np.unique(xs)) <= {-1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5}
+    with pytest.raises(ValueError, match="Unknown random type"):
+        g(dict(rand_type="poisson"))
