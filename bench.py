@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="capture a forward step into a hipGraph and replay it (measured: no gain, the step is not launch-bound)")
     ap.add_argument("--conv-search", action="store_true", help="let MIOpen's find step time its candidate kernels during warm-up (measured: no gain for this net)")
     ap.add_argument("--corr-iters", type=int, default=200)
+    ap.add_argument("--bucket-mb", type=int, default=48, help="gradient all-reduce bucket size (train mode)")
     return ap.parse_args()
 
 
@@ -96,7 +97,7 @@ def corr_roofline(device, batch, h, w, iters):
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
     # calibrated -- profiles/rNN_rocprof_summary.md).  Counters cannot be read from inside this process, so
     # the figure comes from the newest committed profile of exactly this kernel and shape.
-    traffic, traffic_detail = None, None
+    traffic, traffic_detail, profiled = None, None, None
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_corr_hbm.json")), reverse=True):
         try:
@@ -105,13 +106,22 @@ def corr_roofline(device, batch, h, w, iters):
                 traffic = round(pj["traffic_bytes_per_launch"])
                 traffic_detail = {"unit": "bytes per launch", "source": "profiles/" + os.path.basename(f),
                                   "vs_algorithmic": round(pj["traffic_bytes_per_launch"] / alg_bytes, 3)}
+                # the same fraction from the committed rocprofv3 kernel trace (slower clocks under the profiler), and what the
+                # matrix pipes really executed: MFMA instructions x 2048 flop (products against the zero padding are skipped)
+                us = pj["avg_us_kernel_trace"]
+                profiled = {"source": "profiles/" + os.path.basename(f), "us_per_launch": round(us, 2),
+                            "frac": round(alg_flops / (us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                            "executed_flops_per_launch": pj.get("executed_flops_per_launch"),
+                            "frac_executed": round(pj["executed_flops_per_launch"] / (us * 1e-6) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if pj.get("executed_flops_per_launch") else None,
+                            "mfma_busy": round(pj["mfma_util"], 4) if pj.get("mfma_util") else None}
                 break
         except Exception:
             pass
     return {
         "kernel": "corr_fwd (K=1,md=20,s2=2) [%d,%d,%d,%d]" % (batch, C, H, W),
         "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
+        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "frac_profiled": profiled["frac"] if profiled else None, "profiled": profiled,
+        "traffic": traffic, "traffic_detail": traffic_detail,
         "us_per_launch": round(t * 1e6, 2), "us_per_launch_cold_caches": round(cold_us, 2),
         "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
         "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
@@ -148,8 +158,28 @@ def cpu_baseline(P_cpu, img0, img1, flow_gpu, budget_s=20.0):
                       f"(restated reference kernels, OpenMP) + torch-CPU fp32 conv; {os.cpu_count()} host cpus"}, epe
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run, one rank per GPU
+    (RCCL over xGMI), and pass its JSON line through.  Fails loudly when the box has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this box has {have} visible GPU(s); refusing to report a {n}-GPU number from fewer ranks")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -161,7 +191,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ranks_seen = parallel.ranks_seen(device)            # what RCCL actually connected (one all-reduce of ones)
+    if ranks_seen != world:
+        raise SystemExit(f"bench.py: all-reduce of ones returned {ranks_seen}, expected {world}")
 
     B, H, W = args.batch, args.height, args.width
     P_cpu = nets.init_params("C", seed=0) if args.net == "C" else nets.init_params_flownet2(seed=0)   # same weights on every rank
@@ -176,15 +210,17 @@ def main():
         gt = torch.randn(B, 2, H, W, device=device) * 5
         gt[torch.rand(B, 1, H, W, device=device).expand(-1, 2, -1, -1) < 0.05] = float("nan")
         parallel.broadcast_params(plist, src=0)
+        # the ONE exchange of the path: sum-all-reduce of the fp32 gradients (39.18 M floats = 156.7 MB) over RCCL, scaled by
+        # 1/world (parallel.cpp:377), in reverse-order buckets launched from gradient hooks while backward is still running;
+        # identical Adam step on every rank
+        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=args.bucket_mb << 20)
 
         def step():
-            opt.zero_grad(set_to_none=False)
+            exchange.zero_grad()
             pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
             loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], Fn), gt, Fn)
             loss.backward()
-            # the ONE exchange of the path: sum-all-reduce of the fp32 gradients (39.18 M floats = 156.7 MB, one
-            # bucket) over RCCL, scaled by 1/world (parallel.cpp:377); identical Adam step on every rank
-            parallel.allreduce_gradients(plist)
+            exchange.finish()
             opt.step()
             return loss
     else:
@@ -227,7 +263,7 @@ def main():
 
     if rank == 0:
         pairs = world * B * args.steps
-        conv_gf = nets.conv_flops("C", H, W) * B / 1e9
+        conv_gf = (nets.conv_flops("C", H, W) if args.net == "C" else nets.flownet2_conv_flops(H, W)) * B / 1e9
         res = {
             "metric": "image-pairs/sec " + ("FlowNetC " if args.net == "C" else "FlowNet2 (CSS+SD+fusion) ") + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
             "value": round(pairs / elapsed, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -238,7 +274,7 @@ def main():
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
                        "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
                        "conv_stack": "stem: own MFMA kernel; 3x3/2, small-map 3x3 and 4x4/2 deconvs: own im2col/col2im + library GEMM; other convolutions: MIOpen fp32 via torch (%.1f GFLOP/step/GPU)" % conv_gf,
-                       "launch": "hipGraph replay" if use_graph else "host launches"},
+                       "launch": "hipGraph replay" if use_graph else "host launches", "ranks_seen_by_rccl": ranks_seen},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
         if world == 1:

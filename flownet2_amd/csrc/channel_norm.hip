@@ -182,6 +182,8 @@ FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C
       return fail(FN2_ERR_LAUNCH, "downsample: hipMemcpyAsync failed");
     return FN2_OK;
   }
+  // a 1-pixel-high or -wide top makes the reference divide by zero (:104-105: scale = inf, radius = (int)ceil(inf) is undefined)
+  if (Hout < 2 || Wout < 2) return fail(FN2_ERR_INVALID_ARG, "downsample: top_height and top_width must be at least 2 when the size changes (downsample_layer.cu:104-105 divides by size - 1)");
   DownArgs a;
   a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
   a.widthScale = (float)(Win - 1) / (float)(Wout - 1);     // :104

@@ -716,7 +716,10 @@ class CustomDataLayer(Layer):
     def Forward_gpu(self, bottom, top):
         from . import sample_format as SF
         records = self._next_batch()
-        samples, shape, labels = _wrap(SF.stage_records, records, top[0].device)
+        # uint8 `data` records only (float_data Datums: sample_format.parse_datum + decode_batch(float_data=True)); the payload must
+        # hold every byte the slicing decodes
+        need = SF.sample_bytes(self.datum_channels_, self.datum_height_, self.datum_width_, self.slice_point_, self.channel_encoding_)
+        samples, shape, labels = _wrap(SF.stage_records, records, top[0].device, need)
         CHECK(shape == (self.datum_channels_, self.datum_height_, self.datum_width_), "records of different shapes in one database")
         if self.mean_host_ is not None and self.mean_ is None:
             self.mean_ = self.mean_host_.to(top[0].device)

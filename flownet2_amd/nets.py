@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 NEG_SLOPE = 0.1          # ReLU negative_slope of every FlowNet conv/deconv
 FLOW_SCALE = 20.0        # deploy multiplies predict_flow2 by 20 (training divides GT by 20)
+SD_FLOW_SCALE = 0.05     # FlowNet-SD predicts in units of 0.05 px: its deploy branch multiplies by 0.05 (released FlowNet2 graph; flownetsd_flow2 / div_flow in the third-party ports)
 LOSS_WEIGHTS = {6: 0.32, 5: 0.08, 4: 0.02, 3: 0.01, 2: 0.005}   # Appendix B (memory)
 
 # name: (kind, Cin, Cout, k, stride, pad)
@@ -303,6 +304,27 @@ _FUSE_TABLE = [("conv0", "conv", 11, 64, 3, 1, 1), ("conv1", "conv", 64, 64, 3, 
                ("interconv0", "conv", 82, 16, 3, 1, 1), ("Convolution7", "conv", 16, 2, 3, 1, 1)]
 
 
+_SD_RES = {"conv0": 1, "conv1": 2, "conv1_1": 2, "conv2": 4, "conv2_1": 4, "conv3": 8, "conv3_1": 8, "conv4": 16, "conv4_1": 16, "conv5": 32,
+           "conv5_1": 32, "conv6": 64, "conv6_1": 64, "Convolution1": 64, "deconv5": 32, "upsample_flow6to5": 32, "interconv5": 32,
+           "Convolution2": 32, "deconv4": 16, "upsample_flow5to4": 16, "interconv4": 16, "Convolution3": 16, "deconv3": 8,
+           "upsample_flow4to3": 8, "interconv3": 8, "Convolution4": 8, "deconv2": 4, "upsample_flow3to2": 4, "interconv2": 4, "Convolution5": 4}
+_FUSE_RES = {"conv0": 1, "conv1": 2, "conv1_1": 2, "conv2": 4, "conv2_1": 4, "Convolution5": 4, "deconv1": 2, "upsample_flow2to1": 2,
+             "interconv1": 2, "Convolution6": 2, "deconv0": 1, "upsample_flow1to0": 1, "interconv0": 1, "Convolution7": 1}
+
+
+def _table_flops(table, res, h, w):
+    fl = 0.0
+    for (name, k, ci, co, ks, s, p) in table:
+        oh, ow = h // res[name], w // res[name]          # output size of the layer (a deconv's input is half of it)
+        fl += 2.0 * (oh * ow * co * ci * ks * ks if k == "conv" else (oh // 2) * (ow // 2) * ci * co * ks * ks)
+    return fl
+
+
+def flownet2_conv_flops(h: int, w: int) -> float:
+    """Multiply-add flops of the conv / deconv layers of one full FlowNet2 forward (C + S + S + SD + fusion) per image pair."""
+    return conv_flops("C", h, w) + 2 * conv_flops("S", h, w, 12) + _table_flops(_SD_TABLE, _SD_RES, h, w) + _table_flops(_FUSE_TABLE, _FUSE_RES, h, w)
+
+
 def _init_table(table, prefix, g, params, device):
     for (name, k, ci, co, ks, s, p) in table:
         shape = (co, ci, ks, ks) if k == "conv" else (ci, co, ks, ks)
@@ -366,7 +388,7 @@ def flownet_sd_core(P, x, backend):
     cat3 = torch.cat([c3, _deconv(cat4, P, "deconv3", backend=backend), _up(P, flow4, "upsample_flow4to3", backend)], 1)
     flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False), "Convolution4", backend)
     cat2 = torch.cat([c2, _deconv(cat3, P, "deconv2", backend=backend), _up(P, flow3, "upsample_flow3to2", backend)], 1)
-    return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False), "Convolution5", backend)      # 1/4 resolution, units px/20? (SD: px/0.05)
+    return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False), "Convolution5", backend)      # 1/4 resolution, units of 1/SD_FLOW_SCALE px
 
 
 def fusion_core(P, x, backend):
@@ -407,7 +429,7 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     f2, w2, e2 = refine_input(flow2_q)
     flow3_q = flownet_s_core(_Prefixed(P, "net3_"), torch.cat([a, b, w2, f2 * (1.0 / FLOW_SCALE), e2], 1), backend)[2]
     flow_css = backend.resample(flow3_q * FLOW_SCALE, ah, aw, type=1)               # NEAREST into the fusion net (Appendix B)
-    flow_sd = backend.resample(flownet_sd_core(_Prefixed(P, "netsd_"), torch.cat([a, b], 1), backend) * 0.05 * FLOW_SCALE, ah, aw, type=1)
+    flow_sd = backend.resample(flownet_sd_core(_Prefixed(P, "netsd_"), torch.cat([a, b], 1), backend) * SD_FLOW_SCALE, ah, aw, type=1)
     err_css = backend.channel_norm(a - backend.flow_warp(b, flow_css))
     err_sd = backend.channel_norm(a - backend.flow_warp(b, flow_sd))
     fuse_in = torch.cat([a, flow_sd, flow_css, backend.channel_norm(flow_sd), backend.channel_norm(flow_css), err_sd, err_css], 1)

@@ -3,9 +3,11 @@ the CPU tests).  The hot path shards by image pair: infer
 needs exactly one exchange per step, the sum-all-reduce of the gradients.
 
 Replaces the reference's P2PSync (src/caffe/parallel.cpp:117-437): a hand-rolled CUDA peer-to-peer TREE with one host
-thread per GPU that broadcasts the flat weight buffer down the tree every iteration (:287-322), reduces the flat
-gradient buffer up the tree (:325-380), scales by 1/solver_count on the root (:377) and updates on the root only.
-Here every rank applies the same update after the all-reduce, so no weight broadcast is needed after the initial one.
+thread per GPU that broadcasts the flat weight buffer down the tree every iteration (on_start, :287-322), reduces the flat
+gradient buffer up the tree once the whole backward pass is over (on_gradients_ready, :325-380), scales by 1/solver_count
+on the root (:377) and updates on the root only.  Here every rank applies the same update after the all-reduce, so no weight
+broadcast is needed after the initial one, and the exchange is cut into buckets that leave while backward is still running
+(GradientExchange).
 """
 from __future__ import annotations
 
@@ -38,12 +40,92 @@ def broadcast_params(params: Iterable[torch.Tensor], src: int = 0) -> None:
         dist.broadcast(p.data, src)
 
 
-def allreduce_gradients(params: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20) -> None:
-    """Sum the gradients over ranks and scale by 1/world (parallel.cpp:377), in flat fp32 buckets.
+class GradientExchange:
+    """Bucketed sum-all-reduce of the fp32 gradients, overlapped with backward; result scaled by 1/world (parallel.cpp:377).
 
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound, so few large
-    buckets (default 256 MB: FlowNetC's 156.7 MB of gradients travel as ONE bucket) beat many small ones.
-    Gradients stay fp32 (parity with the reference)."""
+    * The parameters (given in forward order) are cut into flat fp32 buckets in REVERSE order -- backward produces the
+      decoder's gradients first -- and every parameter's `.grad` is a view into its bucket: no gather / scatter copies.
+    * A post-accumulate hook per parameter counts its bucket down; the last gradient of a bucket launches that bucket's
+      `all_reduce(async_op=True)`: with the "nccl" (= RCCL) backend it runs on the communicator's own HIP stream behind an
+      event on the compute stream, so the exchange of bucket k overlaps the backward kernels of buckets k+1...
+    * `finish()` (after `loss.backward()`) launches what has not been launched (parameters that got no gradient this step),
+      waits, and scales by 1/world.
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound and every collective pays a
+    fixed latency, so buckets are few and large (default 48 MB: FlowNetC's 156.7 MB travel as 4 buckets; the first leaves
+    after the decoder, ~25 % into backward).  Gradients stay fp32 (parity with the reference)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world()
+        self.buckets: List[dict] = []
+        cur, size = [], 0
+        for p in reversed(self.params):
+            nb = p.numel() * p.element_size()
+            if cur and size + nb > bucket_bytes:
+                self._close(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nb
+        if cur:
+            self._close(cur)
+        self._index = {}
+        self._handles = []
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._index[id(p)] = bi
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def _close(self, ps):
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.buckets.append({"params": ps, "flat": flat, "pending": len(ps), "work": None, "launched": False})
+
+    def reset(self):
+        for b in self.buckets:
+            b["pending"], b["work"], b["launched"] = len(b["params"]), None, False
+
+    def zero_grad(self):
+        """Zero the flat buckets (the gradients are views of them; `optimizer.zero_grad(set_to_none=True)` would cut the views)."""
+        for b in self.buckets:
+            b["flat"].zero_()
+        self.reset()
+
+    def _launch(self, b):
+        b["launched"] = True
+        if self.world > 1:
+            b["work"] = dist.all_reduce(b["flat"], async_op=True)
+
+    def _on_grad(self, p):
+        b = self.buckets[self._index[id(p)]]
+        b["pending"] -= 1
+        if b["pending"] == 0 and not b["launched"]:
+            self._launch(b)
+
+    def finish(self):
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        for b in self.buckets:
+            if b["work"] is not None:
+                b["work"].wait()
+                b["flat"].mul_(1.0 / self.world)
+        n = sum(1 for b in self.buckets if b["pending"] == 0)
+        self.reset()
+        return n           # buckets whose exchange was launched from inside backward
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+def allreduce_gradients(params: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20) -> None:
+    """Post-backward form of the exchange (no overlap): sum over ranks, scale by 1/world, in flat fp32 buckets."""
     w = world()
     if w == 1:
         return
@@ -78,3 +160,12 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
+
+
+def ranks_seen(device) -> int:
+    """One all-reduce of ones: the number of ranks the collective library actually connected."""
+    if world() == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t)
+    return int(round(float(t)))

@@ -145,7 +145,7 @@ def decode_batch(samples: torch.Tensor, channels: int, H: int, W: int, slice_poi
     return tops
 
 
-def stage_records(records: Sequence[bytes], device="cuda"):
+def stage_records(records: Sequence[bytes], device="cuda", expect_bytes: Optional[int] = None):
     """Parses a batch of LMDB values on the host (header walk only) and uploads their raw `data` payloads: returns (samples uint8
     [N, stride] on the device, the first Datum's (channels, H, W), labels).  All records must have the same shape (the layer CHECKs
     that, :545).  One host copy per record, from the record into the page-locked staging buffer (fn2_custom_data_stage_records)."""
@@ -157,6 +157,10 @@ def stage_records(records: Sequence[bytes], device="cuda"):
     ch, h, w, nb = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
     labels = (C.c_int * n)()
     check(L.fn2_custom_data_stage_records(ptrs, lens, n, None, 0, C.byref(ch), C.byref(h), C.byref(w), C.byref(nb), labels))
+    if expect_bytes is not None and nb.value < expect_bytes:
+        # a short payload would be decoded from whatever the reused staging buffer still holds behind it
+        raise _lib.Fn2Error(_lib.FN2_ERR_INVALID_ARG if hasattr(_lib, "FN2_ERR_INVALID_ARG") else 1,
+                            f"record holds {nb.value} data bytes, the slicing needs {expect_bytes} (custom_data_layer.cpp:86-136 reads them all)")
     stride = (nb.value + 15) // 16 * 16                         # keeps every sample 16-byte aligned
     host = _staging(n, stride)
     check(L.fn2_custom_data_stage_records(ptrs, lens, n, C.c_void_p(host.data_ptr()), stride, None, None, None, None, None))

@@ -14,14 +14,28 @@ import os
 import torch
 
 CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_gfx950.csv")
-_done = False
+_state = None          # None = not tried yet, True = table active, False = unavailable (cached: enable() runs once per layer call)
+_private = None
+
+
+def _cleanup():
+    if _private and os.path.exists(_private):
+        try:
+            os.unlink(_private)
+        except OSError:
+            pass
+
+
+def active() -> bool:
+    return bool(_state)
 
 
 def enable() -> bool:
     """Idempotent.  Returns True when the tuned selections are active."""
-    global _done
-    if _done:
-        return True
+    global _state, _private
+    if _state is not None:
+        return _state
+    _state = False
     if os.environ.get("FN2_NO_TUNED_GEMM") == "1" or not os.path.exists(CSV) or not torch.cuda.is_available():
         return False
     try:
@@ -30,15 +44,20 @@ def enable() -> bool:
             return False
         # TunableOp rewrites "its" file when the process exits: give every process a private copy, so that the table in the
         # tree is never touched and the ranks of a multi-GPU job do not write one file
+        import atexit
         import shutil
         import tempfile
-        private = os.path.join(tempfile.gettempdir(), "fn2_gemm_gfx950_%d.csv" % os.getpid())
+        fd, private = tempfile.mkstemp(prefix="fn2_gemm_gfx950_", suffix=".csv")
+        os.close(fd)
         shutil.copyfile(CSV, private)
+        _private = private
         tn.enable(True)
         tn.tuning_enable(False)
         tn.set_filename(private, insert_device_ordinal=False)
         tn.read_file(private)
-        _done = True
+        tn.write_file_on_exit(False)    # look-up only: nothing to record, and the private copy can go at exit
+        atexit.register(_cleanup)
+        _state = True
     except Exception:                                               # TunableOp unavailable in this torch build: library defaults
         return False
     return True

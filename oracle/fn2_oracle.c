@@ -781,6 +781,7 @@ FN2_API int fn2_downsample_forward_cpu(const float* bottom, float* top, int N, i
     memcpy(top, bottom, sizeof(float) * (size_t)N * C * Hin * Win);
     return FN2_OK;
   }
+  if (Hout < 2 || Wout < 2) return FN2_ERR_INVALID_ARG;              /* :104-105 divide by size - 1: inf scale, undefined radius */
   const float widthScale = (float)(Win - 1) / (float)(Wout - 1);      /* :104 */
   const float heightScale = (float)(Hin - 1) / (float)(Hout - 1);     /* :105 */
   const int wradius = (int)ceilf(widthScale), hradius = (int)ceilf(heightScale);   /* :107-108 */

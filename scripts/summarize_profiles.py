@@ -125,6 +125,8 @@ summary = {"tag": tag, "kernel": "corr_fwd_pair<10> [8,256,40,56]", "avg_us_kern
            "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "fetch_correction": fetch_factor,
            "write_correction": write_factor, "hbm_read_bytes": fetch_bytes, "hbm_write_bytes": write_bytes,
            "traffic_bytes_per_launch": fetch_bytes + write_bytes, "algorithmic_bytes_per_launch": alg,
-           "mfma_util": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui) if gui else None}
+           "mfma_util": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui) if gui else None,
+           "sq_insts_mfma": sq.get("SQ_INSTS_MFMA"), "executed_flops_per_launch": sq.get("SQ_INSTS_MFMA", 0.0) * 2048.0,
+           "source": "profiles/%s_rocprof_summary.md (kernel-trace avg; --pmc passes of their own)" % tag}
 json.dump(summary, open(os.path.join(OUT, f"{tag}_corr_hbm.json"), "w"), indent=1)
 print(open(os.path.join(OUT, f"{tag}_rocprof_summary.md")).read()[:6000])

@@ -211,3 +211,83 @@ def test_reference_stock_layers_pin_the_fast_paths():
     nob = ref.convolution(x, w, None, kernel=3, stride=1, pad=1)
     close(hv(ops.bias_leaky_relu_(dv(nob), dv(b), 0.1)), ref.convolution(x, w, b, kernel=3, stride=1, pad=1, relu=True), 1e-6, "bias + ReLU")
     close(oracle.bias_leaky_relu_forward(nob, b, 0.1), ref.convolution(x, w, b, kernel=3, stride=1, pad=1, relu=True), 1e-6, "bias + ReLU oracle")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json sizes, element by element against the reference's own kernels (oracle/_ref runs them on the same GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _maxerr(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(8, 256, 40, 56), (4, 256, 48, 96), (1, 256, 56, 128)])
+def test_reference_gpu_correlation_at_baseline_shapes(shape):
+    """All 441 displacement channels and both bottom diffs at the conv3 shapes of BASELINE.json's configs (FlowNetC batch 8
+    @448x320, FlowNet2 batch 4 @768x384, batch 1 @1024x448) -- correlation_layer.cu:431-603 executed here vs the MFMA kernels."""
+    import torch
+    from flownet2_amd import ops
+    N, C, H, W = shape
+    b0, b1 = rnd(shape, 50), rnd(shape, 51)
+    top = ref.correlation(b0, b1, 20, 1, 20, 1, 2, 0)
+    assert top.shape == (N, 441, H, W)
+    td = rnd(top.shape, 52)
+    _, d0, d1 = ref.correlation(b0, b1, 20, 1, 20, 1, 2, 0, td)
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    mine = ops.correlation_forward(p, dv(b0), dv(b1)).cpu().numpy()
+    s = max(1.0, float(np.abs(top).max()))
+    assert _maxerr(mine, top) <= 2e-6 * s
+    h0, h1 = ops.correlation_backward(p, dv(b0), dv(b1), dv(td))
+    for mine_d, want in ((h0, d0), (h1, d1)):
+        sd = max(1.0, float(np.abs(want).max()))
+        assert _maxerr(mine_d.cpu().numpy(), want) <= 3e-6 * sd
+
+
+@pytest.mark.gpu
+def test_reference_gpu_flow_warp_resample_at_baseline_shapes():
+    """FlowWarp at the FlowNet2 refinement size [4,3,384,768] (smooth + rough flow, forward and both diffs) and Resample
+    [4,2,96,192] -> [384,768] (LINEAR x4 and NEAREST), flow_warp_layer.cu:357-514 / resample_layer.cu:128-206 executed here."""
+    import torch
+    from flownet2_amd import ops
+    dv = lambda a: torch.from_numpy(a).cuda()
+    N, C, H, W = 4, 3, 384, 768
+    img, g = rnd((N, C, H, W), 60), rnd((N, C, H, W), 61)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    smooth = np.stack([6 * np.sin(yy / 37) + 3 * np.cos(xx / 53), 5 * np.cos(yy / 41) - 4 * np.sin(xx / 29)])[None].repeat(N, 0).astype(np.float32)
+    for flow in (smooth, rnd((N, 2, H, W), 62, 8.0)):
+        out, di, df = ref.flow_warp(img, flow, 1, g)
+        assert _maxerr(ops.flow_warp_forward(dv(img), dv(flow), 1).cpu().numpy(), out) <= 1e-6 * max(1.0, float(np.abs(out).max()))
+        hi, hf = ops.flow_warp_backward(dv(img), dv(flow), dv(g))
+        # the reference accumulates the image gradient with float atomics in arrival order: compare at the summation-order tolerance
+        assert _maxerr(hi.cpu().numpy(), di) <= 2e-5 * max(1.0, float(np.abs(di).max()))
+        assert _maxerr(hf.cpu().numpy(), df) <= 1e-5 * max(1.0, float(np.abs(df).max()))
+    x = rnd((4, 2, 96, 192), 63, 4.0)
+    for t in (1, 2):            # NEAREST, LINEAR
+        want = ref.resample(x, 384, 768, t, True)
+        assert _maxerr(ops.resample_forward(dv(x), 384, 768, t, True).cpu().numpy(), want) <= 1e-6 * max(1.0, float(np.abs(want).max()))
+    x = rnd((8, 2, 80, 112), 64, 4.0)                       # FlowNetC deploy tail: [8,2,80,112] -> [320,448]
+    want = ref.resample(x, 320, 448, 2, True)
+    assert _maxerr(ops.resample_forward(dv(x), 320, 448, 2, True).cpu().numpy(), want) <= 1e-6 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)])
+def test_reference_gpu_l1loss_at_training_scales(hw):
+    """L1Loss{l2_per_location, normalize_by_num_entries} at the five prediction scales of a FlowNetC training step (batch 8
+    @448x320), NaN-masked ground truth: loss and both diffs vs the reference's L1LossLayer (l1loss_layer.cu:67-190)."""
+    import torch
+    from flownet2_amd import ops
+    shape = (8, 2) + hw
+    b0, b1 = rnd(shape, 70, 2.0), rnd(shape, 71, 2.0)
+    m = np.random.default_rng(72).random((8, 1) + hw) < 0.07
+    b1[np.broadcast_to(m, shape)] = np.nan
+    cfg = dict(l2_per_location=True, normalize_by_num_entries=True)
+    loss, weighted, d0, d1 = ref.l1loss(b0, b1, loss_weight=0.32, **cfg)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    p = ops.l1_params(**cfg)
+    hl, ws = ops.l1loss_forward(p, dv(b0), dv(b1))
+    assert abs(float(hl) - loss) <= 2e-6 * max(1.0, abs(loss))
+    h0, h1 = ops.l1loss_backward(p, dv(b0), dv(b1), 0.32, ws)
+    assert _maxerr(h0.cpu().numpy(), d0) <= 2e-6
+    assert _maxerr(h1.cpu().numpy(), d1) <= 2e-6
