@@ -23,6 +23,8 @@ EXPORTS = [
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward",
     "fn2_bias_leaky_relu_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
+    "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
+    "fn2_conv_mfma_num_variants", "fn2_debug_set_conv_variant",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
@@ -108,6 +110,12 @@ def lib():
     L.fn2_im2col_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, vp]
     L.fn2_col2im_bias_relu_forward.argtypes = [fp, fp, fp, i, i, i, i, i, i, i, i, C.c_float, vp]
     L.fn2_conv_k7s2_relu_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, i, C.c_float, vp]
+    L.fn2_conv_mfma_supported.argtypes = [i] * 7
+    L.fn2_conv_mfma_packed_floats.argtypes = [i, i, i]
+    L.fn2_conv_mfma_packed_floats.restype = sz
+    L.fn2_conv_mfma_pack_weights.argtypes = [fp, fp, i, i, i, vp]
+    L.fn2_conv_mfma_forward.argtypes = [fp, fp, fp, fp] + [i] * 13 + [C.c_float, vp]
+    L.fn2_debug_set_conv_variant.argtypes = [i]
     ip = C.POINTER(C.c_int)
     L.fn2_datum_parse.argtypes = [vp, sz, C.POINTER(DatumView)]
     L.fn2_datum_float_data.argtypes = [vp, sz, fp, sz]

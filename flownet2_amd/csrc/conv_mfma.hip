@@ -1,0 +1,361 @@
+// Direct convolution (Convolution{kernel_size KS, stride S, pad} + bias + ReLU{negative_slope}) of the FlowNet encoders on
+// v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation in k order (bit-identical to an fmaf chain).
+//
+// Reference: ConvolutionLayer::Forward_gpu (src/caffe/layers/conv_layer.cu:8-23: per SAMPLE im2col_gpu + cublasSgemm, then
+// forward_gpu_bias -- base_conv_layer.cpp:326-348) followed by the in-place ReLU layer (relu_layer.cu:8-27).  Here: one
+// launch per layer for the whole mini-batch, no column matrix, NCHW in and out (no layout transposes), bias and activation in
+// the epilogue, optional channel slices on both blobs (a consumer's concat blob can be written in place).
+//
+// GEMM view.  Output pixels are cut into 4x4 PATCHES (one MFMA M tile: 16 pixels), output channels into groups of 16 (one N
+// tile); K = (channel quad cq, ky, kx) k-steps, the 4 k values of a k-step being the 4 channels of the quad -- so that the
+// pixel operand of tap (ky, kx) for lane (pixel p, kq) is ONE ds_read_b32 at  lane_base + immediate  from a window of the
+// input staged in its natural [channel][row][column] order:
+//     address = [kq * CS + (py * S) * RS + px * S]  +  [cq * 4 * CS + ky * RS + kx + 4 * S * patch]
+//   * pixel operand: the input window of a workgroup tile, CQ channel quads at a time, arrives by 16-byte LDS-DMA
+//     (buffer_load_dwordx4 ... lds) straight from NCHW; rows / columns outside the image and channels beyond Cin are
+//     out-of-range for the buffer descriptor and come back 0.0f = the zero padding.  Two window buffers, one barrier per chunk.
+//     RS == 4 (mod 16) and CS == 16 (mod 32) make the stride-1 reads conflict-free (stride 2: 2-way, the odd banks idle).
+//   * weight operand: pre-packed once per weight blob (fn2_conv_mfma_pack_weights) as [Cout/64][k-step][lane][4]: lane
+//     (co, kq) holds W[64 g + 16 j + co][4 cq + kq][ky][kx] for j = 0..3, so a wave's operand for a k-step is ONE coalesced
+//     global_load_dwordx{MW} per lane straight into registers, prefetched NBUFA - 1 k-steps ahead; no LDS for weights.
+//   * wave tile = MW channel groups x NP patches (MW * NP accumulator tiles), workgroup = WM x WNX x WNY waves.
+//   * epilogue: the MFMA result layout hands every lane 4 consecutive x of one output channel: bias + leaky ReLU + 16-byte store.
+#include "fn2_common.hpp"
+
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
+
+namespace fn2 {
+namespace cv {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int up_mod(int v, int r, int m) { return v + ((r - v % m) + m) % m; }   // smallest >= v with == r (mod m)
+
+struct Args {
+  const float* in; const float* wp; const float* bias; float* out;
+  int N, Cin, Hin, Win, in_ctot, in_c0;
+  int Cout, Hout, Wout, out_ctot, out_c0;
+  int pad;
+  int nchunks;        // chunks of CQ channel quads
+  int ksteps;         // k-steps of the packed weights per 64-channel group (= quads * KS * KS), multiple of the chunk length
+  int tx, ty;         // workgroup tiles per sample along x / y
+  int ng;             // Cout / (16 * MW * WM)
+  unsigned total;     // workgroups with work
+  float slope; int relu;
+};
+
+template <int KS_, int S_, int MW_, int NP_, int WM_, int WNX_, int WNY_, int CQ_>
+struct Cfg {
+  static constexpr int KS = KS_, S = S_, MW = MW_, NP = NP_, WM = WM_, WNX = WNX_, WNY = WNY_, CQ = CQ_;
+  static constexpr int NW = WM * WNX * WNY, THREADS = 64 * NW;
+  static constexpr int PADL = 4;                                     // window columns left of S * x0 (16-byte aligned start)
+  static constexpr int TW = 4 * NP * WNX, TH = 4 * WNY;              // output pixels of a workgroup tile
+  static constexpr int WR = (TH - 1) * S + KS;                       // window rows per channel
+  static constexpr int WC = (TW - 1) * S + KS + PADL;                // window columns incl. the left margin (pad <= PADL)
+  static constexpr int RS = up_mod(cdiv(WC, 4) * 4, 4, 16);          // row stride (dwords)
+  static constexpr int CS = up_mod(WR * RS, 16, 32);                 // channel stride
+  static constexpr int SLOTS_C = CS / 4;                             // 16-byte slots per channel
+  static constexpr int SLOTS = 4 * CQ * SLOTS_C;                     // per chunk
+  static constexpr int NRUN = cdiv(SLOTS, 64);                       // 1 KiB LDS-DMA runs per chunk
+  static constexpr int RPW = cdiv(NRUN, NW);                         // runs per wave
+  static constexpr int BUF = NRUN * 256;                             // dwords per window buffer (whole runs)
+  static constexpr int KSC = CQ * KS * KS;                           // k-steps per chunk
+  static constexpr int NBUFA = (KSC % 6 == 0) ? 6 : (KSC % 5 == 0) ? 5 : (KSC % 4 == 0) ? 4 : 3;   // weight-operand ring
+  static_assert(KSC % NBUFA == 0, "ring phase must repeat per chunk");
+  static_assert(2 * BUF * 4 <= 160 * 1024, "LDS");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MW> struct WVec;
+template <> struct WVec<1> { using T = float; };
+template <> struct WVec<2> { using T = f32x2; };
+template <> struct WVec<4> { using T = f32x4; };
+
+template <int MW>
+__device__ __forceinline__ float wget(const typename WVec<MW>::T& v, int j) {
+  if constexpr (MW == 1) return v; else return v[j];
+}
+
+// LDS-DMA of one chunk's window: run r = i * NW + wave -> 1 KiB at dst + 1024 r (a __device__ function, not a lambda: the
+// host pass of a __global__ template cannot see the amdgcn builtins inside a lambda body)
+template <class K>
+__device__ __forceinline__ void stage_chunk(__amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[K::RPW], unsigned dst, int wave, unsigned soff) {
+#pragma unroll
+  for (int i = 0; i < K::RPW; ++i) {
+    const int r = i * K::NW + wave;
+    if (r < K::NRUN)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)r), 16, voff[i], soff, 0, 0);
+  }
+}
+
+template <class K>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma(Args a) {
+  static_assert(K::THREADS == 256, "launch bounds");
+  constexpr int KS = K::KS, S = K::S, MW = K::MW, NP = K::NP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % K::WM, wnx = (wave / K::WM) % K::WNX, wny = wave / (K::WM * K::WNX);
+
+  // ---- task: XCD-contiguous ranges of the (sample, tile row, tile column, channel group) list, channel group fastest:
+  // the workgroups that share an input window run next to each other on one XCD (its L2 serves the re-reads)
+  const unsigned per_xcd = (a.total + 7) / 8;
+  unsigned t = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= per_xcd || t >= a.total) return;
+  const int g = t % a.ng; t /= a.ng;
+  const int bx = t % a.tx; t /= a.tx;
+  const int by = t % a.ty;
+  const int n = t / a.ty;
+  const int x0 = bx * K::TW, y0 = by * K::TH;
+
+  // ---- LDS-DMA plan: run r = i * NW + wave, slot s = 64 r + lane -> (channel, window row, group of 4 columns)
+  const size_t plane = (size_t)a.Hin * a.Win;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + ((size_t)n * a.in_ctot + a.in_c0) * plane), 0, (unsigned)(4u * a.Cin * plane), 0x00020000);
+  constexpr unsigned OOB = 0x7ffffff0u;
+  unsigned voff[K::RPW];
+#pragma unroll
+  for (int i = 0; i < K::RPW; ++i) {
+    const int s = (i * K::NW + wave) * 64 + lane;
+    voff[i] = OOB;
+    if (s < K::SLOTS) {
+      const int c = s / K::SLOTS_C, rem = s % K::SLOTS_C;
+      const int row = rem / (K::RS / 4), gq = rem % (K::RS / 4);
+      const int yi = S * y0 - a.pad + row, xi = S * x0 - K::PADL + 4 * gq;
+      if (row < K::WR && 4 * gq < K::WC && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win)
+        voff[i] = 4u * (unsigned)(c * plane + (size_t)yi * a.Win + xi);
+    }
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  const unsigned chunk_bytes = 4u * 4u * K::CQ * (unsigned)plane;
+  auto stage = [&](int chunk, int buf) { stage_chunk<K>(rs, voff, lds_base + 4u * (unsigned)(buf * K::BUF), wave, (unsigned)chunk * chunk_bytes); };
+
+  // ---- operands
+  const int kq = lane >> 4, p16 = lane & 15, py = p16 >> 2, px = p16 & 3;
+  const int bbase = kq * K::CS + (S * (4 * wny + py)) * K::RS + S * (4 * NP * wnx + px) + K::PADL - a.pad;
+  using WV = typename WVec<MW>::T;
+  // packed weights: [Cout/64][ksteps][64 lanes][4]; this wave's channel groups: 16 * MW * (g * WM + wm) ...
+  const int cg0 = (g * K::WM + wm) * MW;                      // first 16-channel group of this wave
+  const float* wl = a.wp + ((size_t)(cg0 / 4) * a.ksteps * 64 + lane) * 4 + (cg0 % 4);
+  auto wload = [&](int ks) -> WV { return *reinterpret_cast<const WV*>(wl + (size_t)ks * 256); };
+
+  f32x4 acc[MW][NP];
+#pragma unroll
+  for (int j = 0; j < MW; ++j)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  WV wreg[K::NBUFA];
+  stage(0, 0);
+#pragma unroll
+  for (int i = 0; i < K::NBUFA - 1; ++i) wreg[i] = wload(i);
+
+  for (int c = 0; c < a.nchunks; ++c) {
+    const int buf = c & 1;
+    // everything this wave has in flight up to here: the window of chunk c and the weight prefetch; wait for all of it (the
+    // weight loads are NBUFA - 1 k-steps old), then publish
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (c + 1 < a.nchunks) stage(c + 1, buf ^ 1);
+    const float* win = smem + buf * K::BUF + bbase;
+    const int ks0 = c * K::KSC;
+#pragma unroll
+    for (int ks = 0; ks < K::KSC; ++ks) {
+      wreg[(ks + K::NBUFA - 1) % K::NBUFA] = wload(ks0 + ks + K::NBUFA - 1);      // the packed array carries NBUFA spare k-steps
+      const int cq = ks / (KS * KS), ky = (ks / KS) % KS, kx = ks % KS;
+      float b[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) b[p] = win[cq * 4 * K::CS + ky * K::RS + kx + 4 * S * p];
+      const WV w = wreg[ks % K::NBUFA];
+#pragma unroll
+      for (int j = 0; j < MW; ++j)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[p], wget<MW>(w, j), acc[j][p], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane (row block = lane >> 4, channel = lane & 15) holds 4 consecutive x of output row y0 + 4 wny + (lane >> 4)
+  const int y = y0 + 4 * wny + (lane >> 4);
+  if (y < a.Hout) {
+#pragma unroll
+    for (int j = 0; j < MW; ++j) {
+      const int co = 16 * (cg0 + j) + (lane & 15);
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      float* orow = a.out + (((size_t)n * a.out_ctot + a.out_c0 + co) * a.Hout + y) * a.Wout;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int x = x0 + 4 * (NP * wnx + p);
+        f32x4 v = acc[j][p];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = v[r] + bv;
+          if (a.relu) s = s > 0.f ? s : s * a.slope;
+          v[r] = s;
+        }
+        if (x + 3 < a.Wout) *reinterpret_cast<f32x4*>(orow + x) = v;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (x + r < a.Wout) orow[x + r] = v[r];
+        }
+      }
+    }
+  }
+}
+
+// weight [Cout][Cin][KS][KS] -> packed [Cout/64][ksteps + spare][64][4]
+__global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS, int ksteps, int kalloc) {
+  const long long total = (long long)(Cout / 64) * kalloc * 256;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long long r = i >> 8;
+    const int ks = (int)(r % kalloc), grp = (int)(r / kalloc);
+    const int co = 64 * grp + 16 * j + (lane & 15), kq = lane >> 4;
+    const int cq = ks / (KS * KS), tap = ks % (KS * KS);
+    const int ci = 4 * cq + kq;
+    float v = 0.f;
+    if (ks < ksteps && ci < Cin) v = w[((size_t)co * Cin + ci) * KS * KS + tap];
+    wp[i] = v;
+  }
+}
+
+constexpr int kSpare = 8;          // spare (zero) k-steps behind every group: the weight prefetch runs NBUFA - 1 k-steps ahead
+constexpr int kChunkQuads = 2;     // k-steps are padded to a whole number of chunks of at most this many channel quads
+
+inline int ksteps_for(int Cin, int KS) { return cdiv(cdiv(Cin, 4), kChunkQuads) * kChunkQuads * KS * KS; }
+
+template <class K>
+static int launch(const Args& base, hipStream_t st) {
+  Args a = base;
+  a.tx = cdiv(a.Wout, K::TW); a.ty = cdiv(a.Hout, K::TH);
+  a.ng = a.Cout / (16 * K::MW * K::WM);
+  a.nchunks = cdiv(cdiv(a.Cin, 4), K::CQ);
+  const long long total = (long long)a.N * a.tx * a.ty * a.ng;
+  if (total > 0x7fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: grid too large");
+  a.total = (unsigned)total;
+  const unsigned grid = 8 * ((a.total + 7) / 8);
+  constexpr size_t lds = sizeof(float) * 2 * K::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_mfma<K>), dim3(grid), dim3(K::THREADS), lds, st, a);
+  return check_launch("conv_mfma_forward");
+}
+
+struct Variant {
+  int ks, s, mw, np, wm, wnx, wny;
+  int (*fn)(const Args&, hipStream_t);
+};
+
+// X-macro list of the tile variants: (KS, S, MW, NP, WM, WNX, WNY, CQ)
+#define FN2_CV_LIST(X) \
+  /* 3x3 stride 1 */ \
+  X(3, 1, 2, 7, 2, 2, 1, 2) X(3, 1, 2, 7, 2, 1, 2, 2) X(3, 1, 4, 7, 1, 2, 2, 2) X(3, 1, 4, 7, 1, 1, 4, 2) \
+  X(3, 1, 2, 6, 2, 2, 1, 2) X(3, 1, 4, 6, 1, 2, 2, 2) X(3, 1, 4, 4, 1, 2, 2, 2) X(3, 1, 2, 4, 2, 2, 1, 2) \
+  /* 3x3 stride 2 */ \
+  X(3, 2, 2, 7, 2, 1, 2, 2) X(3, 2, 4, 7, 1, 1, 4, 2) X(3, 2, 2, 6, 2, 2, 1, 2) X(3, 2, 4, 6, 1, 2, 2, 2) X(3, 2, 2, 4, 2, 2, 1, 2) \
+  /* 5x5 stride 2 */ \
+  X(5, 2, 2, 7, 2, 2, 1, 1) X(5, 2, 2, 7, 2, 1, 2, 1) X(5, 2, 4, 7, 1, 2, 2, 1) X(5, 2, 4, 7, 1, 1, 4, 1) \
+  X(5, 2, 2, 6, 2, 2, 1, 1) X(5, 2, 4, 6, 1, 2, 2, 1) X(5, 2, 4, 4, 1, 2, 2, 1)
+
+#define FN2_CV_ROW(KS, S, MW, NP, WM, WNX, WNY, CQ) {KS, S, MW, NP, WM, WNX, WNY, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>>},
+static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+int g_forced_variant = -1;
+
+// cost model: rounds of workgroups over 256 CUs x (accumulator tiles of a workgroup, incl. those hanging over the image edge)
+static double variant_cost(const Variant& v, const Args& a) {
+  const int tw = 4 * v.np * v.wnx, th = 4 * v.wny;
+  const long long wgs = (long long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * (a.Cout / (16 * v.mw * v.wm));
+  const double per_cu = (double)((wgs + 255) / 256);
+  const double units = (double)v.mw * v.np;                         // accumulator tiles per wave
+  // small wave tiles pay more operand traffic per MFMA: mild penalty
+  const double eff = 1.0 / (1.0 + 0.08 * (4.0 / v.mw - 1.0) + 0.02 * (7.0 / v.np - 1.0));
+  return per_cu * units / eff;
+}
+
+static bool variant_applies(const Variant& v, const Args& a, int KS, int S) {
+  return v.ks == KS && v.s == S && a.Cout % (16 * v.mw * v.wm) == 0;
+}
+
+}  // namespace cv
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API size_t fn2_conv_mfma_packed_floats(int Cout, int Cin, int kernel) {
+  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || kernel <= 0) return 0;
+  return (size_t)(Cout / 64) * (cv::ksteps_for(Cin, kernel) + cv::kSpare) * 256;
+}
+
+FN2_API int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int Cout, int Cin, int kernel, void* stream) {
+  if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights: null blob");
+  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 5))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights: needs Cout %% 64 == 0 and kernel_size 3 or 5 (got Cout %d, kernel %d)", Cout, kernel);
+  const int ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare;
+  const long long total = (long long)(Cout / 64) * kalloc * 256;
+  hipLaunchKernelGGL(cv::pack_weights, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), weight, packed, Cout, Cin, kernel, ksteps, kalloc);
+  return check_launch("conv_mfma_pack_weights");
+}
+
+FN2_API int fn2_conv_mfma_supported(int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
+  if (Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 64 != 0 || Win % 4 != 0) return 0;
+  if (!((kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 5 && stride == 2))) return 0;
+  if (pad < 0 || pad > 4 || pad > kernel - 1) return 0;
+  if ((long long)Cin * Hin * Win >= (1ll << 28)) return 0;
+  const int Hout = (Hin + 2 * pad - kernel) / stride + 1, Wout = (Win + 2 * pad - kernel) / stride + 1;
+  return Hout >= 1 && Wout >= 1;
+}
+
+FN2_API int fn2_debug_set_conv_variant(int v) { cv::g_forced_variant = v; return FN2_OK; }
+FN2_API int fn2_conv_mfma_num_variants(void) { return cv::kNumVariants; }
+
+FN2_API int fn2_conv_mfma_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                                  int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                  int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
+                                  int relu, float negative_slope, void* stream) {
+  if (N < 0) return fail(FN2_ERR_INVALID_ARG, "conv_mfma: bad batch");
+  if (N == 0) return FN2_OK;
+  if (!bottom || !packed_weight || !top) return fail(FN2_ERR_INVALID_ARG, "conv_mfma: null blob");
+  if (!fn2_conv_mfma_supported(Cin, Hin, Win, Cout, kernel, stride, pad))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: unsupported geometry (Cin %d, %dx%d, Cout %d, k %d s %d p %d)", Cin, Hin, Win, Cout, kernel, stride, pad);
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels)
+    return fail(FN2_ERR_INVALID_ARG, "conv_mfma: channel slice outside the blob");
+  if (((reinterpret_cast<uintptr_t>(bottom) | reinterpret_cast<uintptr_t>(top) | reinterpret_cast<uintptr_t>(packed_weight)) & 15) != 0)
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: blobs must be 16-byte aligned");
+  cv::Args a{};
+  a.in = bottom; a.wp = packed_weight; a.bias = bias; a.out = top;
+  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.in_ctot = bottom_channels; a.in_c0 = bottom_c0;
+  a.Cout = Cout; a.Hout = (Hin + 2 * pad - kernel) / stride + 1; a.Wout = (Win + 2 * pad - kernel) / stride + 1;
+  a.out_ctot = top_channels; a.out_c0 = top_c0; a.pad = pad;
+  a.ksteps = cv::ksteps_for(Cin, kernel) + cv::kSpare;
+  a.slope = negative_slope; a.relu = relu;
+  if ((a.Wout % 4) != 0 && ((size_t)a.Wout * sizeof(float)) % 16 != 0) { /* scalar tail stores handle it */ }
+  int best = -1;
+  if (cv::g_forced_variant >= 0) {
+    if (cv::g_forced_variant >= cv::kNumVariants || !cv::variant_applies(cv::kVariants[cv::g_forced_variant], a, kernel, stride))
+      return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: forced variant %d does not apply", cv::g_forced_variant);
+    best = cv::g_forced_variant;
+  } else {
+    double bc = 0;
+    for (int i = 0; i < cv::kNumVariants; ++i) {
+      if (!cv::variant_applies(cv::kVariants[i], a, kernel, stride)) continue;
+      const double c = cv::variant_cost(cv::kVariants[i], a);
+      if (best < 0 || c < bc) { best = i; bc = c; }
+    }
+  }
+  if (best < 0) return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: no kernel variant for this geometry");
+  return cv::kVariants[best].fn(a, as_stream(stream));
+}

@@ -6,6 +6,8 @@ reference, resample_layer.hpp:25, downsample_layer.hpp:30) return no gradient.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -150,6 +152,43 @@ def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
     if not ops.conv_k7s2_relu_supported(x.shape[1], x.shape[2], x.shape[3], weight.shape[0]):
         return None
     return ops.conv_k7s2_relu_forward(x.contiguous(), weight.contiguous(), bias, negative_slope)
+
+
+_PACKED = {}     # id(weight tensor) -> (weak reference, _version, packed copy): one repack per weight update, not per forward
+
+
+def _packed_conv_weight(w):
+    import weakref
+    key = id(w)
+    hit = _PACKED.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        hit = (weakref.ref(w, lambda _r, k=key: _PACKED.pop(k, None)), w._version, ops.conv_mfma_pack_weights(w.detach()))
+        _PACKED[key] = hit
+    return hit[2]
+
+
+def _mfma_conv_enabled(kernel, stride):
+    """FN2_CONV_MFMA: "all" (default), "none", or a comma list of k<kernel>s<stride> classes, e.g. "k5s2,k3s1"."""
+    sel = os.environ.get("FN2_CONV_MFMA", "all")
+    return sel in ("all", "force") or (sel != "none" and ("k%ds%d" % (kernel, stride)) in sel.split(","))
+
+
+def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
+    """Convolution + bias (+ leaky ReLU) as ONE direct MFMA kernel (csrc/conv_mfma.hip), NCHW in and out, optionally written into
+    a channel slice of `out`.  Returns None when the kernel does not apply (autograd needed, unsupported geometry, disabled):
+    the caller then runs the library convolution."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return None
+    Cout, Cin, k, _ = weight.shape
+    if not x.is_cuda or not _mfma_conv_enabled(k, stride) or not ops.conv_mfma_supported(Cin, x.shape[2], x.shape[3], Cout, k, stride, pad):
+        return None
+    # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
+    # large enough to run the matrix pipes efficiently, and the library's GEMM route wins (scripts/conv_bench.py, profiles/)
+    Ho, Wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
+    if x.shape[0] * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and os.environ.get("FN2_CONV_MFMA", "") != "force":
+        return None
+    return ops.conv_mfma_forward(x.contiguous(), _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
+                                 out=out, out_c0=out_c0)
 
 
 def _no_grad_needed(*ts):

@@ -80,6 +80,10 @@ def _conv(x, P, name, stride, pad, act=True, backend=None):
         y = backend.conv_k7s2_relu(x, w, P[name + ".b"], NEG_SLOPE)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
         if y is not None:
             return y
+    if w.shape[2] in (3, 5) and backend is not None and hasattr(backend, "conv_mfma_relu"):
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)    # direct MFMA convolution, bias + ReLU fused (csrc/conv_mfma.hip)
+        if y is not None:
+            return y
     if act and w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
         y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE)
         if y is not None:

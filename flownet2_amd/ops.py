@@ -254,6 +254,50 @@ def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
     return out
 
 
+def conv_mfma_supported(Cin, Hin, Win, Cout, kernel, stride, pad) -> bool:
+    return bool(_lib.lib().fn2_conv_mfma_supported(int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad)))
+
+
+def conv_mfma_pack_weights(weight):
+    """weight [Cout, Cin, k, k] -> the MFMA operand order fn2_conv_mfma_forward reads (once per weight update)."""
+    w = _chk(weight, "weight")
+    Cout, Cin, k, k2 = w.shape
+    n = _lib.lib().fn2_conv_mfma_packed_floats(Cout, Cin, k)
+    if k != k2 or n == 0:
+        raise ValueError(f"conv_mfma: unsupported weight shape {tuple(w.shape)}")
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().fn2_conv_mfma_pack_weights(_ptr(w), _ptr(packed), Cout, Cin, k, _stream()))
+    return packed
+
+
+def conv_mfma_forward(x, packed_weight, bias, Cout, kernel, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0,
+                      in_c0=0, Cin=None):
+    """act(Convolution{kernel, stride, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] (a new blob if out is None)."""
+    x = _chk(x, "bottom[0]")
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    Ho, Wo = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (Ho, Wo):
+            raise ValueError(f"conv_mfma: top blob {tuple(out.shape)} does not match [{N},*,{Ho},{Wo}]")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    pw = _chk(packed_weight, "packed weight", ndim=1)
+    check(_lib.lib().fn2_conv_mfma_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                           kernel, stride, pad, int(bool(relu)), C.c_float(float(negative_slope)), _stream()))
+    return out
+
+
+def set_conv_variant(v: int):
+    check(_lib.lib().fn2_debug_set_conv_variant(int(v)))
+
+
+def conv_num_variants() -> int:
+    return int(_lib.lib().fn2_conv_mfma_num_variants())
+
+
 def im2col_forward(x, kernel, pad, stride):
     """[N,C,H,W] -> col [N, C*k*k, Hc*Wc] (Caffe's im2col row order), batched."""
     x = _chk(x, "bottom[0]")

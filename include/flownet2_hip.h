@@ -245,6 +245,32 @@ int fn2_conv_k7s2_relu_forward(const float* bottom, const float* weight, const f
                                int N, int Cin, int Hin, int Win, int Cout, float negative_slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Direct convolution of the FlowNet encoders on the fp32 matrix cores, fused with its bias and (optionally) its ReLU:
+ *   top[:, top_c0 : top_c0 + Cout] = act(Convolution{kernel_size, stride, pad}(bottom[:, bottom_c0 : bottom_c0 + Cin]) + bias)
+ *   <- ConvolutionLayer::Forward_gpu, src/caffe/layers/conv_layer.cu:8-23 (per-sample im2col_gpu + cublasSgemm in
+ *      forward_gpu_gemm, base_conv_layer.cpp:326-341, then forward_gpu_bias :343-348; weight [Cout, Cin, k, k]) and, when
+ *      relu != 0, the in-place ReLULayer::Forward_gpu, src/caffe/layers/relu_layer.cu:8-27.
+ *   One launch for the mini-batch, NCHW in and out, no column matrix.  bottom / top may be channel slices of wider blobs
+ *   (bottom_channels / top_channels = the blobs' channel counts): a Concat consumer (concat_layer.cu) can be written in place.
+ *   The weight operand is the PACKED form of the layer's weight blob (MFMA operand order, zero-padded to whole channel
+ *   quads): fn2_conv_mfma_packed_floats() floats, written by fn2_conv_mfma_pack_weights() -- once per weight update
+ *   (LayerSetUp / after Solver::ApplyUpdate), not per forward.
+ *   Supported (fn2_conv_mfma_supported): kernel 3 (stride 1 or 2) or 5 (stride 2), pad <= 4, Cout % 64 == 0, Win % 4 == 0,
+ *   16-byte aligned blobs; callers keep the library convolution otherwise.  Forward only.  Exact fp32 (k-ordered fma chains;
+ *   every kernel variant produces the same bits).
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_conv_mfma_supported(int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
+size_t fn2_conv_mfma_packed_floats(int Cout, int Cin, int kernel);
+int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int Cout, int Cin, int kernel, void* stream);
+int fn2_conv_mfma_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                          int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                          int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
+                          int relu, float negative_slope, void* stream);
+/* Test / profiling hooks: number of tile variants, and a forced variant (-1 = choose by the cost model). */
+int fn2_conv_mfma_num_variants(void);
+int fn2_debug_set_conv_variant(int variant);
+
+/* ------------------------------------------------------------------------------------------------
  * im2col / col2im of Caffe's GEMM convolution, batched over the mini-batch (square kernel, no dilation):
  *   fn2_im2col_forward            <- im2col_gpu, src/caffe/util/im2col.cu:8-72, as used by
  *                                    BaseConvolutionLayer::forward_gpu_gemm (base_conv_layer.cpp:325-341)

@@ -912,6 +912,70 @@ FN2_API int fn2_conv_k7s2_relu_forward_cpu(const float* in, const float* weight,
 }
 
 
+/* Direct convolution + bias + optional ReLU on PACKED weights: the CPU twin of csrc/conv_mfma.hip.
+ * Reference arithmetic: Convolution{kernel_size, stride, pad} (conv_layer.cpp:25-40 / base_conv_layer.cpp:255-318: im2col + GEMM +
+ * bias) and the in-place ReLU (relu_layer.cpp:23-30).  The reference's SGEMM summation order is library-defined; the HIP kernel
+ * accumulates in the order (channel quad, ky, kx, channel within the quad) with fused multiply-adds (v_mfma_f32_16x16x4_f32 is a
+ * k-ordered fma chain), zero padding included as 0-products -- restated here with fmaf in the same order, so the two agree bit for bit.
+ * Packed layout (fn2_conv_mfma_pack_weights): [Cout/64][k-steps + 8 spare][lane 64][4], lane = 16 * kq + co, element j:
+ * W[64 g + 16 j + co][4 cq + kq][ky][kx], k-step = (cq * k + ky) * k + kx; zero beyond Cin. */
+static int conv_mfma_ksteps(int Cin, int k) { return (((Cin + 3) / 4 + 1) / 2) * 2 * k * k; }
+
+FN2_API size_t fn2_conv_mfma_packed_floats_cpu(int Cout, int Cin, int kernel) {
+  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || kernel <= 0) return 0;
+  return (size_t)(Cout / 64) * (conv_mfma_ksteps(Cin, kernel) + 8) * 256;
+}
+
+FN2_API int fn2_conv_mfma_pack_weights_cpu(const float* weight, float* packed, int Cout, int Cin, int kernel) {
+  if (!weight || !packed || Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 5)) return FN2_ERR_INVALID_ARG;
+  const int ksteps = conv_mfma_ksteps(Cin, kernel), kalloc = ksteps + 8, kk = kernel * kernel;
+  for (int g = 0; g < Cout / 64; ++g)
+    for (int ks = 0; ks < kalloc; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int co = 64 * g + 16 * j + (lane & 15), ci = 4 * (ks / kk) + (lane >> 4), tap = ks % kk;
+          packed[(((size_t)g * kalloc + ks) * 64 + lane) * 4 + j] =
+              (ks < ksteps && ci < Cin) ? weight[((size_t)co * Cin + ci) * kk + tap] : 0.f;
+        }
+  return FN2_OK;
+}
+
+FN2_API int fn2_conv_mfma_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
+                                      int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                      int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
+                                      int relu, float negative_slope) {
+  if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 64 != 0 || kernel < 1 || stride < 1 || pad < 0) return FN2_ERR_INVALID_ARG;
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
+  const int Ho = (Hin + 2 * pad - kernel) / stride + 1, Wo = (Win + 2 * pad - kernel) / stride + 1;
+  const int quads = (Cin + 3) / 4, kalloc = conv_mfma_ksteps(Cin, kernel) + 8;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co) {
+      const float* wg = packed + (size_t)(co / 64) * kalloc * 256 + ((co % 64) / 16) + 4 * (co % 16);
+      for (int y = 0; y < Ho; ++y)
+        for (int x = 0; x < Wo; ++x) {
+          float acc = 0.f;
+          for (int cq = 0; cq < quads; ++cq)
+            for (int ky = 0; ky < kernel; ++ky)
+              for (int kx = 0; kx < kernel; ++kx) {
+                const int ks = (cq * kernel + ky) * kernel + kx;
+                const int yi = stride * y - pad + ky, xi = stride * x - pad + kx;
+                for (int kq = 0; kq < 4; ++kq) {
+                  const int ci = 4 * cq + kq;
+                  float v = 0.f;
+                  if (ci < Cin && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+                    v = bottom[(((size_t)n * bottom_channels + bottom_c0 + ci) * Hin + yi) * Win + xi];
+                  acc = fmaf(v, wg[(size_t)ks * 256 + 64 * kq], acc);
+                }
+              }
+          float t = acc + (bias ? bias[co] : 0.f);
+          if (relu) t = t > 0.f ? t : t * negative_slope;
+          top[(((size_t)n * top_channels + top_c0 + co) * Ho + y) * Wo + x] = t;
+        }
+    }
+  return FN2_OK;
+}
+
 /* Batched im2col / col2im of Caffe's GEMM convolution (src/caffe/util/im2col.cpp:20-50 im2col_cpu, :168-200 col2im_cpu;
  * GPU twins im2col.cu:8-72, 246-318).  col2im carries the deconvolution's bias and optional leaky ReLU like the HIP path;
  * the additions run over the column grid rows ascending, then columns ascending (the reference GPU kernel's order). */
