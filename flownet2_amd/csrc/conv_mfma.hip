@@ -45,7 +45,8 @@ struct Args {
   int ksteps;         // k-steps of the packed weights per 64-channel group (= quads * KS * KS), multiple of the chunk length
   int tx, ty;         // workgroup tiles per sample along x / y
   int ng;             // Cout / (16 * MW * WM)
-  unsigned total;     // workgroups with work
+  unsigned total;     // tiles (= workgroups of the plain launch)
+  unsigned nbig;      // split-tail launch: tiles that run whole (a multiple of 256); the rest run as two half-channel workgroups
   float slope; int relu;
 };
 
@@ -97,25 +98,15 @@ __device__ __forceinline__ void stage_chunk(__amdgpu_buffer_rsrc_t rs, const uns
   }
 }
 
+// One workgroup tile: channel group g (of 16 * MW * WM channels), pixel tile (bx, by) of sample n.
 template <class K>
-__global__ void __launch_bounds__(256, 2)
-conv_mfma(Args a) {
+__device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, int n) {
   static_assert(K::THREADS == 256, "launch bounds");
-  constexpr int KS = K::KS, S = K::S, MW = K::MW, NP = K::NP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KS = K::KS, S = K::S, MW = K::MW, NP = K::NP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % K::WM, wnx = (wave / K::WM) % K::WNX, wny = wave / (K::WM * K::WNX);
-
-  // ---- task: XCD-contiguous ranges of the (sample, tile row, tile column, channel group) list, channel group fastest:
-  // the workgroups that share an input window run next to each other on one XCD (its L2 serves the re-reads)
-  const unsigned per_xcd = (a.total + 7) / 8;
-  unsigned t = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (blockIdx.x / 8 >= per_xcd || t >= a.total) return;
-  const int g = t % a.ng; t /= a.ng;
-  const int bx = t % a.tx; t /= a.tx;
-  const int by = t % a.ty;
-  const int n = t / a.ty;
   const int x0 = bx * K::TW, y0 = by * K::TH;
 
   // ---- LDS-DMA plan: run r = i * NW + wave, slot s = 64 r + lane -> (channel, window row, group of 4 columns)
@@ -212,6 +203,49 @@ conv_mfma(Args a) {
   }
 }
 
+// Task list: (sample, tile row, tile column, channel group), channel group fastest, cut into 8 contiguous ranges, one per XCD
+// (block b runs on XCD b % 8): the workgroups that share an input window run next to each other on one XCD, whose L2 serves
+// the re-reads.
+__device__ __forceinline__ void decode_tile(const Args& a, unsigned t, int& g, int& bx, int& by, int& n) {
+  g = t % a.ng; t /= a.ng;
+  bx = t % a.tx; t /= a.tx;
+  by = t % a.ty;
+  n = t / a.ty;
+}
+
+template <class K>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma(Args a) {
+  const unsigned per_xcd = (a.total + 7) / 8;
+  const unsigned t = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= per_xcd || t >= a.total) return;
+  int g, bx, by, n;
+  decode_tile(a, t, g, bx, by, n);
+  conv_body<K>(a, g, bx, by, n);
+}
+
+// The same launch with a split tail.  With W tiles over 256 CUs the last, partial round (W mod 256 tiles) leaves most CUs idle for
+// a whole tile time; here the first a.nbig tiles (whole rounds) run as they are and each remaining tile is cut into two
+// workgroups of half the channels (MW / 2 channel groups per wave): if they are at most 256 the tail costs half a tile time.
+// The arithmetic per output element is the same k-ordered chain: same bits.
+template <class K>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_tail(Args a) {
+  using KH = Cfg<K::KS, K::S, K::MW / 2, K::NP, K::WM, K::WNX, K::WNY, K::CQ>;
+  int g, bx, by, n;
+  if (blockIdx.x < a.nbig) {
+    const unsigned t = (blockIdx.x % 8) * (a.nbig / 8) + blockIdx.x / 8;
+    decode_tile(a, t, g, bx, by, n);
+    conv_body<K>(a, g, bx, by, n);
+  } else {
+    const unsigned b = blockIdx.x - a.nbig, nsm = 2 * (a.total - a.nbig), per_xcd = (nsm + 7) / 8;
+    const unsigned u = (b % 8) * per_xcd + b / 8;
+    if (b / 8 >= per_xcd || u >= nsm) return;
+    decode_tile(a, a.nbig + u / 2, g, bx, by, n);
+    conv_body<KH>(a, 2 * g + (int)(u & 1), bx, by, n);
+  }
+}
+
 // weight [Cout][Cin][KS][KS] -> packed [Cout/64][ksteps + spare][64][4]
 __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS, int ksteps, int kalloc) {
   const long long total = (long long)(Cout / 64) * kalloc * 256;
@@ -234,14 +268,20 @@ constexpr int kChunkQuads = 2;     // k-steps are padded to a whole number of ch
 inline int ksteps_for(int Cin, int KS) { return cdiv(cdiv(Cin, 4), kChunkQuads) * kChunkQuads * KS * KS; }
 
 template <class K>
-static int launch(const Args& base, hipStream_t st) {
-  Args a = base;
+static void set_geometry(Args& a) {
   a.tx = cdiv(a.Wout, K::TW); a.ty = cdiv(a.Hout, K::TH);
   a.ng = a.Cout / (16 * K::MW * K::WM);
   a.nchunks = cdiv(cdiv(a.Cin, 4), K::CQ);
-  const long long total = (long long)a.N * a.tx * a.ty * a.ng;
-  if (total > 0x7fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: grid too large");
-  a.total = (unsigned)total;
+}
+
+inline long long tiles_of(const Args& a) { return (long long)a.N * a.tx * a.ty * a.ng; }
+
+template <class K>
+static int launch(const Args& base, hipStream_t st) {
+  Args a = base;
+  set_geometry<K>(a);
+  if (tiles_of(a) > 0x3fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: grid too large");
+  a.total = (unsigned)tiles_of(a); a.nbig = a.total;
   const unsigned grid = 8 * ((a.total + 7) / 8);
   constexpr size_t lds = sizeof(float) * 2 * K::BUF;
   static bool attr_set = false;
@@ -253,37 +293,71 @@ static int launch(const Args& base, hipStream_t st) {
   return check_launch("conv_mfma_forward");
 }
 
+// whole rounds of tiles, then the remainder as half-channel workgroups (conv_mfma_tail)
+inline unsigned whole_rounds(long long tiles) { return (unsigned)(tiles / 256 * 256); }
+
+template <class K>
+static int launch_tail(const Args& base, hipStream_t st) {
+  if constexpr (K::MW < 2) {
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: variant has no split tail");
+  } else {
+    Args a = base;
+    set_geometry<K>(a);
+    if (tiles_of(a) > 0x1fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: grid too large");
+    a.total = (unsigned)tiles_of(a); a.nbig = whole_rounds(a.total);
+    const unsigned nsm = 2 * (a.total - a.nbig);
+    const unsigned grid = a.nbig + 8 * ((nsm + 7) / 8);
+    constexpr size_t lds = sizeof(float) * 2 * K::BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_tail<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_tail<K>), dim3(grid), dim3(K::THREADS), lds, st, a);
+    return check_launch("conv_mfma_forward");
+  }
+}
+
 struct Variant {
   int ks, s, mw, np, wm, wnx, wny;
   int (*fn)(const Args&, hipStream_t);
+  int (*fn_tail)(const Args&, hipStream_t);     // nullptr: no split-tail form
 };
 
-// X-macro list of the tile variants: (KS, S, MW, NP, WM, WNX, WNY, CQ)
+// X-macro list of the tile variants: (KS, S, MW, NP, WM, WNX, WNY, CQ, split-tail form instantiated)
 #define FN2_CV_LIST(X) \
   /* 3x3 stride 1 */ \
-  X(3, 1, 2, 7, 2, 2, 1, 2) X(3, 1, 2, 7, 2, 1, 2, 2) X(3, 1, 4, 7, 1, 2, 2, 2) X(3, 1, 4, 7, 1, 1, 4, 2) \
-  X(3, 1, 2, 6, 2, 2, 1, 2) X(3, 1, 4, 6, 1, 2, 2, 2) X(3, 1, 4, 4, 1, 2, 2, 2) X(3, 1, 2, 4, 2, 2, 1, 2) \
+  X(3, 1, 2, 7, 2, 2, 1, 2, 1) X(3, 1, 2, 7, 2, 1, 2, 2, 1) X(3, 1, 4, 7, 1, 2, 2, 2, 0) X(3, 1, 4, 7, 1, 1, 4, 2, 0) \
+  X(3, 1, 2, 6, 2, 2, 1, 2, 1) X(3, 1, 4, 6, 1, 2, 2, 2, 0) X(3, 1, 4, 4, 1, 2, 2, 2, 0) X(3, 1, 2, 4, 2, 2, 1, 2, 1) \
   /* 3x3 stride 2 */ \
-  X(3, 2, 2, 7, 2, 1, 2, 2) X(3, 2, 4, 7, 1, 1, 4, 2) X(3, 2, 2, 6, 2, 2, 1, 2) X(3, 2, 4, 6, 1, 2, 2, 2) X(3, 2, 2, 4, 2, 2, 1, 2) \
+  X(3, 2, 2, 7, 2, 1, 2, 2, 1) X(3, 2, 4, 7, 1, 1, 4, 2, 0) X(3, 2, 2, 6, 2, 2, 1, 2, 1) X(3, 2, 4, 6, 1, 2, 2, 2, 0) X(3, 2, 2, 4, 2, 2, 1, 2, 1) \
   /* 5x5 stride 2 */ \
-  X(5, 2, 2, 7, 2, 2, 1, 1) X(5, 2, 2, 7, 2, 1, 2, 1) X(5, 2, 4, 7, 1, 2, 2, 1) X(5, 2, 4, 7, 1, 1, 4, 1) \
-  X(5, 2, 2, 6, 2, 2, 1, 1) X(5, 2, 4, 6, 1, 2, 2, 1) X(5, 2, 4, 4, 1, 2, 2, 1)
+  X(5, 2, 2, 7, 2, 2, 1, 1, 1) X(5, 2, 2, 7, 2, 1, 2, 1, 1) X(5, 2, 4, 7, 1, 2, 2, 1, 0) X(5, 2, 4, 7, 1, 1, 4, 1, 0) \
+  X(5, 2, 2, 6, 2, 2, 1, 1, 1) X(5, 2, 4, 6, 1, 2, 2, 1, 0) X(5, 2, 4, 4, 1, 2, 2, 1, 0)
 
-#define FN2_CV_ROW(KS, S, MW, NP, WM, WNX, WNY, CQ) {KS, S, MW, NP, WM, WNX, WNY, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>>},
+template <class K, int TAIL> struct TailFn { static constexpr int (*fn)(const Args&, hipStream_t) = nullptr; };
+template <class K> struct TailFn<K, 1> { static constexpr int (*fn)(const Args&, hipStream_t) = &launch_tail<K>; };
+
+#define FN2_CV_ROW(KS, S, MW, NP, WM, WNX, WNY, CQ, TAIL) \
+  {KS, S, MW, NP, WM, WNX, WNY, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>>, TailFn<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>, TAIL>::fn},
 static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-int g_forced_variant = -1;
+int g_forced_variant = -1;       // >= 0: plain launch of that variant; >= 1000: its split-tail launch
 
-// cost model: rounds of workgroups over 256 CUs x (accumulator tiles of a workgroup, incl. those hanging over the image edge)
-static double variant_cost(const Variant& v, const Args& a) {
+// Cost model: tile times of the busiest CU x accumulator tiles of a wave (tiles hanging over the image edge included), with a
+// mild penalty for small wave tiles (more operand traffic per MFMA).  tail: the last partial round as half tiles.
+static double variant_cost(const Variant& v, const Args& a, bool tail) {
   const int tw = 4 * v.np * v.wnx, th = 4 * v.wny;
   const long long wgs = (long long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * (a.Cout / (16 * v.mw * v.wm));
-  const double per_cu = (double)((wgs + 255) / 256);
-  const double units = (double)v.mw * v.np;                         // accumulator tiles per wave
-  // small wave tiles pay more operand traffic per MFMA: mild penalty
+  double rounds = (double)((wgs + 255) / 256);
+  if (tail) {
+    const long long r = wgs % 256;
+    if (wgs < 256 || r == 0 || r > 128) return 1e30;               // nothing to gain
+    rounds = (double)(wgs / 256) + 0.5 * 1.12;                      // half tiles run MW / 2: less efficient
+  }
   const double eff = 1.0 / (1.0 + 0.08 * (4.0 / v.mw - 1.0) + 0.02 * (7.0 / v.np - 1.0));
-  return per_cu * units / eff;
+  return rounds * v.mw * v.np / eff;
 }
 
 static bool variant_applies(const Variant& v, const Args& a, int KS, int S) {
@@ -344,18 +418,22 @@ FN2_API int fn2_conv_mfma_forward(const float* bottom, const float* packed_weigh
   a.slope = negative_slope; a.relu = relu;
   if ((a.Wout % 4) != 0 && ((size_t)a.Wout * sizeof(float)) % 16 != 0) { /* scalar tail stores handle it */ }
   int best = -1;
+  bool tail = false;
   if (cv::g_forced_variant >= 0) {
-    if (cv::g_forced_variant >= cv::kNumVariants || !cv::variant_applies(cv::kVariants[cv::g_forced_variant], a, kernel, stride))
+    tail = cv::g_forced_variant >= 1000;
+    best = cv::g_forced_variant % 1000;
+    if (best >= cv::kNumVariants || !cv::variant_applies(cv::kVariants[best], a, kernel, stride) || (tail && !cv::kVariants[best].fn_tail))
       return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: forced variant %d does not apply", cv::g_forced_variant);
-    best = cv::g_forced_variant;
   } else {
     double bc = 0;
     for (int i = 0; i < cv::kNumVariants; ++i) {
       if (!cv::variant_applies(cv::kVariants[i], a, kernel, stride)) continue;
-      const double c = cv::variant_cost(cv::kVariants[i], a);
-      if (best < 0 || c < bc) { best = i; bc = c; }
+      for (int t = 0; t < (cv::kVariants[i].fn_tail ? 2 : 1); ++t) {
+        const double c = cv::variant_cost(cv::kVariants[i], a, t == 1);
+        if (best < 0 || c < bc) { best = i; bc = c; tail = t == 1; }
+      }
     }
   }
   if (best < 0) return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: no kernel variant for this geometry");
-  return cv::kVariants[best].fn(a, as_stream(stream));
+  return tail ? cv::kVariants[best].fn_tail(a, as_stream(stream)) : cv::kVariants[best].fn(a, as_stream(stream));
 }

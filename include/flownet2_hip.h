@@ -266,7 +266,8 @@ int fn2_conv_mfma_forward(const float* bottom, const float* packed_weight, const
                           int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                           int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
                           int relu, float negative_slope, void* stream);
-/* Test / profiling hooks: number of tile variants, and a forced variant (-1 = choose by the cost model). */
+/* Test / profiling hooks: number of tile variants, and a forced variant (-1 = choose by the cost model; v = plain launch of
+ * variant v; 1000 + v = its split-tail launch: whole rounds of tiles, the remainder as half-channel workgroups). */
 int fn2_conv_mfma_num_variants(void);
 int fn2_debug_set_conv_variant(int variant);
 

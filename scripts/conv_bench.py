@@ -67,7 +67,8 @@ def main():
         pw = ops.conv_mfma_pack_weights(w)
         out = torch.empty_like(want)
         first = None
-        for v in range(ops.conv_num_variants()):
+        nv = ops.conv_num_variants()
+        for v in list(range(nv)) + [1000 + i for i in range(nv)]:          # 1000 + i: split-tail launch of variant i
             ops.set_conv_variant(v)
             try:
                 ops.conv_mfma_forward(x, pw, b, Cout, k, s, p, True, 0.1, out=out)
@@ -79,7 +80,7 @@ def main():
             if first is None:
                 first = (v, out.clone())
             t = timeit(lambda: ops.conv_mfma_forward(x, pw, b, Cout, k, s, p, True, 0.1, out=out), a.iters)
-            print(f"   variant {v:2d}: {t:7.1f} us {gf / t * 1e3:6.1f} TF   max|diff vs torch| {err:.2e}{same}", flush=True)
+            print(f"   variant {v:4d}: {t:7.1f} us {gf / t * 1e3:6.1f} TF   max|diff vs torch| {err:.2e}{same}", flush=True)
         ops.set_conv_variant(-1)
         t = timeit(lambda: ops.conv_mfma_forward(x, pw, b, Cout, k, s, p, True, 0.1, out=out), a.iters)
         print(f"   cost-model choice: {t:7.1f} us {gf / t * 1e3:6.1f} TF", flush=True)

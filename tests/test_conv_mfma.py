@@ -70,7 +70,8 @@ def test_hip_conv_equals_oracle_bitwise_in_every_variant(case):
     want = oracle.conv_mfma_forward(x, pw.cpu().numpy(), b, Cout, k, s, p, True, 0.1)
     ran = 0
     try:
-        for v in range(ops.conv_num_variants()):
+        nv = ops.conv_num_variants()
+        for v in list(range(nv)) + [1000 + i for i in range(nv)]:          # plain launches, then the split-tail launches
             ops.set_conv_variant(v)
             try:
                 got = ops.conv_mfma_forward(dv(x), pw, dv(b), Cout, k, s, p, True, 0.1)
@@ -80,7 +81,7 @@ def test_hip_conv_equals_oracle_bitwise_in_every_variant(case):
             assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"variant {v}"
     finally:
         ops.set_conv_variant(-1)
-    assert ran >= 3
+    assert ran >= 5
     got = ops.conv_mfma_forward(dv(x), pw, None, Cout, k, s, p, False, 0.1)
     assert np.array_equal(got.cpu().numpy(), oracle.conv_mfma_forward(x, pw.cpu().numpy(), None, Cout, k, s, p, False, 0.1))
 
