@@ -25,6 +25,7 @@ EXPORTS = [
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
     "fn2_conv_mfma_num_variants", "fn2_debug_set_conv_variant",
+    "fn2_caffemodel_index", "fn2_caffemodel_read_blob",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
@@ -39,6 +40,13 @@ class Fn2Error(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"[fn2 status {status}] {message}")
         self.status = status
+
+
+class CaffemodelEntry(C.Structure):
+    """fn2_caffemodel_entry (include/flownet2_hip.h)."""
+    _fields_ = [("name_off", C.c_size_t), ("name_len", C.c_size_t), ("type_off", C.c_size_t), ("type_len", C.c_size_t),
+                ("v1_type", C.c_longlong), ("v1", C.c_int), ("blob_index", C.c_int), ("num_axes", C.c_int), ("dim", C.c_longlong * 8),
+                ("count", C.c_size_t), ("is_double", C.c_int), ("blob_off", C.c_size_t), ("blob_len", C.c_size_t)]
 
 
 class CorrParams(C.Structure):
@@ -116,6 +124,8 @@ def lib():
     L.fn2_conv_mfma_pack_weights.argtypes = [fp, fp, i, i, i, vp]
     L.fn2_conv_mfma_forward.argtypes = [fp, fp, fp, fp] + [i] * 13 + [C.c_float, vp]
     L.fn2_debug_set_conv_variant.argtypes = [i]
+    L.fn2_caffemodel_index.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), i, C.POINTER(C.c_int)]
+    L.fn2_caffemodel_read_blob.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), fp, sz]
     ip = C.POINTER(C.c_int)
     L.fn2_datum_parse.argtypes = [vp, sz, C.POINTER(DatumView)]
     L.fn2_datum_float_data.argtypes = [vp, sz, fp, sz]

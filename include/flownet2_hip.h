@@ -288,6 +288,32 @@ int fn2_col2im_bias_relu_forward(const float* col, const float* bias, float* im,
                                  int kernel, int pad, int stride, int apply_relu, float negative_slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * .caffemodel reader (host code): the trained blobs of a serialized NetParameter
+ *   <- Net::CopyTrainedLayersFromBinaryProto / CopyTrainedLayersFrom, src/caffe/net.cpp:752-819 (layers matched BY NAME, blobs by
+ *      index, shapes CHECKed) and Blob::FromProto, src/caffe/blob.cpp:459-508 (shape message or the legacy 4-D fields; double_data
+ *      wins over data).  Layers with DoesUseCustomCopyBlobs (DataAugmentation: blobs 0 = iteration count, 1 = per-pixel mean,
+ *      2 = per-channel mean, data_augmentation_layer.cpp:162-205) come out like any other layer; the caller picks blob 2.
+ *   fn2_caffemodel_index fills up to max_entries entries (one per BlobProto, file order) and reports the total in *num_entries
+ *   (call with max_entries 0 to size the array).  Offsets are byte offsets into the caller's buffer (names are not copied).
+ *   fn2_caffemodel_read_blob copies one blob as floats (count elements).  Both the current `layer` (field 100) and the deprecated
+ *   V1 `layers` (field 2) lists are read; V1 entries carry the LayerType enum in v1_type instead of a type string.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fn2_caffemodel_entry {
+  size_t name_off, name_len;      /* layer name (LayerParameter.name) */
+  size_t type_off, type_len;      /* layer type string (empty for V1 layers) */
+  long long v1_type;              /* V1LayerParameter.type enum value, -1 otherwise */
+  int v1;                         /* 1: entry of the deprecated `layers` list */
+  int blob_index;                 /* index in the layer's blobs */
+  int num_axes;
+  long long dim[8];
+  size_t count;                   /* elements of data (or double_data) */
+  int is_double;                  /* stored as double_data */
+  size_t blob_off, blob_len;      /* the BlobProto message */
+} fn2_caffemodel_entry;
+int fn2_caffemodel_index(const void* buf, size_t len, fn2_caffemodel_entry* entries, int max_entries, int* num_entries);
+int fn2_caffemodel_read_blob(const void* buf, size_t len, const fn2_caffemodel_entry* entry, float* dst, size_t dst_floats);
+
+/* ------------------------------------------------------------------------------------------------
  * CustomData sample format  (type: "CustomData"; SURVEY.md 8f row 4: the on-disk format of the training sets)
  *   An LMDB value is a serialized `Datum` (src/caffe/proto/caffe.proto:30-41) whose `data` bytes hold, plane after plane,
  *   the slices named by DataParameter.slice_point / .encoding (caffe.proto:923-927, :979-980).  The FlyingChairs sets written by

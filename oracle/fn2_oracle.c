@@ -1689,3 +1689,117 @@ FN2_API int fn2_data_augmentation_forward_cpu(const fn2_data_aug_params* p, cons
           top[(size_t)n * count + (size_t)c * area + px] -= (p->mean_mode == FN2_MEAN_PER_PIXEL) ? mean[(size_t)c * area + px] : mean[c];
   return FN2_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * .caffemodel reader twin (checker for csrc/caffemodel.cpp): NetParameter.layer (100) / .layers (2) -> blobs, as
+ * Net::CopyTrainedLayersFrom (net.cpp:752-800) and Blob::FromProto (blob.cpp:459-508) see them.  Written as a table of
+ * (message, field) handlers over one generic field iterator -- a different shape from the product code on purpose.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const unsigned char* p; const unsigned char* end; } cm_span;
+
+static int cm_varint(cm_span* s, uint64_t* v) {
+  uint64_t r = 0; int shift = 0;
+  while (s->p < s->end && shift < 64) {
+    unsigned char b = *s->p++;
+    r |= (uint64_t)(b & 0x7f) << shift;
+    if (!(b & 0x80)) { *v = r; return 1; }
+    shift += 7;
+  }
+  return 0;
+}
+
+/* returns 0 at end, 1 on a field, -1 on malformed input; payload = value bytes for wire types 1, 2, 5 */
+static int cm_next(cm_span* s, unsigned* num, unsigned* wt, uint64_t* val, cm_span* payload) {
+  if (s->p >= s->end) return 0;
+  uint64_t key, l;
+  if (!cm_varint(s, &key) || (key >> 3) == 0 || (key >> 3) > 0x1fffffffull) return -1;
+  *num = (unsigned)(key >> 3); *wt = (unsigned)(key & 7);
+  if (*wt == 0) return cm_varint(s, val) ? 1 : -1;
+  if (*wt == 1) l = 8; else if (*wt == 5) l = 4;
+  else if (*wt == 2) { if (!cm_varint(s, &l)) return -1; }
+  else return -1;
+  if ((uint64_t)(s->end - s->p) < l) return -1;
+  payload->p = s->p; payload->end = s->p + l; s->p += l;
+  return 1;
+}
+
+static int cm_blob_meta(cm_span b, fn2_caffemodel_entry* e) {
+  long long legacy[4] = {0, 0, 0, 0};
+  int shape_seen = 0, legacy_seen = 0, rc;
+  size_t nfloat = 0, ndouble = 0;
+  unsigned num, wt; uint64_t v; cm_span pl;
+  e->num_axes = 0;
+  while ((rc = cm_next(&b, &num, &wt, &v, &pl)) == 1) {
+    if (wt == 0 && num >= 1 && num <= 4) { legacy[num - 1] = (int32_t)v; legacy_seen = 1; }
+    if (num == 7 && wt == 2) {
+      unsigned sn, sw; uint64_t sv; cm_span spl; int src;
+      shape_seen = 1;
+      while ((src = cm_next(&pl, &sn, &sw, &sv, &spl)) == 1) {
+        if (sn != 1) continue;
+        if (sw == 0) { if (e->num_axes >= 8) return 0; e->dim[e->num_axes++] = (long long)sv; }
+        if (sw == 2) while (spl.p < spl.end) { uint64_t x; if (!cm_varint(&spl, &x) || e->num_axes >= 8) return 0; e->dim[e->num_axes++] = (long long)x; }
+      }
+      if (src < 0) return 0;
+    }
+    if (num == 5) nfloat += wt == 2 ? (size_t)(pl.end - pl.p) / 4 : (wt == 5 ? 1 : 0);
+    if (num == 8) ndouble += wt == 2 ? (size_t)(pl.end - pl.p) / 8 : (wt == 1 ? 1 : 0);
+  }
+  if (rc < 0) return 0;
+  if (!shape_seen && legacy_seen) { e->num_axes = 4; memcpy(e->dim, legacy, sizeof(legacy)); }
+  e->is_double = ndouble > 0;
+  e->count = ndouble > 0 ? ndouble : nfloat;
+  return 1;
+}
+
+FN2_API int fn2_caffemodel_index_cpu(const void* buf, size_t len, fn2_caffemodel_entry* entries, int max_entries, int* num_entries) {
+  if (!buf || !num_entries || (max_entries > 0 && !entries)) return FN2_ERR_INVALID_ARG;
+  const unsigned char* base = (const unsigned char*)buf;
+  cm_span net = {base, base + len}, layer;
+  unsigned num, wt; uint64_t v; int rc, count = 0;
+  while ((rc = cm_next(&net, &num, &wt, &v, &layer)) == 1) {
+    if (wt != 2 || (num != 100 && num != 2)) continue;
+    const int v1 = num == 2;
+    fn2_caffemodel_entry head;
+    memset(&head, 0, sizeof(head));
+    head.v1 = v1; head.v1_type = -1;
+    const int first = count;
+    int bi = 0, lrc;
+    unsigned ln, lw; uint64_t lv; cm_span lp;
+    while ((lrc = cm_next(&layer, &ln, &lw, &lv, &lp)) == 1) {
+      if (lw == 2 && ln == (v1 ? 4u : 1u)) { head.name_off = (size_t)(lp.p - base); head.name_len = (size_t)(lp.end - lp.p); }
+      else if (!v1 && lw == 2 && ln == 2) { head.type_off = (size_t)(lp.p - base); head.type_len = (size_t)(lp.end - lp.p); }
+      else if (v1 && lw == 0 && ln == 5) head.v1_type = (long long)lv;
+      else if (lw == 2 && ln == (v1 ? 6u : 7u)) {
+        fn2_caffemodel_entry e;
+        memset(&e, 0, sizeof(e));
+        e.blob_index = bi++; e.blob_off = (size_t)(lp.p - base); e.blob_len = (size_t)(lp.end - lp.p);
+        if (!cm_blob_meta(lp, &e)) return FN2_ERR_INVALID_ARG;
+        if (count < max_entries) entries[count] = e;
+        ++count;
+      }
+    }
+    if (lrc < 0) return FN2_ERR_INVALID_ARG;
+    for (int i = first; i < count && i < max_entries; ++i) {
+      entries[i].name_off = head.name_off; entries[i].name_len = head.name_len; entries[i].type_off = head.type_off;
+      entries[i].type_len = head.type_len; entries[i].v1 = head.v1; entries[i].v1_type = head.v1_type;
+    }
+  }
+  if (rc < 0) return FN2_ERR_INVALID_ARG;
+  *num_entries = count;
+  return FN2_OK;
+}
+
+FN2_API int fn2_caffemodel_read_blob_cpu(const void* buf, size_t len, const fn2_caffemodel_entry* e, float* dst, size_t dst_floats) {
+  if (!buf || !e || !dst || e->blob_off > len || e->blob_len > len - e->blob_off || dst_floats < e->count) return FN2_ERR_INVALID_ARG;
+  long long want = 1;
+  for (int i = 0; i < e->num_axes; ++i) want *= e->dim[i];
+  if ((size_t)want != e->count) return FN2_ERR_INVALID_ARG;
+  cm_span b = {(const unsigned char*)buf + e->blob_off, (const unsigned char*)buf + e->blob_off + e->blob_len}, pl;
+  unsigned num, wt; uint64_t v; int rc; size_t k = 0;
+  while ((rc = cm_next(&b, &num, &wt, &v, &pl)) == 1) {
+    if (wt == 0) continue;
+    if (!e->is_double && num == 5) for (; pl.p + 4 <= pl.end && k < e->count; pl.p += 4) memcpy(dst + k++, pl.p, 4);
+    if (e->is_double && num == 8) for (; pl.p + 8 <= pl.end && k < e->count; pl.p += 8) { double d; memcpy(&d, pl.p, 8); dst[k++] = (float)d; }
+  }
+  return rc < 0 || k != e->count ? FN2_ERR_INVALID_ARG : FN2_OK;
+}

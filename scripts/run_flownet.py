@@ -6,7 +6,7 @@
 Same behaviour as the reference script: images are read as RGB, fed as BGR raw 0..255 floats, the net runs at the
 ADAPTED (x64) size and the flow is resampled / rescaled back to the TARGET size, and the result is written as .flo.
 Differences: no prototxt template / .caffemodel (neither is in the reference tree; the graph is flownet2_amd/nets.py,
-weights are a name->array .npz in Caffe blob layout or seeded random), and no "retry up to 5x on NaN" loop -- the
+weights are a .caffemodel read by flownet2_amd.caffemodel, a name->array .npz in Caffe blob layout, or seeded random), and no "retry up to 5x on NaN" loop -- the
 reference needs it for a race in its kernels (run-flownet.py:72-96); these kernels are deterministic."""
 import argparse
 import os
@@ -30,21 +30,34 @@ def read_image(path):
 
 
 def load_params(net, weights, device):
+    """-> (params on the device, mean or None).  `weights`: a .caffemodel (matched by layer name like Net::CopyTrainedLayersFrom,
+    net.cpp:752-800; the DataAugmentation layers' per-channel mean comes with it) or a name -> array .npz in Caffe blob layout."""
     P = nets.init_params_flownet2(0) if net == "2" else nets.init_params(net, 0)
-    if weights:
+    mean = None
+    if weights and weights.endswith(".caffemodel"):
+        from flownet2_amd import caffemodel
+        found, means, ignored = caffemodel.to_params(caffemodel.load_file(weights), P)
+        for k, v in found.items():
+            P[k] = torch.from_numpy(np.ascontiguousarray(v))
+        missing = [k for k in P if k not in found]
+        print(f"{weights}: {len(found)} blobs copied, {len(missing)} parameters keep their seeded values, ignored source layers: {ignored}")
+        if means:
+            first = next(iter(means.values()))
+            mean = torch.from_numpy(first[:3].copy()).to(device)        # img0 / img1 layers hold the same data-set mean
+    elif weights:
         blob = np.load(weights)
         for k in P:
             if k in blob:
                 assert tuple(blob[k].shape) == tuple(P[k].shape), f"{k}: shape mismatch"      # net.cpp:783-799
                 P[k] = torch.from_numpy(blob[k].astype(np.float32))
-    return {k: v.to(device) for k, v in P.items()}
+    return {k: v.to(device) for k, v in P.items()}, mean
 
 
-def infer(net, P, img0, img1):
+def infer(net, P, img0, img1, mean=None):
     with torch.no_grad():
         if net == "2":
-            return nets.flownet2_deploy_forward(P, img0, img1, Fn)
-        return nets.deploy_forward(net, P, img0, img1, Fn)
+            return nets.flownet2_deploy_forward(P, img0, img1, Fn, mean=mean)
+        return nets.deploy_forward(net, P, img0, img1, Fn, mean=mean)
 
 
 def main():
@@ -58,9 +71,9 @@ def main():
         if not os.path.exists(f):
             raise SystemExit("image does not exist: " + f)
     dev = torch.device("cuda", a.gpu)
-    P = load_params(a.net, a.weights, dev)
+    P, mean = load_params(a.net, a.weights, dev)
     i0, i1 = torch.from_numpy(read_image(a.img0)).to(dev), torch.from_numpy(read_image(a.img1)).to(dev)
-    flow = infer(a.net, P, i0, i1)
+    flow = infer(a.net, P, i0, i1, mean)
     flo.write_flo(a.out, flow[0].cpu().numpy())                                         # predict_flow_final -> (H,W,2)
     print("wrote", a.out, tuple(flow.shape[2:]))
 

@@ -35,7 +35,7 @@ def main():
     torch.cuda.set_device(dev)
     entries = [l.split() for l in open(a.listfile) if l.strip()]
     mine = parallel.shard(entries)
-    P = RF.load_params(a.net, a.weights, dev)
+    P, mean = RF.load_params(a.net, a.weights, dev)
     i = 0
     while i < len(mine):
         first = RF.read_image(mine[i][0])
@@ -44,7 +44,7 @@ def main():
             group.append(mine[i + len(group)])
         i0 = torch.cat([torch.from_numpy(RF.read_image(e[0])) for e in group]).to(dev)
         i1 = torch.cat([torch.from_numpy(RF.read_image(e[1])) for e in group]).to(dev)
-        flow = RF.infer(a.net, P, i0, i1).cpu().numpy()
+        flow = RF.infer(a.net, P, i0, i1, mean).cpu().numpy()
         for k, e in enumerate(group):
             flo.write_flo(e[2], flow[k])
         i += len(group)
