@@ -238,7 +238,54 @@ class Datum {
   std::string data_;
   std::vector<float> float_data_;
 };
-class BlobProto {};
+// caffe.proto:5-22 (what Blob::FromProto / ToProto and the Layer constructor touch)
+class BlobShape {
+ public:
+  int dim_size() const { return (int)dim_.size(); }
+  long long dim(int i) const { return dim_[i]; }
+  void add_dim(long long v) { dim_.push_back(v); }
+  void clear_dim() { dim_.clear(); }
+ private:
+  std::vector<long long> dim_;
+};
+class BlobProto {
+ public:
+  bool has_shape() const { return has_shape_; }
+  const BlobShape& shape() const { return shape_; }
+  BlobShape* mutable_shape() { has_shape_ = true; return &shape_; }
+  void clear_shape() { shape_ = BlobShape(); has_shape_ = false; }
+  bool has_num() const { return has_legacy_; }
+  bool has_channels() const { return has_legacy_; }
+  bool has_height() const { return has_legacy_; }
+  bool has_width() const { return has_legacy_; }
+  int num() const { return legacy_[0]; }
+  int channels() const { return legacy_[1]; }
+  int height() const { return legacy_[2]; }
+  int width() const { return legacy_[3]; }
+  int data_size() const { return (int)data_.size(); }
+  float data(int i) const { return data_[i]; }
+  void add_data(float v) { data_.push_back(v); }
+  void clear_data() { data_.clear(); }
+  int diff_size() const { return (int)diff_.size(); }
+  float diff(int i) const { return diff_[i]; }
+  void add_diff(float v) { diff_.push_back(v); }
+  void clear_diff() { diff_.clear(); }
+  int double_data_size() const { return (int)double_data_.size(); }
+  double double_data(int i) const { return double_data_[i]; }
+  void add_double_data(double v) { double_data_.push_back(v); }
+  void clear_double_data() { double_data_.clear(); }
+  int double_diff_size() const { return (int)double_diff_.size(); }
+  double double_diff(int i) const { return double_diff_[i]; }
+  void add_double_diff(double v) { double_diff_.push_back(v); }
+  void clear_double_diff() { double_diff_.clear(); }
+ private:
+  BlobShape shape_;
+  bool has_shape_ = false, has_legacy_ = false;
+  int legacy_[4] = {0, 0, 0, 0};
+  std::vector<float> data_, diff_;
+  std::vector<double> double_data_, double_diff_;
+};
+
 
 template <typename T>
 class RepeatedField {
@@ -445,6 +492,12 @@ enum Phase { TRAIN = 0, TEST = 1 };
 
 class LayerParameter {
  public:
+  int blobs_size() const { return (int)blobs_.size(); }                     // = 7: trained blobs carried by the message (layer.hpp:46-52)
+  const BlobProto& blobs(int i) const { return blobs_[i]; }
+  BlobProto* add_blobs() { blobs_.emplace_back(); return &blobs_.back(); }
+  void clear_blobs() { blobs_.clear(); }
+  void Clear() { *this = LayerParameter(); }
+  void CopyFrom(const LayerParameter& o) { *this = o; }
   const std::string& name() const { return name_; }
   const std::string& type() const { return type_; }
   void set_name(const std::string& v) { name_ = v; }
@@ -487,6 +540,7 @@ class LayerParameter {
   AugmentationParameter augmentation_param_;
   CoeffScheduleParameter coeff_schedule_param_;
   std::vector<ParamSpec> param_;
+  std::vector<BlobProto> blobs_;
   std::string name_, type_;
   std::vector<float> loss_weight_;
   bool reshape_every_iter_ = true;

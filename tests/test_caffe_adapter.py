@@ -112,3 +112,16 @@ def test_adapter_is_a_drop_in_for_the_reference_layers(adapter):
     np.testing.assert_allclose(a_top, r_top, rtol=0, atol=2e-6)
     np.testing.assert_allclose(a0, r0, rtol=0, atol=3e-6)
     np.testing.assert_allclose(a1, r1, rtol=0, atol=3e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/caffe"), reason="reference tree not present (GPU box)")
+def test_adapter_compiles_against_the_reference_headers(tmp_path):
+    """fn2_caffe_layers.cpp against include/caffe/layer.hpp:42-53,236-324, blob.hpp, layer_factory.hpp:67-84, common.hpp of the
+    reference itself (its include/ first on the path; only boost / glog / gflags / CUDA / CBLAS and the protoc output are
+    stand-ins): a drift between the runnable stand-in headers (compat/) and the real plug-in interface fails here."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "flownet2_amd", "csrc", "caffe_adapter", "real_headers_check", "check.sh")
+    out = subprocess.run(["bash", script, str(tmp_path / "adapter.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert os.path.getsize(str(tmp_path / "adapter.o")) > 10000
