@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "libflownet2_hip.so")
 # every symbol include/flownet2_hip.h declares
 EXPORTS = [
     "fn2_version", "fn2_last_error_string",
-    "fn2_correlation_out_shape", "fn2_correlation_workspace_bytes", "fn2_correlation_forward", "fn2_correlation_backward",
+    "fn2_correlation_out_shape", "fn2_correlation_workspace_bytes", "fn2_correlation_forward", "fn2_correlation_forward_fused", "fn2_correlation_backward",
     "fn2_correlation1d_out_shape", "fn2_correlation1d_forward", "fn2_correlation1d_backward",
     "fn2_flow_warp_forward", "fn2_flow_warp_backward_workspace_bytes", "fn2_flow_warp_backward",
     "fn2_resample_forward",
@@ -90,6 +90,7 @@ def lib():
     L.fn2_correlation_workspace_bytes.argtypes = [C.POINTER(CorrParams), i, i, i, i]
     L.fn2_correlation_workspace_bytes.restype = sz
     L.fn2_correlation_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_correlation_forward_fused.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, i, i, i, C.c_float, vp, sz, vp]
     L.fn2_correlation_backward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_correlation1d_out_shape.argtypes = [C.POINTER(CorrParams), i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.fn2_correlation1d_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp]

@@ -31,6 +31,7 @@ int corr_geometry(const fn2_corr_params* p, int N, int C, int H, int W, CorrGeom
   g->N = N; g->C = C; g->H = H; g->W = W;
   g->pad = p->pad; g->K = p->kernel_size; g->md = p->max_displacement; g->s1 = p->stride1; g->s2 = p->stride2;
   g->type = p->corr_type;
+  g->relu = 0; g->slope = 0.f; g->top_c0 = 0;
   g->kr = (g->K - 1) / 2;
   const int border = g->md + g->kr;
   g->topW = (int)std::ceil((float)(W + 2 * g->pad - border * 2) / (float)g->s1);
@@ -40,6 +41,7 @@ int corr_geometry(const fn2_corr_params* p, int N, int C, int H, int W, CorrGeom
   g->ngr = g->md / g->s2;
   g->ngw = 2 * g->ngr + 1;
   g->topC = g->ngw * g->ngw;
+  g->top_ctot = g->topC;
   if (g->pad < g->md)
     return fail(FN2_ERR_INVALID_ARG, "correlation: pad (%d) < max_displacement (%d) reads outside the padded blob in the reference; refused", g->pad, g->md);
   return FN2_OK;
@@ -84,7 +86,9 @@ __global__ void __launch_bounds__(256) corr_fwd_generic(const float* __restrict_
         }
       }
     }
-    top[idx] = sum / (float)(g.K * g.K * g.C);
+    float v = sum / (float)(g.K * g.K * g.C);
+    if (g.relu) v = v > 0.f ? v : v * g.slope;
+    top[(((size_t)n * g.top_ctot + g.top_c0 + tc) * g.topH + y) * g.topW + x] = v;
   }
 }
 
@@ -184,10 +188,21 @@ FN2_API int fn2_correlation_out_shape(const fn2_corr_params* p, int C, int H, in
 FN2_API size_t fn2_correlation_workspace_bytes(const fn2_corr_params*, int, int, int, int) { return 0; }
 
 FN2_API int fn2_correlation_forward(const fn2_corr_params* p, const float* bottom0, const float* bottom1, float* top,
-                                    int N, int C, int H, int W, void*, size_t, void* stream) {
+                                    int N, int C, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+  return fn2_correlation_forward_fused(p, bottom0, bottom1, top, N, C, H, W, 0, 0, 0, 0.f, ws, ws_bytes, stream);
+}
+
+FN2_API int fn2_correlation_forward_fused(const fn2_corr_params* p, const float* bottom0, const float* bottom1, float* top,
+                                          int N, int C, int H, int W, int top_channels, int top_c0, int relu, float negative_slope,
+                                          void*, size_t, void* stream) {
   CorrGeom g;
   int rc = corr_geometry(p, N, C, H, W, &g);
   if (rc) return rc;
+  if (top_channels > 0) {
+    if (top_c0 < 0 || top_c0 + g.topC > top_channels) return fail(FN2_ERR_INVALID_ARG, "correlation_forward: channel slice outside the top blob");
+    g.top_ctot = top_channels; g.top_c0 = top_c0;
+  }
+  g.relu = relu != 0; g.slope = negative_slope;
   if (N == 0) return FN2_OK;
   if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation_forward: NULL blob pointer");
   hipStream_t st = as_stream(stream);

@@ -9,6 +9,10 @@ struct CorrGeom {
   int pad, K, md, s1, s2, kr;
   int topC, topH, topW, ngr, ngw;
   int type;
+  // fused epilogue (fn2_correlation_forward_fused): the top blob may be a channel slice [top_c0, top_c0 + topC) of a blob with
+  // top_ctot channels, and the in-place ReLU that follows the layer in the FlowNetC graph can be applied on the way out
+  int top_ctot, top_c0, relu;
+  float slope;
 };
 
 bool corr_fwd_mfma_supported(const CorrGeom& g);

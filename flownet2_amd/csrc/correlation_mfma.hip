@@ -66,6 +66,8 @@ struct MfmaArgs {
   int NI, NSPAN;        // M patch rows per y-parity class, x spans
   int TH, TD;           // live / dead tasks per sample
   int LP, DP;           // live / dead list entries per XCD
+  int ctot, c0;         // top blob: channels of the whole blob, first channel of the D*D slice this layer writes
+  int relu; float slope;   // fused ReLU{negative_slope} on the way out
 };
 
 // live N patch-rows of M patch-row I: a in [alo, ahi] (may be empty)
@@ -164,7 +166,11 @@ __device__ __forceinline__ void epilogue(const Acc& acc, float* smem, float* __r
     for (int r = 0; r < 4; ++r) {         // reg r <-> mj
       const int oo = 4 * b + nj - r;      // o + R
       if (oo >= 0 && oo < K::D)
-        smem[((mi * 4 + ni) * K::D + oo) * K::XS + S2 * (4 * Jw + r) + px] = pow2 ? acc[b][r] * rcp : acc[b][r] / sumelems;
+      {
+        float v = pow2 ? acc[b][r] * rcp : acc[b][r] / sumelems;
+        if (g.relu) v = v > 0.f ? v : v * g.slope;
+        smem[((mi * 4 + ni) * K::D + oo) * K::XS + S2 * (4 * Jw + r) + px] = v;
+      }
     }
   }
   __syncthreads();
@@ -176,7 +182,7 @@ __device__ __forceinline__ void epilogue(const Acc& acc, float* smem, float* __r
   if (x < g.W && STORE) {
     const unsigned plane = (unsigned)g.H * (unsigned)g.W;
     const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
-        top + (size_t)k.n * K::D * K::D * plane, 0, 4u * K::D * K::D * plane, 0x00020000);
+        top + ((size_t)k.n * g.ctot + g.c0) * plane, 0, 4u * K::D * K::D * plane, 0x00020000);
     const unsigned hw4 = 4u * plane, w4 = 4u * (unsigned)g.W;
     constexpr int STEP = kThreads / K::SPANPX;
     int rowid = tid / K::SPANPX, rmi = 0, rni = 0, oo = rowid;
@@ -646,7 +652,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const float* a_n = b0 + (size_t)k.n * g.C * plane;
   const float* b_n = b1 + (size_t)k.n * g.C * plane;
   const int i2_0 = i0 - R + 4 * k.a;
-  const size_t top_n = (size_t)k.n * K::D * K::D;
+  const size_t top_n = (size_t)k.n * g.ctot + g.c0;
 
   // Output rows of this task: rowid = (rmi * 4 + rni) * D + oo  <->  top[n, (qq = 4a + rni - rmi, oo), y = 2 (4I + rmi) + py,
   // 32-pixel span].  8 threads x 16 bytes per row, 32 rows per pass; offsets are 32-bit inside the sample's output
@@ -729,8 +735,10 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
         const int oo = 4 * b + nj - r;
         if (oo >= 0 && oo < K::D) {
           float* dst = smem + ((mi * 4 + ni) * K::D + oo) * K::XS + 2 * (4 * Jw + r);
-          dst[0] = acc0[b][r];
-          dst[1] = acc1[b][r];
+          float v0 = acc0[b][r], v1 = acc1[b][r];
+          if (g.relu) { v0 = v0 > 0.f ? v0 : v0 * g.slope; v1 = v1 > 0.f ? v1 : v1 * g.slope; }
+          dst[0] = v0;
+          dst[1] = v1;
         }
       }
     }
@@ -759,6 +767,7 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   using K = Cfg<S2, R>;
   MfmaArgs g;
   g.N = cg.N; g.C = cg.C; g.H = cg.H; g.W = cg.W;
+  g.ctot = cg.top_ctot; g.c0 = cg.top_c0; g.relu = cg.relu; g.slope = cg.slope;
   const int Hc = (cg.H + S2 - 1) / S2, Wc = (cg.W + S2 - 1) / S2;
   g.NI = (Hc + 3) / 4;
   g.NSPAN = (Wc + K::SPANC - 1) / K::SPANC;

@@ -34,6 +34,16 @@ def correlation(b0, b1, pad=0, kernel_size=1, max_displacement=0, stride_1=1, st
     return _Correlation.apply(b0.contiguous(), b1.contiguous(), p)
 
 
+def correlation_relu_into(b0, b1, out, out_c0, negative_slope, pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1):
+    """Correlation + ReLU{negative_slope} written into the channel slice [out_c0, out_c0 + topC) of `out`: the cost volume lands
+    in the [conv_redir | corr] blob conv3_1 reads, without the separate activation and concat passes.  Inference only
+    (returns None when autograd needs the unfused graph)."""
+    if torch.is_grad_enabled() and (b0.requires_grad or b1.requires_grad):
+        return None
+    p = ops.corr_params(pad, kernel_size, max_displacement, stride_1, stride_2, ops.MULTIPLY)
+    return ops.correlation_forward(p, b0.contiguous(), b1.contiguous(), out=out, out_c0=out_c0, relu=True, negative_slope=negative_slope)
+
+
 class _FlowWarp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, flow, fill_value):

@@ -180,10 +180,20 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     c2 = _conv(c1, P, "conv2", 2, 2, backend=backend)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
     c3a, c3b = c3[:n], c3[n:]
-    corr = backend.correlation(c3a, c3b, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
-    corr = F.leaky_relu(corr, NEG_SLOPE)
     redir = _conv(c3a, P, "conv_redir", 1, 0, backend=backend)
-    c31 = _conv(torch.cat([redir, corr], 1), P, "conv3_1", 1, 1, backend=backend)
+    cat = None
+    if hasattr(backend, "correlation_relu_into") and c3a.is_cuda:
+        # the correlation writes its 441 activated planes straight into the [conv_redir | corr] blob (no ReLU pass, no Concat pass)
+        cat = torch.empty((n, redir.shape[1] + 441, c3a.shape[2], c3a.shape[3]), device=c3a.device, dtype=c3a.dtype)
+        if backend.correlation_relu_into(c3a, c3b, cat, redir.shape[1], NEG_SLOPE, pad=20, kernel_size=1, max_displacement=20,
+                                         stride_1=1, stride_2=2) is None:
+            cat = None
+        else:
+            cat[:, :redir.shape[1]].copy_(redir)
+    if cat is None:
+        corr = backend.correlation(c3a, c3b, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
+        cat = torch.cat([redir, F.leaky_relu(corr, NEG_SLOPE)], 1)
+    c31 = _conv(cat, P, "conv3_1", 1, 1, backend=backend)
     c4 = _conv(c31, P, "conv4", 2, 1, backend=backend)
     c41 = _conv(c4, P, "conv4_1", 1, 1, backend=backend)
     c5 = _conv(c41, P, "conv5", 2, 1, backend=backend)

@@ -48,15 +48,22 @@ def correlation_out_shape(p: CorrParams, Cc: int, H: int, W: int):
     return tc.value, th.value, tw.value
 
 
-def correlation_forward(p: CorrParams, bottom0: torch.Tensor, bottom1: torch.Tensor, out: torch.Tensor | None = None):
+def correlation_forward(p: CorrParams, bottom0: torch.Tensor, bottom1: torch.Tensor, out: torch.Tensor | None = None,
+                        out_c0: int = 0, relu: bool = False, negative_slope: float = 0.0):
+    """top = Correlation(bottom0, bottom1).  With `out` wider than topC channels the layer writes the slice
+    [out_c0, out_c0 + topC) of it (the Concat that follows it in FlowNetC); relu applies ReLU{negative_slope} on the way out."""
     b0, b1 = _chk(bottom0, "bottom[0]"), _chk(bottom1, "bottom[1]")
     if b0.shape != b1.shape:   # correlation_layer.cpp:45-47
         raise ValueError("Both bottom blobs must have same shape")
     N, Cc, H, W = b0.shape
     tc, th, tw = correlation_out_shape(p, Cc, H, W)
     top = out if out is not None else torch.empty((N, tc, th, tw), device=b0.device, dtype=torch.float32)
-    assert top.is_contiguous() and tuple(top.shape) == (N, tc, th, tw)
-    check(_lib.lib().fn2_correlation_forward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(top), N, Cc, H, W, None, 0, _stream()))
+    assert top.is_contiguous() and top.shape[0] == N and tuple(top.shape[2:]) == (th, tw) and out_c0 + tc <= top.shape[1]
+    if not relu and out_c0 == 0 and top.shape[1] == tc:
+        check(_lib.lib().fn2_correlation_forward(C.byref(p), _ptr(b0), _ptr(b1), _ptr(top), N, Cc, H, W, None, 0, _stream()))
+    else:
+        check(_lib.lib().fn2_correlation_forward_fused(C.byref(p), _ptr(b0), _ptr(b1), _ptr(top), N, Cc, H, W, int(top.shape[1]), int(out_c0),
+                                                       int(bool(relu)), C.c_float(float(negative_slope)), None, 0, _stream()))
     return top
 
 

@@ -80,6 +80,15 @@ int fn2_correlation_forward(const fn2_corr_params* p,
                             const float* bottom0, const float* bottom1, float* top,
                             int N, int C, int H, int W,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same forward with the two passes that follow the layer in the FlowNetC graph folded into its epilogue:
+ *   - the in-place ReLU{negative_slope} on the cost volume (ReLULayer::Forward_gpu, relu_layer.cu:8-27) when relu != 0;
+ *   - the Concat with conv_redir (ConcatLayer::Forward_gpu, concat_layer.cu:8-52): the top is written as the channel slice
+ *     [top_c0, top_c0 + topC) of a blob with top_channels channels (top_channels = 0: a plain [N, topC, topH, topW] top).
+ * Same arithmetic as fn2_correlation_forward followed by those layers (the ReLU is applied to the final value). */
+int fn2_correlation_forward_fused(const fn2_corr_params* p,
+                                  const float* bottom0, const float* bottom1, float* top,
+                                  int N, int C, int H, int W, int top_channels, int top_c0, int relu, float negative_slope,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 /* Writes (overwrites) both bottom diffs; like the reference it ignores propagate_down
  * (correlation_layer.cu:508-603).  Either diff pointer may be NULL to skip that half. */
 int fn2_correlation_backward(const fn2_corr_params* p,

@@ -912,6 +912,30 @@ FN2_API int fn2_conv_k7s2_relu_forward_cpu(const float* in, const float* weight,
 }
 
 
+/* Correlation followed by the in-place ReLU (relu_layer.cu:8-27) and written as a channel slice of a wider blob (the Concat that
+ * follows it, concat_layer.cu:8-52): the checker of fn2_correlation_forward_fused, composed from the plain forward above. */
+FN2_API int fn2_correlation_forward_fused_cpu(const fn2_corr_params* p, const float* bottom0, const float* bottom1, float* top,
+                                              int N, int C, int H, int W, int top_channels, int top_c0, int relu, float negative_slope) {
+  int tc, th, tw;
+  int rc = fn2_correlation_out_shape_cpu(p, C, H, W, &tc, &th, &tw);
+  if (rc) return rc;
+  if (top_channels <= 0) { top_channels = tc; top_c0 = 0; }
+  if (top_c0 < 0 || top_c0 + tc > top_channels) return FN2_ERR_INVALID_ARG;
+  const size_t per = (size_t)tc * th * tw;
+  float* tmp = (float*)malloc(sizeof(float) * per * (size_t)(N > 0 ? N : 1));
+  if (!tmp) return FN2_ERR_WORKSPACE;
+  rc = fn2_correlation_forward_cpu(p, bottom0, bottom1, tmp, N, C, H, W);
+  if (!rc)
+    for (int n = 0; n < N; ++n)
+      for (size_t i = 0; i < per; ++i) {
+        float v = tmp[(size_t)n * per + i];
+        if (relu) v = v > 0.f ? v : v * negative_slope;
+        top[((size_t)n * top_channels + top_c0) * th * tw + i] = v;
+      }
+  free(tmp);
+  return rc;
+}
+
 /* Direct convolution + bias + optional ReLU on PACKED weights: the CPU twin of csrc/conv_mfma.hip.
  * Reference arithmetic: Convolution{kernel_size, stride, pad} (conv_layer.cpp:25-40 / base_conv_layer.cpp:255-318: im2col + GEMM +
  * bias) and the in-place ReLU (relu_layer.cpp:23-30).  The reference's SGEMM summation order is library-defined; the HIP kernel

@@ -718,3 +718,32 @@ def test_training_gradients_fused_path_matches_stock_ops():
     assert (num / den) ** 0.5 <= 2e-3, f"all gradients together: relative L2 error {(num / den) ** 0.5:.3e}"
     assert float(np.median(list(rel.values()))) <= 1e-4, f"median relative L2 error {float(np.median(list(rel.values()))):.3e}"
     assert rel[worst] <= 5e-2, f"{worst}: relative L2 error {rel[worst]:.3e}"
+
+
+@pytest.mark.parametrize("case", [(2, 64, 24, 40, 20, 1, 20, 1, 2, 0), (1, 16, 12, 16, 4, 1, 4, 1, 1, 0), (1, 8, 11, 13, 4, 3, 2, 1, 2, 1),
+                                  (2, 256, 16, 24, 20, 1, 20, 1, 2, 0)])
+def test_correlation_fused_relu_and_channel_slice(case):
+    """fn2_correlation_forward_fused = Correlation + in-place ReLU{0.1} + Concat slice (relu_layer.cu:8-27, concat_layer.cu:8-52):
+    bit-identical to the same kernel family followed by those passes, and equal to the oracle's composition."""
+    import ctypes as C
+    N, Cc, H, W, pad, K, md, s1, s2, t = case
+    b0, b1 = rand((N, Cc, H, W), 31), rand((N, Cc, H, W), 32)
+    p = ops.corr_params(pad, K, md, s1, s2, t)
+    try:
+        for impl in (0, 1, 3):               # automatic, generic kernel, general (dword LDS-DMA) MFMA kernel
+            ops.set_correlation_impl(impl)
+            plain = ops.correlation_forward(p, dev(b0), dev(b1))
+            tc = plain.shape[1]
+            out = torch.full((N, tc + 7, plain.shape[2], plain.shape[3]), 5.0, device="cuda")
+            ops.correlation_forward(p, dev(b0), dev(b1), out=out, out_c0=4, relu=True, negative_slope=0.1)
+            assert torch.equal(out[:, 4:4 + tc], torch.nn.functional.leaky_relu(plain, 0.1)), impl
+            assert bool((out[:, :4] == 5).all()) and bool((out[:, 4 + tc:] == 5).all())
+    finally:
+        ops.set_correlation_impl(0)
+    fp = C.POINTER(C.c_float)
+    top = np.full(tuple(out.shape), 5.0, np.float32)
+    po = oracle.corr_params(pad, K, md, s1, s2, t)
+    rc = oracle.lib().fn2_correlation_forward_fused_cpu(C.byref(po), b0.ctypes.data_as(fp), b1.ctypes.data_as(fp), top.ctypes.data_as(fp),
+                                                        N, Cc, H, W, tc + 7, 4, 1, C.c_float(0.1))
+    assert rc == 0
+    assert_close(out.cpu().numpy(), top, 2e-6)
