@@ -26,6 +26,8 @@ EXPORTS = [
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
     "fn2_conv_mfma_num_variants", "fn2_debug_set_conv_variant",
     "fn2_caffemodel_index", "fn2_caffemodel_read_blob",
+    "fn2_conv_wino_supported", "fn2_conv_wino_packed_floats", "fn2_conv_wino_pack_weights", "fn2_conv_wino_forward",
+    "fn2_conv_wino_num_variants", "fn2_debug_set_wino_variant",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
@@ -125,6 +127,12 @@ def lib():
     L.fn2_conv_mfma_pack_weights.argtypes = [fp, fp, i, i, i, vp]
     L.fn2_conv_mfma_forward.argtypes = [fp, fp, fp, fp] + [i] * 13 + [C.c_float, vp]
     L.fn2_debug_set_conv_variant.argtypes = [i]
+    L.fn2_conv_wino_supported.argtypes = [i] * 5
+    L.fn2_conv_wino_packed_floats.argtypes = [i, i]
+    L.fn2_conv_wino_packed_floats.restype = sz
+    L.fn2_conv_wino_pack_weights.argtypes = [fp, fp, i, i, vp]
+    L.fn2_conv_wino_forward.argtypes = [fp, fp, fp, fp] + [i] * 11 + [C.c_float, vp]
+    L.fn2_debug_set_wino_variant.argtypes = [i]
     L.fn2_caffemodel_index.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), i, C.POINTER(C.c_int)]
     L.fn2_caffemodel_read_blob.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), fp, sz]
     ip = C.POINTER(C.c_int)

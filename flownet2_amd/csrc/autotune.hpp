@@ -1,0 +1,64 @@
+// First-use selection among kernel variants that produce identical results: every candidate is timed once on the caller's
+// own arguments (the output is simply written several times) and the fastest is remembered per problem shape.
+// Falls back to the caller's cost model while the stream is being captured into a graph (no host synchronisation allowed there)
+// or when FN2_AUTOTUNE=0.
+#pragma once
+#include <array>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+#include "fn2_common.hpp"
+
+namespace fn2 {
+
+using TuneKey = std::array<int, 10>;
+
+struct TuneCache {
+  std::mutex mu;
+  std::map<TuneKey, int> best;
+};
+
+inline bool autotune_enabled(hipStream_t st) {
+  static const bool on = [] { const char* e = std::getenv("FN2_AUTOTUNE"); return !(e && e[0] == '0'); }();
+  if (!on) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  return true;
+}
+
+// run(candidate) launches one candidate and returns FN2_OK, or a non-zero status if it does not apply (skipped).
+// Returns the chosen candidate (cached), or -1 if none could be timed.
+template <class Run>
+int autotune_pick(TuneCache& cache, const TuneKey& key, int ncand, hipStream_t st, Run run) {
+  {
+    std::lock_guard<std::mutex> lk(cache.mu);
+    auto it = cache.best.find(key);
+    if (it != cache.best.end()) return it->second;
+  }
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return -1;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return -1; }
+  int best = -1;
+  float best_ms = 0.f;
+  for (int c = 0; c < ncand; ++c) {
+    if (run(c) != FN2_OK) { (void)hipGetLastError(); continue; }      // warm-up launch (also: does it apply at all)
+    (void)hipEventRecord(e0, st);
+    run(c); run(c);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+    if (best < 0 || ms < best_ms) { best = c; best_ms = ms; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  last_error().clear();
+  if (best >= 0) {
+    std::lock_guard<std::mutex> lk(cache.mu);
+    cache.best[key] = best;
+  }
+  return best;
+}
+
+}  // namespace fn2

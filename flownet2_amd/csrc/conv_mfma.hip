@@ -21,6 +21,7 @@
 //   * wave tile = MW channel groups x NP patches (MW * NP accumulator tiles), workgroup = WM x WNX x WNY waves.
 //   * epilogue: the MFMA result layout hands every lane 4 consecutive x of one output channel: bias + leaky ReLU + 16-byte store.
 #include "fn2_common.hpp"
+#include "autotune.hpp"
 
 #include <mutex>
 #include <type_traits>
@@ -425,12 +426,28 @@ FN2_API int fn2_conv_mfma_forward(const float* bottom, const float* packed_weigh
     if (best >= cv::kNumVariants || !cv::variant_applies(cv::kVariants[best], a, kernel, stride) || (tail && !cv::kVariants[best].fn_tail))
       return fail(FN2_ERR_UNSUPPORTED, "conv_mfma: forced variant %d does not apply", cv::g_forced_variant);
   } else {
-    double bc = 0;
-    for (int i = 0; i < cv::kNumVariants; ++i) {
-      if (!cv::variant_applies(cv::kVariants[i], a, kernel, stride)) continue;
-      for (int t = 0; t < (cv::kVariants[i].fn_tail ? 2 : 1); ++t) {
-        const double c = cv::variant_cost(cv::kVariants[i], a, t == 1);
-        if (best < 0 || c < bc) { best = i; bc = c; tail = t == 1; }
+    hipStream_t st = as_stream(stream);
+    int picked = -1;
+    if (autotune_enabled(st)) {
+      // candidates 2 i / 2 i + 1 = plain / split-tail launch of variant i; all of them write the same bits
+      static TuneCache cache;
+      const TuneKey key{N, Cin, Hin, Win, Cout, kernel, stride, pad, bottom_channels == Cin, top_channels == Cout};
+      picked = autotune_pick(cache, key, 2 * cv::kNumVariants, st, [&](int c) -> int {
+        const cv::Variant& v = cv::kVariants[c / 2];
+        if (!cv::variant_applies(v, a, kernel, stride)) return FN2_ERR_UNSUPPORTED;
+        if (c & 1) return (v.fn_tail && cv::variant_cost(v, a, true) < 1e29) ? v.fn_tail(a, st) : FN2_ERR_UNSUPPORTED;
+        return v.fn(a, st);
+      });
+    }
+    if (picked >= 0) { best = picked / 2; tail = (picked & 1) != 0; }
+    else {
+      double bc = 0;
+      for (int i = 0; i < cv::kNumVariants; ++i) {
+        if (!cv::variant_applies(cv::kVariants[i], a, kernel, stride)) continue;
+        for (int t = 0; t < (cv::kVariants[i].fn_tail ? 2 : 1); ++t) {
+          const double c = cv::variant_cost(cv::kVariants[i], a, t == 1);
+          if (best < 0 || c < bc) { best = i; bc = c; tail = t == 1; }
+        }
       }
     }
   }

@@ -1,0 +1,455 @@
+// 3x3 / stride 1 convolution + bias + ReLU as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate).
+//
+// Reference: ConvolutionLayer::Forward_gpu (src/caffe/layers/conv_layer.cu:8-23: im2col + cublasSgemm per sample, then
+// forward_gpu_bias, base_conv_layer.cpp:326-348) + the in-place ReLU (relu_layer.cu:8-27), for kernel_size 3, stride 1.
+// Same contraction with 2.25x fewer multiplies (Lavin & Gray's minimal filtering, the algorithm MIOpen's fp32 Winograd kernels
+// and cuDNN use for this layer class):
+//     Y = A^T [ sum_c (G g_c G^T) (.) (B^T d_c B) ] A          per 2x2 output tile, d = the 4x4 input patch under it
+// The 16 element-wise products are 16 independent [tiles x channels] x [channels x Cout] GEMMs -- one MFMA accumulator tile per
+// Winograd position:  rows = 16 output TILES (a TGY x TGX block of 2x2 tiles), columns = 16 output channels, k = 4 channels.
+//   * d: the input window of the workgroup tile arrives by 16-byte LDS-DMA in natural [channel][row][column] order (zero padding
+//     = out-of-range for the buffer descriptor); every lane (tile, kq) reads its 4x4 patch of channel 4 cq + kq as aligned
+//     8-byte pairs and applies B^T . B in registers (32 add / sub) -> its 16 A operands.
+//   * U = G g G^T is precomputed once per weight blob (fn2_conv_wino_pack_weights) in MFMA operand order
+//     [Cout/16][channel quad][position quad][lane][4] and staged through LDS next to the window (one 4 KiB slab per channel
+//     quad, shared by the 4 waves of a workgroup, which own different pixels of the same 16 output channels).
+//   * the result layout hands every lane the 16 positions of 4 horizontally adjacent tiles of one channel: A^T . A in registers,
+//     bias + ReLU, two 16-byte stores per output row.
+// Numerics: exact fp32 products and k-ordered fma chains per position; the transforms add rounding of a few ulp of the largest
+// patch element (measured against the reference's Convolution layer and fp64 in tests/test_conv_wino.py).  The oracle twin
+// (oracle/fn2_oracle.c: fn2_conv_wino_forward_cpu) performs the same operations in the same order: bit-identical.
+#include "fn2_common.hpp"
+#include "autotune.hpp"
+
+namespace fn2 {
+namespace wino {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int up_mod(int v, int r, int m) { return v + ((r - v % m) + m) % m; }
+
+struct Args {
+  const float* in; const float* up; const float* bias; float* out;
+  int N, Cin, Hin, Win, in_ctot, in_c0;
+  int Cout, Hout, Wout, out_ctot, out_c0;
+  int nchunks, kquads;     // chunks of CQ channel quads; quads per output-channel group in the packed weights (incl. padding)
+  int tx, ty, ng;          // workgroup tiles per sample along x / y; output-channel groups (Cout / 16)
+  unsigned total, nbig;    // tiles; split-tail launch: tiles that run whole (multiple of 256), the rest as two x-halves (MT / 2)
+  float slope; int relu;
+};
+
+constexpr int kCQ = 2;     // channel quads per chunk (weights are padded to whole chunks)
+constexpr int kPad = 1;    // the only padding instantiated (3x3 "same" convolution)
+
+template <int TGY_, int TGX_, int MT_, int WNY_, int WNX_>
+struct Cfg {
+  static constexpr int TGY = TGY_, TGX = TGX_, MT = MT_, WNY = WNY_, WNX = WNX_, CQ = kCQ;
+  static constexpr int NW = WNY * WNX;
+  static constexpr int PADL = 4;
+  static constexpr int TH = 2 * TGY * WNY, TW = 2 * TGX * MT * WNX;     // output pixels of a workgroup tile
+  static constexpr int WR = TH + 2, WC = TW + 2 + PADL;                 // window rows / columns (columns from x0 - PADL)
+  static constexpr int RS = up_mod(cdiv(WC, 4) * 4, TGX == 8 ? 8 : 4, 16);
+  static constexpr int CS = up_mod(WR * RS, 32, 64);
+  static constexpr int URUN = 4 * CQ;                                   // 1 KiB runs of U per chunk (4 per channel quad)
+  static constexpr int WSLOTS = 4 * CQ * CS / 4;
+  static constexpr int WRUN = cdiv(WSLOTS, 64);
+  static constexpr int NRUN = URUN + WRUN;
+  static constexpr int RPW = cdiv(NRUN, NW);
+  static constexpr int BUF = NRUN * 256;                                // dwords per buffer: [U | window]
+  static constexpr int WOFF = URUN * 256;
+  static_assert(NW == 4 && TGY * TGX == 16 && 2 * BUF * 4 <= 160 * 1024, "workgroup shape");
+};
+
+// LDS-DMA of one chunk: runs [0, URUN) = the chunk's U slab (a linear copy), runs [URUN, NRUN) = the input window.
+// (A __device__ function, not a lambda: the host pass of a __global__ template cannot see amdgcn builtins inside a lambda body.)
+template <class K>
+__device__ __forceinline__ void stage_chunk(__amdgpu_buffer_rsrc_t rsU, __amdgpu_buffer_rsrc_t rsW, const unsigned (&voff)[K::RPW], unsigned dst,
+                                            int wave, unsigned soff_u, unsigned soff_w) {
+#pragma unroll
+  for (int i = 0; i < K::RPW; ++i) {
+    const int r = i * K::NW + wave;
+    if (r < K::NRUN) {
+      lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)r);
+      if (r < K::URUN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, lp, 16, voff[i], soff_u, 0, 0);
+      else             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lp, 16, voff[i], soff_w, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// One workgroup tile: 16 output channels (group g) x TH x TW pixels of sample n.
+template <class K>
+__device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, int n) {
+  constexpr int MT = K::MT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wnx = wave % K::WNX, wny = wave / K::WNX;
+  const int x0 = bx * K::TW, y0 = by * K::TH;
+
+  const size_t plane = (size_t)a.Hin * a.Win;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + ((size_t)n * a.in_ctot + a.in_c0) * plane), 0, (unsigned)(4u * a.Cin * plane), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.up + (size_t)g * a.kquads * 1024), 0, (unsigned)(4096u * a.kquads), 0x00020000);
+  constexpr unsigned OOB = 0x7ffffff0u;
+  unsigned voff[K::RPW];
+#pragma unroll
+  for (int i = 0; i < K::RPW; ++i) {
+    const int r = i * K::NW + wave;
+    voff[i] = OOB;
+    if (r < K::URUN) voff[i] = 16u * (unsigned)(r * 64 + lane);
+    else if (r < K::NRUN) {
+      const int s = (r - K::URUN) * 64 + lane;
+      const int c = s / (K::CS / 4), rem = s % (K::CS / 4);
+      const int row = rem / (K::RS / 4), gq = rem % (K::RS / 4);
+      const int yi = y0 - kPad + row, xi = x0 - K::PADL + 4 * gq;
+      if (c < 4 * K::CQ && row < K::WR && 4 * gq < K::WC && yi >= 0 && yi < a.Hin && xi >= 0 && xi < a.Win)
+        voff[i] = 4u * (unsigned)(c * plane + (size_t)yi * a.Win + xi);
+    }
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  const unsigned chunk_w = 16u * K::CQ * (unsigned)plane, chunk_u = 4096u * K::CQ;
+
+  // ---- operands: lane (tile t16 = (ty, tx) of the TGY x TGX block, kq)
+  const int kq = lane >> 4, t16 = lane & 15;
+  const int ty = K::TGX == 8 ? t16 >> 3 : t16 >> 2, tx = K::TGX == 8 ? t16 & 7 : t16 & 3;
+  // patch column j of this lane <-> window column 2 * (global tile column) + PADL - pad + j; dcol = that for j = -1: even,
+  // so the patch is the middle four of the three aligned pairs (dcol, +1), (+2, +3), (+4, +5)
+  const int dcol = 2 * (K::TGX * MT * wnx + tx) + K::PADL - kPad - 1;
+  const int dbase = K::WOFF + kq * K::CS + (2 * (K::TGY * wny + ty)) * K::RS + dcol;
+
+  f32x4 acc[MT][16];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[m][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_chunk<K>(rsU, rsW, voff, lds_base, wave, 0u, 0u);
+  for (int c = 0; c < a.nchunks; ++c) {
+    const int buf = c & 1;
+    wait_vm0();                              // this wave's part of chunk c (issued one chunk ago) has landed
+    __builtin_amdgcn_s_barrier();            // ... and everybody's; everybody is also done reading the other buffer
+    if (c + 1 < a.nchunks)
+      stage_chunk<K>(rsU, rsW, voff, lds_base + 4u * (unsigned)((buf ^ 1) * K::BUF), wave, (unsigned)(c + 1) * chunk_u, (unsigned)(c + 1) * chunk_w);
+    const float* sb = smem + buf * K::BUF;
+#pragma unroll
+    for (int q = 0; q < K::CQ; ++q) {
+      // B operands: U[position][16 channels of the group][channel 4 q + kq] for the 16 positions, 4 per 16-byte read
+      f32x4 u[4];
+#pragma unroll
+      for (int pq = 0; pq < 4; ++pq) u[pq] = *reinterpret_cast<const f32x4*>(sb + (q * 4 + pq) * 256 + lane * 4);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        // the 4x4 patch of channel 4 q + kq under tile (ty, tx) of block m, then V = B^T d B
+        const float* dp = sb + dbase + q * 4 * K::CS + m * 2 * K::TGX;
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 p0 = *reinterpret_cast<const f32x2*>(dp + i * K::RS);
+          const f32x2 p1 = *reinterpret_cast<const f32x2*>(dp + i * K::RS + 2);
+          const f32x2 p2 = *reinterpret_cast<const f32x2*>(dp + i * K::RS + 4);
+          d[i][0] = p0[1]; d[i][1] = p1[0]; d[i][2] = p1[1]; d[i][3] = p2[0];
+        }
+        float w[4][4], v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w[0][j] = d[0][j] - d[2][j];
+          w[1][j] = d[1][j] + d[2][j];
+          w[2][j] = d[2][j] - d[1][j];
+          w[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i][0] = w[i][0] - w[i][2];
+          v[i][1] = w[i][1] + w[i][2];
+          v[i][2] = w[i][2] - w[i][1];
+          v[i][3] = w[i][1] - w[i][3];
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+          acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p >> 2][p & 3], u[p >> 2][p & 3], acc[m][p], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (tile-row block rb = lane >> 4, channel lane & 15) holds, per position, the 4 tiles rb * 4 + r:
+  // block row trow, 4 consecutive tile columns tc0 .. tc0 + 3 -> Y = A^T M A per tile: 2 output rows x 8 consecutive columns
+  const int rb = lane >> 4;
+  const int trow = K::TGX == 8 ? rb >> 1 : rb, tc0 = K::TGX == 8 ? 4 * (rb & 1) : 0;
+  const int co = 16 * g + (lane & 15);
+  const float bv = a.bias ? a.bias[co] : 0.f;
+  const int oy = y0 + 2 * (K::TGY * wny + trow);
+  float* oplane = a.out + ((size_t)n * a.out_ctot + a.out_c0 + co) * a.Hout * a.Wout;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int ox = x0 + 2 * (K::TGX * (MT * wnx + m) + tc0);
+    float y[2][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float t[2][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t[0][k] = acc[m][k][r] + acc[m][4 + k][r] + acc[m][8 + k][r];
+        t[1][k] = acc[m][4 + k][r] - acc[m][8 + k][r] - acc[m][12 + k][r];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        y[h][2 * r] = t[h][0] + t[h][1] + t[h][2];
+        y[h][2 * r + 1] = t[h][1] - t[h][2] - t[h][3];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (oy + h >= a.Hout) continue;
+      float* orow = oplane + (size_t)(oy + h) * a.Wout;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s = y[h][e] + bv;
+        if (a.relu) s = s > 0.f ? s : s * a.slope;
+        y[h][e] = s;
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int x = ox + 4 * half;
+        if (x + 3 < a.Wout) *reinterpret_cast<f32x4*>(orow + x) = f32x4{y[h][4 * half], y[h][4 * half + 1], y[h][4 * half + 2], y[h][4 * half + 3]};
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (x + e < a.Wout) orow[x + e] = y[h][4 * half + e];
+        }
+      }
+    }
+  }
+}
+
+// Task list: (sample, tile row, tile column, channel group), channel group fastest, cut into 8 contiguous ranges, one per XCD.
+__device__ __forceinline__ void decode_tile(const Args& a, unsigned t, int& g, int& bx, int& by, int& n) {
+  g = t % a.ng; t /= a.ng;
+  bx = t % a.tx; t /= a.tx;
+  by = t % a.ty;
+  n = t / a.ty;
+}
+
+template <class K>
+__global__ void __launch_bounds__(256, 2)
+conv_wino(Args a) {
+  const unsigned per_xcd = (a.total + 7) / 8;
+  const unsigned t = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= per_xcd || t >= a.total) return;
+  int g, bx, by, n;
+  decode_tile(a, t, g, bx, by, n);
+  wino_body<K>(a, g, bx, by, n);
+}
+
+// Split tail (see conv_mfma.hip): whole rounds of tiles run as they are, every remaining tile as two workgroups of half the
+// width (MT / 2 tile blocks per wave).  Same arithmetic per output element: same bits.
+template <class K>
+__global__ void __launch_bounds__(256, 2)
+conv_wino_tail(Args a) {
+  using KH = Cfg<K::TGY, K::TGX, K::MT / 2, K::WNY, K::WNX>;
+  int g, bx, by, n;
+  if (blockIdx.x < a.nbig) {
+    const unsigned t = (blockIdx.x % 8) * (a.nbig / 8) + blockIdx.x / 8;
+    decode_tile(a, t, g, bx, by, n);
+    wino_body<K>(a, g, bx, by, n);
+  } else {
+    const unsigned b = blockIdx.x - a.nbig, nsm = 2 * (a.total - a.nbig), per_xcd = (nsm + 7) / 8;
+    const unsigned u = (b % 8) * per_xcd + b / 8;
+    if (b / 8 >= per_xcd || u >= nsm) return;
+    decode_tile(a, a.nbig + u / 2, g, bx, by, n);
+    wino_body<KH>(a, g, 2 * bx + (int)(u & 1), by, n);
+  }
+}
+
+// weight [Cout][Cin][3][3] -> U = G g G^T in MFMA operand order [Cout/16][quads][position quad][lane][4]
+// (lane = 16 kq + co, element e of position quad pq = position 4 pq + e = (xi, nu) = (pq, e)), zero beyond Cin.
+__device__ __host__ inline void wino_u(const float g[3][3], float U[4][4]) {
+  float tmp[4][3];
+  for (int k = 0; k < 3; ++k) {
+    tmp[0][k] = g[0][k];
+    tmp[1][k] = ((g[0][k] + g[1][k]) + g[2][k]) * 0.5f;
+    tmp[2][k] = ((g[0][k] - g[1][k]) + g[2][k]) * 0.5f;
+    tmp[3][k] = g[2][k];
+  }
+  for (int i = 0; i < 4; ++i) {
+    U[i][0] = tmp[i][0];
+    U[i][1] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) * 0.5f;
+    U[i][2] = ((tmp[i][0] - tmp[i][1]) + tmp[i][2]) * 0.5f;
+    U[i][3] = tmp[i][2];
+  }
+}
+
+__global__ void pack_u(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int kquads) {
+  const long long total = (long long)(Cout / 16) * kquads * 64;       // one thread per (group, quad, lane)
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long r = i >> 6;
+    const int cq = (int)(r % kquads), grp = (int)(r / kquads);
+    const int co = 16 * grp + (lane & 15), ci = 4 * cq + (lane >> 4);
+    float g[3][3], U[4][4];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) g[a][b] = ci < Cin ? w[((size_t)co * Cin + ci) * 9 + a * 3 + b] : 0.f;
+    wino_u(g, U);
+    float* dst = up + ((size_t)grp * kquads + cq) * 1024 + lane * 4;
+    for (int pq = 0; pq < 4; ++pq)
+      for (int e = 0; e < 4; ++e) dst[pq * 256 + e] = U[pq][e];
+  }
+}
+
+inline int kquads_for(int Cin) { return cdiv(cdiv(Cin, 4), kCQ) * kCQ; }
+
+template <class K>
+static void set_geometry(Args& a) {
+  a.tx = cdiv(a.Wout, K::TW); a.ty = cdiv(a.Hout, K::TH);
+  a.ng = a.Cout / 16;
+  a.nchunks = a.kquads / K::CQ;
+}
+inline long long tiles_of(const Args& a) { return (long long)a.N * a.tx * a.ty * a.ng; }
+
+template <class K>
+static int launch(const Args& base, hipStream_t st) {
+  Args a = base;
+  set_geometry<K>(a);
+  if (tiles_of(a) > 0x3fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_wino: grid too large");
+  a.total = (unsigned)tiles_of(a); a.nbig = a.total;
+  constexpr size_t lds = sizeof(float) * 2 * K::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wino<K>), dim3(8 * ((a.total + 7) / 8)), dim3(256), lds, st, a);
+  return check_launch("conv_wino_forward");
+}
+
+template <class K>
+static int launch_tail(const Args& base, hipStream_t st) {
+  if constexpr (K::MT < 2) {
+    return fail(FN2_ERR_UNSUPPORTED, "conv_wino: variant has no split tail");
+  } else {
+    Args a = base;
+    set_geometry<K>(a);
+    if (tiles_of(a) > 0x1fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_wino: grid too large");
+    a.total = (unsigned)tiles_of(a); a.nbig = (unsigned)(tiles_of(a) / 256 * 256);
+    const unsigned nsm = 2 * (a.total - a.nbig);
+    constexpr size_t lds = sizeof(float) * 2 * K::BUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_tail<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wino_tail<K>), dim3(a.nbig + 8 * ((nsm + 7) / 8)), dim3(256), lds, st, a);
+    return check_launch("conv_wino_forward");
+  }
+}
+
+struct Variant {
+  int tgy, tgx, mt, wny, wnx;
+  int (*fn)(const Args&, hipStream_t);
+  int (*fn_tail)(const Args&, hipStream_t);
+};
+template <class K, bool TAIL> struct TailFn { static constexpr int (*fn)(const Args&, hipStream_t) = nullptr; };
+template <class K> struct TailFn<K, true> { static constexpr int (*fn)(const Args&, hipStream_t) = &launch_tail<K>; };
+
+// (TGY, TGX, MT, WNY, WNX): tile block shape, blocks per wave (along x), waves of the workgroup (y, x)
+#define FN2_WV_LIST(X) \
+  X(4, 4, 2, 4, 1) X(4, 4, 2, 2, 2) X(4, 4, 2, 1, 4) X(2, 8, 2, 4, 1) X(2, 8, 2, 2, 2) X(2, 8, 2, 1, 4) \
+  X(4, 4, 1, 4, 1) X(4, 4, 1, 2, 2) X(4, 4, 1, 1, 4) X(2, 8, 1, 4, 1) X(2, 8, 1, 2, 2) X(2, 8, 1, 1, 4)
+#define FN2_WV_ROW(TGY, TGX, MT, WNY, WNX) \
+  {TGY, TGX, MT, WNY, WNX, &launch<Cfg<TGY, TGX, MT, WNY, WNX>>, TailFn<Cfg<TGY, TGX, MT, WNY, WNX>, (MT >= 2)>::fn},
+static const Variant kVariants[] = {FN2_WV_LIST(FN2_WV_ROW)};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+int g_forced_variant = -1;
+
+static double variant_cost(const Variant& v, const Args& a, bool tail) {
+  const int th = 2 * v.tgy * v.wny, tw = 2 * v.tgx * v.mt * v.wnx;
+  const long long wgs = (long long)a.N * cdiv(a.Hout, th) * cdiv(a.Wout, tw) * (a.Cout / 16);
+  double rounds = (double)((wgs + 255) / 256);
+  if (tail) {
+    const long long r = wgs % 256;
+    if (wgs < 256 || r == 0 || r > 128) return 1e30;
+    rounds = (double)(wgs / 256) + 0.56;
+  }
+  return rounds * v.mt * (v.mt == 2 ? 1.35 : 1.0);      // measured: the 1-block-per-wave variants (112 VGPRs, 3-4 workgroups per CU) run the matrix pipes fuller
+}
+
+}  // namespace wino
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API int fn2_conv_wino_supported(int Cin, int Hin, int Win, int Cout, int pad) {
+  if (Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 16 != 0 || Win % 4 != 0 || pad != wino::kPad) return 0;
+  return (long long)Cin * Hin * Win < (1ll << 28);
+}
+
+FN2_API size_t fn2_conv_wino_packed_floats(int Cout, int Cin) {
+  if (Cout <= 0 || Cout % 16 != 0 || Cin <= 0) return 0;
+  return (size_t)(Cout / 16) * wino::kquads_for(Cin) * 1024;
+}
+
+FN2_API int fn2_conv_wino_pack_weights(const float* weight, float* packed, int Cout, int Cin, void* stream) {
+  if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "conv_wino_pack_weights: null blob");
+  if (Cout <= 0 || Cout % 16 != 0 || Cin <= 0) return fail(FN2_ERR_UNSUPPORTED, "conv_wino_pack_weights: needs Cout %% 16 == 0 (got %d)", Cout);
+  const int kquads = wino::kquads_for(Cin);
+  const long long total = (long long)(Cout / 16) * kquads * 64;
+  hipLaunchKernelGGL(wino::pack_u, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), weight, packed, Cout, Cin, kquads);
+  return check_launch("conv_wino_pack_weights");
+}
+
+FN2_API int fn2_debug_set_wino_variant(int v) { wino::g_forced_variant = v; return FN2_OK; }
+FN2_API int fn2_conv_wino_num_variants(void) { return wino::kNumVariants; }
+
+FN2_API int fn2_conv_wino_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                                  int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                  int Cout, int top_channels, int top_c0, int pad, int relu, float negative_slope, void* stream) {
+  if (N < 0) return fail(FN2_ERR_INVALID_ARG, "conv_wino: bad batch");
+  if (N == 0) return FN2_OK;
+  if (!bottom || !packed_weight || !top) return fail(FN2_ERR_INVALID_ARG, "conv_wino: null blob");
+  if (!fn2_conv_wino_supported(Cin, Hin, Win, Cout, pad))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_wino: unsupported geometry (Cin %d, %dx%d, Cout %d, pad %d)", Cin, Hin, Win, Cout, pad);
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels)
+    return fail(FN2_ERR_INVALID_ARG, "conv_wino: channel slice outside the blob");
+  if (((reinterpret_cast<uintptr_t>(bottom) | reinterpret_cast<uintptr_t>(top) | reinterpret_cast<uintptr_t>(packed_weight)) & 15) != 0)
+    return fail(FN2_ERR_UNSUPPORTED, "conv_wino: blobs must be 16-byte aligned");
+  wino::Args a{};
+  a.in = bottom; a.up = packed_weight; a.bias = bias; a.out = top;
+  a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.in_ctot = bottom_channels; a.in_c0 = bottom_c0;
+  a.Cout = Cout; a.Hout = Hin + 2 * pad - 2; a.Wout = Win + 2 * pad - 2; a.out_ctot = top_channels; a.out_c0 = top_c0;
+  a.kquads = wino::kquads_for(Cin);
+  a.slope = negative_slope; a.relu = relu;
+  int best = -1;
+  bool tail = false;
+  if (wino::g_forced_variant >= 0) {
+    tail = wino::g_forced_variant >= 1000;
+    best = wino::g_forced_variant % 1000;
+    if (best >= wino::kNumVariants || (tail && !wino::kVariants[best].fn_tail))
+      return fail(FN2_ERR_UNSUPPORTED, "conv_wino: forced variant %d does not apply", wino::g_forced_variant);
+  } else {
+    hipStream_t st = as_stream(stream);
+    int picked = -1;
+    if (autotune_enabled(st)) {
+      static TuneCache cache;
+      const TuneKey key{N, Cin, Hin, Win, Cout, pad, bottom_channels == Cin, top_channels == Cout, 0, 0};
+      picked = autotune_pick(cache, key, 2 * wino::kNumVariants, st, [&](int c) -> int {
+        const wino::Variant& v = wino::kVariants[c / 2];
+        if (c & 1) return (v.fn_tail && wino::variant_cost(v, a, true) < 1e29) ? v.fn_tail(a, st) : FN2_ERR_UNSUPPORTED;
+        return v.fn(a, st);
+      });
+    }
+    if (picked >= 0) { best = picked / 2; tail = (picked & 1) != 0; }
+    else {
+      double bc = 0;
+      for (int i = 0; i < wino::kNumVariants; ++i)
+        for (int t = 0; t < (wino::kVariants[i].fn_tail ? 2 : 1); ++t) {
+          const double c = wino::variant_cost(wino::kVariants[i], a, t == 1);
+          if (best < 0 || c < bc) { best = i; bc = c; tail = t == 1; }
+        }
+    }
+  }
+  return tail ? wino::kVariants[best].fn_tail(a, as_stream(stream)) : wino::kVariants[best].fn(a, as_stream(stream));
+}

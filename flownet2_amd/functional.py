@@ -183,19 +183,42 @@ def _mfma_conv_enabled(kernel, stride):
     return sel in ("all", "force") or (sel != "none" and ("k%ds%d" % (kernel, stride)) in sel.split(","))
 
 
+_PACKED_U = {}
+
+
+def _packed_wino_weight(w):
+    import weakref
+    key = id(w)
+    hit = _PACKED_U.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        hit = (weakref.ref(w, lambda _r, k=key: _PACKED_U.pop(k, None)), w._version, ops.conv_wino_pack_weights(w.detach()))
+        _PACKED_U[key] = hit
+    return hit[2]
+
+
 def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
-    """Convolution + bias (+ leaky ReLU) as ONE direct MFMA kernel (csrc/conv_mfma.hip), NCHW in and out, optionally written into
-    a channel slice of `out`.  Returns None when the kernel does not apply (autograd needed, unsupported geometry, disabled):
-    the caller then runs the library convolution."""
+    """Convolution + bias (+ leaky ReLU) as ONE MFMA kernel, NCHW in and out, optionally written into a channel slice of `out`:
+    Winograd F(2x2, 3x3) for 3x3 / stride 1 / pad 1 (csrc/conv_wino.hip), the direct kernel otherwise (csrc/conv_mfma.hip).
+    Returns None when neither applies (autograd needed, unsupported geometry, too little work to fill the chip, disabled): the
+    caller then runs the library convolution."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return None
     Cout, Cin, k, _ = weight.shape
-    if not x.is_cuda or not _mfma_conv_enabled(k, stride) or not ops.conv_mfma_supported(Cin, x.shape[2], x.shape[3], Cout, k, stride, pad):
+    if not x.is_cuda or not _mfma_conv_enabled(k, stride):
+        return None
+    force = os.environ.get("FN2_CONV_MFMA", "") == "force"
+    N, _, H, W = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if (k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)):
+        # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1500 the launch cannot fill 1024 SIMDs and the
+        # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
+        if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1500:
+            return ops.conv_wino_forward(x.contiguous(), _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0)
+    if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None
     # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
     # large enough to run the matrix pipes efficiently, and the library's GEMM route wins (scripts/conv_bench.py, profiles/)
-    Ho, Wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
-    if x.shape[0] * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and os.environ.get("FN2_CONV_MFMA", "") != "force":
+    if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not force:
         return None
     return ops.conv_mfma_forward(x.contiguous(), _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
                                  out=out, out_c0=out_c0)

@@ -305,6 +305,49 @@ def conv_num_variants() -> int:
     return int(_lib.lib().fn2_conv_mfma_num_variants())
 
 
+def conv_wino_supported(Cin, Hin, Win, Cout, pad) -> bool:
+    return bool(_lib.lib().fn2_conv_wino_supported(int(Cin), int(Hin), int(Win), int(Cout), int(pad)))
+
+
+def conv_wino_pack_weights(weight):
+    """weight [Cout, Cin, 3, 3] -> U = G g G^T in MFMA operand order (once per weight update)."""
+    w = _chk(weight, "weight")
+    Cout, Cin, k, k2 = w.shape
+    n = _lib.lib().fn2_conv_wino_packed_floats(Cout, Cin)
+    if k != 3 or k2 != 3 or n == 0:
+        raise ValueError(f"conv_wino: unsupported weight shape {tuple(w.shape)}")
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().fn2_conv_wino_pack_weights(_ptr(w), _ptr(packed), Cout, Cin, _stream()))
+    return packed
+
+
+def conv_wino_forward(x, packed_weight, bias, Cout, pad=1, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """act(Convolution{3, 1, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout], Winograd F(2x2, 3x3)."""
+    x = _chk(x, "bottom[0]")
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (Ho, Wo):
+            raise ValueError(f"conv_wino: top blob {tuple(out.shape)} does not match [{N},*,{Ho},{Wo}]")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    pw = _chk(packed_weight, "packed weight", ndim=1)
+    check(_lib.lib().fn2_conv_wino_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                           pad, int(bool(relu)), C.c_float(float(negative_slope)), _stream()))
+    return out
+
+
+def set_wino_variant(v: int):
+    check(_lib.lib().fn2_debug_set_wino_variant(int(v)))
+
+
+def wino_num_variants() -> int:
+    return int(_lib.lib().fn2_conv_wino_num_variants())
+
+
 def im2col_forward(x, kernel, pad, stride):
     """[N,C,H,W] -> col [N, C*k*k, Hc*Wc] (Caffe's im2col row order), batched."""
     x = _chk(x, "bottom[0]")

@@ -281,6 +281,24 @@ int fn2_conv_mfma_num_variants(void);
 int fn2_debug_set_conv_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution (+ bias, + optional ReLU) as Winograd F(2x2, 3x3) on the fp32 matrix cores:
+ *   same layer and blob conventions as fn2_conv_mfma_forward (conv_layer.cu:8-23, base_conv_layer.cpp:326-348, relu_layer.cu:8-27;
+ *   channel slices on both blobs), 2.25x fewer multiplies: Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A per 2x2 output tile.
+ *   The weight operand is U = G g G^T in MFMA operand order, fn2_conv_wino_packed_floats() floats written by
+ *   fn2_conv_wino_pack_weights() once per weight update.  fp32 products and accumulation; the transforms add a few ulp of rounding
+ *   relative to the direct sum (the library kernels the reference's cuDNN / MIOpen builds use for this layer are Winograd as well).
+ *   Supported (fn2_conv_wino_supported): Cout % 16 == 0, Win % 4 == 0, pad 1, 16-byte aligned blobs.  Forward only.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_conv_wino_supported(int Cin, int Hin, int Win, int Cout, int pad);
+size_t fn2_conv_wino_packed_floats(int Cout, int Cin);
+int fn2_conv_wino_pack_weights(const float* weight, float* packed, int Cout, int Cin, void* stream);
+int fn2_conv_wino_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                          int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                          int Cout, int top_channels, int top_c0, int pad, int relu, float negative_slope, void* stream);
+int fn2_conv_wino_num_variants(void);
+int fn2_debug_set_wino_variant(int variant);     /* as fn2_debug_set_conv_variant */
+
+/* ------------------------------------------------------------------------------------------------
  * im2col / col2im of Caffe's GEMM convolution, batched over the mini-batch (square kernel, no dilation):
  *   fn2_im2col_forward            <- im2col_gpu, src/caffe/util/im2col.cu:8-72, as used by
  *                                    BaseConvolutionLayer::forward_gpu_gemm (base_conv_layer.cpp:325-341)

@@ -278,6 +278,31 @@ def conv_mfma_forward(x, packed, bias, Cout, kernel, stride, pad, relu=True, neg
     return out
 
 
+def conv_wino_pack_weights(weight):
+    w = _f32(weight)
+    Cout, Cin, k, _ = w.shape
+    assert k == 3
+    L = lib()
+    L.fn2_conv_wino_packed_floats_cpu.restype = C.c_size_t
+    n = L.fn2_conv_wino_packed_floats_cpu(Cout, Cin)
+    assert n > 0, "unsupported weight shape"
+    packed = np.empty(n, np.float32)
+    _check(L.fn2_conv_wino_pack_weights_cpu(_p(w), _p(packed), Cout, Cin), "conv_wino_pack_weights")
+    return packed
+
+
+def conv_wino_forward(x, packed, bias, Cout, pad=1, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    x, packed = _f32(x), _f32(packed)
+    bias = _f32(bias) if bias is not None else None
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    if out is None:
+        out = np.zeros((N, Cout, H + 2 * pad - 2, W + 2 * pad - 2), np.float32)
+    _check(lib().fn2_conv_wino_forward_cpu(_p(x), _p(packed), _p(bias), _p(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                           pad, int(bool(relu)), C.c_float(negative_slope)), "conv_wino_forward")
+    return out
+
+
 def upsample_flow_deconv_forward(x, weight, bias=None):
     x, weight = _f32(x), _f32(weight)
     bias = _f32(bias) if bias is not None else None

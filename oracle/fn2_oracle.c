@@ -1000,6 +1000,113 @@ FN2_API int fn2_conv_mfma_forward_cpu(const float* bottom, const float* packed, 
   return FN2_OK;
 }
 
+/* 3x3 / stride 1 convolution as Winograd F(2x2, 3x3): the CPU twin of csrc/conv_wino.hip, operation for operation.
+ * Reference arithmetic: conv_layer.cpp:25-40 / base_conv_layer.cpp:255-318 (+ relu_layer.cpp:23-30); the reference sums K = 9 Cin
+ * products per output in a library-defined order, Winograd sums Cin products per transform-domain position and combines 16 of
+ * them: both are fp32 roundings of the same exact value (tests compare against the reference's layer and fp64 at 1e-5 x scale).
+ * This restatement follows the HIP kernel's order exactly -- U = G g G^T ((a + b) + c) * 0.5, V = B^T d B rows first, fmaf chains over
+ * the channels in ascending order per position (padded channels contribute exact zeros), Y = A^T M A rows first -- so it is bit-identical.
+ * Packed layout: [Cout/16][quads][position quad][lane = 16 kq + co][4]. */
+static int wino_kquads(int Cin) { return (((Cin + 3) / 4 + 1) / 2) * 2; }
+
+static void wino_u_cpu(const float g[3][3], float U[4][4]) {
+  float tmp[4][3];
+  for (int k = 0; k < 3; ++k) {
+    tmp[0][k] = g[0][k];
+    tmp[1][k] = ((g[0][k] + g[1][k]) + g[2][k]) * 0.5f;
+    tmp[2][k] = ((g[0][k] - g[1][k]) + g[2][k]) * 0.5f;
+    tmp[3][k] = g[2][k];
+  }
+  for (int i = 0; i < 4; ++i) {
+    U[i][0] = tmp[i][0];
+    U[i][1] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) * 0.5f;
+    U[i][2] = ((tmp[i][0] - tmp[i][1]) + tmp[i][2]) * 0.5f;
+    U[i][3] = tmp[i][2];
+  }
+}
+
+FN2_API size_t fn2_conv_wino_packed_floats_cpu(int Cout, int Cin) {
+  if (Cout <= 0 || Cout % 16 != 0 || Cin <= 0) return 0;
+  return (size_t)(Cout / 16) * wino_kquads(Cin) * 1024;
+}
+
+FN2_API int fn2_conv_wino_pack_weights_cpu(const float* weight, float* packed, int Cout, int Cin) {
+  if (!weight || !packed || Cout <= 0 || Cout % 16 != 0 || Cin <= 0) return FN2_ERR_INVALID_ARG;
+  const int kquads = wino_kquads(Cin);
+  for (int grp = 0; grp < Cout / 16; ++grp)
+    for (int cq = 0; cq < kquads; ++cq)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = 16 * grp + (lane & 15), ci = 4 * cq + (lane >> 4);
+        float g[3][3], U[4][4];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) g[a][b] = ci < Cin ? weight[((size_t)co * Cin + ci) * 9 + a * 3 + b] : 0.f;
+        wino_u_cpu(g, U);
+        float* dst = packed + ((size_t)grp * kquads + cq) * 1024 + lane * 4;
+        for (int pq = 0; pq < 4; ++pq)
+          for (int e = 0; e < 4; ++e) dst[pq * 256 + e] = U[pq][e];
+      }
+  return FN2_OK;
+}
+
+FN2_API int fn2_conv_wino_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
+                                      int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                      int Cout, int top_channels, int top_c0, int pad, int relu, float negative_slope) {
+  if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 16 != 0 || pad != 1) return FN2_ERR_INVALID_ARG;
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
+  const int Ho = Hin + 2 * pad - 2, Wo = Win + 2 * pad - 2, kquads = wino_kquads(Cin);
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co) {
+      const float* ug = packed + (size_t)(co / 16) * kquads * 1024 + (co % 16) * 4;
+      for (int ty = 0; 2 * ty < Ho; ++ty)
+        for (int tx = 0; 2 * tx < Wo; ++tx) {
+          float M[16];
+          for (int p = 0; p < 16; ++p) M[p] = 0.f;
+          for (int c = 0; c < 4 * kquads; ++c) {
+            float d[4][4], w[4][4], v[4][4];
+            for (int i = 0; i < 4; ++i)
+              for (int j = 0; j < 4; ++j) {
+                const int yi = 2 * ty - pad + i, xi = 2 * tx - pad + j;
+                d[i][j] = (c < Cin && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+                              ? bottom[(((size_t)n * bottom_channels + bottom_c0 + c) * Hin + yi) * Win + xi] : 0.f;
+              }
+            for (int j = 0; j < 4; ++j) {
+              w[0][j] = d[0][j] - d[2][j];
+              w[1][j] = d[1][j] + d[2][j];
+              w[2][j] = d[2][j] - d[1][j];
+              w[3][j] = d[1][j] - d[3][j];
+            }
+            for (int i = 0; i < 4; ++i) {
+              v[i][0] = w[i][0] - w[i][2];
+              v[i][1] = w[i][1] + w[i][2];
+              v[i][2] = w[i][2] - w[i][1];
+              v[i][3] = w[i][1] - w[i][3];
+            }
+            const float* uc = ug + (size_t)(c / 4) * 1024 + (c % 4) * 64;          /* lane = 16 kq + co */
+            for (int p = 0; p < 16; ++p) M[p] = fmaf(v[p >> 2][p & 3], uc[(p >> 2) * 256 + (p & 3)], M[p]);
+          }
+          float t[2][4], y[2][2];
+          for (int k = 0; k < 4; ++k) {
+            t[0][k] = M[k] + M[4 + k] + M[8 + k];
+            t[1][k] = M[4 + k] - M[8 + k] - M[12 + k];
+          }
+          for (int h = 0; h < 2; ++h) {
+            y[h][0] = t[h][0] + t[h][1] + t[h][2];
+            y[h][1] = t[h][1] - t[h][2] - t[h][3];
+          }
+          for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 2; ++e) {
+              const int oy = 2 * ty + h, ox = 2 * tx + e;
+              if (oy >= Ho || ox >= Wo) continue;
+              float s = y[h][e] + (bias ? bias[co] : 0.f);
+              if (relu) s = s > 0.f ? s : s * negative_slope;
+              top[(((size_t)n * top_channels + top_c0 + co) * Ho + oy) * Wo + ox] = s;
+            }
+        }
+    }
+  return FN2_OK;
+}
+
 /* Batched im2col / col2im of Caffe's GEMM convolution (src/caffe/util/im2col.cpp:20-50 im2col_cpu, :168-200 col2im_cpu;
  * GPU twins im2col.cu:8-72, 246-318).  col2im carries the deconvolution's bias and optional leaky ReLU like the HIP path;
  * the additions run over the column grid rows ascending, then columns ascending (the reference GPU kernel's order). */

@@ -19,6 +19,10 @@ LAYERS_C = [  # name, N, Cin, H, W, Cout, k, s, p     (FlowNetC batch 8 @448x320
     ("conv2", 16, 64, 160, 224, 128, 5, 2, 2), ("conv3", 16, 128, 80, 112, 256, 5, 2, 2), ("conv3_1", 8, 473, 40, 56, 256, 3, 1, 1),
     ("conv4", 8, 256, 40, 56, 512, 3, 2, 1), ("conv4_1", 8, 512, 20, 28, 512, 3, 1, 1), ("conv5", 8, 512, 20, 28, 512, 3, 2, 1),
     ("conv5_1", 8, 512, 10, 14, 512, 3, 1, 1), ("conv6", 8, 512, 10, 14, 1024, 3, 2, 1)]
+LAYERS_SD = [  # FlowNet2-SD / fusion / interconv layers, batch 4 @768x384
+    ("sd_conv0", 4, 6, 384, 768, 64, 3, 1, 1), ("sd_conv1_1", 4, 64, 192, 384, 128, 3, 1, 1), ("sd_conv2_1", 4, 128, 96, 192, 128, 3, 1, 1),
+    ("sd_ic2", 4, 194, 96, 192, 64, 3, 1, 1), ("sd_ic3", 4, 386, 48, 96, 128, 3, 1, 1), ("sd_ic4", 4, 770, 24, 48, 256, 3, 1, 1),
+    ("fuse_conv0", 4, 11, 384, 768, 64, 3, 1, 1)]
 LAYERS_2 = [  # FlowNet2 batch 4 @768x384 (FlowNetS stage)
     ("conv2", 4, 64, 192, 384, 128, 5, 2, 2), ("conv3", 4, 128, 96, 192, 256, 5, 2, 2), ("conv3_1", 4, 256, 48, 96, 256, 3, 1, 1),
     ("conv4", 4, 256, 48, 96, 512, 3, 2, 1), ("conv4_1", 4, 512, 24, 48, 512, 3, 1, 1), ("conv5", 4, 512, 24, 48, 512, 3, 2, 1),
@@ -44,7 +48,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
-    layers = LAYERS_C if a.net == "C" else LAYERS_2
+    layers = {"C": LAYERS_C, "2": LAYERS_2, "SD": LAYERS_SD}[a.net]
     if a.layers:
         layers = [l for l in layers if l[0] in a.layers.split(",")]
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -61,6 +65,27 @@ def main():
             t_gemm = timeit(lambda: Fn.conv_gemm_relu(x, w, b, s, p, 0.1), a.iters)
             line += f" | im2col+GEMM {t_gemm:7.1f} us {gf / t_gemm * 1e3:6.1f} TF"
         print(line, flush=True)
+        if k == 3 and s == 1 and ops.conv_wino_supported(Cin, H, W, Cout, p):
+            pu = ops.conv_wino_pack_weights(w)
+            outw = torch.empty_like(want)
+            firstw = None
+            nv = ops.wino_num_variants()
+            for v in list(range(nv)) + [1000 + i for i in range(nv)]:
+                ops.set_wino_variant(v)
+                try:
+                    ops.conv_wino_forward(x, pu, b, Cout, p, True, 0.1, out=outw)
+                except flownet2_amd.Fn2Error:
+                    continue
+                torch.cuda.synchronize()
+                err = float((outw - want).abs().max())
+                same = "" if firstw is None else ("  bits==first" if torch.equal(outw, firstw) else "  BITS DIFFER")
+                if firstw is None:
+                    firstw = outw.clone()
+                t = timeit(lambda: ops.conv_wino_forward(x, pu, b, Cout, p, True, 0.1, out=outw), a.iters)
+                print(f"   winograd {v:4d}: {t:7.1f} us {gf / t * 1e3:6.1f} TF(direct-equivalent)   max|diff vs torch| {err:.2e}{same}", flush=True)
+            ops.set_wino_variant(-1)
+            t = timeit(lambda: ops.conv_wino_forward(x, pu, b, Cout, p, True, 0.1, out=outw), a.iters)
+            print(f"   winograd cost-model choice: {t:7.1f} us {gf / t * 1e3:6.1f} TF(direct-equivalent)", flush=True)
         if not ops.conv_mfma_supported(Cin, H, W, Cout, k, s, p):
             print("   (conv_mfma: unsupported geometry)")
             continue
