@@ -210,9 +210,9 @@ def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, o
     N, _, H, W = x.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if (k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)):
-        # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1500 the launch cannot fill 1024 SIMDs and the
+        # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1000 the launch cannot fill 1024 SIMDs and the
         # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
-        if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1500:
+        if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
             return ops.conv_wino_forward(x.contiguous(), _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0)
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None

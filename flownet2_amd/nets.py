@@ -76,17 +76,34 @@ def _conv(x, P, name, stride, pad, act=True, backend=None):
     """Convolution (+ ReLU{negative_slope 0.1}).  With a backend that has conv_bias_leaky_relu the library runs the
     bias-free convolution and bias + activation are one in-place pass (csrc/bias_act.hip) instead of two."""
     w = P[name + ".w"]
+    if _TRACE_CONV:
+        y = _conv_routed(x, P, name, stride, pad, act, backend)
+        print("conv route %-16s in %-22s k%d s%d act=%d -> %s" % (name, tuple(x.shape), w.shape[2], stride, act, _LAST_ROUTE[0]))
+        return y
+    return _conv_routed(x, P, name, stride, pad, act, backend)
+
+
+_TRACE_CONV = __import__("os").environ.get("FN2_TRACE_CONV") == "1"
+_LAST_ROUTE = [""]
+
+
+def _conv_routed(x, P, name, stride, pad, act, backend):
+    w = P[name + ".w"]
+    _LAST_ROUTE[0] = "library conv2d"
     if act and stride == 2 and pad == 3 and w.shape[2] == 7 and backend is not None and hasattr(backend, "conv_k7s2_relu"):
         y = backend.conv_k7s2_relu(x, w, P[name + ".b"], NEG_SLOPE)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
         if y is not None:
+            _LAST_ROUTE[0] = "stem kernel"
             return y
     if w.shape[2] in (3, 5) and backend is not None and hasattr(backend, "conv_mfma_relu"):
-        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)    # direct MFMA convolution, bias + ReLU fused (csrc/conv_mfma.hip)
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)    # Winograd / direct MFMA convolution, bias + ReLU fused
         if y is not None:
+            _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
     if act and w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
         y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE)
         if y is not None:
+            _LAST_ROUTE[0] = "im2col + library GEMM"
             return y
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
         return backend.conv_bias_leaky_relu(F.conv2d(x, w, None, stride=stride, padding=pad), P[name + ".b"], NEG_SLOPE)
@@ -151,7 +168,7 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
     def pf(x, name):
         if backend is not None and hasattr(backend, "predict_flow_conv"):
             return backend.predict_flow_conv(x, P[name + ".w"], P[name + ".b"])
-        return _conv(x, P, name, 1, 1, act=False)
+        return _conv(x, P, name, 1, 1, act=False, backend=backend)
 
     def up(x, name):
         if backend is not None and hasattr(backend, "upsample_flow_deconv"):
@@ -377,7 +394,7 @@ class _Prefixed(dict):
 def _pf(P, x, name, backend):
     if backend is not None and hasattr(backend, "predict_flow_conv"):
         return backend.predict_flow_conv(x, P[name + ".w"], P[name + ".b"])
-    return _conv(x, P, name, 1, 1, act=False)
+    return _conv(x, P, name, 1, 1, act=False, backend=backend)
 
 
 def _up(P, x, name, backend):
@@ -396,13 +413,13 @@ def flownet_sd_core(P, x, backend):
     c6 = _conv(_conv(c5, P, "conv6", 2, 1, backend=backend), P, "conv6_1", 1, 1, backend=backend)
     flow6 = _pf(P, c6, "Convolution1", backend)
     cat5 = torch.cat([c5, _deconv(c6, P, "deconv5", backend=backend), _up(P, flow6, "upsample_flow6to5", backend)], 1)
-    flow5 = _pf(P, _conv(cat5, P, "interconv5", 1, 1, act=False), "Convolution2", backend)
+    flow5 = _pf(P, _conv(cat5, P, "interconv5", 1, 1, act=False, backend=backend), "Convolution2", backend)
     cat4 = torch.cat([c4, _deconv(cat5, P, "deconv4", backend=backend), _up(P, flow5, "upsample_flow5to4", backend)], 1)
-    flow4 = _pf(P, _conv(cat4, P, "interconv4", 1, 1, act=False), "Convolution3", backend)
+    flow4 = _pf(P, _conv(cat4, P, "interconv4", 1, 1, act=False, backend=backend), "Convolution3", backend)
     cat3 = torch.cat([c3, _deconv(cat4, P, "deconv3", backend=backend), _up(P, flow4, "upsample_flow4to3", backend)], 1)
-    flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False), "Convolution4", backend)
+    flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False, backend=backend), "Convolution4", backend)
     cat2 = torch.cat([c2, _deconv(cat3, P, "deconv2", backend=backend), _up(P, flow3, "upsample_flow3to2", backend)], 1)
-    return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False), "Convolution5", backend)      # 1/4 resolution, units of 1/SD_FLOW_SCALE px
+    return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False, backend=backend), "Convolution5", backend)      # 1/4 resolution, units of 1/SD_FLOW_SCALE px
 
 
 def fusion_core(P, x, backend):
@@ -411,9 +428,9 @@ def fusion_core(P, x, backend):
     c2 = _conv(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, backend=backend)
     flow2 = _pf(P, c2, "Convolution5", backend)
     cat1 = torch.cat([c1, _deconv(c2, P, "deconv1", backend=backend), _up(P, flow2, "upsample_flow2to1", backend)], 1)
-    flow1 = _pf(P, _conv(cat1, P, "interconv1", 1, 1, act=False), "Convolution6", backend)
+    flow1 = _pf(P, _conv(cat1, P, "interconv1", 1, 1, act=False, backend=backend), "Convolution6", backend)
     cat0 = torch.cat([c0, _deconv(cat1, P, "deconv0", backend=backend), _up(P, flow1, "upsample_flow1to0", backend)], 1)
-    return _pf(P, _conv(cat0, P, "interconv0", 1, 1, act=False), "Convolution7", backend)        # full resolution, pixels
+    return _pf(P, _conv(cat0, P, "interconv0", 1, 1, act=False, backend=backend), "Convolution7", backend)        # full resolution, pixels
 
 
 def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor] = None):
