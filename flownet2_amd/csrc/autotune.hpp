@@ -4,9 +4,11 @@
 // or when FN2_AUTOTUNE=0.
 #pragma once
 #include <array>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 
 #include "fn2_common.hpp"
 
@@ -14,9 +16,37 @@ namespace fn2 {
 
 using TuneKey = std::array<int, 10>;
 
+// FN2_AUTOTUNE_CACHE=<file>: picks are appended to / preloaded from a text file ("<cache name> k0 .. k9 best" per line), so a
+// second process (e.g. a profiled run) launches no candidates.
 struct TuneCache {
+  explicit TuneCache(const char* name_) : name(name_) {}
   std::mutex mu;
   std::map<TuneKey, int> best;
+  std::string name;
+  bool loaded = false;
+  void load_locked() {
+    if (loaded) return;
+    loaded = true;
+    const char* path = std::getenv("FN2_AUTOTUNE_CACHE");
+    if (!path) return;
+    if (FILE* f = std::fopen(path, "r")) {
+      char nm[64];
+      TuneKey k;
+      int b;
+      while (std::fscanf(f, "%63s %d %d %d %d %d %d %d %d %d %d %d", nm, &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &k[9], &b) == 12)
+        if (name == nm) best[k] = b;
+      std::fclose(f);
+    }
+  }
+  void store_locked(const TuneKey& k, int b) {
+    best[k] = b;
+    const char* path = std::getenv("FN2_AUTOTUNE_CACHE");
+    if (!path) return;
+    if (FILE* f = std::fopen(path, "a")) {
+      std::fprintf(f, "%s %d %d %d %d %d %d %d %d %d %d %d\n", name.c_str(), k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], b);
+      std::fclose(f);
+    }
+  }
 };
 
 inline bool autotune_enabled(hipStream_t st) {
@@ -33,6 +63,7 @@ template <class Run>
 int autotune_pick(TuneCache& cache, const TuneKey& key, int ncand, hipStream_t st, Run run) {
   {
     std::lock_guard<std::mutex> lk(cache.mu);
+    cache.load_locked();
     auto it = cache.best.find(key);
     if (it != cache.best.end()) return it->second;
   }
@@ -56,7 +87,7 @@ int autotune_pick(TuneCache& cache, const TuneKey& key, int ncand, hipStream_t s
   last_error().clear();
   if (best >= 0) {
     std::lock_guard<std::mutex> lk(cache.mu);
-    cache.best[key] = best;
+    cache.store_locked(key, best);
   }
   return best;
 }

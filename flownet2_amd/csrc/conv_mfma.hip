@@ -430,7 +430,7 @@ FN2_API int fn2_conv_mfma_forward(const float* bottom, const float* packed_weigh
     int picked = -1;
     if (autotune_enabled(st)) {
       // candidates 2 i / 2 i + 1 = plain / split-tail launch of variant i; all of them write the same bits
-      static TuneCache cache;
+      static TuneCache cache("conv_mfma");
       const TuneKey key{N, Cin, Hin, Win, Cout, kernel, stride, pad, bottom_channels == Cin, top_channels == Cout};
       picked = autotune_pick(cache, key, 2 * cv::kNumVariants, st, [&](int c) -> int {
         const cv::Variant& v = cv::kVariants[c / 2];

@@ -433,7 +433,7 @@ FN2_API int fn2_conv_wino_forward(const float* bottom, const float* packed_weigh
     hipStream_t st = as_stream(stream);
     int picked = -1;
     if (autotune_enabled(st)) {
-      static TuneCache cache;
+      static TuneCache cache("conv_wino");
       const TuneKey key{N, Cin, Hin, Win, Cout, pad, bottom_channels == Cin, top_channels == Cout, 0, 0};
       picked = autotune_pick(cache, key, 2 * wino::kNumVariants, st, [&](int c) -> int {
         const wino::Variant& v = wino::kVariants[c / 2];

@@ -8,6 +8,10 @@ TAG=${1:-r01}
 R=gpurun_out/$TAG
 export TMPDIR=/tmp
 mkdir -p $R
+# the convolution kernels pick their tile variant by timing every candidate on first use: record the picks once so that the
+# profiled runs below launch no candidates
+export FN2_AUTOTUNE_CACHE=$PWD/$R/autotune.txt
+rm -f $FN2_AUTOTUNE_CACHE
 # warm MIOpen's find-db so the profiled run shows steady-state kernels only
 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_profiled.json 2>/dev/null
@@ -25,4 +29,12 @@ python tests/cpu_baselines.py >> gpurun_out/layer_microbench.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/layers -o lay -- python scripts/layer_microbench.py > /dev/null 2>&1
 timeout 300 python scripts/train_pipeline.py --iters 8 2>/dev/null | tail -11 > gpurun_out/train_pipeline.txt
 python bench.py --steps 30 --warmup 5 > $R/bench.json 2> $R/bench.err
+# the other configurations of BASELINE.json (FlowNet2 at 768x384 batch 4 and 1024x448 batch 1, FlowNetC training step) and the
+# per-variant convolution timings
+python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_flownet2.json 2>/dev/null
+python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_flownet2_1024.json 2>/dev/null
+python bench.py --mode train --steps 15 --warmup 4 --no-cpu-baseline > $R/bench_train.json 2>/dev/null
+timeout 300 python scripts/conv_bench.py --net C --layers conv2,conv3,conv3_1,conv4_1 > $R/conv_bench_C.txt 2>&1
+# matrix-pipe counters of the convolution kernels alone (a counter pass of its own)
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_conv -o conv -- env FN2_AUTOTUNE=0 python scripts/conv_bench.py --net C --layers conv2,conv3_1 --iters 3 > /dev/null 2>&1
 tail -c 300 $R/bench.json

@@ -121,6 +121,33 @@ if os.path.exists(pmc_path):
 lines += ["", "bench line of the unprofiled run in the same session:", "```", open(os.path.join(R, "bench.json")).read().strip(), "```", ""]
 open(os.path.join(OUT, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 
+import shutil
+for extra in ("bench.json", "bench_flownet2.json", "bench_flownet2_1024.json", "bench_train.json"):
+    if os.path.exists(os.path.join(R, extra)) and os.path.getsize(os.path.join(R, extra)) > 0:
+        shutil.copyfile(os.path.join(R, extra), os.path.join(OUT, f"{tag}_{extra}"))
+if os.path.exists(os.path.join(R, "conv_bench_C.txt")):
+    shutil.copyfile(os.path.join(R, "conv_bench_C.txt"), os.path.join(OUT, f"{tag}_conv_bench_flownetc.txt"))
+# matrix-pipe counters of the convolution kernels (scripts/conv_bench.py under --pmc)
+pmc_conv = os.path.join(R, "pmc_conv", "conv_counter_collection.csv")
+if os.path.exists(pmc_conv):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(pmc_conv)):
+        if "fn2::cv::" in r["Kernel_Name"] or "fn2::wino::" in r["Kernel_Name"]:
+            per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    cl = ["# Matrix-pipe and LDS counters of the convolution kernels (round %s)" % tag, "",
+          "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- python scripts/conv_bench.py --net C --layers conv2,conv3_1`",
+          "(FN2_AUTOTUNE=0: every tile variant is launched by the script itself).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).", "",
+          "| kernel | dispatches | GUI cycles / launch | MFMA instructions | MFMA busy % | LDS bank-conflict cycles / LDS active |", "|---|---|---|---|---|---|"]
+    for name, c in sorted(per.items()):
+        gui_k = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"]) / 8.0
+        busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+        insts = sum(c["SQ_INSTS_MFMA"]) / len(c["SQ_INSTS_MFMA"])
+        conf = sum(c.get("SQ_LDS_BANK_CONFLICT", [0])) / max(1, len(c.get("SQ_LDS_BANK_CONFLICT", [0])))
+        act = sum(c.get("SQ_LDS_IDX_ACTIVE", [0])) / max(1, len(c.get("SQ_LDS_IDX_ACTIVE", [0])))
+        cl.append("| `%s` | %d | %.0f | %.0f | %.1f | %.3f |" % (short(name.replace("void ", ""), 80), len(c["GRBM_GUI_ACTIVE"]), gui_k, insts,
+                                                              100 * busy / (1024.0 * gui_k) if gui_k else 0, conf / act if act else 0))
+    open(os.path.join(OUT, f"{tag}_conv_counters.md"), "w").write("\n".join(cl) + "\n")
+
 summary = {"tag": tag, "kernel": "corr_fwd_pair<10> [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
            "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "fetch_correction": fetch_factor,
            "write_correction": write_factor, "hbm_read_bytes": fetch_bytes, "hbm_write_bytes": write_bytes,
