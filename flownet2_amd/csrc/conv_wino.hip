@@ -44,23 +44,26 @@ struct Args {
 constexpr int kCQ = 2;     // channel quads per chunk (weights are padded to whole chunks)
 constexpr int kPad = 1;    // the only padding instantiated (3x3 "same" convolution)
 
-template <int TGY_, int TGX_, int MT_, int WNY_, int WNX_>
+template <int TGY_, int TGX_, int MT_, int WNY_, int WNX_, int WM_ = 1, int MW_ = 1>
 struct Cfg {
-  static constexpr int TGY = TGY_, TGX = TGX_, MT = MT_, WNY = WNY_, WNX = WNX_, CQ = kCQ;
-  static constexpr int NW = WNY * WNX;
+  static constexpr int TGY = TGY_, TGX = TGX_, MT = MT_, WNY = WNY_, WNX = WNX_, WM = WM_, MW = MW_, CQ = kCQ;      // MW: 16-channel groups per WAVE (they share the transformed patch)
+  static constexpr int NW = WNY * WNX * WM, THREADS = 64 * NW;      // WM waves work on WM different 16-channel groups of the same pixels
   static constexpr int PADL = 4;
   static constexpr int TH = 2 * TGY * WNY, TW = 2 * TGX * MT * WNX;     // output pixels of a workgroup tile
   static constexpr int WR = TH + 2, WC = TW + 2 + PADL;                 // window rows / columns (columns from x0 - PADL)
-  static constexpr int RS = up_mod(cdiv(WC, 4) * 4, TGX == 8 ? 8 : 4, 16);
-  static constexpr int CS = up_mod(WR * RS, 32, 64);
-  static constexpr int URUN = 4 * CQ;                                   // 1 KiB runs of U per chunk (4 per channel quad)
+  // Row / channel strides of the window.  The conflict-free choice (RS == 4 or 8 mod 16, CS == 32 mod 64) pads a 38-column row to 52:
+  // the kernel is bound by what it stages per MFMA (24 B/clk/CU through L2 at 3 workgroups per CU), not by LDS cycles (28 % busy), so the
+  // rows are kept dense and the pair reads take their 2-way conflicts.
+  static constexpr int RS = cdiv(WC, 4) * 4;
+  static constexpr int CS = cdiv(WR * RS, 8) * 8;
+  static constexpr int URUN = 4 * CQ * WM * MW;                              // 1 KiB runs of U per chunk (4 per channel quad and channel group)
   static constexpr int WSLOTS = 4 * CQ * CS / 4;
   static constexpr int WRUN = cdiv(WSLOTS, 64);
   static constexpr int NRUN = URUN + WRUN;
   static constexpr int RPW = cdiv(NRUN, NW);
   static constexpr int BUF = NRUN * 256;                                // dwords per buffer: [U | window]
   static constexpr int WOFF = URUN * 256;
-  static_assert(NW == 4 && TGY * TGX == 16 && 2 * BUF * 4 <= 160 * 1024, "workgroup shape");
+  static_assert((NW == 4 || NW == 8) && TGY * TGX == 16 && 2 * BUF * 4 <= 160 * 1024, "workgroup shape");
 };
 
 // LDS-DMA of one chunk: runs [0, URUN) = the chunk's U slab (a linear copy), runs [URUN, NRUN) = the input window.
@@ -81,6 +84,48 @@ __device__ __forceinline__ void stage_chunk(__amdgpu_buffer_rsrc_t rsU, __amdgpu
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Operands of one k-step (channel quad) of one tile block as they come out of LDS: U for the 16 positions, and the 4x4 input
+// patch as three aligned pairs per row (the patch is the middle four values).
+struct WOps { f32x4 u[4]; float d0[4]; f32x2 d12[4]; float d3[4]; };
+
+template <class K>
+__device__ __forceinline__ void wino_load(WOps& o, const float* ub, const float* dp) {
+#pragma unroll
+  for (int pq = 0; pq < 4; ++pq) o.u[pq] = *reinterpret_cast<const f32x4*>(ub + pq * 256);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {           // patch columns 0 .. 3 = window columns dcol + 1 .. dcol + 4 (dcol even): dword, aligned pair, dword
+    o.d0[i] = dp[i * K::RS + 1];
+    o.d12[i] = *reinterpret_cast<const f32x2*>(dp + i * K::RS + 2);
+    o.d3[i] = dp[i * K::RS + 4];
+  }
+}
+
+// V = B^T d B, rows first
+__device__ __forceinline__ void wino_transform(const WOps& o, float (&v)[16]) {
+  float d[4][4], w[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { d[i][0] = o.d0[i]; d[i][1] = o.d12[i][0]; d[i][2] = o.d12[i][1]; d[i][3] = o.d3[i]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w[0][j] = d[0][j] - d[2][j];
+    w[1][j] = d[1][j] + d[2][j];
+    w[2][j] = d[2][j] - d[1][j];
+    w[3][j] = d[1][j] - d[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[4 * i + 0] = w[i][0] - w[i][2];
+    v[4 * i + 1] = w[i][1] + w[i][2];
+    v[4 * i + 2] = w[i][2] - w[i][1];
+    v[4 * i + 3] = w[i][1] - w[i][3];
+  }
+}
+
+__device__ __forceinline__ void wino_mfma(f32x4 (&acc)[16], const float (&v)[16], const f32x4 (&u)[4]) {
+#pragma unroll
+  for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], u[p >> 2][p & 3], acc[p], 0, 0, 0);
+}
+
 // One workgroup tile: 16 output channels (group g) x TH x TW pixels of sample n.
 template <class K>
 __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, int n) {
@@ -88,21 +133,21 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wnx = wave % K::WNX, wny = wave / K::WNX;
+  const int wm = wave % K::WM, wnx = (wave / K::WM) % K::WNX, wny = wave / (K::WM * K::WNX);
   const int x0 = bx * K::TW, y0 = by * K::TH;
 
   const size_t plane = (size_t)a.Hin * a.Win;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in + ((size_t)n * a.in_ctot + a.in_c0) * plane), 0, (unsigned)(4u * a.Cin * plane), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.up + (size_t)g * a.kquads * 1024), 0, (unsigned)(4096u * a.kquads), 0x00020000);
+      const_cast<float*>(a.up + (size_t)g * K::WM * K::MW * a.kquads * 1024), 0, (unsigned)(4096u * a.kquads * K::WM * K::MW), 0x00020000);
   constexpr unsigned OOB = 0x7ffffff0u;
   unsigned voff[K::RPW];
 #pragma unroll
   for (int i = 0; i < K::RPW; ++i) {
     const int r = i * K::NW + wave;
     voff[i] = OOB;
-    if (r < K::URUN) voff[i] = 16u * (unsigned)(r * 64 + lane);
+    if (r < K::URUN) voff[i] = 4096u * (unsigned)((r / (4 * K::CQ)) * a.kquads) + 16u * (unsigned)((r % (4 * K::CQ)) * 64 + lane);   // slab r / (4 CQ) of the WM channel groups
     else if (r < K::NRUN) {
       const int s = (r - K::URUN) * 64 + lane;
       const int c = s / (K::CS / 4), rem = s % (K::CS / 4);
@@ -123,13 +168,53 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
   const int dcol = 2 * (K::TGX * MT * wnx + tx) + K::PADL - kPad - 1;
   const int dbase = K::WOFF + kq * K::CS + (2 * (K::TGY * wny + ty)) * K::RS + dcol;
 
-  f32x4 acc[MT][16];
+  constexpr int MW = K::MW;
+  f32x4 acc[MT * MW][16];                     // [tile block m][channel group j] -> index m * MW + j
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT * MW; ++m)
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[m][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   stage_chunk<K>(rsU, rsW, voff, lds_base, wave, 0u, 0u);
+  if constexpr (MT == 1 && MW == 1 && K::CQ == 2) {
+    // Software pipeline over the k-steps (two per chunk), one barrier per chunk:
+    //   the MFMAs of k-step k run while the operands of k+1 -- read from LDS one step earlier -- are transformed (independent
+    //   VALU work in the MFMA issue gaps), and the LDS reads of k+2 are in flight.  The barrier that publishes chunk c+1 and frees
+    //   chunk c's buffer sits between the two k-steps of chunk c, when every wave holds (c, q1) in registers.
+    const float* ub0 = smem + (wm * K::CQ * 4) * 256 + lane * 4;           // U slab of this wave's channel group, k-step q0
+    const float* dp0 = smem + dbase;
+    float vA[16], vB[16];
+    WOps LA, LB;
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    if (a.nchunks > 1) stage_chunk<K>(rsU, rsW, voff, lds_base + 4u * (unsigned)K::BUF, wave, chunk_u, chunk_w);
+    wino_load<K>(LA, ub0, dp0);
+    wino_load<K>(LB, ub0 + 4 * 256, dp0 + 4 * K::CS);
+    wino_transform(LA, vA);
+    for (int c = 0; c < a.nchunks; ++c) {
+      const bool more = c + 1 < a.nchunks;
+      const int nb = (c + 1) & 1;
+      // k-step (c, q0); the operands of (c, q1) are transformed in its shadow
+      wino_mfma(acc[0], vA, LA.u);
+      wino_transform(LB, vB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        wait_vm0();
+        __builtin_amdgcn_s_barrier();
+        if (c + 2 < a.nchunks)
+          stage_chunk<K>(rsU, rsW, voff, lds_base + 4u * (unsigned)((c & 1) * K::BUF), wave, (unsigned)(c + 2) * chunk_u, (unsigned)(c + 2) * chunk_w);
+        wino_load<K>(LA, ub0 + nb * K::BUF, dp0 + nb * K::BUF);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step (c, q1); (c + 1, q0) is transformed in its shadow, (c + 1, q1) goes into flight
+      wino_mfma(acc[0], vB, LB.u);
+      if (more) {
+        wino_transform(LA, vA);
+        __builtin_amdgcn_sched_barrier(0);
+        wino_load<K>(LB, ub0 + nb * K::BUF + 4 * 256, dp0 + nb * K::BUF + 4 * K::CS);
+      }
+    }
+  } else {
   for (int c = 0; c < a.nchunks; ++c) {
     const int buf = c & 1;
     wait_vm0();                              // this wave's part of chunk c (issued one chunk ago) has landed
@@ -140,9 +225,11 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
 #pragma unroll
     for (int q = 0; q < K::CQ; ++q) {
       // B operands: U[position][16 channels of the group][channel 4 q + kq] for the 16 positions, 4 per 16-byte read
-      f32x4 u[4];
+      f32x4 u[MW][4];
 #pragma unroll
-      for (int pq = 0; pq < 4; ++pq) u[pq] = *reinterpret_cast<const f32x4*>(sb + (q * 4 + pq) * 256 + lane * 4);
+      for (int j = 0; j < MW; ++j)
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) u[j][pq] = *reinterpret_cast<const f32x4*>(sb + (((wm * MW + j) * K::CQ + q) * 4 + pq) * 256 + lane * 4);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         // the 4x4 patch of channel 4 q + kq under tile (ty, tx) of block m, then V = B^T d B
@@ -171,31 +258,37 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
           v[i][3] = w[i][1] - w[i][3];
         }
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-          acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p >> 2][p & 3], u[p >> 2][p & 3], acc[m][p], 0, 0, 0);
+        for (int j = 0; j < MW; ++j)
+#pragma unroll
+          for (int p = 0; p < 16; ++p)
+            acc[m * MW + j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p >> 2][p & 3], u[j][p >> 2][p & 3], acc[m * MW + j][p], 0, 0, 0);
       }
     }
+  }
   }
 
   // ---- epilogue: lane (tile-row block rb = lane >> 4, channel lane & 15) holds, per position, the 4 tiles rb * 4 + r:
   // block row trow, 4 consecutive tile columns tc0 .. tc0 + 3 -> Y = A^T M A per tile: 2 output rows x 8 consecutive columns
   const int rb = lane >> 4;
   const int trow = K::TGX == 8 ? rb >> 1 : rb, tc0 = K::TGX == 8 ? 4 * (rb & 1) : 0;
-  const int co = 16 * g + (lane & 15);
-  const float bv = a.bias ? a.bias[co] : 0.f;
   const int oy = y0 + 2 * (K::TGY * wny + trow);
+#pragma unroll
+  for (int j = 0; j < MW; ++j) {
+  const int co = 16 * ((g * K::WM + wm) * MW + j) + (lane & 15);
+  const float bv = a.bias ? a.bias[co] : 0.f;
   float* oplane = a.out + ((size_t)n * a.out_ctot + a.out_c0 + co) * a.Hout * a.Wout;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int ox = x0 + 2 * (K::TGX * (MT * wnx + m) + tc0);
+    const f32x4 (&am)[16] = acc[m * MW + j];
     float y[2][8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float t[2][4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        t[0][k] = acc[m][k][r] + acc[m][4 + k][r] + acc[m][8 + k][r];
-        t[1][k] = acc[m][4 + k][r] - acc[m][8 + k][r] - acc[m][12 + k][r];
+        t[0][k] = am[k][r] + am[4 + k][r] + am[8 + k][r];
+        t[1][k] = am[4 + k][r] - am[8 + k][r] - am[12 + k][r];
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -224,18 +317,29 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
       }
     }
   }
+  }
 }
 
-// Task list: (sample, tile row, tile column, channel group), channel group fastest, cut into 8 contiguous ranges, one per XCD.
+// Task list, cut into 8 contiguous ranges, one per XCD (block b runs on XCD b % 8): (group block, sample, tile row, tile column,
+// group within the block of kGL), innermost fastest.  The kGL workgroups that share an input window run back to back on one XCD
+// (the window is fetched once into its L2), and a contiguous range stays inside one block of kGL channel groups, whose U slabs
+// (kGL x Cin x 64 B, e.g. 1.9 MB for conv3_1) then live in that XCD's 4 MiB L2 instead of streaming from the Infinity Cache for
+// every workgroup (with the group index fastest over all 16 groups every XCD cycled through the whole 7.8 MB).
+constexpr int kGL = 4;
 __device__ __forceinline__ void decode_tile(const Args& a, unsigned t, int& g, int& bx, int& by, int& n) {
-  g = t % a.ng; t /= a.ng;
+  const unsigned per_block = (unsigned)a.N * a.ty * a.tx * kGL;
+  const int gh = t / per_block;
+  t -= gh * per_block;
+  const int gl = a.ng - gh * kGL < kGL ? a.ng - gh * kGL : kGL;      // the last block may hold fewer groups
+  const int glo = t % gl; t /= gl;
+  g = gh * kGL + glo;
   bx = t % a.tx; t /= a.tx;
   by = t % a.ty;
   n = t / a.ty;
 }
 
 template <class K>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(K::THREADS, (K::NW == 4 && K::MT == 1 && K::MW == 1) ? 3 : 2)      // 3 workgroups of 4 waves per CU: <= 168 VGPRs
 conv_wino(Args a) {
   const unsigned per_xcd = (a.total + 7) / 8;
   const unsigned t = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -248,9 +352,9 @@ conv_wino(Args a) {
 // Split tail (see conv_mfma.hip): whole rounds of tiles run as they are, every remaining tile as two workgroups of half the
 // width (MT / 2 tile blocks per wave).  Same arithmetic per output element: same bits.
 template <class K>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(K::THREADS, 2)
 conv_wino_tail(Args a) {
-  using KH = Cfg<K::TGY, K::TGX, K::MT / 2, K::WNY, K::WNX>;
+  using KH = Cfg<K::TGY, K::TGX, K::MT / 2, K::WNY, K::WNX, K::WM, K::MW>;
   int g, bx, by, n;
   if (blockIdx.x < a.nbig) {
     const unsigned t = (blockIdx.x % 8) * (a.nbig / 8) + blockIdx.x / 8;
@@ -305,7 +409,7 @@ inline int kquads_for(int Cin) { return cdiv(cdiv(Cin, 4), kCQ) * kCQ; }
 template <class K>
 static void set_geometry(Args& a) {
   a.tx = cdiv(a.Wout, K::TW); a.ty = cdiv(a.Hout, K::TH);
-  a.ng = a.Cout / 16;
+  a.ng = a.Cout / (16 * K::WM * K::MW);
   a.nchunks = a.kquads / K::CQ;
 }
 inline long long tiles_of(const Args& a) { return (long long)a.N * a.tx * a.ty * a.ng; }
@@ -322,7 +426,7 @@ static int launch(const Args& base, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wino<K>), dim3(8 * ((a.total + 7) / 8)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_wino<K>), dim3(8 * ((a.total + 7) / 8)), dim3(K::THREADS), lds, st, a);
   return check_launch("conv_wino_forward");
 }
 
@@ -342,39 +446,49 @@ static int launch_tail(const Args& base, hipStream_t st) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_tail<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL((conv_wino_tail<K>), dim3(a.nbig + 8 * ((nsm + 7) / 8)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_wino_tail<K>), dim3(a.nbig + 8 * ((nsm + 7) / 8)), dim3(K::THREADS), lds, st, a);
     return check_launch("conv_wino_forward");
   }
 }
 
 struct Variant {
-  int tgy, tgx, mt, wny, wnx;
+  int tgy, tgx, mt, wny, wnx, wm, mw;
   int (*fn)(const Args&, hipStream_t);
   int (*fn_tail)(const Args&, hipStream_t);
 };
 template <class K, bool TAIL> struct TailFn { static constexpr int (*fn)(const Args&, hipStream_t) = nullptr; };
 template <class K> struct TailFn<K, true> { static constexpr int (*fn)(const Args&, hipStream_t) = &launch_tail<K>; };
 
-// (TGY, TGX, MT, WNY, WNX): tile block shape, blocks per wave (along x), waves of the workgroup (y, x)
+// (TGY, TGX, MT, WNY, WNX, WM): tile block shape, blocks per wave (along x), waves of the workgroup along y / x / channel groups
+// (TGY, TGX, MT, WNY, WNX, WM, MW)
 #define FN2_WV_LIST(X) \
-  X(4, 4, 2, 4, 1) X(4, 4, 2, 2, 2) X(4, 4, 2, 1, 4) X(2, 8, 2, 4, 1) X(2, 8, 2, 2, 2) X(2, 8, 2, 1, 4) \
-  X(4, 4, 1, 4, 1) X(4, 4, 1, 2, 2) X(4, 4, 1, 1, 4) X(2, 8, 1, 4, 1) X(2, 8, 1, 2, 2) X(2, 8, 1, 1, 4)
-#define FN2_WV_ROW(TGY, TGX, MT, WNY, WNX) \
-  {TGY, TGX, MT, WNY, WNX, &launch<Cfg<TGY, TGX, MT, WNY, WNX>>, TailFn<Cfg<TGY, TGX, MT, WNY, WNX>, (MT >= 2)>::fn},
+  X(4, 4, 2, 4, 1, 1, 1) X(4, 4, 2, 2, 2, 1, 1) X(4, 4, 2, 1, 4, 1, 1) X(2, 8, 2, 4, 1, 1, 1) X(2, 8, 2, 2, 2, 1, 1) X(2, 8, 2, 1, 4, 1, 1) \
+  X(4, 4, 1, 4, 1, 1, 1) X(4, 4, 1, 2, 2, 1, 1) X(4, 4, 1, 1, 4, 1, 1) X(2, 8, 1, 4, 1, 1, 1) X(2, 8, 1, 2, 2, 1, 1) X(2, 8, 1, 1, 4, 1, 1) \
+  /* two channel groups per WAVE: one transformed patch feeds 32 MFMAs */ \
+  X(4, 4, 1, 4, 1, 1, 2) X(4, 4, 1, 2, 2, 1, 2) X(4, 4, 1, 1, 4, 1, 2) X(2, 8, 1, 4, 1, 1, 2) X(2, 8, 1, 2, 2, 1, 2) X(2, 8, 1, 1, 4, 1, 2) \
+  /* two channel groups per workgroup on separate waves (small maps), eight waves on pixels only */ \
+  X(4, 4, 1, 1, 2, 2, 1) X(4, 4, 1, 2, 1, 2, 1) X(2, 8, 1, 1, 2, 2, 1) X(2, 8, 1, 2, 1, 2, 1) X(4, 4, 1, 1, 8, 1, 1) X(2, 8, 1, 2, 4, 1, 1)
+#define FN2_WV_ROW(TGY, TGX, MT, WNY, WNX, WM, MW) \
+  {TGY, TGX, MT, WNY, WNX, WM, MW, &launch<Cfg<TGY, TGX, MT, WNY, WNX, WM, MW>>, TailFn<Cfg<TGY, TGX, MT, WNY, WNX, WM, MW>, (MT >= 2)>::fn},
 static const Variant kVariants[] = {FN2_WV_LIST(FN2_WV_ROW)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 int g_forced_variant = -1;
 
+static bool variant_applies(const Variant& v, const Args& a) { return a.Cout % (16 * v.wm * v.mw) == 0; }
+
+// Cost model (used when the candidates cannot be timed): tile times of the busiest CU x MFMA work of a workgroup per SIMD.
 static double variant_cost(const Variant& v, const Args& a, bool tail) {
+  if (!variant_applies(v, a)) return 1e30;
   const int th = 2 * v.tgy * v.wny, tw = 2 * v.tgx * v.mt * v.wnx;
-  const long long wgs = (long long)a.N * cdiv(a.Hout, th) * cdiv(a.Wout, tw) * (a.Cout / 16);
+  const long long wgs = (long long)a.N * cdiv(a.Hout, th) * cdiv(a.Wout, tw) * (a.Cout / (16 * v.wm * v.mw));
   double rounds = (double)((wgs + 255) / 256);
   if (tail) {
     const long long r = wgs % 256;
     if (wgs < 256 || r == 0 || r > 128) return 1e30;
     rounds = (double)(wgs / 256) + 0.56;
   }
-  return rounds * v.mt * (v.mt == 2 ? 1.35 : 1.0);      // measured: the 1-block-per-wave variants (112 VGPRs, 3-4 workgroups per CU) run the matrix pipes fuller
+  const double per_simd = v.mt * v.mw * (v.wny * v.wnx * v.wm / 4.0);      // accumulator blocks per SIMD and workgroup
+  return rounds * per_simd * (v.mt == 2 ? 1.35 : 1.0);              // measured: the 1-block-per-wave variants (112 VGPRs) run the matrix pipes fuller
 }
 
 }  // namespace wino
@@ -427,7 +541,7 @@ FN2_API int fn2_conv_wino_forward(const float* bottom, const float* packed_weigh
   if (wino::g_forced_variant >= 0) {
     tail = wino::g_forced_variant >= 1000;
     best = wino::g_forced_variant % 1000;
-    if (best >= wino::kNumVariants || (tail && !wino::kVariants[best].fn_tail))
+    if (best >= wino::kNumVariants || !wino::variant_applies(wino::kVariants[best], a) || (tail && !wino::kVariants[best].fn_tail))
       return fail(FN2_ERR_UNSUPPORTED, "conv_wino: forced variant %d does not apply", wino::g_forced_variant);
   } else {
     hipStream_t st = as_stream(stream);
@@ -437,6 +551,7 @@ FN2_API int fn2_conv_wino_forward(const float* bottom, const float* packed_weigh
       const TuneKey key{N, Cin, Hin, Win, Cout, pad, bottom_channels == Cin, top_channels == Cout, 0, 0};
       picked = autotune_pick(cache, key, 2 * wino::kNumVariants, st, [&](int c) -> int {
         const wino::Variant& v = wino::kVariants[c / 2];
+        if (!wino::variant_applies(v, a)) return FN2_ERR_UNSUPPORTED;
         if (c & 1) return (v.fn_tail && wino::variant_cost(v, a, true) < 1e29) ? v.fn_tail(a, st) : FN2_ERR_UNSUPPORTED;
         return v.fn(a, st);
       });
