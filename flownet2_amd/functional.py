@@ -196,13 +196,8 @@ def _packed_wino_weight(w):
     return hit[2]
 
 
-def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
-    """Convolution + bias (+ leaky ReLU) as ONE MFMA kernel, NCHW in and out, optionally written into a channel slice of `out`:
-    Winograd F(2x2, 3x3) for 3x3 / stride 1 / pad 1 (csrc/conv_wino.hip), the direct kernel otherwise (csrc/conv_mfma.hip).
-    Returns None when neither applies (autograd needed, unsupported geometry, too little work to fill the chip, disabled): the
-    caller then runs the library convolution."""
-    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        return None
+def _conv_mfma_pick(x, weight, stride, pad):
+    """Which own kernel serves this layer: "wino", "direct" or None (see conv_mfma_relu)."""
     Cout, Cin, k, _ = weight.shape
     if not x.is_cuda or not _mfma_conv_enabled(k, stride):
         return None
@@ -213,15 +208,64 @@ def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, o
         # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1000 the launch cannot fill 1024 SIMDs and the
         # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
         if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
-            return ops.conv_wino_forward(x.contiguous(), _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0)
+            return "wino"
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None
     # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
     # large enough to run the matrix pipes efficiently, and the library's GEMM route wins (scripts/conv_bench.py, profiles/)
     if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not force:
         return None
+    return "direct"
+
+
+def _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out=None, out_c0=0):
+    Cout, _, k, _ = weight.shape
+    if kind == "wino":
+        return ops.conv_wino_forward(x.contiguous(), _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0)
     return ops.conv_mfma_forward(x.contiguous(), _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
                                  out=out, out_c0=out_c0)
+
+
+class _ConvMFMA(torch.autograd.Function):
+    """Training form: the forward is the own fused kernel (convolution + bias + leaky ReLU in one launch); the backward undoes the
+    activation and reduces the bias gradient in one fused pass (csrc/bias_act.hip, from the saved OUTPUT) and hands the two
+    convolution gradients to the library (aten::convolution_backward = MIOpen's bwd-data / bwd-weights kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kind, stride, pad, negative_slope, act):
+        y = _conv_mfma_run(kind, x.detach(), weight.detach(), bias.detach() if bias is not None else None, stride, pad, negative_slope, act)
+        ctx.cfg = (stride, pad, negative_slope, act, bias is not None)
+        ctx.save_for_backward(x, weight, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        stride, pad, slope, act, has_bias = ctx.cfg
+        need_b = has_bias and ctx.needs_input_grad[2]
+        g = g.contiguous()
+        if act:
+            d, db = ops.bias_leaky_relu_backward(y, g, slope, need_b)
+        else:
+            d, db = g, (g.sum((0, 2, 3)) if need_b else None)
+        gx, gw, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                        [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
+        return gx, gw, db, None, None, None, None, None
+
+
+def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
+    """Convolution + bias (+ leaky ReLU) as ONE MFMA kernel, NCHW in and out, optionally written into a channel slice of `out`:
+    Winograd F(2x2, 3x3) for 3x3 / stride 1 / pad 1 (csrc/conv_wino.hip), the direct kernel otherwise (csrc/conv_mfma.hip).
+    With autograd active the same forward runs inside an autograd function (library backward).  Returns None when neither kernel
+    applies (unsupported geometry, too little work to fill the chip, disabled): the caller then runs the library convolution."""
+    kind = _conv_mfma_pick(x, weight, stride, pad)
+    if kind is None:
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        if out is not None or os.environ.get("FN2_CONV_MFMA_TRAIN", "1") == "0":
+            return None
+        return _ConvMFMA.apply(x, weight, bias, kind, stride, pad, negative_slope, act)
+    return _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out, out_c0)
 
 
 def _no_grad_needed(*ts):

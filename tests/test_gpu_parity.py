@@ -687,15 +687,24 @@ def test_training_gradients_fused_path_matches_stock_ops():
     gt[:, :, :10, :20] = float("nan")
 
     def grads(stock):
+        # stock: library convolutions + stock bias / ReLU ops everywhere; otherwise the training graph as bench.py --mode train runs
+        # it: own MFMA forward kernels inside autograd functions (forced on at this small size) + the fused bias / ReLU function
         Pd = {k: v.cuda().clone().requires_grad_(True) for k, v in P.items()}
-        keep = Fn.conv_bias_leaky_relu
+        keep, keep_env = Fn.conv_bias_leaky_relu, os.environ.get("FN2_CONV_MFMA")
         if stock:
             Fn.conv_bias_leaky_relu = lambda y, b, s=0.1: torch.nn.functional.leaky_relu(y + b.view(1, -1, 1, 1), s)
+            os.environ["FN2_CONV_MFMA"] = "none"
+        else:
+            os.environ["FN2_CONV_MFMA"] = "force"
         try:
             loss = nets.multiscale_loss(nets.flownet_c_core(Pd, im0.cuda(), im1.cuda(), Fn), gt.cuda(), Fn)
             loss.backward()
         finally:
             Fn.conv_bias_leaky_relu = keep
+            if keep_env is None:
+                os.environ.pop("FN2_CONV_MFMA", None)
+            else:
+                os.environ["FN2_CONV_MFMA"] = keep_env
         return float(loss.detach()), {k: v.grad.detach().cpu() for k, v in Pd.items() if v.grad is not None}
 
     l_fused, g_fused = grads(False)
