@@ -111,16 +111,22 @@ def l1_loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, n
 
 
 def predict_flow_conv(x, weight, bias=None):
-    """HIP kernel when no gradient is needed (deploy nets); MIOpen conv2d otherwise (training keeps autograd)."""
-    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=1)
-    return ops.predict_flow_conv_forward(x.contiguous(), weight.contiguous(), bias)
+    """predict_flow (Convolution{3,1,1} -> 2 channels): own forward kernel; with autograd active inside _OwnForwardConv."""
+    run = lambda xx, ww, bb: ops.predict_flow_conv_forward(xx.contiguous(), ww.contiguous(), bb)
+    if _needs_grad(x, weight, bias):
+        if not _train_fast_forward():
+            return torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=1)
+        return _OwnForwardConv.apply(x, weight, bias, run, 1, 1, 0.0, False, False)
+    return run(x, weight, bias)
 
 
 def upsample_flow_deconv(x, weight, bias=None):
-    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return torch.nn.functional.conv_transpose2d(x, weight, bias, stride=2, padding=1)
-    return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)
+    run = lambda xx, ww, bb: ops.upsample_flow_deconv_forward(xx.contiguous(), ww.contiguous(), bb)
+    if _needs_grad(x, weight, bias):
+        if not _train_fast_forward():
+            return torch.nn.functional.conv_transpose2d(x, weight, bias, stride=2, padding=1)
+        return _OwnForwardConv.apply(x, weight, bias, run, 2, 1, 0.0, False, True)
+    return run(x, weight, bias)
 
 
 class _BiasLeakyReLU(torch.autograd.Function):
@@ -157,11 +163,14 @@ def conv_bias_leaky_relu(y, bias, negative_slope=0.1):
 def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
     """Stem convolution + bias + leaky ReLU.  Returns None when the fused HIP kernel does not apply (autograd needed or
     unsupported shape): the caller then runs the library convolution."""
-    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return None
     if not ops.conv_k7s2_relu_supported(x.shape[1], x.shape[2], x.shape[3], weight.shape[0]):
         return None
-    return ops.conv_k7s2_relu_forward(x.contiguous(), weight.contiguous(), bias, negative_slope)
+    run = lambda xx, ww, bb: ops.conv_k7s2_relu_forward(xx.contiguous(), ww.contiguous(), bb, negative_slope)
+    if _needs_grad(x, weight, bias):
+        if not _train_fast_forward():
+            return None
+        return _OwnForwardConv.apply(x, weight, bias, run, 2, 3, negative_slope, True, False)
+    return run(x, weight, bias)
 
 
 _PACKED = {}     # id(weight tensor) -> (weak reference, _version, packed copy): one repack per weight update, not per forward
@@ -226,31 +235,40 @@ def _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out=
                                  out=out, out_c0=out_c0)
 
 
-class _ConvMFMA(torch.autograd.Function):
-    """Training form: the forward is the own fused kernel (convolution + bias + leaky ReLU in one launch); the backward undoes the
-    activation and reduces the bias gradient in one fused pass (csrc/bias_act.hip, from the saved OUTPUT) and hands the two
-    convolution gradients to the library (aten::convolution_backward = MIOpen's bwd-data / bwd-weights kernels)."""
+class _OwnForwardConv(torch.autograd.Function):
+    """Training form of the fused forward kernels: `runner(x, weight, bias)` is one of the own kernels (convolution or
+    deconvolution + bias [+ leaky ReLU] in one launch or one GEMM route); the backward undoes the activation and reduces the bias
+    gradient in one fused pass (csrc/bias_act.hip, from the saved OUTPUT) and hands the two convolution gradients to the library
+    (aten::convolution_backward = MIOpen's bwd-data / bwd-weights kernels)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, kind, stride, pad, negative_slope, act):
-        y = _conv_mfma_run(kind, x.detach(), weight.detach(), bias.detach() if bias is not None else None, stride, pad, negative_slope, act)
-        ctx.cfg = (stride, pad, negative_slope, act, bias is not None)
+    def forward(ctx, x, weight, bias, runner, stride, pad, negative_slope, act, transposed):
+        y = runner(x.detach(), weight.detach(), bias.detach() if bias is not None else None)
+        ctx.cfg = (stride, pad, negative_slope, act, bias is not None, transposed)
         ctx.save_for_backward(x, weight, y if act else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
-        stride, pad, slope, act, has_bias = ctx.cfg
+        stride, pad, slope, act, has_bias, transposed = ctx.cfg
         need_b = has_bias and ctx.needs_input_grad[2]
         g = g.contiguous()
         if act:
             d, db = ops.bias_leaky_relu_backward(y, g, slope, need_b)
         else:
             d, db = g, (g.sum((0, 2, 3)) if need_b else None)
-        gx, gw, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+        gx, gw, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
                                                         [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
-        return gx, gw, db, None, None, None, None, None
+        return gx, gw, db, None, None, None, None, None, None
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _train_fast_forward():
+    return os.environ.get("FN2_CONV_MFMA_TRAIN", "1") != "0"
 
 
 def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
@@ -264,7 +282,8 @@ def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, o
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         if out is not None or os.environ.get("FN2_CONV_MFMA_TRAIN", "1") == "0":
             return None
-        return _ConvMFMA.apply(x, weight, bias, kind, stride, pad, negative_slope, act)
+        return _OwnForwardConv.apply(x, weight, bias, lambda xx, ww, bb: _conv_mfma_run(kind, xx, ww, bb, stride, pad, negative_slope, act),
+                                     stride, pad, negative_slope, act, False)
     return _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out, out_c0)
 
 
@@ -275,26 +294,41 @@ def _no_grad_needed(*ts):
 def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1):
     """Convolution + bias + leaky ReLU the way the reference computes it -- im2col, one (batched) library GEMM, bias --
     with our batched im2col and fused bias/activation pass around rocBLAS/hipBLASLt.  Used for the layers where that
-    beats the library's direct convolution on gfx950 (nets._use_gemm_conv).  Returns None if autograd is needed."""
-    if not _no_grad_needed(x, weight, bias):
-        return None
+    beats the library's direct convolution on gfx950 (nets._use_gemm_conv).  With autograd active the same forward runs inside
+    _OwnForwardConv."""
     tuning.enable()
     N, Cin, H, W = x.shape
     Cout, k = weight.shape[0], weight.shape[2]
     Hc, Wc = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    col = ops.im2col_forward(x.contiguous(), k, pad, stride)                   # [N, Cin*k*k, Hc*Wc]
-    y = torch.matmul(weight.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
-    return ops.bias_leaky_relu_(y, bias, negative_slope)
+
+    def run(xx, ww, bb):
+        col = ops.im2col_forward(xx.contiguous(), k, pad, stride)                   # [N, Cin*k*k, Hc*Wc]
+        y = torch.matmul(ww.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
+        return ops.bias_leaky_relu_(y, bb, negative_slope)
+
+    if _needs_grad(x, weight, bias):
+        if not _train_fast_forward():
+            return None
+        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, False)
+    return run(x, weight, bias)
 
 
-def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negative_slope=0.1):
+def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negative_slope=0.1, weight=None):
     """Deconvolution + bias + leaky ReLU as the reference computes it -- weight^T x bottom (one batched library GEMM), then
     col2im -- with the bias and activation folded into our col2im pass.  weight_t = weight.view(Cin, Cout*k*k).t().contiguous()
-    (cached by the caller).  Returns None if autograd is needed."""
-    if not _no_grad_needed(x, weight_t, bias):
-        return None
+    (cached by the caller; rebuilt from `weight` when autograd is active, inside _OwnForwardConv).  Returns None if autograd is
+    needed and `weight` was not given."""
     tuning.enable()
     N, Cin, H, W = x.shape
-    col = torch.matmul(weight_t, x.contiguous().view(N, Cin, H * W))            # [N, Cout*k*k, H*W]
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
-    return ops.col2im_bias_relu_forward(col, bias, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope)
+
+    def run_t(xx, wt, bb):
+        col = torch.matmul(wt, xx.contiguous().view(N, Cin, H * W))            # [N, Cout*k*k, H*W]
+        return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope)
+
+    if _needs_grad(x, weight_t, bias, weight):
+        if weight is None or not _train_fast_forward():
+            return None
+        run = lambda xx, ww, bb: run_t(xx, ww.reshape(Cin, cout * kernel * kernel).t().contiguous(), bb)
+        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, True)
+    return run_t(x, weight_t, bias)

@@ -151,9 +151,10 @@ def _use_gemm_conv(x, stride):
 
 def _deconv(x, P, name, act=True, backend=None):
     w = P[name + ".w"]
-    if (act and backend is not None and hasattr(backend, "deconv_gemm_relu") and w.shape[0] >= 64
-            and not (torch.is_grad_enabled() and w.requires_grad)):
-        y = backend.deconv_gemm_relu(x, _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, NEG_SLOPE)
+    if act and backend is not None and hasattr(backend, "deconv_gemm_relu") and w.shape[0] >= 64:
+        training = torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)
+        y = backend.deconv_gemm_relu(x, None if training else _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, NEG_SLOPE,
+                                     weight=w)
         if y is not None:
             return y
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
