@@ -238,6 +238,392 @@ corr_bwd_mfma(const float* __restrict__ other, const float* __restrict__ top_dif
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation (stride_2 2, radius 10, W % 4 == 0, 16-byte aligned blobs): the same decomposition and the same
+// arithmetic, with the staging of the forward kernels.  The 4 rows x 72 pixels x 16 channels of the other map arrive by
+// 16-byte LDS-DMA in their natural [channel][row][column] order (zero padding = out-of-range for the buffer descriptor),
+// two buffers, ONE barrier per chunk (the first generation spends five per patch row on a register round trip: 16 loads +
+// 4 ds_write_b128 per stager lane and chunk); the slab of G for the next patch row is gathered while the last chunk of the
+// current one is multiplied.  B operand = one ds_read_b32 at lane base + immediate (2-way bank conflicts: the channel stride
+// is a multiple of 4 dwords).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dma {
+constexpr int R = 10, S2 = 2;
+using K = Cfg<S2, R>;
+constexpr int RS = K::BPX;                    // 72 dwords per staged row
+constexpr int SLOTS_R = RS / 4;               // 18 slots
+constexpr int SLOTS_C = 4 * SLOTS_R + 1;      // 73: one pad slot per channel -> channel stride 292 dwords == 4 (mod 32)
+constexpr int CS = 4 * SLOTS_C;
+constexpr int SLOTS = kKC * SLOTS_C;          // 1168 per chunk
+constexpr int NRUN = cdiv(SLOTS, 64);         // 19
+constexpr int RPW = cdiv(NRUN, kWaves);       // 3
+constexpr int BUF = NRUN * 256;
+constexpr int LDS_FLOATS = cmax(2 * BUF, K::OUT_FLOATS);
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+
+__device__ __forceinline__ void stage(__amdgpu_buffer_rsrc_t rs, const unsigned (&voff)[RPW], unsigned dst, int wave, unsigned soff) {
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int r = i * kWaves + wave;
+    if (r < NRUN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)r), 16, voff[i], soff, 0, 0);
+  }
+}
+
+template <int WHICH>
+__device__ __forceinline__ void gather_g(float (&Gv)[K::NB][4], __amdgpu_buffer_rsrc_t g_rs, const Args& g, int plane, int r0, int i0, int jw, int pi, int pj, int kk,
+                                         int py, int px) {
+  constexpr unsigned OOB = 0x7ffffff0u;
+#pragma unroll
+  for (int b = 0; b < K::NB; ++b) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      int q, o, yy, xx;
+      if (WHICH == 0) {
+        q = (r0 + ks) - (i0 + pi);
+        o = (jw - R + 4 * b + kk) - (jw + pj);
+        yy = S2 * (i0 + pi) + py;
+        xx = S2 * (jw + pj) + px;
+      } else {
+        q = (i0 + pi) - (r0 + ks);
+        o = (jw + pj) - (jw - R + 4 * b + kk);
+        yy = S2 * (r0 + ks) + py;
+        xx = S2 * (jw - R + 4 * b + kk) + px;
+      }
+      const bool ok = q >= -R && q <= R && o >= -R && o <= R && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      const unsigned off = ok ? 4u * (unsigned)(((q + R) * K::D + (o + R)) * plane + yy * g.W + xx) : OOB;
+      Gv[b][ks] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rs, off, 0, 0));
+    }
+  }
+}
+
+template <int WHICH>
+__global__ void __launch_bounds__(kThreads, 4)
+corr_bwd_dma(const float* __restrict__ other, const float* __restrict__ top_diff, float* __restrict__ out, Args g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = (int)(blockIdx.x % 8) * g.GP + (int)(blockIdx.x / 8);
+  if (L >= g.G) return;
+  int t = L;
+  const int cq = t % g.NCQ; t /= g.NCQ;
+  const int span = t % g.NSPAN; t /= g.NSPAN;
+  const int I = t % g.NI; t /= g.NI;
+  const int py = t % S2; t /= S2;
+  const int n = t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = wave % S2, Jw = wave / S2;
+  const int i0 = 4 * I, jS = K::SPANC * span, jw = jS + 4 * Jw;
+  const int Hc = (g.H - py + S2 - 1) / S2;
+  if (i0 >= Hc) return;
+  const int plane = g.H * g.W;
+  const float* src_n = other + ((size_t)n * g.C + (size_t)cq * kCQ) * plane;
+  const __amdgpu_buffer_rsrc_t s_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_n), 0, 4u * kCQ * (unsigned)plane, 0x00020000);
+  const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(top_diff + (size_t)n * K::D * K::D * plane), 0, 4u * K::D * K::D * (unsigned)plane, 0x00020000);
+  constexpr unsigned OOB = 0x7ffffff0u;
+
+  const int kk = lane >> 4, pi = (lane & 15) >> 2, pj = lane & 3, ch = lane & 15;
+
+  // live patch rows of the contraction side: r0 = i0 - R + 4a, a in [alo, ahi]
+  int alo = 0, ahi = K::NB - 1;
+  while (alo < K::NB && i0 - R + 4 * alo + 3 < 0) ++alo;
+  while (ahi >= 0 && i0 - R + 4 * ahi >= Hc) --ahi;
+
+  // ---- DMA plan: slot -> (channel, row, 4 columns); column / channel part once, row part per patch row
+  int srow[RPW];
+  unsigned vxc[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int s = (i * kWaves + wave) * 64 + lane;
+    srow[i] = -1; vxc[i] = 0;
+    if (s < SLOTS) {
+      const int c = s / SLOTS_C, rem = s % SLOTS_C;
+      if (rem < 4 * SLOTS_R) {
+        const int row = rem / SLOTS_R, gq = rem % SLOTS_R;
+        const int xb = S2 * (jS - R) + 4 * gq;
+        if (xb >= 0 && xb < g.W) { srow[i] = row; vxc[i] = 4u * (unsigned)(c * plane + xb); }
+      }
+    }
+  }
+  auto row_offsets = [&](int a, unsigned (&voff)[RPW]) {
+    const int r0 = i0 - R + 4 * a;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      voff[i] = OOB;
+      if (srow[i] >= 0) {
+        const int ir = r0 + srow[i], yb = S2 * ir + py;
+        if (ir >= 0 && yb < g.H) voff[i] = vxc[i] + 4u * (unsigned)(yb * g.W);
+      }
+    }
+  };
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  const unsigned chunk_bytes = 4u * kKC * (unsigned)plane;
+
+  f32x4 acc[kNCH][2];
+#pragma unroll
+  for (int c = 0; c < kNCH; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int bAddr = ch * CS + S2 * (4 * Jw + kk) + px;
+  if (alo <= ahi) {
+    float Gc[K::NB][4], Gn[K::NB][4];
+    unsigned voff[RPW];
+    gather_g<WHICH>(Gc, g_rs, g, plane, i0 - R + 4 * alo, i0, jw, pi, pj, kk, py, px);
+    row_offsets(alo, voff);
+    stage(s_rs, voff, lds_base, wave, 0u);
+    int buf = 0;
+    for (int a = alo; a <= ahi; ++a) {
+#pragma unroll
+      for (int c16 = 0; c16 < kNCH; ++c16) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c16 + 1 < kNCH) stage(s_rs, voff, lds_base + 4u * (unsigned)((buf ^ 1) * BUF), wave, (unsigned)(c16 + 1) * chunk_bytes);
+        else if (a < ahi) {
+          row_offsets(a + 1, voff);
+          stage(s_rs, voff, lds_base + 4u * (unsigned)((buf ^ 1) * BUF), wave, 0u);
+          gather_g<WHICH>(Gn, g_rs, g, plane, i0 - R + 4 * (a + 1), i0, jw, pi, pj, kk, py, px);
+        }
+        const float* sb = smem + buf * BUF + bAddr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int b = 0; b < K::NB; ++b)
+            acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gc[b][ks], sb[ks * RS + 2 * 4 * b], acc[c16][b & 1], 0, 0, 0);
+        buf ^= 1;
+      }
+      if (a < ahi) {
+#pragma unroll
+        for (int b = 0; b < K::NB; ++b)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) Gc[b][ks] = Gn[b][ks];
+      }
+    }
+  }
+
+  // ---- epilogue (as the first generation): accumulators -> LDS -> 128-byte rows
+  __syncthreads();
+  const float sumelems = (float)g.C;
+  const bool pow2 = (g.C & (g.C - 1)) == 0;
+  const float rcp = 1.0f / sumelems;
+  const int opi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < kNCH; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc[c][0][r] + acc[c][1][r];
+      smem[((c * kKC + ch) * 4 + opi) * K::XS + S2 * (4 * Jw + r) + px] = pow2 ? v * rcp : v / sumelems;
+    }
+  }
+  __syncthreads();
+  const int xl = tid % K::SPANPX;
+  const int x = S2 * jS + xl;
+  if (x < g.W) {
+    float* out_n = out + ((size_t)n * g.C + (size_t)cq * kCQ) * plane;
+    for (int rowid = tid / K::SPANPX; rowid < kCQ * 4; rowid += kThreads / K::SPANPX) {
+      const int c = rowid >> 2, rpi = rowid & 3;
+      const int y = S2 * (i0 + rpi) + py;
+      if (y < g.H) out_n[(size_t)c * plane + (size_t)y * g.W + x] = smem[rowid * K::XS + xl];
+    }
+  }
+}
+}  // namespace dma
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Third generation: G through LDS.  Generations 1 and 2 gather every wave's slab of G = top_diff[(k - m), m] with 24 scattered
+// dword loads per lane and patch row -- ~28 cache lines per wave instruction, 192 such instructions per workgroup and patch row:
+// the texture path, not the matrix pipe, sets their run time (the LDS-DMA staging of generation 2 changed nothing: 194 -> 190 us).
+// Here the chunk is ONE contraction row r (class row of the other map) and everything a workgroup needs for it arrives by
+// coalesced 16-byte LDS-DMA:
+//   * the row of the other map, 64 channels x 72 pixels, natural order (channel stride 76 dwords);
+//   * the rows of top_diff that hold G for that contraction row.  WHICH 0 (d bottom0): displacement row q = r - (i0 + pi) for
+//     each of the 4 output rows pi, all 21 o: 4 x 21 rows of the 32 output pixels of the workgroup (128 bytes each).
+//     WHICH 1 (d bottom1): q = (i0 + pi) - r, taken at the CONTRACTION position: 4 x 21 rows of the 72 staged pixels.
+//   The A operand of patch b is then one ds_read_b32 at lane base + immediate (+ a lane mask for displacements outside the band).
+// Rows r outside the image are skipped altogether (the earlier generations multiply their zeros).
+// Same products as before, summed row by row over the contraction rows; two accumulators per channel chunk.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace g3 {
+constexpr int R = 10, S2 = 2, D = 21;
+using K = Cfg<S2, R>;
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+constexpr int BSL = K::BPX / 4 + 1;             // 19 slots per channel of the staged row (one pad slot): stride 76 dwords
+constexpr int BCS = 4 * BSL;
+constexpr int BSLOTS = kCQ * BSL;               // 1216 = 19 whole runs
+constexpr int BRUN = BSLOTS / 64;
+static_assert(BSLOTS % 64 == 0, "the other-map region ends on a run boundary");
+template <int WHICH> struct G {
+  static constexpr int GW = WHICH == 0 ? K::SPANPX : K::BPX;     // pixels per G row: the 32 output pixels / the 72 staged pixels
+  static constexpr int GSL = GW / 4;
+  static constexpr int GSLOTS = 4 * D * GSL;
+  static constexpr int SLOTS = BSLOTS + GSLOTS;
+  static constexpr int NRUN = cdiv(SLOTS, 64);
+  static constexpr int RPW = cdiv(NRUN, kWaves);
+  static constexpr int BUF = NRUN * 256;
+  static constexpr int GOFF = BSLOTS * 4;                         // dword offset of the G slab inside a buffer
+  static constexpr int LDS_FLOATS = cmax(2 * BUF, K::OUT_FLOATS);
+};
+
+template <int WHICH>
+__device__ __forceinline__ void stage(const float* bsrc, unsigned bbytes, const float* gsrc, unsigned gbytes,
+                                      const unsigned (&vb)[G<WHICH>::RPW], const int (&gpi)[G<WHICH>::RPW], unsigned dst, int wave, int r, int i0) {
+  using T = G<WHICH>;
+  constexpr unsigned OOB = 0x7ffffff0u;
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bsrc), 0, bbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gsrc), 0, gbytes, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < T::RPW; ++i) {
+    const int run = i * kWaves + wave;
+    if (run < BRUN) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, vb[i], 0, 0, 0);
+    } else if (run < T::NRUN) {
+      const int q = WHICH == 0 ? r - i0 - gpi[i] : i0 + gpi[i] - r;          // displacement row of this slab row
+      const unsigned v = (gpi[i] >= 0 && q >= -R && q <= R) ? vb[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, v, 0, 0, 0);
+    }
+  }
+}
+
+template <int WHICH>
+__global__ void __launch_bounds__(kThreads, WHICH == 0 ? 4 : 2)
+corr_bwd_g3(const float* __restrict__ other, const float* __restrict__ top_diff, float* __restrict__ out, Args g) {
+  using T = G<WHICH>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int L = (int)(blockIdx.x % 8) * g.GP + (int)(blockIdx.x / 8);
+  if (L >= g.G) return;
+  int t = L;
+  const int cq = t % g.NCQ; t /= g.NCQ;
+  const int span = t % g.NSPAN; t /= g.NSPAN;
+  const int I = t % g.NI; t /= g.NI;
+  const int py = t % S2; t /= S2;
+  const int n = t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = wave % S2, Jw = wave / S2;
+  const int i0 = 4 * I, jS = K::SPANC * span;
+  const int Hc = (g.H - py + S2 - 1) / S2;
+  if (i0 >= Hc) return;
+  const int plane = g.H * g.W;
+  const float* src_n = other + ((size_t)n * g.C + (size_t)cq * kCQ) * plane;
+  const float* td_n = top_diff + (size_t)n * D * D * plane;
+  constexpr unsigned OOB = 0x7ffffff0u;
+
+  const int kk = lane >> 4, pi = (lane & 15) >> 2, pj = lane & 3, ch = lane & 15;
+  const int rlo = i0 - R < 0 ? 0 : i0 - R, rhi = i0 + 3 + R > Hc - 1 ? Hc - 1 : i0 + 3 + R;
+
+  // ---- DMA plan.  Runs [0, BRUN): (channel, 4 pixels) of the other map's row; the rest: (pi, oo, 4 pixels) of the G slab.
+  // Per-lane byte offsets are relative to per-chunk base pointers (the image row / the displacement row move with r).
+  unsigned vb[T::RPW];
+  int gpi[T::RPW];
+#pragma unroll
+  for (int i = 0; i < T::RPW; ++i) {
+    const int s = (i * kWaves + wave) * 64 + lane;
+    vb[i] = OOB; gpi[i] = -1;
+    if (s < BSLOTS) {
+      const int c = s / BSL, gq = s % BSL;
+      const int xb = S2 * (jS - R) + 4 * gq;
+      if (gq < K::BPX / 4 && xb >= 0 && xb < g.W) vb[i] = 4u * (unsigned)(c * plane + xb);
+    } else if (s < T::SLOTS) {
+      const int sg = s - BSLOTS;
+      const int spi = sg / (D * T::GSL), oo = (sg / T::GSL) % D, gq = sg % T::GSL;
+      if (WHICH == 0) {
+        // top_diff[(q + R) * 21 + oo][y = 2 (i0 + pi) + py][2 jS + 4 gq ..], q = r - i0 - pi:
+        //   channel = (r - i0 + R - 3) * 21  [per-chunk base]  +  21 * (3 - pi) + oo  [here]
+        const int y = S2 * (i0 + spi) + py, x = S2 * jS + 4 * gq;
+        if (y < g.H && x < g.W) { vb[i] = 4u * (unsigned)((D * (3 - spi) + oo) * plane + y * g.W + x); gpi[i] = spi; }
+      } else {
+        // top_diff[(q + R) * 21 + oo][y = 2 r + py][2 (jS - R) + 4 gq ..], q = i0 + pi - r:
+        //   channel = (i0 - r + R) * 21, row y  [per-chunk base]  +  21 * pi + oo  [here]
+        const int x = S2 * (jS - R) + 4 * gq;
+        if (x >= 0 && x < g.W) { vb[i] = 4u * (unsigned)((D * spi + oo) * plane + x); gpi[i] = spi; }
+      }
+    }
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+
+  // ---- operand addresses (dwords inside a buffer)
+  const int bAddr = ch * BCS + S2 * (4 * Jw + kk) + px;                     // + c16 * 16 * BCS + 8 b
+  int aAddr, aStep;
+  int amask = 0;                                                            // bit b: displacement column of patch b is inside the band
+  if (WHICH == 0) {
+    aAddr = T::GOFF + (pi * D + (kk - pj)) * T::GW + S2 * (4 * Jw + pj) + px;   // + b * 4 * GW   (oo = 4 b + kk - pj)
+    aStep = 4 * T::GW;
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) { const int oo = 4 * b + kk - pj; if (oo >= 0 && oo < D) amask |= 1 << b; }
+  } else {
+    aAddr = T::GOFF + (pi * D + (pj + 2 * R - kk)) * T::GW + S2 * (4 * Jw + kk) + px;   // + b * (8 - 4 * GW)   (oo = pj + 2R - 4 b - kk)
+    aStep = 8 - 4 * T::GW;
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) { const int oo = pj + 2 * R - 4 * b - kk; if (oo >= 0 && oo < D) amask |= 1 << b; }
+  }
+
+  f32x4 acc[kNCH][2];
+#pragma unroll
+  for (int c = 0; c < kNCH; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned td_bytes = 4u * D * D * (unsigned)plane, src_bytes = 4u * kCQ * (unsigned)plane;
+  // chunk r: base pointers (may point below the blob for displacement rows that do not exist: those lanes are masked in stage())
+#define FN2_G3_STAGE(rr, bb)                                                                                                     \
+  do {                                                                                                                           \
+    const int yb_ = S2 * (rr) + py;                                                                                              \
+    const long long goff_ = WHICH == 0 ? (long long)((rr) - i0 + R - 3) * D * plane                                              \
+                                       : (long long)(i0 - (rr) + R) * D * plane + (long long)yb_ * g.W;                          \
+    stage<WHICH>(src_n + (size_t)yb_ * g.W, src_bytes - 4u * (unsigned)(yb_ * g.W), td_n + goff_,                                \
+                 (unsigned)((long long)td_bytes - 4 * goff_), vb, gpi, lds_base + 4u * (unsigned)((bb) * T::BUF), wave, (rr), i0); \
+  } while (0)
+
+  FN2_G3_STAGE(rlo, 0);
+  int buf = 0;
+  for (int r = rlo; r <= rhi; ++r) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (r < rhi) FN2_G3_STAGE(r + 1, buf ^ 1);
+    const float* sb = smem + buf * T::BUF;
+    float Gv[K::NB];
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) {
+      const float v = sb[aAddr + b * aStep];
+      Gv[b] = (amask >> b) & 1 ? v : 0.f;
+    }
+#pragma unroll
+    for (int c16 = 0; c16 < kNCH; ++c16)
+#pragma unroll
+      for (int b = 0; b < K::NB; ++b)
+        acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gv[b], sb[bAddr + c16 * kKC * BCS + 8 * b], acc[c16][b & 1], 0, 0, 0);
+    buf ^= 1;
+  }
+#undef FN2_G3_STAGE
+
+  // ---- epilogue (as the earlier generations): accumulators -> LDS -> 128-byte rows
+  __syncthreads();
+  const float sumelems = (float)g.C;
+  const bool pow2 = (g.C & (g.C - 1)) == 0;
+  const float rcp = 1.0f / sumelems;
+  const int opi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < kNCH; ++c) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float v = acc[c][0][rr] + acc[c][1][rr];
+      smem[((c * kKC + ch) * 4 + opi) * K::XS + S2 * (4 * Jw + rr) + px] = pow2 ? v * rcp : v / sumelems;
+    }
+  }
+  __syncthreads();
+  const int xl = tid % K::SPANPX;
+  const int x = S2 * jS + xl;
+  if (x < g.W) {
+    float* out_n = out + ((size_t)n * g.C + (size_t)cq * kCQ) * plane;
+    for (int rowid = tid / K::SPANPX; rowid < kCQ * 4; rowid += kThreads / K::SPANPX) {
+      const int c = rowid >> 2, rpi = rowid & 3;
+      const int y = S2 * (i0 + rpi) + py;
+      if (y < g.H) out_n[(size_t)c * plane + (size_t)y * g.W + x] = smem[rowid * K::XS + xl];
+    }
+  }
+}
+}  // namespace g3
+
+int g_corr_bwd_gen = 0;           // test hook (fn2_debug_set_correlation_impl(6)): 2 = run generation 2 where generation 3 applies
+int g_corr_bwd_first_gen = 0;     // test hook (fn2_debug_set_correlation_impl(5)): run the first-generation kernel where both apply
+
 template <int S2, int R, int WHICH>
 static int launch(const CorrGeom& cg, const float* other, const float* top_diff, float* out, hipStream_t st) {
   using K = Cfg<S2, R>;
@@ -251,6 +637,29 @@ static int launch(const CorrGeom& cg, const float* other, const float* top_diff,
   if (G > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation backward: problem too large for the MFMA path");
   g.G = (int)G;
   g.GP = (g.G + 7) / 8;
+  if constexpr (S2 == 2 && R == 10) {
+    const bool aligned = cg.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(other) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned && !g_corr_bwd_first_gen && g_corr_bwd_gen != 2 && ((reinterpret_cast<uintptr_t>(top_diff)) & 15) == 0) {
+      const size_t lds3 = sizeof(float) * g3::G<WHICH>::LDS_FLOATS;
+      static bool attr3_set = false;
+      if (!attr3_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g3::corr_bwd_g3<WHICH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        attr3_set = true;
+      }
+      hipLaunchKernelGGL((g3::corr_bwd_g3<WHICH>), dim3(8 * g.GP), dim3(kThreads), lds3, st, other, top_diff, out, g);
+      return check_launch("correlation_backward (mfma, G through LDS)");
+    }
+    if (aligned && !g_corr_bwd_first_gen) {
+      const size_t lds2 = sizeof(float) * dma::LDS_FLOATS;
+      static bool attr2_set = false;
+      if (!attr2_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dma::corr_bwd_dma<WHICH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        attr2_set = true;
+      }
+      hipLaunchKernelGGL((dma::corr_bwd_dma<WHICH>), dim3(8 * g.GP), dim3(kThreads), lds2, st, other, top_diff, out, g);
+      return check_launch("correlation_backward (mfma, LDS-DMA staging)");
+    }
+  }
   const size_t lds = sizeof(float) * K::LDS_FLOATS;
   static bool attr_set = false;
   if (!attr_set) {

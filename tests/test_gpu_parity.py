@@ -756,3 +756,31 @@ def test_correlation_fused_relu_and_channel_slice(case):
                                                         N, Cc, H, W, tc + 7, 4, 1, C.c_float(0.1))
     assert rc == 0
     assert_close(out.cpu().numpy(), top, 2e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 128, 16, 24), (2, 64, 11, 28), (8, 256, 40, 56)])
+def test_correlation_backward_generations_agree_bitwise(shape):
+    """Three generations of the MFMA backward.  1 (register-staged) and 2 (LDS-DMA staging, gathered G) perform the same
+    multiplications in the same order: identical bits.  3 (G through LDS, one contraction row per chunk) sums the same products
+    row by row: equal at rounding level, on ragged heights too; all against the oracle on the small shapes."""
+    N, C, H, W = shape
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    b0, b1 = rand(shape, 41), rand(shape, 42)
+    td = rand((N, 441, H, W), 43)
+    try:
+        ops.set_correlation_impl(5)
+        f0, f1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        ops.set_correlation_impl(6)
+        s0, s1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        ops.set_correlation_impl(0)
+        t0, t1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+    finally:
+        ops.set_correlation_impl(0)
+    assert torch.equal(f0, s0) and torch.equal(f1, s1)
+    assert_close(host(t0), host(f0), 2e-6, "generation 3 vs 1, bottom 0 diff")
+    assert_close(host(t1), host(f1), 2e-6, "generation 3 vs 1, bottom 1 diff")
+    if N * C * H * W <= 2 * 64 * 24 * 40:
+        o0, o1 = oracle.correlation_backward(oracle.corr_params(20, 1, 20, 1, 2), b0, b1, td)
+        for got in ((s0, s1), (t0, t1)):
+            assert_close(host(got[0]), o0, 3e-6, "bottom 0 diff")
+            assert_close(host(got[1]), o1, 3e-6, "bottom 1 diff")
