@@ -227,12 +227,29 @@ def _conv_mfma_pick(x, weight, stride, pad):
     return "direct"
 
 
+def _channel_slice(x):
+    """(blob, first channel): x itself, or -- when x is a channel-slice view `blob[:, c0:c0+C]` of a contiguous NCHW blob (a skip
+    tensor that was written straight into its Concat blob) -- that blob and the offset, so that the kernels read it in place."""
+    if x.is_contiguous():
+        return x, 0
+    b = x._base
+    if (b is not None and b.dim() == 4 and b.is_contiguous() and x.dim() == 4 and x.stride() == b.stride() and x.shape[0] == b.shape[0]
+            and x.shape[2:] == b.shape[2:]):
+        plane = b.shape[2] * b.shape[3]
+        off = x.storage_offset() - b.storage_offset()
+        if off % plane == 0 and 0 <= off // plane and off // plane + x.shape[1] <= b.shape[1]:
+            return b, off // plane
+    return x.contiguous(), 0
+
+
 def _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out=None, out_c0=0):
-    Cout, _, k, _ = weight.shape
+    Cout, Cin, k, _ = weight.shape
+    blob, c0 = _channel_slice(x)
     if kind == "wino":
-        return ops.conv_wino_forward(x.contiguous(), _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0)
-    return ops.conv_mfma_forward(x.contiguous(), _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
-                                 out=out, out_c0=out_c0)
+        return ops.conv_wino_forward(blob, _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0,
+                                     in_c0=c0, Cin=Cin)
+    return ops.conv_mfma_forward(blob, _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
+                                 out=out, out_c0=out_c0, in_c0=c0, Cin=Cin)
 
 
 class _OwnForwardConv(torch.autograd.Function):

@@ -163,6 +163,34 @@ def _deconv(x, P, name, act=True, backend=None):
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
+def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
+    """A convolution whose output is the FIRST input of a Concat (a decoder skip tensor): where the own MFMA kernels apply and no
+    gradient is needed, the Concat blob [N, Cout + extra_channels, H, W] is allocated here and the convolution writes its channels
+    straight into it (ConcatLayer, concat_layer.cu:8-52, becomes a no-op for this input).  Returns (blob or None, the layer's output --
+    a channel-slice view of the blob, or an ordinary tensor)."""
+    w = P[name + ".w"]
+    if (backend is not None and hasattr(backend, "conv_mfma_relu") and x.is_cuda and w.shape[2] in (3, 5)
+            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))):
+        k = w.shape[2]
+        ho, wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
+        blob = torch.empty((x.shape[0], w.shape[0] + extra_channels, ho, wo), device=x.device, dtype=x.dtype)
+        if backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0) is not None:
+            return blob, blob[:, :w.shape[0]]
+    return None, _conv(x, P, name, stride, pad, backend=backend)
+
+
+def _concat(blob, skip, pieces):
+    """Concat([skip] + pieces): with a blob from _conv_into_concat only the (small) remaining pieces are copied."""
+    if blob is None:
+        return torch.cat([skip] + pieces, 1)
+    c = skip.shape[1]
+    for t in pieces:
+        blob[:, c:c + t.shape[1]].copy_(t)
+        c += t.shape[1]
+    assert c == blob.shape[1]
+    return blob
+
+
 def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
     # predict_flow (3x3 conv -> 2 ch) and upsample_flow (4x4/2 deconv 2 -> 2) go through the backend's flow-head
     # kernels when it has them (HIP: flow_head.hip); otherwise the stock conv path
@@ -407,8 +435,9 @@ def _up(P, x, name, backend):
 def flownet_sd_core(P, x, backend):
     c0 = _conv(x, P, "conv0", 1, 1, backend=backend)
     c1 = _conv(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, backend=backend)
-    c2 = _conv(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, backend=backend)
-    c3 = _conv(_conv(c2, P, "conv3", 2, 1, backend=backend), P, "conv3_1", 1, 1, backend=backend)
+    # the skip tensors of the two finest decoder levels are written straight into their Concat blobs (66 / 66 % of those copies)
+    blob2, c2 = _conv_into_concat(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, 64 + 2, backend)
+    blob3, c3 = _conv_into_concat(_conv(c2, P, "conv3", 2, 1, backend=backend), P, "conv3_1", 1, 1, 128 + 2, backend)
     c4 = _conv(_conv(c3, P, "conv4", 2, 1, backend=backend), P, "conv4_1", 1, 1, backend=backend)
     c5 = _conv(_conv(c4, P, "conv5", 2, 1, backend=backend), P, "conv5_1", 1, 1, backend=backend)
     c6 = _conv(_conv(c5, P, "conv6", 2, 1, backend=backend), P, "conv6_1", 1, 1, backend=backend)
@@ -417,20 +446,22 @@ def flownet_sd_core(P, x, backend):
     flow5 = _pf(P, _conv(cat5, P, "interconv5", 1, 1, act=False, backend=backend), "Convolution2", backend)
     cat4 = torch.cat([c4, _deconv(cat5, P, "deconv4", backend=backend), _up(P, flow5, "upsample_flow5to4", backend)], 1)
     flow4 = _pf(P, _conv(cat4, P, "interconv4", 1, 1, act=False, backend=backend), "Convolution3", backend)
-    cat3 = torch.cat([c3, _deconv(cat4, P, "deconv3", backend=backend), _up(P, flow4, "upsample_flow4to3", backend)], 1)
+    cat3 = _concat(blob3, c3, [_deconv(cat4, P, "deconv3", backend=backend), _up(P, flow4, "upsample_flow4to3", backend)])
     flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False, backend=backend), "Convolution4", backend)
-    cat2 = torch.cat([c2, _deconv(cat3, P, "deconv2", backend=backend), _up(P, flow3, "upsample_flow3to2", backend)], 1)
+    cat2 = _concat(blob2, c2, [_deconv(cat3, P, "deconv2", backend=backend), _up(P, flow3, "upsample_flow3to2", backend)])
     return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False, backend=backend), "Convolution5", backend)      # 1/4 resolution, units of 1/SD_FLOW_SCALE px
 
 
 def fusion_core(P, x, backend):
-    c0 = _conv(x, P, "conv0", 1, 1, backend=backend)
-    c1 = _conv(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, backend=backend)
+    # conv0 / conv1_1 write their 64 / 128 channels straight into the 82- / 162-channel Concat blobs of the decoder (387 MB and 191 MB
+    # at 768x384 batch 4: the two largest copies of a FlowNet2 forward)
+    blob0, c0 = _conv_into_concat(x, P, "conv0", 1, 1, 16 + 2, backend)
+    blob1, c1 = _conv_into_concat(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, 32 + 2, backend)
     c2 = _conv(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, backend=backend)
     flow2 = _pf(P, c2, "Convolution5", backend)
-    cat1 = torch.cat([c1, _deconv(c2, P, "deconv1", backend=backend), _up(P, flow2, "upsample_flow2to1", backend)], 1)
+    cat1 = _concat(blob1, c1, [_deconv(c2, P, "deconv1", backend=backend), _up(P, flow2, "upsample_flow2to1", backend)])
     flow1 = _pf(P, _conv(cat1, P, "interconv1", 1, 1, act=False, backend=backend), "Convolution6", backend)
-    cat0 = torch.cat([c0, _deconv(cat1, P, "deconv0", backend=backend), _up(P, flow1, "upsample_flow1to0", backend)], 1)
+    cat0 = _concat(blob0, c0, [_deconv(cat1, P, "deconv0", backend=backend), _up(P, flow1, "upsample_flow1to0", backend)])
     return _pf(P, _conv(cat0, P, "interconv0", 1, 1, act=False, backend=backend), "Convolution7", backend)        # full resolution, pixels
 
 

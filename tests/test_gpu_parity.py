@@ -558,6 +558,20 @@ def test_flownet2_stack_end_to_end_epe():
         out = nets.flownet2_deploy_forward(Pd, i0.cuda(), i1.cuda(), Fn).cpu()
     epe = float(((out - ref) ** 2).sum(1).sqrt().mean())
     assert np.isfinite(epe) and epe <= 1e-4, epe
+    # the same with every convolution that CAN run on the own MFMA kernels forced onto them (at this small size the work
+    # thresholds keep most of them on the library): Winograd / direct kernels, Concat blobs written in place, channel-slice inputs
+    keep = os.environ.get("FN2_CONV_MFMA")
+    os.environ["FN2_CONV_MFMA"] = "force"
+    try:
+        with torch.no_grad():
+            forced = nets.flownet2_deploy_forward(Pd, i0.cuda(), i1.cuda(), Fn).cpu()
+    finally:
+        if keep is None:
+            os.environ.pop("FN2_CONV_MFMA", None)
+        else:
+            os.environ["FN2_CONV_MFMA"] = keep
+    epe = float(((forced - ref) ** 2).sum(1).sqrt().mean())
+    assert np.isfinite(epe) and epe <= 1e-4, epe
     # non-64-multiple target size exercises the ADAPTED/TARGET resample pair and the SCALE factors
     j0, j1 = i0[:, :, :100, :150].contiguous(), i1[:, :, :100, :150].contiguous()
     with torch.no_grad():
