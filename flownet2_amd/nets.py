@@ -90,6 +90,13 @@ _LAST_ROUTE = [""]
 def _conv_routed(x, P, name, stride, pad, act, backend):
     w = P[name + ".w"]
     _LAST_ROUTE[0] = "library conv2d"
+    if w.shape[2] == 7 and w.shape[1] % 4 == 0 and backend is not None and hasattr(backend, "conv_mfma_relu"):
+        # the 12-channel stems of FlowNet2's stacked nets are whole channel quads: the direct MFMA kernel does them in one pass
+        # (the register-resident stem kernel needs two passes with partial sums through memory)
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)
+        if y is not None:
+            _LAST_ROUTE[0] = "fn2 MFMA conv"
+            return y
     if act and stride == 2 and pad == 3 and w.shape[2] == 7 and backend is not None and hasattr(backend, "conv_k7s2_relu"):
         y = backend.conv_k7s2_relu(x, w, P[name + ".b"], NEG_SLOPE)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
         if y is not None:

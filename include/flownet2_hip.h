@@ -264,7 +264,7 @@ int fn2_conv_k7s2_relu_forward(const float* bottom, const float* weight, const f
  *   The weight operand is the PACKED form of the layer's weight blob (MFMA operand order, zero-padded to whole channel
  *   quads): fn2_conv_mfma_packed_floats() floats, written by fn2_conv_mfma_pack_weights() -- once per weight update
  *   (LayerSetUp / after Solver::ApplyUpdate), not per forward.
- *   Supported (fn2_conv_mfma_supported): kernel 3 (stride 1 or 2) or 5 (stride 2), pad <= 4, Cout % 64 == 0, Win % 4 == 0,
+ *   Supported (fn2_conv_mfma_supported): kernel 3 (stride 1 or 2), 5 (stride 2) or 7 (stride 2), pad <= 4, Cout % 64 == 0, Win % 4 == 0,
  *   16-byte aligned blobs; callers keep the library convolution otherwise.  Forward only.  Exact fp32 (k-ordered fma chains;
  *   every kernel variant produces the same bits).
  * ---------------------------------------------------------------------------------------------- */

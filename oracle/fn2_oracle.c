@@ -951,7 +951,7 @@ FN2_API size_t fn2_conv_mfma_packed_floats_cpu(int Cout, int Cin, int kernel) {
 }
 
 FN2_API int fn2_conv_mfma_pack_weights_cpu(const float* weight, float* packed, int Cout, int Cin, int kernel) {
-  if (!weight || !packed || Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 5)) return FN2_ERR_INVALID_ARG;
+  if (!weight || !packed || Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 5 && kernel != 7)) return FN2_ERR_INVALID_ARG;
   const int ksteps = conv_mfma_ksteps(Cin, kernel), kalloc = ksteps + 8, kk = kernel * kernel;
   for (int g = 0; g < Cout / 64; ++g)
     for (int ks = 0; ks < kalloc; ++ks)

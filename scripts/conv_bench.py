@@ -19,8 +19,8 @@ LAYERS_C = [  # name, N, Cin, H, W, Cout, k, s, p     (FlowNetC batch 8 @448x320
     ("conv2", 16, 64, 160, 224, 128, 5, 2, 2), ("conv3", 16, 128, 80, 112, 256, 5, 2, 2), ("conv3_1", 8, 473, 40, 56, 256, 3, 1, 1),
     ("conv4", 8, 256, 40, 56, 512, 3, 2, 1), ("conv4_1", 8, 512, 20, 28, 512, 3, 1, 1), ("conv5", 8, 512, 20, 28, 512, 3, 2, 1),
     ("conv5_1", 8, 512, 10, 14, 512, 3, 1, 1), ("conv6", 8, 512, 10, 14, 1024, 3, 2, 1)]
-LAYERS_SD = [  # FlowNet2-SD / fusion / interconv layers, batch 4 @768x384
-    ("sd_conv0", 4, 6, 384, 768, 64, 3, 1, 1), ("sd_conv1_1", 4, 64, 192, 384, 128, 3, 1, 1), ("sd_conv2_1", 4, 128, 96, 192, 128, 3, 1, 1),
+LAYERS_SD = [  # FlowNet2-SD / fusion / interconv layers and the 12-channel stem, batch 4 @768x384
+    ("net2_conv1", 4, 12, 384, 768, 64, 7, 2, 3), ("sd_conv0", 4, 6, 384, 768, 64, 3, 1, 0 + 1), ("sd_conv1_1", 4, 64, 192, 384, 128, 3, 1, 1), ("sd_conv2_1", 4, 128, 96, 192, 128, 3, 1, 1),
     ("sd_ic2", 4, 194, 96, 192, 64, 3, 1, 1), ("sd_ic3", 4, 386, 48, 96, 128, 3, 1, 1), ("sd_ic4", 4, 770, 24, 48, 256, 3, 1, 1),
     ("fuse_conv0", 4, 11, 384, 768, 64, 3, 1, 1)]
 LAYERS_2 = [  # FlowNet2 batch 4 @768x384 (FlowNetS stage)

@@ -115,7 +115,7 @@ def test_layer_registry_and_blob_count_checks():
         l1.SetUp([Blob(1, 2, 4, 4, device="cpu")] * 3, [Blob(device="cpu")])
 
 
-def test_flo_bytes_roundtrip_and_fixture_layout(tmp_path):
+def test_flo_bytes_roundtrip_on_synthetic_blobs(tmp_path):      # the reference-held fixtures: tests/test_flo_fixtures.py
     rng = np.random.default_rng(0)
     blob = rng.standard_normal((2, 5, 7)).astype(np.float32)          # [2,H,W] like predict_flow_final
     p = str(tmp_path / "a.flo")

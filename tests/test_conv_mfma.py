@@ -13,7 +13,7 @@ import oracle
 
 CASES = [  # N, Cin, H, W, Cout, k, s, p
     (2, 8, 12, 16, 64, 3, 1, 1), (1, 13, 9, 20, 64, 3, 1, 1), (2, 5, 11, 12, 128, 3, 2, 1), (1, 16, 16, 24, 64, 5, 2, 2),
-    (1, 7, 13, 28, 128, 5, 2, 2), (1, 4, 8, 8, 64, 3, 1, 0), (1, 9, 10, 12, 64, 3, 2, 0)]
+    (1, 7, 13, 28, 128, 5, 2, 2), (1, 4, 8, 8, 64, 3, 1, 0), (1, 9, 10, 12, 64, 3, 2, 0), (1, 12, 20, 32, 64, 7, 2, 3), (2, 5, 18, 24, 64, 7, 2, 3)]
 
 
 def rnd(shape, seed, scale=1.0):
@@ -109,7 +109,8 @@ def test_hip_conv_channel_slices_and_reference_layer():
 @pytest.mark.gpu
 @pytest.mark.parametrize("layer", [("conv2", 16, 64, 160, 224, 128, 5, 2, 2), ("conv3", 16, 128, 80, 112, 256, 5, 2, 2),
                                    ("conv3_1", 8, 473, 40, 56, 256, 3, 1, 1), ("conv4", 8, 256, 40, 56, 512, 3, 2, 1),
-                                   ("conv4_1", 8, 512, 20, 28, 512, 3, 1, 1), ("conv3_1@768", 4, 256, 48, 96, 256, 3, 1, 1)])
+                                   ("conv4_1", 8, 512, 20, 28, 512, 3, 1, 1), ("conv3_1@768", 4, 256, 48, 96, 256, 3, 1, 1),
+                                   ("net2_conv1@768", 4, 12, 384, 768, 64, 7, 2, 3)])
 def test_conv_mfma_at_flownet_shapes(layer):
     """The layers of BASELINE.json's configs at full size: against torch's fp64-accumulated result on a sample of outputs and
     against MIOpen's fp32 result everywhere, at 1e-5 x scale."""
