@@ -308,7 +308,7 @@ def _no_grad_needed(*ts):
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts))
 
 
-def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1):
+def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True):
     """Convolution + bias + leaky ReLU the way the reference computes it -- im2col, one (batched) library GEMM, bias --
     with our batched im2col and fused bias/activation pass around rocBLAS/hipBLASLt.  Used for the layers where that
     beats the library's direct convolution on gfx950 (nets._use_gemm_conv).  With autograd active the same forward runs inside
@@ -321,12 +321,14 @@ def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1):
     def run(xx, ww, bb):
         col = ops.im2col_forward(xx.contiguous(), k, pad, stride)                   # [N, Cin*k*k, Hc*Wc]
         y = torch.matmul(ww.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
-        return ops.bias_leaky_relu_(y, bb, negative_slope)
+        if act:
+            return ops.bias_leaky_relu_(y, bb, negative_slope)
+        return y.add_(bb.view(1, -1, 1, 1)) if bb is not None else y          # a convolution without ReLU (FlowNet-SD's inter-convolutions)
 
     if _needs_grad(x, weight, bias):
         if not _train_fast_forward():
             return None
-        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, False)
+        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, act, False)
     return run(x, weight, bias)
 
 

@@ -107,8 +107,8 @@ def _conv_routed(x, P, name, stride, pad, act, backend):
         if y is not None:
             _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
-    if act and w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
-        y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE)
+    if w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
+        y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)
         if y is not None:
             _LAST_ROUTE[0] = "im2col + library GEMM"
             return y

@@ -55,7 +55,13 @@ def enable() -> bool:
         tn.tuning_enable(False)
         tn.set_filename(private, insert_device_ordinal=False)
         tn.read_file(private)
-        tn.write_file_on_exit(False)    # look-up only: nothing to record, and the private copy can go at exit
+        # look-up only: nothing to record.  TunableOp rewrites "its" file when the process exits; point it at the null device (or
+        # switch the write off where the API exists) and drop the private copy right away
+        if hasattr(tn, "write_file_on_exit"):
+            tn.write_file_on_exit(False)
+        else:
+            tn.set_filename(os.devnull, insert_device_ordinal=False)
+        _cleanup()
         atexit.register(_cleanup)
         _state = True
     except Exception:                                               # TunableOp unavailable in this torch build: library defaults

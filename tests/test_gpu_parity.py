@@ -485,6 +485,8 @@ def test_gemm_conv_paths_match_library_convolutions():
         ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1), 0.1)
         got = Fn.conv_gemm_relu(x, w, b, stride, 1, 0.1)
         assert_close(host(got), host(ref), 1e-5, "conv via im2col + GEMM")
+        plain = Fn.conv_gemm_relu(x, w, b, stride, 1, 0.1, act=False)           # FlowNet-SD's inter-convolutions: no ReLU
+        assert_close(host(plain), host(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)), 1e-5, "conv via im2col + GEMM, no ReLU")
     wd = dev(rand((64, 32, 4, 4), 67, 0.05)); bd = dev(rand((32,), 68))
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(x, wd, bd, stride=2, padding=1), 0.1)
     got = Fn.deconv_gemm_relu(x, wd.reshape(64, 32 * 16).t().contiguous(), bd, 32)
