@@ -20,7 +20,7 @@ EXPORTS = [
     "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
     "fn2_channel_norm_forward", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
-    "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward",
+    "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward", "fn2_upsample_flow_deconv_forward_into",
     "fn2_bias_leaky_relu_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
@@ -28,7 +28,11 @@ EXPORTS = [
     "fn2_caffemodel_index", "fn2_caffemodel_read_blob",
     "fn2_conv_wino_supported", "fn2_conv_wino_packed_floats", "fn2_conv_wino_pack_weights", "fn2_conv_wino_forward",
     "fn2_conv_wino_num_variants", "fn2_debug_set_wino_variant",
-    "fn2_im2col_forward", "fn2_col2im_bias_relu_forward",
+    "fn2_conv_plane_supported", "fn2_conv_plane_ksplit", "fn2_conv_plane_workspace_bytes", "fn2_conv_plane_forward",
+    "fn2_conv_plane_num_variants", "fn2_debug_set_plane_variant", "fn2_debug_set_plane_ksplit",
+    "fn2_deconv_plane_supported", "fn2_deconv_plane_ksplit", "fn2_deconv_plane_workspace_bytes", "fn2_deconv_plane_packed_floats",
+    "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_forward",
+    "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
     "fn2_augmentation_matrix", "fn2_flow_augmentation_forward",
@@ -113,6 +117,7 @@ def lib():
     L.fn2_predict_flow_conv_workspace_bytes.restype = sz
     L.fn2_predict_flow_conv_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_upsample_flow_deconv_forward.argtypes = [fp, fp, fp, fp, i, i, i, vp]
+    L.fn2_upsample_flow_deconv_forward_into.argtypes = [fp, fp, fp, fp, i, i, i, i, i, vp]
     L.fn2_bias_leaky_relu_forward.argtypes = [fp, fp, i, i, i, i, C.c_float, vp]
     L.fn2_bias_leaky_relu_backward_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_bias_leaky_relu_backward_workspace_bytes.restype = sz
@@ -120,6 +125,7 @@ def lib():
     L.fn2_conv_k7s2_relu_supported.argtypes = [i, i, i, i]
     L.fn2_im2col_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, vp]
     L.fn2_col2im_bias_relu_forward.argtypes = [fp, fp, fp, i, i, i, i, i, i, i, i, C.c_float, vp]
+    L.fn2_col2im_bias_relu_forward_into.argtypes = [fp, fp, fp, i, i, i, i, i, i, i, i, C.c_float, i, i, vp]
     L.fn2_conv_k7s2_relu_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, i, C.c_float, vp]
     L.fn2_conv_mfma_supported.argtypes = [i] * 7
     L.fn2_conv_mfma_packed_floats.argtypes = [i, i, i]
@@ -133,6 +139,21 @@ def lib():
     L.fn2_conv_wino_pack_weights.argtypes = [fp, fp, i, i, vp]
     L.fn2_conv_wino_forward.argtypes = [fp, fp, fp, fp] + [i] * 11 + [C.c_float, vp]
     L.fn2_debug_set_wino_variant.argtypes = [i]
+    L.fn2_conv_plane_supported.argtypes = [i] * 7
+    L.fn2_conv_plane_ksplit.argtypes = [i] * 7
+    L.fn2_conv_plane_workspace_bytes.argtypes = [i] * 7
+    L.fn2_conv_plane_workspace_bytes.restype = sz
+    L.fn2_conv_plane_forward.argtypes = [fp, fp, fp, fp] + [i] * 12 + [C.c_float, vp, sz, vp]
+    L.fn2_debug_set_plane_variant.argtypes = [i]
+    L.fn2_debug_set_plane_ksplit.argtypes = [i]
+    L.fn2_deconv_plane_supported.argtypes = [i] * 5
+    L.fn2_deconv_plane_ksplit.argtypes = [i] * 5
+    L.fn2_deconv_plane_workspace_bytes.argtypes = [i] * 5
+    L.fn2_deconv_plane_workspace_bytes.restype = sz
+    L.fn2_deconv_plane_packed_floats.argtypes = [i, i]
+    L.fn2_deconv_plane_packed_floats.restype = sz
+    L.fn2_deconv_plane_pack_weights.argtypes = [fp, fp, i, i, vp]
+    L.fn2_deconv_plane_forward.argtypes = [fp, fp, fp, fp] + [i] * 10 + [C.c_float, vp, sz, vp]
     L.fn2_caffemodel_index.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), i, C.POINTER(C.c_int)]
     L.fn2_caffemodel_read_blob.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), fp, sz]
     ip = C.POINTER(C.c_int)

@@ -1,7 +1,7 @@
 // First-use selection among kernel variants that produce identical results: every candidate is timed once on the caller's
 // own arguments (the output is simply written several times) and the fastest is remembered per problem shape.
-// Falls back to the caller's cost model while the stream is being captured into a graph (no host synchronisation allowed there)
-// or when FN2_AUTOTUNE=0.
+// Falls back to the caller's cost model when FN2_AUTOTUNE=0, or while the stream is being captured into a graph (no host
+// synchronisation allowed there) for a shape that has no remembered pick yet.
 #pragma once
 #include <array>
 #include <cstdio>
@@ -49,12 +49,16 @@ struct TuneCache {
   }
 };
 
-inline bool autotune_enabled(hipStream_t st) {
+// FN2_AUTOTUNE=0 switches the selection off altogether (cost model only).  While the stream is being captured into a graph no
+// candidate can be timed (no host synchronisation there), but a pick remembered from an earlier eager call is still used.
+inline bool autotune_enabled(hipStream_t) {
   static const bool on = [] { const char* e = std::getenv("FN2_AUTOTUNE"); return !(e && e[0] == '0'); }();
-  if (!on) return false;
+  return on;
+}
+
+inline bool stream_is_capturing(hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-  return true;
+  return hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
 }
 
 // run(candidate) launches one candidate and returns FN2_OK, or a non-zero status if it does not apply (skipped).
@@ -67,6 +71,7 @@ int autotune_pick(TuneCache& cache, const TuneKey& key, int ncand, hipStream_t s
     auto it = cache.best.find(key);
     if (it != cache.best.end()) return it->second;
   }
+  if (stream_is_capturing(st)) return -1;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess) return -1;
   if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return -1; }

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) conv3x3_c2_gather(const float* __restrict
 // out[n, o, Y, X] = bias[o] + sum_c sum_{ky,kx : (Y + 1 - ky) even, (X + 1 - kx) even} w[c, o, ky, kx] * in[n, c, (Y+1-ky)/2, (X+1-kx)/2]
 __global__ void __launch_bounds__(256) deconv4x4s2_c2(const float* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out,
-                                                       int N, int H, int W) {
+                                                       int N, int H, int W, int out_ctot, int out_c0) {
   const int Ho = 2 * H, Wo = 2 * W;
   const long long total = (long long)N * Ho * Wo;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -134,8 +134,8 @@ __global__ void __launch_bounds__(256) deconv4x4s2_c2(const float* __restrict__ 
         }
       }
     }
-    out[(((size_t)n * 2 + 0) * Ho + Y) * Wo + X] = a0;
-    out[(((size_t)n * 2 + 1) * Ho + Y) * Wo + X] = a1;
+    out[(((size_t)n * out_ctot + out_c0 + 0) * Ho + Y) * Wo + X] = a0;
+    out[(((size_t)n * out_ctot + out_c0 + 1) * Ho + Y) * Wo + X] = a1;
   }
 }
 
@@ -191,6 +191,17 @@ FN2_API int fn2_upsample_flow_deconv_forward(const float* in, const float* weigh
   if (N == 0) return FN2_OK;
   if (!in || !weight || !out) return fail(FN2_ERR_INVALID_ARG, "upsample_flow_deconv: NULL blob pointer");
   const long long total = (long long)N * 4 * H * W;
-  hipLaunchKernelGGL(deconv4x4s2_c2, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), in, weight, bias, out, N, H, W);
+  hipLaunchKernelGGL(deconv4x4s2_c2, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), in, weight, bias, out, N, H, W, 2, 0);
   return check_launch("upsample_flow_deconv_forward");
+}
+
+FN2_API int fn2_upsample_flow_deconv_forward_into(const float* in, const float* weight, const float* bias, float* top,
+                                                  int N, int H, int W, int top_channels, int top_c0, void* stream) {
+  if (N < 0 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "upsample_flow_deconv: bad shape");
+  if (top_c0 < 0 || top_c0 + 2 > top_channels) return fail(FN2_ERR_INVALID_ARG, "upsample_flow_deconv: channel slice outside the blob");
+  if (N == 0) return FN2_OK;
+  if (!in || !weight || !top) return fail(FN2_ERR_INVALID_ARG, "upsample_flow_deconv: NULL blob pointer");
+  const long long total = (long long)N * 4 * H * W;
+  hipLaunchKernelGGL(deconv4x4s2_c2, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), in, weight, bias, top, N, H, W, top_channels, top_c0);
+  return check_launch("upsample_flow_deconv_forward_into");
 }

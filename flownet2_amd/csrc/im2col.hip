@@ -19,6 +19,7 @@ struct ColArgs {
   int k, pad, stride;
   float slope;
   int relu;
+  int im_ctot, im_c0; // col2im: the image blob may be a channel slice [c0, c0 + C) of a blob with ctot channels
 };
 
 // grid: (ceil(Hc*Wc / 256), N * C).  Thread = one column position of one channel: k*k loads from a k x k window
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) col2im_bias_relu_kernel(const float* __re
       }
     }
     v += b;
-    im[(size_t)plane * hw + p] = (a.relu && v <= 0.f) ? v * a.slope : v;
+    im[((size_t)(plane / (unsigned)a.C) * a.im_ctot + a.im_c0 + plane % (unsigned)a.C) * hw + p] = (a.relu && v <= 0.f) ? v * a.slope : v;
   }
 }
 
@@ -76,7 +77,7 @@ static int col_geometry(const char* who, int N, int C, int H, int W, int k, int 
   a->C = C; a->H = H; a->W = W; a->k = k; a->pad = pad; a->stride = stride;
   a->Hc = (H + 2 * pad - k) / stride + 1;
   a->Wc = (W + 2 * pad - k) / stride + 1;
-  a->slope = 0.f; a->relu = 0;
+  a->slope = 0.f; a->relu = 0; a->im_ctot = C; a->im_c0 = 0;
   if ((long long)N * C > 0x7fffffffll / 256 || (long long)H * W >= (1ll << 31) || (long long)k * k * a->Hc * a->Wc >= (1ll << 31))
     return fail(FN2_ERR_UNSUPPORTED, "%s: blob too large", who);
   return FN2_OK;
@@ -106,25 +107,37 @@ FN2_API int fn2_im2col_forward(const float* im, float* col, int N, int C, int H,
   return check_launch("im2col_forward");
 }
 
-FN2_API int fn2_col2im_bias_relu_forward(const float* col, const float* bias, float* im, int N, int C, int H, int W,
-                                         int kernel, int pad, int stride, int apply_relu, float negative_slope, void* stream) {
+static int col2im_launch(const float* col, const float* bias, float* im, int N, int C, int H, int W, int kernel, int pad, int stride,
+                         int apply_relu, float negative_slope, int im_ctot, int im_c0, void* stream) {
   ColArgs a;
   int rc = col_geometry("col2im_bias_relu", N, C, H, W, kernel, pad, stride, &a);
   if (rc) return rc;
+  if (im_c0 < 0 || im_c0 + C > im_ctot) return fail(FN2_ERR_INVALID_ARG, "col2im_bias_relu: channel slice outside the blob");
   if (N == 0) return FN2_OK;
   if (!im || !col) return fail(FN2_ERR_INVALID_ARG, "col2im_bias_relu: null blob");
-  a.relu = apply_relu ? 1 : 0; a.slope = negative_slope;
+  a.relu = apply_relu ? 1 : 0; a.slope = negative_slope; a.im_ctot = im_ctot; a.im_c0 = im_c0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const unsigned hw = (unsigned)H * W, hwc = (unsigned)a.Hc * a.Wc;
   unsigned bx = (hw + 255) / 256; if (bx > 64) bx = 64;
   const long long planes = (long long)N * C;
-  // gridDim.y <= 65535: fold the planes in chunks that start on a channel-0 boundary (bias[plane % C])
+  // gridDim.y <= 65535: fold the planes in chunks of whole samples (the kernel derives (n, c) from its plane index)
   const long long step = planes > 65535 ? ((65535 / C) > 0 ? (long long)(65535 / C) * C : 0) : planes;
   if (step == 0) return fail(FN2_ERR_UNSUPPORTED, "col2im_bias_relu: more than 65535 channels");
   for (long long p0 = 0; p0 < planes; p0 += step) {
     const unsigned py = (unsigned)((planes - p0) < step ? (planes - p0) : step);
     hipLaunchKernelGGL(col2im_bias_relu_kernel, dim3(bx, py), dim3(256), 0, st, col + (size_t)p0 * kernel * kernel * hwc, bias,
-                       im + (size_t)p0 * hw, a);
+                       im + (size_t)(p0 / C) * im_ctot * hw, a);
   }
   return check_launch("col2im_bias_relu_forward");
+}
+
+FN2_API int fn2_col2im_bias_relu_forward(const float* col, const float* bias, float* im, int N, int C, int H, int W,
+                                         int kernel, int pad, int stride, int apply_relu, float negative_slope, void* stream) {
+  return col2im_launch(col, bias, im, N, C, H, W, kernel, pad, stride, apply_relu, negative_slope, C, 0, stream);
+}
+
+FN2_API int fn2_col2im_bias_relu_forward_into(const float* col, const float* bias, float* top, int N, int C, int H, int W,
+                                              int kernel, int pad, int stride, int apply_relu, float negative_slope,
+                                              int top_channels, int top_c0, void* stream) {
+  return col2im_launch(col, bias, top, N, C, H, W, kernel, pad, stride, apply_relu, negative_slope, top_channels, top_c0, stream);
 }

@@ -120,7 +120,10 @@ def predict_flow_conv(x, weight, bias=None):
     return run(x, weight, bias)
 
 
-def upsample_flow_deconv(x, weight, bias=None):
+def upsample_flow_deconv(x, weight, bias=None, out=None, out_c0=0):
+    """upsample_flow (Deconvolution{4,2,1} 2 -> 2 channels); `out`: write into that channel slice of a Concat blob (no autograd)."""
+    if out is not None and not _needs_grad(x, weight, bias):
+        return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias, out=out, out_c0=out_c0)
     run = lambda xx, ww, bb: ops.upsample_flow_deconv_forward(xx.contiguous(), ww.contiguous(), bb)
     if _needs_grad(x, weight, bias):
         if not _train_fast_forward():
@@ -206,7 +209,7 @@ def _packed_wino_weight(w):
 
 
 def _conv_mfma_pick(x, weight, stride, pad):
-    """Which own kernel serves this layer: "wino", "direct" or None (see conv_mfma_relu)."""
+    """Which own kernel serves this layer: "wino", "plane", "direct" or None (see conv_mfma_relu)."""
     Cout, Cin, k, _ = weight.shape
     if not x.is_cuda or not _mfma_conv_enabled(k, stride):
         return None
@@ -218,6 +221,10 @@ def _conv_mfma_pick(x, weight, stride, pad):
         # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
         if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
             return "wino"
+    if (k == 3 and (force or Ho * Wo <= 320) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
+            and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad)):
+        # the encoder layers below 1/16 resolution (conv5 .. conv6_1): whole planes in LDS, pixels of several samples per MFMA tile, split K
+        return "plane"
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None
     # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
@@ -248,6 +255,9 @@ def _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out=
     if kind == "wino":
         return ops.conv_wino_forward(blob, _packed_wino_weight(weight), bias, Cout, pad, act, negative_slope, out=out, out_c0=out_c0,
                                      in_c0=c0, Cin=Cin)
+    if kind == "plane":
+        return ops.conv_plane_forward(blob, _packed_conv_weight(weight), bias, Cout, stride, pad, act, negative_slope, out=out, out_c0=out_c0,
+                                      in_c0=c0, Cin=Cin)
     return ops.conv_mfma_forward(blob, _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
                                  out=out, out_c0=out_c0, in_c0=c0, Cin=Cin)
 
@@ -332,7 +342,35 @@ def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True):
     return run(x, weight, bias)
 
 
-def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negative_slope=0.1, weight=None):
+_PACKED_D = {}
+
+
+def _packed_deconv_weight(w):
+    import weakref
+    key = id(w)
+    hit = _PACKED_D.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        hit = (weakref.ref(w, lambda _r, k=key: _PACKED_D.pop(k, None)), w._version, ops.deconv_plane_pack_weights(w.detach().contiguous()))
+        _PACKED_D[key] = hit
+    return hit[2]
+
+
+def deconv_mfma_relu(x, weight, bias, negative_slope=0.1, act=True, out=None, out_c0=0):
+    """Deconvolution{4, 2, 1} + bias (+ leaky ReLU) as ONE MFMA kernel (csrc/conv_plane.hip, one output parity class per wave), NCHW in
+    and out, optionally written into a channel slice of `out` (the consumer's Concat blob).  weight: Caffe's [Cin, Cout, 4, 4] blob.
+    Opt-in (FN2_DECONV_PLANE=1): on the FlowNet shapes the library GEMM (130+ TFLOP/s) + our col2im pass is 5-25 % faster than this
+    kernel (profiles/r02_deconv_bench.txt).  Returns None when the kernel does not apply or a gradient is needed: the caller then
+    takes the GEMM + col2im route."""
+    if not x.is_cuda or os.environ.get("FN2_DECONV_PLANE", "0") == "0" or _needs_grad(x, weight, bias):
+        return None
+    Cin, Cout = weight.shape[:2]
+    if tuple(weight.shape[2:]) != (4, 4) or not ops.deconv_plane_supported(x.shape[0], Cin, x.shape[2], x.shape[3], Cout):
+        return None
+    blob, c0 = _channel_slice(x)
+    return ops.deconv_plane_forward(blob, _packed_deconv_weight(weight), bias, Cout, act, negative_slope, out=out, out_c0=out_c0, in_c0=c0, Cin=Cin)
+
+
+def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negative_slope=0.1, weight=None, out=None, out_c0=0):
     """Deconvolution + bias + leaky ReLU as the reference computes it -- weight^T x bottom (one batched library GEMM), then
     col2im -- with the bias and activation folded into our col2im pass.  weight_t = weight.view(Cin, Cout*k*k).t().contiguous()
     (cached by the caller; rebuilt from `weight` when autograd is active, inside _OwnForwardConv).  Returns None if autograd is
@@ -341,10 +379,12 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     N, Cin, H, W = x.shape
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
 
-    def run_t(xx, wt, bb):
+    def run_t(xx, wt, bb, out=None, out_c0=0):
         col = torch.matmul(wt, xx.contiguous().view(N, Cin, H * W))            # [N, Cout*k*k, H*W]
-        return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope)
+        return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope, out=out, out_c0=out_c0)
 
+    if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)
+        return None if _needs_grad(x, weight_t, bias, weight) else run_t(x, weight_t, bias, out, out_c0)
     if _needs_grad(x, weight_t, bias, weight):
         if weight is None or not _train_fast_forward():
             return None

@@ -158,6 +158,10 @@ def _use_gemm_conv(x, stride):
 
 def _deconv(x, P, name, act=True, backend=None):
     w = P[name + ".w"]
+    if act and backend is not None and hasattr(backend, "deconv_mfma_relu") and w.shape[0] >= 64:
+        y = backend.deconv_mfma_relu(x, w, P[name + ".b"], NEG_SLOPE, True)      # one MFMA kernel, a parity class per wave (csrc/conv_plane.hip)
+        if y is not None:
+            return y
     if act and backend is not None and hasattr(backend, "deconv_gemm_relu") and w.shape[0] >= 64:
         training = torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)
         y = backend.deconv_gemm_relu(x, None if training else _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, NEG_SLOPE,
@@ -199,6 +203,9 @@ def _concat(blob, skip, pieces):
 
 
 def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
+    """The refinement stages.  Every skip argument is a tensor or a pair (concat blob, tensor) from _conv_into_concat: with a blob the
+    Concat layer (concat_layer.cu:8-52) has nothing to copy -- the skip convolution already wrote its channels there, and the
+    deconvolution and the upsampled flow are written behind them by their own kernels."""
     # predict_flow (3x3 conv -> 2 ch) and upsample_flow (4x4/2 deconv 2 -> 2) go through the backend's flow-head
     # kernels when it has them (HIP: flow_head.hip); otherwise the stock conv path
     def pf(x, name):
@@ -206,21 +213,48 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
             return backend.predict_flow_conv(x, P[name + ".w"], P[name + ".b"])
         return _conv(x, P, name, 1, 1, act=False, backend=backend)
 
-    def up(x, name):
+    def up(x, name, out=None, out_c0=0):
         if backend is not None and hasattr(backend, "upsample_flow_deconv"):
+            if out is not None:
+                return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"], out=out, out_c0=out_c0)
             return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"])
         return _deconv(x, P, name, act=False)
 
+    def stage(skip, x, dname, flow, uname):
+        blob, s = skip if isinstance(skip, tuple) else (None, skip)
+        if blob is None:
+            return torch.cat([s, _deconv(x, P, dname, backend=backend), up(flow, uname)], 1)
+        cs, cd = s.shape[1], P[dname + ".w"].shape[1]
+        assert blob.shape[1] == cs + cd + 2
+        d = None
+        if hasattr(backend, "deconv_mfma_relu"):
+            d = backend.deconv_mfma_relu(x, P[dname + ".w"], P[dname + ".b"], NEG_SLOPE, True, out=blob, out_c0=cs)
+        if d is None and hasattr(backend, "deconv_gemm_relu") and P[dname + ".w"].shape[0] >= 64:
+            # library GEMM (weight^T x bottom), then our col2im + bias + ReLU pass straight into the blob
+            d = backend.deconv_gemm_relu(x, _transposed_deconv_weight(P[dname + ".w"]), P[dname + ".b"], cd, 4, 2, 1, NEG_SLOPE, out=blob, out_c0=cs)
+        if d is None:
+            blob[:, cs:cs + cd].copy_(_deconv(x, P, dname, backend=backend))
+        if hasattr(backend, "upsample_flow_deconv"):
+            up(flow, uname, out=blob, out_c0=cs + cd)
+        else:
+            blob[:, cs + cd:].copy_(up(flow, uname))
+        return blob
+
     flow6 = pf(conv6_1, "Convolution1")
-    c5 = torch.cat([conv5_1, _deconv(conv6_1, P, "deconv5", backend=backend), up(flow6, "upsample_flow6to5")], 1)
+    c5 = stage(conv5_1, conv6_1, "deconv5", flow6, "upsample_flow6to5")
     flow5 = pf(c5, "Convolution2")
-    c4 = torch.cat([conv4_1, _deconv(c5, P, "deconv4", backend=backend), up(flow5, "upsample_flow5to4")], 1)
+    c4 = stage(conv4_1, c5, "deconv4", flow5, "upsample_flow5to4")
     flow4 = pf(c4, "Convolution3")
-    c3 = torch.cat([conv3_1, _deconv(c4, P, "deconv3", backend=backend), up(flow4, "upsample_flow4to3")], 1)
+    c3 = stage(conv3_1, c4, "deconv3", flow4, "upsample_flow4to3")
     flow3 = pf(c3, "Convolution4")
-    c2 = torch.cat([conv2, _deconv(c3, P, "deconv2", backend=backend), up(flow3, "upsample_flow3to2")], 1)
+    c2 = stage(conv2, c3, "deconv2", flow3, "upsample_flow3to2")
     flow2 = pf(c2, "Convolution5")
     return {2: flow2, 3: flow3, 4: flow4, 5: flow5, 6: flow6}
+
+
+def _skip_conv(x, P, name, stride, pad, dname, backend):
+    """An encoder convolution whose output is also the first input of a refinement Concat: (concat blob or None, output tensor)."""
+    return _conv_into_concat(x, P, name, stride, pad, P[dname + ".w"].shape[1] + 2, backend)
 
 
 def flownet_c_core(P, img0, img1, backend, towers=None):
@@ -230,7 +264,8 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     x = towers if towers is not None else torch.cat([img0, img1], 0)
     n = x.shape[0] // 2
     c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
-    c2 = _conv(c1, P, "conv2", 2, 2, backend=backend)
+    # conv2 of BOTH towers goes into a [2N, 128 + 64 + 2, h, w] blob: its first N samples are the concat2 blob of the refinement
+    blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
     c3a, c3b = c3[:n], c3[n:]
     redir = _conv(c3a, P, "conv_redir", 1, 0, backend=backend)
@@ -246,28 +281,29 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     if cat is None:
         corr = backend.correlation(c3a, c3b, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
         cat = torch.cat([redir, F.leaky_relu(corr, NEG_SLOPE)], 1)
-    c31 = _conv(cat, P, "conv3_1", 1, 1, backend=backend)
+    blob3, c31 = _skip_conv(cat, P, "conv3_1", 1, 1, "deconv3", backend)
     c4 = _conv(c31, P, "conv4", 2, 1, backend=backend)
-    c41 = _conv(c4, P, "conv4_1", 1, 1, backend=backend)
+    blob4, c41 = _skip_conv(c4, P, "conv4_1", 1, 1, "deconv4", backend)
     c5 = _conv(c41, P, "conv5", 2, 1, backend=backend)
-    c51 = _conv(c5, P, "conv5_1", 1, 1, backend=backend)
+    blob5, c51 = _skip_conv(c5, P, "conv5_1", 1, 1, "deconv5", backend)
     c6 = _conv(c51, P, "conv6", 2, 1, backend=backend)
     c61 = _conv(c6, P, "conv6_1", 1, 1, backend=backend)
-    return _decoder(P, c61, c51, c41, c31, c2[:n], backend)
+    skip2 = (blob2[:n], c2[:n]) if blob2 is not None else c2[:n]
+    return _decoder(P, c61, (blob5, c51), (blob4, c41), (blob3, c31), skip2, backend)
 
 
 def flownet_s_core(P, x, backend=None):
     c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
-    c2 = _conv(c1, P, "conv2", 2, 2, backend=backend)
+    blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
-    c31 = _conv(c3, P, "conv3_1", 1, 1, backend=backend)
+    blob3, c31 = _skip_conv(c3, P, "conv3_1", 1, 1, "deconv3", backend)
     c4 = _conv(c31, P, "conv4", 2, 1, backend=backend)
-    c41 = _conv(c4, P, "conv4_1", 1, 1, backend=backend)
+    blob4, c41 = _skip_conv(c4, P, "conv4_1", 1, 1, "deconv4", backend)
     c5 = _conv(c41, P, "conv5", 2, 1, backend=backend)
-    c51 = _conv(c5, P, "conv5_1", 1, 1, backend=backend)
+    blob5, c51 = _skip_conv(c5, P, "conv5_1", 1, 1, "deconv5", backend)
     c6 = _conv(c51, P, "conv6", 2, 1, backend=backend)
     c61 = _conv(c6, P, "conv6_1", 1, 1, backend=backend)
-    return _decoder(P, c61, c51, c41, c31, c2, backend)
+    return _decoder(P, c61, (blob5, c51), (blob4, c41), (blob3, c31), (blob2, c2), backend)
 
 
 def adapted_size(h: int, w: int, divisor: int = 64):

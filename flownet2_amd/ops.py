@@ -219,13 +219,20 @@ def predict_flow_conv_forward(x, weight, bias=None):
     return out
 
 
-def upsample_flow_deconv_forward(x, weight, bias=None):
-    """Deconvolution{kernel 4, stride 2, pad 1, num_output 2} on a 2-channel flow (the upsample_flow heads)."""
+def upsample_flow_deconv_forward(x, weight, bias=None, out=None, out_c0=0):
+    """Deconvolution{kernel 4, stride 2, pad 1, num_output 2} on a 2-channel flow (the upsample_flow heads); with `out` the two
+    channels go to out[:, out_c0:out_c0+2] of a wider blob (the refinement Concat)."""
     x, w = _chk(x, "bottom[0]"), _chk(weight, "weight")
     N, Cc, H, W = x.shape
     if Cc != 2 or tuple(w.shape) != (2, 2, 4, 4):
         raise ValueError("upsample_flow expects a 2-channel flow and a [2,2,4,4] weight")
     b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    if out is not None:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (2 * H, 2 * W):
+            raise ValueError(f"upsample_flow: top blob {tuple(out.shape)} does not match [{N},*,{2 * H},{2 * W}]")
+        check(_lib.lib().fn2_upsample_flow_deconv_forward_into(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, H, W, out.shape[1], int(out_c0), _stream()))
+        return out[:, out_c0:out_c0 + 2]
     out = torch.empty((N, 2, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
     check(_lib.lib().fn2_upsample_flow_deconv_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(out), N, H, W, _stream()))
     return out
@@ -340,6 +347,96 @@ def conv_wino_forward(x, packed_weight, bias, Cout, pad=1, relu=True, negative_s
     return out
 
 
+def conv_plane_supported(N, Cin, Hin, Win, Cout, stride, pad) -> bool:
+    return bool(_lib.lib().fn2_conv_plane_supported(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(stride), int(pad)))
+
+
+def conv_plane_ksplit(N, Cin, Hin, Win, Cout, stride, pad) -> int:
+    return int(_lib.lib().fn2_conv_plane_ksplit(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(stride), int(pad)))
+
+
+_PLANE_WS = {}      # device -> the split-K partial-sum workspace (grown on demand, reused by every layer: launches are stream-ordered)
+
+
+def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """act(Convolution{3, stride, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] for small feature maps
+    (csrc/conv_plane.hip); packed_weight = conv_mfma_pack_weights(weight)."""
+    x = _chk(x, "bottom[0]")
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (Ho, Wo):
+            raise ValueError(f"conv_plane: top blob {tuple(out.shape)} does not match [{N},*,{Ho},{Wo}]")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    pw = _chk(packed_weight, "packed weight", ndim=1)
+    need = int(_lib.lib().fn2_conv_plane_workspace_bytes(N, Cin, H, W, Cout, stride, pad))
+    ws = _PLANE_WS.get(x.device)
+    if need and (ws is None or ws.numel() * 4 < need):
+        ws = _PLANE_WS[x.device] = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_conv_plane_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                            stride, pad, int(bool(relu)), C.c_float(float(negative_slope)),
+                                            _ptr(ws if need else None), need, _stream()))
+    return out
+
+
+def deconv_plane_supported(N, Cin, Hin, Win, Cout) -> bool:
+    return bool(_lib.lib().fn2_deconv_plane_supported(int(N), int(Cin), int(Hin), int(Win), int(Cout)))
+
+
+def deconv_plane_ksplit(N, Cin, Hin, Win, Cout) -> int:
+    return int(_lib.lib().fn2_deconv_plane_ksplit(int(N), int(Cin), int(Hin), int(Win), int(Cout)))
+
+
+def deconv_plane_pack_weights(weight):
+    """weight [Cin, Cout, 4, 4] (Caffe's deconvolution blob) -> per-parity-class MFMA operand order (once per weight update)."""
+    w = _chk(weight, "weight")
+    Cin, Cout, k, k2 = w.shape
+    n = _lib.lib().fn2_deconv_plane_packed_floats(Cin, Cout)
+    if k != 4 or k2 != 4 or n == 0:
+        raise ValueError(f"deconv_plane: unsupported weight shape {tuple(w.shape)}")
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().fn2_deconv_plane_pack_weights(_ptr(w), _ptr(packed), Cin, Cout, _stream()))
+    return packed
+
+
+def deconv_plane_forward(x, packed_weight, bias, Cout, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """act(Deconvolution{4, 2, 1}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] (csrc/conv_plane.hip, MODE 1)."""
+    x = _chk(x, "bottom[0]")
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    if out is None:
+        out = torch.empty((N, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (2 * H, 2 * W):
+            raise ValueError(f"deconv_plane: top blob {tuple(out.shape)} does not match [{N},*,{2 * H},{2 * W}]")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    pw = _chk(packed_weight, "packed weight", ndim=1)
+    need = int(_lib.lib().fn2_deconv_plane_workspace_bytes(N, Cin, H, W, Cout))
+    ws = _PLANE_WS.get(x.device)
+    if need and (ws is None or ws.numel() * 4 < need):
+        ws = _PLANE_WS[x.device] = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    check(_lib.lib().fn2_deconv_plane_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                              int(bool(relu)), C.c_float(float(negative_slope)), _ptr(ws if need else None), need, _stream()))
+    return out
+
+
+def set_plane_variant(v: int):
+    check(_lib.lib().fn2_debug_set_plane_variant(int(v)))
+
+
+def set_plane_ksplit(k: int):
+    check(_lib.lib().fn2_debug_set_plane_ksplit(int(k)))
+
+
+def plane_num_variants() -> int:
+    return int(_lib.lib().fn2_conv_plane_num_variants())
+
+
 def set_wino_variant(v: int):
     check(_lib.lib().fn2_debug_set_wino_variant(int(v)))
 
@@ -358,14 +455,22 @@ def im2col_forward(x, kernel, pad, stride):
     return col
 
 
-def col2im_bias_relu_forward(col, bias, N, Cc, H, W, kernel, pad, stride, relu=True, negative_slope=0.1):
-    """col [N, C*k*k, Hc*Wc] -> image [N,C,H,W] (+ bias[c], optional leaky ReLU): the tail of a Deconvolution forward."""
+def col2im_bias_relu_forward(col, bias, N, Cc, H, W, kernel, pad, stride, relu=True, negative_slope=0.1, out=None, out_c0=0):
+    """col [N, C*k*k, Hc*Wc] -> image [N,C,H,W] (+ bias[c], optional leaky ReLU): the tail of a Deconvolution forward; with `out` the
+    image goes to out[:, out_c0:out_c0+C] of a wider blob."""
     if not (col.is_cuda and col.dtype == torch.float32 and col.is_contiguous()):
         raise ValueError("col2im: expected a contiguous float32 CUDA (HIP) column blob")
     Hc, Wc = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
     if col.numel() != N * Cc * kernel * kernel * Hc * Wc:
         raise ValueError(f"col2im: column blob has {col.numel()} entries, expected {N * Cc * kernel * kernel * Hc * Wc}")
     b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    if out is not None:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (H, W):
+            raise ValueError(f"col2im: top blob {tuple(out.shape)} does not match [{N},*,{H},{W}]")
+        check(_lib.lib().fn2_col2im_bias_relu_forward_into(_ptr(col), _ptr(b), _ptr(out), N, Cc, H, W, int(kernel), int(pad), int(stride),
+                                                           int(bool(relu)), C.c_float(float(negative_slope)), out.shape[1], int(out_c0), _stream()))
+        return out[:, out_c0:out_c0 + Cc]
     out = torch.empty((N, Cc, H, W), device=col.device, dtype=torch.float32)
     check(_lib.lib().fn2_col2im_bias_relu_forward(_ptr(col), _ptr(b), _ptr(out), N, Cc, H, W, int(kernel), int(pad), int(stride),
                                                   int(bool(relu)), C.c_float(float(negative_slope)), _stream()))

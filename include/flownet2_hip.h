@@ -220,6 +220,10 @@ int fn2_predict_flow_conv_forward(const float* in, const float* weight, const fl
                                   int N, int C, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const float* bias, float* out,
                                      int N, int H, int W, void* stream);
+/* The same layer written into channels [top_c0, top_c0 + 2) of a wider top blob [N, top_channels, 2H, 2W]: the upsampled flow is
+ * the last input of the refinement stages' Concat layers (concat_layer.cu:8-52), which then has nothing left to copy. */
+int fn2_upsample_flow_deconv_forward_into(const float* in, const float* weight, const float* bias, float* top,
+                                          int N, int H, int W, int top_channels, int top_c0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution bias + leaky ReLU, in place (one pass): top[n,c,:,:] = f(top[n,c,:,:] + bias[c]), f(t) = t > 0 ? t : t * negative_slope.
@@ -299,6 +303,52 @@ int fn2_conv_wino_num_variants(void);
 int fn2_debug_set_wino_variant(int variant);     /* as fn2_debug_set_conv_variant */
 
 /* ------------------------------------------------------------------------------------------------
+ * 3x3 convolution (+ bias, + optional ReLU) for SMALL feature maps (the encoder layers below 1/16 resolution: conv4 .. conv6_1):
+ *   same layer, blob and weight conventions as fn2_conv_mfma_forward with kernel 3 (conv_layer.cu:8-23, base_conv_layer.cpp:326-348,
+ *   relu_layer.cu:8-27; packed_weight = fn2_conv_mfma_pack_weights(kernel 3); channel slices on both blobs).
+ *   The output pixels of a group of samples are flattened into MFMA M tiles, whole input planes live in LDS, and the channel
+ *   (K) axis is split over fn2_conv_plane_ksplit() workgroups whose partial sums (workspace: fn2_conv_plane_workspace_bytes())
+ *   a second kernel adds in part order before bias and ReLU.  ksplit depends on the layer geometry only, so the result is
+ *   one fixed fp32 summation order: per part the k-ordered fma chain of fn2_conv_mfma_forward, parts added in order.
+ *   Part p covers the 2-quad units [p U / ksplit, (p + 1) U / ksplit) of the channel axis, U = ceil(Cin / 8).
+ *   Supported (fn2_conv_plane_supported): stride 1 or 2, pad 0 or 1, Cin % 8 == 0, Cout % 64 == 0, a padded input plane of at most
+ *   768 floats (3072 when Win % 4 == 0); 16-byte aligned blobs and workspace.  Forward only.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_conv_plane_supported(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad);
+int fn2_conv_plane_ksplit(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad);
+size_t fn2_conv_plane_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad);
+int fn2_conv_plane_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                           int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                           int Cout, int top_channels, int top_c0, int stride, int pad,
+                           int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream);
+int fn2_conv_plane_num_variants(void);
+int fn2_debug_set_plane_variant(int variant);    /* as fn2_debug_set_conv_variant (no split-tail forms) */
+int fn2_debug_set_plane_ksplit(int ksplit);      /* > 0: force the number of K parts (changes the summation order); 0: by geometry */
+
+/* ------------------------------------------------------------------------------------------------
+ * Deconvolution{kernel 4, stride 2, pad 1} (+ bias, + optional ReLU) of the refinement stages (deconv5 .. deconv2), same kernel family:
+ *   top[:, top_c0 : top_c0 + Cout] = act(Deconvolution(bottom[:, bottom_c0 : bottom_c0 + Cin]) + bias), top is [N, *, 2 Hin, 2 Win]
+ *   <- DeconvolutionLayer::Forward_gpu, src/caffe/layers/deconv_layer.cu:8-26 (per sample backward_gpu_gemm = weight^T x bottom, then
+ *      col2im_gpu: base_conv_layer.cpp:375-393, im2col.cu:246-318; then forward_gpu_bias; weight blob [Cin, Cout, 4, 4]) and, when
+ *      relu != 0, the in-place ReLULayer::Forward_gpu, relu_layer.cu:8-27.
+ *   No column matrix: every output parity class (Y % 2, X % 2) is a 2x2-tap convolution of the input, one class per wave on a shared
+ *   LDS window; the top blob may be a channel slice of the consumer's Concat blob (concat_layer.cu).  packed_weight =
+ *   fn2_deconv_plane_pack_weights(weight) (fn2_deconv_plane_packed_floats() floats), once per weight update.  K split and workspace as
+ *   for fn2_conv_plane_forward (fn2_deconv_plane_ksplit / fn2_deconv_plane_workspace_bytes).
+ *   Supported (fn2_deconv_plane_supported): Cout % 64 == 0, a padded input plane of at most 768 floats (3072 when Win % 4 == 0), any Cin;
+ *   16-byte aligned blobs and workspace.  Forward only.
+ * ---------------------------------------------------------------------------------------------- */
+int fn2_deconv_plane_supported(int N, int Cin, int Hin, int Win, int Cout);
+int fn2_deconv_plane_ksplit(int N, int Cin, int Hin, int Win, int Cout);
+size_t fn2_deconv_plane_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout);
+size_t fn2_deconv_plane_packed_floats(int Cin, int Cout);
+int fn2_deconv_plane_pack_weights(const float* weight, float* packed, int Cin, int Cout, void* stream);
+int fn2_deconv_plane_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                             int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                             int Cout, int top_channels, int top_c0, int relu, float negative_slope,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * im2col / col2im of Caffe's GEMM convolution, batched over the mini-batch (square kernel, no dilation):
  *   fn2_im2col_forward            <- im2col_gpu, src/caffe/util/im2col.cu:8-72, as used by
  *                                    BaseConvolutionLayer::forward_gpu_gemm (base_conv_layer.cpp:325-341)
@@ -313,6 +363,11 @@ int fn2_debug_set_wino_variant(int variant);     /* as fn2_debug_set_conv_varian
 int fn2_im2col_forward(const float* im, float* col, int N, int C, int H, int W, int kernel, int pad, int stride, void* stream);
 int fn2_col2im_bias_relu_forward(const float* col, const float* bias, float* im, int N, int C, int H, int W,
                                  int kernel, int pad, int stride, int apply_relu, float negative_slope, void* stream);
+/* the same pass written into channels [top_c0, top_c0 + C) of a wider top blob [N, top_channels, H, W] (the deconvolution is an input
+ * of a refinement Concat, concat_layer.cu:8-52) */
+int fn2_col2im_bias_relu_forward_into(const float* col, const float* bias, float* top, int N, int C, int H, int W,
+                                      int kernel, int pad, int stride, int apply_relu, float negative_slope,
+                                      int top_channels, int top_c0, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * .caffemodel reader (host code): the trained blobs of a serialized NetParameter

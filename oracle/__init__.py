@@ -278,6 +278,47 @@ def conv_mfma_forward(x, packed, bias, Cout, kernel, stride, pad, relu=True, neg
     return out
 
 
+def conv_plane_forward(x, packed, bias, Cout, stride, pad, ksplit, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """CPU twin of fn2_conv_plane_forward (packed = conv_mfma_pack_weights(weight [Cout, Cin, 3, 3])); ksplit = fn2_conv_plane_ksplit()."""
+    x = _f32(x)
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    if out is None:
+        out = np.zeros((N, Cout, Ho, Wo), np.float32)
+    bias = _f32(bias) if bias is not None else None
+    _check(lib().fn2_conv_plane_forward_cpu(_p(x), _p(packed), _p(bias), _p(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                            stride, pad, int(bool(relu)), C.c_float(negative_slope), int(ksplit)), "conv_plane_forward")
+    return out
+
+
+def deconv_plane_pack_weights(weight):
+    """weight [Cin, Cout, 4, 4] (Caffe's deconvolution blob) -> the per-parity-class MFMA operand order of fn2_deconv_plane_forward."""
+    w = _f32(weight)
+    Cin, Cout = w.shape[:2]
+    assert w.shape[2:] == (4, 4)
+    L = lib()
+    L.fn2_deconv_plane_packed_floats_cpu.restype = C.c_size_t
+    n = L.fn2_deconv_plane_packed_floats_cpu(Cin, Cout)
+    assert n > 0, "unsupported weight shape"
+    packed = np.empty(n, np.float32)
+    _check(L.fn2_deconv_plane_pack_weights_cpu(_p(w), _p(packed), Cin, Cout), "deconv_plane_pack_weights")
+    return packed
+
+
+def deconv_plane_forward(x, packed, bias, Cout, ksplit, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """CPU twin of fn2_deconv_plane_forward; ksplit = fn2_deconv_plane_ksplit()."""
+    x, packed = _f32(x), _f32(packed)
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    if out is None:
+        out = np.zeros((N, Cout, 2 * H, 2 * W), np.float32)
+    bias = _f32(bias) if bias is not None else None
+    _check(lib().fn2_deconv_plane_forward_cpu(_p(x), _p(packed), _p(bias), _p(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                              int(bool(relu)), C.c_float(negative_slope), int(ksplit)), "deconv_plane_forward")
+    return out
+
+
 def conv_wino_pack_weights(weight):
     w = _f32(weight)
     Cout, Cin, k, _ = w.shape

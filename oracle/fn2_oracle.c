@@ -865,6 +865,21 @@ FN2_API int fn2_upsample_flow_deconv_forward_cpu(const float* in, const float* w
   return FN2_OK;
 }
 
+/* the same layer into channels [top_c0, top_c0 + 2) of a wider top blob (the last input of a refinement Concat) */
+FN2_API int fn2_upsample_flow_deconv_forward_into_cpu(const float* in, const float* weight, const float* bias, float* top,
+                                                      int N, int H, int W, int top_channels, int top_c0) {
+  if (N < 0 || H < 1 || W < 1 || top_c0 < 0 || top_c0 + 2 > top_channels) return FN2_ERR_INVALID_ARG;
+  const size_t plane = (size_t)4 * H * W;
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * 2 * plane);
+  if (!tmp) return FN2_ERR_INVALID_ARG;
+  const int rc = fn2_upsample_flow_deconv_forward_cpu(in, weight, bias, tmp, N, H, W);
+  if (rc == FN2_OK)
+    for (int n = 0; n < N; ++n)
+      memcpy(top + ((size_t)n * top_channels + top_c0) * plane, tmp + (size_t)n * 2 * plane, sizeof(float) * 2 * plane);
+  free(tmp);
+  return rc;
+}
+
 /* Convolution bias term + in-place leaky ReLU (base_conv_layer.cpp:343-348 forward_gpu_bias: top += bias[c];
  * relu_layer.cu:8-14 ReLUForward: out = in > 0 ? in : in * negative_slope), fp32 like the reference. */
 FN2_API int fn2_bias_leaky_relu_forward_cpu(float* data, const float* bias, int N, int C, int H, int W, float negative_slope) {
@@ -1000,6 +1015,124 @@ FN2_API int fn2_conv_mfma_forward_cpu(const float* bottom, const float* packed, 
   return FN2_OK;
 }
 
+/* 3x3 convolution for small feature maps with the channel axis split into `ksplit` parts: the CPU twin of csrc/conv_plane.hip (MODE 0).
+ * Same reference arithmetic and packed weights as fn2_conv_mfma_forward_cpu (kernel 3); per part a k-ordered fmaf chain over its
+ * channel quads (channel quad, ky, kx, channel within the quad), then the parts added in part order, then bias and ReLU.  Part p
+ * covers the 2-quad units [p U / ksplit, (p + 1) U / ksplit), U = ceil(quads / 2).
+ * ksplit is what fn2_conv_plane_ksplit() reports for the layer (passed in: the oracle does not link the HIP library). */
+FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
+                                       int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                       int Cout, int top_channels, int top_c0, int stride, int pad,
+                                       int relu, float negative_slope, int ksplit) {
+  if (N < 0 || Cin < 1 || Cin % 4 != 0 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 64 != 0 || stride < 1 || pad < 0 || ksplit < 1) return FN2_ERR_INVALID_ARG;
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
+  const int quads = Cin / 4, units = (quads + 1) / 2, kalloc = conv_mfma_ksteps(Cin, 3) + 8;
+  if (ksplit > units) return FN2_ERR_INVALID_ARG;
+  const int Ho = (Hin + 2 * pad - 3) / stride + 1, Wo = (Win + 2 * pad - 3) / stride + 1;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co) {
+      const float* wg = packed + (size_t)(co / 64) * kalloc * 256 + ((co % 64) / 16) + 4 * (co % 16);
+      for (int y = 0; y < Ho; ++y)
+        for (int x = 0; x < Wo; ++x) {
+          float sum = 0.f;
+          for (int part = 0; part < ksplit; ++part) {
+            float acc = 0.f;
+            const int q0 = 2 * (int)((long long)part * units / ksplit), q1 = 2 * (int)((long long)(part + 1) * units / ksplit);
+            for (int cq = q0; cq < q1; ++cq)
+              for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                  const int ks = (cq * 3 + ky) * 3 + kx;
+                  const int yi = stride * y - pad + ky, xi = stride * x - pad + kx;
+                  for (int kq = 0; kq < 4; ++kq) {
+                    float v = 0.f;
+                    if (4 * cq + kq < Cin && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+                      v = bottom[(((size_t)n * bottom_channels + bottom_c0 + 4 * cq + kq) * Hin + yi) * Win + xi];
+                    acc = fmaf(v, wg[(size_t)ks * 256 + 64 * kq], acc);
+                  }
+                }
+            sum = part == 0 ? acc : sum + acc;
+          }
+          float t = sum + (bias ? bias[co] : 0.f);
+          if (relu) t = t > 0.f ? t : t * negative_slope;
+          top[(((size_t)n * top_channels + top_c0 + co) * Ho + y) * Wo + x] = t;
+        }
+    }
+  return FN2_OK;
+}
+
+/* Deconvolution{4x4, stride 2, pad 1} + bias + optional ReLU on packed weights: the CPU twin of csrc/conv_plane.hip (MODE 1).
+ * Reference arithmetic: DeconvolutionLayer::Forward_cpu (deconv_layer.cpp:8-26: weight^T x bottom, col2im, bias) and the in-place ReLU
+ * (relu_layer.cpp:23-30): out[Y][X] = sum_ci sum_{ky, kx} in[y][x] W[ci][co][ky][kx] with Y = 2 y - 1 + ky, X = 2 x - 1 + kx.  Every
+ * output pixel (Y, X) = (2 m + py, 2 l + px) has 2 x 2 contributing taps: rows in[m + py - 1 + a'] with ky = (3, 1) for py = 0 and
+ * (2, 0) for py = 1 (a' = 0, 1), columns likewise; summation order (channel quad, a', b', channel within the quad) with fmaf, K split as
+ * in fn2_conv_plane_forward_cpu.  Packed layout: [class 2 py + px][Cout/64][(quads padded to 2-quad units) * 4 + 8 spare][lane 64][4],
+ * lane = 16 kq + co, element j: W[4 cq + kq][64 g + 16 j + co][ky(py, a')][kx(px, b')], k-step = (cq * 2 + a') * 2 + b'. */
+static int deconv_plane_ksteps(int Cin) { return (((Cin + 3) / 4 + 1) / 2) * 2 * 4; }
+
+FN2_API size_t fn2_deconv_plane_packed_floats_cpu(int Cin, int Cout) {
+  if (Cin <= 0 || Cout <= 0 || Cout % 64 != 0) return 0;
+  return 4 * (size_t)(Cout / 64) * (deconv_plane_ksteps(Cin) + 8) * 256;
+}
+
+static int deconv_tap(int parity, int t) { return parity == 0 ? (t == 0 ? 3 : 1) : (t == 0 ? 2 : 0); }
+
+FN2_API int fn2_deconv_plane_pack_weights_cpu(const float* weight, float* packed, int Cin, int Cout) {
+  if (!weight || !packed || Cin <= 0 || Cout <= 0 || Cout % 64 != 0) return FN2_ERR_INVALID_ARG;
+  const int ksteps = deconv_plane_ksteps(Cin), kalloc = ksteps + 8;
+  for (int cls = 0; cls < 4; ++cls)
+    for (int g = 0; g < Cout / 64; ++g)
+      for (int ks = 0; ks < kalloc; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int co = 64 * g + 16 * j + (lane & 15), ci = 4 * (ks / 4) + (lane >> 4);
+            const int ky = deconv_tap(cls >> 1, (ks >> 1) & 1), kx = deconv_tap(cls & 1, ks & 1);
+            packed[((((size_t)cls * (Cout / 64) + g) * kalloc + ks) * 64 + lane) * 4 + j] =
+                (ks < ksteps && ci < Cin) ? weight[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.f;
+          }
+  return FN2_OK;
+}
+
+FN2_API int fn2_deconv_plane_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
+                                         int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                         int Cout, int top_channels, int top_c0, int relu, float negative_slope, int ksplit) {
+  if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 64 != 0 || ksplit < 1) return FN2_ERR_INVALID_ARG;
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
+  const int quads = (Cin + 3) / 4, units = (quads + 1) / 2, kalloc = deconv_plane_ksteps(Cin) + 8;
+  if (ksplit > units) return FN2_ERR_INVALID_ARG;
+  const int Ho = 2 * Hin, Wo = 2 * Win;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co)
+      for (int Y = 0; Y < Ho; ++Y)
+        for (int X = 0; X < Wo; ++X) {
+          const int py = Y & 1, px = X & 1, m = Y >> 1, l = X >> 1, cls = 2 * py + px;
+          const float* wg = packed + ((size_t)cls * (Cout / 64) + co / 64) * kalloc * 256 + ((co % 64) / 16) + 4 * (co % 16);
+          float sum = 0.f;
+          for (int part = 0; part < ksplit; ++part) {
+            float acc = 0.f;
+            const int q0 = 2 * (int)((long long)part * units / ksplit), q1 = 2 * (int)((long long)(part + 1) * units / ksplit);
+            for (int cq = q0; cq < q1; ++cq)
+              for (int ta = 0; ta < 2; ++ta)
+                for (int tb = 0; tb < 2; ++tb) {
+                  const int ks = (cq * 2 + ta) * 2 + tb;
+                  const int yi = m + py - 1 + ta, xi = l + px - 1 + tb;
+                  for (int kq = 0; kq < 4; ++kq) {
+                    float v = 0.f;
+                    if (4 * cq + kq < Cin && yi >= 0 && yi < Hin && xi >= 0 && xi < Win)
+                      v = bottom[(((size_t)n * bottom_channels + bottom_c0 + 4 * cq + kq) * Hin + yi) * Win + xi];
+                    acc = fmaf(v, wg[(size_t)ks * 256 + 64 * kq], acc);
+                  }
+                }
+            sum = part == 0 ? acc : sum + acc;
+          }
+          float t = sum + (bias ? bias[co] : 0.f);
+          if (relu) t = t > 0.f ? t : t * negative_slope;
+          top[(((size_t)n * top_channels + top_c0 + co) * Ho + Y) * Wo + X] = t;
+        }
+  return FN2_OK;
+}
+
 /* 3x3 / stride 1 convolution as Winograd F(2x2, 3x3): the CPU twin of csrc/conv_wino.hip, operation for operation.
  * Reference arithmetic: conv_layer.cpp:25-40 / base_conv_layer.cpp:255-318 (+ relu_layer.cpp:23-30); the reference sums K = 9 Cin
  * products per output in a library-defined order, Winograd sums Cin products per transform-domain position and combines 16 of
@@ -1129,8 +1262,24 @@ FN2_API int fn2_im2col_forward_cpu(const float* im, float* col, int N, int C, in
   return FN2_OK;
 }
 
+static int col2im_bias_relu_cpu(const float* col, const float* bias, float* im, int N, int C, int H, int W,
+                                int kernel, int pad, int stride, int apply_relu, float negative_slope, int im_ctot, int im_c0);
+
 FN2_API int fn2_col2im_bias_relu_forward_cpu(const float* col, const float* bias, float* im, int N, int C, int H, int W,
                                              int kernel, int pad, int stride, int apply_relu, float negative_slope) {
+  return col2im_bias_relu_cpu(col, bias, im, N, C, H, W, kernel, pad, stride, apply_relu, negative_slope, C, 0);
+}
+
+/* the same pass into channels [top_c0, top_c0 + C) of a wider top blob */
+FN2_API int fn2_col2im_bias_relu_forward_into_cpu(const float* col, const float* bias, float* top, int N, int C, int H, int W,
+                                                  int kernel, int pad, int stride, int apply_relu, float negative_slope,
+                                                  int top_channels, int top_c0) {
+  if (top_c0 < 0 || top_c0 + C > top_channels) return FN2_ERR_INVALID_ARG;
+  return col2im_bias_relu_cpu(col, bias, top, N, C, H, W, kernel, pad, stride, apply_relu, negative_slope, top_channels, top_c0);
+}
+
+static int col2im_bias_relu_cpu(const float* col, const float* bias, float* im, int N, int C, int H, int W,
+                                int kernel, int pad, int stride, int apply_relu, float negative_slope, int im_ctot, int im_c0) {
   if (N < 0 || C < 1 || H < 1 || W < 1 || kernel < 1 || pad < 0 || stride < 1 || H + 2 * pad < kernel || W + 2 * pad < kernel)
     return FN2_ERR_INVALID_ARG;
   const int Hc = (H + 2 * pad - kernel) / stride + 1, Wc = (W + 2 * pad - kernel) / stride + 1;
@@ -1152,7 +1301,7 @@ FN2_API int fn2_col2im_bias_relu_forward_cpu(const float* col, const float* bias
           }
         }
         v += b;
-        im[(size_t)pl * H * W + (size_t)yy * W + xx] = (apply_relu && v <= 0.f) ? v * negative_slope : v;
+        im[((size_t)(pl / C) * im_ctot + im_c0 + pl % C) * H * W + (size_t)yy * W + xx] = (apply_relu && v <= 0.f) ? v * negative_slope : v;
       }
   }
   return FN2_OK;

@@ -18,7 +18,7 @@ from flownet2_amd import functional as Fn, nets, ops  # noqa: E402
 LAYERS_C = [  # name, N, Cin, H, W, Cout, k, s, p     (FlowNetC batch 8 @448x320; the siamese towers run as batch 16)
     ("conv2", 16, 64, 160, 224, 128, 5, 2, 2), ("conv3", 16, 128, 80, 112, 256, 5, 2, 2), ("conv3_1", 8, 473, 40, 56, 256, 3, 1, 1),
     ("conv4", 8, 256, 40, 56, 512, 3, 2, 1), ("conv4_1", 8, 512, 20, 28, 512, 3, 1, 1), ("conv5", 8, 512, 20, 28, 512, 3, 2, 1),
-    ("conv5_1", 8, 512, 10, 14, 512, 3, 1, 1), ("conv6", 8, 512, 10, 14, 1024, 3, 2, 1)]
+    ("conv5_1", 8, 512, 10, 14, 512, 3, 1, 1), ("conv6", 8, 512, 10, 14, 1024, 3, 2, 1), ("conv6_1", 8, 1024, 5, 7, 1024, 3, 1, 1)]
 LAYERS_SD = [  # FlowNet2-SD / fusion / interconv layers and the 12-channel stem, batch 4 @768x384
     ("net2_conv1", 4, 12, 384, 768, 64, 7, 2, 3), ("sd_conv0", 4, 6, 384, 768, 64, 3, 1, 0 + 1), ("sd_conv1_1", 4, 64, 192, 384, 128, 3, 1, 1), ("sd_conv2_1", 4, 128, 96, 192, 128, 3, 1, 1),
     ("sd_ic2", 4, 194, 96, 192, 64, 3, 1, 1), ("sd_ic3", 4, 386, 48, 96, 128, 3, 1, 1), ("sd_ic4", 4, 770, 24, 48, 256, 3, 1, 1),
@@ -26,7 +26,7 @@ LAYERS_SD = [  # FlowNet2-SD / fusion / interconv layers and the 12-channel stem
 LAYERS_2 = [  # FlowNet2 batch 4 @768x384 (FlowNetS stage)
     ("conv2", 4, 64, 192, 384, 128, 5, 2, 2), ("conv3", 4, 128, 96, 192, 256, 5, 2, 2), ("conv3_1", 4, 256, 48, 96, 256, 3, 1, 1),
     ("conv4", 4, 256, 48, 96, 512, 3, 2, 1), ("conv4_1", 4, 512, 24, 48, 512, 3, 1, 1), ("conv5", 4, 512, 24, 48, 512, 3, 2, 1),
-    ("conv5_1", 4, 512, 12, 24, 512, 3, 1, 1)]
+    ("conv5_1", 4, 512, 12, 24, 512, 3, 1, 1), ("conv6", 4, 512, 12, 24, 1024, 3, 2, 1), ("conv6_1", 4, 1024, 6, 12, 1024, 3, 1, 1)]
 
 
 def timeit(fn, iters=20, warm=3):
@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--net", default="C")
     ap.add_argument("--layers", default="")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--plane-ksplit", default="", help="comma list of K splits to time for the small-map kernel (default: the geometry's own)")
+    ap.add_argument("--only-plane", action="store_true")
     a = ap.parse_args()
     layers = {"C": LAYERS_C, "2": LAYERS_2, "SD": LAYERS_SD}[a.net]
     if a.layers:
@@ -86,6 +88,30 @@ def main():
             ops.set_wino_variant(-1)
             t = timeit(lambda: ops.conv_wino_forward(x, pu, b, Cout, p, True, 0.1, out=outw), a.iters)
             print(f"   winograd cost-model choice: {t:7.1f} us {gf / t * 1e3:6.1f} TF(direct-equivalent)", flush=True)
+        if k == 3 and ops.conv_plane_supported(N, Cin, H, W, Cout, s, p):
+            pwp = ops.conv_mfma_pack_weights(w)
+            outp = torch.empty_like(want)
+            for ksp in ([int(v) for v in a.plane_ksplit.split(",")] if a.plane_ksplit else [0]):
+                ops.set_plane_ksplit(ksp)
+                ks_used = ops.conv_plane_ksplit(N, Cin, H, W, Cout, s, p)
+                firstp = None
+                for v in range(ops.plane_num_variants()):
+                    ops.set_plane_variant(v)
+                    try:
+                        ops.conv_plane_forward(x, pwp, b, Cout, s, p, True, 0.1, out=outp)
+                    except flownet2_amd.Fn2Error:
+                        continue
+                    torch.cuda.synchronize()
+                    err = float((outp - want).abs().max())
+                    same = "" if firstp is None else ("  bits==first" if torch.equal(outp, firstp) else "  BITS DIFFER")
+                    if firstp is None:
+                        firstp = outp.clone()
+                    t = timeit(lambda: ops.conv_plane_forward(x, pwp, b, Cout, s, p, True, 0.1, out=outp), a.iters)
+                    print(f"   plane ksplit {ks_used:2d} variant {v:3d}: {t:7.1f} us {gf / t * 1e3:6.1f} TF   max|diff vs torch| {err:.2e}{same}", flush=True)
+                ops.set_plane_variant(-1)
+            ops.set_plane_ksplit(0)
+        if a.only_plane:
+            continue
         if not ops.conv_mfma_supported(Cin, H, W, Cout, k, s, p):
             print("   (conv_mfma: unsupported geometry)")
             continue

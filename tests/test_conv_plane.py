@@ -1,0 +1,240 @@
+"""Small-map 3x3 convolution (csrc/conv_plane.hip, fn2_conv_plane_*): the oracle twin against torch's fp64 convolution (CPU), the HIP
+kernels against the oracle BIT FOR BIT in every tile variant and for several K splits, against the reference's own Convolution + ReLU
+layers (oracle/_ref: conv_layer.cu:8-23, base_conv_layer.cpp:326-348, relu_layer.cu:8-27), and the encoder layers of BASELINE.json's
+configs below 1/16 resolution at full size."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import flownet2_amd
+
+import oracle
+
+CASES = [  # N, Cin, H, W, Cout, s, p    (odd widths -> dword DMA, widths % 4 == 0 -> 16-byte DMA; ragged batches; one sample larger than a tile block)
+    (8, 16, 5, 7, 64, 1, 1), (3, 8, 10, 14, 128, 1, 1), (5, 16, 10, 14, 64, 2, 1), (2, 8, 20, 28, 64, 2, 1), (2, 16, 12, 24, 64, 1, 1),
+    (1, 8, 40, 56, 64, 2, 1), (3, 24, 6, 12, 64, 1, 0), (2, 8, 14, 32, 128, 1, 1), (1, 32, 24, 48, 64, 2, 1), (7, 8, 7, 16, 64, 2, 1)]
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def torch64(x, w, b, s, p, relu):
+    y = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double() if b is not None else None, stride=s, padding=p)
+    return (F.leaky_relu(y, 0.1) if relu else y).numpy()
+
+
+@pytest.mark.parametrize("case", CASES[:6])
+def test_oracle_plane_conv_matches_fp64_convolution(case):
+    N, Cin, H, W, Cout, s, p = case
+    x, w, b = rnd((N, Cin, H, W), 1), rnd((Cout, Cin, 3, 3), 2, 0.2), rnd((Cout,), 3)
+    pw = oracle.conv_mfma_pack_weights(w)
+    for ksplit in (1, 2) if Cin >= 16 else (1,):
+        for relu in (True, False):
+            got = oracle.conv_plane_forward(x, pw, b, Cout, s, p, ksplit, relu, 0.1)
+            want = torch64(x, w, b, s, p, relu)
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    # one part = the direct kernel's chain, bit for bit
+    assert np.array_equal(oracle.conv_plane_forward(x, pw, b, Cout, s, p, 1), oracle.conv_mfma_forward(x, pw, b, Cout, 3, s, p))
+
+
+def test_oracle_plane_conv_channel_slices():
+    x, w, b = rnd((2, 20, 6, 9), 4), rnd((64, 8, 3, 3), 5, 0.2), rnd((64,), 6)
+    pw = oracle.conv_mfma_pack_weights(w)
+    out = np.full((2, 70, 6, 9), 7.0, np.float32)
+    oracle.conv_plane_forward(x, pw, b, 64, 1, 1, 1, True, 0.1, out=out, out_c0=3, in_c0=4, Cin=8)
+    want = oracle.conv_plane_forward(np.ascontiguousarray(x[:, 4:12]), pw, b, 64, 1, 1, 1, True, 0.1)
+    assert np.array_equal(out[:, 3:67], want) and (out[:, :3] == 7).all() and (out[:, 67:] == 7).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_hip_plane_conv_equals_oracle_bitwise_in_every_variant(case):
+    from flownet2_amd import ops
+    N, Cin, H, W, Cout, s, p = case
+    x, w, b = rnd((N, Cin, H, W), 11), rnd((Cout, Cin, 3, 3), 12, 0.2), rnd((Cout,), 13)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    pw = ops.conv_mfma_pack_weights(dv(w))
+    pwh = pw.cpu().numpy()
+    assert ops.conv_plane_supported(N, Cin, H, W, Cout, s, p)
+    ran = 0
+    try:
+        for ksplit in (0, 1, 2, 3, 4):                   # 0: the geometry's own; forced values are clamped to the number of 2-quad units
+            ops.set_plane_ksplit(ksplit)
+            ks = ops.conv_plane_ksplit(N, Cin, H, W, Cout, s, p)
+            assert ksplit == 0 or ks == ksplit or ks <= (Cin // 4 + 1) // 2
+            want = oracle.conv_plane_forward(x, pwh, b, Cout, s, p, ks, True, 0.1)
+            for v in range(ops.plane_num_variants()):
+                ops.set_plane_variant(v)
+                try:
+                    got = ops.conv_plane_forward(dv(x), pw, dv(b), Cout, s, p, True, 0.1)
+                except flownet2_amd.Fn2Error:
+                    continue                              # variant of the other stride / DMA width, or a plane too small for 16-byte runs
+                ran += 1
+                assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"variant {v}, ksplit {ks}"
+            ops.set_plane_variant(-1)
+            got = ops.conv_plane_forward(dv(x), pw, None, Cout, s, p, False, 0.1)              # the autotuned pick, no bias, no ReLU
+            assert np.array_equal(got.cpu().numpy(), oracle.conv_plane_forward(x, pwh, None, Cout, s, p, ks, False, 0.1))
+    finally:
+        ops.set_plane_variant(-1)
+        ops.set_plane_ksplit(0)
+    assert ran >= 2
+
+
+@pytest.mark.gpu
+def test_hip_plane_conv_channel_slices_and_reference_layer():
+    from flownet2_amd import ops
+    from oracle import ref
+    dv = lambda a: torch.from_numpy(a).cuda()
+    x, w, b = rnd((3, 20, 6, 9), 4), rnd((64, 8, 3, 3), 5, 0.2), rnd((64,), 6)
+    pw = ops.conv_mfma_pack_weights(dv(w))
+    out = torch.full((3, 70, 6, 9), 7.0, device="cuda")
+    ops.conv_plane_forward(dv(x), pw, dv(b), 64, 1, 1, True, 0.1, out=out, out_c0=3, in_c0=4, Cin=8)
+    ks = ops.conv_plane_ksplit(3, 8, 6, 9, 64, 1, 1)
+    want = oracle.conv_plane_forward(np.ascontiguousarray(x[:, 4:12]), pw.cpu().numpy(), b, 64, 1, 1, ks, True, 0.1)
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, 3:67], want) and (o[:, :3] == 7).all() and (o[:, 67:] == 7).all()
+    if ref.available():
+        for (s, H, W) in [(1, 10, 14), (2, 20, 28), (1, 5, 7)]:
+            x, w, b = rnd((4, 64, H, W), 20 + s), rnd((128, 64, 3, 3), 21 + s, 0.1), rnd((128,), 22)
+            r = ref.convolution(x, w, b, kernel=3, stride=s, pad=1, relu=True)
+            got = ops.conv_plane_forward(dv(x), ops.conv_mfma_pack_weights(dv(w)), dv(b), 128, s, 1, True, 0.1).cpu().numpy()
+            assert np.abs(got - r).max() <= 1e-5 * max(1.0, np.abs(r).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", [("conv4", 8, 256, 40, 56, 512, 2), ("conv5", 8, 512, 20, 28, 512, 2), ("conv5_1", 8, 512, 10, 14, 512, 1),
+                                   ("conv6", 8, 512, 10, 14, 1024, 2), ("conv6_1", 8, 1024, 5, 7, 1024, 1),
+                                   ("conv5@768", 4, 512, 24, 48, 512, 2), ("conv5_1@768", 4, 512, 12, 24, 512, 1), ("conv6_1@768", 4, 1024, 6, 12, 1024, 1),
+                                   ("conv5_1@1024", 1, 512, 14, 32, 512, 1), ("conv6_1@1024", 1, 1024, 7, 16, 1024, 1)])
+def test_conv_plane_at_flownet_shapes(layer):
+    """The small-map encoder layers of BASELINE.json's configs at full size: against the library's fp32 result everywhere and torch's
+    fp64-accumulated result on the first sample, at 1e-5 x scale."""
+    from flownet2_amd import ops
+    name, N, Cin, H, W, Cout, s = layer
+    assert ops.conv_plane_supported(N, Cin, H, W, Cout, s, 1), name
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    got = ops.conv_plane_forward(x, ops.conv_mfma_pack_weights(w), b, Cout, s, 1, True, 0.1)
+    lib = F.leaky_relu(F.conv2d(x, w, b, stride=s, padding=1), 0.1)
+    scale = max(1.0, float(lib.abs().max()))
+    assert float((got - lib).abs().max()) <= 1e-5 * scale
+    want64 = F.leaky_relu(F.conv2d(x[:1].double(), w.double(), b.double(), stride=s, padding=1), 0.1)
+    assert float((got[:1].double() - want64).abs().max()) <= 4e-6 * scale
+
+
+# ------------------------------------------------------------------------------------------------ deconvolution 4x4 / stride 2 / pad 1
+DECONV_CASES = [  # N, Cin, H, W, Cout     (Cin not a multiple of 4 / 8: the refinement stages concatenate 2 flow channels)
+    (8, 16, 5, 7, 64), (3, 10, 10, 14, 128), (2, 26, 20, 28, 64), (1, 6, 40, 56, 64), (2, 16, 6, 12, 64), (5, 32, 7, 16, 64), (1, 9, 12, 24, 128)]
+
+
+def torch64_deconv(x, w, b, relu):
+    y = F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double() if b is not None else None,
+                           stride=2, padding=1)
+    return (F.leaky_relu(y, 0.1) if relu else y).numpy()
+
+
+@pytest.mark.parametrize("case", DECONV_CASES[:5])
+def test_oracle_plane_deconv_matches_fp64_deconvolution(case):
+    N, Cin, H, W, Cout = case
+    x, w, b = rnd((N, Cin, H, W), 1), rnd((Cin, Cout, 4, 4), 2, 0.2), rnd((Cout,), 3)
+    pw = oracle.deconv_plane_pack_weights(w)
+    for ksplit in (1, 2) if Cin > 8 else (1,):
+        for relu in (True, False):
+            got = oracle.deconv_plane_forward(x, pw, b, Cout, ksplit, relu, 0.1)
+            want = torch64_deconv(x, w, b, relu)
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
+def test_oracle_plane_deconv_matches_the_oracle_deconvolution_layer_and_slices():
+    """Against the oracle's plain Deconvolution restatement (deconv_layer.cpp:8-26 through col2im), and into a channel slice of a wider blob."""
+    x, w, b = rnd((2, 10, 6, 9), 4), rnd((10, 64, 4, 4), 5, 0.2), rnd((64,), 6)
+    pw = oracle.deconv_plane_pack_weights(w)
+    want = torch64_deconv(x, w, b, True)
+    out = np.full((2, 70, 12, 18), 7.0, np.float32)
+    big = np.concatenate([rnd((2, 3, 6, 9), 7), x, rnd((2, 2, 6, 9), 8)], 1)
+    oracle.deconv_plane_forward(big, pw, b, 64, 1, True, 0.1, out=out, out_c0=4, in_c0=3, Cin=10)
+    assert np.abs(out[:, 4:68] - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert (out[:, :4] == 7).all() and (out[:, 68:] == 7).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_hip_plane_deconv_equals_oracle_bitwise_in_every_variant(case):
+    from flownet2_amd import ops
+    N, Cin, H, W, Cout = case
+    x, w, b = rnd((N, Cin, H, W), 11), rnd((Cin, Cout, 4, 4), 12, 0.2), rnd((Cout,), 13)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    pw = ops.deconv_plane_pack_weights(dv(w))
+    pwh = pw.cpu().numpy()
+    assert np.array_equal(pwh, oracle.deconv_plane_pack_weights(w))
+    assert ops.deconv_plane_supported(N, Cin, H, W, Cout)
+    ran = 0
+    try:
+        for ksplit in (0, 1, 2, 3):
+            ops.set_plane_ksplit(ksplit)
+            ks = ops.deconv_plane_ksplit(N, Cin, H, W, Cout)
+            want = oracle.deconv_plane_forward(x, pwh, b, Cout, ks, True, 0.1)
+            for v in range(ops.plane_num_variants()):
+                ops.set_plane_variant(v)
+                try:
+                    got = ops.deconv_plane_forward(dv(x), pw, dv(b), Cout, True, 0.1)
+                except flownet2_amd.Fn2Error:
+                    continue
+                ran += 1
+                assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"variant {v}, ksplit {ks}"
+            ops.set_plane_variant(-1)
+            got = ops.deconv_plane_forward(dv(x), pw, None, Cout, False, 0.1)
+            assert np.array_equal(got.cpu().numpy(), oracle.deconv_plane_forward(x, pwh, None, Cout, ks, False, 0.1))
+    finally:
+        ops.set_plane_variant(-1)
+        ops.set_plane_ksplit(0)
+    assert ran >= 2
+
+
+@pytest.mark.gpu
+def test_hip_plane_deconv_channel_slices_and_reference_layer():
+    from flownet2_amd import ops
+    from oracle import ref
+    dv = lambda a: torch.from_numpy(a).cuda()
+    x, w, b = rnd((3, 10, 6, 9), 4), rnd((10, 64, 4, 4), 5, 0.2), rnd((64,), 6)
+    big = np.concatenate([rnd((3, 3, 6, 9), 7), x, rnd((3, 2, 6, 9), 8)], 1)
+    pw = ops.deconv_plane_pack_weights(dv(w))
+    out = torch.full((3, 70, 12, 18), 7.0, device="cuda")
+    ops.deconv_plane_forward(dv(big), pw, dv(b), 64, True, 0.1, out=out, out_c0=4, in_c0=3, Cin=10)
+    ks = ops.deconv_plane_ksplit(3, 10, 6, 9, 64)
+    want = oracle.deconv_plane_forward(x, pw.cpu().numpy(), b, 64, ks, True, 0.1)
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:, 4:68], want) and (o[:, :4] == 7).all() and (o[:, 68:] == 7).all()
+    if ref.available():
+        x, w, b = rnd((2, 34, 10, 14), 20), rnd((34, 128, 4, 4), 21, 0.1), rnd((128,), 22)
+        r = ref.convolution(x, w, b, kernel=4, stride=2, pad=1, deconv=True, relu=True)
+        got = ops.deconv_plane_forward(dv(x), ops.deconv_plane_pack_weights(dv(w)), dv(b), 128, True, 0.1).cpu().numpy()
+        assert np.abs(got - r).max() <= 1e-5 * max(1.0, np.abs(r).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layer", [("deconv5", 8, 1024, 5, 7, 512), ("deconv4", 8, 1026, 10, 14, 256), ("deconv3", 8, 770, 20, 28, 128),
+                                   ("deconv2", 8, 386, 40, 56, 64), ("deconv4@768", 4, 1026, 12, 24, 256), ("deconv3@768", 4, 770, 24, 48, 128),
+                                   ("deconv5@1024", 1, 1024, 7, 16, 512), ("deconv3@1024", 1, 770, 28, 64, 128)])
+def test_deconv_plane_at_flownet_shapes(layer):
+    """The refinement deconvolutions of BASELINE.json's configs at full size: against the library's fp32 result everywhere and torch's
+    fp64-accumulated result on the first sample, at 1e-5 x scale."""
+    from flownet2_amd import ops
+    name, N, Cin, H, W, Cout = layer
+    assert ops.deconv_plane_supported(N, Cin, H, W, Cout), name
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, device="cuda", generator=g) * (2.0 / (Cin * 4)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    got = ops.deconv_plane_forward(x, ops.deconv_plane_pack_weights(w), b, Cout, True, 0.1)
+    lib = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=2, padding=1), 0.1)
+    scale = max(1.0, float(lib.abs().max()))
+    assert float((got - lib).abs().max()) <= 1e-5 * scale
+    want64 = F.leaky_relu(F.conv_transpose2d(x[:1].double(), w.double(), b.double(), stride=2, padding=1), 0.1)
+    assert float((got[:1].double() - want64).abs().max()) <= 4e-6 * scale

@@ -410,6 +410,11 @@ def test_upsample_flow_deconv(shape):
                                                stride=2, padding=1).numpy()
     assert_close(out, ref.astype(np.float32), 1e-6, "upsample_flow vs torch fp64")
     assert_close(out, oracle.upsample_flow_deconv_forward(x, w, b), 1e-6, "upsample_flow vs oracle")
+    # into the last two channels of a wider blob (the refinement Concat): same bits, the other channels untouched
+    blob = torch.full((shape[0], 9, 2 * shape[2], 2 * shape[3]), 7.0, device="cuda")
+    ops.upsample_flow_deconv_forward(dev(x), dev(w), dev(b), out=blob, out_c0=7)
+    np.testing.assert_array_equal(host(blob[:, 7:]), out)
+    assert bool((blob[:, :7] == 7).all())
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 20, 28), (3, 5, 7, 9), (1, 130, 3, 5), (2, 16, 1, 1)])
@@ -470,6 +475,10 @@ def test_deconv_via_gemm_and_col2im(case, relu):
     col = np.matmul(w.reshape(Cin, Cout * 16).T.astype(np.float64), x.reshape(N, Cin, H * W).astype(np.float64)).astype(np.float32)
     got = host(ops.col2im_bias_relu_forward(dev(col), dev(b), N, Cout, 2 * H, 2 * W, 4, 1, 2, relu, 0.1))
     np.testing.assert_array_equal(got, oracle.col2im_bias_relu_forward(col, b, N, Cout, 2 * H, 2 * W, 4, 1, 2, relu, 0.1))
+    blob = torch.full((N, Cout + 5, 2 * H, 2 * W), 7.0, device="cuda")           # into a channel slice of a Concat blob
+    ops.col2im_bias_relu_forward(dev(col), dev(b), N, Cout, 2 * H, 2 * W, 4, 1, 2, relu, 0.1, out=blob, out_c0=3)
+    np.testing.assert_array_equal(host(blob[:, 3:3 + Cout]), got)
+    assert bool((blob[:, :3] == 7).all()) and bool((blob[:, 3 + Cout:] == 7).all())
     ref = torch.nn.functional.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
                                                stride=2, padding=1)
     if relu:
