@@ -173,6 +173,8 @@ def lib():
     L.fn2_data_augmentation_forward.argtypes = [C.POINTER(DataAugParams), fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
+    if hasattr(L, "fn2_debug_set_resample_generic"):
+        L.fn2_debug_set_resample_generic.argtypes = [i]
     for name in EXPORTS:
         if not hasattr(L, name):
             raise RuntimeError(f"{SO_PATH} does not export {name}")

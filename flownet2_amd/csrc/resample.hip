@@ -120,9 +120,90 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
   }
 }
 
+// LINEAR up-sampling by an exact integer factor F on both axes (the x4 flow up-sampling behind every FlowNet2 stage and the deploy
+// head).  With fx = fy = 1 / F the F x F outputs of one INPUT pixel (i, j) share their tap window: x_in = j + (ph + 0.5) / F - 0.5
+// rounds to j for every phase, so the reference's loop (:75-92) visits the same 5 x 5 input taps for all of them and only the
+// coefficients differ.  One thread per input pixel: the 25 taps are read once; the 16 taps of the outer ring have coefficient 0 for
+// every phase (triangle support 1), so they enter as ONE term  poison = sum 0 * tap  -- 0 for finite taps, NaN if the reference's
+// 0 * NaN / 0 * Inf would have poisoned the sums (the sign of a zero sum aside, the result is the reference's) -- and each output is
+// 9 fused multiply-adds in the reference's order plus the sum / wsum division (:93).  Stores are whole 16-byte (8-byte) rows.
+template <int F>
+__global__ void __launch_bounds__(256) resample_up_linear(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
+  const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= hw_in) return;
+  const int i = p / a.Win, j = p - i * a.Win;
+  // per-axis tap tables: columns j - 2 .. j + 2 (rows i - 2 .. i + 2), the in-image mask, and per phase the 3 inner coefficients
+  unsigned xo[5], yo[5], mx = 0u, my = 0u;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int x = j - 2 + t, y = i - 2 + t;
+    const bool okx = x >= 0 && x < a.Win, oky = y >= 0 && y < a.Hin;
+    xo[t] = okx ? (unsigned)x : 0u;
+    yo[t] = oky ? (unsigned)y * a.Win : 0u;
+    mx |= (okx ? 1u : 0u) << t;
+    my |= (oky ? 1u : 0u) << t;
+  }
+  float px[F][3], ky[F][3], wsum[F][F];
+#pragma unroll
+  for (int ph = 0; ph < F; ++ph) {
+    const float x_in = (F * j + ph) * a.fx + a.fy / 2.0f - 0.5f;   // :62
+    const float y_in = (F * i + ph) * a.fy + a.fx / 2.0f - 0.5f;   // :63
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int x = j - 1 + t, y = i - 1 + t;
+      px[ph][t] = ((mx >> (t + 1)) & 1u) ? a.ax * triangle_coeff(a.ax * (x_in - x)) * a.ay : 0.f;
+      ky[ph][t] = ((my >> (t + 1)) & 1u) ? triangle_coeff(a.ay * (y_in - y)) : 0.f;
+    }
+  }
+#pragma unroll
+  for (int py = 0; py < F; ++py)
+#pragma unroll
+    for (int qx = 0; qx < F; ++qx) {
+      float w = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w += px[qx][t] * ky[py][r];
+      wsum[py][qx] = w;
+    }
+  using vec_t = __attribute__((ext_vector_type(F))) float;
+  const int c_lo = blockIdx.y * a.ppt, c_hi = min(a.NC, c_lo + a.ppt);
+  for (int c = c_lo; c < c_hi; ++c) {
+    const float* src = in + (size_t)c * hw_in;
+    float v[3][3], poison = 0.f;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const float s = ((mx >> t) & (my >> r) & 1u) ? src[yo[r] + xo[t]] : 0.f;
+        if (r >= 1 && r <= 3 && t >= 1 && t <= 3) v[r - 1][t - 1] = s;
+        else poison = fmaf(0.f, s, poison);
+      }
+    float* dst = out + (size_t)c * hw_out + (size_t)(F * i) * a.Wout + F * j;
+#pragma unroll
+    for (int py = 0; py < F; ++py) {
+      vec_t o;
+#pragma unroll
+      for (int qx = 0; qx < F; ++qx) {
+        float sum = poison;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) sum = fmaf(px[qx][t] * ky[py][r], v[r][t], sum);
+        o[qx] = (!wsum[py][qx]) ? 0.f : (sum / wsum[py][qx]);   // :93
+      }
+      *reinterpret_cast<vec_t*>(dst + (size_t)py * a.Wout) = o;
+    }
+  }
+}
+
 }  // namespace fn2
 
 using namespace fn2;
+
+static int g_resample_generic = 0;     // test hook: 1 = always the per-output-pixel kernels
+FN2_API int fn2_debug_set_resample_generic(int on) { g_resample_generic = on; return FN2_OK; }
 
 FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int Hin, int Win, int Hout, int Wout,
                                  int type, int antialias_param, void* stream) {
@@ -153,6 +234,18 @@ FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int 
   const dim3 grid(bx, by);
   hipStream_t st = as_stream(stream);
   const bool fast = a.rx <= 2 && a.ry <= 2;
+  // exact x2 / x4 LINEAR up-sampling: one thread per INPUT pixel (resample_up_linear)
+  const int up = (Wout == 4 * Win && Hout == 4 * Hin) ? 4 : (Wout == 2 * Win && Hout == 2 * Hin) ? 2 : 0;
+  if (type == FN2_RESAMPLE_LINEAR && up && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !g_resample_generic) {
+    const unsigned bxi = (unsigned)(((long long)Hin * Win + 255) / 256);
+    a.ppt = 1;
+    while (a.ppt < 4 && (long long)bxi * ((a.NC + 2 * a.ppt - 1) / (2 * a.ppt)) >= 1024) a.ppt *= 2;
+    const dim3 gi(bxi, (unsigned)((a.NC + a.ppt - 1) / a.ppt));
+    if (gi.y > 65535u) return fail(FN2_ERR_UNSUPPORTED, "resample: too many planes");
+    if (up == 4) hipLaunchKernelGGL((resample_up_linear<4>), gi, dim3(256), 0, st, in, out, a);
+    else hipLaunchKernelGGL((resample_up_linear<2>), gi, dim3(256), 0, st, in, out, a);
+    return check_launch("resample_forward");
+  }
   if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, grid, dim3(256), 0, st, in, out, a);
   else if (type == FN2_RESAMPLE_CUBIC) {
     if (fast) hipLaunchKernelGGL((resample_interp<true, true>), grid, dim3(256), 0, st, in, out, a);

@@ -109,6 +109,11 @@ def set_correlation_impl(impl):
     check(_lib.lib().fn2_debug_set_correlation_impl(int(impl)))
 
 
+def set_resample_generic(on):
+    """Test hook: True = always the per-output-pixel Resample kernels (no integer-factor up-sampling path)."""
+    check(_lib.lib().fn2_debug_set_resample_generic(int(bool(on))))
+
+
 def flow_warp_forward(image, flow, fill_value=FILL_ZERO):
     im, fl = _chk(image, "bottom[0] (image)"), _chk(flow, "bottom[1] (flow)")
     N, Cc, H, W = im.shape

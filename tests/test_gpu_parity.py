@@ -294,6 +294,30 @@ def test_resample(code, shape, antialias):
         assert np.array_equal(host(out), x)
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 24, 48, 4), (1, 3, 5, 7, 4), (3, 2, 9, 12, 2), (1, 1, 1, 1, 4), (1, 2, 2, 3, 2), (2, 2, 96, 192, 4)])
+def test_resample_integer_upsampling_path_equals_the_per_pixel_kernel(shape):
+    """LINEAR x2 / x4 up-sampling has a kernel of its own (one thread per INPUT pixel, resample_layer.cu:39-95 restated per phase):
+    same values as the per-output-pixel kernel (which is pinned tap for tap against the reference) -- including the reference's
+    0 * NaN / 0 * Inf poisoning through taps of coefficient 0 -- and the oracle."""
+    N, Cc, H, W, F = shape
+    x = rand((N, Cc, H, W), 91)
+    if H * W >= 12:
+        x[0, 0, H // 2, W // 3] = np.nan
+        x[-1, -1, H - 1, W - 1] = np.inf
+    got = host(ops.resample_forward(dev(x), F * H, F * W, ops.LINEAR, True))
+    ops.set_resample_generic(True)
+    try:
+        want = host(ops.resample_forward(dev(x), F * H, F * W, ops.LINEAR, True))
+    finally:
+        ops.set_resample_generic(False)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_array_equal(got[ok], want[ok])
+    orc = oracle.resample_forward(x, F * H, F * W, ops.LINEAR, True)
+    assert np.array_equal(np.isnan(got), np.isnan(orc))
+    assert_close(np.nan_to_num(got, nan=0.0, posinf=0.0, neginf=0.0), np.nan_to_num(orc, nan=0.0, posinf=0.0, neginf=0.0), 1e-6, "resample x%d vs oracle" % F)
+
+
 def test_resample_rejects_area():
     import flownet2_amd
     with pytest.raises(flownet2_amd.Fn2Error):
