@@ -35,6 +35,11 @@ python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 30 --warmup 5
 python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_flownet2_1024.json 2>/dev/null
 python bench.py --mode train --steps 15 --warmup 4 --no-cpu-baseline > $R/bench_train.json 2>/dev/null
 timeout 300 python scripts/conv_bench.py --net C --layers conv2,conv3,conv3_1,conv4_1 > $R/conv_bench_C.txt 2>&1
+# the small-map kernels (csrc/conv_plane.hip): every variant of the convolutions and of the (opt-in) deconvolutions next to the GEMM routes
+timeout 300 python scripts/conv_bench.py --net C --layers conv4,conv5,conv5_1,conv6,conv6_1 --only-plane > $R/conv_plane_bench_C.txt 2>&1
+timeout 300 python scripts/deconv_bench.py --net C > $R/deconv_bench_C.txt 2>&1
+# kernel table of the FlowNet2 step (768x384, batch 4)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench2 -o bench2 -- python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
 # matrix-pipe counters of the convolution kernels alone (a counter pass of its own)
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_conv -o conv -- env FN2_AUTOTUNE=0 python scripts/conv_bench.py --net C --layers conv2,conv3_1 --iters 3 > /dev/null 2>&1
 tail -c 300 $R/bench.json

@@ -92,8 +92,20 @@ if gui:
 ks = kernel_stats(os.path.join(R, "bench", "bench_kernel_stats.csv"))
 lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5` (FlowNetC forward, batch 8 @448x320)", "",
           "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-for r in ks[:28]:
+for r in ks[:34]:
     lines.append("| `%s` | %s | %.2f | %.2f | %s |" % (short(r["Name"], 90), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+# share of the own kernels in the steady-state step: the correlation roofline loop of bench.py (200 + launches of corr_fwd_*) is not part of a step
+step_rows = [r for r in ks if "distribution_elementwise" not in r["Name"]]
+def _per_step(r):
+    calls, tot = int(r["Calls"]), float(r["TotalDurationNs"])
+    if "corr_fwd_" in r["Name"] and calls > 25:
+        return tot / calls * 25
+    return tot
+tot_ns = sum(_per_step(r) for r in step_rows)
+own_ns = sum(_per_step(r) for r in step_rows if "fn2::" in r["Name"])
+cat_calls = sum(int(r["Calls"]) for r in ks if "CatArrayBatchedCopy" in r["Name"])
+lines += ["", "`fn2::` kernels: **%.1f %%** of the GPU time of the 25 traced steps (the correlation kernel counted once per step); "
+          "`CatArrayBatchedCopy` launches: %.1f per step." % (100.0 * own_ns / tot_ns, cat_calls / 25.0)]
 # --- matrix-pipe utilisation of the conv stack (counter pass over the same bench command)
 pmc_path = os.path.join(R, "pmc_bench", "bench_counter_collection.csv")
 if os.path.exists(pmc_path):
@@ -127,6 +139,20 @@ for extra in ("bench.json", "bench_flownet2.json", "bench_flownet2_1024.json", "
         shutil.copyfile(os.path.join(R, extra), os.path.join(OUT, f"{tag}_{extra}"))
 if os.path.exists(os.path.join(R, "conv_bench_C.txt")):
     shutil.copyfile(os.path.join(R, "conv_bench_C.txt"), os.path.join(OUT, f"{tag}_conv_bench_flownetc.txt"))
+for src, dst in (("conv_plane_bench_C.txt", "conv_plane_bench_flownetc.txt"), ("deconv_bench_C.txt", "deconv_bench_flownetc.txt")):
+    if os.path.exists(os.path.join(R, src)):
+        shutil.copyfile(os.path.join(R, src), os.path.join(OUT, f"{tag}_{dst}"))
+k2 = os.path.join(R, "bench2", "bench2_kernel_stats.csv")
+if os.path.exists(k2):
+    rows2 = kernel_stats(k2)
+    tot2 = sum(float(r["TotalDurationNs"]) for r in rows2)
+    own2 = sum(float(r["TotalDurationNs"]) for r in rows2 if "fn2::" in r["Name"])
+    with open(os.path.join(OUT, f"{tag}_flownet2_kernels.md"), "w") as fh:
+        fh.write("# FlowNet2 (CSS + SD + fusion) deploy forward, batch 4 @768x384: kernel table\n\n"
+                 "`rocprofv3 --kernel-trace --stats -- python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 10 --warmup 3` (13 steps in the trace).\n"
+                 "`fn2::` kernels: %.1f %% of the GPU time.\n\n| kernel | calls | total ms | avg us | %% |\n|---|---|---|---|---|\n" % (100.0 * own2 / tot2))
+        for r in rows2[:40]:
+            fh.write("| `%s` | %s | %.2f | %.2f | %s |\n" % (short(r["Name"], 90), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
 # matrix-pipe counters of the convolution kernels (scripts/conv_bench.py under --pmc)
 pmc_conv = os.path.join(R, "pmc_conv", "conv_counter_collection.csv")
 if os.path.exists(pmc_conv):
