@@ -63,7 +63,15 @@ struct Cfg {
   static constexpr int RPW = cdiv(NRUN, NW);
   static constexpr int BUF = NRUN * 256;                                // dwords per buffer: [U | window]
   static constexpr int WOFF = URUN * 256;
-  static_assert((NW == 4 || NW == 8) && TGY * TGX == 16 && 2 * BUF * 4 <= 160 * 1024, "workgroup shape");
+  // The software-pipelined variants (MT == 1, MW == 1) run 3 waves per SIMD under a 168-VGPR cap; with the per-lane DMA offsets in
+  // registers the loop spilled them, and every reload in front of a buffer_load ... lds drained the vector-memory queue
+  // (s_waitcnt vmcnt(0)).  Their offsets live in an LDS table behind the two buffers instead: one ds_read_b32 per DMA instruction.
+  // (Only the window runs need a table: a U run is a linear copy, lane * 16 bytes behind a scalar offset.)
+  static constexpr bool VOFF_LDS = MT_ == 1 && MW_ == 1;
+  static constexpr int UI = URUN / NW;                                    // the first UI DMA instructions of every wave are U runs
+  static_assert(URUN % NW == 0, "U runs are dealt evenly");
+  static constexpr int LDS_FLOATS = 2 * BUF + (VOFF_LDS ? (RPW - UI) * THREADS : 0);
+  static_assert((NW == 4 || NW == 8) && TGY * TGX == 16 && LDS_FLOATS * 4 <= 160 * 1024, "workgroup shape");
 };
 
 // LDS-DMA of one chunk: runs [0, URUN) = the chunk's U slab (a linear copy), runs [URUN, NRUN) = the input window.
@@ -78,6 +86,25 @@ __device__ __forceinline__ void stage_chunk(__amdgpu_buffer_rsrc_t rsU, __amdgpu
       lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)r);
       if (r < K::URUN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, lp, 16, voff[i], soff_u, 0, 0);
       else             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lp, 16, voff[i], soff_w, 0, 0);
+    }
+  }
+}
+
+// the same with the per-lane offsets of the window runs in an LDS table (entry i - UI of this thread at tab[(i - UI) * THREADS])
+template <class K>
+__device__ __forceinline__ void stage_chunk_tab(__amdgpu_buffer_rsrc_t rsU, __amdgpu_buffer_rsrc_t rsW, const unsigned* tab, unsigned lane16, int kquads,
+                                                unsigned dst, int wave, unsigned soff_u, unsigned soff_w) {
+#pragma unroll
+  for (int i = 0; i < K::RPW; ++i) {
+    const int r = i * K::NW + wave;
+    if (r < K::NRUN) {
+      lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)r);
+      if (i < K::UI) {
+        const unsigned so = soff_u + 4096u * (unsigned)((r / (4 * K::CQ)) * kquads) + 1024u * (unsigned)(r % (4 * K::CQ));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, lp, 16, lane16, so, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, lp, 16, tab[(i - K::UI) * K::THREADS], soff_w, 0, 0);
+      }
     }
   }
 }
@@ -177,6 +204,10 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
 
   stage_chunk<K>(rsU, rsW, voff, lds_base, wave, 0u, 0u);
   if constexpr (MT == 1 && MW == 1 && K::CQ == 2) {
+    unsigned* vtab = reinterpret_cast<unsigned*>(smem + 2 * K::BUF) + tid;      // this thread's column of the DMA offset table
+#pragma unroll
+    for (int i = K::UI; i < K::RPW; ++i) vtab[(i - K::UI) * K::THREADS] = voff[i];
+    const unsigned lane16 = 16u * (unsigned)lane;
     // Software pipeline over the k-steps (two per chunk), one barrier per chunk:
     //   the MFMAs of k-step k run while the operands of k+1 -- read from LDS one step earlier -- are transformed (independent
     //   VALU work in the MFMA issue gaps), and the LDS reads of k+2 are in flight.  The barrier that publishes chunk c+1 and frees
@@ -202,7 +233,7 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
         wait_vm0();
         __builtin_amdgcn_s_barrier();
         if (c + 2 < a.nchunks)
-          stage_chunk<K>(rsU, rsW, voff, lds_base + 4u * (unsigned)((c & 1) * K::BUF), wave, (unsigned)(c + 2) * chunk_u, (unsigned)(c + 2) * chunk_w);
+          stage_chunk_tab<K>(rsU, rsW, vtab, lane16, a.kquads, lds_base + 4u * (unsigned)((c & 1) * K::BUF), wave, (unsigned)(c + 2) * chunk_u, (unsigned)(c + 2) * chunk_w);
         wino_load<K>(LA, ub0 + nb * K::BUF, dp0 + nb * K::BUF);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -420,7 +451,7 @@ static int launch(const Args& base, hipStream_t st) {
   set_geometry<K>(a);
   if (tiles_of(a) > 0x3fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_wino: grid too large");
   a.total = (unsigned)tiles_of(a); a.nbig = a.total;
-  constexpr size_t lds = sizeof(float) * 2 * K::BUF;
+  constexpr size_t lds = sizeof(float) * K::LDS_FLOATS;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -440,7 +471,8 @@ static int launch_tail(const Args& base, hipStream_t st) {
     if (tiles_of(a) > 0x1fffff00ll) return fail(FN2_ERR_UNSUPPORTED, "conv_wino: grid too large");
     a.total = (unsigned)tiles_of(a); a.nbig = (unsigned)(tiles_of(a) / 256 * 256);
     const unsigned nsm = 2 * (a.total - a.nbig);
-    constexpr size_t lds = sizeof(float) * 2 * K::BUF;
+    using KH = Cfg<K::TGY, K::TGX, K::MT / 2, K::WNY, K::WNX, K::WM, K::MW>;
+    constexpr size_t lds = sizeof(float) * (K::LDS_FLOATS > KH::LDS_FLOATS ? K::LDS_FLOATS : KH::LDS_FLOATS);
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_tail<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
