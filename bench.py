@@ -248,6 +248,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # The cyclic collector is paused for the K timed steps (config.python_gc): a generation-2 pass over the interpreter's objects
+    # takes milliseconds -- two steps of the batch-1 configuration -- and has nothing to collect here (no reference cycles in a step).
+    import gc
+    gc_was_on = gc.isenabled() and os.environ.get("FN2_BENCH_GC", "off") != "on"
+    if gc_was_on:
+        gc.collect()
+        gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -259,6 +266,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     elapsed = parallel.max_over_ranks(elapsed, device)
 
     if rank == 0:
@@ -276,7 +285,7 @@ def main():
                        "conv_stack": "own fp32 MFMA kernels: direct 5x5/2 (conv2, conv3), Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), 7x7/2 stem, flow heads; small-map 3x3 layers "
                                      "and 4x4/2 deconvs: own im2col/col2im + library fp32 GEMM (%.1f GFLOP/step/GPU)" % conv_gf,
                        "tuned_gemm_table_accepted": tuning.active(),
-                       "launch": "hipGraph replay" if use_graph else "host launches", "ranks_seen_by_rccl": ranks_seen},
+                       "launch": "hipGraph replay" if use_graph else "host launches", "python_gc": "paused for the timed steps" if gc_was_on else "on", "ranks_seen_by_rccl": ranks_seen},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
         if world == 1:
