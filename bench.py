@@ -34,8 +34,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # same table: dense f32-input MFMA peak (= f32 v
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: after the synchronisation in front of the timed region the chip needs ~10 steps (25 ms) to come back to its steady
+    # clocks (2.85, 2.70, 2.59 ... 2.31 ms per step, also under hipGraph replay); 100 steps keep that ramp below 1 % of the mean
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=448)
@@ -132,6 +134,8 @@ def corr_roofline(device, batch, h, w, iters):
 def step_percentiles(marks):
     ts = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
     pick = lambda q: round(ts[min(len(ts) - 1, int(q * len(ts)))], 4)
+    if os.environ.get("FN2_BENCH_STEPS"):           # debugging aid: the device time of every step, in order
+        print("steps ms:", " ".join("%.3f" % marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1)), file=sys.stderr)
     return [pick(0.1), pick(0.5), pick(0.9)]
 
 

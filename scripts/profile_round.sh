@@ -28,12 +28,12 @@ python scripts/layer_microbench.py > gpurun_out/layer_microbench.txt 2>/dev/null
 python tests/cpu_baselines.py >> gpurun_out/layer_microbench.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/layers -o lay -- python scripts/layer_microbench.py > /dev/null 2>&1
 timeout 300 python scripts/train_pipeline.py --iters 8 2>/dev/null | tail -11 > gpurun_out/train_pipeline.txt
-python bench.py --steps 30 --warmup 5 > $R/bench.json 2> $R/bench.err
+python bench.py > $R/bench.json 2> $R/bench.err
 # the other configurations of BASELINE.json (FlowNet2 at 768x384 batch 4 and 1024x448 batch 1, FlowNetC training step) and the
 # per-variant convolution timings
-python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_flownet2.json 2>/dev/null
-python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_flownet2_1024.json 2>/dev/null
-python bench.py --mode train --steps 15 --warmup 4 --no-cpu-baseline > $R/bench_train.json 2>/dev/null
+python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 60 --warmup 8 --no-cpu-baseline > $R/bench_flownet2.json 2>/dev/null
+python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 60 --warmup 8 --no-cpu-baseline > $R/bench_flownet2_1024.json 2>/dev/null
+python bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_train.json 2>/dev/null
 timeout 300 python scripts/conv_bench.py --net C --layers conv2,conv3,conv3_1,conv4_1 > $R/conv_bench_C.txt 2>&1
 # the small-map kernels (csrc/conv_plane.hip): every variant of the convolutions and of the (opt-in) deconvolutions next to the GEMM routes
 timeout 300 python scripts/conv_bench.py --net C --layers conv4,conv5,conv5_1,conv6,conv6_1 --only-plane > $R/conv_plane_bench_C.txt 2>&1
