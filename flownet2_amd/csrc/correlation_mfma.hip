@@ -490,7 +490,11 @@ struct HCfg {
   static_assert(CHB % 64 == 32, "channel stride must flip bank bit 5");
 };
 
-template <int R, int LO, int HI, typename Acc>
+// PROJ (profiling only, wrong results): 0 = the kernel; 1 = only 3 of every 8 MFMAs issue -- the matrix-pipe time a split-bf16
+// (bf16 x 3, 6 products per fp32 product on v_mfma_f32_16x16x16_bf16: 48 cycles per 16 channels against 128) variant would have
+// on the same staging, LDS traffic and epilogue, with the operand split taken as free; 2 = no MFMA at all (the data-movement
+// floor of this structure).  The operands are kept alive by empty asm statements, so the LDS reads stay.
+template <int R, int LO, int HI, int PROJ = 0, typename Acc>
 __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
                                             unsigned lds_base, int lane, int wave, int Jw, int py, int i0, int i2_0, int jS) {
   using K = Cfg<2, R>;
@@ -564,6 +568,12 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
   auto mfma_step = [&](const Ops& o, int r, int j) {
     if constexpr (NT > 0) {
       const int t = j >> 1;
+      if constexpr (PROJ != 0) {
+        if (PROJ == 2 || (j + 2 * NT * r) % 8 >= 3) {
+          asm volatile("" ::"v"(o.a[r].x), "v"(o.a[r].y), "v"(o.b[r][t].x), "v"(o.b[r][t].y));
+          return;
+        }
+      }
       if (j & 1) acc1[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[r].y, o.b[r][t].y, acc1[LO + t], 0, 0, 0);
       else       acc0[LO + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[r].x, o.b[r][t].x, acc0[LO + t], 0, 0, 0);
     }
@@ -629,7 +639,7 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
   chunk_step(F{}, F{}, c + 1, slot, o1, o0);
 }
 
-template <int R>
+template <int R, int PROJ = 0>
 __global__ void __launch_bounds__(256, 3)
 corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
               unsigned long long* __restrict__ dbg) {
@@ -696,7 +706,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   {
     const int sel = tile_range_sel<2, R>(jw, Wc);
-#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, Jw, Jw, k.py, i0, i2_0, jS)
+#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_, PROJ>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, Jw, Jw, k.py, i0, i2_0, jS)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
       case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
@@ -761,6 +771,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
 }
 
 int g_corr_force_dword = 0;   // test hook: run the general (dword LDS-DMA) kernel even where the paired one applies
+int g_corr_proj = 0;          // profiling hook (fn2_debug_set_correlation_impl(7 / 8)): the PROJ = 1 / 2 builds of corr_fwd_pair
 
 template <int S2, int R>
 static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* top, hipStream_t st) {
@@ -794,6 +805,17 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
       if (!attr3_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         attr3_set = true;
+      }
+      if (g_corr_proj == 1 || g_corr_proj == 2) {
+        static bool attrp_set = false;
+        if (!attrp_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+          attrp_set = true;
+        }
+        if (g_corr_proj == 1) hipLaunchKernelGGL((corr_fwd_pair<R, 1>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+        else                  hipLaunchKernelGGL((corr_fwd_pair<R, 2>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+        return check_launch("correlation_forward (mfma, paired parities, projection build)");
       }
       hipLaunchKernelGGL((corr_fwd_pair<R>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
       return check_launch("correlation_forward (mfma, paired parities)");
