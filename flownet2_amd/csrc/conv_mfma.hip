@@ -154,9 +154,9 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
 
   for (int c = 0; c < a.nchunks; ++c) {
     const int buf = c & 1;
-    // everything this wave has in flight up to here: the window of chunk c and the weight prefetch; wait for all of it (the
-    // weight loads are NBUFA - 1 k-steps old), then publish
-    wait_vmcnt<0>();
+    // in flight: the window of chunk c (issued a whole chunk ago) and, younger than it, the weight prefetch of the last NBUFA - 1
+    // k-steps; loads retire in order, so the window has landed once at most NBUFA - 1 loads remain -- no need to drain the ring
+    wait_vmcnt<K::NBUFA - 1>();
     __builtin_amdgcn_s_barrier();
     if (c + 1 < a.nchunks) stage(c + 1, buf ^ 1);
     const float* win = smem + buf * K::BUF + bbase;
