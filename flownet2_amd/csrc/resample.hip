@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(256) resample_up_linear(const float* __restric
         for (int r = 0; r < 3; ++r)
 #pragma unroll
           for (int t = 0; t < 3; ++t) sum = fmaf(px[qx][t] * ky[py][r], v[r][t], sum);
-        o[qx] = (!wsum[py][qx]) ? 0.f : (sum / wsum[py][qx]);   // :93
+        const float ws = wsum[py][qx];                            // :93 -- away from the border the coefficients (multiples of 1/64) sum to exactly 1: x / 1 == x
+        o[qx] = (!ws) ? 0.f : (ws == 1.0f ? sum : sum / ws);
       }
       *reinterpret_cast<vec_t*>(dst + (size_t)py * a.Wout) = o;
     }
@@ -239,7 +240,7 @@ FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int 
   if (type == FN2_RESAMPLE_LINEAR && up && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !g_resample_generic) {
     const unsigned bxi = (unsigned)(((long long)Hin * Win + 255) / 256);
     a.ppt = 1;
-    while (a.ppt < 4 && (long long)bxi * ((a.NC + 2 * a.ppt - 1) / (2 * a.ppt)) >= 1024) a.ppt *= 2;
+    while (a.ppt < 4 && (long long)bxi * ((a.NC + 2 * a.ppt - 1) / (2 * a.ppt)) >= 8192) a.ppt *= 2;     // >= 8k workgroups before planes share a thread: the kernel is latency-bound (25 loads, then 16 stores)
     const dim3 gi(bxi, (unsigned)((a.NC + a.ppt - 1) / a.ppt));
     if (gi.y > 65535u) return fail(FN2_ERR_UNSUPPORTED, "resample: too many planes");
     if (up == 4) hipLaunchKernelGGL((resample_up_linear<4>), gi, dim3(256), 0, st, in, out, a);
