@@ -238,3 +238,85 @@ def test_deconv_plane_at_flownet_shapes(layer):
     assert float((got - lib).abs().max()) <= 1e-5 * scale
     want64 = F.leaky_relu(F.conv_transpose2d(x[:1].double(), w.double(), b.double(), stride=2, padding=1), 0.1)
     assert float((got[:1].double() - want64).abs().max()) <= 4e-6 * scale
+
+
+# ------------------------------------------------------------------------------------------------ seeded random geometries
+def _random_geometries(seed, n, deconv):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(rng.integers(1, 10))
+        H, W = int(rng.integers(1, 34)), int(rng.integers(1, 50))
+        Cout = 64 * int(rng.integers(1, 3))
+        if deconv:
+            Cin = int(rng.integers(1, 41))
+            out.append((N, Cin, H, W, Cout))
+        else:
+            Cin = 8 * int(rng.integers(1, 6))
+            s, p = int(rng.integers(1, 3)), int(rng.integers(0, 2))
+            if H + 2 * p < 3 or W + 2 * p < 3:
+                continue
+            out.append((N, Cin, H, W, Cout, s, p))
+    return out
+
+
+@pytest.mark.gpu
+def test_hip_plane_conv_random_geometries_equal_oracle_bitwise():
+    """40 seeded random layer geometries (sample groups, row bands, odd widths, ragged batches, both strides and paddings): wherever the
+    kernel family reports support, the autotuned launch and two forced tile variants equal the oracle twin bit for bit."""
+    from flownet2_amd import ops
+    dv = lambda a: torch.from_numpy(a).cuda()
+    ran = 0
+    for i, (N, Cin, H, W, Cout, s, p) in enumerate(_random_geometries(2024, 40, False)):
+        if not ops.conv_plane_supported(N, Cin, H, W, Cout, s, p):
+            continue
+        x, w, b = rnd((N, Cin, H, W), 100 + i), rnd((Cout, Cin, 3, 3), 200 + i, 0.2), rnd((Cout,), 300 + i)
+        pw = ops.conv_mfma_pack_weights(dv(w))
+        ks = ops.conv_plane_ksplit(N, Cin, H, W, Cout, s, p)
+        want = oracle.conv_plane_forward(x, pw.cpu().numpy(), b, Cout, s, p, ks, True, 0.1)
+        got = ops.conv_plane_forward(dv(x), pw, dv(b), Cout, s, p, True, 0.1).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, Cin, H, W, Cout, s, p, ks)
+        try:
+            for v in range(ops.plane_num_variants()):
+                if v % 5 != i % 5:
+                    continue
+                ops.set_plane_variant(v)
+                try:
+                    got = ops.conv_plane_forward(dv(x), pw, dv(b), Cout, s, p, True, 0.1).cpu().numpy()
+                except flownet2_amd.Fn2Error:
+                    continue
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, Cin, H, W, Cout, s, p, ks, v)
+        finally:
+            ops.set_plane_variant(-1)
+        ran += 1
+    assert ran >= 15
+
+
+@pytest.mark.gpu
+def test_hip_plane_deconv_random_geometries_equal_oracle_bitwise():
+    from flownet2_amd import ops
+    dv = lambda a: torch.from_numpy(a).cuda()
+    ran = 0
+    for i, (N, Cin, H, W, Cout) in enumerate(_random_geometries(4048, 30, True)):
+        if not ops.deconv_plane_supported(N, Cin, H, W, Cout):
+            continue
+        x, w, b = rnd((N, Cin, H, W), 400 + i), rnd((Cin, Cout, 4, 4), 500 + i, 0.2), rnd((Cout,), 600 + i)
+        pw = ops.deconv_plane_pack_weights(dv(w))
+        ks = ops.deconv_plane_ksplit(N, Cin, H, W, Cout)
+        want = oracle.deconv_plane_forward(x, pw.cpu().numpy(), b, Cout, ks, True, 0.1)
+        got = ops.deconv_plane_forward(dv(x), pw, dv(b), Cout, True, 0.1).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, Cin, H, W, Cout, ks)
+        try:
+            for v in range(ops.plane_num_variants()):
+                if v % 4 != i % 4:
+                    continue
+                ops.set_plane_variant(v)
+                try:
+                    got = ops.deconv_plane_forward(dv(x), pw, dv(b), Cout, True, 0.1).cpu().numpy()
+                except flownet2_amd.Fn2Error:
+                    continue
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, Cin, H, W, Cout, ks, v)
+        finally:
+            ops.set_plane_variant(-1)
+        ran += 1
+    assert ran >= 12
