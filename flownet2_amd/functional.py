@@ -285,9 +285,35 @@ class _OwnForwardConv(torch.autograd.Function):
             d, db = ops.bias_leaky_relu_backward(y, g, slope, need_b)
         else:
             d, db = g, (g.sum((0, 2, 3)) if need_b else None)
-        gx, gw, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
-                                                        [bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]), False])
-        return gx, gw, db, None, None, None, None, None, None
+        need_x, need_w = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
+        gx = _own_bwd_data(d, w, stride, pad, transposed) if need_x else None
+        lib_x = need_x and gx is None
+        gxl, gw, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
+                                                         [lib_x, need_w, False])
+        return (gxl if lib_x else gx), gw, db, None, None, None, None, None, None
+
+
+def _own_bwd_data(d, w, stride, pad, transposed):
+    """bottom_diff of a 3x3 / stride 1 / pad 1 convolution (ConvolutionLayer::Backward_gpu, conv_layer.cu:36-46: backward_gpu_gemm =
+    weight^T x top_diff + col2im) = the same convolution of top_diff with the weights rotated by 180 degrees and their channel axes
+    swapped: the own Winograd kernel (csrc/conv_wino.hip) on a repacked weight, the output channels padded to a multiple of 16.
+    FN2_WINO_BWD: "all" (default), "odd" (only layers whose input channel count is not a multiple of 8: conv3_1's 473) or "none" (the
+    library's data gradient).  Measured on the FlowNetC training step: 11.47 / 11.52 / 11.53 ms median -- the library already runs
+    these layers in its own Winograd kernels, so this is ownership more than speed.  Returns None when it does not apply."""
+    mode = os.environ.get("FN2_WINO_BWD", "all")
+    Cout, Cin, k, k2 = w.shape
+    if transposed or mode == "none" or k != 3 or k2 != 3 or stride != 1 or pad != 1 or not d.is_cuda:
+        return None
+    if mode == "odd" and Cin % 8 == 0:
+        return None
+    Cp = (Cin + 15) // 16 * 16
+    if not ops.conv_wino_supported(Cout, d.shape[2], d.shape[3], Cp, 1):
+        return None
+    wt = w.detach().flip(2, 3).transpose(0, 1)                      # [Cin, Cout, 3, 3]: rot180, channel axes swapped
+    if Cp != Cin:
+        wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 3, 3))], 0)
+    gx = ops.conv_wino_forward(d.contiguous(), ops.conv_wino_pack_weights(wt.contiguous()), None, Cp, 1, False, 0.0)
+    return gx[:, :Cin] if Cp != Cin else gx
 
 
 def _needs_grad(*ts):

@@ -725,6 +725,28 @@ def test_sweep_correlation_mfma_kernels_agree_with_generic(shape):
     assert_close(host(outs[0]), oracle.correlation_forward(oracle.corr_params(20, 1, 20, 1, 2), host(b0), host(b1)), 2e-6, "vs oracle")
 
 
+@pytest.mark.parametrize("case", [(2, 13, 12, 16, 32), (1, 473, 8, 12, 64), (3, 16, 9, 20, 16)])
+def test_own_winograd_data_gradient_matches_autograd(case):
+    """bottom_diff of a 3x3 / stride 1 / pad 1 convolution through the own Winograd kernel on rotated, transposed weights
+    (functional._own_bwd_data; conv_layer.cu:36-46 / base_conv_layer.cpp:352-368) against torch's fp64 data gradient."""
+    from flownet2_amd import functional as Fn
+    N, Cin, H, W, Cout = case
+    x, w, d = rand((N, Cin, H, W), 71), rand((Cout, Cin, 3, 3), 72, 0.2), rand((N, Cout, H, W), 73)
+    keep = os.environ.get("FN2_WINO_BWD")
+    os.environ["FN2_WINO_BWD"] = "all"
+    try:
+        got = Fn._own_bwd_data(dev(d), dev(w), 1, 1, False)
+    finally:
+        if keep is None:
+            os.environ.pop("FN2_WINO_BWD", None)
+        else:
+            os.environ["FN2_WINO_BWD"] = keep
+    assert got is not None and tuple(got.shape) == (N, Cin, H, W)
+    want = torch.nn.grad.conv2d_input((N, Cin, H, W), torch.from_numpy(w).double(), torch.from_numpy(d).double(), stride=1, padding=1).numpy()
+    assert_close(host(got.contiguous()), want.astype(np.float32), 4e-6, "winograd data gradient vs fp64")
+    assert Fn._own_bwd_data(dev(d), dev(w), 2, 1, False) is None and Fn._own_bwd_data(dev(d), dev(w), 1, 1, True) is None
+
+
 def test_training_gradients_fused_path_matches_stock_ops():
     """One FlowNetC training loss (multi-scale L1, NaN ground truth) differentiated twice: with the fused bias + leaky ReLU
     autograd function, and with the stock torch ops in its place.  Every parameter gradient must agree."""
