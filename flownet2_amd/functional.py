@@ -221,9 +221,10 @@ def _conv_mfma_pick(x, weight, stride, pad):
         # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
         if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
             return "wino"
-    if (k == 3 and (force or Ho * Wo <= 320) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
+    if (k == 3 and (force or Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "1200"))) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
             and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad)):
-        # the encoder layers below 1/16 resolution (conv5 .. conv6_1): whole planes in LDS, pixels of several samples per MFMA tile, split K
+        # the encoder layers from 1/16 resolution down (conv4 .. conv6_1): whole planes or row bands in LDS, pixels of several samples per MFMA
+        # tile, split K.  Up to 1200 output pixels per sample it is level with or ahead of the im2col + GEMM route (bench A/B: 2.317 vs 2.324 ms)
         return "plane"
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None

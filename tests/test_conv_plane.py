@@ -107,7 +107,7 @@ def test_hip_plane_conv_channel_slices_and_reference_layer():
 @pytest.mark.gpu
 @pytest.mark.parametrize("layer", [("conv4", 8, 256, 40, 56, 512, 2), ("conv5", 8, 512, 20, 28, 512, 2), ("conv5_1", 8, 512, 10, 14, 512, 1),
                                    ("conv6", 8, 512, 10, 14, 1024, 2), ("conv6_1", 8, 1024, 5, 7, 1024, 1),
-                                   ("conv5@768", 4, 512, 24, 48, 512, 2), ("conv5_1@768", 4, 512, 12, 24, 512, 1), ("conv6_1@768", 4, 1024, 6, 12, 1024, 1),
+                                   ("conv4@768", 4, 256, 48, 96, 512, 2), ("conv4@1024", 1, 256, 56, 128, 512, 2), ("conv5@768", 4, 512, 24, 48, 512, 2), ("conv5_1@768", 4, 512, 12, 24, 512, 1), ("conv6_1@768", 4, 1024, 6, 12, 1024, 1),
                                    ("conv5_1@1024", 1, 512, 14, 32, 512, 1), ("conv6_1@1024", 1, 1024, 7, 16, 1024, 1)])
 def test_conv_plane_at_flownet_shapes(layer):
     """The small-map encoder layers of BASELINE.json's configs at full size: against the library's fp32 result everywhere and torch's
