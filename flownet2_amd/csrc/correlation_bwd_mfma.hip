@@ -452,8 +452,13 @@ constexpr int BRUN = BSLOTS / 64;
 static_assert(BSLOTS % 64 == 0, "the other-map region ends on a run boundary");
 template <int WHICH> struct G {
   static constexpr int GW = WHICH == 0 ? K::SPANPX : K::BPX;     // pixels per G row: the 32 output pixels / the 72 staged pixels
-  static constexpr int GSL = GW / 4;
-  static constexpr int GSLOTS = 4 * D * GSL;
+  // Row stride of the G slab in LDS: one 16-byte slot of padding per row.  With dense rows (32 or 72 dwords) the A-operand read --
+  // lane (pi, pj, kk) at row pi * 21 + (kk - pj) + ... -- put all 64 lanes on 4 banks (stride 32) or on multiples of 8 (stride 72):
+  // 68 % of the LDS cycles of the kernel were bank conflicts (PMC) and the LDS, not the matrix pipe, set its pace.
+  static constexpr int GS = GW + 4;
+  static constexpr int GSL = GW / 4;                             // data slots per row
+  static constexpr int GSLS = GS / 4;                            // slots per row incl. the padding slot
+  static constexpr int GSLOTS = 4 * D * GSLS;
   static constexpr int SLOTS = BSLOTS + GSLOTS;
   static constexpr int NRUN = cdiv(SLOTS, 64);
   static constexpr int RPW = cdiv(NRUN, kWaves);
@@ -524,8 +529,10 @@ corr_bwd_g3(const float* __restrict__ other, const float* __restrict__ top_diff,
       if (gq < K::BPX / 4 && xb >= 0 && xb < g.W) vb[i] = 4u * (unsigned)(c * plane + xb);
     } else if (s < T::SLOTS) {
       const int sg = s - BSLOTS;
-      const int spi = sg / (D * T::GSL), oo = (sg / T::GSL) % D, gq = sg % T::GSL;
-      if (WHICH == 0) {
+      const int spi = sg / (D * T::GSLS), oo = (sg / T::GSLS) % D, gq = sg % T::GSLS;
+      if (gq >= T::GSL) {
+        // the padding slot of a row: stays out of range (written as zeros, never read)
+      } else if (WHICH == 0) {
         // top_diff[(q + R) * 21 + oo][y = 2 (i0 + pi) + py][2 jS + 4 gq ..], q = r - i0 - pi:
         //   channel = (r - i0 + R - 3) * 21  [per-chunk base]  +  21 * (3 - pi) + oo  [here]
         const int y = S2 * (i0 + spi) + py, x = S2 * jS + 4 * gq;
@@ -545,13 +552,13 @@ corr_bwd_g3(const float* __restrict__ other, const float* __restrict__ top_diff,
   int aAddr, aStep;
   int amask = 0;                                                            // bit b: displacement column of patch b is inside the band
   if (WHICH == 0) {
-    aAddr = T::GOFF + (pi * D + (kk - pj)) * T::GW + S2 * (4 * Jw + pj) + px;   // + b * 4 * GW   (oo = 4 b + kk - pj)
-    aStep = 4 * T::GW;
+    aAddr = T::GOFF + (pi * D + (kk - pj)) * T::GS + S2 * (4 * Jw + pj) + px;   // + b * 4 * GS   (oo = 4 b + kk - pj)
+    aStep = 4 * T::GS;
 #pragma unroll
     for (int b = 0; b < K::NB; ++b) { const int oo = 4 * b + kk - pj; if (oo >= 0 && oo < D) amask |= 1 << b; }
   } else {
-    aAddr = T::GOFF + (pi * D + (pj + 2 * R - kk)) * T::GW + S2 * (4 * Jw + kk) + px;   // + b * (8 - 4 * GW)   (oo = pj + 2R - 4 b - kk)
-    aStep = 8 - 4 * T::GW;
+    aAddr = T::GOFF + (pi * D + (pj + 2 * R - kk)) * T::GS + S2 * (4 * Jw + kk) + px;   // + b * (8 - 4 * GS)   (oo = pj + 2R - 4 b - kk)
+    aStep = 8 - 4 * T::GS;
 #pragma unroll
     for (int b = 0; b < K::NB; ++b) { const int oo = pj + 2 * R - 4 * b - kk; if (oo >= 0 && oo < D) amask |= 1 << b; }
   }
