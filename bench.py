@@ -286,8 +286,9 @@ def main():
             "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
                        "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
-                       "conv_stack": "own fp32 MFMA kernels: direct 5x5/2 (conv2, conv3), Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), 7x7/2 stem, flow heads; small-map 3x3 layers "
-                                     "and 4x4/2 deconvs: own im2col/col2im + library fp32 GEMM (%.1f GFLOP/step/GPU)" % conv_gf,
+                       "conv_stack": "own fp32 MFMA kernels: direct 5x5/2 (conv2, conv3), Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), small-map kernel with deterministic "
+                                     "split-K (conv4 .. conv6_1), 7x7/2 stem, flow heads; 4x4/2 deconvolutions: library fp32 GEMM + own col2im/bias/ReLU pass into the "
+                                     "concat blob; no Concat copies (%.1f GFLOP/step/GPU)" % conv_gf,
                        "tuned_gemm_table_accepted": tuning.active(),
                        "launch": "hipGraph replay" if use_graph else "host launches", "python_gc": "paused for the timed steps" if gc_was_on else "on", "ranks_seen_by_rccl": ranks_seen},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
