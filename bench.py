@@ -27,6 +27,9 @@ if ROOT not in sys.path:
 from flownet2_amd import functional as Fn   # noqa: E402
 from flownet2_amd import nets, ops, parallel, tuning   # noqa: E402
 
+CONV_STACK_NOTE = ("own fp32 MFMA kernels: direct 5x5/2 (conv2, conv3), Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), small-map kernel with deterministic "
+                   "split-K (conv4 .. conv6_1), 7x7/2 stem, flow heads; 4x4/2 deconvolutions: library fp32 GEMM + own col2im/bias/ReLU pass into the "
+                   "concat blob; no Concat copies")
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6290 measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3    # same table: dense f32-input MFMA peak (= f32 vector peak)
 
@@ -44,6 +47,7 @@ def parse():
     ap.add_argument("--mode", choices=["fwd", "train"], default="fwd")
     ap.add_argument("--net", choices=["C", "2"], default="C", help="C = FlowNetC (headline, configs[1]); 2 = full FlowNet2 stack (configs[2]: use --batch 4 --height 384 --width 768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip the FlowNet2 768x384 / 1024x448 and train-step legs reported under `extra`")
     ap.add_argument("--graph", action="store_true", help="capture a forward step into a hipGraph and replay it (measured: no gain, the step is not launch-bound)")
     ap.add_argument("--conv-search", action="store_true", help="let MIOpen's find step time its candidate kernels during warm-up (measured: no gain for this net)")
     ap.add_argument("--corr-iters", type=int, default=200)
@@ -119,10 +123,16 @@ def corr_roofline(device, batch, h, w, iters):
                 break
         except Exception:
             pass
+    # `achieved` / `frac` follow the committed rocprofv3 kernel trace of this exact kernel and shape when there is one (the
+    # profiler's clocks: the figure profiles/ can be checked against); the live hipEvent figure of THIS run is achieved_live / frac_live
+    tf_prof = alg_flops / (profiled["us_per_launch"] * 1e-6) / 1e12 if profiled else None
     return {
         "kernel": "corr_fwd (K=1,md=20,s2=2) [%d,%d,%d,%d]" % (batch, C, H, W),
-        "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "frac_profiled": profiled["frac"] if profiled else None, "profiled": profiled,
+        "bound": "mfma", "achieved": round(tf_prof if profiled else tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": profiled["frac"] if profiled else round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+        "frac_source": (profiled["source"] + " (rocprofv3 kernel trace)") if profiled else "live hipEvent timing (no committed profile of this shape)",
+        "achieved_live": round(tf, 3), "frac_live": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+        "frac_profiled": profiled["frac"] if profiled else None, "profiled": profiled,
         "traffic": traffic, "traffic_detail": traffic_detail,
         "us_per_launch": round(t * 1e6, 2), "us_per_launch_cold_caches": round(cold_us, 2),
         "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
@@ -180,6 +190,129 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0):
+    """W untimed warm-up steps (+ untimed settling steps until `settle_s` seconds of back-to-back stepping have passed: the chip
+    needs ~25 ms of load to come back to its steady clocks, and a short run otherwise sits inside that ramp), then EXACTLY `steps`
+    timed steps between barrier + synchronize on both sides.  Returns the measurements and what the caller needs for the oracle leg."""
+    P_cpu = nets.init_params("C", seed=0) if net == "C" else nets.init_params_flownet2(seed=0)   # same weights on every rank
+    P = {k: v.to(device) for k, v in P_cpu.items()}
+    img0, img1 = synth_batch(B, H, W, seed=1234 + rank, device=device)
+
+    if mode == "train":
+        for v in P.values():
+            v.requires_grad_(True)
+        plist = list(P.values())
+        opt = torch.optim.Adam(plist, lr=1e-5)
+        gt = torch.randn(B, 2, H, W, device=device) * 5
+        gt[torch.rand(B, 1, H, W, device=device).expand(-1, 2, -1, -1) < 0.05] = float("nan")
+        parallel.broadcast_params(plist, src=0)
+        # the ONE exchange of the path: sum-all-reduce of the fp32 gradients (39.18 M floats = 156.7 MB) over RCCL, scaled by
+        # 1/world (parallel.cpp:377), in reverse-order buckets launched from gradient hooks while backward is still running;
+        # identical Adam step on every rank
+        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20)
+
+        def step():
+            exchange.zero_grad()
+            pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
+            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], Fn), gt, Fn)
+            loss.backward()
+            exchange.finish()
+            opt.step()
+            return loss
+    else:
+        def step():
+            with torch.no_grad():
+                if net == "2":
+                    return nets.flownet2_deploy_forward(P, img0, img1, Fn)
+                return nets.deploy_forward("C", P, img0, img1, Fn)
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    use_graph = mode == "fwd" and graph
+    if use_graph:
+        # One step = ~130 kernels: captured once (hipGraph through torch's CUDAGraph; same kernels, order and buffers)
+        # and replayed, which removes the host launch path.  The warm-up above has run every lazy initialisation.
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step()
+        g.replay()
+        step_fn = g.replay
+    else:
+        step_fn = step
+    # settling: untimed steps, back to back, until the chip has been under this load for settle_s seconds
+    torch.cuda.synchronize()
+    settle_steps, t_s = 0, time.perf_counter()
+    while warmup > 0 and time.perf_counter() - t_s < settle_s and settle_steps < 2000:
+        for _ in range(4):
+            step_fn()
+        settle_steps += 4
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # The cyclic collector is paused for the K timed steps (config.python_gc): a generation-2 pass over the interpreter's objects
+    # takes milliseconds -- two steps of the batch-1 configuration -- and has nothing to collect here (no reference cycles in a step).
+    import gc
+    gc_was_on = gc.isenabled() and os.environ.get("FN2_BENCH_GC", "off") != "on"
+    if gc_was_on:
+        gc.collect()
+        gc.disable()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        r = step_fn()
+        if r is not None:
+            out = r
+        marks[i + 1].record()                  # per-step spread (device time); the headline stays the host clock around all K steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
+    elapsed = parallel.max_over_ranks(elapsed, device)
+    return {"elapsed": elapsed, "marks": marks, "out": out, "P_cpu": P_cpu, "img0": img0, "img1": img1, "use_graph": use_graph,
+            "gc_paused": gc_was_on, "settle_steps": settle_steps}
+
+
+def flownet2_epe_vs_cpu(P_cpu, img0, img1, flow_gpu):
+    """Oracle leg for the FlowNet2 extras: the same stacked graph on the host, once; (EPE, seconds)."""
+    from oracle import backend as cpu_backend
+    t0 = time.time()
+    with torch.no_grad():
+        ref = nets.flownet2_deploy_forward(P_cpu, img0.cpu(), img1.cpu(), cpu_backend)
+    return float(((flow_gpu.cpu() - ref) ** 2).sum(1).sqrt().mean()), time.time() - t0
+
+
+def extras(device, args):
+    """BASELINE configs 3, 5 (per-GPU leg) and 4 on the same GPU, after the headline: reported under `extra`, never as `value`."""
+    ex = {}
+    for key, (B, H, W, steps) in {"flownet2_768x384": (4, 384, 768, 20), "flownet2_1024x448": (1, 448, 1024, 30)}.items():
+        m = run_workload("2", "fwd", B, H, W, steps, 5, device, 1, 0)
+        p = step_percentiles(m["marks"])
+        ex[key] = {"metric": "image-pairs/sec FlowNet2 (CSS+SD+fusion) forward at %dx%d" % (W, H), "value": round(B * steps / m["elapsed"], 2),
+                   "unit": "image-pairs/s", "batch": B, "steps": steps, "warmup": 5, "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
+                   "ms_per_step_p10_p50_p90": p, "dtype": "f32",
+                   "conv_tflops": round(nets.flownet2_conv_flops(H, W) * B * steps / m["elapsed"] / 1e12, 2)}
+        if not args.no_cpu_baseline:
+            epe, secs = flownet2_epe_vs_cpu(m["P_cpu"], m["img0"], m["img1"], m["out"])
+            ex[key]["epe_vs_cpu_oracle"] = epe
+            ex[key]["cpu_oracle_seconds_per_batch"] = round(secs, 2)
+        del m
+        torch.cuda.empty_cache()
+    m = run_workload("C", "train", 8, 320, 448, 20, 5, device, 1, 0, bucket_mb=args.bucket_mb)
+    ex["train_448x320"] = {"metric": "image-pairs/sec FlowNetC fwd+bwd+allreduce+Adam at 448x320", "value": round(8 * 20 / m["elapsed"], 2),
+                           "unit": "image-pairs/s", "batch": 8, "steps": 20, "warmup": 5, "ms_per_step": round(m["elapsed"] / 20 * 1e3, 4),
+                           "ms_per_step_p10_p50_p90": step_percentiles(m["marks"]), "dtype": "f32", "loss": float(m["out"]),
+                           "conv_tflops": round(nets.conv_flops("C", 320, 448) * 8 * 3 * 20 / m["elapsed"] / 1e12, 2)}
+    del m
+    torch.cuda.empty_cache()
+    return ex
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -202,77 +335,8 @@ def main():
         raise SystemExit(f"bench.py: all-reduce of ones returned {ranks_seen}, expected {world}")
 
     B, H, W = args.batch, args.height, args.width
-    P_cpu = nets.init_params("C", seed=0) if args.net == "C" else nets.init_params_flownet2(seed=0)   # same weights on every rank
-    P = {k: v.to(device) for k, v in P_cpu.items()}
-    img0, img1 = synth_batch(B, H, W, seed=1234 + rank, device=device)
-
-    if args.mode == "train":
-        for v in P.values():
-            v.requires_grad_(True)
-        plist = list(P.values())
-        opt = torch.optim.Adam(plist, lr=1e-5)
-        gt = torch.randn(B, 2, H, W, device=device) * 5
-        gt[torch.rand(B, 1, H, W, device=device).expand(-1, 2, -1, -1) < 0.05] = float("nan")
-        parallel.broadcast_params(plist, src=0)
-        # the ONE exchange of the path: sum-all-reduce of the fp32 gradients (39.18 M floats = 156.7 MB) over RCCL, scaled by
-        # 1/world (parallel.cpp:377), in reverse-order buckets launched from gradient hooks while backward is still running;
-        # identical Adam step on every rank
-        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=args.bucket_mb << 20)
-
-        def step():
-            exchange.zero_grad()
-            pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
-            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], Fn), gt, Fn)
-            loss.backward()
-            exchange.finish()
-            opt.step()
-            return loss
-    else:
-        def step():
-            with torch.no_grad():
-                if args.net == "2":
-                    return nets.flownet2_deploy_forward(P, img0, img1, Fn)
-                return nets.deploy_forward("C", P, img0, img1, Fn)
-
-    for _ in range(args.warmup):
-        out = step()
-    use_graph = args.mode == "fwd" and args.graph
-    if use_graph:
-        # One step = ~130 kernels: captured once (hipGraph through torch's CUDAGraph; same kernels, order and buffers)
-        # and replayed, which removes the host launch path.  The warm-up above has run every lazy initialisation.
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = step()
-        graph.replay()
-        step_fn = graph.replay
-    else:
-        step_fn = step
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # The cyclic collector is paused for the K timed steps (config.python_gc): a generation-2 pass over the interpreter's objects
-    # takes milliseconds -- two steps of the batch-1 configuration -- and has nothing to collect here (no reference cycles in a step).
-    import gc
-    gc_was_on = gc.isenabled() and os.environ.get("FN2_BENCH_GC", "off") != "on"
-    if gc_was_on:
-        gc.collect()
-        gc.disable()
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        r = step_fn()
-        if r is not None:
-            out = r
-        marks[i + 1].record()                  # per-step spread (device time); the headline stays the host clock around all K steps
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if gc_was_on:
-        gc.enable()
-    elapsed = parallel.max_over_ranks(elapsed, device)
+    m = run_workload(args.net, args.mode, B, H, W, args.steps, args.warmup, device, world, rank, args.bucket_mb, args.graph)
+    elapsed, marks, out, P_cpu, img0, img1 = m["elapsed"], m["marks"], m["out"], m["P_cpu"], m["img0"], m["img1"]
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -286,11 +350,10 @@ def main():
             "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
                        "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
-                       "conv_stack": "own fp32 MFMA kernels: direct 5x5/2 (conv2, conv3), Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), small-map kernel with deterministic "
-                                     "split-K (conv4 .. conv6_1), 7x7/2 stem, flow heads; 4x4/2 deconvolutions: library fp32 GEMM + own col2im/bias/ReLU pass into the "
-                                     "concat blob; no Concat copies (%.1f GFLOP/step/GPU)" % conv_gf,
+                       "conv_stack": CONV_STACK_NOTE + " (%.1f GFLOP/step/GPU)" % conv_gf,
                        "tuned_gemm_table_accepted": tuning.active(),
-                       "launch": "hipGraph replay" if use_graph else "host launches", "python_gc": "paused for the timed steps" if gc_was_on else "on", "ranks_seen_by_rccl": ranks_seen},
+                       "launch": "hipGraph replay" if m["use_graph"] else "host launches", "python_gc": "paused for the timed steps" if m["gc_paused"] else "on",
+                       "untimed_settling_steps_after_warmup": m["settle_steps"], "ranks_seen_by_rccl": ranks_seen},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
         if world == 1:
@@ -299,6 +362,13 @@ def main():
                 cb, epe = cpu_baseline(P_cpu, img0, img1, out)
                 res["cpu_baseline"] = cb
                 res["epe_vs_cpu_oracle"] = epe
+            elif args.mode == "fwd" and args.net == "2" and not args.no_cpu_baseline:
+                res["epe_vs_cpu_oracle"], _ = flownet2_epe_vs_cpu(P_cpu, img0, img1, out)
+            headline = args.mode == "fwd" and args.net == "C" and (B, H, W) == (8, 320, 448)
+            if headline and not args.no_extras:
+                del m, out
+                torch.cuda.empty_cache()
+                res["extra"] = extras(device, args)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

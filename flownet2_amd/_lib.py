@@ -29,7 +29,7 @@ EXPORTS = [
     "fn2_conv_wino_supported", "fn2_conv_wino_packed_floats", "fn2_conv_wino_pack_weights", "fn2_conv_wino_forward",
     "fn2_conv_wino_num_variants", "fn2_debug_set_wino_variant",
     "fn2_conv_plane_supported", "fn2_conv_plane_ksplit", "fn2_conv_plane_workspace_bytes", "fn2_conv_plane_forward",
-    "fn2_conv_plane_num_variants", "fn2_debug_set_plane_variant", "fn2_debug_set_plane_ksplit",
+    "fn2_conv_plane_num_variants", "fn2_debug_set_plane_variant", "fn2_debug_set_plane_ksplit", "fn2_set_batch_invariant", "fn2_get_batch_invariant",
     "fn2_deconv_plane_supported", "fn2_deconv_plane_ksplit", "fn2_deconv_plane_workspace_bytes", "fn2_deconv_plane_packed_floats",
     "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_forward",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
@@ -146,6 +146,8 @@ def lib():
     L.fn2_conv_plane_forward.argtypes = [fp, fp, fp, fp] + [i] * 12 + [C.c_float, vp, sz, vp]
     L.fn2_debug_set_plane_variant.argtypes = [i]
     L.fn2_debug_set_plane_ksplit.argtypes = [i]
+    L.fn2_set_batch_invariant.argtypes = [i]
+    L.fn2_get_batch_invariant.argtypes = []
     L.fn2_deconv_plane_supported.argtypes = [i] * 5
     L.fn2_deconv_plane_ksplit.argtypes = [i] * 5
     L.fn2_deconv_plane_workspace_bytes.argtypes = [i] * 5

@@ -19,7 +19,8 @@ using TuneKey = std::array<int, 10>;
 // FN2_AUTOTUNE_CACHE=<file>: picks are appended to / preloaded from a text file ("<cache name> k0 .. k9 best" per line), so a
 // second process (e.g. a profiled run) launches no candidates.
 struct TuneCache {
-  explicit TuneCache(const char* name_) : name(name_) {}
+  // table_version: something that changes with the variant table (its size): a cache file written by another build never matches
+  TuneCache(const char* name_, int table_version) : name(std::string(name_) + "#" + std::to_string(table_version)) {}
   std::mutex mu;
   std::map<TuneKey, int> best;
   std::string name;
@@ -63,13 +64,18 @@ inline bool stream_is_capturing(hipStream_t st) {
 
 // run(candidate) launches one candidate and returns FN2_OK, or a non-zero status if it does not apply (skipped).
 // Returns the chosen candidate (cached), or -1 if none could be timed.
-template <class Run>
-int autotune_pick(TuneCache& cache, const TuneKey& key, int ncand, hipStream_t st, Run run) {
+// usable(candidate): cheap host-side check that a candidate applies to this problem; a remembered pick (a FN2_AUTOTUNE_CACHE file
+// can be stale or corrupt) is used only if it is in range and still usable -- otherwise it is dropped and the shape is tuned again.
+template <class Run, class Usable>
+int autotune_pick(TuneCache& cache, const TuneKey& key, int ncand, hipStream_t st, Run run, Usable usable) {
   {
     std::lock_guard<std::mutex> lk(cache.mu);
     cache.load_locked();
     auto it = cache.best.find(key);
-    if (it != cache.best.end()) return it->second;
+    if (it != cache.best.end()) {
+      if (it->second >= 0 && it->second < ncand && usable(it->second)) return it->second;
+      cache.best.erase(it);
+    }
   }
   if (stream_is_capturing(st)) return -1;
   hipEvent_t e0, e1;

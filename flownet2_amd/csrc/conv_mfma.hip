@@ -432,14 +432,18 @@ FN2_API int fn2_conv_mfma_forward(const float* bottom, const float* packed_weigh
     int picked = -1;
     if (autotune_enabled(st)) {
       // candidates 2 i / 2 i + 1 = plain / split-tail launch of variant i; all of them write the same bits
-      static TuneCache cache("conv_mfma");
+      static TuneCache cache("conv_mfma", cv::kNumVariants);
+      auto usable = [&](int c) -> bool {
+        const cv::Variant& v = cv::kVariants[c / 2];
+        return cv::variant_applies(v, a, kernel, stride) && (!(c & 1) || (v.fn_tail && cv::variant_cost(v, a, true) < 1e29));
+      };
       const TuneKey key{N, Cin, Hin, Win, Cout, kernel, stride, pad, bottom_channels == Cin, top_channels == Cout};
       picked = autotune_pick(cache, key, 2 * cv::kNumVariants, st, [&](int c) -> int {
         const cv::Variant& v = cv::kVariants[c / 2];
         if (!cv::variant_applies(v, a, kernel, stride)) return FN2_ERR_UNSUPPORTED;
         if (c & 1) return (v.fn_tail && cv::variant_cost(v, a, true) < 1e29) ? v.fn_tail(a, st) : FN2_ERR_UNSUPPORTED;
         return v.fn(a, st);
-      });
+      }, usable);
     }
     if (picked >= 0) { best = picked / 2; tail = (picked & 1) != 0; }
     else {

@@ -453,9 +453,13 @@ static int forward(Args a, int mode, int stride, void* workspace, size_t workspa
     if (best >= kNumVariants) return fail(FN2_ERR_UNSUPPORTED, "%s: no variant %d", what, best);
   } else {
     if (autotune_enabled(st)) {
-      static TuneCache cache_conv("conv_plane"), cache_deconv("deconv_plane");
+      static TuneCache cache_conv("conv_plane", kNumVariants), cache_deconv("deconv_plane", kNumVariants);
+      auto usable = [&](int i) -> bool {
+        Args t = a;
+        return kVariants[i].mode == mode && kVariants[i].s == stride && plan(kVariants[i], t);
+      };
       const TuneKey key{a.N, a.Cin, a.Hin, a.Win, a.Cout, stride, a.pad, a.ksplit, a.in_ctot == a.Cin, a.out_ctot == a.Cout};
-      best = autotune_pick(mode == 0 ? cache_conv : cache_deconv, key, kNumVariants, st, run);
+      best = autotune_pick(mode == 0 ? cache_conv : cache_deconv, key, kNumVariants, st, run, usable);
     }
     if (best < 0) {
       double bc = 0;
@@ -507,7 +511,7 @@ static void fill_args(cp::Args& a, int N, int Cin, int Hin, int Win, int Cout, i
   a.Hout = (Hin + 2 * pad - 3) / stride + 1; a.Wout = (Win + 2 * pad - 3) / stride + 1;
   a.P = a.Hout * a.Wout; a.Wp = a.Wout;
   a.units = ((Cin + 3) / 4 + 1) / 2;
-  a.ksplit = cp::ksplit_for((long long)cp::cdiv(N * a.P, 16) * (Cout / 16), a.units);
+  a.ksplit = cp::ksplit_for((long long)cp::cdiv(order_batch(N) * a.P, 16) * (Cout / 16), a.units);
   a.ksteps = a.units * 2 * 9 + cp::kSpare;                        // fn2_conv_mfma_pack_weights: whole chunks of 2 quads + 8 spare k-steps
   a.class_stride = 0;
 }
@@ -571,7 +575,7 @@ static void fill_deconv_args(cp::Args& a, int N, int Cin, int Hin, int Win, int 
   a.Hout = 2 * Hin; a.Wout = 2 * Win;
   a.P = Hin * Win; a.Wp = Win;
   a.units = ((Cin + 3) / 4 + 1) / 2;
-  a.ksplit = cp::ksplit_for(4ll * cp::cdiv(N * a.P, 16) * (Cout / 16), a.units);
+  a.ksplit = cp::ksplit_for(4ll * cp::cdiv(order_batch(N) * a.P, 16) * (Cout / 16), a.units);
   a.ksteps = a.units * 2 * 4 + cp::kSpare;
   a.class_stride = (size_t)(Cout / 64) * a.ksteps * 256;
 }

@@ -579,14 +579,18 @@ FN2_API int fn2_conv_wino_forward(const float* bottom, const float* packed_weigh
     hipStream_t st = as_stream(stream);
     int picked = -1;
     if (autotune_enabled(st)) {
-      static TuneCache cache("conv_wino");
+      static TuneCache cache("conv_wino", wino::kNumVariants);
+      auto usable = [&](int c) -> bool {
+        const wino::Variant& v = wino::kVariants[c / 2];
+        return wino::variant_applies(v, a) && (!(c & 1) || (v.fn_tail && wino::variant_cost(v, a, true) < 1e29));
+      };
       const TuneKey key{N, Cin, Hin, Win, Cout, pad, bottom_channels == Cin, top_channels == Cout, 0, 0};
       picked = autotune_pick(cache, key, 2 * wino::kNumVariants, st, [&](int c) -> int {
         const wino::Variant& v = wino::kVariants[c / 2];
         if (!wino::variant_applies(v, a)) return FN2_ERR_UNSUPPORTED;
         if (c & 1) return (v.fn_tail && wino::variant_cost(v, a, true) < 1e29) ? v.fn_tail(a, st) : FN2_ERR_UNSUPPORTED;
         return v.fn(a, st);
-      });
+      }, usable);
     }
     if (picked >= 0) { best = picked / 2; tail = (picked & 1) != 0; }
     else {

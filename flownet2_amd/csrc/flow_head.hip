@@ -146,7 +146,7 @@ using namespace fn2;
 constexpr int kHeadG = 16;     // waves (channel groups) per block: 64 pixels x 16 groups, 72 KB of LDS for the reduction
 
 static int head_splits(int N, int C, int H, int W) {
-  const long long blocks = ((long long)N * H * W + kHeadPix - 1) / kHeadPix;
+  const long long blocks = ((long long)order_batch(N) * H * W + kHeadPix - 1) / kHeadPix;     // the channel split fixes the summation order
   // power of two in {1, 2, 4, 8}: ~4096 waves in flight, but at least 8 channels per wave
   int nsplit = 1;
   while (nsplit < 8 && blocks * kHeadG * nsplit < 4096 && C >= 8 * kHeadG * nsplit * 2) nsplit *= 2;

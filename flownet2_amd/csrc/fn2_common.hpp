@@ -15,6 +15,11 @@ namespace fn2 {
 
 std::string& last_error();
 
+// fn2_set_batch_invariant (api.cpp): with the flag on, every launch parameter that fixes a summation order and would otherwise depend
+// on the batch size is computed for a batch of ONE sample (order_batch(N) == 1), so the bits of a sample do not depend on its batch.
+int& batch_invariant_flag();
+inline int order_batch(int N) { return batch_invariant_flag() ? 1 : N; }
+
 inline int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;

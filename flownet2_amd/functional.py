@@ -14,6 +14,48 @@ from . import ops
 from . import tuning
 
 
+_BATCH_INVARIANT = [False]
+
+
+def set_batch_invariant(on: bool = True):
+    """Make the bits of a sample independent of the batch it is computed in (scripts/run_flownet_many.py: one .flo per pair, whatever
+    the batching and the sharding over GPUs -- run-flownet-many.py:27-81).  The own kernels are batch-invariant by construction except
+    for the K split of the small-map kernels (fn2_set_batch_invariant fixes it to the one-sample value); the library calls that are
+    left (rocBLAS / hipBLASLt GEMMs, MIOpen convolutions of small layers) choose their kernels -- and with them the summation order --
+    by problem size, so in this mode they run sample by sample."""
+    _BATCH_INVARIANT[0] = bool(on)
+    ops.set_batch_invariant(bool(on))
+    from . import nets
+    nets._BATCH_INVARIANT_ROUTES[0] = bool(on)
+
+
+def batch_invariant() -> bool:
+    return _BATCH_INVARIANT[0]
+
+
+def _matmul_per_sample(w2d, x3d):
+    """w2d [M, K] x x3d [N, K, P] -> [N, M, P]; one GEMM per sample in batch-invariant mode."""
+    if not _BATCH_INVARIANT[0] or x3d.shape[0] == 1:
+        return torch.matmul(w2d, x3d)
+    out = torch.empty((x3d.shape[0], w2d.shape[0], x3d.shape[2]), device=x3d.device, dtype=x3d.dtype)
+    for n in range(x3d.shape[0]):
+        torch.matmul(w2d, x3d[n], out=out[n])
+    return out
+
+
+def lib_conv2d(x, w, b, stride, pad):
+    """The library convolution of a layer no own kernel serves (MIOpen through torch); sample by sample in batch-invariant mode."""
+    if not _BATCH_INVARIANT[0] or x.shape[0] == 1 or not x.is_cuda:
+        return torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad)
+    return torch.cat([torch.nn.functional.conv2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
+
+
+def lib_conv_transpose2d(x, w, b, stride, pad):
+    if not _BATCH_INVARIANT[0] or x.shape[0] == 1 or not x.is_cuda:
+        return torch.nn.functional.conv_transpose2d(x, w, b, stride=stride, padding=pad)
+    return torch.cat([torch.nn.functional.conv_transpose2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
+
+
 class _Correlation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, b0, b1, params):
@@ -179,6 +221,16 @@ def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
 _PACKED = {}     # id(weight tensor) -> (weak reference, _version, packed copy): one repack per weight update, not per forward
 
 
+def invalidate_weight_caches():
+    """Drop every packed / transposed weight copy.  The caches notice in-place writes through the tensor itself (`_version`), but not
+    writes through `.data` or a checkpoint load into `.data`: call this after such a write (parallel.broadcast_params does)."""
+    from . import nets
+    _PACKED.clear()
+    _PACKED_U.clear()
+    _PACKED_D.clear()
+    nets._WT_CACHE.clear()
+
+
 def _packed_conv_weight(w):
     import weakref
     key = id(w)
@@ -215,6 +267,8 @@ def _conv_mfma_pick(x, weight, stride, pad):
         return None
     force = os.environ.get("FN2_CONV_MFMA", "") == "force"
     N, _, H, W = x.shape
+    if _BATCH_INVARIANT[0]:
+        N = 1               # the route (and with it the arithmetic) must not depend on the batch: decide as for one sample
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if (k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)):
         # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1000 the launch cannot fill 1024 SIMDs and the
@@ -222,7 +276,7 @@ def _conv_mfma_pick(x, weight, stride, pad):
         if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
             return "wino"
     if (k == 3 and (force or Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "1200"))) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
-            and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad)):
+            and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad) and (N == x.shape[0] or ops.conv_plane_supported(x.shape[0], Cin, H, W, Cout, stride, pad))):
         # the encoder layers from 1/16 resolution down (conv4 .. conv6_1): whole planes or row bands in LDS, pixels of several samples per MFMA
         # tile, split K.  Up to 1200 output pixels per sample it is level with or ahead of the im2col + GEMM route (bench A/B: 2.317 vs 2.324 ms)
         return "plane"
@@ -271,7 +325,9 @@ class _OwnForwardConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, runner, stride, pad, negative_slope, act, transposed):
-        y = runner(x.detach(), weight.detach(), bias.detach() if bias is not None else None)
+        # autograd does not record inside forward(): the parameter OBJECT goes to the runner, so that the packed-weight caches
+        # (keyed on the parameter and its _version) hit until the optimizer writes the weight
+        y = runner(x, weight, bias)
         ctx.cfg = (stride, pad, negative_slope, act, bias is not None, transposed)
         ctx.save_for_backward(x, weight, y if act else None)
         return y
@@ -357,7 +413,7 @@ def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True):
 
     def run(xx, ww, bb):
         col = ops.im2col_forward(xx.contiguous(), k, pad, stride)                   # [N, Cin*k*k, Hc*Wc]
-        y = torch.matmul(ww.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
+        y = _matmul_per_sample(ww.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
         if act:
             return ops.bias_leaky_relu_(y, bb, negative_slope)
         return y.add_(bb.view(1, -1, 1, 1)) if bb is not None else y          # a convolution without ReLU (FlowNet-SD's inter-convolutions)
@@ -407,7 +463,7 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
 
     def run_t(xx, wt, bb, out=None, out_c0=0):
-        col = torch.matmul(wt, xx.contiguous().view(N, Cin, H * W))            # [N, Cout*k*k, H*W]
+        col = _matmul_per_sample(wt, xx.contiguous().view(N, Cin, H * W))     # [N, Cout*k*k, H*W]
         return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope, out=out, out_c0=out_c0)
 
     if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)

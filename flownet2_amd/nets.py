@@ -112,9 +112,10 @@ def _conv_routed(x, P, name, stride, pad, act, backend):
         if y is not None:
             _LAST_ROUTE[0] = "im2col + library GEMM"
             return y
+    conv2d = getattr(backend, "lib_conv2d", None) or (lambda xx, ww, bb, s, p: F.conv2d(xx, ww, bb, stride=s, padding=p))
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
-        return backend.conv_bias_leaky_relu(F.conv2d(x, w, None, stride=stride, padding=pad), P[name + ".b"], NEG_SLOPE)
-    y = F.conv2d(x, w, P[name + ".b"], stride=stride, padding=pad)
+        return backend.conv_bias_leaky_relu(conv2d(x, w, None, stride, pad), P[name + ".b"], NEG_SLOPE)
+    y = conv2d(x, w, P[name + ".b"], stride, pad)
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
@@ -152,8 +153,13 @@ def _use_gemm_conv(x, stride):
     least 64 input channels whose column matrix (written and read once) stays below 128 MB -- the GEMM runs at 85-125
     TFLOP/s against 35-95 for the direct kernels; at 170 MB it is a tie, at 300 MB the column traffic loses."""
     n, c, h, w = x.shape
+    if _BATCH_INVARIANT_ROUTES[0]:
+        n = 1               # batch-invariant mode (functional.set_batch_invariant): the route must not depend on the batch size
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     return c >= 64 and 4 * n * c * 9 * ho * wo <= (128 << 20)
+
+
+_BATCH_INVARIANT_ROUTES = [False]
 
 
 def _deconv(x, P, name, act=True, backend=None):
@@ -168,9 +174,10 @@ def _deconv(x, P, name, act=True, backend=None):
                                      weight=w)
         if y is not None:
             return y
+    deconv2d = getattr(backend, "lib_conv_transpose2d", None) or (lambda xx, ww, bb, s, p: F.conv_transpose2d(xx, ww, bb, stride=s, padding=p))
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
-        return backend.conv_bias_leaky_relu(F.conv_transpose2d(x, P[name + ".w"], None, stride=2, padding=1), P[name + ".b"], NEG_SLOPE)
-    y = F.conv_transpose2d(x, P[name + ".w"], P[name + ".b"], stride=2, padding=1)
+        return backend.conv_bias_leaky_relu(deconv2d(x, P[name + ".w"], None, 2, 1), P[name + ".b"], NEG_SLOPE)
+    y = deconv2d(x, P[name + ".w"], P[name + ".b"], 2, 1)
     return F.leaky_relu(y, NEG_SLOPE) if act else y
 
 
@@ -180,14 +187,22 @@ def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
     straight into it (ConcatLayer, concat_layer.cu:8-52, becomes a no-op for this input).  Returns (blob or None, the layer's output --
     a channel-slice view of the blob, or an ordinary tensor)."""
     w = P[name + ".w"]
+    # The blob route writes the later Concat inputs in place (deconvolution, upsampled flow) and discards what those calls return:
+    # it is an INFERENCE route.  With grad mode on and ANY parameter of the net trainable (a frozen encoder with a trainable decoder
+    # included) the stock graph runs instead.
     if (backend is not None and hasattr(backend, "conv_mfma_relu") and x.is_cuda and w.shape[2] in (3, 5)
-            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))):
+            and not (torch.is_grad_enabled() and (x.requires_grad or _any_requires_grad(P)))):
         k = w.shape[2]
         ho, wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
         blob = torch.empty((x.shape[0], w.shape[0] + extra_channels, ho, wo), device=x.device, dtype=x.dtype)
         if backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0) is not None:
             return blob, blob[:, :w.shape[0]]
     return None, _conv(x, P, name, stride, pad, backend=backend)
+
+
+def _any_requires_grad(P) -> bool:
+    vals = P.P.values() if isinstance(P, _Prefixed) else P.values()
+    return any(v.requires_grad for v in vals)
 
 
 def _concat(blob, skip, pieces):

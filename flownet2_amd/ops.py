@@ -360,7 +360,21 @@ def conv_plane_ksplit(N, Cin, Hin, Win, Cout, stride, pad) -> int:
     return int(_lib.lib().fn2_conv_plane_ksplit(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(stride), int(pad)))
 
 
-_PLANE_WS = {}      # device -> the split-K partial-sum workspace (grown on demand, reused by every layer: launches are stream-ordered)
+_PLANE_WS = {}      # (device, stream) -> the split-K partial-sum workspace (grown on demand, reused by every layer: launches are stream-ordered)
+_PLANE_WS_RETIRED = []   # outgrown workspaces are kept alive: a hipGraph captured earlier has their address baked into its kernels
+
+
+def _plane_workspace(device, need):
+    """Per (device, stream) scratch of at least `need` bytes.  Never freed or shrunk: a regrow keeps the old block alive
+    (_PLANE_WS_RETIRED), so a graph captured with the old pointer keeps replaying into memory nobody else owns; separate streams get
+    separate blocks (no ordering exists between them)."""
+    key = (device, int(torch.cuda.current_stream(device).cuda_stream))
+    ws = _PLANE_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            _PLANE_WS_RETIRED.append(ws)
+        ws = _PLANE_WS[key] = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+    return ws
 
 
 def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
@@ -379,9 +393,7 @@ def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, neg
     b = _chk(bias, "bias", ndim=1) if bias is not None else None
     pw = _chk(packed_weight, "packed weight", ndim=1)
     need = int(_lib.lib().fn2_conv_plane_workspace_bytes(N, Cin, H, W, Cout, stride, pad))
-    ws = _PLANE_WS.get(x.device)
-    if need and (ws is None or ws.numel() * 4 < need):
-        ws = _PLANE_WS[x.device] = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    ws = _plane_workspace(x.device, need) if need else None
     check(_lib.lib().fn2_conv_plane_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
                                             stride, pad, int(bool(relu)), C.c_float(float(negative_slope)),
                                             _ptr(ws if need else None), need, _stream()))
@@ -422,9 +434,7 @@ def deconv_plane_forward(x, packed_weight, bias, Cout, relu=True, negative_slope
     b = _chk(bias, "bias", ndim=1) if bias is not None else None
     pw = _chk(packed_weight, "packed weight", ndim=1)
     need = int(_lib.lib().fn2_deconv_plane_workspace_bytes(N, Cin, H, W, Cout))
-    ws = _PLANE_WS.get(x.device)
-    if need and (ws is None or ws.numel() * 4 < need):
-        ws = _PLANE_WS[x.device] = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    ws = _plane_workspace(x.device, need) if need else None
     check(_lib.lib().fn2_deconv_plane_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
                                               int(bool(relu)), C.c_float(float(negative_slope)), _ptr(ws if need else None), need, _stream()))
     return out
@@ -436,6 +446,15 @@ def set_plane_variant(v: int):
 
 def set_plane_ksplit(k: int):
     check(_lib.lib().fn2_debug_set_plane_ksplit(int(k)))
+
+
+def set_batch_invariant(on: bool):
+    """fn2_set_batch_invariant: summation orders that would depend on N are computed for a batch of one sample."""
+    check(_lib.lib().fn2_set_batch_invariant(1 if on else 0))
+
+
+def get_batch_invariant() -> bool:
+    return bool(_lib.lib().fn2_get_batch_invariant())
 
 
 def plane_num_variants() -> int:

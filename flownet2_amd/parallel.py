@@ -36,8 +36,11 @@ def broadcast_params(params: Iterable[torch.Tensor], src: int = 0) -> None:
     """Initial weight broadcast (the reference repeats it every iteration, parallel.cpp:304-320)."""
     if world() == 1:
         return
-    for p in params:
-        dist.broadcast(p.data, src)
+    with torch.no_grad():
+        for p in params:
+            dist.broadcast(p, src)      # in place on the parameter itself: bumps p._version, which the packed-weight caches check
+    from . import functional
+    functional.invalidate_weight_caches()
 
 
 class GradientExchange:
@@ -70,6 +73,7 @@ class GradientExchange:
             self._close(cur)
         self._index = {}
         self._handles = []
+        self._defer = False
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._index[id(p)] = bi
@@ -100,10 +104,31 @@ class GradientExchange:
         if self.world > 1:
             b["work"] = dist.all_reduce(b["flat"], async_op=True)
 
+    def no_sync(self):
+        """Context manager for gradient ACCUMULATION (iter_size > 1 in the reference's solver: several backward passes before
+        on_gradients_ready, solver.cpp:221-226): backward passes inside it only accumulate into the buckets; the exchange is launched
+        by finish() -- or by the hooks of the first backward pass after the context, which must be the last before finish()."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._defer = self._defer, True
+            try:
+                yield self
+            finally:
+                self._defer = prev
+                self.reset()                # the passes inside the context launched nothing: count the next pass from scratch
+        return ctx()
+
     def _on_grad(self, p):
         b = self.buckets[self._index[id(p)]]
+        if b["launched"]:
+            raise RuntimeError("GradientExchange: a gradient arrived for a bucket whose all-reduce is already in flight (a second "
+                               "backward() before finish()); wrap accumulation passes in no_sync()")
+        if self._defer:
+            return
         b["pending"] -= 1
-        if b["pending"] == 0 and not b["launched"]:
+        if b["pending"] == 0:
             self._launch(b)
 
     def finish(self):

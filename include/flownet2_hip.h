@@ -324,6 +324,12 @@ int fn2_conv_plane_forward(const float* bottom, const float* packed_weight, cons
 int fn2_conv_plane_num_variants(void);
 int fn2_debug_set_plane_variant(int variant);    /* as fn2_debug_set_conv_variant (no split-tail forms) */
 int fn2_debug_set_plane_ksplit(int ksplit);      /* > 0: force the number of K parts (changes the summation order); 0: by geometry */
+/* Batch-invariant summation orders (scripts/run-flownet-many.py:27-81 writes one .flo per pair: the bits of a pair must not depend
+ * on the batch it was computed in, nor on how the list was sharded over GPUs).  on != 0: every quantity that fixes a summation order
+ * and would otherwise depend on N (the K parts of fn2_conv_plane_forward / fn2_deconv_plane_forward) is computed for a batch of ONE
+ * sample.  Every other kernel of this library is batch-invariant by construction (all tile variants run the same k-ordered chain). */
+int fn2_set_batch_invariant(int on);
+int fn2_get_batch_invariant(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Deconvolution{kernel 4, stride 2, pad 1} (+ bias, + optional ReLU) of the refinement stages (deconv5 .. deconv2), same kernel family:

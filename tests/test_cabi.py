@@ -32,7 +32,8 @@ def test_oracle_exports_cpu_twins():
     L = oracle.lib()
     for name in _lib.EXPORTS:
         if name in ("fn2_version", "fn2_last_error_string") or name.endswith("workspace_bytes") or name.endswith("_supported") \
-                or name.endswith("_num_variants") or name.startswith("fn2_debug_set_") or name.endswith("_ksplit"):
+                or name.endswith("_num_variants") or name.startswith("fn2_debug_set_") or name.endswith("_ksplit") \
+                or name.endswith("_batch_invariant"):
             # (tile-variant hooks; ksplit is a launch-geometry query whose value the twins take as an argument)
             continue
         assert hasattr(L, name + "_cpu"), name + "_cpu"

@@ -222,3 +222,42 @@ def test_dp2_flownetc_gradient_exchange_matches_single_process(tmp_path):
     _flownet_loss(P2, (a, b, gt), be).backward()
     k = "Convolution5.w"
     assert float((P2[k].grad - P[k].grad).abs().max()) > 1e-3 * float(P[k].grad.abs().max())
+
+
+def test_gradient_exchange_accumulation_needs_no_sync():
+    """A second backward() before finish() must not add into a bucket whose all-reduce has been launched (round-2 advisor finding):
+    it raises; inside no_sync() the passes accumulate and the exchange leaves with finish()."""
+    import torch
+    from flownet2_amd import parallel
+    torch.manual_seed(0)
+    w = [torch.randn(4, 3, requires_grad=True), torch.randn(3, requires_grad=True)]
+    ex = parallel.GradientExchange(w, bucket_bytes=1 << 20)
+    x = torch.randn(5, 3)
+    loss = lambda: ((x @ w[0].t()).sum() + (w[1] * 2).sum())
+    ex.zero_grad()
+    loss().backward()
+    with pytest.raises(RuntimeError, match="no_sync"):
+        loss().backward()
+    ex.finish()
+    # accumulation: two passes inside no_sync, the third outside launches from its hooks; gradient = 3 x one pass
+    ex.zero_grad()
+    loss().backward()
+    ex.finish()
+    one = [p.grad.clone() for p in w]
+    ex.zero_grad()
+    with ex.no_sync():
+        loss().backward()
+        loss().backward()
+    loss().backward()
+    assert ex.finish() == 1
+    for g1, p in zip(one, w):
+        assert torch.allclose(p.grad, 3 * g1)
+    # everything inside no_sync: finish() launches
+    ex.zero_grad()
+    with ex.no_sync():
+        loss().backward()
+        loss().backward()
+    ex.finish()
+    for g1, p in zip(one, w):
+        assert torch.allclose(p.grad, 2 * g1)
+    ex.remove()
