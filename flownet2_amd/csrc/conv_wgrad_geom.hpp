@@ -1,0 +1,119 @@
+// Geometry of the weight-gradient kernel (csrc/conv_wgrad.hip): every index formula the kernel uses -- LDS images, LDS-DMA slot
+// decode, operand addresses, accumulator-tile -> weight-element map, K parts -- as plain constexpr / inline C++, shared with the
+// lane-level host model (oracle/wgrad_model.cpp, test infrastructure) that replays the kernel's data movement on the CPU.
+#pragma once
+
+namespace fn2 {
+namespace wg {
+
+constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+constexpr int up_mod_c(int v, int r, int m) { return v + ((r - v % m) + m) % m; }   // smallest >= v with == r (mod m)
+
+// KS x KS taps, stride S; wave tile = MA groups of 16 `a` channels x NB groups of 16 `b` channels x all KS*KS taps; workgroup =
+// WM x WN waves; chunk = R rows x XT pixels of the `a` map (one sample); V = dwords per LDS-DMA lane (4: 16-byte rows, 1: any width).
+template <int KS_, int S_, int MA_, int NB_, int WM_, int WN_, int XT_, int R_, int V_>
+struct Cfg {
+  static constexpr int KS = KS_, S = S_, MA = MA_, NB = NB_, WM = WM_, WN = WN_, XT = XT_, R = R_, V = V_;
+  static constexpr int NW = WM * WN, THREADS = 64 * NW;
+  static constexpr int T = KS * KS;                          // taps
+  static constexpr int CA = 16 * MA * WM, CB = 16 * NB * WN; // channels of a workgroup's block
+  static constexpr int TILES = MA * NB * T;                  // accumulator tiles per wave
+  static constexpr int KSTEPS = R * XT / 4;                  // MFMA k-steps (4 pixels) per chunk
+  // `a` image: [CA][R][XT], channel stride CSA
+  static constexpr int ROWA = R * XT;
+  static constexpr int CSA = V == 4 ? up_mod_c(ROWA, 4, 32) : up_mod_c(ROWA, 2, 32);
+  static constexpr int SLOTS_CA = CSA / V;
+  static constexpr int SLOTS_A = CA * SLOTS_CA;
+  static constexpr int NRUN_A = cdiv_c(SLOTS_A, 64);
+  static constexpr int A_DW = NRUN_A * 64 * V;
+  // `b` window: [CB][WR][RSB]; window column wc <-> global column S * x0 - PADL + wc, window row wr <-> global row S * y0 - pad + wr
+  static constexpr int PADL = 4;
+  static constexpr int WR = S * (R - 1) + KS;
+  static constexpr int WCOLS = S * (XT - 1) + KS + PADL;
+  static constexpr int RSB = V == 4 ? cdiv_c(WCOLS, 4) * 4 : WCOLS;
+  static constexpr int CSB = V == 4 ? up_mod_c(WR * RSB, 4, 32) : up_mod_c(WR * RSB, S == 1 ? 2 : 4, 32);
+  static constexpr int SLOTS_CB = CSB / V;
+  static constexpr int SLOTS_B = CB * SLOTS_CB;
+  static constexpr int NRUN_B = cdiv_c(SLOTS_B, 64);
+  static constexpr int B_DW = NRUN_B * 64 * V;
+  static constexpr int BUF = A_DW + B_DW;                    // dwords per staging buffer (two of them)
+  static constexpr int RPW_A = cdiv_c(NRUN_A, NW), RPW_B = cdiv_c(NRUN_B, NW);
+  static constexpr int LDS_BYTES = 2 * BUF * 4;
+  static_assert(XT % 4 == 0 && XT >= 4, "chunk width: whole k-steps");
+  static_assert(NW == 4, "256 threads");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(CSA % V == 0 && CSB % V == 0, "whole slots per channel");
+};
+
+// ---- LDS-DMA slot decode.  Slot s of an image = V consecutive dwords at LDS dword address image_base + s * V.
+struct SlotA { int ch, r, x; bool in_image; };      // channel of the block, row of the chunk, first pixel column of the chunk
+template <class K>
+constexpr SlotA slot_a(int s) {
+  const int ch = s / K::SLOTS_CA, d = (s % K::SLOTS_CA) * K::V;
+  return SlotA{ch, d / K::XT, d % K::XT, s < K::SLOTS_A && d < K::ROWA};
+}
+struct SlotB { int ch, wr, wc; bool in_image; };    // channel of the block, window row, first window column
+template <class K>
+constexpr SlotB slot_b(int s) {
+  const int ch = s / K::SLOTS_CB, d = (s % K::SLOTS_CB) * K::V;
+  return SlotB{ch, d / K::RSB, d % K::RSB, s < K::SLOTS_B && d < K::WR * K::RSB};
+}
+
+// ---- MFMA operand addresses (dwords inside a staging buffer).  Lane l: m = n = l & 15, k = l >> 4 (pixel 4 * xq + k of the k-step).
+template <class K>
+constexpr int a_lane_base(int wm, int lane) { return ((wm * K::MA) * 16 + (lane & 15)) * K::CSA + (lane >> 4); }
+template <class K>
+constexpr int a_step_off(int ma, int r, int xq) { return ma * 16 * K::CSA + r * K::XT + 4 * xq; }
+template <class K>
+constexpr int b_lane_base(int wn, int lane, int pad) {
+  return K::A_DW + ((wn * K::NB) * 16 + (lane & 15)) * K::CSB + K::S * (lane >> 4) + K::PADL - pad;
+}
+template <class K>
+constexpr int b_step_off(int nb, int r, int xq, int ky, int kx) { return nb * 16 * K::CSB + (K::S * r + ky) * K::RSB + K::S * 4 * xq + kx; }
+
+// ---- accumulator tile (ma, nb, tap) of wave (wm, wn): lane l, register j holds D[m = 4 * (l >> 4) + j][n = l & 15]
+template <class K> constexpr int tile_index(int ma, int nb, int t) { return (ma * K::NB + nb) * K::T + t; }
+template <class K> constexpr int wave_index(int wm, int wn) { return wm + K::WM * wn; }
+
+// Runtime mirror of the constants the finalize pass needs (which partial-sum element holds weight element (ca, cb, tap)).
+struct SlabMap {
+  int MA, NB, WM, WN, T, CA, CB, TILES;
+  // floats from the start of one part's slab to the element, given the channel-block counts
+  inline long long offset(int ca, int cb, int t, int nblk_b) const {
+    const int blk = (ca / CA) * nblk_b + cb / CB;
+    const int ra = ca % CA, rb = cb % CB;
+    const int wm = ra / (16 * MA), ma = (ra / 16) % MA, m = ra % 16;
+    const int wn = rb / (16 * NB), nb = (rb / 16) % NB, n = rb % 16;
+    const int wave = wm + WM * wn, tile = (ma * NB + nb) * T + t, lane = (m / 4) * 16 + n, reg = m % 4;
+    return (((long long)blk * 4 + wave) * TILES + tile) * 256 + lane * 4 + reg;
+  }
+};
+template <class K>
+constexpr SlabMap slab_map() { return SlabMap{K::MA, K::NB, K::WM, K::WN, K::T, K::CA, K::CB, K::TILES}; }
+
+// ---- K parts: part p of `ksplit` covers the rows (sample n, row y of the `a` map, flattened u = n * Ha + y) [p * U / ksplit,
+// (p + 1) * U / ksplit), U = N * Ha.  A function of the layer geometry only (never of the tile variant): it fixes the summation
+// order -- per part a k-ordered fma chain over the pixels in (n, y, x) order, the parts added in part order.
+inline int part_begin(int p, int ksplit, int U) { return (int)((long long)p * U / ksplit); }
+
+// Channel block of a workgroup per tap class -- the wave tiles of csrc/conv_wgrad.hip's variants: (a channels, b channels).
+inline void class_block(int KS, int& ca, int& cb) {
+  if (KS == 1) { ca = 32; cb = 256; }
+  else if (KS == 3) { ca = 64; cb = 64; }
+  else { ca = 64; cb = 32; }                                   // 4x4, 5x5, 7x7
+}
+
+// Canonical K split of a layer: one workgroup per CU (256) over the channel blocks of its tap class, at least 2 rows per part.
+inline int ksplit_for(int N, int Ca, int Ha, int Cb, int KS) {
+  int ca, cb;
+  class_block(KS, ca, cb);
+  const long long blocks = (long long)cdiv_c(Ca, ca) * cdiv_c(Cb, cb);
+  const int U = N * Ha;
+  long long k = (256 + blocks / 2) / blocks;
+  if (k > U / 2) k = U / 2;
+  if (k < 1) k = 1;
+  return (int)k;
+}
+
+}  // namespace wg
+}  // namespace fn2

@@ -35,8 +35,8 @@ def batch_invariant() -> bool:
 
 def _matmul_per_sample(w2d, x3d):
     """w2d [M, K] x x3d [N, K, P] -> [N, M, P]; one GEMM per sample in batch-invariant mode."""
-    if not _BATCH_INVARIANT[0] or x3d.shape[0] == 1:
-        return torch.matmul(w2d, x3d)
+    if not _BATCH_INVARIANT[0]:
+        return torch.matmul(w2d, x3d)          # (a batch of one included: a 3-D operand takes the batched-GEMM path, another kernel)
     out = torch.empty((x3d.shape[0], w2d.shape[0], x3d.shape[2]), device=x3d.device, dtype=x3d.dtype)
     for n in range(x3d.shape[0]):
         torch.matmul(w2d, x3d[n], out=out[n])
@@ -45,13 +45,13 @@ def _matmul_per_sample(w2d, x3d):
 
 def lib_conv2d(x, w, b, stride, pad):
     """The library convolution of a layer no own kernel serves (MIOpen through torch); sample by sample in batch-invariant mode."""
-    if not _BATCH_INVARIANT[0] or x.shape[0] == 1 or not x.is_cuda:
+    if not _BATCH_INVARIANT[0] or not x.is_cuda:
         return torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad)
     return torch.cat([torch.nn.functional.conv2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
 
 
 def lib_conv_transpose2d(x, w, b, stride, pad):
-    if not _BATCH_INVARIANT[0] or x.shape[0] == 1 or not x.is_cuda:
+    if not _BATCH_INVARIANT[0] or not x.is_cuda:
         return torch.nn.functional.conv_transpose2d(x, w, b, stride=stride, padding=pad)
     return torch.cat([torch.nn.functional.conv_transpose2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
 
@@ -266,14 +266,17 @@ def _conv_mfma_pick(x, weight, stride, pad):
     if not x.is_cuda or not _mfma_conv_enabled(k, stride):
         return None
     force = os.environ.get("FN2_CONV_MFMA", "") == "force"
+    own = force             # lift the work thresholds below which the library is faster
     N, _, H, W = x.shape
     if _BATCH_INVARIANT[0]:
-        N = 1               # the route (and with it the arithmetic) must not depend on the batch: decide as for one sample
+        # the route (and with it the arithmetic) must not depend on the batch: decide as for one sample, and take the own kernels
+        # wherever they apply -- they are batch-invariant by construction, the library's choices are its own business
+        N, own = 1, True
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if (k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)):
         # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1000 the launch cannot fill 1024 SIMDs and the
         # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
-        if force or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
+        if own or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
             return "wino"
     if (k == 3 and (force or Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "1200"))) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
             and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad) and (N == x.shape[0] or ops.conv_plane_supported(x.shape[0], Cin, H, W, Cout, stride, pad))):
@@ -284,7 +287,7 @@ def _conv_mfma_pick(x, weight, stride, pad):
         return None
     # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
     # large enough to run the matrix pipes efficiently, and the library's GEMM route wins (scripts/conv_bench.py, profiles/)
-    if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not force:
+    if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not own:
         return None
     return "direct"
 

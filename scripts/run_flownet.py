@@ -66,11 +66,14 @@ def main():
     ap.add_argument("--net", choices=["C", "S", "2"], default="C")
     ap.add_argument("--weights", default=None)
     ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--no-batch-invariant", action="store_true", help="let kernel selection follow the work size (see run_flownet_many.py)")
     a = ap.parse_args()
     for f in (a.img0, a.img1):
         if not os.path.exists(f):
             raise SystemExit("image does not exist: " + f)
     dev = torch.device("cuda", a.gpu)
+    # same arithmetic as run_flownet_many.py on any batching / sharding of a list: a pair's .flo does not depend on how it was computed
+    Fn.set_batch_invariant(not a.no_batch_invariant)
     P, mean = load_params(a.net, a.weights, dev)
     i0, i1 = torch.from_numpy(read_image(a.img0)).to(dev), torch.from_numpy(read_image(a.img1)).to(dev)
     flow = infer(a.net, P, i0, i1, mean)
