@@ -10,10 +10,13 @@ constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
 constexpr int up_mod_c(int v, int r, int m) { return v + ((r - v % m) + m) % m; }   // smallest >= v with == r (mod m)
 
 // KS x KS taps, stride S; wave tile = MA groups of 16 `a` channels x NB groups of 16 `b` channels x all KS*KS taps; workgroup =
-// WM x WN waves; chunk = R rows x XT pixels of the `a` map (one sample); V = dwords per LDS-DMA lane (4: 16-byte rows, 1: any width).
-template <int KS_, int S_, int MA_, int NB_, int WM_, int WN_, int XT_, int R_, int V_>
+// WM x WN waves; chunk = R rows x XT pixels of the `a` map (one sample).  Staging is 16-byte LDS-DMA (V = 4 dwords per lane): both maps
+// must have a width that is a multiple of 4 (the host pads narrower / odd maps into a workspace first, conv_wgrad.hip: pad_width).
+// DB = 1: two staging buffers (the next chunk's DMA flies under this chunk's MFMAs), one workgroup per CU; DB = 0: one buffer and two
+// workgroups per CU (8 waves: the other workgroup's MFMAs cover this one's DMA latency, barriers and issue stalls).
+template <int KS_, int S_, int MA_, int NB_, int WM_, int WN_, int XT_, int R_, int DB_ = 1>
 struct Cfg {
-  static constexpr int KS = KS_, S = S_, MA = MA_, NB = NB_, WM = WM_, WN = WN_, XT = XT_, R = R_, V = V_;
+  static constexpr int KS = KS_, S = S_, MA = MA_, NB = NB_, WM = WM_, WN = WN_, XT = XT_, R = R_, V = 4, DB = DB_;
   static constexpr int NW = WM * WN, THREADS = 64 * NW;
   static constexpr int T = KS * KS;                          // taps
   static constexpr int CA = 16 * MA * WM, CB = 16 * NB * WN; // channels of a workgroup's block
@@ -21,7 +24,7 @@ struct Cfg {
   static constexpr int KSTEPS = R * XT / 4;                  // MFMA k-steps (4 pixels) per chunk
   // `a` image: [CA][R][XT], channel stride CSA
   static constexpr int ROWA = R * XT;
-  static constexpr int CSA = V == 4 ? up_mod_c(ROWA, 4, 32) : up_mod_c(ROWA, 2, 32);
+  static constexpr int CSA = up_mod_c(ROWA, 4, 32);        // == 4 (mod 32): the A-operand read (16 channels x 2 pixels per half wave) is 2-way
   static constexpr int SLOTS_CA = CSA / V;
   static constexpr int SLOTS_A = CA * SLOTS_CA;
   static constexpr int NRUN_A = cdiv_c(SLOTS_A, 64);
@@ -30,18 +33,19 @@ struct Cfg {
   static constexpr int PADL = 4;
   static constexpr int WR = S * (R - 1) + KS;
   static constexpr int WCOLS = S * (XT - 1) + KS + PADL;
-  static constexpr int RSB = V == 4 ? cdiv_c(WCOLS, 4) * 4 : WCOLS;
-  static constexpr int CSB = V == 4 ? up_mod_c(WR * RSB, 4, 32) : up_mod_c(WR * RSB, S == 1 ? 2 : 4, 32);
+  static constexpr int RSB = cdiv_c(WCOLS, 4) * 4;
+  static constexpr int CSB = up_mod_c(WR * RSB, 4, 32);
   static constexpr int SLOTS_CB = CSB / V;
   static constexpr int SLOTS_B = CB * SLOTS_CB;
   static constexpr int NRUN_B = cdiv_c(SLOTS_B, 64);
   static constexpr int B_DW = NRUN_B * 64 * V;
   static constexpr int BUF = A_DW + B_DW;                    // dwords per staging buffer (two of them)
   static constexpr int RPW_A = cdiv_c(NRUN_A, NW), RPW_B = cdiv_c(NRUN_B, NW);
-  static constexpr int LDS_BYTES = 2 * BUF * 4;
+  static constexpr int LDS_BYTES = (DB ? 2 : 1) * BUF * 4;
+  static constexpr int WG_PER_CU = DB ? 1 : 2;
   static_assert(XT % 4 == 0 && XT >= 4, "chunk width: whole k-steps");
   static_assert(NW == 4, "256 threads");
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS");
   static_assert(CSA % V == 0 && CSB % V == 0, "whole slots per channel");
 };
 
@@ -94,7 +98,7 @@ constexpr SlabMap slab_map() { return SlabMap{K::MA, K::NB, K::WM, K::WN, K::T, 
 // ---- K parts: part p of `ksplit` covers the rows (sample n, row y of the `a` map, flattened u = n * Ha + y) [p * U / ksplit,
 // (p + 1) * U / ksplit), U = N * Ha.  A function of the layer geometry only (never of the tile variant): it fixes the summation
 // order -- per part a k-ordered fma chain over the pixels in (n, y, x) order, the parts added in part order.
-inline int part_begin(int p, int ksplit, int U) { return (int)((long long)p * U / ksplit); }
+constexpr int part_begin(int p, int ksplit, int U) { return (int)((long long)p * U / ksplit); }
 
 // Channel block of a workgroup per tap class -- the wave tiles of csrc/conv_wgrad.hip's variants: (a channels, b channels).
 inline void class_block(int KS, int& ca, int& cb) {
@@ -103,16 +107,26 @@ inline void class_block(int KS, int& ca, int& cb) {
   else { ca = 64; cb = 32; }                                   // 4x4, 5x5, 7x7
 }
 
-// Canonical K split of a layer: one workgroup per CU (256) over the channel blocks of its tap class, at least 2 rows per part.
-inline int ksplit_for(int N, int Ca, int Ha, int Cb, int KS) {
+// Canonical K split of a layer (a function of its geometry only): the k that minimises a two-term cost model over the channel blocks
+// of its tap class -- whole rounds of 256 workgroups (one per CU) at 120 TFLOP/s, plus writing and re-reading k slabs of partial sums
+// at 3 TB/s -- with at least 2 rows per part and at most 64 parts; ties go to the smaller k.
+inline int ksplit_for(int N, int Ca, int Ha, int Wa, int Cb, int KS) {
   int ca, cb;
   class_block(KS, ca, cb);
   const long long blocks = (long long)cdiv_c(Ca, ca) * cdiv_c(Cb, cb);
   const int U = N * Ha;
-  long long k = (256 + blocks / 2) / blocks;
-  if (k > U / 2) k = U / 2;
-  if (k < 1) k = 1;
-  return (int)k;
+  int kmax = U / 2 < 64 ? U / 2 : 64;
+  if (kmax < 1) kmax = 1;
+  const double flops = 2.0 * N * Ha * Wa * (double)(blocks * ca) * cb * KS * KS;       // incl. the padding of the last blocks
+  const double t_compute = flops / 120e12, t_slab = 2.0 * 4.0 * (double)(blocks * ca) * cb * KS * KS / 3e12;
+  int best = 1;
+  double best_t = 0;
+  for (int k = 1; k <= kmax; ++k) {
+    const long long wgs = blocks * k, rounds = (wgs + 255) / 256;
+    const double t = (double)rounds * (t_compute * 256.0 / (double)wgs) + (double)k * t_slab;
+    if (k == 1 || t < best_t * (1.0 - 1e-9)) { best = k; best_t = t; }
+  }
+  return best;
 }
 
 }  // namespace wg

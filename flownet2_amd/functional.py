@@ -347,10 +347,32 @@ class _OwnForwardConv(torch.autograd.Function):
             d, db = g, (g.sum((0, 2, 3)) if need_b else None)
         need_x, need_w = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
         gx = _own_bwd_data(d, w, stride, pad, transposed) if need_x else None
-        lib_x = need_x and gx is None
-        gxl, gw, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
-                                                         [lib_x, need_w, False])
-        return (gxl if lib_x else gx), gw, db, None, None, None, None, None, None
+        gw = _own_bwd_weight(d, x, w, stride, pad, transposed) if need_w else None
+        lib_x, lib_w = need_x and gx is None, need_w and gw is None
+        if lib_x or lib_w:
+            gxl, gwl, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
+                                                              [lib_x, lib_w, False])
+            gx, gw = (gxl if lib_x else gx), (gwl if lib_w else gw)
+        return gx, gw, db, None, None, None, None, None, None
+
+
+def _own_bwd_weight(d, x, w, stride, pad, transposed):
+    """weight_diff of a Convolution (ConvolutionLayer::Backward_gpu -> weight_gpu_gemm, conv_layer.cu:40-52) or Deconvolution
+    (deconv_layer.cu:36-50, the roles of the two blobs swapped) on the own fp32 MFMA kernel (csrc/conv_wgrad.hip): NCHW in, weight
+    layout out, no layout transposes, deterministic.  FN2_OWN_WGRAD=0 hands it back to the library.  Returns None when the kernel does
+    not apply (tap classes 1/1, 3/1, 3/2, 4/2, 5/2; layers with fewer than 16 output channels -- the 2-channel flow heads -- stay
+    with the library: a 16-wide MFMA tile would be 8x padding)."""
+    if os.environ.get("FN2_OWN_WGRAD", "1") == "0" or not d.is_cuda:
+        return None
+    k = w.shape[2]
+    a, b = (x, d) if transposed else (d, x)          # `a`: the map at the convolution's OUTPUT resolution
+    if w.shape[3] != k or min(a.shape[1], b.shape[1]) < 16:
+        return None
+    if not ops.conv_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], b.shape[1], b.shape[2], b.shape[3], k, stride, pad):
+        return None
+    ab, a0 = _channel_slice(a)
+    bb, b0 = _channel_slice(b)
+    return ops.conv_wgrad(ab, bb, k, stride, pad, a_c0=a0, Ca=a.shape[1], b_c0=b0, Cb=b.shape[1])
 
 
 def _own_bwd_data(d, w, stride, pad, transposed):

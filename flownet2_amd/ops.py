@@ -400,6 +400,38 @@ def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, neg
     return out
 
 
+def conv_wgrad_supported(N, Ca, Ha, Wa, Cb, Hb, Wb, kernel, stride, pad) -> bool:
+    return bool(_lib.lib().fn2_conv_wgrad_supported(int(N), int(Ca), int(Ha), int(Wa), int(Cb), int(Hb), int(Wb), int(kernel), int(stride), int(pad)))
+
+
+def conv_wgrad_ksplit(N, Ca, Ha, Wa, Cb, Hb, Wb, kernel, stride, pad) -> int:
+    return int(_lib.lib().fn2_conv_wgrad_ksplit(int(N), int(Ca), int(Ha), int(Wa), int(Cb), int(Hb), int(Wb), int(kernel), int(stride), int(pad)))
+
+
+def conv_wgrad(a, b, kernel, stride, pad, out=None, accumulate=False, a_c0=0, Ca=None, b_c0=0, Cb=None):
+    """dw[ca][cb][ky][kx] (+)= sum a[n, a_c0 + ca, y, x] * b[n, b_c0 + cb, stride y + ky - pad, stride x + kx - pad] (csrc/conv_wgrad.hip).
+    Convolution: a = top_diff, b = bottom -> [Cout, Cin, k, k]; Deconvolution: a = bottom, b = top_diff -> [Cin, Cout, k, k]."""
+    a, b = _chk(a, "a"), _chk(b, "b")
+    N, Atot, Ha, Wa = a.shape
+    Nb, Btot, Hb, Wb = b.shape
+    if N != Nb:
+        raise ValueError("conv_wgrad: batch sizes differ")
+    Ca = Atot - a_c0 if Ca is None else Ca
+    Cb = Btot - b_c0 if Cb is None else Cb
+    if out is None:
+        out = torch.empty((Ca, Cb, kernel, kernel), device=a.device, dtype=torch.float32)
+        accumulate = False
+    else:
+        out = _chk(out, "weight diff")
+        if tuple(out.shape) != (Ca, Cb, kernel, kernel):
+            raise ValueError("conv_wgrad: weight diff has the wrong shape")
+    need = int(_lib.lib().fn2_conv_wgrad_workspace_bytes(N, Ca, Ha, Wa, Cb, Hb, Wb, kernel, stride, pad))
+    ws = _plane_workspace(a.device, need) if need else None
+    check(_lib.lib().fn2_conv_wgrad(_ptr(a), _ptr(b), _ptr(out), N, Ca, Ha, Wa, Atot, a_c0, Cb, Hb, Wb, Btot, b_c0, int(kernel), int(stride), int(pad),
+                                    int(bool(accumulate)), _ptr(ws), need, _stream()))
+    return out
+
+
 def deconv_plane_supported(N, Cin, Hin, Win, Cout) -> bool:
     return bool(_lib.lib().fn2_deconv_plane_supported(int(N), int(Cin), int(Hin), int(Win), int(Cout)))
 

@@ -355,6 +355,28 @@ int fn2_deconv_plane_forward(const float* bottom, const float* packed_weight, co
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weight gradient of a Convolution or Deconvolution layer (fp32 MFMA, NCHW, deterministic):
+ *     dw[ca][cb][ky][kx] (+)= sum_{n,y,x} a[n][a_c0 + ca][y][x] * b[n][b_c0 + cb][stride*y + ky - pad][stride*x + kx - pad]   (0 outside b)
+ *   <- ConvolutionLayer::Backward_gpu, src/caffe/layers/conv_layer.cu:40-52 (weight_gpu_gemm, base_conv_layer.cpp:368-384: per sample
+ *      im2col_gpu + cublasSgemm with beta = 1): a = top_diff [N, Cout, Hout, Wout], b = bottom, dw = weight_diff [Cout][Cin][k][k];
+ *   <- DeconvolutionLayer::Backward_gpu, deconv_layer.cu:36-50 (weight_gpu_gemm(top_diff, bottom): the roles swapped): a = bottom
+ *      [N, Cin, Hin, Win], b = top_diff, dw = weight_diff [Cin][Cout][k][k].
+ *   accumulate != 0 adds into dw like the reference (the solver clears the diffs once per iteration); 0 overwrites.
+ *   kernel / stride classes: 1/1, 3/1, 3/2, 4/2, 5/2; pad <= kernel - 1.  Summation order: the rows (n, y) of `a` are cut into
+ *   fn2_conv_wgrad_ksplit(...) contiguous parts; per part one fma chain over its pixels in (n, y, x) order, the parts added in part
+ *   order -- a function of the layer geometry only, restated by the oracle twin.  Workspace: the parts' partial sums (+ width-padded
+ *   copies of maps whose width is not a multiple of 4), fn2_conv_wgrad_workspace_bytes.  The bias gradient: fn2_bias_leaky_relu_backward. */
+int fn2_debug_set_wgrad_buffers(int two_buffers);   /* 0 / 1: force the one-buffer (2 workgroups per CU) / two-buffer kernels; -1: default.  Same bits. */
+int fn2_debug_set_wgrad_chunk(int pixels);          /* force the chunk width (8, 16, 28, 56) where it applies; 0: by row width.  Same bits. */
+int fn2_conv_wgrad_supported(int N, int Ca, int Ha, int Wa, int Cb, int Hb, int Wb, int kernel, int stride, int pad);
+int fn2_conv_wgrad_ksplit(int N, int Ca, int Ha, int Wa, int Cb, int Hb, int Wb, int kernel, int stride, int pad);
+size_t fn2_conv_wgrad_workspace_bytes(int N, int Ca, int Ha, int Wa, int Cb, int Hb, int Wb, int kernel, int stride, int pad);
+int fn2_conv_wgrad(const float* a, const float* b, float* dw,
+                   int N, int Ca, int Ha, int Wa, int a_channels, int a_c0,
+                   int Cb, int Hb, int Wb, int b_channels, int b_c0,
+                   int kernel, int stride, int pad, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * im2col / col2im of Caffe's GEMM convolution, batched over the mini-batch (square kernel, no dilation):
  *   fn2_im2col_forward            <- im2col_gpu, src/caffe/util/im2col.cu:8-72, as used by
  *                                    BaseConvolutionLayer::forward_gpu_gemm (base_conv_layer.cpp:325-341)

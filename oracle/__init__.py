@@ -292,6 +292,21 @@ def conv_plane_forward(x, packed, bias, Cout, stride, pad, ksplit, relu=True, ne
     return out
 
 
+def conv_wgrad(a, b, kernel, stride, pad, ksplit, out=None, accumulate=False, a_c0=0, Ca=None, b_c0=0, Cb=None):
+    """CPU twin of fn2_conv_wgrad: dw[ca][cb][ky][kx] (+)= sum a[n, a_c0+ca, y, x] * b[n, b_c0+cb, stride y + ky - pad, stride x + kx - pad];
+    ksplit = fn2_conv_wgrad_ksplit() (it fixes the summation order)."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    N, Atot, Ha, Wa = a.shape
+    _, Btot, Hb, Wb = b.shape
+    Ca = Atot - a_c0 if Ca is None else Ca
+    Cb = Btot - b_c0 if Cb is None else Cb
+    if out is None:
+        out, accumulate = np.zeros((Ca, Cb, kernel, kernel), np.float32), False
+    _check(lib().fn2_conv_wgrad_cpu(_p(a), _p(b), _p(out), N, Ca, Ha, Wa, Atot, a_c0, Cb, Hb, Wb, Btot, b_c0, int(kernel), int(stride), int(pad),
+                                    int(bool(accumulate)), int(ksplit)), "conv_wgrad")
+    return out
+
+
 def deconv_plane_pack_weights(weight):
     """weight [Cin, Cout, 4, 4] (Caffe's deconvolution blob) -> the per-parity-class MFMA operand order of fn2_deconv_plane_forward."""
     w = _f32(weight)

@@ -1061,6 +1061,50 @@ FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed,
   return FN2_OK;
 }
 
+/* Weight gradient of a Convolution / Deconvolution layer: the CPU twin of csrc/conv_wgrad.hip.
+ * Reference arithmetic: ConvolutionLayer::Backward_cpu (conv_layer.cpp:43-66) -> weight_cpu_gemm (base_conv_layer.cpp:289-303: per sample
+ * im2col + cblas_sgemm(top_diff x col^T) accumulated into weight_diff):
+ *     dw[ca][cb][ky][kx] (+)= sum_{n,y,x} a[n][ca][y][x] * b[n][cb][stride y + ky - pad][stride x + kx - pad]     (0 outside b)
+ * with a = top_diff, b = bottom for a Convolution; a = bottom, b = top_diff for a Deconvolution (deconv_layer.cpp:28-45, the roles swapped).
+ * Summation order of the HIP kernel: the rows u = n * Ha + y of `a` are cut into `ksplit` contiguous parts [p U / ksplit, (p + 1) U /
+ * ksplit); per part one fmaf chain over its pixels in (n, y, x) order; the parts added in part order.  ksplit is what
+ * fn2_conv_wgrad_ksplit() reports (passed in: the oracle does not link the HIP library). */
+FN2_API int fn2_conv_wgrad_cpu(const float* a, const float* b, float* dw,
+                               int N, int Ca, int Ha, int Wa, int a_channels, int a_c0,
+                               int Cb, int Hb, int Wb, int b_channels, int b_c0,
+                               int kernel, int stride, int pad, int accumulate, int ksplit) {
+  if (!a || !b || !dw || N < 0 || Ca < 1 || Ha < 1 || Wa < 1 || Cb < 1 || Hb < 1 || Wb < 1 || kernel < 1 || stride < 1 || pad < 0 || ksplit < 1)
+    return FN2_ERR_INVALID_ARG;
+  if (a_c0 < 0 || a_c0 + Ca > a_channels || b_c0 < 0 || b_c0 + Cb > b_channels) return FN2_ERR_INVALID_ARG;
+  const int U = N * Ha;
+  if (ksplit > (U > 0 ? U : 1)) return FN2_ERR_INVALID_ARG;
+#pragma omp parallel for collapse(2)
+  for (int ca = 0; ca < Ca; ++ca)
+    for (int cb = 0; cb < Cb; ++cb)
+      for (int ky = 0; ky < kernel; ++ky)
+        for (int kx = 0; kx < kernel; ++kx) {
+          float sum = 0.f;
+          for (int part = 0; part < ksplit; ++part) {
+            float acc = 0.f;
+            const int u0 = (int)((long long)part * U / ksplit), u1 = (int)((long long)(part + 1) * U / ksplit);
+            for (int u = u0; u < u1; ++u) {
+              const int n = u / Ha, y = u % Ha, yi = stride * y + ky - pad;
+              if (yi < 0 || yi >= Hb) continue;                                           /* fmaf(a, 0, acc) == acc */
+              const float* ar = a + (((size_t)n * a_channels + a_c0 + ca) * Ha + y) * Wa;
+              const float* br = b + (((size_t)n * b_channels + b_c0 + cb) * Hb + yi) * Wb;
+              for (int x = 0; x < Wa; ++x) {
+                const int xi = stride * x + kx - pad;
+                if (xi >= 0 && xi < Wb) acc = fmaf(ar[x], br[xi], acc);
+              }
+            }
+            sum = part == 0 ? acc : sum + acc;
+          }
+          float* o = dw + (((size_t)ca * Cb + cb) * kernel + ky) * kernel + kx;
+          *o = accumulate ? *o + sum : sum;
+        }
+  return FN2_OK;
+}
+
 /* Deconvolution{4x4, stride 2, pad 1} + bias + optional ReLU on packed weights: the CPU twin of csrc/conv_plane.hip (MODE 1).
  * Reference arithmetic: DeconvolutionLayer::Forward_cpu (deconv_layer.cpp:8-26: weight^T x bottom, col2im, bias) and the in-place ReLU
  * (relu_layer.cpp:23-30): out[Y][X] = sum_ci sum_{ky, kx} in[y][x] W[ci][co][ky][kx] with Y = 2 y - 1 + ky, X = 2 x - 1 + kx.  Every
