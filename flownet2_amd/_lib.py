@@ -32,6 +32,7 @@ EXPORTS = [
     "fn2_conv_plane_num_variants", "fn2_debug_set_plane_variant", "fn2_debug_set_plane_ksplit", "fn2_set_batch_invariant", "fn2_get_batch_invariant",
     "fn2_deconv_plane_supported", "fn2_deconv_plane_ksplit", "fn2_deconv_plane_workspace_bytes", "fn2_deconv_plane_packed_floats",
     "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_forward",
+    "fn2_tconv_supported", "fn2_tconv_forward", "fn2_tconv_num_variants", "fn2_debug_set_tconv_variant",
     "fn2_debug_set_wgrad_buffers", "fn2_debug_set_wgrad_chunk", "fn2_conv_wgrad_supported", "fn2_conv_wgrad_ksplit", "fn2_conv_wgrad_workspace_bytes", "fn2_conv_wgrad",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
@@ -149,6 +150,9 @@ def lib():
     L.fn2_debug_set_plane_ksplit.argtypes = [i]
     L.fn2_set_batch_invariant.argtypes = [i]
     L.fn2_get_batch_invariant.argtypes = []
+    L.fn2_tconv_supported.argtypes = [i] * 8
+    L.fn2_tconv_forward.argtypes = [fp, fp, fp, fp] + [i] * 14 + [C.c_float, vp]
+    L.fn2_debug_set_tconv_variant.argtypes = [i]
     L.fn2_debug_set_wgrad_buffers.argtypes = [i]
     L.fn2_debug_set_wgrad_chunk.argtypes = [i]
     L.fn2_conv_wgrad_supported.argtypes = [i] * 10

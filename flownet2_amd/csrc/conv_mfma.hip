@@ -332,6 +332,8 @@ struct Variant {
   X(3, 1, 2, 6, 2, 2, 1, 2, 1) X(3, 1, 4, 6, 1, 2, 2, 2, 0) X(3, 1, 4, 4, 1, 2, 2, 2, 0) X(3, 1, 2, 4, 2, 2, 1, 2, 1) \
   /* 3x3 stride 2 */ \
   X(3, 2, 2, 7, 2, 1, 2, 2, 1) X(3, 2, 4, 7, 1, 1, 4, 2, 0) X(3, 2, 2, 6, 2, 2, 1, 2, 1) X(3, 2, 4, 6, 1, 2, 2, 2, 0) X(3, 2, 2, 4, 2, 2, 1, 2, 1) \
+  /* 4x4 stride 2 (the data gradient of the Deconvolution{4, 2, 1} layers: a convolution of top_diff with the weight blob as it is) */ \
+  X(4, 2, 2, 7, 2, 2, 1, 2, 1) X(4, 2, 2, 7, 2, 1, 2, 2, 1) X(4, 2, 4, 7, 1, 2, 2, 2, 0) X(4, 2, 2, 6, 2, 2, 1, 2, 1) X(4, 2, 4, 4, 1, 2, 2, 2, 0) X(4, 2, 2, 4, 2, 2, 1, 2, 1) \
   /* 5x5 stride 2 */ \
   X(5, 2, 2, 7, 2, 2, 1, 1, 1) X(5, 2, 2, 7, 2, 1, 2, 1, 1) X(5, 2, 4, 7, 1, 2, 2, 1, 0) X(5, 2, 4, 7, 1, 1, 4, 1, 0) \
   X(5, 2, 2, 6, 2, 2, 1, 1, 1) X(5, 2, 4, 6, 1, 2, 2, 1, 0) X(5, 2, 4, 4, 1, 2, 2, 1, 0) \
@@ -379,8 +381,8 @@ FN2_API size_t fn2_conv_mfma_packed_floats(int Cout, int Cin, int kernel) {
 
 FN2_API int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int Cout, int Cin, int kernel, void* stream) {
   if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights: null blob");
-  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 5 && kernel != 7))
-    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights: needs Cout %% 64 == 0 and kernel_size 3, 5 or 7 (got Cout %d, kernel %d)", Cout, kernel);
+  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights: needs Cout %% 64 == 0 and kernel_size 3, 4, 5 or 7 (got Cout %d, kernel %d)", Cout, kernel);
   const int ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare;
   const long long total = (long long)(Cout / 64) * kalloc * 256;
   hipLaunchKernelGGL(cv::pack_weights, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), weight, packed, Cout, Cin, kernel, ksteps, kalloc);
@@ -389,7 +391,7 @@ FN2_API int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int C
 
 FN2_API int fn2_conv_mfma_supported(int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
   if (Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 64 != 0 || Win % 4 != 0) return 0;
-  if (!((kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 5 && stride == 2) || (kernel == 7 && stride == 2))) return 0;
+  if (!((kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 4 && stride == 2) || (kernel == 5 && stride == 2) || (kernel == 7 && stride == 2))) return 0;
   if (pad < 0 || pad > 4 || pad > kernel - 1) return 0;
   if ((long long)Cin * Hin * Win >= (1ll << 28)) return 0;
   const int Hout = (Hin + 2 * pad - kernel) / stride + 1, Wout = (Win + 2 * pad - kernel) / stride + 1;

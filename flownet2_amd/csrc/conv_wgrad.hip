@@ -301,7 +301,7 @@ static int pick_variant(int KS, int S, int Wa) {
   int xt = Wa <= 8 ? 8 : Wa <= 16 ? 16 : 28;
   if (KS == 3 && S == 1 && Wa >= 56 && cdiv_c(Wa, 56) * 56 <= cdiv_c(Wa, 28) * 28) xt = 56;
   if (g_forced_xt > 0 && (g_forced_xt >= 28 || g_forced_xt >= Wa)) xt = g_forced_xt;     // (chunks of several rows need whole rows)
-  const int db = g_forced_db >= 0 ? g_forced_db : 0;
+  const int db = g_forced_db >= 0 ? g_forced_db : 1;      // two buffers: measured faster on every FlowNetC layer (and the 5x5 one-buffer kernel spills)
   for (int i = 0; i < kNumVariants; ++i)
     if (kVariants[i].ks == KS && kVariants[i].s == S && kVariants[i].xt == xt && kVariants[i].db == db) return i;
   return -1;

@@ -228,6 +228,7 @@ def invalidate_weight_caches():
     _PACKED.clear()
     _PACKED_U.clear()
     _PACKED_D.clear()
+    _PACKED_T.clear()
     nets._WT_CACHE.clear()
 
 
@@ -346,7 +347,7 @@ class _OwnForwardConv(torch.autograd.Function):
         else:
             d, db = g, (g.sum((0, 2, 3)) if need_b else None)
         need_x, need_w = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
-        gx = _own_bwd_data(d, w, stride, pad, transposed) if need_x else None
+        gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
         gw = _own_bwd_weight(d, x, w, stride, pad, transposed) if need_w else None
         lib_x, lib_w = need_x and gx is None, need_w and gw is None
         if lib_x or lib_w:
@@ -375,26 +376,71 @@ def _own_bwd_weight(d, x, w, stride, pad, transposed):
     return ops.conv_wgrad(ab, bb, k, stride, pad, a_c0=a0, Ca=a.shape[1], b_c0=b0, Cb=b.shape[1])
 
 
-def _own_bwd_data(d, w, stride, pad, transposed):
-    """bottom_diff of a 3x3 / stride 1 / pad 1 convolution (ConvolutionLayer::Backward_gpu, conv_layer.cu:36-46: backward_gpu_gemm =
-    weight^T x top_diff + col2im) = the same convolution of top_diff with the weights rotated by 180 degrees and their channel axes
-    swapped: the own Winograd kernel (csrc/conv_wino.hip) on a repacked weight, the output channels padded to a multiple of 16.
-    FN2_WINO_BWD: "all" (default), "odd" (only layers whose input channel count is not a multiple of 8: conv3_1's 473) or "none" (the
-    library's data gradient).  Measured on the FlowNetC training step: 11.47 / 11.52 / 11.53 ms median -- the library already runs
-    these layers in its own Winograd kernels, so this is ownership more than speed.  Returns None when it does not apply."""
+_PACKED_T = {}     # tconv / deconv-data-gradient packings, keyed like _PACKED
+
+
+def _cached_pack(cache, w, tag, make):
+    import weakref
+    key = (id(w), tag)
+    hit = cache.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        hit = (weakref.ref(w, lambda _r, k=key: cache.pop(k, None)), w._version, make())
+        cache[key] = hit
+    return hit[2]
+
+
+def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
+    """bottom_diff on the own kernels (ConvolutionLayer::Backward_gpu, conv_layer.cu:53-57: backward_gpu_gemm = weight^T x top_diff +
+    col2im; DeconvolutionLayer::Backward_gpu, deconv_layer.cu:52-56: forward_gpu_gemm of top_diff):
+      * Convolution 3x3 / stride 1 / pad 1: the same convolution of top_diff with the weights rotated by 180 degrees and their channel
+        axes swapped -- the Winograd kernel (csrc/conv_wino.hip) on a repacked weight, output channels padded to a multiple of 16;
+      * Convolution 5x5 / 2 / 2 and 3x3 / 2 / 1: the transposed convolution of top_diff with the weight blob as it is (csrc/tconv_mfma.hip);
+      * Deconvolution 4x4 / 2 / 1: the 4x4 / 2 / 1 CONVOLUTION of top_diff with the weight blob as it is (csrc/conv_mfma.hip), output
+        channels padded to a multiple of 64.
+    FN2_OWN_DGRAD=0 hands everything back to the library; FN2_WINO_BWD: "all" (default), "odd" or "none" for the Winograd case.
+    Returns None when no own kernel applies."""
+    if os.environ.get("FN2_OWN_DGRAD", "1") == "0" or not d.is_cuda:
+        return None
     mode = os.environ.get("FN2_WINO_BWD", "all")
-    Cout, Cin, k, k2 = w.shape
-    if transposed or mode == "none" or k != 3 or k2 != 3 or stride != 1 or pad != 1 or not d.is_cuda:
+    k, k2 = w.shape[2], w.shape[3]
+    if k != k2:
+        return None
+    if transposed:
+        Cin, Cout = w.shape[0], w.shape[1]                       # the layer's bottom / top channels
+        if not (k == 4 and stride == 2 and pad == 1) or Cout % 4 != 0:
+            return None
+        Cp = (Cin + 63) // 64 * 64
+        if not ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
+            return None
+
+        def make():
+            wt = w.detach()
+            if Cp != Cin:
+                wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 4, 4))], 0)
+            return ops.conv_mfma_pack_weights(wt.contiguous())
+        gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 4, 2, 1, False, 0.0)
+        return gx[:, :Cin] if Cp != Cin else gx
+    Cout, Cin = w.shape[0], w.shape[1]
+    if stride == 2 and (k, pad) in ((5, 2), (3, 1)) and x_shape is not None and Cin % 64 == 0:
+        H, W = int(x_shape[2]), int(x_shape[3])
+        if not ops.tconv_supported(Cout, d.shape[2], d.shape[3], Cin, H, W, k, pad):
+            return None
+        pw = _cached_pack(_PACKED_T, w, "tconv", lambda: ops.tconv_pack_weights(w.detach()))
+        return ops.tconv_forward(d.contiguous(), pw, None, Cin, k, pad, out_hw=(H, W))
+    if mode == "none" or k != 3 or stride != 1 or pad != 1:
         return None
     if mode == "odd" and Cin % 8 == 0:
         return None
     Cp = (Cin + 15) // 16 * 16
     if not ops.conv_wino_supported(Cout, d.shape[2], d.shape[3], Cp, 1):
         return None
-    wt = w.detach().flip(2, 3).transpose(0, 1)                      # [Cin, Cout, 3, 3]: rot180, channel axes swapped
-    if Cp != Cin:
-        wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 3, 3))], 0)
-    gx = ops.conv_wino_forward(d.contiguous(), ops.conv_wino_pack_weights(wt.contiguous()), None, Cp, 1, False, 0.0)
+
+    def make_wino():
+        wt = w.detach().flip(2, 3).transpose(0, 1)                  # [Cin, Cout, 3, 3]: rot180, channel axes swapped
+        if Cp != Cin:
+            wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 3, 3))], 0)
+        return ops.conv_wino_pack_weights(wt.contiguous())
+    gx = ops.conv_wino_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "wino-dgrad", make_wino), None, Cp, 1, False, 0.0)
     return gx[:, :Cin] if Cp != Cin else gx
 
 

@@ -400,6 +400,44 @@ def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, neg
     return out
 
 
+def tconv_supported(Cin, Hin, Win, Cout, Hout, Wout, kernel, pad) -> bool:
+    return bool(_lib.lib().fn2_tconv_supported(int(Cin), int(Hin), int(Win), int(Cout), int(Hout), int(Wout), int(kernel), int(pad)))
+
+
+def tconv_pack_weights(weight):
+    """weight [Cin, Cout, k, k] (Caffe's Deconvolution blob; for a data gradient the Convolution's own [Cout_conv, Cin_conv, k, k] blob)
+    -> the MFMA operand order fn2_tconv_forward reads: fn2_conv_mfma_pack_weights of the [Cout][Cin][k][k] view."""
+    return conv_mfma_pack_weights(weight.transpose(0, 1).contiguous())
+
+
+def tconv_forward(x, packed_weight, bias, Cout, kernel, pad, out_hw=None, relu=False, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """Transposed convolution, stride 2 (csrc/tconv_mfma.hip): the Deconvolution forward (+ bias + ReLU) or a stride-2 Convolution's
+    data gradient.  out_hw: output size (default 2 (H - 1) + kernel - 2 pad)."""
+    x = _chk(x, "bottom[0]")
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    Ho, Wo = out_hw if out_hw is not None else (2 * (H - 1) + kernel - 2 * pad, 2 * (W - 1) + kernel - 2 * pad)
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
+    else:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (Ho, Wo):
+            raise ValueError(f"tconv: top blob {tuple(out.shape)} does not match [{N},*,{Ho},{Wo}]")
+    b = _chk(bias, "bias", ndim=1) if bias is not None else None
+    pw = _chk(packed_weight, "packed weight", ndim=1)
+    check(_lib.lib().fn2_tconv_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, Ho, Wo, out.shape[1], out_c0,
+                                       int(kernel), int(pad), int(bool(relu)), C.c_float(float(negative_slope)), _stream()))
+    return out
+
+
+def set_tconv_variant(v: int):
+    check(_lib.lib().fn2_debug_set_tconv_variant(int(v)))
+
+
+def tconv_num_variants() -> int:
+    return int(_lib.lib().fn2_tconv_num_variants())
+
+
 def conv_wgrad_supported(N, Ca, Ha, Wa, Cb, Hb, Wb, kernel, stride, pad) -> bool:
     return bool(_lib.lib().fn2_conv_wgrad_supported(int(N), int(Ca), int(Ha), int(Wa), int(Cb), int(Hb), int(Wb), int(kernel), int(stride), int(pad)))
 

@@ -355,6 +355,24 @@ int fn2_deconv_plane_forward(const float* bottom, const float* packed_weight, co
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Transposed convolution, stride 2 (fp32 MFMA, NCHW, no column matrix / col2im):
+ *     top[n][top_c0 + co][Y][X] = act(bias[co] + sum_{ci,ky,kx: Y = 2y - pad + ky, X = 2x - pad + kx} bottom[n][bottom_c0 + ci][y][x] * W[ci][co][ky][kx])
+ *   <- DeconvolutionLayer::Forward_gpu, src/caffe/layers/deconv_layer.cu:8-26 (backward_gpu_gemm + col2im_gpu, base_conv_layer.cpp:375-393,
+ *      forward_gpu_bias) with weight blob [Cin, Cout, 4, 4], kernel 4 / pad 1, Hout = 2 Hin, + the in-place ReLU (relu_layer.cu:8-27);
+ *   <- ConvolutionLayer::Backward_gpu's data gradient (conv_layer.cu:53-57 -> backward_gpu_gemm, base_conv_layer.cpp:352-366) of a
+ *      stride-2 Convolution: bottom = top_diff, W = the layer's weight [Cout_conv, Cin_conv, k, k] (already [in][out][k][k]), top =
+ *      bottom_diff of size Hout x Wout (the layer's input size), kernel / pad 5 / 2 or 3 / 1, bias NULL, relu 0.
+ *   packed_weight = fn2_conv_mfma_pack_weights of the [Cout][Cin][k][k] VIEW of W (its first two axes swapped), Cout % 64 == 0,
+ *   Win % 4 == 0.  Same bits from every tile variant (fn2_debug_set_tconv_variant).  No workspace. */
+int fn2_tconv_supported(int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int kernel, int pad);
+int fn2_tconv_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                      int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                      int Cout, int Hout, int Wout, int top_channels, int top_c0, int kernel, int pad,
+                      int relu, float negative_slope, void* stream);
+int fn2_tconv_num_variants(void);
+int fn2_debug_set_tconv_variant(int variant);
+
+/* ------------------------------------------------------------------------------------------------
  * Weight gradient of a Convolution or Deconvolution layer (fp32 MFMA, NCHW, deterministic):
  *     dw[ca][cb][ky][kx] (+)= sum_{n,y,x} a[n][a_c0 + ca][y][x] * b[n][b_c0 + cb][stride*y + ky - pad][stride*x + kx - pad]   (0 outside b)
  *   <- ConvolutionLayer::Backward_gpu, src/caffe/layers/conv_layer.cu:40-52 (weight_gpu_gemm, base_conv_layer.cpp:368-384: per sample

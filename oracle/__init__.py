@@ -292,6 +292,22 @@ def conv_plane_forward(x, packed, bias, Cout, stride, pad, ksplit, relu=True, ne
     return out
 
 
+def tconv_forward(x, weight, bias, kernel, pad, out_hw=None, relu=False, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
+    """CPU twin of fn2_tconv_forward; weight: the unpacked [Cin, Cout, k, k] blob."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(weight, np.float32)
+    N, Ctot, H, W = x.shape
+    Cin = Ctot - in_c0 if Cin is None else Cin
+    Cout = w.shape[1]
+    Ho, Wo = out_hw if out_hw is not None else (2 * (H - 1) + kernel - 2 * pad, 2 * (W - 1) + kernel - 2 * pad)
+    if out is None:
+        out = np.zeros((N, Cout, Ho, Wo), np.float32)
+    bias = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    _check(lib().fn2_tconv_forward_cpu(_p(x), _p(w), _p(bias), _p(out), N, Cin, H, W, Ctot, in_c0, Cout, Ho, Wo, out.shape[1], out_c0,
+                                       int(kernel), int(pad), int(bool(relu)), C.c_float(negative_slope)), "tconv_forward")
+    return out
+
+
 def conv_wgrad(a, b, kernel, stride, pad, ksplit, out=None, accumulate=False, a_c0=0, Ca=None, b_c0=0, Cb=None):
     """CPU twin of fn2_conv_wgrad: dw[ca][cb][ky][kx] (+)= sum a[n, a_c0+ca, y, x] * b[n, b_c0+cb, stride y + ky - pad, stride x + kx - pad];
     ksplit = fn2_conv_wgrad_ksplit() (it fixes the summation order)."""

@@ -966,7 +966,7 @@ FN2_API size_t fn2_conv_mfma_packed_floats_cpu(int Cout, int Cin, int kernel) {
 }
 
 FN2_API int fn2_conv_mfma_pack_weights_cpu(const float* weight, float* packed, int Cout, int Cin, int kernel) {
-  if (!weight || !packed || Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 5 && kernel != 7)) return FN2_ERR_INVALID_ARG;
+  if (!weight || !packed || Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7)) return FN2_ERR_INVALID_ARG;
   const int ksteps = conv_mfma_ksteps(Cin, kernel), kalloc = ksteps + 8, kk = kernel * kernel;
   for (int g = 0; g < Cout / 64; ++g)
     for (int ks = 0; ks < kalloc; ++ks)
@@ -1058,6 +1058,44 @@ FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed,
           top[(((size_t)n * top_channels + top_c0 + co) * Ho + y) * Wo + x] = t;
         }
     }
+  return FN2_OK;
+}
+
+/* Transposed convolution, stride 2 (+ bias + optional ReLU): the CPU twin of csrc/tconv_mfma.hip.
+ * Reference arithmetic: DeconvolutionLayer::Forward_cpu (deconv_layer.cpp:8-26: weight^T x bottom, col2im, bias) / the data gradient of
+ * ConvolutionLayer::Backward_cpu (conv_layer.cpp:57-62 -> backward_cpu_gemm, base_conv_layer.cpp:305-317):
+ *     top[n][co][Y][X] = act(bias[co] + sum_{ci,ky,kx: Y = 2y - pad + ky, X = 2x - pad + kx} bottom[n][ci][y][x] W[ci][co][ky][kx]).
+ * Summation order of the HIP kernel per output element: channel quads ascending; within a quad the taps ky (== Y + pad mod 2) and kx
+ * (== X + pad mod 2) ascending; within a tap the 4 channels of the quad, with fmaf.  weight is the UNPACKED blob [Cin][Cout][k][k]. */
+FN2_API int fn2_tconv_forward_cpu(const float* bottom, const float* weight, const float* bias, float* top,
+                                  int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                  int Cout, int Hout, int Wout, int top_channels, int top_c0, int kernel, int pad,
+                                  int relu, float negative_slope) {
+  if (!bottom || !weight || !top || N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Hout < 1 || Wout < 1 || kernel < 1 || pad < 0) return FN2_ERR_INVALID_ARG;
+  if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
+  const int quads = (Cin + 3) / 4;
+#pragma omp parallel for collapse(2)
+  for (int n = 0; n < N; ++n)
+    for (int co = 0; co < Cout; ++co)
+      for (int Y = 0; Y < Hout; ++Y)
+        for (int X = 0; X < Wout; ++X) {
+          float acc = 0.f;
+          for (int cq = 0; cq < quads; ++cq)
+            for (int ky = (Y + pad) & 1; ky < kernel; ky += 2)
+              for (int kx = (X + pad) & 1; kx < kernel; kx += 2) {
+                const int y2 = Y + pad - ky, x2 = X + pad - kx;          /* = 2 y, 2 x (even by construction) */
+                if (y2 < 0 || x2 < 0 || (y2 >> 1) >= Hin || (x2 >> 1) >= Win) continue;
+                for (int kq = 0; kq < 4; ++kq) {
+                  const int ci = 4 * cq + kq;
+                  if (ci >= Cin) break;
+                  acc = fmaf(bottom[(((size_t)n * bottom_channels + bottom_c0 + ci) * Hin + (y2 >> 1)) * Win + (x2 >> 1)],
+                             weight[(((size_t)ci * Cout + co) * kernel + ky) * kernel + kx], acc);
+                }
+              }
+          float t = acc + (bias ? bias[co] : 0.f);
+          if (relu) t = t > 0.f ? t : t * negative_slope;
+          top[(((size_t)n * top_channels + top_c0 + co) * Hout + Y) * Wout + X] = t;
+        }
   return FN2_OK;
 }
 

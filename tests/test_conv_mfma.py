@@ -13,7 +13,8 @@ import oracle
 
 CASES = [  # N, Cin, H, W, Cout, k, s, p
     (2, 8, 12, 16, 64, 3, 1, 1), (1, 13, 9, 20, 64, 3, 1, 1), (2, 5, 11, 12, 128, 3, 2, 1), (1, 16, 16, 24, 64, 5, 2, 2),
-    (1, 7, 13, 28, 128, 5, 2, 2), (1, 4, 8, 8, 64, 3, 1, 0), (1, 9, 10, 12, 64, 3, 2, 0), (1, 12, 20, 32, 64, 7, 2, 3), (2, 5, 18, 24, 64, 7, 2, 3)]
+    (1, 7, 13, 28, 128, 5, 2, 2), (1, 4, 8, 8, 64, 3, 1, 0), (1, 9, 10, 12, 64, 3, 2, 0), (1, 12, 20, 32, 64, 7, 2, 3), (2, 5, 18, 24, 64, 7, 2, 3),
+    (2, 10, 12, 16, 64, 4, 2, 1), (1, 64, 10, 28, 128, 4, 2, 1)]     # 4x4 / 2 / 1: the Deconvolution layers' data gradient
 
 
 def rnd(shape, seed, scale=1.0):
