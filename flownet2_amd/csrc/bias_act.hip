@@ -120,3 +120,36 @@ FN2_API int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, i
   }
   return check_launch("bias_leaky_relu_forward");
 }
+
+// ---- deploy head: top[n, top_c0 + c] = bottom[n, c] * scale + shift[c], TWO roundings (product, then sum: no fma contraction) -- the
+// bits of Eltwise{coeff: 1/255} (eltwise_layer.cu:46-52: 0 + coeff * x) followed by the mean subtraction of the deploy-time
+// DataAugmentation layer (data_augmentation_layer.cu:592-621: x - mean[c]) when the Resample between them is the identity, in one pass,
+// written into a channel slice of the blob the first convolution reads (FlowNetS: [img0 | img1] along the channel axis).
+namespace fn2 {
+__global__ void __launch_bounds__(256) scale_shift(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ shift,
+                                                   int C, unsigned hw, int out_ctot, int out_c0, float scale) {
+  const unsigned plane = blockIdx.y;                       // n * C + c
+  const unsigned n = plane / (unsigned)C, c = plane % (unsigned)C;
+  const float sh = shift ? shift[c] : 0.f;
+  const float* p = in + (size_t)plane * hw;
+  float* q = out + ((size_t)n * out_ctot + out_c0 + c) * hw;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+    float prod = p[i] * scale;
+    asm volatile("" : "+v"(prod));       // the product is rounded on its own: hipcc contracts a * b + c into an fma otherwise (also through __fmul_rn)
+    q[i] = prod + sh;
+  }
+}
+}  // namespace fn2
+
+FN2_API int fn2_scale_shift_forward(const float* bottom, float* top, const float* shift, int N, int C, int H, int W,
+                                    int top_channels, int top_c0, float scale, void* stream) {
+  if (N < 0 || C < 1 || H < 1 || W < 1) return fn2::fail(FN2_ERR_INVALID_ARG, "scale_shift: bad shape [%d,%d,%d,%d]", N, C, H, W);
+  if (top_c0 < 0 || top_c0 + C > top_channels) return fn2::fail(FN2_ERR_INVALID_ARG, "scale_shift: channel slice outside the blob");
+  if (N == 0) return FN2_OK;
+  if (!bottom || !top) return fn2::fail(FN2_ERR_INVALID_ARG, "scale_shift: NULL blob pointer");
+  if ((long long)N * C > 65535) return fn2::fail(FN2_ERR_UNSUPPORTED, "scale_shift: too many planes");
+  const unsigned hw = (unsigned)H * (unsigned)W;
+  hipLaunchKernelGGL(fn2::scale_shift, dim3(fn2::blocks_for(hw, 256, 64), (unsigned)(N * C)), dim3(256), 0, fn2::as_stream(stream), bottom, top, shift,
+                     C, hw, top_channels, top_c0, scale);
+  return fn2::check_launch("scale_shift_forward");
+}

@@ -56,6 +56,12 @@ def lib_conv_transpose2d(x, w, b, stride, pad):
     return torch.cat([torch.nn.functional.conv_transpose2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
 
 
+def scale_shift(x, scale, shift=None, out=None, out_c0=0):
+    """Deploy head in one pass (no autograd): out[:, out_c0:out_c0+C] = x * scale + shift[c], product and sum rounded separately."""
+    with torch.no_grad():
+        return ops.scale_shift_forward(x.detach().contiguous(), scale, shift, out=out, out_c0=out_c0)
+
+
 class _Correlation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, b0, b1, params):

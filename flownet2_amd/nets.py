@@ -88,35 +88,43 @@ _LAST_ROUTE = [""]
 
 
 def _conv_routed(x, P, name, stride, pad, act, backend):
-    w = P[name + ".w"]
+    return conv_forward(x, P[name + ".w"], P[name + ".b"], stride, pad, act, backend)
+
+
+def conv_forward(x, w, b, stride, pad, act, backend, slope=None):
+    """Convolution{w, stride, pad} + bias (+ ReLU{NEG_SLOPE} when act) on explicit tensors: the routing every graph of this file and the
+    Convolution layer of the prototxt executor (flownet2_amd.layers.ConvolutionLayer) share -- same kernels, same bits."""
+    P = {"x.w": w, "x.b": b}
+    name = "x"
+    slope = NEG_SLOPE if slope is None else slope
     _LAST_ROUTE[0] = "library conv2d"
     if w.shape[2] == 7 and w.shape[1] % 4 == 0 and backend is not None and hasattr(backend, "conv_mfma_relu"):
         # the 12-channel stems of FlowNet2's stacked nets are whole channel quads: the direct MFMA kernel does them in one pass
         # (the register-resident stem kernel needs two passes with partial sums through memory)
-        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, slope, act)
         if y is not None:
             _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
     if act and stride == 2 and pad == 3 and w.shape[2] == 7 and backend is not None and hasattr(backend, "conv_k7s2_relu"):
-        y = backend.conv_k7s2_relu(x, w, P[name + ".b"], NEG_SLOPE)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
+        y = backend.conv_k7s2_relu(x, w, P[name + ".b"], slope)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
         if y is not None:
             _LAST_ROUTE[0] = "stem kernel"
             return y
     if w.shape[2] in (3, 5) and backend is not None and hasattr(backend, "conv_mfma_relu"):
-        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)    # Winograd / direct MFMA convolution, bias + ReLU fused
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, slope, act)    # Winograd / direct MFMA convolution, bias + ReLU fused
         if y is not None:
             _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
     if w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
-        y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, act)
+        y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, slope, act)
         if y is not None:
             _LAST_ROUTE[0] = "im2col + library GEMM"
             return y
     conv2d = getattr(backend, "lib_conv2d", None) or (lambda xx, ww, bb, s, p: F.conv2d(xx, ww, bb, stride=s, padding=p))
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
-        return backend.conv_bias_leaky_relu(conv2d(x, w, None, stride, pad), P[name + ".b"], NEG_SLOPE)
+        return backend.conv_bias_leaky_relu(conv2d(x, w, None, stride, pad), P[name + ".b"], slope)
     y = conv2d(x, w, P[name + ".b"], stride, pad)
-    return F.leaky_relu(y, NEG_SLOPE) if act else y
+    return F.leaky_relu(y, slope) if act else y
 
 
 _CONSTS: Dict[tuple, torch.Tensor] = {}
@@ -163,22 +171,29 @@ _BATCH_INVARIANT_ROUTES = [False]
 
 
 def _deconv(x, P, name, act=True, backend=None):
-    w = P[name + ".w"]
+    return deconv_forward(x, P[name + ".w"], P[name + ".b"], act, backend)
+
+
+def deconv_forward(x, w, b, act=True, backend=None, slope=None):
+    """Deconvolution{4, 2, 1} + bias (+ ReLU): the routing shared with flownet2_amd.layers.DeconvolutionLayer."""
+    P = {"x.w": w, "x.b": b}
+    name = "x"
+    slope = NEG_SLOPE if slope is None else slope
     if act and backend is not None and hasattr(backend, "deconv_mfma_relu") and w.shape[0] >= 64:
-        y = backend.deconv_mfma_relu(x, w, P[name + ".b"], NEG_SLOPE, True)      # one MFMA kernel, a parity class per wave (csrc/conv_plane.hip)
+        y = backend.deconv_mfma_relu(x, w, P[name + ".b"], slope, True)      # one MFMA kernel, a parity class per wave (csrc/conv_plane.hip)
         if y is not None:
             return y
     if act and backend is not None and hasattr(backend, "deconv_gemm_relu") and w.shape[0] >= 64:
         training = torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)
-        y = backend.deconv_gemm_relu(x, None if training else _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, NEG_SLOPE,
+        y = backend.deconv_gemm_relu(x, None if training else _transposed_deconv_weight(w), P[name + ".b"], w.shape[1], 4, 2, 1, slope,
                                      weight=w)
         if y is not None:
             return y
     deconv2d = getattr(backend, "lib_conv_transpose2d", None) or (lambda xx, ww, bb, s, p: F.conv_transpose2d(xx, ww, bb, stride=s, padding=p))
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
-        return backend.conv_bias_leaky_relu(deconv2d(x, P[name + ".w"], None, 2, 1), P[name + ".b"], NEG_SLOPE)
+        return backend.conv_bias_leaky_relu(deconv2d(x, P[name + ".w"], None, 2, 1), P[name + ".b"], slope)
     y = deconv2d(x, P[name + ".w"], P[name + ".b"], 2, 1)
-    return F.leaky_relu(y, NEG_SLOPE) if act else y
+    return F.leaky_relu(y, slope) if act else y
 
 
 def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
@@ -334,22 +349,23 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
     """
     N, _, H, W = img0.shape
     ah, aw = adapted_size(H, W)
+    neg_default = mean is None
     if mean is None:
         mean = _const(img0.device, (0.411, 0.433, 0.45))   # BGR order of a typical RGB mean
-    if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled():
-        # At the ADAPTED size the LINEAR Resample is the identity (one tap of weight 1), so the head is x / 255 - mean per image:
-        # one pass per image, written straight into the blob the towers (C: batch axis) or conv1 (S: channel axis) read --
-        # instead of scale, subtract and concat as three passes.
-        neg_mean = -mean.view(1, 3, 1, 1)
+    if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "scale_shift"):
+        # At the ADAPTED size the LINEAR Resample is the identity (one tap of weight 1), so the head is x * (1 / 255) - mean per image:
+        # one pass per image (product and difference rounded separately: the bits of the Eltwise and mean-subtraction layers), written
+        # straight into the blob the towers (C: batch axis) or conv1 (S: channel axis) read -- instead of scale, subtract and concat.
+        neg_mean = _const(img0.device, (-0.411, -0.433, -0.45)) if neg_default else (-mean).contiguous()
         if kind == "C":
             x = torch.empty((2 * N, 3, H, W), device=img0.device, dtype=torch.float32)
-            torch.add(neg_mean, img0, alpha=1.0 / 255.0, out=x[:N])
-            torch.add(neg_mean, img1, alpha=1.0 / 255.0, out=x[N:])
+            backend.scale_shift(img0, 1.0 / 255.0, neg_mean, out=x[:N])
+            backend.scale_shift(img1, 1.0 / 255.0, neg_mean, out=x[N:])
             flows = flownet_c_core(P, None, None, backend, towers=x)
         else:
             x = torch.empty((N, 6, H, W), device=img0.device, dtype=torch.float32)
-            torch.add(neg_mean, img0, alpha=1.0 / 255.0, out=x[:, :3])
-            torch.add(neg_mean, img1, alpha=1.0 / 255.0, out=x[:, 3:])
+            backend.scale_shift(img0, 1.0 / 255.0, neg_mean, out=x, out_c0=0)
+            backend.scale_shift(img1, 1.0 / 255.0, neg_mean, out=x, out_c0=3)
             flows = flownet_s_core(P, x, backend)
     else:
         pre = []
@@ -528,12 +544,13 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     + six Resample calls per forward."""
     N, _, H, W = img0.shape
     ah, aw = adapted_size(H, W)
+    neg_mean = _const(img0.device, (-0.411, -0.433, -0.45)) if mean is None else (-mean).contiguous()
     if mean is None:
         mean = _const(img0.device, (0.411, 0.433, 0.45))
-    if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled():
-        # LINEAR Resample at equal size is the identity: scale and mean in one pass per image
-        a = torch.add(-mean.view(1, 3, 1, 1), img0, alpha=1.0 / 255.0)
-        b = torch.add(-mean.view(1, 3, 1, 1), img1, alpha=1.0 / 255.0)
+    if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "scale_shift"):
+        # LINEAR Resample at equal size is the identity: scale and mean in one pass per image (two roundings, like the two layers)
+        a = backend.scale_shift(img0, 1.0 / 255.0, neg_mean)
+        b = backend.scale_shift(img1, 1.0 / 255.0, neg_mean)
     else:
         a = backend.resample(img0 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)
         b = backend.resample(img1 * (1.0 / 255.0), ah, aw) - mean.view(1, 3, 1, 1)

@@ -255,6 +255,22 @@ def bias_leaky_relu_(x, bias=None, negative_slope=0.1):
     return x
 
 
+def scale_shift_forward(x, scale, shift=None, out=None, out_c0=0):
+    """out[:, out_c0 : out_c0 + C] = x * scale + shift[c] with the product and the sum rounded separately (csrc/bias_act.hip): the deploy
+    head's Eltwise{1/255} + mean subtraction in one pass, written into a channel slice of `out` [N, *, H, W] (a new blob if None)."""
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _chk(out, "top[0]")
+        if out.shape[0] != N or tuple(out.shape[2:]) != (H, W):
+            raise ValueError("scale_shift: top blob does not match the bottom")
+    s = _chk(shift, "shift", ndim=1) if shift is not None else None
+    check(_lib.lib().fn2_scale_shift_forward(_ptr(x), _ptr(out), _ptr(s), N, Cc, H, W, out.shape[1], out_c0, C.c_float(float(scale)), _stream()))
+    return out
+
+
 def conv_k7s2_relu_supported(Cin, Hin, Win, Cout) -> bool:
     return bool(_lib.lib().fn2_conv_k7s2_relu_supported(int(Cin), int(Hin), int(Win), int(Cout)))
 

@@ -1,0 +1,337 @@
+"""Mirrors of the STOCK Caffe layers a FlowNet2 prototxt contains, on the fast paths of this repository: the prototxt executor
+(flownet2_amd.net.Net) creates them by `type:` string through the same LayerRegistry as the custom layers (layer_factory.hpp:75-84).
+
+    Convolution    conv_layer.cpp:8-40, base_conv_layer.cpp:15-254 (LayerSetUp / Reshape), conv_layer.cu:8-23
+    Deconvolution  deconv_layer.cpp:8-45 (weight blob [Cin, Cout/g, kh, kw], base_conv_layer.cpp:125-139), deconv_layer.cu:8-26
+    ReLU           relu_layer.cu:8-27 (negative_slope), in place
+    Eltwise        eltwise_layer.cpp:12-65, eltwise_layer.cu:34-66 (SUM with coeff, PROD, MAX; ONE bottom allowed: eltwise_layer.hpp:29)
+    Concat / Slice concat_layer.cpp:24-65 / slice_layer.cpp:24-88
+    Silence, Input silence_layer.cu, input_layer.cpp
+
+Forward only where the training graph of this repository does not go through these classes (nets.py + autograd train; the executor
+is the deploy path of scripts/run-flownet.py).  Convolution / Deconvolution call the SAME routing functions as nets.py
+(nets.conv_forward / deconv_forward and the flow-head kernels), so a prototxt-built net computes the same bits as nets.deploy_forward.
+A ReLU that directly follows a Convolution / Deconvolution in place is folded into that layer by the executor (`fused_relu_`): one
+kernel, as in nets.py.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from . import layers as L
+from .layers import Blob, CHECK, CheckError, Layer
+
+
+def _first(v, default):
+    if v is None:
+        return default
+    if isinstance(v, list):
+        return v[0] if v else default
+    return v
+
+
+def fill_blob(blob: Blob, filler: dict, seed_name: str = ""):
+    """include/caffe/filler.hpp: constant (:25-43), diagonal (:264-290: blob[n][n][:, :] = diag_val[n] / kernel_area, else 0).  The random
+    fillers (msra, xavier, gaussian, uniform) exist to be overwritten by CopyTrainedLayersFrom in a deploy net: they draw from a
+    torch generator seeded by the layer name (boost's stream is not reproducible)."""
+    t = str(filler.get("type", "constant"))
+    shape = blob.shape()
+    if t == "constant":
+        blob.data = torch.full(shape, float(filler.get("value", 0.0)), dtype=torch.float32, device=blob.device)
+    elif t == "diagonal":
+        num, ch = shape[0], shape[1] if len(shape) > 1 else 1
+        area = 1
+        for s in shape[2:]:
+            area *= s
+        w = torch.zeros(shape, dtype=torch.float32)
+        dv = list(filler.get("diag_val", []))
+        for n in range(min(num, ch)):
+            w[n, n] = (float(dv[n]) if n < len(dv) else 1.0) / float(area)
+        blob.data = w.to(blob.device)
+    elif t in ("msra", "xavier", "gaussian", "uniform", "positive_unitball", "bilinear"):
+        import zlib
+        g = torch.Generator().manual_seed(zlib.crc32(seed_name.encode()) & 0x7fffffff)
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        std = float(filler.get("std", 0.0)) if t == "gaussian" else (2.0 / max(1, fan_in)) ** 0.5
+        blob.data = (torch.randn(shape, generator=g) * std).to(blob.device)
+    else:
+        raise CheckError("Unknown filler name: " + t)                                   # filler.hpp:319
+
+
+class _ConvBase(Layer):
+    """BaseConvolutionLayer::LayerSetUp / Reshape (base_conv_layer.cpp:15-254): square or h / w kernels, pad, stride; group 1 and
+    dilation 1 only (all a FlowNet uses)."""
+    transposed = False
+
+    def MinBottomBlobs(self): return 1
+    def MinTopBlobs(self): return 1
+
+    def _geom(self):
+        cp = self.layer_param_.convolution_param
+        CHECK("num_output" in cp, "num_output is required")
+        kh = int(cp["kernel_h"]) if "kernel_h" in cp else int(_first(cp.get("kernel_size"), 0))
+        kw = int(cp["kernel_w"]) if "kernel_w" in cp else int(_first(cp.get("kernel_size"), 0))
+        CHECK(kh > 0 and kw > 0, "Filter dimensions cannot be zero.")                    # base_conv_layer.cpp:45
+        ph = int(cp["pad_h"]) if "pad_h" in cp else int(_first(cp.get("pad"), 0))
+        pw = int(cp["pad_w"]) if "pad_w" in cp else int(_first(cp.get("pad"), 0))
+        sh = int(cp["stride_h"]) if "stride_h" in cp else int(_first(cp.get("stride"), 1))
+        sw = int(cp["stride_w"]) if "stride_w" in cp else int(_first(cp.get("stride"), 1))
+        CHECK(int(cp.get("group", 1)) == 1, "group > 1 is not supported by this mirror")
+        CHECK(int(_first(cp.get("dilation"), 1)) == 1, "dilation > 1 is not supported by this mirror")
+        CHECK(kh == kw and ph == pw and sh == sw, "only square kernels / pads / strides are supported by this mirror")
+        return int(cp["num_output"]), kh, ph, sh, bool(cp.get("bias_term", True))
+
+    def LayerSetUp(self, bottom, top):
+        self.num_output_, self.kernel_, self.pad_, self.stride_, self.bias_term_ = self._geom()
+        self.fused_relu_ = None                 # negative slope of an in-place ReLU folded in by the executor
+        cin = bottom[0].channels()
+        cp = self.layer_param_.convolution_param
+        if not self.blobs_:                                                               # base_conv_layer.cpp:125-152
+            wshape = [cin, self.num_output_, self.kernel_, self.kernel_] if self.transposed else [self.num_output_, cin, self.kernel_, self.kernel_]
+            w = Blob(*wshape, device=bottom[0].device)
+            fill_blob(w, cp.get("weight_filler", {}), self.layer_param_.name + ".w")
+            self.blobs_ = [w]
+            if self.bias_term_:
+                b = Blob(self.num_output_, device=bottom[0].device)
+                fill_blob(b, cp.get("bias_filler", {}), self.layer_param_.name + ".b")
+                self.blobs_.append(b)
+
+    def _out_hw(self, h, w):
+        k, p, s = self.kernel_, self.pad_, self.stride_
+        if self.transposed:
+            return s * (h - 1) + k - 2 * p, s * (w - 1) + k - 2 * p                       # deconv_layer.cpp:8-22
+        return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1                        # conv_layer.cpp:8-23
+
+    def Reshape(self, bottom, top):
+        cin = self.blobs_[0].shape(0) if self.transposed else self.blobs_[0].shape(1)
+        for b, t in zip(bottom, top):
+            CHECK(b.channels() == cin, "Input size incompatible with convolution kernel.")  # base_conv_layer.cpp:196
+            ho, wo = self._out_hw(b.height(), b.width())
+            t.Reshape(b.num(), self.num_output_, ho, wo)
+
+    def _backend(self):
+        if self.backend_ is not None:
+            return self.backend_
+        from . import functional
+        return functional
+
+
+class ConvolutionLayer(_ConvBase):
+    def type(self): return "Convolution"
+
+    def Forward_gpu(self, bottom, top):
+        from . import nets
+        be = self._backend()
+        w, b = self.blobs_[0].data, (self.blobs_[1].data if self.bias_term_ else None)
+        k, s, p = self.kernel_, self.stride_, self.pad_
+        for bt, tp in zip(bottom, top):
+            x = bt.data
+            if k == 1 and s == 1 and p == 0 and self.fused_relu_ is None and b is not None and getattr(self, "diagonal_", None) is not None:
+                # the deploy tail's SCALE convolution (weight_filler diagonal, run-flownet.py:47-48): y[c] = diag[c] x[c] + 0 x[other]
+                tp.data = x * self.diagonal_.view(1, -1, 1, 1) + b.view(1, -1, 1, 1) if bool((b != 0).any()) else x * self.diagonal_.view(1, -1, 1, 1)
+            elif k == 3 and s == 1 and p == 1 and self.num_output_ == 2 and self.fused_relu_ is None and hasattr(be, "predict_flow_conv"):
+                tp.data = be.predict_flow_conv(x, w, b)                                   # the predict_flow heads (csrc/flow_head.hip)
+            else:
+                y = nets.conv_forward(x, w, b if b is not None else torch.zeros(self.num_output_, device=x.device), s, p,
+                                      self.fused_relu_ is not None, be, slope=self.fused_relu_)
+                tp.data = y
+
+    def note_weights_changed(self):
+        """After the weights were (re)loaded: a 1x1 weight that is diagonal is applied as a per-channel scale (exactly what the zero
+        off-diagonal products add up to for finite inputs)."""
+        self.diagonal_ = None
+        w = self.blobs_[0].data
+        if self.kernel_ == 1 and w.shape[0] == w.shape[1]:
+            m = w.view(w.shape[0], w.shape[1])
+            d = torch.diagonal(m)
+            if bool((m - torch.diag(d) == 0).all()):
+                self.diagonal_ = d.contiguous()
+
+
+class DeconvolutionLayer(_ConvBase):
+    transposed = True
+
+    def type(self): return "Deconvolution"
+
+    def Forward_gpu(self, bottom, top):
+        from . import nets
+        be = self._backend()
+        w, b = self.blobs_[0].data, (self.blobs_[1].data if self.bias_term_ else None)
+        k, s, p = self.kernel_, self.stride_, self.pad_
+        for bt, tp in zip(bottom, top):
+            x = bt.data
+            if (k, s, p) == (4, 2, 1) and w.shape[0] == 2 and w.shape[1] == 2 and self.fused_relu_ is None and hasattr(be, "upsample_flow_deconv"):
+                tp.data = be.upsample_flow_deconv(x, w, b)                                # the upsample_flow heads (csrc/flow_head.hip)
+            elif (k, s, p) == (4, 2, 1):
+                bb = b if b is not None else torch.zeros(self.num_output_, device=x.device)
+                tp.data = nets.deconv_forward(x, w, bb, self.fused_relu_ is not None, be, slope=self.fused_relu_)
+            else:
+                y = torch.nn.functional.conv_transpose2d(x, w, b, stride=s, padding=p)
+                tp.data = torch.nn.functional.leaky_relu(y, self.fused_relu_) if self.fused_relu_ is not None else y
+
+    def note_weights_changed(self):
+        pass
+
+
+class ReLULayer(Layer):
+    def type(self): return "ReLU"
+    def ExactNumBottomBlobs(self): return 1
+    def ExactNumTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        self.negative_slope_ = float(self.layer_param_.relu_param.get("negative_slope", 0.0))
+        self.folded_ = False                    # True: the producing Convolution / Deconvolution applies it (executor peephole)
+
+    def Reshape(self, bottom, top):
+        top[0].ReshapeLike(bottom[0])
+
+    def Forward_gpu(self, bottom, top):
+        if self.folded_:
+            if top[0] is not bottom[0]:
+                top[0].data = bottom[0].data
+            return
+        x = bottom[0].data
+        be = self.backend_
+        if x.is_cuda and x.is_contiguous() and (be is None or hasattr(be, "conv_bias_leaky_relu")):
+            from . import ops
+            y = x if top[0] is bottom[0] else x.clone()
+            top[0].data = ops.bias_leaky_relu_(y, None, self.negative_slope_)             # csrc/bias_act.hip, in place
+        else:
+            top[0].data = torch.nn.functional.leaky_relu(x, self.negative_slope_)
+
+
+class EltwiseLayer(Layer):
+    def type(self): return "Eltwise"
+    def MinBottomBlobs(self): return 1                                                   # eltwise_layer.hpp:29 (this fork)
+    def ExactNumTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        ep = self.layer_param_.eltwise_param
+        coeff = list(ep.get("coeff", []))
+        CHECK(len(coeff) == 0 or len(coeff) == len(bottom), "Eltwise Layer takes one coefficient per bottom blob.")   # cpp:12-14
+        self.op_ = str(ep.get("operation", "SUM"))
+        CHECK(not (self.op_ == "PROD" and coeff), "Eltwise layer only takes coefficients for summation.")             # cpp:15-17
+        self.coeffs_ = [float(c) for c in coeff] if coeff else [1.0] * len(bottom)
+
+    def Reshape(self, bottom, top):
+        for b in bottom[1:]:
+            CHECK(b.shape() == bottom[0].shape(), "bottom shapes differ")                 # cpp:29-31
+        top[0].ReshapeLike(bottom[0])
+
+    def Forward_gpu(self, bottom, top):
+        xs = [b.data for b in bottom]
+        if self.op_ == "PROD":
+            y = xs[0] * xs[1] if len(xs) > 1 else xs[0].clone()
+            for x in xs[2:]:
+                y = y * x
+        elif self.op_ == "MAX":
+            y = xs[0].clone()
+            for x in xs[1:]:
+                y = torch.maximum(y, x)
+        else:
+            # eltwise_layer.cu:46-52: top = 0; top = coeff_i * bottom_i + top for every i.  0 + c x == c x, 1 a + (-1) b == a - b exactly
+            c = self.coeffs_
+            if len(xs) == 1:
+                y = xs[0] * c[0]
+            elif len(xs) == 2 and c == [1.0, -1.0]:
+                y = xs[0] - xs[1]
+            elif len(xs) == 2 and c == [1.0, 1.0]:
+                y = xs[0] + xs[1]
+            else:
+                y = xs[0] * c[0]
+                for x, ci in zip(xs[1:], c[1:]):
+                    y = torch.add(y, x, alpha=ci)
+        top[0].data = y
+
+
+class ConcatLayer(Layer):
+    def type(self): return "Concat"
+    def MinBottomBlobs(self): return 1
+    def ExactNumTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        cp = self.layer_param_.concat_param
+        CHECK(not ("axis" in cp and "concat_dim" in cp), "Either axis or concat_dim should be specified; not both.")   # cpp:13-14
+        self.axis_ = int(cp.get("concat_dim", cp.get("axis", 1)))
+
+    def Reshape(self, bottom, top):
+        shape = bottom[0].shape()
+        for b in bottom[1:]:
+            s = b.shape()
+            CHECK(len(s) == len(shape) and all(s[i] == shape[i] for i in range(len(s)) if i != self.axis_),
+                  "All inputs must have the same shape, except at concat_axis.")          # cpp:42-49
+            shape[self.axis_] += s[self.axis_]
+        top[0].Reshape(*shape)
+
+    def Forward_gpu(self, bottom, top):
+        top[0].data = bottom[0].data if len(bottom) == 1 else torch.cat([b.data for b in bottom], self.axis_)
+
+
+class SliceLayer(Layer):
+    def type(self): return "Slice"
+    def ExactNumBottomBlobs(self): return 1
+    def MinTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        sp = self.layer_param_.slice_param
+        CHECK(not ("axis" in sp and "slice_dim" in sp), "Either axis or slice_dim should be specified; not both.")     # cpp:13-14
+        self.axis_ = int(sp.get("slice_dim", sp.get("axis", 1)))
+        self.slice_point_ = [int(v) for v in sp.get("slice_point", [])]
+
+    def Reshape(self, bottom, top):
+        n = bottom[0].shape(self.axis_)
+        if self.slice_point_:
+            CHECK(len(self.slice_point_) == len(top) - 1, "slice_point count must be top count - 1")                  # cpp:50
+            cuts = [0] + self.slice_point_ + [n]
+            CHECK(all(cuts[i] < cuts[i + 1] for i in range(len(cuts) - 1)), "slice points must be increasing")         # cpp:56
+        else:
+            CHECK(n % len(top) == 0, "Number of top blobs must evenly divide the slice axis")                          # cpp:67-70
+            step = n // len(top)
+            cuts = [i * step for i in range(len(top) + 1)]
+        self.cuts_ = cuts
+        for i, t in enumerate(top):
+            s = bottom[0].shape()
+            s[self.axis_] = cuts[i + 1] - cuts[i]
+            t.Reshape(*s)
+
+    def Forward_gpu(self, bottom, top):
+        x = bottom[0].data
+        for i, t in enumerate(top):
+            t.data = x.narrow(self.axis_, self.cuts_[i], self.cuts_[i + 1] - self.cuts_[i]).contiguous()
+
+
+class SilenceLayer(Layer):
+    def type(self): return "Silence"
+    def MinBottomBlobs(self): return 1
+    def ExactNumTopBlobs(self): return 0
+    def Reshape(self, bottom, top): pass
+    def Forward_gpu(self, bottom, top): pass
+
+
+class InputLayer(Layer):
+    """input_layer.cpp:8-27: tops shaped by input_param.shape (one shape for all tops, or one per top)."""
+
+    def type(self): return "Input"
+    def ExactNumBottomBlobs(self): return 0
+    def MinTopBlobs(self): return 1
+
+    def LayerSetUp(self, bottom, top):
+        shapes = self.layer_param_.input_param.get("shape", [])
+        if isinstance(shapes, dict):
+            shapes = [shapes]
+        CHECK(len(shapes) in (0, 1, len(top)), "Must specify 'shape' once, once per top blob, or not at all")           # cpp:14-17
+        for i, t in enumerate(top):
+            if shapes:
+                t.Reshape(*[int(d) for d in shapes[i if len(shapes) > 1 else 0].get("dim", [])])
+
+    def Reshape(self, bottom, top): pass
+    def Forward_gpu(self, bottom, top): pass
+
+
+for _name, _cls in (("Convolution", ConvolutionLayer), ("Deconvolution", DeconvolutionLayer), ("ReLU", ReLULayer), ("Eltwise", EltwiseLayer),
+                    ("Concat", ConcatLayer), ("Slice", SliceLayer), ("Silence", SilenceLayer), ("Input", InputLayer)):
+    L.REGISTER_LAYER_CLASS(_name, _cls)

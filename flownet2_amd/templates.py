@@ -1,0 +1,237 @@
+"""deploy.prototxt.template files for FlowNetS / FlowNetC / FlowNet2, AUTHORED FROM flownet2_amd/nets.py.
+
+The reference tree ships no prototxt (models/download-models.sh:3-10 fetches them), so these files restate the graphs of nets.py --
+layer tables, decoder wiring, head / tail -- in the reference's own format: the layer `type:` strings and `*_param` fields of
+src/caffe/proto/caffe.proto, the six `$VAR$` size variables of scripts/run-flownet.py:38-58, the layer names the released
+.caffemodel files use (conv1 ... Convolution5, net2_ / net3_ / netsd_ / fuse_ prefixes) so that CopyTrainedLayersFrom matches them.
+A user-supplied template replaces them (scripts/run_flownet.py model.caffemodel deploy.prototxt.template img0 img1 out.flo); the
+committed copies live in flownet2_amd/prototxt_templates/ and tests/test_prototxt.py checks that they are what this module emits and
+that the nets built from them compute the same bits as nets.deploy_forward / flownet2_deploy_forward.
+"""
+from __future__ import annotations
+
+import os
+from typing import List
+
+from . import nets
+
+NEG = nets.NEG_SLOPE
+
+
+class _Builder:
+    def __init__(self, name: str):
+        self.lines: List[str] = ['name: "%s"' % name]
+        self._n = {}
+
+    def uid(self, base: str) -> str:
+        self._n[base] = self._n.get(base, 0) + 1
+        return "%s%d" % (base, self._n[base])
+
+    def input(self, name: str, channels: int):
+        self.lines += ['input: "%s"' % name, "input_shape { dim: 1 dim: %d dim: $TARGET_HEIGHT$ dim: $TARGET_WIDTH$ }" % channels]
+
+    def layer(self, name: str, type_: str, bottoms, tops, body: str = "", params: str = ""):
+        s = ['layer {', '  name: "%s"' % name, '  type: "%s"' % type_]
+        s += ['  bottom: "%s"' % b for b in bottoms]
+        s += ['  top: "%s"' % t for t in tops]
+        if params:
+            s.append("  " + params)
+        if body:
+            s.append("  " + body)
+        s.append("}")
+        self.lines += s
+
+    # ---- layer shorthands ---------------------------------------------------------------------------------------------
+    def eltwise(self, bottoms, top, coeffs):
+        self.layer(self.uid("Eltwise"), "Eltwise", bottoms, [top], "eltwise_param { operation: SUM %s }" % " ".join("coeff: %r" % float(c) for c in coeffs))
+        return top
+
+    def resample(self, bottom, top, w, h, type_="LINEAR"):
+        self.layer(self.uid("Resample"), "Resample", [bottom], [top], "resample_param { width: %s height: %s type: %s antialias: true }" % (w, h, type_))
+        return top
+
+    def mean_sub(self, name, bottom, top):
+        self.layer(name, "DataAugmentation", [bottom], [top],
+                   "augmentation_param { max_multiplier: 1 augment_during_test: false recompute_mean: 0 mean_per_pixel: false mean: 0.411 mean: 0.433 mean: 0.45 }",
+                   "propagate_down: false")
+        return top
+
+    def concat(self, bottoms, top):
+        self.layer(self.uid("Concat"), "Concat", bottoms, [top], "concat_param { axis: 1 }")
+        return top
+
+    def conv(self, name, bottom, top, cout, k, stride, pad, relu=True, share=None, deconv=False):
+        spec = ('param { name: "%s_w" lr_mult: 1 decay_mult: 1 } param { name: "%s_b" lr_mult: 1 decay_mult: 0 }' % (share, share)) if share \
+            else "param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 1 decay_mult: 0 }"
+        body = ('convolution_param { num_output: %d pad: %d kernel_size: %d stride: %d weight_filler { type: "msra" } bias_filler { type: "constant" } engine: CUDNN }'
+                % (cout, pad, k, stride))
+        self.layer(name, "Deconvolution" if deconv else "Convolution", [bottom], [top], body, spec)
+        if relu:
+            self.layer(self.uid("ReLU"), "ReLU", [top], [top], "relu_param { negative_slope: %r }" % NEG)
+        return top
+
+    def text(self) -> str:
+        return "\n".join(self.lines) + "\n"
+
+
+def _head(b: _Builder):
+    """img0 / img1 (raw 0..255) -> (img0_nomean, img1_nomean) at the ADAPTED size."""
+    outs = []
+    for i in (0, 1):
+        b.input("img%d" % i, 3)
+    for i in (0, 1):
+        s = b.eltwise(["img%d" % i], "img%d_scaled" % i, [1.0 / 255.0])
+        r = b.resample(s, "img%d_resized" % i, "$ADAPTED_WIDTH$", "$ADAPTED_HEIGHT$")
+        outs.append(b.mean_sub("img%ds_aug" % i, r, "img%d_nomean" % i))
+    return outs
+
+
+def _tail(b: _Builder, flow_blob: str, scale_flow: float = nets.FLOW_SCALE):
+    x = b.eltwise([flow_blob], "flow_scaled", [scale_flow]) if scale_flow is not None else flow_blob
+    x = b.resample(x, "flow_resized", "$TARGET_WIDTH$", "$TARGET_HEIGHT$")
+    b.layer("scale_conv1", "Convolution", [x], ["predict_flow_final"],
+            'convolution_param { num_output: 2 pad: 0 kernel_size: 1 stride: 1 weight_filler { type: "diagonal" diag_val: $SCALE_WIDTH$ diag_val: $SCALE_HEIGHT$ } '
+            'bias_filler { type: "constant" } }', "param { lr_mult: 0 decay_mult: 0 } param { lr_mult: 0 decay_mult: 0 }")
+
+
+def _decoder(b: _Builder, p: str, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
+    """nets._decoder: predict_flow6, then four stages Concat[skip, deconv, upsampled flow] -> predict_flow.  Returns the flow2 blob."""
+    flow = b.conv(p + "Convolution1", conv6_1, p + "predict_flow6", 2, 3, 1, 1, relu=False)
+    x = conv6_1
+    names = [("deconv5", 512, "upsample_flow6to5", conv5_1, "Convolution2", 5), ("deconv4", 256, "upsample_flow5to4", conv4_1, "Convolution3", 4),
+             ("deconv3", 128, "upsample_flow4to3", conv3_1, "Convolution4", 3), ("deconv2", 64, "upsample_flow3to2", conv2, "Convolution5", 2)]
+    for dname, cout, uname, skip, pname, lvl in names:
+        d = b.conv(p + dname, x, p + dname, cout, 4, 2, 1, relu=True, deconv=True)
+        u = b.conv(p + uname, flow, p + uname.replace("upsample_flow", "upsampled_flow_"), 2, 4, 2, 1, relu=False, deconv=True)
+        x = b.concat([skip, d, u], p + "concat%d" % lvl)
+        flow = b.conv(p + pname, x, p + "predict_flow%d" % lvl, 2, 3, 1, 1, relu=False)
+    return flow
+
+
+def _encoder_tail(b: _Builder, p: str, x):
+    """conv4 .. conv6_1 of nets._ENC_TAIL; returns (conv6_1, conv5_1, conv4_1)."""
+    outs = {}
+    for (n, ci, co, k, s, pad) in nets._ENC_TAIL:
+        x = b.conv(p + n, x, p + n, co, k, s, pad)
+        outs[n] = x
+    return outs["conv6_1"], outs["conv5_1"], outs["conv4_1"]
+
+
+def _flownet_s(b: _Builder, p: str, x):
+    c1 = b.conv(p + "conv1", x, p + "conv1", 64, 7, 2, 3)
+    c2 = b.conv(p + "conv2", c1, p + "conv2", 128, 5, 2, 2)
+    c3 = b.conv(p + "conv3", c2, p + "conv3", 256, 5, 2, 2)
+    c31 = b.conv(p + "conv3_1", c3, p + "conv3_1", 256, 3, 1, 1)
+    c61, c51, c41 = _encoder_tail(b, p, c31)
+    return _decoder(b, p, c61, c51, c41, c31, c2)
+
+
+def _flownet_c(b: _Builder, a, bb):
+    tow = {}
+    for tag, x in (("a", a), ("b", bb)):
+        c1 = b.conv("conv1" + tag, x, "conv1" + tag, 64, 7, 2, 3, share="conv1")
+        c2 = b.conv("conv2" + tag, c1, "conv2" + tag, 128, 5, 2, 2, share="conv2")
+        c3 = b.conv("conv3" + tag, c2, "conv3" + tag, 256, 5, 2, 2, share="conv3")
+        tow[tag] = (c2, c3)
+    redir = b.conv("conv_redir", tow["a"][1], "conv_redir", 32, 1, 1, 0)
+    b.layer("corr", "Correlation", [tow["a"][1], tow["b"][1]], ["corr"],
+            "correlation_param { pad: 20 kernel_size: 1 max_displacement: 20 stride_1: 1 stride_2: 2 }")
+    b.layer(b.uid("ReLU"), "ReLU", ["corr"], ["corr"], "relu_param { negative_slope: %r }" % NEG)
+    cat = b.concat([redir, "corr"], "blob_redir_corr")
+    c31 = b.conv("conv3_1", cat, "conv3_1", 256, 3, 1, 1)
+    c61, c51, c41 = _encoder_tail(b, "", c31)
+    return _decoder(b, "", c61, c51, c41, c31, tow["a"][0])
+
+
+def flownet_s_template() -> str:
+    b = _Builder("FlowNetS_deploy")
+    a, bb = _head(b)
+    x = b.concat([a, bb], "input")
+    _tail(b, _flownet_s(b, "", x))
+    return b.text()
+
+
+def flownet_c_template() -> str:
+    b = _Builder("FlowNetC_deploy")
+    a, bb = _head(b)
+    _tail(b, _flownet_c(b, a, bb))
+    return b.text()
+
+
+def _table_net(b: _Builder, p: str, table, x, skips, decoder):
+    """FlowNet-SD / fusion: encoder rows of `table` up to the first non-encoder row, then `decoder` = [(deconv, upsample, skip, interconv,
+    predict)] from coarse to fine.  Mirrors nets.flownet_sd_core / fusion_core."""
+    dims = {n: (k, ci, co, ks, s, pad) for (n, k, ci, co, ks, s, pad) in table}
+    blobs = {}
+    for (n, k, ci, co, ks, s, pad) in table:
+        if n in skips["encoder"]:
+            x = b.conv(p + n, x, p + n, co, ks, s, pad)
+            blobs[n] = x
+    flow = b.conv(p + decoder["first_predict"], x, p + "predict_" + decoder["first_predict"], 2, 3, 1, 1, relu=False)
+    for (dname, uname, skip, iname, pname) in decoder["stages"]:
+        d = b.conv(p + dname, x, p + dname, dims[dname][2], 4, 2, 1, relu=True, deconv=True)
+        u = b.conv(p + uname, flow, p + uname + "_out", 2, 4, 2, 1, relu=False, deconv=True)
+        x = b.concat([blobs[skip], d, u], p + "concat_" + dname)
+        ic = b.conv(p + iname, x, p + iname, dims[iname][2], 3, 1, 1, relu=False)
+        flow = b.conv(p + pname, ic, p + "predict_" + pname, 2, 3, 1, 1, relu=False)
+    return flow
+
+
+def flownet2_template() -> str:
+    b = _Builder("FlowNet2_deploy")
+    a, bb = _head(b)
+    AW, AH = "$ADAPTED_WIDTH$", "$ADAPTED_HEIGHT$"
+
+    def refine_input(flow_q, tag):
+        f = b.resample(b.eltwise([flow_q], "flow%s_x20" % tag, [nets.FLOW_SCALE]), "flow%s_full" % tag, AW, AH)
+        b.layer("FlowWarp" + tag, "FlowWarp", [bb, f], ["warped" + tag])
+        diff = b.eltwise([a, "warped" + tag], "diff" + tag, [1.0, -1.0])
+        b.layer("ChannelNorm_err" + tag, "ChannelNorm", [diff], ["err" + tag])
+        fs = b.eltwise([f], "flow%s_scaled" % tag, [1.0 / nets.FLOW_SCALE])
+        return b.concat([a, bb, "warped" + tag, fs, "err" + tag], "net_input" + tag)
+
+    flow1 = _flownet_c(b, a, bb)
+    flow2 = _flownet_s(b, "net2_", refine_input(flow1, "1"))
+    flow3 = _flownet_s(b, "net3_", refine_input(flow2, "2"))
+    flow_css = b.resample(b.eltwise([flow3], "flow3_x20", [nets.FLOW_SCALE]), "flow_css", AW, AH, "NEAREST")
+    sd_enc = ["conv0", "conv1", "conv1_1", "conv2", "conv2_1", "conv3", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1", "conv6", "conv6_1"]
+    sd_flow = _table_net(b, "netsd_", nets._SD_TABLE, b.concat([a, bb], "netsd_input"), {"encoder": sd_enc},
+                         {"first_predict": "Convolution1",
+                          "stages": [("deconv5", "upsample_flow6to5", "conv5_1", "interconv5", "Convolution2"), ("deconv4", "upsample_flow5to4", "conv4_1", "interconv4", "Convolution3"),
+                                     ("deconv3", "upsample_flow4to3", "conv3_1", "interconv3", "Convolution4"), ("deconv2", "upsample_flow3to2", "conv2_1", "interconv2", "Convolution5")]})
+    flow_sd = b.resample(b.eltwise([sd_flow], "flow_sd_scaled", [nets.SD_FLOW_SCALE]), "flow_sd", AW, AH, "NEAREST")
+    errs = {}
+    for tag, f in (("css", flow_css), ("sd", flow_sd)):
+        b.layer("FlowWarp_" + tag, "FlowWarp", [bb, f], ["warped_" + tag])
+        d = b.eltwise([a, "warped_" + tag], "diff_" + tag, [1.0, -1.0])
+        b.layer("ChannelNorm_err_" + tag, "ChannelNorm", [d], ["err_" + tag])
+        b.layer("ChannelNorm_mag_" + tag, "ChannelNorm", [f], ["mag_" + tag])
+        errs[tag] = ("err_" + tag, "mag_" + tag)
+    fuse_in = b.concat([a, flow_sd, flow_css, errs["sd"][1], errs["css"][1], errs["sd"][0], errs["css"][0]], "fuse_input")
+    fuse_enc = ["conv0", "conv1", "conv1_1", "conv2", "conv2_1"]
+    flow = _table_net(b, "fuse_", nets._FUSE_TABLE, fuse_in, {"encoder": fuse_enc},
+                      {"first_predict": "Convolution5",
+                       "stages": [("deconv1", "upsample_flow2to1", "conv1_1", "interconv1", "Convolution6"), ("deconv0", "upsample_flow1to0", "conv0", "interconv0", "Convolution7")]})
+    _tail(b, flow, scale_flow=None)
+    return b.text()
+
+
+TEMPLATES = {"S": ("FlowNetS_deploy.prototxt.template", flownet_s_template), "C": ("FlowNetC_deploy.prototxt.template", flownet_c_template),
+             "2": ("FlowNet2_deploy.prototxt.template", flownet2_template)}
+TEMPLATE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prototxt_templates")
+
+
+def template_path(kind: str) -> str:
+    return os.path.join(TEMPLATE_DIR, TEMPLATES[kind][0])
+
+
+def write_all(directory: str = TEMPLATE_DIR):
+    os.makedirs(directory, exist_ok=True)
+    for kind, (fname, fn) in TEMPLATES.items():
+        with open(os.path.join(directory, fname), "w") as f:
+            f.write(fn())
+
+
+if __name__ == "__main__":
+    write_all()
+    print("wrote", ", ".join(v[0] for v in TEMPLATES.values()), "to", TEMPLATE_DIR)

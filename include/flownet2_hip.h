@@ -239,6 +239,13 @@ int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, int C, in
  * and bias_diff[c] = sum over n, h, w of bottom_diff  <- backward_gpu_bias, base_conv_layer.cpp:389-393 (bias_diff may be
  * NULL).  bottom_diff may alias top_diff.  Deterministic (fixed-order partial sums in the workspace). */
 size_t fn2_bias_leaky_relu_backward_workspace_bytes(int N, int C, int H, int W);
+/* Deploy head in one pass: top[n, top_c0 + c] = bottom[n, c] * scale + shift[c]  (product rounded, then the sum rounded: no fma)
+ *   <- EltwiseLayer::Forward_gpu SUM with one bottom and coeff = scale, src/caffe/layers/eltwise_layer.cu:46-52 (scripts/run-flownet.py's
+ *      deploy nets scale the raw 0..255 images by 1/255), then the per-channel mean subtraction of the deploy-time DataAugmentation layer,
+ *      data_augmentation_layer.cu:592-621 (shift = -mean), the LINEAR Resample between them being the identity at the ADAPTED size.
+ *   top is [N, top_channels, H, W]: the two images land side by side in the blob conv1 reads.  shift may be NULL. */
+int fn2_scale_shift_forward(const float* bottom, float* top, const float* shift, int N, int C, int H, int W,
+                            int top_channels, int top_c0, float scale, void* stream);
 int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
                                  int N, int C, int H, int W, float negative_slope, void* workspace, size_t workspace_bytes,
                                  void* stream);

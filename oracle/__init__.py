@@ -292,6 +292,16 @@ def conv_plane_forward(x, packed, bias, Cout, stride, pad, ksplit, relu=True, ne
     return out
 
 
+def scale_shift_forward(x, scale, shift=None, out=None, out_c0=0):
+    x = np.ascontiguousarray(x, np.float32)
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = np.zeros_like(x)
+    sh = None if shift is None else np.ascontiguousarray(shift, np.float32)
+    _check(lib().fn2_scale_shift_forward_cpu(_p(x), _p(out), _p(sh), N, Cc, H, W, out.shape[1], out_c0, C.c_float(scale)), "scale_shift_forward")
+    return out
+
+
 def tconv_forward(x, weight, bias, kernel, pad, out_hw=None, relu=False, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
     """CPU twin of fn2_tconv_forward; weight: the unpacked [Cin, Cout, k, k] blob."""
     x = np.ascontiguousarray(x, np.float32)

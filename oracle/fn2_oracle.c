@@ -1061,6 +1061,26 @@ FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed,
   return FN2_OK;
 }
 
+/* Deploy head: top[n, top_c0 + c] = bottom[n, c] * scale + shift[c], product and sum rounded separately -- Eltwise{coeff}
+ * (eltwise_layer.cpp:59-65: caffe_set(0) + caffe_axpy(coeff, bottom, top)) then the mean subtraction of the deploy-time
+ * DataAugmentation layer (data_augmentation_layer.cu:592-621).  CPU twin of fn2_scale_shift_forward. */
+FN2_API int fn2_scale_shift_forward_cpu(const float* bottom, float* top, const float* shift, int N, int C, int H, int W,
+                                        int top_channels, int top_c0, float scale) {
+  if (!bottom || !top || N < 0 || C < 1 || H < 1 || W < 1 || top_c0 < 0 || top_c0 + C > top_channels) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      const float* p = bottom + ((size_t)n * C + c) * hw;
+      float* q = top + ((size_t)n * top_channels + top_c0 + c) * hw;
+      const float sh = shift ? shift[c] : 0.f;
+      for (size_t i = 0; i < hw; ++i) {
+        volatile float prod = p[i] * scale;            /* volatile: the compiler must not contract the pair into an fma */
+        q[i] = prod + sh;
+      }
+    }
+  return FN2_OK;
+}
+
 /* Transposed convolution, stride 2 (+ bias + optional ReLU): the CPU twin of csrc/tconv_mfma.hip.
  * Reference arithmetic: DeconvolutionLayer::Forward_cpu (deconv_layer.cpp:8-26: weight^T x bottom, col2im, bias) / the data gradient of
  * ConvolutionLayer::Backward_cpu (conv_layer.cpp:57-62 -> backward_cpu_gemm, base_conv_layer.cpp:305-317):

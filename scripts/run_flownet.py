@@ -1,7 +1,14 @@
 #!/usr/bin/env python
 """py3 re-authoring of the reference's inference driver (scripts/run-flownet.py:1-127) on the MI355X path.
 
-    python scripts/run_flownet.py [--net C|S|2] [--weights w.npz] img0 img1 out.flo
+    python scripts/run_flownet.py model.caffemodel deploy.prototxt.template img0 img1 out.flo     # the reference's argument order
+    python scripts/run_flownet.py [--net C|S|2] [--weights w.caffemodel|w.npz] img0 img1 out.flo   # built-in graph (flownet2_amd/nets.py)
+
+First form: the template's $TARGET_WIDTH$ ... $SCALE_HEIGHT$ variables are substituted exactly as run-flownet.py:38-58 does, the net
+is built layer by layer from the prototxt through the layer registry (flownet2_amd.net.Net = caffe.Net of run-flownet.py:64) and the
+weights are copied by layer name (Net::CopyTrainedLayersFrom).  `model.caffemodel` may be `seed:S` / `seed:C` / `seed:2` for the seeded
+synthetic weights of nets.init_params (no released model can be downloaded here); templates for the three nets ship in
+flownet2_amd/prototxt_templates/.
 
 Same behaviour as the reference script: images are read as RGB, fed as BGR raw 0..255 floats, the net runs at the
 ADAPTED (x64) size and the flow is resampled / rescaled back to the TARGET size, and the result is written as .flo.
@@ -60,7 +67,55 @@ def infer(net, P, img0, img1, mean=None):
         return nets.deploy_forward(net, P, img0, img1, Fn, mean=mean)
 
 
+def infer_prototxt(model, template_path, img0, img1, device):
+    """run-flownet.py:38-98: substitute, build, load, forward; returns predict_flow_final [N,2,H,W]."""
+    from flownet2_amd import net as fnet, prototxt
+    H, W = img0.shape[2], img0.shape[3]
+    text = prototxt.substitute(open(template_path).read(), prototxt.deploy_vars(W, H))
+    n = fnet.Net(text, phase="TEST", device=device)
+    if img0.shape[0] != 1:
+        n.reshape_inputs(img0.shape[0])
+    if model.startswith("seed:"):
+        kind = model.split(":", 1)[1]
+        P = nets.init_params_flownet2(0) if kind == "2" else nets.init_params(kind, 0)
+        missing = [m for m in n.load_param_dict(P) if m != "scale_conv1"]
+        if missing:
+            raise SystemExit("no seeded weights for layers: " + ", ".join(missing))
+    else:
+        ignored = n.CopyTrainedLayersFrom(model)
+        if ignored:
+            print("Ignoring source layers:", ", ".join(ignored))
+    out = n.forward(**{n.inputs[0]: img0, n.inputs[1]: img1})
+    if "predict_flow_final" not in n.blobs:
+        raise SystemExit("the net has no blob 'predict_flow_final' (run-flownet.py:98)")
+    return n.blobs["predict_flow_final"].data
+
+
 def main():
+    if len([a for a in sys.argv[1:] if not a.startswith("-")]) >= 5 and "--net" not in sys.argv:
+        ap = argparse.ArgumentParser()
+        ap.add_argument("caffemodel", help="path to model (or seed:S / seed:C / seed:2)")
+        ap.add_argument("deployproto", help="path to deploy prototxt template")
+        ap.add_argument("img0"); ap.add_argument("img1"); ap.add_argument("out")
+        ap.add_argument("--gpu", type=int, default=0)
+        ap.add_argument("--verbose", action="store_true")
+        ap.add_argument("--no-batch-invariant", action="store_true")
+        a = ap.parse_args()
+        if not a.caffemodel.startswith("seed:") and not os.path.exists(a.caffemodel):
+            raise SystemExit("caffemodel does not exist: " + a.caffemodel)                   # run-flownet.py:20
+        if not os.path.exists(a.deployproto):
+            raise SystemExit("deploy-proto does not exist: " + a.deployproto)                # :21
+        for f in (a.img0, a.img1):
+            if not os.path.exists(f):
+                raise SystemExit("image does not exist: " + f)
+        dev = torch.device("cuda", a.gpu)
+        torch.cuda.set_device(dev)
+        Fn.set_batch_invariant(not a.no_batch_invariant)
+        i0, i1 = torch.from_numpy(read_image(a.img0)).to(dev), torch.from_numpy(read_image(a.img1)).to(dev)
+        flow = infer_prototxt(a.caffemodel, a.deployproto, i0, i1, dev)
+        flo.write_flo(a.out, flow[0].cpu().numpy())
+        print("wrote", a.out, tuple(flow.shape[2:]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("img0"); ap.add_argument("img1"); ap.add_argument("out")
     ap.add_argument("--net", choices=["C", "S", "2"], default="C")

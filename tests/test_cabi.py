@@ -82,7 +82,9 @@ def test_ops_refuse_cpu_tensors_no_fallback():
 
 
 def test_layer_registry_and_blob_count_checks():
-    assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Correlation", "Correlation1D", "CustomData", "DataAugmentation", "Downsample", "FlowAugmentation", "FlowWarp", "GenerateAugmentationParameters", "L1Loss", "Resample"]
+    assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Concat", "Convolution", "Correlation", "Correlation1D", "CustomData", "DataAugmentation",
+                                             "Deconvolution", "Downsample", "Eltwise", "FlowAugmentation", "FlowWarp", "GenerateAugmentationParameters",
+                                             "Input", "L1Loss", "ReLU", "Resample", "Silence", "Slice"]
     with pytest.raises(CheckError, match="Unknown layer type"):
         LayerRegistry.CreateLayer(LayerParameter(type="Nope"))
     with pytest.raises(CheckError, match="already registered"):

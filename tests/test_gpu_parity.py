@@ -916,3 +916,18 @@ def test_correlation_backward_generations_agree_bitwise(shape):
         for got in ((s0, s1), (t0, t1)):
             assert_close(host(got[0]), o0, 3e-6, "bottom 0 diff")
             assert_close(host(got[1]), o1, 3e-6, "bottom 1 diff")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 128), (1, 3, 7, 9), (3, 5, 10, 6)])
+def test_scale_shift_deploy_head_is_two_roundings(shape):
+    """fn2_scale_shift_forward = Eltwise{coeff} then the mean subtraction, bit for bit (product rounded, then the sum: no fma), also into a
+    channel slice -- the oracle twin and the two-pass torch sequence."""
+    N, C, H, W = shape
+    x = np.random.default_rng(31).integers(0, 256, shape).astype(np.float32)
+    sh = -rand((C,), 32, 0.3)
+    got = host(ops.scale_shift_forward(dev(x), 1.0 / 255.0, dev(sh)))
+    np.testing.assert_array_equal(got, oracle.scale_shift_forward(x, 1.0 / 255.0, sh))
+    np.testing.assert_array_equal(got, host(dev(x) * (1.0 / 255.0) + dev(sh).view(1, -1, 1, 1)))
+    blob = torch.full((N, C + 4, H, W), 7.0, device="cuda")
+    ops.scale_shift_forward(dev(x), 1.0 / 255.0, dev(sh), out=blob, out_c0=3)
+    assert torch.equal(blob[:, 3:3 + C].cpu(), torch.from_numpy(got)) and bool((blob[:, :3] == 7).all()) and bool((blob[:, 3 + C:] == 7).all())
