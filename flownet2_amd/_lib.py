@@ -70,7 +70,7 @@ class DatumView(C.Structure):
 
 class DataAugParams(C.Structure):
     _fields_ = [("crop_width", C.c_int), ("crop_height", C.c_int), ("max_multiplier", C.c_float), ("has_chromatic_eigvec", C.c_int),
-                ("chromatic_eigvec", C.c_float * 9), ("mean_mode", C.c_int)]
+                ("chromatic_eigvec", C.c_float * 9), ("mean_mode", C.c_int), ("noise_seed", C.c_ulonglong), ("noise_stream", C.c_ulonglong)]
 
 
 class L1LossParams(C.Structure):

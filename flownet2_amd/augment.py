@@ -5,9 +5,14 @@ Restates AugmentationLayerBase::generate_*_coeffs / generate_valid_spatial_coeff
 modes of GenerateAugmentationParametersLayer::Forward_gpu (src/caffe/layers/generate_augmentation_parameters_layer.cu:20-112).
 
 PARITY: the control flow, distributions and array layout follow the reference; the random STREAM does not -- the reference draws from
-boost generators seeded per thread (caffe_rng_*), whose sequence cannot be reproduced here, so drawn values are "unpinned" by
-construction.  What is deterministic (coeff_to_array / array_to_coeff / add_coeff_to_array, the four-corner validity test) is tested
-against the pinned matrix helpers (tests/test_augmentation.py).  Consumers: ops.data_augmentation_forward, ops.flow_augmentation_forward.
+boost generators seeded per thread (caffe_rng_*, boost::mt19937 behind boost::variate_generator), whose sequence cannot be reproduced
+here, so drawn VALUES are unpinned by construction.  What is pinned instead: the DISTRIBUTIONS (Kolmogorov-Smirnov tests of every
+rand_type / exp / discretize / schedule combination against the closed form, tests/test_augmentation_random.py) and everything
+deterministic (coeff_to_array / array_to_coeff / add_coeff_to_array, the four-corner validity test: tests/test_augmentation.py).
+The generator is counter-based (PhiloxStream: Philox4x32-10, the generator of the device-side noise effect, csrc/philox.hpp): a draw
+is a function of (seed, stream = iteration, position), so any iteration's coefficients can be produced ahead of time by a prefetch
+thread (CoefficientPrefetcher) or re-produced after a restart without replaying the stream.
+Consumers: ops.data_augmentation_forward, ops.flow_augmentation_forward.
 """
 from __future__ import annotations
 
@@ -28,6 +33,71 @@ FIELDS = [("mirror", 0), ("dx", 0), ("dy", 0), ("angle", 0), ("zoom_x", 1), ("zo
 NUM_PARAMS = len(FIELDS)
 DEFAULT = {k: float(v) for k, v in FIELDS}
 SPATIAL = ("mirror", "dx", "dy", "angle", "zoom_x", "zoom_y")
+
+
+class PhiloxStream:
+    """Counter-based random stream with the three calls rng_generate needs (random / uniform / normal), duck-typed like numpy's Generator.
+    Words come from Philox4x32-10 (Salmon et al., SC'11; Random123's constants -- the same function as csrc/philox.hpp and
+    oracle.philox4x32_10) with key = seed and counter = (block index, 0, stream_lo, stream_hi); doubles take 53 bits of two words,
+    normals are Box-Muller in double precision.  Vectorised refills of 256 blocks."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+    def __init__(self, seed: int = 0, stream: int = 0):
+        self.key = (int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff)
+        self.stream = (int(stream) & 0xffffffff, (int(stream) >> 32) & 0xffffffff)
+        self.block = 0
+        self.buf = np.empty(0, np.uint32)
+        self.pos = 0
+        self.spare = None
+
+    @classmethod
+    def words(cls, c0, c1, c2, c3, k0, k1):
+        """Philox4x32-10 on arrays of counters (uint64 arithmetic, 32-bit lanes)."""
+        c0, c1, c2, c3 = (np.asarray(v, np.uint64) for v in (c0, c1, c2, c3))
+        mask = np.uint64(0xffffffff)
+        k0, k1 = np.uint64(k0), np.uint64(k1)
+        for _ in range(10):
+            p0, p1 = np.uint64(cls.M0) * c0, np.uint64(cls.M1) * c2
+            n0, n1, n2, n3 = (p1 >> np.uint64(32)) ^ c1 ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c3 ^ k1, p0 & mask
+            c0, c1, c2, c3 = n0, n1, n2, n3
+            k0, k1 = (k0 + np.uint64(cls.W0)) & mask, (k1 + np.uint64(cls.W1)) & mask
+        return np.stack([c0, c1, c2, c3], -1).astype(np.uint32)
+
+    def _refill(self):
+        idx = np.arange(self.block, self.block + 256, dtype=np.uint64)
+        z = np.zeros(256, np.uint64)
+        self.buf = self.words(idx & np.uint64(0xffffffff), idx >> np.uint64(32), z + np.uint64(self.stream[0]), z + np.uint64(self.stream[1]),
+                              self.key[0], self.key[1]).reshape(-1)
+        self.block += 256
+        self.pos = 0
+
+    def _word(self) -> int:
+        if self.pos >= self.buf.size:
+            self._refill()
+        w = int(self.buf[self.pos])
+        self.pos += 1
+        return w
+
+    def random(self) -> float:
+        """Uniform double in [0, 1): 53 bits of two words (numpy's recipe)."""
+        a, b = self._word() >> 5, self._word() >> 6
+        return (a * 67108864.0 + b) / 9007199254740992.0
+
+    def uniform(self, low: float, high: float) -> float:
+        return low + (high - low) * self.random()
+
+    def normal(self, mean: float = 0.0, sigma: float = 1.0) -> float:
+        if self.spare is not None:
+            z, self.spare = self.spare, None
+            return mean + sigma * z
+        u1, u2 = 1.0 - self.random(), self.random()              # u1 in (0, 1]
+        r, t = math.sqrt(-2.0 * math.log(u1)), 2.0 * math.pi * u2
+        self.spare = r * math.sin(t)
+        return mean + sigma * r * math.cos(t)
+
+
+def make_rng(seed: int = 0, stream: int = 0) -> PhiloxStream:
+    return PhiloxStream(seed, stream)
 
 
 def default_coeff() -> Dict[str, float]:
@@ -223,3 +293,51 @@ def draw_batch(rng, aug: dict, num: int, width: int, height: int, cw: int, ch: i
                 gen(rng, aug, tmp, discount)
                 add_coeff_to_array(tmp, out[n])
     return out
+
+
+
+class CoefficientPrefetcher:
+    """Draws the coefficient blobs of upcoming iterations on a background thread, so the host work (about a millisecond per batch of
+    8 in Python) is off the training step's critical path.  `draw(iteration) -> anything` must be a pure function of the iteration
+    (counter-based streams make it one: PhiloxStream(seed, stream=iteration)); results are handed out strictly in iteration order.
+
+        pre = CoefficientPrefetcher(lambda it: draw_batch(make_rng(seed, it), aug, 8, 512, 384, 448, 320, discount_coeff(it, sched)), depth=4)
+        coeffs = pre.get()            # iteration 0, 1, 2, ...
+    """
+
+    def __init__(self, draw, depth: int = 4, start: int = 0):
+        import queue
+        import threading
+        self._draw, self._q, self._stop = draw, queue.Queue(maxsize=max(1, depth)), threading.Event()
+        self._next = start
+        self._error = None
+        self._t = threading.Thread(target=self._run, args=(start,), daemon=True)
+        self._t.start()
+
+    def _run(self, it):
+        import queue
+        try:
+            while not self._stop.is_set():
+                item = (it, self._draw(it))
+                while not self._stop.is_set():
+                    try:
+                        self._q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                it += 1
+        except BaseException as e:          # noqa: BLE001 -- re-raised by get()
+            self._error = e
+            self._q.put((None, None))
+
+    def get(self):
+        it, item = self._q.get()
+        if it is None:
+            raise self._error
+        assert it == self._next, "coefficients arrive in iteration order"
+        self._next += 1
+        return item
+
+    def close(self):
+        self._stop.set()
+        self._t.join(timeout=2.0)

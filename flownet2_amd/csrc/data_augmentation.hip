@@ -8,6 +8,7 @@
 // The chromatic-eigen transform needs batch statistics of the SOURCE images first (ComputeChromaticEigenspace, :147-187): a reduction
 // kernel (wave shuffles -> LDS -> one atomic per block; 256 blocks: the atomics on the 12 statistics serialise) in front.
 #include "augmentation.hpp"
+#include "philox.hpp"
 
 #include <cfloat>
 #include <cstring>
@@ -22,6 +23,7 @@ struct ItemCoeffs {
   float pow_withmean0, add_withmean0, mult_withmean0, pow_withmean1, add_withmean1, mult_withmean1;
   float lmult_pow, lmult_add, lmult_mult, col_angle;
   float shadow_nx, shadow_ny, shadow_distance, shadow_strength;
+  float noise;                         // tEffectCoeffs::noise: sigma of the additive Gaussian noise of this sample (:578-587)
   int chromatic, eigen, effect;        // needsComputation() of the three groups (per sample; the kernels run on the whole batch, see below)
 };
 
@@ -39,6 +41,7 @@ struct DataAugArgs {
   int n0, n_chunk, C, H, W, ch, cw, mean_mode, spatial;
   long long src_count;
   float max_multiplier;
+  unsigned seed_lo, seed_hi, stream_lo, stream_hi;     // Philox key (seed) and the high counter words (stream = iteration)
   ItemCoeffs item[kItemChunk];
 };
 
@@ -226,12 +229,23 @@ __global__ void __launch_bounds__(256) data_aug_kernel(DataAugArgs a) {
         if (k.eigen) eigen_pixel(px, k, *a.eigen, a.max_multiplier);
         if (k.chromatic) chromatic_pixel(px, k, a.max_multiplier);
       }
+      // the noise effect (:578-587: caffe_gpu_rng_gaussian(count, 0, noise) added to the sample after ApplyEffects): i.i.d. N(0, noise^2)
+      // per element from Philox4x32-10 -- counter (pixel, sample * 4 + channel triple, stream), key = seed -- and Box-Muller
+      float z[3] = {0.f, 0.f, 0.f};
+      if (k.noise > 0.f) {
+        const long long pixn = (long long)y * a.cw + x;
+        const Philox4 r = philox4x32_10((unsigned)pixn, (unsigned)(pixn >> 32) ^ ((unsigned)n * 4u + (unsigned)(c0 / 3)), a.stream_lo, a.stream_hi, a.seed_lo, a.seed_hi);
+        const float r0 = sqrtf(-2.0f * logf(philox_unit(r.v[0]))), t0 = 6.283185307179586f * philox_unit(r.v[1]);
+        const float r1 = sqrtf(-2.0f * logf(philox_unit(r.v[2]))), t1 = 6.283185307179586f * philox_unit(r.v[3]);
+        z[0] = r0 * cosf(t0); z[1] = r0 * sinf(t0); z[2] = r1 * cosf(t1);
+      }
       for (int c = 0; c < nc; ++c) {
         float v = px[c];
         if (k.effect) {                                                                                   // ApplyEffects, :308-315
           if ((x - a.cw / 2) * k.shadow_nx + (y - a.ch / 2) * k.shadow_ny - k.shadow_distance > 0) v -= k.shadow_strength;
           v = clampf(v, 0.f, a.max_multiplier);
         }
+        if (k.noise > 0.f) v = v + k.noise * z[c];
         const long long pix = (long long)y * a.cw + x;
         if (a.mean_mode == FN2_MEAN_PER_CHANNEL) v = v - a.mean[c0 + c];                                  // :620-634
         else if (a.mean_mode == FN2_MEAN_PER_PIXEL) v = v - a.mean[(long long)(c0 + c) * per + pix];      // :613-616
@@ -265,6 +279,8 @@ FN2_API int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const fl
   a.bottom = bottom; a.mean = mean; a.top = top; a.C = C; a.H = H; a.W = W; a.ch = ch; a.cw = cw;
   a.mean_mode = p->mean_mode; a.spatial = do_cropping; a.src_count = (long long)N * C * H * W; a.max_multiplier = p->max_multiplier;
   a.eigen = static_cast<const EigenSpace*>(workspace);
+  a.seed_lo = (unsigned)p->noise_seed; a.seed_hi = (unsigned)(p->noise_seed >> 32);
+  a.stream_lo = (unsigned)p->noise_stream; a.stream_hi = (unsigned)(p->noise_stream >> 32);
 
   // pass 1 over the coefficients (:452-476): the reference launches each colour / effect kernel over the WHOLE batch as soon as ONE
   // sample needs it (has_chromatic_augmentation etc. are batch flags); samples with default coefficients go through it too, and it is
@@ -291,8 +307,8 @@ FN2_API int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const fl
     for (int f = A_POW_NOMEAN0; f <= A_COL_ANGLE; ++f) k->eigen = k->eigen || c.v[f] != kAugDefault[f];   // hpp:86-94 (incl. the unused *_withmean2)
     k->shadow_nx = (float)std::cos((double)c.v[A_SHADOW_ANGLE]); k->shadow_ny = (float)std::sin((double)c.v[A_SHADOW_ANGLE]);   // hpp:110
     k->shadow_distance = c.v[A_SHADOW_DISTANCE]; k->shadow_strength = c.v[A_SHADOW_STRENGTH];
-    if (c.v[A_NOISE] > 0) return fail(FN2_ERR_UNSUPPORTED, "data_augmentation: the noise effect (cuRAND in the reference) is not part of this entry point");
-    k->effect = (c.v[A_FOG_AMOUNT] != 0 && c.v[A_FOG_SIZE] != 0) || c.v[A_MOTION_BLUR_SIZE] > 0 || k->shadow_strength > 0;   // hpp:111
+    k->noise = c.v[A_NOISE] > 0 ? c.v[A_NOISE] : 0.f;
+    k->effect = (c.v[A_FOG_AMOUNT] != 0 && c.v[A_FOG_SIZE] != 0) || c.v[A_MOTION_BLUR_SIZE] > 0 || k->shadow_strength > 0 || k->noise > 0;   // hpp:111
     return FN2_OK;
   };
   if (do_cropping) {

@@ -484,7 +484,9 @@ class DataAugmentationLayer(Layer):
         self.mean_ = None
         self.mean_mode_ = ops.MEAN_NONE
         self.num_iter_ = 0                                                            # blobs_[0], .cu:349-351
-        self.rng_ = np.random.default_rng(self.layer_param_.augmentation_param.get("seed", 0))
+        self.seed_ = int(self.layer_param_.augmentation_param.get("seed", 0))         # ours: key of the counter-based streams
+        self.mean_pixel_ = None                                                       # blobs_[1] / blobs_[2]: the running means of recompute_mean
+        self.mean_channel_ = None
 
     def _generators(self):
         return {k: v for k, v in self.layer_param_.augmentation_param.items() if isinstance(v, dict)}
@@ -496,8 +498,9 @@ class DataAugmentationLayer(Layer):
         if not self.do_cropping_ or not (self.layer_param_.phase == "TRAIN" or ap.get("augment_during_test", False)) or not self._generators():
             return None
         disc = augment.discount_coeff(self.num_iter_, self.layer_param_.coeff_schedule_param)
-        return augment.draw_batch(self.rng_, self._generators(), bottom[0].num(), bottom[0].width(), bottom[0].height(),
-                                  self.cropped_width_, self.cropped_height_, discount=disc)
+        # counter-based stream: the draws of iteration i are a function of (seed, i) alone (prefetchable, restartable)
+        return augment.draw_batch(augment.make_rng(self.seed_, self.num_iter_), self._generators(), bottom[0].num(), bottom[0].width(),
+                                  bottom[0].height(), self.cropped_width_, self.cropped_height_, discount=disc)
 
     def set_mean(self, per_channel=None, per_pixel=None):
         CHECK((per_channel is None) != (per_pixel is None), "give exactly one of per_channel / per_pixel")
@@ -532,7 +535,30 @@ class DataAugmentationLayer(Layer):
             self.mean_ = torch.tensor(self.mean_host_, dtype=torch.float32, device=bottom[0].data.device)
         self.params_.mean_mode = self.mean_mode_
         self.num_iter_ += 1                                                                             # .cu:350
+        self.params_.noise_seed, self.params_.noise_stream = self.seed_, self.num_iter_
         coeffs = bottom[1].data if self.input_params_ else self._draw(bottom)
+        recompute = int(self.layer_param_.augmentation_param.get("recompute_mean", 0))
+        if recompute > 0:                                                                               # .cu:593-621
+            self.params_.mean_mode = ops.MEAN_NONE
+            out = _wrap(ops.data_augmentation_forward, self.params_, bottom[0].data, coeffs, None)
+            if self.mean_pixel_ is None:
+                self.mean_pixel_ = torch.zeros(out.shape[1:], dtype=torch.float32, device=out.device)     # blobs_[1], cpp:113-116
+                self.mean_channel_ = torch.zeros(out.shape[1], dtype=torch.float32, device=out.device)    # blobs_[2]
+            if self.num_iter_ <= recompute:
+                # scal(i - 1); axpy(1 / num) per sample; scal(1 / i); gemv(1 / area) -> per-channel mean   (:600-606)
+                self.mean_pixel_.mul_(float(self.num_iter_ - 1))
+                for n in range(out.shape[0]):
+                    self.mean_pixel_.add_(out[n], alpha=1.0 / out.shape[0])
+                self.mean_pixel_.mul_(1.0 / self.num_iter_)
+                self.mean_channel_ = self.mean_pixel_.mean(dim=(1, 2))
+            if self.layer_param_.augmentation_param.get("mean_per_pixel", True):
+                out.sub_(self.mean_pixel_.unsqueeze(0))                                                   # :609-612
+            else:
+                out.sub_(self.mean_channel_.view(1, -1, 1, 1))                                            # :613-620
+            top[0].data = out
+            if self.output_params_:
+                top[1].data = bottom[1].data if self.input_params_ else (torch.zeros(top[1].shape()) if coeffs is None else torch.from_numpy(coeffs).view(-1, ops.AUG_NUM_PARAMS, 1, 1))
+            return
         if (coeffs is None and not self.do_cropping_ and not self.output_params_ and self.mean_mode_ == ops.MEAN_PER_CHANNEL
                 and bottom[0].data.is_cuda):
             # the deploy nets' use of this layer (no crop, default coefficients: .cu:375-387, then :592-621): top = bottom - mean[c], one
@@ -565,7 +591,7 @@ class GenerateAugmentationParametersLayer(Layer):
     def LayerSetUp(self, bottom, top):
         import numpy as np
         self.layer_param_.reshape_every_iter = False                                  # cpp:35
-        self.rng_ = np.random.default_rng(self.layer_param_.augmentation_param.get("seed", 0))
+        self.seed_ = int(self.layer_param_.augmentation_param.get("seed", 0))
 
     def Reshape(self, bottom, top):
         ap = self.layer_param_.augmentation_param
@@ -603,11 +629,12 @@ class GenerateAugmentationParametersLayer(Layer):
         if self.mode_ in ("add", "replace"):
             in_params = bottom[0].data.detach().cpu().numpy().reshape(self.num_, ops.AUG_NUM_PARAMS).astype(np.float32)
         disc = augment.discount_coeff(self.num_iter_, self.layer_param_.coeff_schedule_param)
+        rng = augment.make_rng(self.seed_ ^ 0x9e3779b97f4a7c15, self.num_iter_)               # a stream of its own next to the DataAugmentation layers'
         if in_params is None:
-            out = augment.draw_batch(self.rng_, gens, self.num_, self.bottomwidth_, self.bottomheight_, self.cropped_width_, self.cropped_height_, disc,
+            out = augment.draw_batch(rng, gens, self.num_, self.bottomwidth_, self.bottomheight_, self.cropped_width_, self.cropped_height_, disc,
                                      in_params=np.zeros((self.num_, ops.AUG_NUM_PARAMS), np.float32), mode="regenerate")
         else:
-            out = augment.draw_batch(self.rng_, gens, self.num_, self.bottomwidth_, self.bottomheight_, self.cropped_width_, self.cropped_height_, disc,
+            out = augment.draw_batch(rng, gens, self.num_, self.bottomwidth_, self.bottomheight_, self.cropped_width_, self.cropped_height_, disc,
                                      in_params=in_params, mode=self.mode_)
         top[0].data = torch.from_numpy(out).view(self.num_, ops.AUG_NUM_PARAMS, 1, 1)          # read on the host by the consumers
 

@@ -641,8 +641,9 @@ def flow_augmentation_forward(flow, coeffs1, coeffs2, crop_height, crop_width):
 MEAN_NONE, MEAN_PER_CHANNEL, MEAN_PER_PIXEL = 0, 1, 2
 
 
-def data_aug_params(crop_width=0, crop_height=0, max_multiplier=255.0, chromatic_eigvec=None, mean_mode=MEAN_NONE):
+def data_aug_params(crop_width=0, crop_height=0, max_multiplier=255.0, chromatic_eigvec=None, mean_mode=MEAN_NONE, noise_seed=0, noise_stream=0):
     p = _lib.DataAugParams(int(crop_width), int(crop_height), float(max_multiplier), int(chromatic_eigvec is not None))
+    p.noise_seed, p.noise_stream = int(noise_seed), int(noise_stream)
     if chromatic_eigvec is not None:
         if len(chromatic_eigvec) != 9:
             raise ValueError("chromatic_eigvec must have 9 entries")

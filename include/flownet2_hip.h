@@ -540,9 +540,11 @@ int fn2_flow_augmentation_forward(const float* flow, const float* coeffs1_host, 
  *   shapes  <- DataAugmentationLayer::Reshape, data_augmentation_layer.cpp:74-160: top [N,C,crop_height,crop_width]; without a crop size
  *              the layer copies the bottom (:590) and only the mean is applied.
  * Not part of this entry point: drawing the coefficients (generate_*_coeffs use boost generators: their stream cannot be reproduced),
- * the noise effect (cuRAND, :578-587: a coefficient array with noise > 0 is refused), fog / motion blur (coefficients exist, the
- * reference has no kernel for them either), the running re-computation of the mean over the first iterations (:597-606; state of the
- * layer object -- pass the mean in).  Colour transforms need 3 channels (CHECKs :489,:540,:548,:556).
+ * fog / motion blur (coefficients exist, the reference has no kernel for them either), the running re-computation of the mean over
+ * the first iterations (:597-606; state of the layer object: flownet2_amd.layers.DataAugmentationLayer keeps it -- pass the mean in).
+ * The noise effect (:578-587: N(0, noise^2) per element from cuRAND's stream, which cannot be reproduced) draws from Philox4x32-10
+ * keyed by noise_seed, counter (pixel, sample, channel triple, noise_stream): reproducible from the parameters alone; pass the
+ * iteration number as noise_stream so that every step draws fresh noise.  Colour transforms need 3 channels (CHECKs :489,:540,:548,:556).
  * ---------------------------------------------------------------------------------------------- */
 enum { FN2_MEAN_NONE = 0, FN2_MEAN_PER_CHANNEL = 1, FN2_MEAN_PER_PIXEL = 2 };
 typedef struct fn2_data_aug_params {
@@ -551,6 +553,8 @@ typedef struct fn2_data_aug_params {
   int has_chromatic_eigvec;        /* chromatic_eigvec = 83 (9 floats), needed when a sample has chromatic-eigen coefficients */
   float chromatic_eigvec[9];
   int mean_mode;                   /* FN2_MEAN_*: what `mean` holds: C floats, or C*crop_height*crop_width floats */
+  unsigned long long noise_seed;   /* key of the counter-based generator behind the noise effect (ours: the reference uses cuRAND's global stream) */
+  unsigned long long noise_stream; /* high counter words: the layer's iteration count */
 } fn2_data_aug_params;
 /* Device scratch for the chromatic-eigen statistics of the batch. */
 size_t fn2_data_augmentation_workspace_bytes(int N);

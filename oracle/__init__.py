@@ -494,10 +494,19 @@ def flow_augmentation_forward(flow, coeffs1, coeffs2, crop_height, crop_width):
 
 class DataAugParams(C.Structure):
     _fields_ = [("crop_width", C.c_int), ("crop_height", C.c_int), ("max_multiplier", C.c_float), ("has_chromatic_eigvec", C.c_int),
-                ("chromatic_eigvec", C.c_float * 9), ("mean_mode", C.c_int)]
+                ("chromatic_eigvec", C.c_float * 9), ("mean_mode", C.c_int), ("noise_seed", C.c_ulonglong), ("noise_stream", C.c_ulonglong)]
 
 
-def data_augmentation_forward(bottom, coeffs=None, crop_height=0, crop_width=0, mean=None, mean_mode=0, max_multiplier=255.0, chromatic_eigvec=None):
+def philox4x32_10(counter, key):
+    c = (C.c_uint32 * 4)(*[int(v) & 0xffffffff for v in counter])
+    k = (C.c_uint32 * 2)(*[int(v) & 0xffffffff for v in key])
+    out = (C.c_uint32 * 4)()
+    _check(lib().fn2_philox4x32_10_cpu(c, k, out), "philox")
+    return [int(v) for v in out]
+
+
+def data_augmentation_forward(bottom, coeffs=None, crop_height=0, crop_width=0, mean=None, mean_mode=0, max_multiplier=255.0, chromatic_eigvec=None,
+                              noise_seed=0, noise_stream=0):
     bottom = _f32(bottom)
     N, Cc, H, W = bottom.shape
     crop = crop_width > 0 and crop_height > 0
@@ -506,6 +515,7 @@ def data_augmentation_forward(bottom, coeffs=None, crop_height=0, crop_width=0, 
     if chromatic_eigvec is not None:
         p.chromatic_eigvec = (C.c_float * 9)(*[float(v) for v in chromatic_eigvec])
     p.mean_mode = mean_mode
+    p.noise_seed, p.noise_stream = int(noise_seed), int(noise_stream)
     co = _f32(coeffs).reshape(N, 42) if coeffs is not None else None
     m = _f32(mean) if mean is not None else None
     top = np.empty((N, Cc, max(ch, 1), max(cw, 1)), np.float32)

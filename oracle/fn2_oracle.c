@@ -1877,6 +1877,24 @@ static inline float oa_clamp(float f, float a, float b) { return fmaxf(a, fminf(
 
 typedef struct oa_eigenspace { float mean_eig[3], mean_rgb[3], max_abs_eig[3], max_rgb[3], min_rgb[3], max_l, eigvec[9]; } oa_eigenspace;
 
+/* Philox4x32-10 (Salmon et al., SC'11; Random123's constants), restated from csrc/philox.hpp: counter (c0..c3), key (k0, k1) -> 4 words */
+static void oa_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static float oa_unit(uint32_t x) { return ((float)x + 1.0f) * 2.3283064365386963e-10f; }
+
+/* the raw generator, for the known-answer test against numpy's Philox and Random123's published vectors */
+FN2_API int fn2_philox4x32_10_cpu(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  oa_philox4x32_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1], out);
+  return FN2_OK;
+}
+
 FN2_API int fn2_data_augmentation_forward_cpu(const fn2_data_aug_params* p, const float* bottom, const float* coeffs, const float* mean,
                                               float* top, int N, int C, int H, int W) {
   if (!p || N < 0 || C < 1 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
@@ -1906,8 +1924,7 @@ FN2_API int fn2_data_augmentation_forward_cpu(const fn2_data_aug_params* p, cons
       const float* v = co[n].v;
       if (v[OA_GAMMA] != 1 || v[OA_BRIGHTNESS] != 0 || v[OA_CONTRAST] != 1 || v[OA_COLOR1] != 1 || v[OA_COLOR2] != 1 || v[OA_COLOR3] != 1) has_chromatic = 1;   /* hpp:48 */
       for (int f = OA_POW_NOMEAN0; f <= OA_COL_ANGLE; ++f) if (v[f] != oa_default[f]) has_eigen = 1;  /* hpp:86-94 */
-      if (v[OA_NOISE] > 0) { free(co); free(mats); return FN2_ERR_UNSUPPORTED; }                        /* cuRAND noise, :578-587 */
-      if ((v[OA_FOG_AMOUNT] != 0 && v[OA_FOG_SIZE] != 0) || v[OA_MOTION_BLUR_SIZE] > 0 || v[OA_SHADOW_STRENGTH] > 0) has_effect = 1;   /* hpp:111 */
+      if ((v[OA_FOG_AMOUNT] != 0 && v[OA_FOG_SIZE] != 0) || v[OA_MOTION_BLUR_SIZE] > 0 || v[OA_SHADOW_STRENGTH] > 0 || v[OA_NOISE] > 0) has_effect = 1;   /* hpp:111 */
     }
     if ((has_chromatic || has_eigen || has_effect) && C != 3) { free(co); free(mats); return FN2_ERR_INVALID_ARG; }   /* :489,:548,:556 */
     if (has_eigen && !p->has_chromatic_eigvec) { free(co); free(mats); return FN2_ERR_INVALID_ARG; }   /* :493-494 (LOG(ERROR), then reads an empty list) */
@@ -2056,6 +2073,21 @@ FN2_API int fn2_data_augmentation_forward_cpu(const fn2_data_aug_params* p, cons
               float sample = top[(((size_t)n * C + c) * ch + y) * cw + x];
               if ((x - cw / 2) * nx + (y - ch / 2) * ny - co[n].v[OA_SHADOW_DISTANCE] > 0) sample -= co[n].v[OA_SHADOW_STRENGTH];
               top[(((size_t)n * C + c) * ch + y) * cw + x] = oa_clamp(sample, 0.f, max_multiplier);
+            }
+        /* the noise effect, :578-587: N(0, noise^2) per element.  The reference draws from cuRAND's stream; the HIP kernel (and this twin)
+         * from Philox4x32-10 -- counter (pixel, sample * 4 + channel triple, stream), key = seed -- through Box-Muller. */
+        const float sigma = co[n].v[OA_NOISE];
+        if (sigma > 0)
+          for (int y = 0; y < ch; ++y)
+            for (int x = 0; x < cw; ++x) {
+              const long long pix = (long long)y * cw + x;
+              uint32_t r[4];
+              oa_philox4x32_10((uint32_t)pix, (uint32_t)(pix >> 32) ^ ((uint32_t)n * 4u), (uint32_t)p->noise_stream, (uint32_t)(p->noise_stream >> 32),
+                               (uint32_t)p->noise_seed, (uint32_t)(p->noise_seed >> 32), r);
+              const float r0 = sqrtf(-2.0f * logf(oa_unit(r[0]))), t0 = 6.283185307179586f * oa_unit(r[1]);
+              const float r1 = sqrtf(-2.0f * logf(oa_unit(r[2]))), t1 = 6.283185307179586f * oa_unit(r[3]);
+              const float z[3] = {r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1)};
+              for (int c = 0; c < 3; ++c) top[(((size_t)n * C + c) * ch + y) * cw + x] += sigma * z[c];
             }
       }
     }

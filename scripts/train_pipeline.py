@@ -7,9 +7,12 @@
   flow  --FlowAugmentation(params0, params1)-->  flow_aug                                                                    [one kernel]
   FlowNetC forward + multi-scale L1 loss + backward + Adam (the step bench.py --mode train times)
 
-Prints the time per stage (HIP events, median of the timed iterations).  The coefficient DRAWS use numpy's generator (the reference's
-boost stream cannot be reproduced, flownet2_amd/augment.py); everything downstream of the coefficient blobs is pinned against the
-reference's layers.  Usage: python scripts/train_pipeline.py [--batch 8] [--iters 10] [--no-train]"""
+Prints the time per stage (HIP events, median of the timed iterations).  The coefficient DRAWS come from a counter-based generator
+(Philox4x32-10, flownet2_amd/augment.py: the reference's boost stream cannot be reproduced, its distributions are pinned): the draws
+of iteration i are a function of (seed, i), so a background thread (augment.CoefficientPrefetcher) produces them ahead of the step and
+the "draw" stages below are what the step WAITS for them; --no-prefetch draws inline (the r02 behaviour).  Everything downstream of
+the coefficient blobs is pinned against the reference's layers.
+Usage: python scripts/train_pipeline.py [--batch 8] [--iters 10] [--no-train] [--no-prefetch]"""
 import argparse
 import os
 import statistics
@@ -54,6 +57,7 @@ def main():
     ap.add_argument("--crop-height", type=int, default=320)
     ap.add_argument("--crop-width", type=int, default=448)
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B, H, W, ch, cw = a.batch, a.height, a.width, a.crop_height, a.crop_width
@@ -66,7 +70,11 @@ def main():
     aug0 = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=aug_p))
     aug1 = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=aug_p))
     faug = LayerRegistry.CreateLayer(LayerParameter(type="FlowAugmentation", augmentation_param=dict(crop_width=cw, crop_height=ch)))
-    rng = np.random.default_rng(1)
+    def draw(it):          # both coefficient blobs of iteration `it`: a pure function of (seed, it)
+        p0 = augment.draw_batch(augment.make_rng(1, 2 * it), AUG0, B, W, H, cw, ch, discount=augment.discount_coeff(it + 1))
+        p1 = augment.draw_batch(augment.make_rng(1, 2 * it + 1), AUG1, B, W, H, cw, ch, discount=1.0, in_params=p0, mode="add")
+        return p0, p1
+    pre = None if a.no_prefetch else augment.CoefficientPrefetcher(draw, depth=4)
     P = {k: v.to(dev).requires_grad_(True) for k, v in nets.init_params("C", seed=0).items()}
     opt = torch.optim.Adam(list(P.values()), lr=1e-5)
     stages = ["decode", "scale", "draw0 (host)", "augment0", "draw1 (host)", "augment1", "flow_aug", "train step"]
@@ -82,7 +90,7 @@ def main():
         img0, img1 = dtop[0].data * (1.0 / 255.0), dtop[1].data * (1.0 / 255.0)
         marks[2].record()
         t0 = time.perf_counter()
-        p0 = augment.draw_batch(rng, AUG0, B, W, H, cw, ch, discount=augment.discount_coeff(it + 1))
+        p0, p1 = pre.get() if pre is not None else draw(it)
         host_ms["draw0 (host)"] = (time.perf_counter() - t0) * 1e3
         marks[3].record()
         b0 = [Blob.from_tensor(img0), Blob.from_tensor(torch.from_numpy(p0).view(B, 42, 1, 1))]
@@ -92,9 +100,7 @@ def main():
             aug0.SetUp(b0, t_img0)
         aug0.Forward(b0, t_img0)
         marks[4].record()
-        t0 = time.perf_counter()
-        p1 = augment.draw_batch(rng, AUG1, B, W, H, cw, ch, discount=1.0, in_params=p0, mode="add")
-        host_ms["draw1 (host)"] = (time.perf_counter() - t0) * 1e3
+        host_ms["draw1 (host)"] = 0.0          # drawn together with p0
         marks[5].record()
         b1 = [Blob.from_tensor(img1), Blob.from_tensor(torch.zeros(1))]
         b1[1].data = torch.from_numpy(p1).view(B, 42, 1, 1)
@@ -122,6 +128,9 @@ def main():
     print("| stage | ms per batch of %d (%dx%d -> %dx%d) |\n|---|---|" % (B, W, H, cw, ch))
     for s in stages:
         print("| %s | %.3f |" % (s, statistics.median(times[s])))
+    if pre is not None:
+        pre.close()
+    print("coefficient draws: %s" % ("prefetch thread, 4 iterations deep (draw0 = time the step waited)" if pre is not None else "inline (draw0 = both blobs)"))
     if not a.no_train:
         print("loss %.4f, NaN ground truth kept: %s" % (float(loss), bool(torch.isnan(t_flow[0].data).any())))
 

@@ -258,9 +258,13 @@ def test_data_augmentation_invariants_and_errors():
     only_spatial = co.copy(); only_spatial[:, 6:] = 0
     without = oracle.data_augmentation_forward(img, only_spatial, ch, cw)
     assert np.abs(with_col[1] - without[1]).max() > 1e-4 and np.abs(with_col[1] - without[1]).max() < 0.02
-    noisy = co.copy(); noisy[0, 41] = 0.1
-    with pytest.raises(ValueError):                      # the noise effect needs cuRAND's stream
-        oracle.data_augmentation_forward(img, noisy, ch, cw)
+    # the noise effect (counter-based stream): only the sample with noise > 0 changes beyond what the effects' clamp does to the batch;
+    # reproducible from (seed, stream), different for another stream -- distribution tests: tests/test_augmentation_random.py
+    noisy = co.copy(); noisy[0, 41] = np.log(1.0) + 0.1
+    n1 = oracle.data_augmentation_forward(img, noisy, ch, cw, noise_seed=5, noise_stream=1)
+    assert np.array_equal(n1, oracle.data_augmentation_forward(img, noisy, ch, cw, noise_seed=5, noise_stream=1))
+    n2 = oracle.data_augmentation_forward(img, noisy, ch, cw, noise_seed=5, noise_stream=2)
+    assert not np.array_equal(n1[0], n2[0]) and np.array_equal(n1[1], n2[1])
     with pytest.raises(ValueError):                      # crop greater than original
         oracle.data_augmentation_forward(img, co, H + 1, W)
     with pytest.raises(ValueError):                      # colour transforms need 3 channels
