@@ -51,12 +51,15 @@ struct Args {
   float slope; int relu;
 };
 
-template <int KS_, int S_, int MW_, int NP_, int WM_, int WNX_, int WNY_, int CQ_>
+// P16 (1x1 kernels only): the M tile is 16 CONSECUTIVE pixels of one row instead of a 4x4 patch -- the launcher flattens every plane into
+// one row of H * W pixels (a 1x1 convolution has no spatial window), so no tile hangs over an image edge: the plain-GEMM form.
+template <int KS_, int S_, int MW_, int NP_, int WM_, int WNX_, int WNY_, int CQ_, int P16_ = 0>
 struct Cfg {
-  static constexpr int KS = KS_, S = S_, MW = MW_, NP = NP_, WM = WM_, WNX = WNX_, WNY = WNY_, CQ = CQ_;
+  static constexpr int KS = KS_, S = S_, MW = MW_, NP = NP_, WM = WM_, WNX = WNX_, WNY = WNY_, CQ = CQ_, P16 = P16_;
   static constexpr int NW = WM * WNX * WNY, THREADS = 64 * NW;
   static constexpr int PADL = 4;                                     // window columns left of S * x0 (16-byte aligned start)
-  static constexpr int TW = 4 * NP * WNX, TH = 4 * WNY;              // output pixels of a workgroup tile
+  static constexpr int TW = (P16 ? 16 : 4) * NP * WNX, TH = (P16 ? 1 : 4) * WNY;   // output pixels of a workgroup tile
+  static_assert(!P16 || (KS == 1 && S == 1), "row tiles are for 1x1 kernels");
   static constexpr int WR = (TH - 1) * S + KS;                       // window rows per channel
   static constexpr int WC = (TW - 1) * S + KS + PADL;                // window columns incl. the left margin (pad <= PADL)
   static constexpr int RS = up_mod(cdiv(WC, 4) * 4, 4, 16);          // row stride (dwords)
@@ -133,8 +136,9 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
   auto stage = [&](int chunk, int buf) { stage_chunk<K>(rs, voff, lds_base + 4u * (unsigned)(buf * K::BUF), wave, (unsigned)chunk * chunk_bytes); };
 
   // ---- operands
-  const int kq = lane >> 4, p16 = lane & 15, py = p16 >> 2, px = p16 & 3;
-  const int bbase = kq * K::CS + (S * (4 * wny + py)) * K::RS + S * (4 * NP * wnx + px) + K::PADL - a.pad;
+  const int kq = lane >> 4, p16 = lane & 15, py = K::P16 ? 0 : p16 >> 2, px = K::P16 ? p16 : p16 & 3;
+  constexpr int PW = K::P16 ? 16 : 4, PH = K::P16 ? 1 : 4;          // pixels of an M tile along x / y
+  const int bbase = kq * K::CS + (S * (PH * wny + py)) * K::RS + S * (PW * NP * wnx + px) + K::PADL - a.pad;
   using WV = typename WVec<MW>::T;
   // packed weights: [Cout/64][ksteps][64 lanes][4]; this wave's channel groups: 16 * MW * (g * WM + wm) ...
   const int cg0 = (g * K::WM + wm) * MW;                      // first 16-channel group of this wave
@@ -167,7 +171,7 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
       const int cq = ks / (KS * KS), ky = (ks / KS) % KS, kx = ks % KS;
       float b[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) b[p] = win[cq * 4 * K::CS + ky * K::RS + kx + 4 * S * p];
+      for (int p = 0; p < NP; ++p) b[p] = win[cq * 4 * K::CS + ky * K::RS + kx + PW * S * p];
       const WV w = wreg[ks % K::NBUFA];
 #pragma unroll
       for (int j = 0; j < MW; ++j)
@@ -177,7 +181,8 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
   }
 
   // ---- epilogue: lane (row block = lane >> 4, channel = lane & 15) holds 4 consecutive x of output row y0 + 4 wny + (lane >> 4)
-  const int y = y0 + 4 * wny + (lane >> 4);
+  // (row tiles: pixels 4 (lane >> 4) .. + 3 of the 16-pixel tile, row y0 + wny)
+  const int y = K::P16 ? y0 + wny : y0 + 4 * wny + (lane >> 4);
   if (y < a.Hout) {
 #pragma unroll
     for (int j = 0; j < MW; ++j) {
@@ -186,7 +191,7 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
       float* orow = a.out + (((size_t)n * a.out_ctot + a.out_c0 + co) * a.Hout + y) * a.Wout;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int x = x0 + 4 * (NP * wnx + p);
+        const int x = K::P16 ? x0 + 16 * (NP * wnx + p) + 4 * (lane >> 4) : x0 + 4 * (NP * wnx + p);
         f32x4 v = acc[j][p];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -232,7 +237,7 @@ conv_mfma(Args a) {
 template <class K>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_tail(Args a) {
-  using KH = Cfg<K::KS, K::S, K::MW / 2, K::NP, K::WM, K::WNX, K::WNY, K::CQ>;
+  using KH = Cfg<K::KS, K::S, K::MW / 2, K::NP, K::WM, K::WNX, K::WNY, K::CQ, K::P16>;
   int g, bx, by, n;
   if (blockIdx.x < a.nbig) {
     const unsigned t = (blockIdx.x % 8) * (a.nbig / 8) + blockIdx.x / 8;
@@ -249,7 +254,7 @@ conv_mfma_tail(Args a) {
 
 // weight [Cout][Cin][KS][KS] -> packed [Cout/64][ksteps + spare][64][4]
 __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KS, int ksteps, int kalloc) {
-  const long long total = (long long)(Cout / 64) * kalloc * 256;
+  const long long total = (long long)((Cout + 63) / 64) * kalloc * 256;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
     long long r = i >> 8;
@@ -258,18 +263,22 @@ __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wp
     const int cq = ks / (KS * KS), tap = ks % (KS * KS);
     const int ci = 4 * cq + kq;
     float v = 0.f;
-    if (ks < ksteps && ci < Cin) v = w[((size_t)co * Cin + ci) * KS * KS + tap];
+    if (ks < ksteps && ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * KS * KS + tap];
     wp[i] = v;
   }
 }
 
 constexpr int kSpare = 8;          // spare (zero) k-steps behind every group: the weight prefetch runs NBUFA - 1 k-steps ahead
-constexpr int kChunkQuads = 2;     // k-steps are padded to a whole number of chunks of at most this many channel quads
+constexpr int kChunkQuads = 2;     // k-steps are padded to a whole number of chunks of at most this many channel quads (8 for 1x1 kernels)
 
-inline int ksteps_for(int Cin, int KS) { return cdiv(cdiv(Cin, 4), kChunkQuads) * kChunkQuads * KS * KS; }
+inline int chunk_quads(int KS) { return KS == 1 ? 8 : kChunkQuads; }
+inline int ksteps_for(int Cin, int KS) { return cdiv(cdiv(Cin, 4), chunk_quads(KS)) * chunk_quads(KS) * KS * KS; }
 
 template <class K>
 static void set_geometry(Args& a) {
+  if constexpr (K::P16) {                 // every plane as ONE row of H * W pixels (contiguous in NCHW; a 1x1 kernel has no spatial window)
+    a.Win *= a.Hin; a.Hin = 1; a.Wout *= a.Hout; a.Hout = 1;
+  }
   a.tx = cdiv(a.Wout, K::TW); a.ty = cdiv(a.Hout, K::TH);
   a.ng = a.Cout / (16 * K::MW * K::WM);
   a.nchunks = cdiv(cdiv(a.Cin, 4), K::CQ);
@@ -320,13 +329,16 @@ static int launch_tail(const Args& base, hipStream_t st) {
 }
 
 struct Variant {
-  int ks, s, mw, np, wm, wnx, wny;
+  int ks, s, mw, np, wm, wnx, wny, p16;
   int (*fn)(const Args&, hipStream_t);
   int (*fn_tail)(const Args&, hipStream_t);     // nullptr: no split-tail form
 };
 
 // X-macro list of the tile variants: (KS, S, MW, NP, WM, WNX, WNY, CQ, split-tail form instantiated)
 #define FN2_CV_LIST(X) \
+  /* 1x1 stride 1: a plain GEMM over the channels (conv_redir; the weight^T x bottom product of the Deconvolution layers), 8 quads per chunk */ \
+  X(1, 1, 2, 7, 2, 2, 1, 8, 1) X(1, 1, 2, 7, 2, 1, 2, 8, 1) X(1, 1, 4, 7, 1, 2, 2, 8, 0) X(1, 1, 4, 7, 1, 1, 4, 8, 0) X(1, 1, 2, 6, 2, 2, 1, 8, 1) \
+  X(1, 1, 2, 4, 2, 2, 1, 8, 1) X(1, 1, 2, 7, 1, 2, 2, 8, 0) X(1, 1, 2, 7, 1, 4, 1, 8, 0) X(1, 1, 2, 4, 1, 2, 2, 8, 0) X(1, 1, 4, 4, 1, 2, 2, 8, 0) \
   /* 3x3 stride 1 */ \
   X(3, 1, 2, 7, 2, 2, 1, 2, 1) X(3, 1, 2, 7, 2, 1, 2, 2, 1) X(3, 1, 4, 7, 1, 2, 2, 2, 0) X(3, 1, 4, 7, 1, 1, 4, 2, 0) \
   X(3, 1, 2, 6, 2, 2, 1, 2, 1) X(3, 1, 4, 6, 1, 2, 2, 2, 0) X(3, 1, 4, 4, 1, 2, 2, 2, 0) X(3, 1, 2, 4, 2, 2, 1, 2, 1) \
@@ -344,8 +356,17 @@ template <class K, int TAIL> struct TailFn { static constexpr int (*fn)(const Ar
 template <class K> struct TailFn<K, 1> { static constexpr int (*fn)(const Args&, hipStream_t) = &launch_tail<K>; };
 
 #define FN2_CV_ROW(KS, S, MW, NP, WM, WNX, WNY, CQ, TAIL) \
-  {KS, S, MW, NP, WM, WNX, WNY, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>>, TailFn<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>, TAIL>::fn},
-static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)};
+  {KS, S, MW, NP, WM, WNX, WNY, 0, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>>, TailFn<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>, TAIL>::fn},
+#define FN2_CV_ROW16(MW, NP, WM, WNX, WNY, TAIL) \
+  {1, 1, MW, NP, WM, WNX, WNY, 1, &launch<Cfg<1, 1, MW, NP, WM, WNX, WNY, 8, 1>>, TailFn<Cfg<1, 1, MW, NP, WM, WNX, WNY, 8, 1>, TAIL>::fn},
+static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)
+  /* 1x1 on flattened planes (16-pixel row tiles): TW = 16 NP WNX pixels */
+  /* (WNY = 1: a flattened plane has one row) */
+  FN2_CV_ROW16(2, 7, 2, 2, 1, 1) FN2_CV_ROW16(2, 7, 4, 1, 1, 1) FN2_CV_ROW16(4, 7, 1, 4, 1, 0) FN2_CV_ROW16(4, 7, 2, 2, 1, 0) FN2_CV_ROW16(2, 5, 2, 2, 1, 1)
+  FN2_CV_ROW16(2, 4, 2, 2, 1, 1) FN2_CV_ROW16(2, 7, 1, 4, 1, 0) FN2_CV_ROW16(2, 5, 1, 4, 1, 0) FN2_CV_ROW16(4, 5, 1, 4, 1, 0) FN2_CV_ROW16(2, 4, 1, 4, 1, 0)
+  FN2_CV_ROW16(4, 5, 2, 2, 1, 0) FN2_CV_ROW16(4, 4, 2, 2, 1, 0)
+  /* planes of 140 (10x14) / 288 (12x24) pixels: 9 x 16 = 144 */
+  FN2_CV_ROW16(2, 9, 4, 1, 1, 1) FN2_CV_ROW16(2, 9, 2, 2, 1, 1) FN2_CV_ROW16(2, 3, 2, 2, 1, 1) FN2_CV_ROW16(4, 3, 1, 4, 1, 0)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int g_forced_variant = -1;       // >= 0: plain launch of that variant; >= 1000: its split-tail launch
@@ -353,8 +374,9 @@ int g_forced_variant = -1;       // >= 0: plain launch of that variant; >= 1000:
 // Cost model: tile times of the busiest CU x accumulator tiles of a wave (tiles hanging over the image edge included), with a
 // mild penalty for small wave tiles (more operand traffic per MFMA).  tail: the last partial round as half tiles.
 static double variant_cost(const Variant& v, const Args& a, bool tail) {
-  const int tw = 4 * v.np * v.wnx, th = 4 * v.wny;
-  const long long wgs = (long long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * (a.Cout / (16 * v.mw * v.wm));
+  const int tw = (v.p16 ? 16 : 4) * v.np * v.wnx, th = (v.p16 ? 1 : 4) * v.wny;
+  const long long wgs = v.p16 ? (long long)a.N * cdiv(a.Wout * a.Hout, tw) * (a.Cout / (16 * v.mw * v.wm))
+                              : (long long)a.N * cdiv(a.Wout, tw) * cdiv(a.Hout, th) * (a.Cout / (16 * v.mw * v.wm));
   double rounds = (double)((wgs + 255) / 256);
   if (tail) {
     const long long r = wgs % 256;
@@ -366,6 +388,7 @@ static double variant_cost(const Variant& v, const Args& a, bool tail) {
 }
 
 static bool variant_applies(const Variant& v, const Args& a, int KS, int S) {
+  if (!v.p16 && a.Win % 4 != 0) return false;          // 4x4-patch tiles stage 16-byte pieces of image rows; row tiles only need H * W % 4 == 0
   return v.ks == KS && v.s == S && a.Cout % (16 * v.mw * v.wm) == 0;
 }
 
@@ -375,23 +398,24 @@ static bool variant_applies(const Variant& v, const Args& a, int KS, int S) {
 using namespace fn2;
 
 FN2_API size_t fn2_conv_mfma_packed_floats(int Cout, int Cin, int kernel) {
-  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || kernel <= 0) return 0;
-  return (size_t)(Cout / 64) * (cv::ksteps_for(Cin, kernel) + cv::kSpare) * 256;
+  if (Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || kernel <= 0) return 0;
+  return (size_t)((Cout + 63) / 64) * (cv::ksteps_for(Cin, kernel) + cv::kSpare) * 256;
 }
 
 FN2_API int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int Cout, int Cin, int kernel, void* stream) {
   if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights: null blob");
-  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7))
-    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights: needs Cout %% 64 == 0 and kernel_size 3, 4, 5 or 7 (got Cout %d, kernel %d)", Cout, kernel);
+  if (Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || (kernel != 1 && kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights: needs Cout %% 32 == 0 and kernel_size 1, 3, 4, 5 or 7 (got Cout %d, kernel %d)", Cout, kernel);
   const int ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare;
-  const long long total = (long long)(Cout / 64) * kalloc * 256;
+  const long long total = (long long)((Cout + 63) / 64) * kalloc * 256;
   hipLaunchKernelGGL(cv::pack_weights, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), weight, packed, Cout, Cin, kernel, ksteps, kalloc);
   return check_launch("conv_mfma_pack_weights");
 }
 
 FN2_API int fn2_conv_mfma_supported(int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
-  if (Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 64 != 0 || Win % 4 != 0) return 0;
-  if (!((kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 4 && stride == 2) || (kernel == 5 && stride == 2) || (kernel == 7 && stride == 2))) return 0;
+  if (Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 32 != 0) return 0;
+  if (kernel == 1 ? ((long long)Hin * Win) % 4 != 0 : Win % 4 != 0) return 0;      // (1x1: the planes are flattened, only their size matters)
+  if (!((kernel == 1 && stride == 1) || (kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 4 && stride == 2) || (kernel == 5 && stride == 2) || (kernel == 7 && stride == 2))) return 0;
   if (pad < 0 || pad > 4 || pad > kernel - 1) return 0;
   if ((long long)Cin * Hin * Win >= (1ll << 28)) return 0;
   const int Hout = (Hin + 2 * pad - kernel) / stride + 1, Wout = (Win + 2 * pad - kernel) / stride + 1;

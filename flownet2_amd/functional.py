@@ -292,6 +292,8 @@ def _conv_mfma_pick(x, weight, stride, pad):
         return "plane"
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None
+    if k == 1 and os.environ.get("FN2_CONV_1X1", "1") != "0":
+        return "direct"     # conv_redir: the alternative is a library GEMM + a bias / activation pass + a copy into the Concat blob
     # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
     # large enough to run the matrix pipes efficiently, and the library's GEMM route wins (scripts/conv_bench.py, profiles/)
     if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not own:
@@ -521,8 +523,11 @@ def deconv_mfma_relu(x, weight, bias, negative_slope=0.1, act=True, out=None, ou
     Opt-in (FN2_DECONV_PLANE=1): on the FlowNet shapes the library GEMM (130+ TFLOP/s) + our col2im pass is 5-25 % faster than this
     kernel (profiles/r02_deconv_bench.txt).  Returns None when the kernel does not apply or a gradient is needed: the caller then
     takes the GEMM + col2im route."""
-    if not x.is_cuda or os.environ.get("FN2_DECONV_PLANE", "0") == "0" or _needs_grad(x, weight, bias):
+    mode = os.environ.get("FN2_DECONV_PLANE", "auto")
+    if not x.is_cuda or mode == "0" or _needs_grad(x, weight, bias):
         return None
+    if mode == "auto" and ((x.shape[2] * x.shape[3]) % 4 == 0 or os.environ.get("FN2_DECONV_GEMM", "own") != "own"):
+        return None        # the GEMM route (own 1x1 MFMA kernel, or the library's with FN2_DECONV_GEMM=lib) serves it; odd planes (5x7) stay here
     Cin, Cout = weight.shape[:2]
     if tuple(weight.shape[2:]) != (4, 4) or not ops.deconv_plane_supported(x.shape[0], Cin, x.shape[2], x.shape[3], Cout):
         return None
@@ -540,7 +545,16 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
 
     def run_t(xx, wt, bb, out=None, out_c0=0):
-        col = _matmul_per_sample(wt, xx.contiguous().view(N, Cin, H * W))     # [N, Cout*k*k, H*W]
+        col = None
+        if xx.is_cuda and os.environ.get("FN2_DECONV_GEMM", "own") == "own" and (cout * kernel * kernel) % 32 == 0 \
+                and ops.conv_mfma_supported(Cin, H, W, cout * kernel * kernel, 1, 1, 0):
+            # weight^T x bottom (base_conv_layer.cpp:375-384) as a 1x1 convolution with Cout * k * k output channels on the own MFMA kernel
+            # (csrc/conv_mfma.hip, kernel_size 1): the column matrix [N, Cout*k*k, H*W] without a library call
+            blob, c0 = _channel_slice(xx)
+            pw = _cached_pack(_PACKED_T, wt, "deconv-gemm", lambda: ops.conv_mfma_pack_weights(wt.detach().reshape(cout * kernel * kernel, Cin, 1, 1)))
+            col = ops.conv_mfma_forward(blob, pw, None, cout * kernel * kernel, 1, 1, 0, False, 0.0, in_c0=c0, Cin=Cin).view(N, cout * kernel * kernel, H * W)
+        if col is None:
+            col = _matmul_per_sample(wt, xx.contiguous().view(N, Cin, H * W))     # [N, Cout*k*k, H*W]
         return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope, out=out, out_c0=out_c0)
 
     if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)

@@ -110,8 +110,8 @@ def conv_forward(x, w, b, stride, pad, act, backend, slope=None):
         if y is not None:
             _LAST_ROUTE[0] = "stem kernel"
             return y
-    if w.shape[2] in (3, 5) and backend is not None and hasattr(backend, "conv_mfma_relu"):
-        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, slope, act)    # Winograd / direct MFMA convolution, bias + ReLU fused
+    if w.shape[2] in (1, 3, 5) and backend is not None and hasattr(backend, "conv_mfma_relu"):
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, slope, act)    # Winograd / direct MFMA convolution (1x1: a plain MFMA GEMM), bias + ReLU fused
         if y is not None:
             _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
@@ -298,17 +298,23 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
     c3a, c3b = c3[:n], c3[n:]
-    redir = _conv(c3a, P, "conv_redir", 1, 0, backend=backend)
-    cat = None
+    cat = redir = None
+    cr = P["conv_redir.w"].shape[0]
     if hasattr(backend, "correlation_relu_into") and c3a.is_cuda:
-        # the correlation writes its 441 activated planes straight into the [conv_redir | corr] blob (no ReLU pass, no Concat pass)
-        cat = torch.empty((n, redir.shape[1] + 441, c3a.shape[2], c3a.shape[3]), device=c3a.device, dtype=c3a.dtype)
-        if backend.correlation_relu_into(c3a, c3b, cat, redir.shape[1], NEG_SLOPE, pad=20, kernel_size=1, max_displacement=20,
+        # the correlation writes its 441 activated planes straight into the [conv_redir | corr] blob (no ReLU pass, no Concat pass), and
+        # conv_redir (1x1: the own MFMA GEMM kernel) its 32 channels in front of them
+        cat = torch.empty((n, cr + 441, c3a.shape[2], c3a.shape[3]), device=c3a.device, dtype=c3a.dtype)
+        if backend.correlation_relu_into(c3a, c3b, cat, cr, NEG_SLOPE, pad=20, kernel_size=1, max_displacement=20,
                                          stride_1=1, stride_2=2) is None:
             cat = None
         else:
-            cat[:, :redir.shape[1]].copy_(redir)
+            into = None
+            if hasattr(backend, "conv_mfma_relu") and not (torch.is_grad_enabled() and _any_requires_grad(P)):
+                into = backend.conv_mfma_relu(c3a, P["conv_redir.w"], P["conv_redir.b"], 1, 0, NEG_SLOPE, True, out=cat, out_c0=0)
+            if into is None:
+                cat[:, :cr].copy_(_conv(c3a, P, "conv_redir", 1, 0, backend=backend))
     if cat is None:
+        redir = _conv(c3a, P, "conv_redir", 1, 0, backend=backend)
         corr = backend.correlation(c3a, c3b, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2)
         cat = torch.cat([redir, F.leaky_relu(corr, NEG_SLOPE)], 1)
     blob3, c31 = _skip_conv(cat, P, "conv3_1", 1, 1, "deconv3", backend)

@@ -958,23 +958,26 @@ FN2_API int fn2_correlation_forward_fused_cpu(const fn2_corr_params* p, const fl
  * k-ordered fma chain), zero padding included as 0-products -- restated here with fmaf in the same order, so the two agree bit for bit.
  * Packed layout (fn2_conv_mfma_pack_weights): [Cout/64][k-steps + 8 spare][lane 64][4], lane = 16 * kq + co, element j:
  * W[64 g + 16 j + co][4 cq + kq][ky][kx], k-step = (cq * k + ky) * k + kx; zero beyond Cin. */
-static int conv_mfma_ksteps(int Cin, int k) { return (((Cin + 3) / 4 + 1) / 2) * 2 * k * k; }
+static int conv_mfma_ksteps(int Cin, int k) {      /* channel quads padded to whole chunks: 2 quads, 8 for 1x1 kernels (csrc/conv_mfma.hip) */
+  const int cq = k == 1 ? 8 : 2;
+  return (((Cin + 3) / 4 + cq - 1) / cq) * cq * k * k;
+}
 
 FN2_API size_t fn2_conv_mfma_packed_floats_cpu(int Cout, int Cin, int kernel) {
-  if (Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || kernel <= 0) return 0;
-  return (size_t)(Cout / 64) * (conv_mfma_ksteps(Cin, kernel) + 8) * 256;
+  if (Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || kernel <= 0) return 0;
+  return (size_t)((Cout + 63) / 64) * (conv_mfma_ksteps(Cin, kernel) + 8) * 256;
 }
 
 FN2_API int fn2_conv_mfma_pack_weights_cpu(const float* weight, float* packed, int Cout, int Cin, int kernel) {
-  if (!weight || !packed || Cout <= 0 || Cout % 64 != 0 || Cin <= 0 || (kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7)) return FN2_ERR_INVALID_ARG;
+  if (!weight || !packed || Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || (kernel != 1 && kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7)) return FN2_ERR_INVALID_ARG;
   const int ksteps = conv_mfma_ksteps(Cin, kernel), kalloc = ksteps + 8, kk = kernel * kernel;
-  for (int g = 0; g < Cout / 64; ++g)
+  for (int g = 0; g < (Cout + 63) / 64; ++g)
     for (int ks = 0; ks < kalloc; ++ks)
       for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 4; ++j) {
           const int co = 64 * g + 16 * j + (lane & 15), ci = 4 * (ks / kk) + (lane >> 4), tap = ks % kk;
           packed[(((size_t)g * kalloc + ks) * 64 + lane) * 4 + j] =
-              (ks < ksteps && ci < Cin) ? weight[((size_t)co * Cin + ci) * kk + tap] : 0.f;
+              (ks < ksteps && ci < Cin && co < Cout) ? weight[((size_t)co * Cin + ci) * kk + tap] : 0.f;
         }
   return FN2_OK;
 }
@@ -983,7 +986,7 @@ FN2_API int fn2_conv_mfma_forward_cpu(const float* bottom, const float* packed, 
                                       int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                                       int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
                                       int relu, float negative_slope) {
-  if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 64 != 0 || kernel < 1 || stride < 1 || pad < 0) return FN2_ERR_INVALID_ARG;
+  if (N < 0 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 32 != 0 || kernel < 1 || stride < 1 || pad < 0) return FN2_ERR_INVALID_ARG;
   if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
   const int Ho = (Hin + 2 * pad - kernel) / stride + 1, Wo = (Win + 2 * pad - kernel) / stride + 1;
   const int quads = (Cin + 3) / 4, kalloc = conv_mfma_ksteps(Cin, kernel) + 8;
