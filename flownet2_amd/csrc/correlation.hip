@@ -171,7 +171,7 @@ FN2_API int fn2_debug_set_correlation_impl(int impl) {
   g_force_generic = (impl == 1);
   fn2::g_corr1d_force_generic = (impl == 1);
   fn2::g_corr_force_dword = (impl == 3);
-  fn2::g_corr_proj = impl == 7 ? 1 : impl == 8 ? 2 : 0;   // profiling builds of the paired-parity forward: 7 = 3/8 of the MFMAs (bf16 x 3 projection), 8 = none (wrong results)
+  fn2::g_corr_proj = impl == 7 ? 1 : impl == 8 ? 2 : impl == 9 ? 3 : 0;   // profiling builds of the paired-parity forward: 7 = 3/8 of the MFMAs (bf16 x 3 projection), 8 = none (wrong results)
   fn2::bwd::g_corr_bwd_first_gen = (impl == 5);
   fn2::bwd::g_corr_bwd_gen = (impl == 6) ? 2 : 0;        // 6 = second-generation MFMA backward (LDS-DMA staging, gathered G)       // 5 = first-generation (register-staged) MFMA backward where the LDS-DMA one applies
   fn2::g_corr_ablation = impl >= 64 ? impl - 64 : 0;

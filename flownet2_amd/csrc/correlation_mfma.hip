@@ -493,7 +493,8 @@ struct HCfg {
 // PROJ (profiling only, wrong results): 0 = the kernel; 1 = only 3 of every 8 MFMAs issue -- the matrix-pipe time a split-bf16
 // (bf16 x 3, 6 products per fp32 product on v_mfma_f32_16x16x16_bf16: 48 cycles per 16 channels against 128) variant would have
 // on the same staging, LDS traffic and epilogue, with the operand split taken as free; 2 = no MFMA at all (the data-movement
-// floor of this structure).  The operands are kept alive by empty asm statements, so the LDS reads stay.
+// floor of this structure); 3 = all the MFMAs, every second LDS-DMA run (half the staging traffic: 46.3 us against 47.3, i.e. the
+// staging volume is NOT what holds this kernel back).  The operands are kept alive by empty asm statements, so the LDS reads stay.
 template <int R, int LO, int HI, int PROJ = 0, typename Acc>
 __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
                                             unsigned lds_base, int lane, int wave, int Jw, int py, int i0, int i2_0, int jS) {
@@ -534,11 +535,13 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_n), 0, sample_bytes, 0x00020000);
   auto run = [&](int i, unsigned slot_bytes, unsigned soff) {
     if (i == H::RPW - 1 && !full) return;                    // wave-uniform
+    if constexpr (PROJ == 3) { if (i & 1) return; }          // profiling: half the staging traffic, all the MFMAs
     lds_ptr_t lp = (lds_ptr_t)(uintptr_t)(slot_bytes + (unsigned)ldst[i]);
     if (isB[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, lp, 16, voff[i], soff, 0, 0);
     else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, lp, 16, voff[i], soff, 0, 0);
   };
   auto wait_landed = [&]() {                                  // everything but the newest chunk's runs has landed
+    if constexpr (PROJ == 3) { wait_vmcnt<H::RPW / 2>(); return; }
     if (full) wait_vmcnt<H::RPW>(); else wait_vmcnt<H::RPW - 1>();
   };
 
@@ -569,7 +572,7 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
     if constexpr (NT > 0) {
       const int t = j >> 1;
       if constexpr (PROJ != 0) {
-        if (PROJ == 2 || (j + 2 * NT * r) % 8 >= 3) {
+        if (PROJ == 2 || (PROJ == 1 && (j + 2 * NT * r) % 8 >= 3)) {
           asm volatile("" ::"v"(o.a[r].x), "v"(o.a[r].y), "v"(o.b[r][t].x), "v"(o.b[r][t].y));
           return;
         }
@@ -610,10 +613,36 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (READ) read_ops(nxt, smem + s1 * H::CHUNK);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (READ && NT > 0 && PROJ == 0) {
+      // The operand reads of chunk c + 1 go BETWEEN the MFMAs of k-step 1, one group (the two first-map operands, then two second-map
+      // tiles at a time) behind each of the first MFMAs.  Issued in one block in front of them (rounds 1-2) they are ~100 cycles in which
+      // this wave feeds nothing to the matrix pipe: hidden while three waves share the SIMD, exposed once the workgroups of a CU have
+      // drifted apart (per-workgroup trace at FlowNetC's shape: the three loops of a CU end at 48k / 68k / 88k cycles).  -1 us of 47.
+      const float* buf = smem + s1 * H::CHUNK;
+      constexpr int GROUPS = 1 + KS * ((NT + 1) / 2);
+      static_assert(GROUPS <= 2 * NT, "one read group per MFMA");
 #pragma unroll
-    for (int j = 0; j < 2 * NT; ++j) mfma_step(cur, 1, j);
+      for (int j = 0; j < 2 * NT; ++j) {
+        mfma_step(cur, 1, j);
+        if (j < GROUPS) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < KS; ++r) nxt.a[r] = *reinterpret_cast<const f32x2*>(buf + aAddr + r * ASTEP);
+          } else {
+            const int r = (j - 1) / ((NT + 1) / 2), t0 = 2 * ((j - 1) % ((NT + 1) / 2));
+#pragma unroll
+            for (int t = t0; t < t0 + 2 && t < NT; ++t) nxt.b[r][t] = *reinterpret_cast<const f32x2*>(buf + bAddr + r * BSTEP + 8 * (LO + t));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      if constexpr (READ) read_ops(nxt, smem + s1 * H::CHUNK);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2 * NT; ++j) mfma_step(cur, 1, j);
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
   using T = std::true_type;
@@ -805,6 +834,15 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
       if (!attr3_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         attr3_set = true;
+      }
+      if (g_corr_proj == 3) {
+        static bool attrq_set = false;
+        if (!attrq_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+          attrq_set = true;
+        }
+        hipLaunchKernelGGL((corr_fwd_pair<R, 3>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+        return check_launch("correlation_forward (mfma, paired parities, projection build)");
       }
       if (g_corr_proj == 1 || g_corr_proj == 2) {
         static bool attrp_set = false;
