@@ -15,10 +15,10 @@ EXPORTS = [
     "fn2_version", "fn2_last_error_string",
     "fn2_correlation_out_shape", "fn2_correlation_workspace_bytes", "fn2_correlation_forward", "fn2_correlation_forward_fused", "fn2_correlation_backward",
     "fn2_correlation1d_out_shape", "fn2_correlation1d_forward", "fn2_correlation1d_backward",
-    "fn2_flow_warp_forward", "fn2_flow_warp_backward_workspace_bytes", "fn2_flow_warp_backward",
-    "fn2_resample_forward",
+    "fn2_flow_warp_forward", "fn2_flow_warp_forward_slices", "fn2_flow_warp_backward_workspace_bytes", "fn2_flow_warp_backward",
+    "fn2_resample_forward", "fn2_resample_forward_slices",
     "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
-    "fn2_channel_norm_forward", "fn2_channel_norm_backward",
+    "fn2_channel_norm_forward", "fn2_channel_norm_forward_slices", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward", "fn2_upsample_flow_deconv_forward_into",
     "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward",
@@ -104,15 +104,18 @@ def lib():
     L.fn2_correlation1d_forward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, i, i, i, i, vp]
     L.fn2_correlation1d_backward.argtypes = [C.POINTER(CorrParams), fp, fp, fp, fp, fp, i, i, i, i, vp]
     L.fn2_flow_warp_forward.argtypes = [fp, fp, fp, i, i, i, i, i, vp]
+    L.fn2_flow_warp_forward_slices.argtypes = [fp, i, i, fp, i, i, fp, i, i, i, i, i, i, i, vp]
     L.fn2_flow_warp_backward_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_flow_warp_backward_workspace_bytes.restype = sz
     L.fn2_flow_warp_backward.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, i, i, vp, sz, vp]
     L.fn2_resample_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, i, vp]
+    L.fn2_resample_forward_slices.argtypes = [fp, C.c_float, fp, i, i, fp, i, i, C.c_float, i, i, i, i, i, i, i, i, vp]
     L.fn2_l1loss_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_l1loss_workspace_bytes.restype = sz
     L.fn2_l1loss_forward.argtypes = [C.POINTER(L1LossParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_l1loss_backward.argtypes = [C.POINTER(L1LossParams), fp, fp, C.c_float, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_channel_norm_forward.argtypes = [fp, fp, i, i, i, i, vp]
+    L.fn2_channel_norm_forward_slices.argtypes = [fp, i, i, fp, i, i, fp, i, i, i, i, i, i, vp]
     L.fn2_channel_norm_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]
     L.fn2_downsample_forward.argtypes = [fp, fp, i, i, i, i, i, i, vp]
     L.fn2_predict_flow_conv_workspace_bytes.argtypes = [i, i, i, i]

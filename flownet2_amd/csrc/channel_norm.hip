@@ -10,18 +10,24 @@
 namespace fn2 {
 
 // grid: (pixel blocks, n) / (pixel blocks, n * C + c); 32-bit pixel index.
-__global__ void __launch_bounds__(256) channel_norm_fwd(const float* __restrict__ bot, float* __restrict__ top,
-                                                        int N, int C, unsigned hw) {
+// bot / sub / top may be channel slices of wider blobs (sample stride = their blob's channel count).  SUB: the norm of bot - sub,
+// i.e. the Eltwise{SUM, coeff 1, -1} in front of the layer in the FlowNet2 graphs folded in (the difference is rounded to fp32
+// before it is squared, exactly as the Eltwise top would have been).
+template <bool SUB>
+__global__ void __launch_bounds__(256) channel_norm_fwd(const float* __restrict__ bot, const float* __restrict__ sub, float* __restrict__ top,
+                                                        int N, int C, unsigned hw, int bctot, int bc0, int sctot, int sc0, int tctot, int tc0) {
   const unsigned s = blockIdx.x * 256u + threadIdx.x;
   if (s >= hw) return;
   for (unsigned n = blockIdx.y; n < (unsigned)N; n += gridDim.y) {
-    const float* p = bot + (size_t)n * C * hw + s;
+    const float* p = bot + ((size_t)n * bctot + bc0) * hw + s;
+    const float* q = SUB ? sub + ((size_t)n * sctot + sc0) * hw + s : nullptr;
     float norm = 0.f;
     for (int c = 0; c < C; ++c) {
-      const float v = p[(size_t)c * hw];
+      float v = p[(size_t)c * hw];
+      if constexpr (SUB) v = v - q[(size_t)c * hw];      // eltwise_layer.cu:  top = 1 * a + (-1) * b
       norm = fmaf(v, v, norm);          // :27-28
     }
-    top[(size_t)n * hw + s] = sqrtf(norm);   // :31-32
+    top[((size_t)n * tctot + tc0) * hw + s] = sqrtf(norm);   // :31-32
   }
 }
 
@@ -146,14 +152,27 @@ __global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restri
 
 using namespace fn2;
 
-FN2_API int fn2_channel_norm_forward(const float* bottom, float* top, int N, int C, int H, int W, void* stream) {
+FN2_API int fn2_channel_norm_forward_slices(const float* bottom, int bottom_channels, int bottom_c0,
+                                            const float* minus, int minus_channels, int minus_c0,
+                                            float* top, int top_channels, int top_c0, int N, int C, int H, int W, void* stream) {
   if (N < 0 || C < 1 || H < 1 || W < 1) return fail(FN2_ERR_INVALID_ARG, "channel_norm: bad shape");
+  if (bottom_c0 < 0 || bottom_c0 + C > bottom_channels || top_c0 < 0 || top_c0 + 1 > top_channels ||
+      (minus && (minus_c0 < 0 || minus_c0 + C > minus_channels)))
+    return fail(FN2_ERR_INVALID_ARG, "channel_norm: channel slice outside its blob");
   if (N == 0) return FN2_OK;
   if (!bottom || !top) return fail(FN2_ERR_INVALID_ARG, "channel_norm: NULL blob pointer");
   if ((long long)H * W >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "channel_norm: plane too large");
   const unsigned hw = (unsigned)H * W;
-  hipLaunchKernelGGL(channel_norm_fwd, dim3((hw + 255) / 256, (unsigned)(N < 65535 ? N : 65535)), dim3(256), 0, as_stream(stream), bottom, top, N, C, hw);
+  const dim3 grid((hw + 255) / 256, (unsigned)(N < 65535 ? N : 65535));
+  if (minus) hipLaunchKernelGGL((channel_norm_fwd<true>), grid, dim3(256), 0, as_stream(stream), bottom, minus, top, N, C, hw,
+                                bottom_channels, bottom_c0, minus_channels, minus_c0, top_channels, top_c0);
+  else hipLaunchKernelGGL((channel_norm_fwd<false>), grid, dim3(256), 0, as_stream(stream), bottom, minus, top, N, C, hw,
+                          bottom_channels, bottom_c0, 0, 0, top_channels, top_c0);
   return check_launch("channel_norm_forward");
+}
+
+FN2_API int fn2_channel_norm_forward(const float* bottom, float* top, int N, int C, int H, int W, void* stream) {
+  return fn2_channel_norm_forward_slices(bottom, C, 0, nullptr, 0, 0, top, 1, 0, N, C, H, W, stream);
 }
 
 FN2_API int fn2_channel_norm_backward(const float* bottom, const float* top, const float* top_diff, float* bottom_diff,

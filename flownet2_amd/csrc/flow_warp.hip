@@ -14,20 +14,22 @@ namespace fn2 {
 constexpr int kWarpChPerThread = 4;
 
 // grid: (pixel blocks, n * cgroups + channel group); 32-bit pixel index (a 64-bit flat index cost more than the warp itself)
+// image / flow / warped may be channel slices of wider blobs: sample n starts ictot (fctot, octot) planes after sample n - 1, the
+// slice at plane ic0 (fc0, oc0).
 __global__ void __launch_bounds__(256) flow_warp_fwd(const float* __restrict__ image, const float* __restrict__ flow,
                                                      float* __restrict__ warped, int N, int C, int H, int W,
-                                                     int cgroups, float fill) {
+                                                     int cgroups, float fill, int ictot, int ic0, int octot, int oc0, int fctot, int fc0) {
   const unsigned wh = (unsigned)H * W;
   const unsigned pix = blockIdx.x * 256u + threadIdx.x;
   if (pix >= wh) return;
   const int y = pix / W, x = pix - y * W;
   for (unsigned g = blockIdx.y; g < (unsigned)N * cgroups; g += gridDim.y) {
     const int n = g / cgroups, cg = g - n * cgroups;
-    const float x2 = (float)x + flow[(size_t)(2 * n) * wh + pix];       // flow_warp_layer.cu:73
-    const float y2 = (float)y + flow[(size_t)(2 * n + 1) * wh + pix];   // :74
+    const float x2 = (float)x + flow[((size_t)n * fctot + fc0) * wh + pix];       // flow_warp_layer.cu:73
+    const float y2 = (float)y + flow[((size_t)n * fctot + fc0 + 1) * wh + pix];   // :74
     const int c0 = cg * kWarpChPerThread;
     const int c1 = min(C, c0 + kWarpChPerThread);
-    float* out = warped + ((size_t)n * C) * wh + pix;
+    float* out = warped + ((size_t)n * octot + oc0) * wh + pix;
     if (x2 >= 0.f && y2 >= 0.f && x2 < (float)W && y2 < (float)H) {    // :108
       const int ixL = (int)x2, iyT = (int)y2;                           // :81-82
       const int ixR = min(ixL + 1, W - 1), iyB = min(iyT + 1, H - 1);   // :83-84
@@ -36,7 +38,7 @@ __global__ void __launch_bounds__(256) flow_warp_fwd(const float* __restrict__ i
       const float cBL = (1 - alpha) * beta, cBR = alpha * beta;
       const unsigned oTL = (unsigned)iyT * W + ixL, oTR = (unsigned)iyT * W + ixR;
       const unsigned oBL = (unsigned)iyB * W + ixL, oBR = (unsigned)iyB * W + ixR;
-      const float* im = image + ((size_t)n * C) * wh;
+      const float* im = image + ((size_t)n * ictot + ic0) * wh;
       for (int c = c0; c < c1; ++c) {
         const float* p = im + (size_t)c * wh;
         // :110-114, contracted like nvcc does: mul + 3 fma
@@ -210,12 +212,16 @@ static int warp_check(const char* what, int N, int C, int H, int W) {
   return FN2_OK;
 }
 
-FN2_API int fn2_flow_warp_forward(const float* image, const float* flow, float* warped, int N, int C, int H, int W,
-                                  int fill_value, void* stream) {
+FN2_API int fn2_flow_warp_forward_slices(const float* image, int image_channels, int image_c0,
+                                         const float* flow, int flow_channels, int flow_c0, float* warped, int top_channels, int top_c0, int N, int C, int H, int W,
+                                         int fill_value, void* stream) {
   int rc = warp_check("flow_warp_forward", N, C, H, W);
   if (rc) return rc;
   if (fill_value != FN2_FILL_ZERO && fill_value != FN2_FILL_NAN)
     return fail(FN2_ERR_INVALID_ARG, "flow_warp_forward: fill_value must be ZERO(1) or NOT_A_NUMBER(2)");
+  if (image_c0 < 0 || image_c0 + C > image_channels || top_c0 < 0 || top_c0 + C > top_channels || flow_c0 < 0 || flow_c0 + 2 > flow_channels)
+    return fail(FN2_ERR_INVALID_ARG, "flow_warp_forward: channel slice [%d,+%d) of %d / [%d,+2) of %d / [%d,+%d) of %d", image_c0, C, image_channels,
+                flow_c0, flow_channels, top_c0, C, top_channels);
   if (N == 0) return FN2_OK;
   if (!image || !flow || !warped) return fail(FN2_ERR_INVALID_ARG, "flow_warp_forward: NULL blob pointer");
   if ((long long)H * W >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "flow_warp_forward: plane too large");
@@ -223,8 +229,14 @@ FN2_API int fn2_flow_warp_forward(const float* image, const float* flow, float* 
   const float fill = (fill_value == FN2_FILL_ZERO) ? 0.f : __builtin_bit_cast(float, 0xFFE00000u);   // flow_warp_layer.cu:372-375
   const long long groups = (long long)N * cgroups;
   const dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)(groups < 65535 ? groups : 65535));
-  hipLaunchKernelGGL(flow_warp_fwd, grid, dim3(256), 0, as_stream(stream), image, flow, warped, N, C, H, W, cgroups, fill);
+  hipLaunchKernelGGL(flow_warp_fwd, grid, dim3(256), 0, as_stream(stream), image, flow, warped, N, C, H, W, cgroups, fill,
+                     image_channels, image_c0, top_channels, top_c0, flow_channels, flow_c0);
   return check_launch("flow_warp_forward");
+}
+
+FN2_API int fn2_flow_warp_forward(const float* image, const float* flow, float* warped, int N, int C, int H, int W,
+                                  int fill_value, void* stream) {
+  return fn2_flow_warp_forward_slices(image, C, 0, flow, 2, 0, warped, C, 0, N, C, H, W, fill_value, stream);
 }
 
 FN2_API size_t fn2_flow_warp_backward_workspace_bytes(int N, int C, int H, int W) {

@@ -28,14 +28,27 @@ struct ResampleArgs {
   float fx, fy, ax, ay;
   int rx, ry;
   int ppt;          // planes per thread (blockIdx.y walks plane groups)
+  // round 3: the layers AROUND a Resample in the FlowNet2 graphs folded in.  in_scale: the Eltwise{coeff} in front of it (every tap is
+  // multiplied -- and rounded -- before it is weighted, as the Eltwise top would have been; 1.0f is exact).  The top may be a channel
+  // slice [oc0, oc0 + C) of a blob with octot channels (the Concat behind it), and a second top out2 = out * out2_scale (the Eltwise
+  // behind it, rounded from the rounded out) may go to a slice of another blob.
+  int C, octot, oc0, o2ctot, o2c0;
+  float in_scale, out2_scale;
 };
+
+__device__ __forceinline__ size_t top_plane(int plane, int C, int ctot, int c0) {     // plane = n * C + c of the logical [N, C] top
+  const int n = plane / C;
+  return (size_t)n * ctot + c0 + (plane - n * C);
+}
+// one rounded product; the empty asm keeps hipcc from contracting it into a neighbouring add
+__device__ __forceinline__ float scaled(float v, float s) { float p = v * s; asm volatile("" : "+v"(p)); return p; }
 
 // Indexing of both kernels: blockIdx.x * 256 + tid = output pixel (32-bit), blockIdx.y = group of `ppt` (n, c) planes.
 // Everything that depends on the pixel only -- source position, tap range, coefficients -- is computed once and reused
 // for the planes of the group (the first version decoded a 64-bit flat index per element and re-evaluated the
 // coefficient of every one of the (2r+1)^2 taps: 30 us for a 10 MB up-sampling).
 
-__global__ void __launch_bounds__(256) resample_nearest(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
+__global__ void __launch_bounds__(256) resample_nearest(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
   if (p >= hw_out) return;
@@ -47,13 +60,16 @@ __global__ void __launch_bounds__(256) resample_nearest(const float* __restrict_
   xr = min(max(xr, 0), a.Win - 1);
   yr = min(max(yr, 0), a.Hin - 1);
   const unsigned src = (unsigned)yr * a.Win + xr;
-  for (int c = blockIdx.y * a.ppt; c < min(a.NC, (int)(blockIdx.y + 1) * a.ppt); ++c)
-    out[(size_t)c * hw_out + p] = in[(size_t)c * hw_in + src];
+  for (int c = blockIdx.y * a.ppt; c < min(a.NC, (int)(blockIdx.y + 1) * a.ppt); ++c) {
+    const float v = scaled(in[(size_t)c * hw_in + src], a.in_scale);
+    out[top_plane(c, a.C, a.octot, a.oc0) * hw_out + p] = v;
+    if (out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
+  }
 }
 
 // FAST: tap radius <= 2 on both axes (every up-sampling and same-size call): the 5 + 5 coefficients live in registers.
 template <bool CUBIC, bool FAST>
-__global__ void __launch_bounds__(256) resample_interp(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
+__global__ void __launch_bounds__(256) resample_interp(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
   if (p >= hw_out) return;
@@ -96,9 +112,11 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
         for (int i = 0; i < 5; ++i) {
           const float w = px[i] * ky[j];
           // in-image taps are read even when their coefficient is 0: a NaN there poisons the result in the reference too
-          sum = fmaf(w, ((mx >> i) & (my >> j) & 1u) ? src[yo[j] + xo[i]] : 0.f, sum);
+          sum = fmaf(w, ((mx >> i) & (my >> j) & 1u) ? scaled(src[yo[j] + xo[i]], a.in_scale) : 0.f, sum);
         }
-      out[(size_t)c * hw_out + p] = (!wsum) ? 0.f : (sum / wsum);   // :93
+      const float v = (!wsum) ? 0.f : (sum / wsum);   // :93
+      out[top_plane(c, a.C, a.octot, a.oc0) * hw_out + p] = v;
+      if (out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
     }
   } else {
     const int y0 = max(yr - a.ry, 0), y1 = min(yr + a.ry, a.Hin - 1);
@@ -111,11 +129,13 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
         for (int x = x0; x <= x1; ++x) {
           const float dx = x_in - x;
           const float w = a.ax * (CUBIC ? bicubic_coeff(a.ax * dx) : triangle_coeff(a.ax * dx)) * a.ay * kyv;
-          sum = fmaf(w, src[(size_t)y * a.Win + x], sum);
+          sum = fmaf(w, scaled(src[(size_t)y * a.Win + x], a.in_scale), sum);
           wsum += w;
         }
       }
-      out[(size_t)c * hw_out + p] = (!wsum) ? 0.f : (sum / wsum);   // :93
+      const float v = (!wsum) ? 0.f : (sum / wsum);   // :93
+      out[top_plane(c, a.C, a.octot, a.oc0) * hw_out + p] = v;
+      if (out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
     }
   }
 }
@@ -128,7 +148,7 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
 // 0 * NaN / 0 * Inf would have poisoned the sums (the sign of a zero sum aside, the result is the reference's) -- and each output is
 // 9 fused multiply-adds in the reference's order plus the sum / wsum division (:93).  Stores are whole 16-byte (8-byte) rows.
 template <int F>
-__global__ void __launch_bounds__(256) resample_up_linear(const float* __restrict__ in, float* __restrict__ out, ResampleArgs a) {
+__global__ void __launch_bounds__(256) resample_up_linear(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
   if (p >= hw_in) return;
@@ -176,11 +196,13 @@ __global__ void __launch_bounds__(256) resample_up_linear(const float* __restric
     for (int r = 0; r < 5; ++r)
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        const float s = ((mx >> t) & (my >> r) & 1u) ? src[yo[r] + xo[t]] : 0.f;
+        const float s = ((mx >> t) & (my >> r) & 1u) ? scaled(src[yo[r] + xo[t]], a.in_scale) : 0.f;
         if (r >= 1 && r <= 3 && t >= 1 && t <= 3) v[r - 1][t - 1] = s;
         else poison = fmaf(0.f, s, poison);
       }
-    float* dst = out + (size_t)c * hw_out + (size_t)(F * i) * a.Wout + F * j;
+    const size_t pix0 = (size_t)(F * i) * a.Wout + F * j;
+    float* dst = out + top_plane(c, a.C, a.octot, a.oc0) * hw_out + pix0;
+    float* dst2 = out2 ? out2 + top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + pix0 : nullptr;
 #pragma unroll
     for (int py = 0; py < F; ++py) {
       vec_t o;
@@ -195,6 +217,12 @@ __global__ void __launch_bounds__(256) resample_up_linear(const float* __restric
         o[qx] = (!ws) ? 0.f : (ws == 1.0f ? sum : sum / ws);
       }
       *reinterpret_cast<vec_t*>(dst + (size_t)py * a.Wout) = o;
+      if (dst2) {
+        vec_t o2;
+#pragma unroll
+        for (int qx = 0; qx < F; ++qx) o2[qx] = scaled(o[qx], a.out2_scale);
+        *reinterpret_cast<vec_t*>(dst2 + (size_t)py * a.Wout) = o2;
+      }
     }
   }
 }
@@ -206,15 +234,20 @@ using namespace fn2;
 static int g_resample_generic = 0;     // test hook: 1 = always the per-output-pixel kernels
 FN2_API int fn2_debug_set_resample_generic(int on) { g_resample_generic = on; return FN2_OK; }
 
-FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int Hin, int Win, int Hout, int Wout,
-                                 int type, int antialias_param, void* stream) {
+FN2_API int fn2_resample_forward_slices(const float* in, float in_scale, float* out, int top_channels, int top_c0,
+                                        float* out2, int top2_channels, int top2_c0, float out2_scale,
+                                        int N, int C, int Hin, int Win, int Hout, int Wout, int type, int antialias_param, void* stream) {
   if (N < 0 || C < 1 || Hin < 1 || Win < 1) return fail(FN2_ERR_INVALID_ARG, "resample: bad bottom shape");
   if (Hout < 1 || Wout < 1) return fail(FN2_ERR_INVALID_ARG, "ResampleLayer must have top_height > 0 and top_width > 0");
   if (type != FN2_RESAMPLE_NEAREST && type != FN2_RESAMPLE_LINEAR && type != FN2_RESAMPLE_CUBIC)
     return fail(FN2_ERR_UNSUPPORTED, "ResampleLayer: only CUBIC, LINEAR and NEAREST interpolation is supported for now");
   if (N == 0) return FN2_OK;
   if (!in || !out) return fail(FN2_ERR_INVALID_ARG, "resample: NULL blob pointer");
+  if (top_c0 < 0 || top_c0 + C > top_channels || (out2 && (top2_c0 < 0 || top2_c0 + C > top2_channels)))
+    return fail(FN2_ERR_INVALID_ARG, "resample: channel slice outside its blob");
   ResampleArgs a;
+  a.C = C; a.octot = top_channels; a.oc0 = top_c0; a.o2ctot = out2 ? top2_channels : C; a.o2c0 = out2 ? top2_c0 : 0;
+  a.in_scale = in_scale; a.out2_scale = out2_scale;
   a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
   a.fx = (float)Win / (float)Wout;                              // :146
   a.fy = (float)Hin / (float)Hout;                              // :147
@@ -237,23 +270,28 @@ FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int 
   const bool fast = a.rx <= 2 && a.ry <= 2;
   // exact x2 / x4 LINEAR up-sampling: one thread per INPUT pixel (resample_up_linear)
   const int up = (Wout == 4 * Win && Hout == 4 * Hin) ? 4 : (Wout == 2 * Win && Hout == 2 * Hin) ? 2 : 0;
-  if (type == FN2_RESAMPLE_LINEAR && up && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && !g_resample_generic) {
+  if (type == FN2_RESAMPLE_LINEAR && up && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0 && !g_resample_generic) {
     const unsigned bxi = (unsigned)(((long long)Hin * Win + 255) / 256);
     a.ppt = 1;
     while (a.ppt < 4 && (long long)bxi * ((a.NC + 2 * a.ppt - 1) / (2 * a.ppt)) >= 8192) a.ppt *= 2;     // >= 8k workgroups before planes share a thread: the kernel is latency-bound (25 loads, then 16 stores)
     const dim3 gi(bxi, (unsigned)((a.NC + a.ppt - 1) / a.ppt));
     if (gi.y > 65535u) return fail(FN2_ERR_UNSUPPORTED, "resample: too many planes");
-    if (up == 4) hipLaunchKernelGGL((resample_up_linear<4>), gi, dim3(256), 0, st, in, out, a);
-    else hipLaunchKernelGGL((resample_up_linear<2>), gi, dim3(256), 0, st, in, out, a);
+    if (up == 4) hipLaunchKernelGGL((resample_up_linear<4>), gi, dim3(256), 0, st, in, out, out2, a);
+    else hipLaunchKernelGGL((resample_up_linear<2>), gi, dim3(256), 0, st, in, out, out2, a);
     return check_launch("resample_forward");
   }
-  if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, grid, dim3(256), 0, st, in, out, a);
+  if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, grid, dim3(256), 0, st, in, out, out2, a);
   else if (type == FN2_RESAMPLE_CUBIC) {
-    if (fast) hipLaunchKernelGGL((resample_interp<true, true>), grid, dim3(256), 0, st, in, out, a);
-    else hipLaunchKernelGGL((resample_interp<true, false>), grid, dim3(256), 0, st, in, out, a);
+    if (fast) hipLaunchKernelGGL((resample_interp<true, true>), grid, dim3(256), 0, st, in, out, out2, a);
+    else hipLaunchKernelGGL((resample_interp<true, false>), grid, dim3(256), 0, st, in, out, out2, a);
   } else {
-    if (fast) hipLaunchKernelGGL((resample_interp<false, true>), grid, dim3(256), 0, st, in, out, a);
-    else hipLaunchKernelGGL((resample_interp<false, false>), grid, dim3(256), 0, st, in, out, a);
+    if (fast) hipLaunchKernelGGL((resample_interp<false, true>), grid, dim3(256), 0, st, in, out, out2, a);
+    else hipLaunchKernelGGL((resample_interp<false, false>), grid, dim3(256), 0, st, in, out, out2, a);
   }
   return check_launch("resample_forward");
+}
+
+FN2_API int fn2_resample_forward(const float* in, float* out, int N, int C, int Hin, int Win, int Hout, int Wout,
+                                 int type, int antialias_param, void* stream) {
+  return fn2_resample_forward_slices(in, 1.0f, out, C, 0, nullptr, 0, 0, 1.0f, N, C, Hin, Win, Hout, Wout, type, antialias_param, stream);
 }

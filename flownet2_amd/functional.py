@@ -114,6 +114,24 @@ def resample(x, height, width, type=ops.LINEAR, antialias=True):
         return ops.resample_forward(x.detach().contiguous(), height, width, type, antialias)
 
 
+def resample_slices(x, height, width, type=ops.LINEAR, antialias=True, in_scale=1.0, out=None, out2=None, out2_scale=1.0):
+    """Resample(x * in_scale) written into a channel slice (blob, c0, C); out2 = top * out2_scale into a second slice (no autograd)."""
+    with torch.no_grad():
+        return ops.resample_forward_slices(x.detach().contiguous(), height, width, type, antialias, in_scale, out, out2, out2_scale)
+
+
+def flow_warp_slices(image, flow, out=None, fill_value=ops.FILL_ZERO):
+    """FlowWarp over channel slices (blob, c0, C) of wider blobs (no autograd: deploy graphs)."""
+    with torch.no_grad():
+        return ops.flow_warp_forward_slices(image, flow, out, fill_value)
+
+
+def channel_norm_slices(x, minus=None, out=None):
+    """ChannelNorm(x - minus) over channel slices, top into one channel of a wider blob (no autograd: deploy graphs)."""
+    with torch.no_grad():
+        return ops.channel_norm_forward_slices(x, minus, out)
+
+
 def downsample(x, top_height, top_width):
     with torch.no_grad():
         return ops.downsample_forward(x.detach().contiguous(), top_height, top_width)

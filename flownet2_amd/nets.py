@@ -220,15 +220,34 @@ def _any_requires_grad(P) -> bool:
     return any(v.requires_grad for v in vals)
 
 
-def _concat(blob, skip, pieces):
-    """Concat([skip] + pieces): with a blob from _conv_into_concat only the (small) remaining pieces are copied."""
+def _refine_stage(P, skip, x, dname, flow, uname, backend):
+    """One refinement Concat [skip | ReLU(deconv(x)) | upsampled flow].  `skip` is a tensor or a pair (concat blob, tensor) from
+    _conv_into_concat: with a blob the Concat layer (concat_layer.cu:8-52) has nothing to copy -- the skip convolution already wrote its
+    channels there, and the deconvolution and the upsampled flow are written behind them by their own kernels."""
+    def up(t, name, out=None, out_c0=0):
+        if backend is not None and hasattr(backend, "upsample_flow_deconv"):
+            if out is not None:
+                return backend.upsample_flow_deconv(t, P[name + ".w"], P[name + ".b"], out=out, out_c0=out_c0)
+            return backend.upsample_flow_deconv(t, P[name + ".w"], P[name + ".b"])
+        return _deconv(t, P, name, act=False)
+
+    blob, s = skip if isinstance(skip, tuple) else (None, skip)
     if blob is None:
-        return torch.cat([skip] + pieces, 1)
-    c = skip.shape[1]
-    for t in pieces:
-        blob[:, c:c + t.shape[1]].copy_(t)
-        c += t.shape[1]
-    assert c == blob.shape[1]
+        return torch.cat([s, _deconv(x, P, dname, backend=backend), up(flow, uname)], 1)
+    cs, cd = s.shape[1], P[dname + ".w"].shape[1]
+    assert blob.shape[1] == cs + cd + 2
+    d = None
+    if hasattr(backend, "deconv_mfma_relu"):
+        d = backend.deconv_mfma_relu(x, P[dname + ".w"], P[dname + ".b"], NEG_SLOPE, True, out=blob, out_c0=cs)
+    if d is None and hasattr(backend, "deconv_gemm_relu") and P[dname + ".w"].shape[0] >= 64:
+        # GEMM (weight^T x bottom), then our col2im + bias + ReLU pass straight into the blob
+        d = backend.deconv_gemm_relu(x, _transposed_deconv_weight(P[dname + ".w"]), P[dname + ".b"], cd, 4, 2, 1, NEG_SLOPE, out=blob, out_c0=cs)
+    if d is None:
+        blob[:, cs:cs + cd].copy_(_deconv(x, P, dname, backend=backend))
+    if hasattr(backend, "upsample_flow_deconv"):
+        up(flow, uname, out=blob, out_c0=cs + cd)
+    else:
+        blob[:, cs + cd:].copy_(up(flow, uname))
     return blob
 
 
@@ -243,32 +262,8 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
             return backend.predict_flow_conv(x, P[name + ".w"], P[name + ".b"])
         return _conv(x, P, name, 1, 1, act=False, backend=backend)
 
-    def up(x, name, out=None, out_c0=0):
-        if backend is not None and hasattr(backend, "upsample_flow_deconv"):
-            if out is not None:
-                return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"], out=out, out_c0=out_c0)
-            return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"])
-        return _deconv(x, P, name, act=False)
-
     def stage(skip, x, dname, flow, uname):
-        blob, s = skip if isinstance(skip, tuple) else (None, skip)
-        if blob is None:
-            return torch.cat([s, _deconv(x, P, dname, backend=backend), up(flow, uname)], 1)
-        cs, cd = s.shape[1], P[dname + ".w"].shape[1]
-        assert blob.shape[1] == cs + cd + 2
-        d = None
-        if hasattr(backend, "deconv_mfma_relu"):
-            d = backend.deconv_mfma_relu(x, P[dname + ".w"], P[dname + ".b"], NEG_SLOPE, True, out=blob, out_c0=cs)
-        if d is None and hasattr(backend, "deconv_gemm_relu") and P[dname + ".w"].shape[0] >= 64:
-            # library GEMM (weight^T x bottom), then our col2im + bias + ReLU pass straight into the blob
-            d = backend.deconv_gemm_relu(x, _transposed_deconv_weight(P[dname + ".w"]), P[dname + ".b"], cd, 4, 2, 1, NEG_SLOPE, out=blob, out_c0=cs)
-        if d is None:
-            blob[:, cs:cs + cd].copy_(_deconv(x, P, dname, backend=backend))
-        if hasattr(backend, "upsample_flow_deconv"):
-            up(flow, uname, out=blob, out_c0=cs + cd)
-        else:
-            blob[:, cs + cd:].copy_(up(flow, uname))
-        return blob
+        return _refine_stage(P, skip, x, dname, flow, uname, backend)
 
     flow6 = pf(conv6_1, "Convolution1")
     c5 = stage(conv5_1, conv6_1, "deconv5", flow6, "upsample_flow6to5")
@@ -506,29 +501,23 @@ def _pf(P, x, name, backend):
     return _conv(x, P, name, 1, 1, act=False, backend=backend)
 
 
-def _up(P, x, name, backend):
-    if backend is not None and hasattr(backend, "upsample_flow_deconv"):
-        return backend.upsample_flow_deconv(x, P[name + ".w"], P[name + ".b"])
-    return _deconv(x, P, name, act=False)
-
-
 def flownet_sd_core(P, x, backend):
     c0 = _conv(x, P, "conv0", 1, 1, backend=backend)
     c1 = _conv(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, backend=backend)
     # the skip tensors of the two finest decoder levels are written straight into their Concat blobs (66 / 66 % of those copies)
     blob2, c2 = _conv_into_concat(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, 64 + 2, backend)
     blob3, c3 = _conv_into_concat(_conv(c2, P, "conv3", 2, 1, backend=backend), P, "conv3_1", 1, 1, 128 + 2, backend)
-    c4 = _conv(_conv(c3, P, "conv4", 2, 1, backend=backend), P, "conv4_1", 1, 1, backend=backend)
-    c5 = _conv(_conv(c4, P, "conv5", 2, 1, backend=backend), P, "conv5_1", 1, 1, backend=backend)
+    blob4, c4 = _skip_conv(_conv(c3, P, "conv4", 2, 1, backend=backend), P, "conv4_1", 1, 1, "deconv4", backend)
+    blob5, c5 = _skip_conv(_conv(c4, P, "conv5", 2, 1, backend=backend), P, "conv5_1", 1, 1, "deconv5", backend)
     c6 = _conv(_conv(c5, P, "conv6", 2, 1, backend=backend), P, "conv6_1", 1, 1, backend=backend)
     flow6 = _pf(P, c6, "Convolution1", backend)
-    cat5 = torch.cat([c5, _deconv(c6, P, "deconv5", backend=backend), _up(P, flow6, "upsample_flow6to5", backend)], 1)
+    cat5 = _refine_stage(P, (blob5, c5), c6, "deconv5", flow6, "upsample_flow6to5", backend)
     flow5 = _pf(P, _conv(cat5, P, "interconv5", 1, 1, act=False, backend=backend), "Convolution2", backend)
-    cat4 = torch.cat([c4, _deconv(cat5, P, "deconv4", backend=backend), _up(P, flow5, "upsample_flow5to4", backend)], 1)
+    cat4 = _refine_stage(P, (blob4, c4), cat5, "deconv4", flow5, "upsample_flow5to4", backend)
     flow4 = _pf(P, _conv(cat4, P, "interconv4", 1, 1, act=False, backend=backend), "Convolution3", backend)
-    cat3 = _concat(blob3, c3, [_deconv(cat4, P, "deconv3", backend=backend), _up(P, flow4, "upsample_flow4to3", backend)])
+    cat3 = _refine_stage(P, (blob3, c3), cat4, "deconv3", flow4, "upsample_flow4to3", backend)
     flow3 = _pf(P, _conv(cat3, P, "interconv3", 1, 1, act=False, backend=backend), "Convolution4", backend)
-    cat2 = _concat(blob2, c2, [_deconv(cat3, P, "deconv2", backend=backend), _up(P, flow3, "upsample_flow3to2", backend)])
+    cat2 = _refine_stage(P, (blob2, c2), cat3, "deconv2", flow3, "upsample_flow3to2", backend)
     return _pf(P, _conv(cat2, P, "interconv2", 1, 1, act=False, backend=backend), "Convolution5", backend)      # 1/4 resolution, units of 1/SD_FLOW_SCALE px
 
 
@@ -539,9 +528,9 @@ def fusion_core(P, x, backend):
     blob1, c1 = _conv_into_concat(_conv(c0, P, "conv1", 2, 1, backend=backend), P, "conv1_1", 1, 1, 32 + 2, backend)
     c2 = _conv(_conv(c1, P, "conv2", 2, 1, backend=backend), P, "conv2_1", 1, 1, backend=backend)
     flow2 = _pf(P, c2, "Convolution5", backend)
-    cat1 = _concat(blob1, c1, [_deconv(c2, P, "deconv1", backend=backend), _up(P, flow2, "upsample_flow2to1", backend)])
+    cat1 = _refine_stage(P, (blob1, c1), c2, "deconv1", flow2, "upsample_flow2to1", backend)
     flow1 = _pf(P, _conv(cat1, P, "interconv1", 1, 1, act=False, backend=backend), "Convolution6", backend)
-    cat0 = _concat(blob0, c0, [_deconv(cat1, P, "deconv0", backend=backend), _up(P, flow1, "upsample_flow1to0", backend)])
+    cat0 = _refine_stage(P, (blob0, c0), cat1, "deconv0", flow1, "upsample_flow1to0", backend)
     return _pf(P, _conv(cat0, P, "interconv0", 1, 1, act=False, backend=backend), "Convolution7", backend)        # full resolution, pixels
 
 
@@ -553,6 +542,8 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     neg_mean = _const(img0.device, (-0.411, -0.433, -0.45)) if mean is None else (-mean).contiguous()
     if mean is None:
         mean = _const(img0.device, (0.411, 0.433, 0.45))
+    if img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "resample_slices"):
+        return _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean)
     if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "scale_shift"):
         # LINEAR Resample at equal size is the identity: scale and mean in one pass per image (two roundings, like the two layers)
         a = backend.scale_shift(img0, 1.0 / 255.0, neg_mean)
@@ -578,6 +569,59 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     err_sd = backend.channel_norm(a - backend.flow_warp(b, flow_sd))
     fuse_in = torch.cat([a, flow_sd, flow_css, backend.channel_norm(flow_sd), backend.channel_norm(flow_css), err_sd, err_css], 1)
     flow = fusion_core(_Prefixed(P, "fuse_"), fuse_in, backend)
+    flow = backend.resample(flow, H, W)
+    scale = _const(flow.device, (W / float(aw), H / float(ah)))
+    return flow * scale.view(1, 2, 1, 1)
+
+
+def _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean):
+    """The same graph on the GPU backend without its glue passes: the Concat blobs are allocated once and every producer writes its
+    channel slice (fn2_*_slices), the Eltwise scalings (x20 in front of a Resample, x0.05 behind it, img0 - warped in front of a
+    ChannelNorm) ride in the kernels of their neighbours with the same roundings.  Per forward this removes 7 Concat copies and 19
+    element-wise passes over full-resolution blobs; results equal the layer-by-layer graph bit for bit
+    (tests/test_gpu_parity.py::test_flownet2_slice_path_is_bitwise_the_layer_graph)."""
+    N, _, H, W = img0.shape
+    ah, aw = adapted_size(H, W)
+    dev = img0.device
+    new = lambda c: torch.empty((N, c, ah, aw), device=dev, dtype=torch.float32)
+    towers = torch.empty((2 * N, 3, ah, aw), device=dev, dtype=torch.float32)     # FlowNetC's siamese batch [img0 ; img1]
+    blob = new(12)            # Concat of net2 / net3: [img0 | img1 | warped img1 | flow / 20 | brightness error]
+    pair = new(6)             # Concat of FlowNet-SD: [img0 | img1]
+    fuse = new(11)            # Concat of the fusion net: [img0 | flow_sd | flow_css | |flow_sd| | |flow_css| | err_sd | err_css]
+    for k, img in enumerate((img0, img1)):
+        if (ah, aw) == (H, W):   # LINEAR Resample at equal size is the identity: Eltwise{1/255} and the mean subtraction in one pass
+            src, s = img, 1.0 / 255.0
+        else:                    # Eltwise{1/255} folded into the Resample, then the mean subtraction
+            src, s = backend.resample_slices(img, ah, aw, in_scale=1.0 / 255.0), 1.0
+        backend.scale_shift(src, s, neg_mean, out=towers[k * N:(k + 1) * N])
+        backend.scale_shift(src, s, neg_mean, out=blob, out_c0=3 * k)
+        backend.scale_shift(src, s, neg_mean, out=pair, out_c0=3 * k)
+        if k == 0:
+            backend.scale_shift(src, s, neg_mean, out=fuse, out_c0=0)
+    A, B, WARPED = (blob, 0, 3), (blob, 3, 3), (blob, 6, 3)
+
+    def refine_input(flow_q):                       # flow_q: 1/4 resolution, units px/20 -> channels 6..11 of `blob`
+        flow = backend.resample_slices(flow_q, ah, aw, in_scale=FLOW_SCALE, out2=(blob, 9, 2), out2_scale=1.0 / FLOW_SCALE)
+        backend.flow_warp_slices(B, flow, out=WARPED)
+        backend.channel_norm_slices(A, minus=WARPED, out=(blob, 11, 1))
+
+    flow1_q = flownet_c_core(P, None, None, backend, towers=towers)[2]
+    refine_input(flow1_q)
+    flow2_q = flownet_s_core(_Prefixed(P, "net2_"), blob, backend)[2]
+    refine_input(flow2_q)                           # net2's conv1 has read the blob (stream order): channels 6..11 are rewritten in place
+    flow3_q = flownet_s_core(_Prefixed(P, "net3_"), blob, backend)[2]
+    sd_q = flownet_sd_core(_Prefixed(P, "netsd_"), pair, backend)
+    backend.resample_slices(sd_q, ah, aw, type=1, in_scale=SD_FLOW_SCALE, out=(fuse, 3, 2))        # NEAREST into the fusion net (Appendix B)
+    backend.resample_slices(flow3_q, ah, aw, type=1, in_scale=FLOW_SCALE, out=(fuse, 5, 2))
+    backend.channel_norm_slices((fuse, 3, 2), out=(fuse, 7, 1))
+    backend.channel_norm_slices((fuse, 5, 2), out=(fuse, 8, 1))
+    backend.flow_warp_slices(B, (fuse, 3, 2), out=WARPED)
+    backend.channel_norm_slices(A, minus=WARPED, out=(fuse, 9, 1))
+    backend.flow_warp_slices(B, (fuse, 5, 2), out=WARPED)
+    backend.channel_norm_slices(A, minus=WARPED, out=(fuse, 10, 1))
+    flow = fusion_core(_Prefixed(P, "fuse_"), fuse, backend)
+    if (ah, aw) == (H, W):
+        return flow               # Resample to an equal size and the Eltwise{1, 1} behind it are identities
     flow = backend.resample(flow, H, W)
     scale = _const(flow.device, (W / float(aw), H / float(ah)))
     return flow * scale.view(1, 2, 1, 1)

@@ -128,6 +128,38 @@ def flow_warp_forward(image, flow, fill_value=FILL_ZERO):
     return out
 
 
+def _as_slice(arg, what):
+    """A blob argument of the *_slices entry points: a plain [N,C,H,W] tensor, or (blob, c0, C) = channels [c0, c0 + C) of a wider
+    contiguous blob.  -> (blob, channels of the blob, c0, C)."""
+    if isinstance(arg, tuple):
+        blob, c0, Cc = arg
+        if isinstance(blob, torch.Tensor) and not blob.is_contiguous():
+            raise ValueError(what + ": a sliced blob must be contiguous")
+        blob = _chk(blob, what)
+        if c0 < 0 or Cc < 1 or c0 + Cc > blob.shape[1]:
+            raise ValueError("%s: channel slice [%d, %d) outside a blob of %d channels" % (what, c0, c0 + Cc, blob.shape[1]))
+        return blob, int(blob.shape[1]), int(c0), int(Cc)
+    t = _chk(arg, what)
+    return t, int(t.shape[1]), 0, int(t.shape[1])
+
+
+def flow_warp_forward_slices(image, flow, out=None, fill_value=FILL_ZERO):
+    """FlowWarp whose image bottom and top may be channel slices (blob, c0, C) of wider blobs (the Concat around it disappears).
+    Returns the top blob (a new [N,C,H,W] one if `out` is None)."""
+    im, ictot, ic0, Cc = _as_slice(image, "bottom[0] (image)")
+    fl, fctot, fc0, Cf = _as_slice(flow, "bottom[1] (flow)")
+    N, _, H, W = im.shape
+    if fl.shape[0] != N or Cf != 2 or tuple(fl.shape[2:]) != (H, W):
+        raise ValueError("flow_warp: flow must be [N,2,H,W] of the image's size")
+    if out is None:
+        out = torch.empty((N, Cc, H, W), device=im.device, dtype=torch.float32)
+    top, octot, oc0, Co = _as_slice(out, "top[0]")
+    if Co != Cc or top.shape[0] != N or tuple(top.shape[2:]) != (H, W):
+        raise ValueError("flow_warp: top slice does not match the image")
+    check(_lib.lib().fn2_flow_warp_forward_slices(_ptr(im), ictot, ic0, _ptr(fl), fctot, fc0, _ptr(top), octot, oc0, N, Cc, H, W, int(fill_value), _stream()))
+    return top
+
+
 def flow_warp_backward(image, flow, warped_diff, propagate_image=True, propagate_flow=True):
     im, fl, wd = _chk(image, "image"), _chk(flow, "flow"), _chk(warped_diff, "top.diff")
     N, Cc, H, W = im.shape
@@ -147,6 +179,29 @@ def resample_forward(x, height, width, type=LINEAR, antialias=True):
     out = torch.empty((N, Cc, int(height), int(width)), device=x.device, dtype=torch.float32)
     check(_lib.lib().fn2_resample_forward(_ptr(x), _ptr(out), N, Cc, H, W, int(height), int(width), int(type), int(bool(antialias)), _stream()))
     return out
+
+
+def resample_forward_slices(x, height, width, type=LINEAR, antialias=True, in_scale=1.0, out=None, out2=None, out2_scale=1.0):
+    """Resample(x * in_scale) into a channel slice `out` = (blob, c0, C) (a new blob if None); out2 (optional slice) = top * out2_scale.
+    The Eltwise scalings and the Concat the FlowNet2 graphs put around the layer, without their passes.  Returns the `out` blob."""
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    if height < 1 or width < 1:
+        raise ValueError("ResampleLayer must have top_height > 0 and top_width > 0")
+    if out is None:
+        out = torch.empty((N, Cc, int(height), int(width)), device=x.device, dtype=torch.float32)
+    top, octot, oc0, Co = _as_slice(out, "top[0]")
+    if Co != Cc or top.shape[0] != N or tuple(top.shape[2:]) != (int(height), int(width)):
+        raise ValueError("resample: top slice does not match")
+    t2, o2ctot, o2c0 = None, 0, 0
+    if out2 is not None:
+        t2, o2ctot, o2c0, C2 = _as_slice(out2, "top[1]")
+        if C2 != Cc or t2.shape[0] != N or tuple(t2.shape[2:]) != (int(height), int(width)):
+            raise ValueError("resample: second top slice does not match")
+    check(_lib.lib().fn2_resample_forward_slices(_ptr(x), C.c_float(float(in_scale)), _ptr(top), octot, oc0, _ptr(t2), o2ctot, o2c0,
+                                                 C.c_float(float(out2_scale)), N, Cc, H, W, int(height), int(width), int(type),
+                                                 int(bool(antialias)), _stream()))
+    return top
 
 
 def l1_params(l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False, epsilon=1e-2, plateau=0.0):
@@ -190,6 +245,24 @@ def channel_norm_forward(x):
     out = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
     check(_lib.lib().fn2_channel_norm_forward(_ptr(x), _ptr(out), N, Cc, H, W, _stream()))
     return out
+
+
+def channel_norm_forward_slices(x, minus=None, out=None):
+    """ChannelNorm(x - minus) (minus optional) over channel slices (blob, c0, C); out = (blob, c0, 1) or None for a new [N,1,H,W] blob."""
+    b, bctot, bc0, Cc = _as_slice(x, "bottom[0]")
+    N, _, H, W = b.shape
+    m, mctot, mc0 = None, 0, 0
+    if minus is not None:
+        m, mctot, mc0, Cm = _as_slice(minus, "bottom[1]")
+        if Cm != Cc or tuple(m.shape[2:]) != (H, W) or m.shape[0] != N:
+            raise ValueError("channel_norm: the subtrahend does not match the bottom")
+    if out is None:
+        out = torch.empty((N, 1, H, W), device=b.device, dtype=torch.float32)
+    top, tctot, tc0, Ct = _as_slice(out, "top[0]")
+    if Ct != 1 or top.shape[0] != N or tuple(top.shape[2:]) != (H, W):
+        raise ValueError("channel_norm: top slice must be one channel of the bottom's size")
+    check(_lib.lib().fn2_channel_norm_forward_slices(_ptr(b), bctot, bc0, _ptr(m), mctot, mc0, _ptr(top), tctot, tc0, N, Cc, H, W, _stream()))
+    return top
 
 
 def channel_norm_backward(x, top, top_diff):

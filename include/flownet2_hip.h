@@ -129,6 +129,14 @@ enum { FN2_FILL_ZERO = 1, FN2_FILL_NAN = 2 };
 /* image [N,C,H,W], flow [N,2,H,W] (channel 0 = x/u, 1 = y/v), warped [N,C,H,W]. */
 int fn2_flow_warp_forward(const float* image, const float* flow, float* warped,
                           int N, int C, int H, int W, int fill_value, void* stream);
+/* The same layer reading / writing CHANNEL SLICES of wider blobs: image = channels [image_c0, image_c0 + C) of a contiguous
+ * [N, image_channels, H, W] blob, warped likewise inside [N, top_channels, H, W].  This is what the Concat layers around FlowWarp in
+ * the FlowNet2 graphs amount to (concat_layer.cu:33-60 copies every bottom into the top; a producer that writes the slice and a
+ * consumer that reads it make the copy disappear).  flow = channels [flow_c0, flow_c0 + 2) of a [N, flow_channels, H, W] blob. */
+int fn2_flow_warp_forward_slices(const float* image, int image_channels, int image_c0,
+                                 const float* flow, int flow_channels, int flow_c0,
+                                 float* warped, int top_channels, int top_c0,
+                                 int N, int C, int H, int W, int fill_value, void* stream);
 /* image_diff [N,C,H,W] and flow_diff [N,2,H,W] are both overwritten.  propagate_* == 0 leaves the
  * corresponding diff zero, as flow_warp_layer.cu:507-508 does.  The reference accumulates image_diff with
  * float atomics (:197-200: order not deterministic); here the scatter is inverted through per-pixel
@@ -153,6 +161,15 @@ enum { FN2_RESAMPLE_NEAREST = 1, FN2_RESAMPLE_LINEAR = 2, FN2_RESAMPLE_CUBIC = 3
 int fn2_resample_forward(const float* in, float* out, int N, int C,
                          int Hin, int Win, int Hout, int Wout,
                          int type, int antialias, void* stream);
+/* Resample with the layers the FlowNet2 graphs put around it folded in (FlowNet2_deploy.prototxt: Eltwise{coeff 20} -> Resample ->
+ * {FlowWarp, Eltwise{coeff 0.05} -> Concat}): every tap is in * in_scale (one rounding, as the Eltwise top would have had:
+ * eltwise_layer.cu:46-51 caffe_gpu_axpy), out goes to channels [top_c0, top_c0 + C) of a [N, top_channels, Hout, Wout] blob, and
+ * out2 (may be NULL) = out * out2_scale, rounded from the rounded out, to a slice of a second blob.  in_scale = out2_scale = 1 and
+ * full-width tops reproduce fn2_resample_forward bit for bit. */
+int fn2_resample_forward_slices(const float* in, float in_scale, float* out, int top_channels, int top_c0,
+                                float* out2, int top2_channels, int top2_c0, float out2_scale,
+                                int N, int C, int Hin, int Win, int Hout, int Wout,
+                                int type, int antialias, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * L1Loss  (type: "L1Loss")
@@ -192,6 +209,13 @@ int fn2_l1loss_backward(const fn2_l1loss_params* p, const float* bottom0, const 
  *              a reference bug; we implement what NormBackward :37-47 computes)
  * ---------------------------------------------------------------------------------------------- */
 int fn2_channel_norm_forward(const float* bottom, float* top, int N, int C, int H, int W, void* stream);
+/* ChannelNorm over channel slices of wider blobs; minus != NULL: the norm of (bottom - minus), i.e. the Eltwise{SUM, coeff 1, -1}
+ * the FlowNet2 graphs put in front of the layer (img0 - warped img1) folded in: the difference is rounded to fp32 before it is
+ * squared, as the Eltwise top would have been.  top = channel top_c0 of a [N, top_channels, H, W] blob. */
+int fn2_channel_norm_forward_slices(const float* bottom, int bottom_channels, int bottom_c0,
+                                    const float* minus, int minus_channels, int minus_c0,
+                                    float* top, int top_channels, int top_c0,
+                                    int N, int C, int H, int W, void* stream);
 int fn2_channel_norm_backward(const float* bottom, const float* top, const float* top_diff,
                               float* bottom_diff, int N, int C, int H, int W, void* stream);
 

@@ -2220,3 +2220,78 @@ FN2_API int fn2_caffemodel_read_blob_cpu(const void* buf, size_t len, const fn2_
   }
   return rc < 0 || k != e->count ? FN2_ERR_INVALID_ARG : FN2_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Channel-slice twins (round 3).  The *_slices entry points are the plain layers reading / writing channel ranges of wider blobs,
+ * with the Eltwise layers the FlowNet2 graphs put around them folded in.  The twins restate that literally: gather the slice,
+ * apply the Eltwise scaling (eltwise_layer.cpp:59-65: top = coeff * bottom, one rounding), run the plain layer twin, scatter.
+ * ---------------------------------------------------------------------------------------------- */
+static float* slice_gather(const float* blob, int N, int ctot, int c0, int C, size_t hw) {
+  float* t = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * C * hw);
+  if (!t) return NULL;
+  for (int n = 0; n < N; ++n) memcpy(t + (size_t)n * C * hw, blob + ((size_t)n * ctot + c0) * hw, sizeof(float) * C * hw);
+  return t;
+}
+static void slice_scatter(const float* t, float* blob, int N, int ctot, int c0, int C, size_t hw) {
+  for (int n = 0; n < N; ++n) memcpy(blob + ((size_t)n * ctot + c0) * hw, t + (size_t)n * C * hw, sizeof(float) * C * hw);
+}
+
+FN2_API int fn2_flow_warp_forward_slices_cpu(const float* image, int image_channels, int image_c0,
+                                             const float* flow, int flow_channels, int flow_c0,
+                                             float* warped, int top_channels, int top_c0, int N, int C, int H, int W, int fill_value) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || image_c0 < 0 || image_c0 + C > image_channels || top_c0 < 0 || top_c0 + C > top_channels ||
+      flow_c0 < 0 || flow_c0 + 2 > flow_channels)
+    return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  float* im = slice_gather(image, N, image_channels, image_c0, C, hw);
+  float* fl = slice_gather(flow, N, flow_channels, flow_c0, 2, hw);
+  float* out = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * C * hw);
+  if (!im || !fl || !out) { free(im); free(fl); free(out); return FN2_ERR_INVALID_ARG; }
+  const int rc = fn2_flow_warp_forward_cpu(im, fl, out, N, C, H, W, fill_value);
+  if (rc == FN2_OK) slice_scatter(out, warped, N, top_channels, top_c0, C, hw);
+  free(im); free(fl); free(out);
+  return rc;
+}
+
+FN2_API int fn2_channel_norm_forward_slices_cpu(const float* bottom, int bottom_channels, int bottom_c0,
+                                                const float* minus, int minus_channels, int minus_c0,
+                                                float* top, int top_channels, int top_c0, int N, int C, int H, int W) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || bottom_c0 < 0 || bottom_c0 + C > bottom_channels || top_c0 < 0 || top_c0 + 1 > top_channels ||
+      (minus && (minus_c0 < 0 || minus_c0 + C > minus_channels)))
+    return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  float* b = slice_gather(bottom, N, bottom_channels, bottom_c0, C, hw);
+  float* t = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * hw);
+  if (!b || !t) { free(b); free(t); return FN2_ERR_INVALID_ARG; }
+  if (minus) {                                                        /* Eltwise{SUM, coeff 1, -1}: eltwise_layer.cpp:59-65 */
+    for (int n = 0; n < N; ++n)
+      for (size_t i = 0; i < (size_t)C * hw; ++i) b[(size_t)n * C * hw + i] -= minus[((size_t)n * minus_channels + minus_c0) * hw + i];
+  }
+  const int rc = fn2_channel_norm_forward_cpu(b, t, N, C, H, W);
+  if (rc == FN2_OK) slice_scatter(t, top, N, top_channels, top_c0, 1, hw);
+  free(b); free(t);
+  return rc;
+}
+
+FN2_API int fn2_resample_forward_slices_cpu(const float* in, float in_scale, float* out, int top_channels, int top_c0,
+                                            float* out2, int top2_channels, int top2_c0, float out2_scale,
+                                            int N, int C, int Hin, int Win, int Hout, int Wout, int type, int antialias) {
+  if (N < 0 || C < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1 || top_c0 < 0 || top_c0 + C > top_channels ||
+      (out2 && (top2_c0 < 0 || top2_c0 + C > top2_channels)))
+    return FN2_ERR_INVALID_ARG;
+  const size_t hwi = (size_t)Hin * Win, hwo = (size_t)Hout * Wout, ni = (size_t)(N > 0 ? N : 1) * C * hwi, no = (size_t)(N > 0 ? N : 1) * C * hwo;
+  float* s = (float*)malloc(sizeof(float) * ni);
+  float* t = (float*)malloc(sizeof(float) * no);
+  if (!s || !t) { free(s); free(t); return FN2_ERR_INVALID_ARG; }
+  for (size_t i = 0; i < (size_t)N * C * hwi; ++i) s[i] = in[i] * in_scale;
+  const int rc = fn2_resample_forward_cpu(s, t, N, C, Hin, Win, Hout, Wout, type, antialias);
+  if (rc == FN2_OK) {
+    slice_scatter(t, out, N, top_channels, top_c0, C, hwo);
+    if (out2) {
+      for (size_t i = 0; i < (size_t)N * C * hwo; ++i) t[i] = t[i] * out2_scale;
+      slice_scatter(t, out2, N, top2_channels, top2_c0, C, hwo);
+    }
+  }
+  free(s); free(t);
+  return rc;
+}

@@ -931,3 +931,81 @@ def test_scale_shift_deploy_head_is_two_roundings(shape):
     blob = torch.full((N, C + 4, H, W), 7.0, device="cuda")
     ops.scale_shift_forward(dev(x), 1.0 / 255.0, dev(sh), out=blob, out_c0=3)
     assert torch.equal(blob[:, 3:3 + C].cpu(), torch.from_numpy(got)) and bool((blob[:, :3] == 7).all()) and bool((blob[:, 3 + C:] == 7).all())
+
+
+# ---- channel-slice forms of FlowWarp / ChannelNorm / Resample (round 3) ---------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 5, 17, 23), (3, 3, 64, 96)])
+def test_flow_warp_slices_is_bitwise_the_plain_layer(shape):
+    N, C, H, W = shape
+    wide_in, wide_fl, wide_out = dev(rand((N, C + 4, H, W), 300)), dev(rand((N, 5, H, W), 301, 3.0)), torch.full((N, C + 3, H, W), -9.0, device="cuda")
+    img, flow = wide_in[:, 2:2 + C].contiguous(), wide_fl[:, 1:3].contiguous()
+    plain = ops.flow_warp_forward(img, flow)
+    ops.flow_warp_forward_slices((wide_in, 2, C), (wide_fl, 1, 2), out=(wide_out, 1, C))
+    assert torch.equal(wide_out[:, 1:1 + C], plain)
+    assert float(wide_out[:, :1].max()) == -9.0 and float(wide_out[:, 1 + C:].min()) == -9.0       # the neighbours are untouched
+    assert_close(host(wide_out[:, 1:1 + C]), oracle.flow_warp_forward(host(img), host(flow)), 2e-6, "vs oracle")
+    with pytest.raises(ValueError):
+        ops.flow_warp_forward_slices((wide_in, 3, C + 2), flow)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 2, 17, 23), (2, 7, 33, 8)])
+def test_channel_norm_slices_with_folded_subtraction(shape):
+    N, C, H, W = shape
+    a, b = dev(rand((N, C + 2, H, W), 310)), dev(rand((N, C + 5, H, W), 311))
+    top = torch.full((N, 4, H, W), -9.0, device="cuda")
+    x, y = a[:, 1:1 + C].contiguous(), b[:, 4:4 + C].contiguous()
+    ops.channel_norm_forward_slices((a, 1, C), out=(top, 2, 1))
+    assert torch.equal(top[:, 2:3], ops.channel_norm_forward(x))
+    ops.channel_norm_forward_slices((a, 1, C), minus=(b, 4, C), out=(top, 0, 1))
+    assert torch.equal(top[:, 0:1], ops.channel_norm_forward(x - y))                  # the Eltwise top rounded to fp32, then the layer
+    assert float(top[:, 1].max()) == -9.0 and float(top[:, 3].max()) == -9.0
+    assert_close(host(top[:, 0:1]), oracle.channel_norm_forward(host(x) - host(y)), 2e-6, "vs oracle")
+
+
+@pytest.mark.parametrize("case", [(2, 2, 12, 20, 48, 80, 2), (1, 2, 12, 20, 48, 80, 1), (1, 3, 16, 24, 32, 48, 2), (2, 2, 13, 9, 40, 31, 2),
+                                  (1, 2, 30, 44, 11, 17, 2), (1, 2, 10, 12, 20, 31, 3), (2, 3, 24, 40, 24, 40, 2)])
+def test_resample_slices_folds_the_eltwise_layers_bitwise(case):
+    """Resample(x * 20) into a slice + (top * 0.05) into a second slice == Eltwise{20} -> Resample -> Eltwise{0.05} -> Concat, for the x4 / x2
+    LINEAR fast path, the generic LINEAR / CUBIC / NEAREST kernels, down-sampling with antialiasing and the identity size."""
+    N, C, Hi, Wi, Ho, Wo, typ = case
+    x = dev(rand((N, C, Hi, Wi), 320, 2.0))
+    s_in, s_out = 20.0, 0.05
+    ref = ops.resample_forward((x * s_in).contiguous(), Ho, Wo, typ)
+    blob, blob2 = torch.full((N, C + 3, Ho, Wo), -9.0, device="cuda"), torch.full((N, C + 1, Ho, Wo), -9.0, device="cuda")
+    ops.resample_forward_slices(x, Ho, Wo, typ, True, s_in, out=(blob, 2, C), out2=(blob2, 0, C), out2_scale=s_out)
+    assert torch.equal(blob[:, 2:2 + C], ref)
+    assert torch.equal(blob2[:, :C], ref * s_out)
+    assert float(blob[:, :2].max()) == -9.0 and float(blob[:, 2 + C:].max()) == -9.0 and float(blob2[:, C:].max()) == -9.0
+    assert torch.equal(ops.resample_forward_slices(x, Ho, Wo, typ), ops.resample_forward(x, Ho, Wo, typ))     # scale 1 is exact
+    assert_close(host(blob[:, 2:2 + C]), oracle.resample_forward(host(x) * np.float32(s_in), Ho, Wo, typ), 3e-6, "vs oracle")
+
+
+class _LayerGraphBackend:
+    """functional.py without the *_slices entry points: nets.flownet2_deploy_forward then runs the layer-by-layer graph."""
+
+    def __getattr__(self, name):
+        from flownet2_amd import functional as Fn
+        if name.endswith("_slices"):
+            raise AttributeError(name)
+        return getattr(Fn, name)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 128, 192), (1, 100, 150)])
+def test_flownet2_slice_path_is_bitwise_the_layer_graph(n, h, w):
+    """FlowNet2 with every Concat blob written in place and the Eltwise scalings folded into their neighbours (what deploy runs) against
+    the same graph executed layer by layer (Eltwise, Resample, FlowWarp, ChannelNorm, Concat as separate passes): identical bits, at an
+    adapted size and at one that needs the Resample head and tail."""
+    from flownet2_amd import functional as Fn, nets
+    Pd = {k: v.cuda() for k, v in nets.init_params_flownet2(seed=0).items()}
+    rng = np.random.default_rng(77)
+    i0 = torch.from_numpy(rng.integers(0, 256, (n, 3, h, w)).astype(np.float32)).cuda()
+    i1 = torch.roll(i0, (2, -3), (2, 3)).contiguous()
+    Fn.set_batch_invariant(True)       # both graphs on the deterministic own kernels
+    try:
+        with torch.no_grad():
+            fused = nets.flownet2_deploy_forward(Pd, i0, i1, Fn)
+            layers = nets.flownet2_deploy_forward(Pd, i0, i1, _LayerGraphBackend())
+    finally:
+        Fn.set_batch_invariant(False)
+    assert tuple(fused.shape) == (n, 2, h, w) and float(fused.abs().max()) > 1e-3
+    assert torch.equal(fused, layers)
