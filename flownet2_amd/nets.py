@@ -379,8 +379,13 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
             flows = flownet_c_core(P, pre[0], pre[1], backend)
         else:
             flows = flownet_s_core(P, torch.cat(pre, 1), backend)
-    flow = flows[2] * FLOW_SCALE                                                    # Eltwise, coeff 20
-    flow = backend.resample(flow, H, W)                                             # Resample to TARGET size (x4 up-sampling)
+    if img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "resample_slices"):
+        flow = backend.resample_slices(flows[2], H, W, in_scale=FLOW_SCALE)         # Eltwise{20} folded into the Resample (same roundings)
+        if (ah, aw) == (H, W):
+            return flow                                                              # diag(1, 1): x * 1.0f is x
+    else:
+        flow = flows[2] * FLOW_SCALE                                                # Eltwise, coeff 20
+        flow = backend.resample(flow, H, W)                                         # Resample to TARGET size (x4 up-sampling)
     scale = _const(flow.device, (W / float(aw), H / float(ah)))   # run-flownet.py:47-48
     return flow * scale.view(1, 2, 1, 1)                                            # 1x1 conv, diagonal filler
 
