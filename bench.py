@@ -27,9 +27,12 @@ if ROOT not in sys.path:
 from flownet2_amd import functional as Fn   # noqa: E402
 from flownet2_amd import nets, ops, parallel, tuning   # noqa: E402
 
-CONV_STACK_NOTE = ("own fp32 MFMA kernels: direct 5x5/2 (conv2, conv3), Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), small-map kernel with deterministic "
-                   "split-K (conv4 .. conv6_1), 7x7/2 stem, flow heads; 4x4/2 deconvolutions: library fp32 GEMM + own col2im/bias/ReLU pass into the "
-                   "concat blob; no Concat copies")
+CONV_STACK_NOTE = ("own fp32 MFMA kernels for every layer, no library GEMM or convolution in the forward step: direct 5x5/2 (conv2, conv3), "
+                   "Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), small-map kernel with deterministic split-K (conv4 .. conv6_1), 1x1 "
+                   "(conv_redir; the weight^T x bottom GEMM of the 4x4/2 deconvolutions + own col2im/bias/ReLU pass into the concat blob), "
+                   "7x7/2 stem, flow heads; no Concat copies, no element-wise glue kernels; train mode: own weight-gradient (fp32 MFMA, "
+                   "deterministic split) and data-gradient kernels (Winograd, transposed 5x5/2 and 3x3/2, 4x4/2 as convolution) for the bulk "
+                   "layers, library for the stem / 2-channel heads / smallest maps")
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6290 measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3    # same table: dense f32-input MFMA peak (= f32 vector peak)
 

@@ -13,13 +13,13 @@ mkdir -p $R
 export FN2_AUTOTUNE_CACHE=$PWD/$R/autotune.txt
 rm -f $FN2_AUTOTUNE_CACHE
 # warm MIOpen's find-db so the profiled run shows steady-state kernels only
-python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/bench_profiled.json 2>/dev/null
+python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/bench_profiled.json 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/corr -o corr -- python scripts/corr_microbench.py --iters 200 --backward > $R/corr_stdout.txt 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_sq -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_bench -o bench -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --corr-iters 4 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_bench -o bench -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --corr-iters 4 > /dev/null 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on streaming kernels of known byte count (dword per lane, like the staging loads)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/cal_fetch -o cal -- python scripts/hbm_calibrate.py > $R/cal_stdout.txt 2>/dev/null
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/cal_write -o cal -- python scripts/hbm_calibrate.py > /dev/null 2>&1
@@ -31,15 +31,21 @@ timeout 300 python scripts/train_pipeline.py --iters 8 2>/dev/null | tail -11 > 
 python bench.py > $R/bench.json 2> $R/bench.err
 # the other configurations of BASELINE.json (FlowNet2 at 768x384 batch 4 and 1024x448 batch 1, FlowNetC training step) and the
 # per-variant convolution timings
-python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 60 --warmup 8 --no-cpu-baseline > $R/bench_flownet2.json 2>/dev/null
-python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 60 --warmup 8 --no-cpu-baseline > $R/bench_flownet2_1024.json 2>/dev/null
-python bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline > $R/bench_train.json 2>/dev/null
+python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 60 --warmup 8 --no-cpu-baseline --no-extras > $R/bench_flownet2.json 2>/dev/null
+python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 60 --warmup 8 --no-cpu-baseline --no-extras > $R/bench_flownet2_1024.json 2>/dev/null
+python bench.py --mode train --steps 30 --warmup 5 --no-cpu-baseline --no-extras > $R/bench_train.json 2>/dev/null
 timeout 300 python scripts/conv_bench.py --net C --layers conv2,conv3,conv3_1,conv4_1 > $R/conv_bench_C.txt 2>&1
 # the small-map kernels (csrc/conv_plane.hip): every variant of the convolutions and of the (opt-in) deconvolutions next to the GEMM routes
 timeout 300 python scripts/conv_bench.py --net C --layers conv4,conv5,conv5_1,conv6,conv6_1 --only-plane > $R/conv_plane_bench_C.txt 2>&1
 timeout 300 python scripts/deconv_bench.py --net C > $R/deconv_bench_C.txt 2>&1
 # kernel table of the FlowNet2 step (768x384, batch 4)
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench2 -o bench2 -- python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench2 -o bench2 -- python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
 # matrix-pipe counters of the convolution kernels alone (a counter pass of its own)
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_conv -o conv -- env FN2_AUTOTUNE=0 python scripts/conv_bench.py --net C --layers conv2,conv3_1 --iters 3 > /dev/null 2>&1
+# round 3: kernel table of the FlowNetC TRAINING step, the weight-gradient / transposed-convolution micro-benchmarks, SQ counters of the weight-gradient kernel
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/train -o t -- python bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $R/train_profiled.json 2>/dev/null
+python scripts/summarize_train_trace.py $R/train/t_kernel_stats.csv > $R/train_kernels.txt 2>&1
+timeout 300 python scripts/wgrad_bench.py > $R/wgrad_bench.txt 2>&1
+timeout 300 python scripts/tconv_bench.py > $R/tconv_bench.txt 2>&1
+bash scripts/wgrad_pmc.sh $TAG/wgrad_pmc conv2,conv3_1 > $R/wgrad_counters.txt 2>&1
 tail -c 300 $R/bench.json

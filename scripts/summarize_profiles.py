@@ -139,7 +139,9 @@ for extra in ("bench.json", "bench_flownet2.json", "bench_flownet2_1024.json", "
         shutil.copyfile(os.path.join(R, extra), os.path.join(OUT, f"{tag}_{extra}"))
 if os.path.exists(os.path.join(R, "conv_bench_C.txt")):
     shutil.copyfile(os.path.join(R, "conv_bench_C.txt"), os.path.join(OUT, f"{tag}_conv_bench_flownetc.txt"))
-for src, dst in (("conv_plane_bench_C.txt", "conv_plane_bench_flownetc.txt"), ("deconv_bench_C.txt", "deconv_bench_flownetc.txt")):
+for src, dst in (("conv_plane_bench_C.txt", "conv_plane_bench_flownetc.txt"), ("deconv_bench_C.txt", "deconv_bench_flownetc.txt"),
+                 ("train_kernels.txt", "train_kernels.txt"), ("wgrad_bench.txt", "wgrad_bench.txt"), ("tconv_bench.txt", "tconv_bench.txt"),
+                 ("wgrad_counters.txt", "wgrad_counters.txt")):
     if os.path.exists(os.path.join(R, src)):
         shutil.copyfile(os.path.join(R, src), os.path.join(OUT, f"{tag}_{dst}"))
 k2 = os.path.join(R, "bench2", "bench2_kernel_stats.csv")
