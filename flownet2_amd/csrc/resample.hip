@@ -40,8 +40,9 @@ __device__ __forceinline__ size_t top_plane(int plane, int C, int ctot, int c0) 
   const int n = plane / C;
   return (size_t)n * ctot + c0 + (plane - n * C);
 }
-// one rounded product; the empty asm keeps hipcc from contracting it into a neighbouring add
-__device__ __forceinline__ float scaled(float v, float s) { float p = v * s; asm volatile("" : "+v"(p)); return p; }
+// one rounded product.  Every use below feeds a store or an OPERAND of an explicit fmaf(): there is no a * b + c expression hipcc could
+// contract it into (the bit-equality with the separate Eltwise pass is tested on every kernel of this file).
+__device__ __forceinline__ float scaled(float v, float s) { return v * s; }
 
 // Indexing of both kernels: blockIdx.x * 256 + tid = output pixel (32-bit), blockIdx.y = group of `ppt` (n, c) planes.
 // Everything that depends on the pixel only -- source position, tap range, coefficients -- is computed once and reused
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
 // every phase (triangle support 1), so they enter as ONE term  poison = sum 0 * tap  -- 0 for finite taps, NaN if the reference's
 // 0 * NaN / 0 * Inf would have poisoned the sums (the sign of a zero sum aside, the result is the reference's) -- and each output is
 // 9 fused multiply-adds in the reference's order plus the sum / wsum division (:93).  Stores are whole 16-byte (8-byte) rows.
-template <int F>
+template <int F, bool EXTRA>     // EXTRA: input scaling / channel-slice tops / second top (fn2_resample_forward_slices); false = the plain layer
 __global__ void __launch_bounds__(256) resample_up_linear(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
@@ -196,13 +197,14 @@ __global__ void __launch_bounds__(256) resample_up_linear(const float* __restric
     for (int r = 0; r < 5; ++r)
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        const float s = ((mx >> t) & (my >> r) & 1u) ? scaled(src[yo[r] + xo[t]], a.in_scale) : 0.f;
+        float s = ((mx >> t) & (my >> r) & 1u) ? src[yo[r] + xo[t]] : 0.f;
+        if constexpr (EXTRA) s = scaled(s, a.in_scale);
         if (r >= 1 && r <= 3 && t >= 1 && t <= 3) v[r - 1][t - 1] = s;
         else poison = fmaf(0.f, s, poison);
       }
     const size_t pix0 = (size_t)(F * i) * a.Wout + F * j;
-    float* dst = out + top_plane(c, a.C, a.octot, a.oc0) * hw_out + pix0;
-    float* dst2 = out2 ? out2 + top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + pix0 : nullptr;
+    float* dst = out + (EXTRA ? top_plane(c, a.C, a.octot, a.oc0) : (size_t)c) * hw_out + pix0;
+    float* dst2 = (EXTRA && out2) ? out2 + top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + pix0 : nullptr;
 #pragma unroll
     for (int py = 0; py < F; ++py) {
       vec_t o;
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(256) resample_up_linear(const float* __restric
         o[qx] = (!ws) ? 0.f : (ws == 1.0f ? sum : sum / ws);
       }
       *reinterpret_cast<vec_t*>(dst + (size_t)py * a.Wout) = o;
-      if (dst2) {
+      if (EXTRA && dst2) {
         vec_t o2;
 #pragma unroll
         for (int qx = 0; qx < F; ++qx) o2[qx] = scaled(o[qx], a.out2_scale);
@@ -276,8 +278,11 @@ FN2_API int fn2_resample_forward_slices(const float* in, float in_scale, float* 
     while (a.ppt < 4 && (long long)bxi * ((a.NC + 2 * a.ppt - 1) / (2 * a.ppt)) >= 8192) a.ppt *= 2;     // >= 8k workgroups before planes share a thread: the kernel is latency-bound (25 loads, then 16 stores)
     const dim3 gi(bxi, (unsigned)((a.NC + a.ppt - 1) / a.ppt));
     if (gi.y > 65535u) return fail(FN2_ERR_UNSUPPORTED, "resample: too many planes");
-    if (up == 4) hipLaunchKernelGGL((resample_up_linear<4>), gi, dim3(256), 0, st, in, out, out2, a);
-    else hipLaunchKernelGGL((resample_up_linear<2>), gi, dim3(256), 0, st, in, out, out2, a);
+    const bool extra = in_scale != 1.0f || out2 || top_channels != C;
+    if (up == 4 && extra) hipLaunchKernelGGL((resample_up_linear<4, true>), gi, dim3(256), 0, st, in, out, out2, a);
+    else if (up == 4) hipLaunchKernelGGL((resample_up_linear<4, false>), gi, dim3(256), 0, st, in, out, out2, a);
+    else if (extra) hipLaunchKernelGGL((resample_up_linear<2, true>), gi, dim3(256), 0, st, in, out, out2, a);
+    else hipLaunchKernelGGL((resample_up_linear<2, false>), gi, dim3(256), 0, st, in, out, out2, a);
     return check_launch("resample_forward");
   }
   if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, grid, dim3(256), 0, st, in, out, out2, a);
