@@ -313,11 +313,12 @@ def _conv_mfma_pick(x, weight, stride, pad):
     if k == 1 and os.environ.get("FN2_CONV_1X1", "1") != "0":
         return "direct"     # conv_redir: the alternative is a library GEMM + a bias / activation pass + a copy into the Concat blob
     # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
-    # large enough to run the matrix pipes efficiently (scripts/conv_bench.py, profiles/): the Winograd kernel, where it applies, does
-    # better on such layers; either way the layer stays on an own kernel (the im2col + library GEMM route is left to layers no own kernel
-    # can serve: FN2_CONV_SMALL=lib brings it back for comparison)
+    # large enough to run the matrix pipes efficiently (scripts/conv_bench.py, profiles/), and the im2col + library GEMM route (split-K
+    # GEMMs) is faster: FlowNet2 at batch 1, 1024x448, where most 3x3 layers are "small" by this measure, runs 5.72 ms with it against
+    # 6.20 ms on the own kernels (scripts/probes/fn2_toggle_bench.sh; batch 4 at 768x384: 10.71 / 10.68, FlowNetC batch 8: 2.40 / 2.40).
+    # FN2_CONV_SMALL=own keeps such layers on the own kernels (Winograd where it applies, else direct); batch-invariant mode always does.
     if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not own:
-        if os.environ.get("FN2_CONV_SMALL", "own") == "lib":
+        if os.environ.get("FN2_CONV_SMALL", "lib") == "lib":
             return None
         if k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad):
             return "wino"
