@@ -733,8 +733,10 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #pragma unroll
   for (int b = 0; b < K::NB; ++b) { acc0[b] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  [[maybe_unused]] int wave_sel = 9;
   {
     const int sel = tile_range_sel<2, R>(jw, Wc);
+    wave_sel = sel;
 #define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_, PROJ>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, Jw, Jw, k.py, i0, i2_0, jS)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
@@ -785,6 +787,15 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
     store_rows(std::true_type{});
   }
 #ifdef FN2_ABLATION
+  if (dbg && lane == 0 && blockIdx.x < 1024) {      // per wave (scripts/probes/corr_wave_trace.py): start, loop end, end, {HW_ID, tile-range selector, Jw}
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned long long* w = dbg + 4 * 1024 + 4 * (8 * blockIdx.x + Jw);
+    w[0] = t_start;
+    w[1] = t_loop;
+    w[2] = __builtin_amdgcn_s_memtime();
+    w[3] = hwid | ((unsigned long long)wave_sel << 32) | ((unsigned long long)Jw << 40) | (1ull << 63);
+  }
   if (dbg && threadIdx.x == 0) {
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
