@@ -148,6 +148,65 @@ __global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restri
   }
 }
 
+// The coarsest scales (320x448 -> 10x14 and 5x7: 4,225 and 16,641 taps per output, 2,240 and 560 outputs per batch of 8): a whole WORKGROUP per
+// output element -- with a wave per output the 560 waves of the last scale walked 260 dependent taps per lane (61 us per call, 182 us of a
+// training step for the three coarse scales).  Same tap order per lane class, wave butterfly, then the four wave sums added in wave order
+// (deterministic).
+__global__ void __launch_bounds__(256) downsample_fwd_block(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+  __shared__ float part[3][4];
+  const unsigned hw_out = (unsigned)a.Hout * a.Wout;
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long total = (unsigned long long)a.NC * hw_out;
+  for (unsigned long long o = blockIdx.x; o < total; o += gridDim.x) {
+    const unsigned cn = (unsigned)(o / hw_out), pd = (unsigned)(o - (unsigned long long)cn * hw_out);
+    const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
+    const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
+    const float boty = ((float)desty / (float)(a.Hout - 1)) * (float)(a.Hin - 1);     // :28
+    const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                   // :30-31
+    const int y0 = max(iboty - a.hradius, 0), y1 = min(iboty + a.hradius, a.Hin - 1);
+    const int x0 = max(ibotx - a.wradius, 0), x1 = min(ibotx + a.wradius, a.Win - 1);
+    const int nx = x1 - x0 + 1, ntap = nx * (y1 - y0 + 1);
+    const float* p = src + (size_t)cn * a.Hin * a.Win;
+    float accum_value = 0.f, accum_weight = 0.f, accum_nan = 0.f;
+    for (int t0 = (int)tid; t0 < ntap; t0 += 1024) {           // four taps per thread in flight
+      float sm[4];
+      int tby[4], tbx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = min(t0 + 256 * j, ntap - 1);
+        tby[j] = y0 + t / nx; tbx[j] = x0 + t % nx;
+        sm[j] = p[(size_t)tby[j] * a.Win + tbx[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (t0 + 256 * j >= ntap) break;
+        float sample = sm[j];
+        float weight = fmaxf(0.0f, 1.0f - (fabsf((float)tbx[j] - botx) / a.widthScale)) *
+                       fmaxf(0.0f, 1.0f - (fabsf((float)tby[j] - boty) / a.heightScale));   // :52
+        if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }           // :53-57
+        accum_value = fmaf(sample, weight, accum_value);
+        accum_weight += weight;
+      }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      accum_value += __shfl_xor(accum_value, m, 64);
+      accum_weight += __shfl_xor(accum_weight, m, 64);
+      accum_nan += __shfl_xor(accum_nan, m, 64);
+    }
+    if (lane == 0) { part[0][wave] = accum_value; part[1][wave] = accum_weight; part[2][wave] = accum_nan; }
+    __syncthreads();
+    if (tid == 0) {
+      const float v = ((part[0][0] + part[0][1]) + part[0][2]) + part[0][3];
+      const float w = ((part[1][0] + part[1][1]) + part[1][2]) + part[1][3];
+      const float nn = ((part[2][0] + part[2][1]) + part[2][2]) + part[2][3];
+      if (nn / w > 0.5f) dst[o] = __builtin_bit_cast(float, 0x7fffffffu);   // :64-65
+      else dst[o] = v / w;                                                   // :67
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace fn2
 
 using namespace fn2;
@@ -211,7 +270,10 @@ FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C
   a.hradius = (int)std::ceil(a.heightScale);               // :108
   if ((long long)Hout * Wout >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "downsample: plane too large");
   const long long taps = (long long)(2 * a.wradius + 1) * (2 * a.hradius + 1);
-  if (taps >= 512) {                      // wave per output element
+  if (taps >= 4096) {                     // workgroup per output element
+    const long long outs = (long long)a.NC * Hout * Wout;
+    hipLaunchKernelGGL(downsample_fwd_block, dim3((unsigned)(outs < 65536 ? outs : 65536)), dim3(256), 0, st, bottom, top, a);
+  } else if (taps >= 512) {               // wave per output element
     const long long outs = (long long)a.NC * Hout * Wout;
     const long long blocks = (outs + 3) / 4;
     hipLaunchKernelGGL(downsample_fwd_wave, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, bottom, top, a);

@@ -1,0 +1,14 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from flownet2_amd import ops
+def t(f, it=100):
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / it
+x = torch.randn(8, 2, 320, 448, device="cuda")
+for s in (4, 8, 16, 32, 64):
+    print("downsample [8,2,320,448] -> 1/%d: %.1f us" % (s, t(lambda: ops.downsample_forward(x, 320 // s, 448 // s))))
