@@ -59,14 +59,22 @@ __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restri
   if (threadIdx.x == 0) partial[(size_t)plane * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void __launch_bounds__(64) bias_diff_finalize(const float* __restrict__ partial, float* __restrict__ bias_diff,
-                                                         int N, int C, int chunks) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+// one wave per channel: the N * chunks partials of the channel spread over the lanes (lane l takes partials l, l + 64, ... in order),
+// then a fixed-shape butterfly -- deterministic; a thread per channel walked N * chunks dependent loads (9.6 us per call, 15 calls per
+// FlowNetC training step)
+__global__ void __launch_bounds__(256) bias_diff_finalize(const float* __restrict__ partial, float* __restrict__ bias_diff,
+                                                          int N, int C, int chunks) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
+  const int total = N * chunks;
   float acc = 0.f;
-  for (int n = 0; n < N; ++n)
-    for (int k = 0; k < chunks; ++k) acc += partial[((size_t)n * C + c) * chunks + k];
-  bias_diff[c] = acc;
+  for (int i = lane; i < total; i += 64) {
+    const int n = i / chunks, k = i - n * chunks;
+    acc += partial[((size_t)n * C + c) * chunks + k];
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (lane == 0) bias_diff[c] = acc;
 }
 
 }  // namespace fn2
@@ -93,7 +101,7 @@ FN2_API int fn2_bias_leaky_relu_backward(const float* top_data, const float* top
   float* partial = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(bias_leaky_relu_bwd, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
                      (unsigned)hw, negative_slope);
-  if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 63) / 64), dim3(64), 0, st, partial, bias_diff, N, C, kBwdChunks);
+  if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks);
   return check_launch("bias_leaky_relu_backward");
 }
 
