@@ -366,7 +366,9 @@ static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)
   FN2_CV_ROW16(2, 4, 2, 2, 1, 1) FN2_CV_ROW16(2, 7, 1, 4, 1, 0) FN2_CV_ROW16(2, 5, 1, 4, 1, 0) FN2_CV_ROW16(4, 5, 1, 4, 1, 0) FN2_CV_ROW16(2, 4, 1, 4, 1, 0)
   FN2_CV_ROW16(4, 5, 2, 2, 1, 0) FN2_CV_ROW16(4, 4, 2, 2, 1, 0)
   /* planes of 140 (10x14) / 288 (12x24) pixels: 9 x 16 = 144 */
-  FN2_CV_ROW16(2, 9, 4, 1, 1, 1) FN2_CV_ROW16(2, 9, 2, 2, 1, 1) FN2_CV_ROW16(2, 3, 2, 2, 1, 1) FN2_CV_ROW16(4, 3, 1, 4, 1, 0)};
+  FN2_CV_ROW16(2, 9, 4, 1, 1, 1) FN2_CV_ROW16(2, 9, 2, 2, 1, 1) FN2_CV_ROW16(2, 3, 2, 2, 1, 1) FN2_CV_ROW16(4, 3, 1, 4, 1, 0)
+  /* 256-channel workgroup tiles (36 / 28 accumulator tiles per wave): fewer re-reads of the pixel operand by the big-M deconvolution GEMMs */
+  FN2_CV_ROW16(4, 9, 4, 1, 1, 0) FN2_CV_ROW16(4, 9, 2, 2, 1, 0) FN2_CV_ROW16(4, 7, 4, 1, 1, 0)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int g_forced_variant = -1;       // >= 0: plain launch of that variant; >= 1000: its split-tail launch

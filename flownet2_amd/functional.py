@@ -382,6 +382,9 @@ class _OwnForwardConv(torch.autograd.Function):
         gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
         gw = _own_bwd_weight(d, x, w, stride, pad, transposed) if need_w else None
         lib_x, lib_w = need_x and gx is None, need_w and gw is None
+        if (lib_x or lib_w) and os.environ.get("FN2_TRACE_BWD") == "1":
+            print("bwd on the library: x %s w %s stride %d pad %d transposed %s -> %s%s" % (tuple(x.shape), tuple(w.shape), stride, pad, transposed,
+                                                                                          "data " if lib_x else "", "weight" if lib_w else ""), flush=True)
         if lib_x or lib_w:
             gxl, gwl, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
                                                               [lib_x, lib_w, False])
