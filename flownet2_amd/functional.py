@@ -462,13 +462,37 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
             return None
         pw = _cached_pack(_PACKED_T, w, "tconv", lambda: ops.tconv_pack_weights(w.detach()))
         return ops.tconv_forward(d.contiguous(), pw, None, Cin, k, pad, out_hw=(H, W))
+    if k == 1 and stride == 1 and pad == 0:
+        # 1x1 (conv_redir): bottom_diff = W^T x top_diff, the 1x1 / GEMM form of conv_mfma on the transposed weight
+        Cp = (Cin + 31) // 32 * 32
+        if not ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 1, 1, 0):
+            return None
+
+        def make_1x1():
+            wt = w.detach().transpose(0, 1)                              # [Cin, Cout, 1, 1]
+            if Cp != Cin:
+                wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 1, 1))], 0)
+            return ops.conv_mfma_pack_weights(wt.contiguous())
+        gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "1x1-dgrad", make_1x1), None, Cp, 1, 1, 0, False, 0.0)
+        return gx[:, :Cin] if Cp != Cin else gx
     if mode == "none" or k != 3 or stride != 1 or pad != 1:
         return None
     if mode == "odd" and Cin % 8 == 0:
         return None
     Cp = (Cin + 15) // 16 * 16
     if not ops.conv_wino_supported(Cout, d.shape[2], d.shape[3], Cp, 1):
-        return None
+        # maps the Winograd kernel does not take (10x14, 5x7: conv5_1, conv6_1): the small-map kernel on the same rotated weights
+        Cq = (Cin + 63) // 64 * 64
+        if Cout % 8 != 0 or not ops.conv_plane_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cq, 1, 1):
+            return None
+
+        def make_plane():
+            wt = w.detach().flip(2, 3).transpose(0, 1)
+            if Cq != Cin:
+                wt = torch.cat([wt, wt.new_zeros((Cq - Cin, Cout, 3, 3))], 0)
+            return ops.conv_mfma_pack_weights(wt.contiguous())
+        gx = ops.conv_plane_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "plane-dgrad", make_plane), None, Cq, 1, 1, False, 0.0)
+        return gx[:, :Cin] if Cq != Cin else gx
 
     def make_wino():
         wt = w.detach().flip(2, 3).transpose(0, 1)                  # [Cin, Cout, 3, 3]: rot180, channel axes swapped

@@ -1009,3 +1009,22 @@ def test_flownet2_slice_path_is_bitwise_the_layer_graph(n, h, w):
         Fn.set_batch_invariant(False)
     assert tuple(fused.shape) == (n, 2, h, w) and float(fused.abs().max()) > 1e-3
     assert torch.equal(fused, layers)
+
+
+@pytest.mark.parametrize("case", [((2, 256, 40, 56), (32, 256, 1, 1), 1, 0), ((2, 48, 12, 20), (24, 48, 1, 1), 1, 0),       # 1x1: conv_redir and a padded one
+                                  ((2, 64, 10, 14), (128, 64, 3, 3), 1, 1), ((3, 128, 5, 7), (64, 128, 3, 3), 1, 1)])       # 3x3/1 on maps Winograd does not take
+def test_own_data_gradient_of_1x1_and_small_map_layers(case):
+    """bottom_diff of a 1x1 convolution (the 1x1 / GEMM kernel on the transposed weight) and of 3x3 / stride 1 layers on 10x14 / 5x7 maps
+    (the small-map kernel on the rotated weight) against fp64 autograd: <= 1e-5 * scale."""
+    from flownet2_amd import functional as Fn
+    xs, ws, stride, pad = case
+    w = dev(rand(ws, 330, 0.05))
+    Ho, Wo = (xs[2] + 2 * pad - ws[2]) // stride + 1, (xs[3] + 2 * pad - ws[2]) // stride + 1
+    d = dev(rand((xs[0], ws[0], Ho, Wo), 331))
+    gx = Fn._own_bwd_data(d, w, stride, pad, False, xs)
+    assert gx is not None and tuple(gx.shape) == xs
+    x64 = torch.zeros(xs, dtype=torch.float64, device="cuda", requires_grad=True)
+    y = torch.nn.functional.conv2d(x64, w.double(), None, stride=stride, padding=pad)
+    (ref,) = torch.autograd.grad(y, x64, d.double())
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((gx.double() - ref).abs().max()) <= 1e-5 * scale
