@@ -176,12 +176,55 @@ def l1_loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, n
     return _L1Loss.apply(b0.contiguous(), b1.contiguous() if b1 is not None else None, p)
 
 
+class _PredictFlow(torch.autograd.Function):
+    """predict_flow (Convolution{3,1,1} C -> 2): own forward (csrc/flow_head.hip) and own backward (csrc/flow_head_bwd.hip: weight,
+    bias and bottom gradients as streaming kernels over NCHW -- a 2-channel side cannot feed a matrix tile)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.predict_flow_conv_forward(x.contiguous(), weight.contiguous(), bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        blob, c0 = _channel_slice(x)
+        dx, dw, db = ops.predict_flow_conv_backward((blob, c0, x.shape[1]), w, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                    ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dw, db
+
+
+class _UpsampleFlow(torch.autograd.Function):
+    """upsample_flow (Deconvolution{4,2,1} 2 -> 2): own forward and own backward (csrc/flow_head_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.upsample_flow_deconv_backward(x.contiguous(), w, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                       ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dw, db
+
+
+def _own_head_bwd():
+    return os.environ.get("FN2_OWN_HEAD_BWD", "1") != "0"
+
+
 def predict_flow_conv(x, weight, bias=None):
-    """predict_flow (Convolution{3,1,1} -> 2 channels): own forward kernel; with autograd active inside _OwnForwardConv."""
+    """predict_flow (Convolution{3,1,1} -> 2 channels): own forward kernel; with autograd active own backward kernels too
+    (FN2_OWN_HEAD_BWD=0: backward through _OwnForwardConv, i.e. the library)."""
     run = lambda xx, ww, bb: ops.predict_flow_conv_forward(xx.contiguous(), ww.contiguous(), bb)
     if _needs_grad(x, weight, bias):
         if not _train_fast_forward():
             return torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=1)
+        if _own_head_bwd():
+            return _PredictFlow.apply(x, weight, bias)
         return _OwnForwardConv.apply(x, weight, bias, run, 1, 1, 0.0, False, False)
     return run(x, weight, bias)
 
@@ -194,6 +237,8 @@ def upsample_flow_deconv(x, weight, bias=None, out=None, out_c0=0):
     if _needs_grad(x, weight, bias):
         if not _train_fast_forward():
             return torch.nn.functional.conv_transpose2d(x, weight, bias, stride=2, padding=1)
+        if _own_head_bwd():
+            return _UpsampleFlow.apply(x, weight, bias)
         return _OwnForwardConv.apply(x, weight, bias, run, 2, 1, 0.0, False, True)
     return run(x, weight, bias)
 

@@ -344,6 +344,39 @@ def scale_shift_forward(x, scale, shift=None, out=None, out_c0=0):
     return out
 
 
+def predict_flow_conv_backward(x, weight, top_diff, need_x=True, need_w=True, need_b=True):
+    """Backward of predict_flow (Convolution{3,1,1} C -> 2): (bottom_diff, weight_diff, bias_diff), None where not needed.  `x` may be a
+    channel slice (blob, c0, C)."""
+    xb, xctot, xc0, Cc = _as_slice(x, "bottom[0]")
+    w, g = _chk(weight, "weight"), _chk(top_diff, "top.diff")
+    N, _, H, W = xb.shape
+    if tuple(w.shape) != (2, Cc, 3, 3) or tuple(g.shape) != (N, 2, H, W):
+        raise ValueError("predict_flow_conv_backward: weight must be [2,C,3,3] and top_diff [N,2,H,W]")
+    dx = torch.empty((N, Cc, H, W), device=g.device, dtype=torch.float32) if need_x else None
+    dw = torch.empty_like(w) if need_w else None
+    db = torch.empty(2, device=g.device, dtype=torch.float32) if need_b else None
+    nbytes = _lib.lib().fn2_predict_flow_conv_backward_workspace_bytes(N, Cc, H, W) if (need_w or need_b) else 0
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=g.device)
+    check(_lib.lib().fn2_predict_flow_conv_backward(_ptr(xb), xctot, xc0, _ptr(w), _ptr(g), _ptr(dx), _ptr(dw), _ptr(db), N, Cc, H, W, 0,
+                                                    _ptr(ws), nbytes, _stream()))
+    return dx, dw, db
+
+
+def upsample_flow_deconv_backward(x, weight, top_diff, need_x=True, need_w=True, need_b=True):
+    """Backward of upsample_flow (Deconvolution{4,2,1} 2 -> 2): (bottom_diff, weight_diff, bias_diff), None where not needed."""
+    x, w, g = _chk(x, "bottom[0]"), _chk(weight, "weight"), _chk(top_diff, "top.diff")
+    N, Cc, H, W = x.shape
+    if Cc != 2 or tuple(w.shape) != (2, 2, 4, 4) or tuple(g.shape) != (N, 2, 2 * H, 2 * W):
+        raise ValueError("upsample_flow_deconv_backward: bottom [N,2,H,W], weight [2,2,4,4], top_diff [N,2,2H,2W]")
+    dx = torch.empty_like(x) if need_x else None
+    dw = torch.empty_like(w) if need_w else None
+    db = torch.empty(2, device=g.device, dtype=torch.float32) if need_b else None
+    nbytes = _lib.lib().fn2_upsample_flow_deconv_backward_workspace_bytes(N, H, W) if (need_w or need_b) else 0
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=g.device)
+    check(_lib.lib().fn2_upsample_flow_deconv_backward(_ptr(x), _ptr(w), _ptr(g), _ptr(dx), _ptr(dw), _ptr(db), N, H, W, 0, _ptr(ws), nbytes, _stream()))
+    return dx, dw, db
+
+
 def conv_k7s2_relu_supported(Cin, Hin, Win, Cout) -> bool:
     return bool(_lib.lib().fn2_conv_k7s2_relu_supported(int(Cin), int(Hin), int(Win), int(Cout)))
 

@@ -237,13 +237,30 @@ int fn2_downsample_forward(const float* bottom, float* top, int N, int C,
  *   upsample_flow* = Deconvolution{kernel_size 4, stride 2, pad 1, num_output 2} on a 2-channel flow
  *                    <- DeconvolutionLayer::Forward_gpu, src/caffe/layers/deconv_layer.cu (CPU twin deconv_layer.cpp:8-45;
  *                       weight [Cin=2, Cout=2, 4, 4], base_conv_layer.cpp:125-139)
- * Forward only (inference); bias may be NULL.
+ * bias may be NULL.
  * ---------------------------------------------------------------------------------------------- */
 size_t fn2_predict_flow_conv_workspace_bytes(int N, int C, int H, int W);   /* the per-tap partial image (18 planes per channel split) */
 int fn2_predict_flow_conv_forward(const float* in, const float* weight, const float* bias, float* out,
                                   int N, int C, int H, int W, void* workspace, size_t workspace_bytes, void* stream);
 int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const float* bias, float* out,
                                      int N, int H, int W, void* stream);
+/* Backward of the two heads (round 3; csrc/flow_head_bwd.hip): streaming kernels over NCHW, fixed summation order (deterministic).
+ *   predict_flow:  <- ConvolutionLayer::Backward_gpu, src/caffe/layers/conv_layer.cu:26-60 (backward_gpu_bias, weight_gpu_gemm,
+ *                     backward_gpu_gemm: base_conv_layer.cpp:352-393) with weight [2, C, 3, 3]; bottom may be a channel slice
+ *                     [bottom_c0, bottom_c0 + C) of a [N, bottom_channels, H, W] blob (the Concat it reads).
+ *   upsample_flow: <- DeconvolutionLayer::Backward_gpu, src/caffe/layers/deconv_layer.cu:27-58 with weight [2, 2, 4, 4];
+ *                     bottom [N, 2, H, W], top_diff [N, 2, 2H, 2W].
+ * Any of bottom_diff / weight_diff / bias_diff may be NULL (= propagate_down false).  accumulate != 0 adds into weight_diff / bias_diff
+ * like the reference (the solver clears the diffs once per iteration); bottom_diff is always overwritten.  Workspace: the per-part
+ * partial sums (only needed for weight_diff / bias_diff). */
+size_t fn2_predict_flow_conv_backward_workspace_bytes(int N, int C, int H, int W);
+int fn2_predict_flow_conv_backward(const float* bottom, int bottom_channels, int bottom_c0, const float* weight, const float* top_diff,
+                                   float* bottom_diff, float* weight_diff, float* bias_diff, int N, int C, int H, int W,
+                                   int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+size_t fn2_upsample_flow_deconv_backward_workspace_bytes(int N, int H, int W);
+int fn2_upsample_flow_deconv_backward(const float* bottom, const float* weight, const float* top_diff, float* bottom_diff,
+                                      float* weight_diff, float* bias_diff, int N, int H, int W, int accumulate,
+                                      void* workspace, size_t workspace_bytes, void* stream);
 /* The same layer written into channels [top_c0, top_c0 + 2) of a wider top blob [N, top_channels, 2H, 2W]: the upsampled flow is
  * the last input of the refinement stages' Concat layers (concat_layer.cu:8-52), which then has nothing left to copy. */
 int fn2_upsample_flow_deconv_forward_into(const float* in, const float* weight, const float* bias, float* top,

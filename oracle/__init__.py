@@ -395,6 +395,26 @@ def upsample_flow_deconv_forward(x, weight, bias=None):
     return out
 
 
+def predict_flow_conv_backward(x, weight, top_diff):
+    """(bottom_diff, weight_diff, bias_diff) of predict_flow (Convolution{3,1,1} C -> 2), accumulated in double."""
+    x, weight, g = _f32(x), _f32(weight), _f32(top_diff)
+    N, Cc, H, W = x.shape
+    assert weight.shape == (2, Cc, 3, 3) and g.shape == (N, 2, H, W)
+    dx, dw, db = np.empty_like(x), np.empty_like(weight), np.empty(2, np.float32)
+    _check(lib().fn2_predict_flow_conv_backward_cpu(_p(x), Cc, 0, _p(weight), _p(g), _p(dx), _p(dw), _p(db), N, Cc, H, W, 0), "predict_flow_conv_backward")
+    return dx, dw, db
+
+
+def upsample_flow_deconv_backward(x, weight, top_diff):
+    """(bottom_diff, weight_diff, bias_diff) of upsample_flow (Deconvolution{4,2,1} 2 -> 2), accumulated in double."""
+    x, weight, g = _f32(x), _f32(weight), _f32(top_diff)
+    N, Cc, H, W = x.shape
+    assert Cc == 2 and weight.shape == (2, 2, 4, 4) and g.shape == (N, 2, 2 * H, 2 * W)
+    dx, dw, db = np.empty_like(x), np.empty_like(weight), np.empty(2, np.float32)
+    _check(lib().fn2_upsample_flow_deconv_backward_cpu(_p(x), _p(weight), _p(g), _p(dx), _p(dw), _p(db), N, H, W, 0), "upsample_flow_deconv_backward")
+    return dx, dw, db
+
+
 # ------------------------------------------------------------------------------------------------
 # CustomData sample format (Datum wire format, writer packing, decode) -- host arrays throughout
 # ------------------------------------------------------------------------------------------------

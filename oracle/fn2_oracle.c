@@ -2295,3 +2295,107 @@ FN2_API int fn2_resample_forward_slices_cpu(const float* in, float in_scale, flo
   free(s); free(t);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the 2-channel flow heads (CPU twins of csrc/flow_head_bwd.hip): ConvolutionLayer::Backward_cpu (conv_layer.cpp:42-70) with
+ * weight [2, C, 3, 3] and DeconvolutionLayer::Backward_cpu (deconv_layer.cpp:28-60) with weight [2, 2, 4, 4], written as the sums they
+ * are, accumulated in double (the HIP kernels use fixed-order fp32 partial sums: compared at 1e-5 * scale).
+ * ---------------------------------------------------------------------------------------------- */
+FN2_API int fn2_predict_flow_conv_backward_cpu(const float* bottom, int bottom_channels, int bottom_c0, const float* weight, const float* top_diff,
+                                               float* bottom_diff, float* weight_diff, float* bias_diff, int N, int C, int H, int W, int accumulate) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || bottom_c0 < 0 || bottom_c0 + C > bottom_channels) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  if (weight_diff) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int co = 0; co < 2; ++co)
+      for (int c = 0; c < C; ++c)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            double acc = 0.0;
+            for (int n = 0; n < N; ++n)
+              for (int y = 0; y < H; ++y) {
+                const int yy = y + ky - 1;
+                if (yy < 0 || yy >= H) continue;
+                for (int x = 0; x < W; ++x) {
+                  const int xx = x + kx - 1;
+                  if (xx < 0 || xx >= W) continue;
+                  acc += (double)top_diff[((size_t)n * 2 + co) * hw + (size_t)y * W + x] *
+                         (double)bottom[((size_t)n * bottom_channels + bottom_c0 + c) * hw + (size_t)yy * W + xx];
+                }
+              }
+            float* d = weight_diff + (((size_t)co * C + c) * 3 + ky) * 3 + kx;
+            *d = (accumulate ? *d : 0.f) + (float)acc;
+          }
+  }
+  if (bias_diff)
+    for (int co = 0; co < 2; ++co) {
+      double acc = 0.0;
+      for (int n = 0; n < N; ++n)
+        for (size_t i = 0; i < hw; ++i) acc += top_diff[((size_t)n * 2 + co) * hw + i];
+      bias_diff[co] = (accumulate ? bias_diff[co] : 0.f) + (float)acc;
+    }
+  if (bottom_diff) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < C; ++c)
+        for (int y = 0; y < H; ++y)
+          for (int x = 0; x < W; ++x) {
+            double acc = 0.0;
+            for (int co = 0; co < 2; ++co)
+              for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                  const int yy = y - ky + 1, xx = x - kx + 1;
+                  if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                  acc += (double)top_diff[((size_t)n * 2 + co) * hw + (size_t)yy * W + xx] * (double)weight[(((size_t)co * C + c) * 3 + ky) * 3 + kx];
+                }
+            bottom_diff[((size_t)n * C + c) * hw + (size_t)y * W + x] = (float)acc;
+          }
+  }
+  return FN2_OK;
+}
+
+FN2_API int fn2_upsample_flow_deconv_backward_cpu(const float* bottom, const float* weight, const float* top_diff, float* bottom_diff,
+                                                  float* weight_diff, float* bias_diff, int N, int H, int W, int accumulate) {
+  if (N < 0 || H < 1 || W < 1) return FN2_ERR_INVALID_ARG;
+  const int Ho = 2 * H, Wo = 2 * W;
+  const size_t hw = (size_t)H * W, hwo = (size_t)Ho * Wo;
+  if (weight_diff)
+    for (int ci = 0; ci < 2; ++ci)
+      for (int co = 0; co < 2; ++co)
+        for (int ky = 0; ky < 4; ++ky)
+          for (int kx = 0; kx < 4; ++kx) {
+            double acc = 0.0;
+            for (int n = 0; n < N; ++n)
+              for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                  const int Y = 2 * y - 1 + ky, X = 2 * x - 1 + kx;
+                  if (Y < 0 || Y >= Ho || X < 0 || X >= Wo) continue;
+                  acc += (double)bottom[((size_t)n * 2 + ci) * hw + (size_t)y * W + x] * (double)top_diff[((size_t)n * 2 + co) * hwo + (size_t)Y * Wo + X];
+                }
+            float* d = weight_diff + ((ci * 2 + co) * 4 + ky) * 4 + kx;
+            *d = (accumulate ? *d : 0.f) + (float)acc;
+          }
+  if (bias_diff)
+    for (int co = 0; co < 2; ++co) {
+      double acc = 0.0;
+      for (int n = 0; n < N; ++n)
+        for (size_t i = 0; i < hwo; ++i) acc += top_diff[((size_t)n * 2 + co) * hwo + i];
+      bias_diff[co] = (accumulate ? bias_diff[co] : 0.f) + (float)acc;
+    }
+  if (bottom_diff)
+    for (int n = 0; n < N; ++n)
+      for (int ci = 0; ci < 2; ++ci)
+        for (int y = 0; y < H; ++y)
+          for (int x = 0; x < W; ++x) {
+            double acc = 0.0;
+            for (int co = 0; co < 2; ++co)
+              for (int ky = 0; ky < 4; ++ky)
+                for (int kx = 0; kx < 4; ++kx) {
+                  const int Y = 2 * y - 1 + ky, X = 2 * x - 1 + kx;
+                  if (Y < 0 || Y >= Ho || X < 0 || X >= Wo) continue;
+                  acc += (double)top_diff[((size_t)n * 2 + co) * hwo + (size_t)Y * Wo + X] * (double)weight[((ci * 2 + co) * 4 + ky) * 4 + kx];
+                }
+            bottom_diff[((size_t)n * 2 + ci) * hw + (size_t)y * W + x] = (float)acc;
+          }
+  return FN2_OK;
+}

@@ -1028,3 +1028,49 @@ def test_own_data_gradient_of_1x1_and_small_map_layers(case):
     (ref,) = torch.autograd.grad(y, x64, d.double())
     scale = max(1.0, float(ref.abs().max()))
     assert float((gx.double() - ref).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("shape", [(2, 194, 24, 40), (1, 1026, 10, 14), (3, 37, 5, 7), (2, 16, 17, 23)])
+def test_predict_flow_conv_backward(shape):
+    """Own backward of predict_flow (Convolution{3,1,1} C -> 2): weight, bias and bottom gradients vs the double-accumulating oracle twin
+    (1e-5 * scale), reading the bottom from a channel slice, deterministic run to run, and through autograd against conv2d."""
+    from flownet2_amd import functional as Fn
+    N, C, H, W = shape
+    blob, w, g = rand((N, C + 3, H, W), 340), rand((2, C, 3, 3), 341, 0.1), rand((N, 2, H, W), 342)
+    x = np.ascontiguousarray(blob[:, 2:2 + C])
+    odx, odw, odb = oracle.predict_flow_conv_backward(x, w, g)
+    dx, dw, db = ops.predict_flow_conv_backward((dev(blob), 2, C), dev(w), dev(g))
+    assert_close(host(dx), odx, 1e-5, "bottom_diff")
+    assert_close(host(dw), odw, 1e-5, "weight_diff")
+    assert_close(host(db), odb, 1e-5, "bias_diff")
+    dx2, dw2, db2 = ops.predict_flow_conv_backward(dev(x), dev(w), dev(g))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+    only_w = ops.predict_flow_conv_backward(dev(x), dev(w), dev(g), need_x=False, need_b=False)
+    assert only_w[0] is None and only_w[2] is None and torch.equal(only_w[1], dw)
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(rand((2,), 343)).requires_grad_(True)
+    Fn.predict_flow_conv(xt, wt, bt).backward(dev(g))
+    xr, wr, br = dev(x).double().requires_grad_(True), dev(w).double().requires_grad_(True), bt.detach().double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr, br, padding=1).backward(dev(g).double())
+    for got, ref in ((xt.grad, xr.grad), (wt.grad, wr.grad), (bt.grad, br.grad)):
+        assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 56), (8, 5, 7), (1, 17, 23), (3, 10, 14)])
+def test_upsample_flow_deconv_backward(shape):
+    """Own backward of upsample_flow (Deconvolution{4,2,1} 2 -> 2) vs the oracle twin and through autograd against conv_transpose2d."""
+    from flownet2_amd import functional as Fn
+    N, H, W = shape
+    x, w, g = rand((N, 2, H, W), 350), rand((2, 2, 4, 4), 351, 0.3), rand((N, 2, 2 * H, 2 * W), 352)
+    odx, odw, odb = oracle.upsample_flow_deconv_backward(x, w, g)
+    dx, dw, db = ops.upsample_flow_deconv_backward(dev(x), dev(w), dev(g))
+    assert_close(host(dx), odx, 1e-5, "bottom_diff")
+    assert_close(host(dw), odw, 1e-5, "weight_diff")
+    assert_close(host(db), odb, 1e-5, "bias_diff")
+    again = ops.upsample_flow_deconv_backward(dev(x), dev(w), dev(g))
+    assert all(torch.equal(a, b) for a, b in zip((dx, dw, db), again))
+    xt, wt, bt = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(rand((2,), 353)).requires_grad_(True)
+    Fn.upsample_flow_deconv(xt, wt, bt).backward(dev(g))
+    xr, wr, br = dev(x).double().requires_grad_(True), dev(w).double().requires_grad_(True), bt.detach().double().requires_grad_(True)
+    torch.nn.functional.conv_transpose2d(xr, wr, br, stride=2, padding=1).backward(dev(g).double())
+    for got, ref in ((xt.grad, xr.grad), (wt.grad, wr.grad), (bt.grad, br.grad)):
+        assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
