@@ -810,6 +810,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #endif
 }
 
+int g_corr_skip_dead = 0;     // profiling hook (fn2_debug_set_correlation_impl(14)): launch no zero-fill workgroups
 int g_corr_force_dword = 0;   // test hook: run the general (dword LDS-DMA) kernel even where the paired one applies
 int g_corr_proj = 0;          // profiling hook (fn2_debug_set_correlation_impl(7 / 8)): the PROJ = 1 / 2 builds of corr_fwd_pair
 
@@ -835,6 +836,7 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   if (NL + ND > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
   g.LP = (int)((NL + 7) / 8);
   g.DP = (int)((ND + 7) / 8);
+  if (g_corr_skip_dead) g.DP = 0;          // profiling only (wrong output): what the zero-fill workgroups cost
   const unsigned grid = 8u * (unsigned)(g.LP + g.DP);
   if constexpr (S2 == 2 && R == 10) {
     const bool aligned = cg.W % 4 == 0 &&
