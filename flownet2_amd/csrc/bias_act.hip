@@ -40,15 +40,18 @@ __global__ void __launch_bounds__(256) bias_leaky_relu(float* __restrict__ data,
 // (n, c) plane (wave shuffles + LDS), a second small kernel adds the partials of a channel in a fixed order.
 constexpr int kBwdChunks = 8;      // blocks per (n, c) plane
 
+// top_diff may be a channel slice of a wider blob (the gradient of a Concat arrives as one: concat_layer.cu:62-90 hands every bottom its
+// range of top_diff): plane (n, c) of it starts at ((n * dctot + dc0 + c) * hw)
 __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restrict__ top_data, const float* __restrict__ top_diff,
                                                            float* __restrict__ bottom_diff, float* __restrict__ partial,
-                                                           unsigned hw, float slope) {
+                                                           unsigned hw, float slope, int C, int dctot, int dc0) {
   __shared__ float red[4];
   const unsigned plane = blockIdx.y;
   const size_t base = (size_t)plane * hw;
+  const size_t dbase = ((size_t)(plane / (unsigned)C) * dctot + dc0 + plane % (unsigned)C) * hw;
   float acc = 0.f;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < hw; i += gridDim.x * 256u) {
-    const float g = top_diff[base + i] * (top_data[base + i] > 0.f ? 1.f : slope);
+    const float g = top_diff[dbase + i] * (top_data[base + i] > 0.f ? 1.f : slope);
     bottom_diff[base + i] = g;
     acc += g;
   }
@@ -87,10 +90,11 @@ FN2_API size_t fn2_bias_leaky_relu_backward_workspace_bytes(int N, int C, int H,
   return sizeof(float) * (size_t)N * C * kBwdChunks;
 }
 
-FN2_API int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
-                                         int N, int C, int H, int W, float negative_slope, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
+FN2_API int fn2_bias_leaky_relu_backward_slices(const float* top_data, const float* top_diff, int diff_channels, int diff_c0,
+                                                float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
   if (N < 0 || C <= 0 || H <= 0 || W <= 0) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: bad shape [%d,%d,%d,%d]", N, C, H, W);
+  if (diff_c0 < 0 || diff_c0 + C > diff_channels) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: top_diff slice outside its blob");
   if (N == 0) return FN2_OK;
   if (!top_data || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: null blob");
   const long long planes = (long long)N * C, hw = (long long)H * W;
@@ -100,9 +104,16 @@ FN2_API int fn2_bias_leaky_relu_backward(const float* top_data, const float* top
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(bias_leaky_relu_bwd, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
-                     (unsigned)hw, negative_slope);
+                     (unsigned)hw, negative_slope, C, diff_channels, diff_c0);
   if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks);
   return check_launch("bias_leaky_relu_backward");
+}
+
+FN2_API int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
+                                         int N, int C, int H, int W, float negative_slope, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  return fn2_bias_leaky_relu_backward_slices(top_data, top_diff, C, 0, bottom_diff, bias_diff, N, C, H, W, negative_slope, workspace,
+                                             workspace_bytes, stream);
 }
 
 FN2_API int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, int C, int H, int W, float negative_slope,

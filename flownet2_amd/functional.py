@@ -418,10 +418,12 @@ class _OwnForwardConv(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         stride, pad, slope, act, has_bias, transposed = ctx.cfg
         need_b = has_bias and ctx.needs_input_grad[2]
-        g = g.contiguous()
         if act:
-            d, db = ops.bias_leaky_relu_backward(y, g, slope, need_b)
+            # the gradient of a Concat arrives as a channel-slice view of the Concat's top_diff: read in place (no .contiguous() copy)
+            gb, g0 = _channel_slice(g)
+            d, db = ops.bias_leaky_relu_backward(y, (gb, g0, g.shape[1]), slope, need_b)
         else:
+            g = g.contiguous()
             d, db = g, (g.sum((0, 2, 3)) if need_b else None)
         need_x, need_w = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
         gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None

@@ -290,6 +290,11 @@ int fn2_scale_shift_forward(const float* bottom, float* top, const float* shift,
 int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,
                                  int N, int C, int H, int W, float negative_slope, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* The same with top_diff = channels [diff_c0, diff_c0 + C) of a [N, diff_channels, H, W] blob: the gradient a Concat hands its bottoms
+ * (concat_layer.cu:62-90) read in place instead of copied out first. */
+int fn2_bias_leaky_relu_backward_slices(const float* top_data, const float* top_diff, int diff_channels, int diff_c0,
+                                        float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope,
+                                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stem convolution of the FlowNet encoders, fused with its bias and ReLU:

@@ -2399,3 +2399,14 @@ FN2_API int fn2_upsample_flow_deconv_backward_cpu(const float* bottom, const flo
           }
   return FN2_OK;
 }
+
+FN2_API int fn2_bias_leaky_relu_backward_slices_cpu(const float* top_data, const float* top_diff, int diff_channels, int diff_c0,
+                                                    float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || diff_c0 < 0 || diff_c0 + C > diff_channels) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  float* g = slice_gather(top_diff, N, diff_channels, diff_c0, C, hw);
+  if (!g) return FN2_ERR_INVALID_ARG;
+  const int rc = fn2_bias_leaky_relu_backward_cpu(top_data, g, bottom_diff, bias_diff, N, C, H, W, negative_slope);
+  free(g);
+  return rc;
+}

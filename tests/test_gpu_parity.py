@@ -1074,3 +1074,14 @@ def test_upsample_flow_deconv_backward(shape):
     torch.nn.functional.conv_transpose2d(xr, wr, br, stride=2, padding=1).backward(dev(g).double())
     for got, ref in ((xt.grad, xr.grad), (wt.grad, wr.grad), (bt.grad, br.grad)):
         assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_bias_leaky_relu_backward_reads_a_concat_gradient_slice_in_place():
+    """top_diff as channels [c0, c0 + C) of a wider blob (what a Concat hands its bottoms) gives the bits of the copied-out slice."""
+    N, C, H, W = 2, 24, 17, 23
+    y, wide = dev(rand((N, C, H, W), 360)), dev(rand((N, C + 7, H, W), 361))
+    d0, b0 = ops.bias_leaky_relu_backward(y, wide[:, 5:5 + C].contiguous(), 0.1)
+    d1, b1 = ops.bias_leaky_relu_backward(y, (wide, 5, C), 0.1)
+    assert torch.equal(d0, d1) and torch.equal(b0, b1)
+    with pytest.raises(ValueError):
+        ops.bias_leaky_relu_backward(y, (wide, 10, C), 0.1)
