@@ -9,8 +9,9 @@
 
 Prints the time per stage (HIP events, median of the timed iterations).  The coefficient DRAWS come from a counter-based generator
 (Philox4x32-10, flownet2_amd/augment.py: the reference's boost stream cannot be reproduced, its distributions are pinned): the draws
-of iteration i are a function of (seed, i), so a background thread (augment.CoefficientPrefetcher) produces them ahead of the step and
-the "draw" stages below are what the step WAITS for them; --no-prefetch draws inline (the r02 behaviour).  Everything downstream of
+of iteration i are a function of (seed, i), so a worker PROCESS (augment.CoefficientPrefetcher(process=True)) produces them ahead of the
+step and the "draw" stages below are what the step WAITS for them; --prefetch-thread uses a background thread instead (no gain: it competes
+with the step's own Python for the interpreter lock), --no-prefetch draws inline (the r02 behaviour).  Everything downstream of
 the coefficient blobs is pinned against the reference's layers.
 Usage: python scripts/train_pipeline.py [--batch 8] [--iters 10] [--no-train] [--no-prefetch]"""
 import argparse
@@ -48,6 +49,13 @@ def synthetic_records(n, H, W, seed=0):
     return recs
 
 
+def draw_pair(it, B, W, H, cw, ch):
+    """Both coefficient blobs of iteration `it`: a pure function of (seed, it) (module level: the prefetch process pickles it)."""
+    p0 = augment.draw_batch(augment.make_rng(1, 2 * it), AUG0, B, W, H, cw, ch, discount=augment.discount_coeff(it + 1))
+    p1 = augment.draw_batch(augment.make_rng(1, 2 * it + 1), AUG1, B, W, H, cw, ch, discount=1.0, in_params=p0, mode="add")
+    return p0, p1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
@@ -58,6 +66,7 @@ def main():
     ap.add_argument("--crop-width", type=int, default=448)
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--prefetch-thread", action="store_true", help="draw on a background thread instead of a worker process")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B, H, W, ch, cw = a.batch, a.height, a.width, a.crop_height, a.crop_width
@@ -70,13 +79,11 @@ def main():
     aug0 = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=aug_p))
     aug1 = LayerRegistry.CreateLayer(LayerParameter(type="DataAugmentation", augmentation_param=aug_p))
     faug = LayerRegistry.CreateLayer(LayerParameter(type="FlowAugmentation", augmentation_param=dict(crop_width=cw, crop_height=ch)))
-    def draw(it):          # both coefficient blobs of iteration `it`: a pure function of (seed, it)
-        p0 = augment.draw_batch(augment.make_rng(1, 2 * it), AUG0, B, W, H, cw, ch, discount=augment.discount_coeff(it + 1))
-        p1 = augment.draw_batch(augment.make_rng(1, 2 * it + 1), AUG1, B, W, H, cw, ch, discount=1.0, in_params=p0, mode="add")
-        return p0, p1
-    pre = None if a.no_prefetch else augment.CoefficientPrefetcher(draw, depth=4)
+    import functools
+    draw = functools.partial(draw_pair, B=B, W=W, H=H, cw=cw, ch=ch)
+    pre = None if a.no_prefetch else augment.CoefficientPrefetcher(draw, depth=4, process=not a.prefetch_thread)
     P = {k: v.to(dev).requires_grad_(True) for k, v in nets.init_params("C", seed=0).items()}
-    opt = torch.optim.Adam(list(P.values()), lr=1e-5)
+    opt = torch.optim.Adam(list(P.values()), lr=1e-5, fused=True)
     stages = ["decode", "scale", "draw0 (host)", "augment0", "draw1 (host)", "augment1", "flow_aug", "train step"]
     times = {s: [] for s in stages}
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -116,7 +123,7 @@ def main():
         faug.Forward(bf, t_flow)
         marks[7].record()
         if not a.no_train:
-            opt.zero_grad(set_to_none=False)
+            opt.zero_grad(set_to_none=True)          # gradients handed over, not zero-filled + accumulated (as bench.py --mode train)
             loss = nets.multiscale_loss(nets.flownet_c_core(P, t_img0[0].data, t_img1[0].data, Fn), t_flow[0].data, Fn)
             loss.backward()
             opt.step()
@@ -130,7 +137,9 @@ def main():
         print("| %s | %.3f |" % (s, statistics.median(times[s])))
     if pre is not None:
         pre.close()
-    print("coefficient draws: %s" % ("prefetch thread, 4 iterations deep (draw0 = time the step waited)" if pre is not None else "inline (draw0 = both blobs)"))
+    how = "inline (draw0 = both blobs)" if pre is None else ("prefetch %s, 4 iterations deep (draw0 = time the step waited)" % ("thread" if a.prefetch_thread else "process"))
+    print("coefficient draws: %s" % how)
+    print("iteration (sum of the stages): %.3f ms" % sum(statistics.median(times[s_]) for s_ in stages))
     if not a.no_train:
         print("loss %.4f, NaN ground truth kept: %s" % (float(loss), bool(torch.isnan(t_flow[0].data).any())))
 

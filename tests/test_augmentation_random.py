@@ -122,6 +122,36 @@ def test_prefetcher_hands_out_iterations_in_order_and_surfaces_errors():
     pre.close()
 
 
+def _draw_for_process(it, seed):                 # module level: the worker process pickles it
+    aug = dict(translate=dict(rand_type="uniform_bernoulli", prob=1.0, mean=0.0, spread=0.02))
+    return A.draw_batch(A.make_rng(seed, it), aug, 4, 64, 48, 56, 40, 1.0)
+
+
+def _bad_for_process(it):
+    if it == 1:
+        raise RuntimeError("boom")
+    return it
+
+
+def test_prefetcher_in_a_worker_process():
+    """process=True: the draws run in a spawned interpreter (no competition for the consumer's interpreter lock); same order, same
+    values, errors surface in get()."""
+    import functools
+    pre = A.CoefficientPrefetcher(functools.partial(_draw_for_process, seed=9), depth=3, process=True)
+    try:
+        for it in range(6):
+            assert np.array_equal(pre.get(), _draw_for_process(it, 9))
+    finally:
+        pre.close()
+    pre = A.CoefficientPrefetcher(_bad_for_process, depth=2, process=True)
+    try:
+        assert pre.get() == 0
+        with pytest.raises(RuntimeError, match="boom"):
+            pre.get()
+    finally:
+        pre.close()
+
+
 def test_oracle_noise_effect_is_gaussian_with_the_samples_sigma():
     img = np.full((2, 3, 96, 128), 0.5, np.float32)
     co = np.zeros((2, 42), np.float32)
