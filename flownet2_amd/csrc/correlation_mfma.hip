@@ -484,7 +484,8 @@ struct HCfg {
   static constexpr int NBR = BSZ / 256, NAR = ASZ / 256, NRUN = NBR + NAR;     // 1 KiB runs per chunk: 9 + 4
   static constexpr int RPW = cdiv(NRUN, WAVES);       // runs per wave: RPW for waves < NRUN % WAVES (or all), else RPW - 1
   static constexpr int NFULL = NRUN % WAVES == 0 ? WAVES : NRUN % WAVES;
-  static constexpr int LDS_FLOATS = cmax(NBUF * CHUNK, K::OROWS * K::XS);
+  static constexpr int ROWTAB = K::OROWS * K::XS;      // behind the output image: byte offset of every image row in top (epilogue)
+  static constexpr int LDS_FLOATS = cmax(NBUF * CHUNK, ROWTAB + K::OROWS);
   static_assert(R == 10, "bank analysis above is for 72-pixel rows");
   static_assert(BSZ % 256 == 0 && ASZ % 256 == 0 && K::BPX % 4 == 0, "whole 1 KiB runs of 16-byte slots");
   static_assert(CHB % 64 == 32, "channel stride must flip bank bit 5");
@@ -694,38 +695,33 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const size_t top_n = (size_t)k.n * g.ctot + g.c0;
 
   // Output rows of this task: rowid = (rmi * 4 + rni) * D + oo  <->  top[n, (qq = 4a + rni - rmi, oo), y = 2 (4I + rmi) + py,
-  // 32-pixel span].  8 threads x 16 bytes per row, 32 rows per pass; offsets are 32-bit inside the sample's output
-  // (buffer store), the (rmi, rni, oo) decode is carried incrementally: 32 = 21 + 11.
+  // 32-pixel span].  8 threads x 16 bytes per row, 32 rows per pass; offsets are 32-bit inside the sample's output (buffer store).
   const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
       top + top_n * plane, 0, (unsigned)(4u * K::D * K::D * (unsigned)plane), 0x00020000);
-  auto store_rows = [&](auto from_lds) {
-    constexpr bool LDS = decltype(from_lds)::value;
+  // Dead tasks write zeros for the rows that exist; live tasks look the row's offset up in a table
+  // the workgroup builds once (the decode, its range tests and the offset arithmetic cost ~25 VALU instructions per row and thread before --
+  // VALU time is matrix-pipe time for the workgroups still in their K loops, and the epilogue + DMA plan were 1.4 VALU instructions per MFMA
+  // of the whole launch, profiles/r03_corr_stall_counters.txt).
+  constexpr unsigned NOROW = 0xffffffffu;
+  const unsigned hw4 = 4u * (unsigned)plane, w4 = 4u * (unsigned)g.W;
+  auto row_offset = [&](int rowid) -> unsigned {              // rowid = (rmi * 4 + rni) * D + oo
+    const int blk = rowid / K::D, oo = rowid - blk * K::D, rmi = blk >> 2, rni = blk & 3;
+    const int qq = 4 * k.a + rni - rmi, y = 2 * (i0 + rmi) + k.py;
+    return (qq >= 0 && qq < K::D && y < g.H) ? (unsigned)(qq * K::D + oo) * hw4 + (unsigned)y * w4 : NOROW;
+  };
+  auto store_zero_rows = [&]() {
     const int xq = tid & 7, x = 2 * jS + 4 * xq;
     if (x >= g.W) return;                                   // W % 4 == 0: a quad is inside or outside as a whole
-    int rowid = tid >> 3;                                   // < 32
-    int rni = rowid >= K::D ? 1 : 0, oo = rowid - rni * K::D, rmi = 0;
-    const unsigned hw4 = 4u * (unsigned)plane, w4 = 4u * (unsigned)g.W;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (; rowid < K::OROWS; rowid += H::THREADS / 8) {
-      const int qq = 4 * k.a + rni - rmi, y = 2 * (i0 + rmi) + k.py;
-      if (qq >= 0 && qq < K::D && y < g.H) {
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (LDS) {
-          const float* src = smem + rowid * K::XS + 4 * xq;
-          v = f32x4{src[0], src[1], src[2], src[3]};
-        }
-        const unsigned off = (unsigned)(qq * K::D + oo) * hw4 + (unsigned)y * w4 + 4u * (unsigned)x;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsT, off, 0, 0);
-      }
-      oo += (H::THREADS / 8) - K::D;                        // + 32 rows = one (rmi, rni) block further, + 11
-      ++rni;
-      if (oo >= K::D) { oo -= K::D; ++rni; }
-      if (rni >= 4) { rni -= 4; ++rmi; }
+    for (int rowid = tid >> 3; rowid < K::OROWS; rowid += H::THREADS / 8) {
+      const unsigned off = row_offset(rowid);
+      if (off != NOROW)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, z), rsT, off + 4u * (unsigned)x, 0, 0);
     }
   };
-
   if (!k.live) {          // dead task: zeros, no LDS round trip
-    store_rows(std::false_type{});
+    store_zero_rows();
     return;
   }
 
@@ -761,11 +757,9 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
     const float sumelems = (float)g.C;
     const bool pow2 = (g.C & (g.C - 1)) == 0;
     const float rcp = 1.0f / sumelems;
-    // 1 / C is exact for power-of-two channel counts (x / 2^k == x * 2^-k); otherwise keep the reference's true division
-    if (pow2) {
-#pragma unroll
-      for (int b = 0; b < K::NB; ++b) { acc0[b] *= rcp; acc1[b] *= rcp; }
-    } else {
+    // 1 / C: exact for power-of-two channel counts (x / 2^k == x * 2^-k) and applied to the rows on their way out, together with the
+    // ReLU; otherwise the reference's true division, here
+    if (!pow2) {
 #pragma unroll
       for (int b = 0; b < K::NB; ++b) { acc0[b] /= sumelems; acc1[b] /= sumelems; }
     }
@@ -776,15 +770,32 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
         const int oo = 4 * b + nj - r;
         if (oo >= 0 && oo < K::D) {
           float* dst = smem + ((mi * 4 + ni) * K::D + oo) * K::XS + 2 * (4 * Jw + r);
-          float v0 = acc0[b][r], v1 = acc1[b][r];
-          if (g.relu) { v0 = v0 > 0.f ? v0 : v0 * g.slope; v1 = v1 > 0.f ? v1 : v1 * g.slope; }
-          dst[0] = v0;
-          dst[1] = v1;
+          dst[0] = acc0[b][r];
+          dst[1] = acc1[b][r];
         }
       }
     }
+    unsigned* rowtab = reinterpret_cast<unsigned*>(smem + H::ROWTAB);
+    for (int rowid = tid; rowid < K::OROWS; rowid += H::THREADS) rowtab[rowid] = row_offset(rowid);
     __syncthreads();
-    store_rows(std::true_type{});
+    const int xq = tid & 7, x = 2 * jS + 4 * xq;
+    if (x < g.W) {
+      const float scale = pow2 ? rcp : 1.0f;
+      const float slope = g.slope;
+      const bool relu = g.relu != 0;
+#pragma unroll 1
+      for (int rowid = tid >> 3; rowid < K::OROWS; rowid += H::THREADS / 8) {
+        const unsigned off = rowtab[rowid];
+        if (off == NOROW) continue;
+        const float* src = smem + rowid * K::XS + 4 * xq;
+        f32x4 v = f32x4{src[0], src[1], src[2], src[3]} * scale;
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rsT, off + 4u * (unsigned)x, 0, 0);
+      }
+    }
   }
 #ifdef FN2_ABLATION
   if (dbg && lane == 0 && blockIdx.x < 1024) {      // per wave (scripts/probes/corr_wave_trace.py): start, loop end, end, {HW_ID, tile-range selector, Jw}
