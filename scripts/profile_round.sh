@@ -15,7 +15,9 @@ rm -f $FN2_AUTOTUNE_CACHE
 # warm MIOpen's find-db so the profiled run shows steady-state kernels only
 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/bench_profiled.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/corr -o corr -- python scripts/corr_microbench.py --iters 200 --backward > $R/corr_stdout.txt 2>/dev/null
+# 6000 forward launches (0.25 s): the chip needs ~25 ms of load (the first ~500 launches) to reach its steady clocks -- a 200-launch run
+# (rounds 1-2) sat inside that ramp and read 47 us for a kernel that runs at 41.3 us from launch 500 on; the average below includes the ramp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/corr -o corr -- python scripts/corr_microbench.py --iters 6000 --backward > $R/corr_stdout.txt 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_sq -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1

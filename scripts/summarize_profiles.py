@@ -34,7 +34,8 @@ lines = [f"# rocprofv3 summary, round tag {tag}", "",
 
 # --- correlation micro-benchmark: kernel trace
 ks = kernel_stats(os.path.join(R, "corr", "corr_kernel_stats.csv"))
-lines += ["## `rocprofv3 --kernel-trace --stats -- python scripts/corr_microbench.py --iters 200 --backward`", "",
+lines += ["## `rocprofv3 --kernel-trace --stats -- python scripts/corr_microbench.py --iters 6000 --backward`", "",
+          "(6,000 forward / 1,200 backward launches: the average includes the ~25 ms clock ramp of the first ~500 launches; rounds 1-2 profiled 200 launches, i.e. the ramp only)", "",
           "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
 corr_avg_us = None
 for r in ks[:6]:
