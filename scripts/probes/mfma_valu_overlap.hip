@@ -1,6 +1,7 @@
 // Does f32 VALU work overlap with v_mfma_f32_16x16x4_f32 on one SIMD?  One wave per SIMD (1024 waves), a loop of 16 independent MFMAs
 // with M independent v_add_f32 / v_fma_f32 threaded between them; prints cycles per loop trip for M = 0, 8, 16, 32, 64.
 //   hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_valu_overlap.hip -o /tmp/mvo && /tmp/mvo
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -35,6 +36,9 @@ static void run(float* d, const char* what) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL((probe<M, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, d, 10, 1.0f);
+  // the chip needs ~25 ms of load to reach its steady clocks (round 3: a single 0.4 ms launch -- rounds 1-2 -- reads the ramp clock, ~2.17 GHz)
+  for (int w = 0; w < (getenv("FN2_PROBE_WARM") ? atoi(getenv("FN2_PROBE_WARM")) : 0); ++w)
+    hipLaunchKernelGGL((probe<M, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, d, iters, 1.0f);
   hipEventRecord(e0, 0);
   hipLaunchKernelGGL((probe<M, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, d, iters, 1.0f);
   hipEventRecord(e1, 0);
