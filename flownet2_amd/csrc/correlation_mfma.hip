@@ -25,6 +25,7 @@
 // (A first generation with register staging and ds_read_b128 operands ran 62 us where these run 51 / 42 us; DESIGN.md.)
 //
 // Scheduling: decode_task below (live tasks first, dead tasks last, lists balanced over the 8 XCDs).
+#include <algorithm>
 #include "correlation.hpp"
 
 #include <type_traits>
@@ -69,6 +70,18 @@ struct MfmaArgs {
   int ctot, c0;         // top blob: channels of the whole blob, first channel of the D*D slice this layer writes
   int relu; float slope;   // fused ReLU{negative_slope} on the way out
 };
+
+// Which patch column Jw the wave on SIMD s of a workgroup takes (corr_fwd_pair): code bits [2s, 2s + 2) = Jw.  N tiles outside the image
+// are skipped, so the four waves of a task carry 4 / 5 / 6 / 6 tile units (full 32-pixel span) or 6 / 5 / 4 / 0 (the ragged last span of a
+// 56-pixel row), and the three workgroups that share a CU -- list entries j, j + 32, j + 64 of an XCD: the dispatcher deals one workgroup
+// to every CU of the XCD, then the next round -- stacked 17 units on one SIMD against 13.5 on average when every workgroup let wave w take
+// column w (per-wave trace, scripts/probes/corr_wave_trace.py: all SIMDs of a CU end together, at the pace of the busiest).  The host picks
+// the three bijections SIMD -> Jw of a CU's workgroups that minimise the busiest SIMD (15 here); a wave reads its SIMD from HW_ID.
+struct SimdPlan {
+  int on;
+  unsigned char p[8][96];          // [XCD][entry of the XCD's range]; entries >= 96 start when a slot frees up: no plan
+};
+constexpr unsigned char kIdentityPlan = 0xE4;
 
 // live N patch-rows of M patch-row I: a in [alo, ahi] (may be empty)
 template <int S2, int R>
@@ -672,7 +685,7 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
 template <int R, int PROJ = 0>
 __global__ void __launch_bounds__(256, 3)
 corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
-              unsigned long long* __restrict__ dbg) {
+              unsigned long long* __restrict__ dbg, SimdPlan plan) {
   using K = Cfg<2, R>;
   using H = HCfg<R>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -683,7 +696,20 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
   const Task k = decode_task<2, R>(g);
   if (!k.valid) return;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int Jw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int Jw = wave;
+  if (k.live && plan.on && blockIdx.x < 8 * 96) {          // SimdPlan: the wave on SIMD s takes the patch column the host planned for it
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const int simd = (int)((hwid >> 4) & 3u);
+    int* note = reinterpret_cast<int*>(smem + H::NBUF * H::CHUNK);      // behind the ring; the output image reaches it only in the epilogue
+    static_assert(H::NBUF * H::CHUNK + 4 <= H::LDS_FLOATS, "room for the four SIMD notes");
+    if (lane == 0) note[wave] = simd;
+    __syncthreads();
+    const int seen = (1 << note[0]) | (1 << note[1]) | (1 << note[2]) | (1 << note[3]);
+    if (seen == 15)                                          // the four waves sit on four SIMDs (else: wave w keeps column w)
+      Jw = __builtin_amdgcn_readfirstlane((plan.p[blockIdx.x % 8][blockIdx.x / 8] >> (2 * simd)) & 3);
+  }
   const int i0 = 4 * k.I, jS = K::SPANC * k.span, jw = jS + 4 * Jw;
   const int Hc = (g.H - k.py + 1) / 2;
   const int Wc = g.W / 2;                          // W % 4 == 0: both x parities have W / 2 class columns
@@ -733,7 +759,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
   {
     const int sel = tile_range_sel<2, R>(jw, Wc);
     wave_sel = sel;
-#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_, PROJ>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, Jw, Jw, k.py, i0, i2_0, jS)
+#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_, PROJ>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, wave, Jw, k.py, i0, i2_0, jS)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
       case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
@@ -822,6 +848,65 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
 }
 
 int g_corr_skip_dead = 0;     // profiling hook (fn2_debug_set_correlation_impl(14)): launch no zero-fill workgroups
+int g_corr_simd_plan = 1;      // profiling / test hook (fn2_debug_set_correlation_impl(13) switches the SIMD plan of corr_fwd_pair off)
+
+// Tile units of wave Jw of a span (the specialised N-tile ranges of tile_range_sel).
+template <int R>
+static int pair_tiles(int span, int Jw, int Wc) {
+  using K = Cfg<2, R>;
+  const int jw = K::SPANC * span + 4 * Jw;
+  if (jw >= Wc) return 0;
+  int lo = K::NB, hi = -1;
+  for (int b = 0; b < K::NB; ++b) {
+    const int j2 = jw - R + 4 * b;
+    if (j2 + 3 >= 0 && j2 < Wc) { lo = std::min(lo, b); hi = std::max(hi, b); }
+  }
+  if (hi < lo) return 0;
+  return std::max(hi, K::HI_MIN) - std::min(lo, K::LO_MAX) + 1;
+}
+
+template <int R>
+static void build_simd_plan(const MfmaArgs& g, SimdPlan& plan) {
+  static const int perms[24][4] = {{0,1,2,3},{0,1,3,2},{0,2,1,3},{0,2,3,1},{0,3,1,2},{0,3,2,1},{1,0,2,3},{1,0,3,2},{1,2,0,3},{1,2,3,0},{1,3,0,2},{1,3,2,0},
+                                   {2,0,1,3},{2,0,3,1},{2,1,0,3},{2,1,3,0},{2,3,0,1},{2,3,1,0},{3,0,1,2},{3,0,2,1},{3,1,0,2},{3,1,2,0},{3,2,0,1},{3,2,1,0}};
+  auto code = [](const int* pm) { return (unsigned char)(pm[0] | (pm[1] << 2) | (pm[2] << 4) | (pm[3] << 6)); };
+  const int Wc = g.W / 2, per_span = g.TH / g.NSPAN;
+  // the plan is a function of (N, H, W) only: the 147k-step search below runs once per geometry, not once per launch
+  struct Cached { int N, H, W; SimdPlan plan; };
+  static thread_local Cached cache[4] = {};
+  static thread_local int next = 0;
+  for (const Cached& c : cache)
+    if (c.N == g.N && c.H == g.H && c.W == g.W && c.N > 0) { plan = c.plan; plan.on = g_corr_simd_plan; return; }
+  plan.on = g_corr_simd_plan;
+  for (int x = 0; x < 8; ++x)
+    for (int j = 0; j < 32; ++j) {
+      int tv[3][4];
+      for (int s = 0; s < 3; ++s) {
+        const int e = j + 32 * s;
+        const long long t = (long long)x * g.LP + e;
+        const bool live = e < g.LP && t < (long long)g.N * g.TH;
+        const int span = live ? (int)((t % g.TH) / per_span) : 0;
+        for (int w = 0; w < 4; ++w) tv[s][w] = live ? pair_tiles<R>(span, w, Wc) : 0;
+      }
+      int best = 1 << 30, bb = 0, bc = 0;
+      for (int b = 0; b < 24; ++b)
+        for (int c = 0; c < 24; ++c) {
+          int mx = 0, sq = 0;
+          for (int sd = 0; sd < 4; ++sd) {
+            const int l = tv[0][sd] + tv[1][perms[b][sd]] + tv[2][perms[c][sd]];
+            mx = std::max(mx, l); sq += l * l;
+          }
+          const int cost = mx * 4096 + sq;          // busiest SIMD first, then the spread
+          if (cost < best) { best = cost; bb = b; bc = c; }
+        }
+      plan.p[x][j] = kIdentityPlan;
+      plan.p[x][j + 32] = code(perms[bb]);
+      plan.p[x][j + 64] = code(perms[bc]);
+    }
+  cache[next] = Cached{g.N, g.H, g.W, plan};
+  next = (next + 1) % 4;
+}
+
 int g_corr_force_dword = 0;   // test hook: run the general (dword LDS-DMA) kernel even where the paired one applies
 int g_corr_proj = 0;          // profiling hook (fn2_debug_set_correlation_impl(7 / 8)): the PROJ = 1 / 2 builds of corr_fwd_pair
 
@@ -854,6 +939,8 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
         ((reinterpret_cast<uintptr_t>(b0) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(top)) & 15) == 0;
     if (!g_corr_force_dword && !g_corr_ablation && aligned) {
       const size_t lds3 = sizeof(float) * HCfg<R>::LDS_FLOATS;
+      SimdPlan plan;
+      build_simd_plan<R>(g, plan);
       static bool attr3_set = false;
       if (!attr3_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
@@ -865,7 +952,7 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
           attrq_set = true;
         }
-        hipLaunchKernelGGL((corr_fwd_pair<R, 3>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+        hipLaunchKernelGGL((corr_fwd_pair<R, 3>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
         return check_launch("correlation_forward (mfma, paired parities, projection build)");
       }
       if (g_corr_proj == 1 || g_corr_proj == 2) {
@@ -875,11 +962,11 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
           attrp_set = true;
         }
-        if (g_corr_proj == 1) hipLaunchKernelGGL((corr_fwd_pair<R, 1>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
-        else                  hipLaunchKernelGGL((corr_fwd_pair<R, 2>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+        if (g_corr_proj == 1) hipLaunchKernelGGL((corr_fwd_pair<R, 1>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
+        else                  hipLaunchKernelGGL((corr_fwd_pair<R, 2>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
         return check_launch("correlation_forward (mfma, paired parities, projection build)");
       }
-      hipLaunchKernelGGL((corr_fwd_pair<R>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg);
+      hipLaunchKernelGGL((corr_fwd_pair<R>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
       return check_launch("correlation_forward (mfma, paired parities)");
     }
   }

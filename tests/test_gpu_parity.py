@@ -933,6 +933,23 @@ def test_scale_shift_deploy_head_is_two_roundings(shape):
     assert torch.equal(blob[:, 3:3 + C].cpu(), torch.from_numpy(got)) and bool((blob[:, :3] == 7).all()) and bool((blob[:, 3 + C:] == 7).all())
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 40, 56), (2, 48, 11, 12), (1, 32, 33, 64), (4, 16, 48, 96), (1, 16, 56, 128), (3, 16, 40, 64), (1, 16, 9, 132)])
+def test_correlation_simd_plan_changes_no_bit(shape):
+    """corr_fwd_pair lets the wave on SIMD s take the patch column the host planned for it (balancing the tile units per SIMD over the
+    three workgroups of a CU); which wave computes a column cannot change a bit of it."""
+    b0, b1 = dev(rand(shape, 244)), dev(rand(shape, 245))
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    outs = {}
+    for impl in (0, 13):
+        ops.set_correlation_impl(impl)
+        try:
+            outs[impl] = ops.correlation_forward(p, b0, b1)
+        finally:
+            ops.set_correlation_impl(0)
+    assert torch.equal(outs[0], outs[13])
+    assert_close(host(outs[0]), oracle.correlation_forward(oracle.corr_params(20, 1, 20, 1, 2), host(b0), host(b1)), 2e-6, "vs oracle")
+
+
 # ---- channel-slice forms of FlowWarp / ChannelNorm / Resample (round 3) ---------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 5, 17, 23), (3, 3, 64, 96)])
 def test_flow_warp_slices_is_bitwise_the_plain_layer(shape):
