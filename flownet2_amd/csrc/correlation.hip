@@ -158,7 +158,7 @@ static int g_force_generic = 0;
 
 using namespace fn2;
 
-namespace fn2 { extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_prio; extern int g_corr_one_chunk_schedule; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; } }
+namespace fn2 { extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; } }
 
 FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   fn2::g_corr_dbg = reinterpret_cast<unsigned long long*>(device_buffer);
@@ -176,8 +176,6 @@ FN2_API int fn2_debug_set_correlation_impl(int impl) {
   fn2::bwd::g_corr_bwd_gen = (impl == 6) ? 2 : 0;        // 6 = second-generation MFMA backward (LDS-DMA staging, gathered G)       // 5 = first-generation (register-staged) MFMA backward where the LDS-DMA one applies
   fn2::g_corr_skip_dead = (impl == 14);                  // 14 (profiling, wrong output): no zero-fill workgroups
   fn2::g_corr_simd_plan = (impl != 13);                  // 13 = corr_fwd_pair without the SIMD plan (wave w takes patch column w)
-  fn2::g_corr_one_chunk_schedule = (impl == 15);         // 15 = the one-chunk-per-barrier schedule of corr_fwd_pair
-  fn2::g_corr_prio = (impl >= 16 && impl <= 18) ? impl - 16 : 0;   // 17 / 18: issue priority by K-loop progress (laggards / leaders first)
   fn2::g_corr_ablation = impl >= 64 ? impl - 64 : 0;
   return FN2_OK;
 }

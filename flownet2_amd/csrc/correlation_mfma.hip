@@ -69,7 +69,6 @@ struct MfmaArgs {
   int LP, DP;           // live / dead list entries per XCD
   int ctot, c0;         // top blob: channels of the whole blob, first channel of the D*D slice this layer writes
   int relu; float slope;   // fused ReLU{negative_slope} on the way out
-  int prio;             // experiment: issue priority by progress through the K loop (two-chunk schedule)
 };
 
 // Which patch column Jw the wave on SIMD s of a workgroup takes (corr_fwd_pair): code bits [2s, 2s + 2) = Jw.  N tiles outside the image
@@ -510,7 +509,7 @@ struct HCfg {
 // on the same staging, LDS traffic and epilogue, with the operand split taken as free; 2 = no MFMA at all (the data-movement
 // floor of this structure); 3 = all the MFMAs, every second LDS-DMA run (half the staging traffic: 46.3 us against 47.3, i.e. the
 // staging volume is NOT what holds this kernel back).  The operands are kept alive by empty asm statements, so the LDS reads stay.
-template <int R, int LO, int HI, int PROJ = 0, int SCHED = 0, typename Acc>
+template <int R, int LO, int HI, int PROJ = 0, typename Acc>
 __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, const float* a_n, const float* b_n, const MfmaArgs& g,
                                             unsigned lds_base, int lane, int wave, int Jw, int py, int i0, int i2_0, int jS) {
   using K = Cfg<2, R>;
@@ -663,111 +662,6 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
   using T = std::true_type;
   using F = std::false_type;
 
-  if constexpr (SCHED == 1) {
-    // TWO chunks per barrier on a ring of FOUR slots.  Per pair (c, c + 1), c even:
-    //   C  k-step 0 of chunk c, with the LDS-DMA of chunks c + 2 and c + 3 issued between its MFMAs (their slots held c - 2 and c - 1, whose
-    //      operands every wave has read before the last barrier)
-    //   D  k-step 1 of chunk c, with the operand reads of chunk c + 1 between its MFMAs (visible since the last barrier)
-    //   E  k-step 0 of chunk c + 1
-    //   A  s_waitcnt vmcnt(0) (chunks c + 2, c + 3: issued 1.5 chunk times ago), s_barrier
-    //   B  k-step 1 of chunk c + 1, with the operand reads of chunk c + 2 between its MFMAs
-    // i.e. one wait + barrier per 48 MFMAs of the heaviest wave instead of one per 24, and half a chunk time more for the data to arrive.
-    static_assert(PROJ == 0, "projection builds use the one-chunk schedule");
-    constexpr int NB4 = 4;
-    auto interleaved_reads = [&](const Ops& use, int r, Ops& into, const float* buf) {      // MFMAs of k-step r of `use`, reads into `into`
-      if constexpr (NT > 0) {
-        constexpr int GROUPS = 1 + KS * ((NT + 1) / 2);
-        static_assert(GROUPS <= 2 * NT, "one read group per MFMA");
-#pragma unroll
-        for (int j = 0; j < 2 * NT; ++j) {
-          mfma_step(use, r, j);
-          if (j < GROUPS) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (j == 0) {
-#pragma unroll
-              for (int q = 0; q < KS; ++q) into.a[q] = *reinterpret_cast<const f32x2*>(buf + aAddr + q * ASTEP);
-            } else {
-              const int q = (j - 1) / ((NT + 1) / 2), t0 = 2 * ((j - 1) % ((NT + 1) / 2));
-#pragma unroll
-              for (int t = t0; t < t0 + 2 && t < NT; ++t) into.b[q][t] = *reinterpret_cast<const f32x2*>(buf + bAddr + q * BSTEP + 8 * (LO + t));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    };
-    auto plain = [&](const Ops& use, int r) {
-#pragma unroll
-      for (int j = 0; j < 2 * NT; ++j) mfma_step(use, r, j);
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto with_issue = [&](const Ops& use, int c2, int slot) {                                  // k-step 0 of `use` + DMA of chunks c2, c2 + 1
-      int sa = slot + 2; if (sa >= NB4) sa -= NB4;
-      int sb = slot + 3; if (sb >= NB4) sb -= NB4;
-      const unsigned ba = lds_base + 4u * (unsigned)(sa * H::CHUNK), bb = lds_base + 4u * (unsigned)(sb * H::CHUNK);
-      const unsigned oa = (unsigned)c2 * chunk_bytes, ob = oa + chunk_bytes;
-      constexpr int TOTAL = 2 * H::RPW, M = 2 * NT > 0 ? 2 * NT : 1, PER = (TOTAL + M - 1) / M;   // runs behind every MFMA
-      int issued = 0;
-#pragma unroll
-      for (int j = 0; j < 2 * NT; ++j) {
-        mfma_step(use, 0, j);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < PER; ++q)
-          if (issued < TOTAL) { if (issued < H::RPW) run(issued, ba, oa); else run(issued - H::RPW, bb, ob); ++issued; }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int i = 0; i < TOTAL; ++i)
-        if (i >= issued) { if (i < H::RPW) run(i, ba, oa); else run(i - H::RPW, bb, ob); }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-#pragma unroll
-    for (int i = 0; i < H::RPW; ++i) run(i, lds_base, 0u);
-#pragma unroll
-    for (int i = 0; i < H::RPW; ++i) run(i, lds_base + 4u * H::CHUNK, chunk_bytes);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    Ops oe, oo;                                   // operands of the even / the odd chunk of a pair
-    read_ops(oe, smem);
-    int slot = 0, c = 0;
-    for (; c + 2 < nchunks; c += 2) {             // nchunks is even and >= 2 (C % 16 == 0)
-      int s1 = slot + 1; if (s1 >= NB4) s1 -= NB4;
-      int s2 = slot + 2; if (s2 >= NB4) s2 -= NB4;
-      if (g.prio) {                               // waves that are behind get the pipes first (prio 1) or last (prio 2)
-        int q = (4 * c) / nchunks;
-        if (g.prio == 1) q = 3 - q;
-        switch (q) {
-          case 0: __builtin_amdgcn_s_setprio(0); break;
-          case 1: __builtin_amdgcn_s_setprio(1); break;
-          case 2: __builtin_amdgcn_s_setprio(2); break;
-          default: __builtin_amdgcn_s_setprio(3); break;
-        }
-      }
-      with_issue(oe, c + 2, slot);                                   // C
-      interleaved_reads(oe, 1, oo, smem + s1 * H::CHUNK);            // D
-      __builtin_amdgcn_sched_barrier(0);
-      plain(oo, 0);                                                  // E
-      wait_vmcnt<0>();                                               // A
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      interleaved_reads(oo, 1, oe, smem + s2 * H::CHUNK);            // B
-      __builtin_amdgcn_sched_barrier(0);
-      slot = s2;
-    }
-    {
-      int s1 = slot + 1; if (s1 >= NB4) s1 -= NB4;
-      plain(oe, 0);
-      interleaved_reads(oe, 1, oo, smem + s1 * H::CHUNK);
-      __builtin_amdgcn_sched_barrier(0);
-      plain(oo, 0);
-      __builtin_amdgcn_s_barrier();               // the last reads of the ring are done: the epilogue's image may overwrite it
-      __builtin_amdgcn_sched_barrier(0);
-      plain(oo, 1);
-    }
-    return;
-  }
-
 #pragma unroll
   for (int i = 0; i < H::RPW; ++i) run(i, lds_base, 0u);
 #pragma unroll
@@ -788,7 +682,7 @@ __device__ __forceinline__ void k_loop_pair(Acc& acc0, Acc& acc1, float* smem, c
   chunk_step(F{}, F{}, c + 1, slot, o1, o0);
 }
 
-template <int R, int PROJ = 0, int SCHED = 0>
+template <int R, int PROJ = 0>
 __global__ void __launch_bounds__(256, 3)
 corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top, MfmaArgs g,
               unsigned long long* __restrict__ dbg, SimdPlan plan) {
@@ -865,7 +759,7 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
   {
     const int sel = tile_range_sel<2, R>(jw, Wc);
     wave_sel = sel;
-#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_, PROJ, SCHED>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, wave, Jw, k.py, i0, i2_0, jS)
+#define FN2_KLOOP(LO_, HI_) k_loop_pair<R, LO_, HI_, PROJ>(acc0, acc1, smem, a_n, b_n, g, lds_base, lane, wave, Jw, k.py, i0, i2_0, jS)
     switch (sel) {
       case 0: FN2_KLOOP(0, K::HI_MIN + 0); break;
       case 1: FN2_KLOOP(0, K::HI_MIN + 1); break;
@@ -953,8 +847,6 @@ corr_fwd_pair(const float* __restrict__ b0, const float* __restrict__ b1, float*
 #endif
 }
 
-int g_corr_prio = 0;                 // profiling hook (fn2_debug_set_correlation_impl(16 + mode))
-int g_corr_one_chunk_schedule = 0;   // test / profiling hook (fn2_debug_set_correlation_impl(15)): one chunk per barrier (rounds 1-2)
 int g_corr_skip_dead = 0;     // profiling hook (fn2_debug_set_correlation_impl(14)): launch no zero-fill workgroups
 int g_corr_simd_plan = 1;      // profiling / test hook (fn2_debug_set_correlation_impl(13) switches the SIMD plan of corr_fwd_pair off)
 
@@ -1040,7 +932,6 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
   if (NL + ND > (1ll << 30)) return fail(FN2_ERR_UNSUPPORTED, "correlation: problem too large for the MFMA path");
   g.LP = (int)((NL + 7) / 8);
   g.DP = (int)((ND + 7) / 8);
-  g.prio = g_corr_prio;
   if (g_corr_skip_dead) g.DP = 0;          // profiling only (wrong output): what the zero-fill workgroups cost
   const unsigned grid = 8u * (unsigned)(g.LP + g.DP);
   if constexpr (S2 == 2 && R == 10) {
@@ -1074,16 +965,6 @@ static int launch(const CorrGeom& cg, const float* b0, const float* b1, float* t
         if (g_corr_proj == 1) hipLaunchKernelGGL((corr_fwd_pair<R, 1>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
         else                  hipLaunchKernelGGL((corr_fwd_pair<R, 2>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
         return check_launch("correlation_forward (mfma, paired parities, projection build)");
-      }
-      if (!g_corr_one_chunk_schedule) {           // two chunks per barrier, ring of four slots
-        const size_t lds4 = sizeof(float) * cmax(4 * HCfg<R>::CHUNK, HCfg<R>::ROWTAB + Cfg<2, R>::OROWS);
-        static bool attr4_set = false;
-        if (!attr4_set) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_fwd_pair<R, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-          attr4_set = true;
-        }
-        hipLaunchKernelGGL((corr_fwd_pair<R, 0, 1>), dim3(grid), dim3(HCfg<R>::THREADS), lds4, st, b0, b1, top, g, g_corr_dbg, plan);
-        return check_launch("correlation_forward (mfma, paired parities, two chunks per barrier)");
       }
       hipLaunchKernelGGL((corr_fwd_pair<R>), dim3(grid), dim3(HCfg<R>::THREADS), lds3, st, b0, b1, top, g, g_corr_dbg, plan);
       return check_launch("correlation_forward (mfma, paired parities)");
