@@ -244,17 +244,9 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         step_fn = g.replay
     else:
         step_fn = step
-    # settling: untimed steps, back to back, until the chip has been under this load for settle_s seconds
-    torch.cuda.synchronize()
-    settle_steps, t_s = 0, time.perf_counter()
-    while warmup > 0 and time.perf_counter() - t_s < settle_s and settle_steps < 2000:
-        for _ in range(4):
-            step_fn()
-        settle_steps += 4
-        torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    # Everything the host has to do before the timed region happens BEFORE the settling steps (event objects, a full garbage collection: a
+    # few milliseconds in which the device would sit idle and fall back to its low clocks), so that the synchronisation in front of the
+    # timed region is followed by the first timed launch at once.
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     # The cyclic collector is paused for the K timed steps (config.python_gc): a generation-2 pass over the interpreter's objects
     # takes milliseconds -- two steps of the batch-1 configuration -- and has nothing to collect here (no reference cycles in a step).
@@ -263,6 +255,17 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
     if gc_was_on:
         gc.collect()
         gc.disable()
+    # settling: untimed steps, back to back, until the chip has been under this load for settle_s seconds
+    torch.cuda.synchronize()
+    settle_steps, t_s = 0, time.perf_counter()
+    while warmup > 0 and time.perf_counter() - t_s < settle_s and settle_steps < 2000:
+        for _ in range(16):
+            step_fn()
+        settle_steps += 16
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
