@@ -49,6 +49,7 @@ __device__ __forceinline__ float scaled(float v, float s) { return v * s; }
 // for the planes of the group (the first version decoded a 64-bit flat index per element and re-evaluated the
 // coefficient of every one of the (2r+1)^2 taps: 30 us for a 10 MB up-sampling).
 
+template <bool EXTRA>
 __global__ void __launch_bounds__(256) resample_nearest(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
@@ -62,14 +63,15 @@ __global__ void __launch_bounds__(256) resample_nearest(const float* __restrict_
   yr = min(max(yr, 0), a.Hin - 1);
   const unsigned src = (unsigned)yr * a.Win + xr;
   for (int c = blockIdx.y * a.ppt; c < min(a.NC, (int)(blockIdx.y + 1) * a.ppt); ++c) {
-    const float v = scaled(in[(size_t)c * hw_in + src], a.in_scale);
-    out[top_plane(c, a.C, a.octot, a.oc0) * hw_out + p] = v;
-    if (out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
+    const float raw = in[(size_t)c * hw_in + src];
+    const float v = EXTRA ? scaled(raw, a.in_scale) : raw;
+    out[(EXTRA ? top_plane(c, a.C, a.octot, a.oc0) : (size_t)c) * hw_out + p] = v;
+    if (EXTRA && out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
   }
 }
 
 // FAST: tap radius <= 2 on both axes (every up-sampling and same-size call): the 5 + 5 coefficients live in registers.
-template <bool CUBIC, bool FAST>
+template <bool CUBIC, bool FAST, bool EXTRA>     // EXTRA: input scaling / channel-slice tops / second top; false = the plain layer
 __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
   const unsigned p = blockIdx.x * 256u + threadIdx.x;
@@ -113,11 +115,12 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
         for (int i = 0; i < 5; ++i) {
           const float w = px[i] * ky[j];
           // in-image taps are read even when their coefficient is 0: a NaN there poisons the result in the reference too
-          sum = fmaf(w, ((mx >> i) & (my >> j) & 1u) ? scaled(src[yo[j] + xo[i]], a.in_scale) : 0.f, sum);
+          const float tap = ((mx >> i) & (my >> j) & 1u) ? src[yo[j] + xo[i]] : 0.f;      // (the load stays unconditional: clamped address)
+          sum = fmaf(w, EXTRA ? scaled(tap, a.in_scale) : tap, sum);
         }
       const float v = (!wsum) ? 0.f : (sum / wsum);   // :93
-      out[top_plane(c, a.C, a.octot, a.oc0) * hw_out + p] = v;
-      if (out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
+      out[(EXTRA ? top_plane(c, a.C, a.octot, a.oc0) : (size_t)c) * hw_out + p] = v;
+      if (EXTRA && out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
     }
   } else {
     const int y0 = max(yr - a.ry, 0), y1 = min(yr + a.ry, a.Hin - 1);
@@ -130,13 +133,14 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
         for (int x = x0; x <= x1; ++x) {
           const float dx = x_in - x;
           const float w = a.ax * (CUBIC ? bicubic_coeff(a.ax * dx) : triangle_coeff(a.ax * dx)) * a.ay * kyv;
-          sum = fmaf(w, scaled(src[(size_t)y * a.Win + x], a.in_scale), sum);
+          const float tap = src[(size_t)y * a.Win + x];
+          sum = fmaf(w, EXTRA ? scaled(tap, a.in_scale) : tap, sum);
           wsum += w;
         }
       }
       const float v = (!wsum) ? 0.f : (sum / wsum);   // :93
-      out[top_plane(c, a.C, a.octot, a.oc0) * hw_out + p] = v;
-      if (out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
+      out[(EXTRA ? top_plane(c, a.C, a.octot, a.oc0) : (size_t)c) * hw_out + p] = v;
+      if (EXTRA && out2) out2[top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out + p] = scaled(v, a.out2_scale);
     }
   }
 }
@@ -285,14 +289,16 @@ FN2_API int fn2_resample_forward_slices(const float* in, float in_scale, float* 
     else hipLaunchKernelGGL((resample_up_linear<2, false>), gi, dim3(256), 0, st, in, out, out2, a);
     return check_launch("resample_forward");
   }
-  if (type == FN2_RESAMPLE_NEAREST) hipLaunchKernelGGL(resample_nearest, grid, dim3(256), 0, st, in, out, out2, a);
-  else if (type == FN2_RESAMPLE_CUBIC) {
-    if (fast) hipLaunchKernelGGL((resample_interp<true, true>), grid, dim3(256), 0, st, in, out, out2, a);
-    else hipLaunchKernelGGL((resample_interp<true, false>), grid, dim3(256), 0, st, in, out, out2, a);
-  } else {
-    if (fast) hipLaunchKernelGGL((resample_interp<false, true>), grid, dim3(256), 0, st, in, out, out2, a);
-    else hipLaunchKernelGGL((resample_interp<false, false>), grid, dim3(256), 0, st, in, out, out2, a);
-  }
+  const bool ex = in_scale != 1.0f || out2 || top_channels != C;
+#define FN2_RS(K_) do { if (ex) hipLaunchKernelGGL((K_<true>), grid, dim3(256), 0, st, in, out, out2, a); \
+                        else hipLaunchKernelGGL((K_<false>), grid, dim3(256), 0, st, in, out, out2, a); } while (0)
+#define FN2_RSI(C_, F_) do { if (ex) hipLaunchKernelGGL((resample_interp<C_, F_, true>), grid, dim3(256), 0, st, in, out, out2, a); \
+                             else hipLaunchKernelGGL((resample_interp<C_, F_, false>), grid, dim3(256), 0, st, in, out, out2, a); } while (0)
+  if (type == FN2_RESAMPLE_NEAREST) FN2_RS(resample_nearest);
+  else if (type == FN2_RESAMPLE_CUBIC) { if (fast) FN2_RSI(true, true); else FN2_RSI(true, false); }
+  else { if (fast) FN2_RSI(false, true); else FN2_RSI(false, false); }
+#undef FN2_RS
+#undef FN2_RSI
   return check_launch("resample_forward");
 }
 

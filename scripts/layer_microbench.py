@@ -1,21 +1,29 @@
 #!/usr/bin/env python
 """Micro-benchmarks of the custom layers at the SURVEY section 8(d) sizes: time, algorithmic bytes, achieved GB/s
-(fraction of the 8 TB/s HBM peak).  Inputs are resident in HBM; 20 warm-ups, 100 timed launches, median of 5 rounds."""
+(fraction of the 8 TB/s HBM peak).  Inputs are resident in HBM; >= 40 ms of warm-up launches, then 5 back-to-back rounds of 100 timed
+launches, median."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flownet2_amd import ops
 dev = "cuda"
 def timeit(f, iters=100, rounds=5):
+    """Steady clocks: the chip needs ~25 ms of load to reach them (rounds 1-2 timed 100 launches after 20 warm-ups, i.e. the clock ramp), so
+    the op first runs for >= 40 ms, and the rounds follow back to back without a synchronisation in between."""
     for _ in range(20): f()
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(rounds):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): f()
+    e1.record(); torch.cuda.synchronize()
+    per = max(e0.elapsed_time(e1) / 20, 1e-3)                      # ms per launch, first estimate
+    for _ in range(min(20000, int(40.0 / per) + 1)): f()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(rounds + 1)]
+    marks[0].record()
+    for r in range(rounds):
         for _ in range(iters): f()
-        e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / iters * 1e3)
-    return statistics.median(ts)
+        marks[r + 1].record()
+    torch.cuda.synchronize()
+    return statistics.median(marks[r].elapsed_time(marks[r + 1]) / iters * 1e3 for r in range(rounds))
 rows = []
 def add(name, f, nbytes):
     t = timeit(f)
