@@ -191,6 +191,7 @@ __device__ __forceinline__ void chromatic_pixel(float* rgb, const ItemCoeffs& k,
   }
 }
 
+template <bool NOISE>      // the noise effect has its own instantiation: the Philox rounds and the Box-Muller transform cost the plain path 26 % (registers)
 __global__ void __launch_bounds__(256) data_aug_kernel(DataAugArgs a) {
   const long long per = (long long)a.ch * a.cw, total = per * a.n_chunk;
   for (long long index = blockIdx.x * (long long)blockDim.x + threadIdx.x; index < total; index += (long long)gridDim.x * blockDim.x) {
@@ -232,7 +233,7 @@ __global__ void __launch_bounds__(256) data_aug_kernel(DataAugArgs a) {
       // the noise effect (:578-587: caffe_gpu_rng_gaussian(count, 0, noise) added to the sample after ApplyEffects): i.i.d. N(0, noise^2)
       // per element from Philox4x32-10 -- counter (pixel, sample * 4 + channel triple, stream), key = seed -- and Box-Muller
       float z[3] = {0.f, 0.f, 0.f};
-      if (k.noise > 0.f) {
+      if (NOISE && k.noise > 0.f) {
         const long long pixn = (long long)y * a.cw + x;
         const Philox4 r = philox4x32_10((unsigned)pixn, (unsigned)(pixn >> 32) ^ ((unsigned)n * 4u + (unsigned)(c0 / 3)), a.stream_lo, a.stream_hi, a.seed_lo, a.seed_hi);
         const float r0 = sqrtf(-2.0f * logf(philox_unit(r.v[0]))), t0 = 6.283185307179586f * philox_unit(r.v[1]);
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(256) data_aug_kernel(DataAugArgs a) {
           if ((x - a.cw / 2) * k.shadow_nx + (y - a.ch / 2) * k.shadow_ny - k.shadow_distance > 0) v -= k.shadow_strength;
           v = clampf(v, 0.f, a.max_multiplier);
         }
-        if (k.noise > 0.f) v = v + k.noise * z[c];
+        if (NOISE && k.noise > 0.f) v = v + k.noise * z[c];
         const long long pix = (long long)y * a.cw + x;
         if (a.mean_mode == FN2_MEAN_PER_CHANNEL) v = v - a.mean[c0 + c];                                  // :620-634
         else if (a.mean_mode == FN2_MEAN_PER_PIXEL) v = v - a.mean[(long long)(c0 + c) * per + pix];      // :613-616
@@ -346,7 +347,10 @@ FN2_API int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const fl
       }
       else { std::memset(&a.item[k], 0, sizeof(ItemCoeffs)); a.item[k].m.identity(); }
     }
-    hipLaunchKernelGGL(data_aug_kernel, dim3(blocks_for((long long)a.n_chunk * ch * cw, 256)), dim3(256), 0, st, a);
+    bool noisy = false;
+    for (int k = 0; k < a.n_chunk; ++k) noisy = noisy || a.item[k].noise > 0.f;
+    if (noisy) hipLaunchKernelGGL((data_aug_kernel<true>), dim3(blocks_for((long long)a.n_chunk * ch * cw, 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((data_aug_kernel<false>), dim3(blocks_for((long long)a.n_chunk * ch * cw, 256)), dim3(256), 0, st, a);
   }
   return check_launch("data_augmentation_forward");
 }

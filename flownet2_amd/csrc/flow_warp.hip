@@ -16,6 +16,7 @@ constexpr int kWarpChPerThread = 4;
 // grid: (pixel blocks, n * cgroups + channel group); 32-bit pixel index (a 64-bit flat index cost more than the warp itself)
 // image / flow / warped may be channel slices of wider blobs: sample n starts ictot (fctot, octot) planes after sample n - 1, the
 // slice at plane ic0 (fc0, oc0).
+template <bool SLICED>     // false: the plain layer (dense [N,C,H,W] image / [N,2,H,W] flow / top): its own instantiation, the indexing of rounds 1-2
 __global__ void __launch_bounds__(256) flow_warp_fwd(const float* __restrict__ image, const float* __restrict__ flow,
                                                      float* __restrict__ warped, int N, int C, int H, int W,
                                                      int cgroups, float fill, int ictot, int ic0, int octot, int oc0, int fctot, int fc0) {
@@ -25,11 +26,11 @@ __global__ void __launch_bounds__(256) flow_warp_fwd(const float* __restrict__ i
   const int y = pix / W, x = pix - y * W;
   for (unsigned g = blockIdx.y; g < (unsigned)N * cgroups; g += gridDim.y) {
     const int n = g / cgroups, cg = g - n * cgroups;
-    const float x2 = (float)x + flow[((size_t)n * fctot + fc0) * wh + pix];       // flow_warp_layer.cu:73
-    const float y2 = (float)y + flow[((size_t)n * fctot + fc0 + 1) * wh + pix];   // :74
+    const float x2 = (float)x + flow[(SLICED ? (size_t)n * fctot + fc0 : (size_t)(2 * n)) * wh + pix];           // flow_warp_layer.cu:73
+    const float y2 = (float)y + flow[(SLICED ? (size_t)n * fctot + fc0 + 1 : (size_t)(2 * n + 1)) * wh + pix];   // :74
     const int c0 = cg * kWarpChPerThread;
     const int c1 = min(C, c0 + kWarpChPerThread);
-    float* out = warped + ((size_t)n * octot + oc0) * wh + pix;
+    float* out = warped + (SLICED ? (size_t)n * octot + oc0 : (size_t)n * C) * wh + pix;
     if (x2 >= 0.f && y2 >= 0.f && x2 < (float)W && y2 < (float)H) {    // :108
       const int ixL = (int)x2, iyT = (int)y2;                           // :81-82
       const int ixR = min(ixL + 1, W - 1), iyB = min(iyT + 1, H - 1);   // :83-84
@@ -38,7 +39,7 @@ __global__ void __launch_bounds__(256) flow_warp_fwd(const float* __restrict__ i
       const float cBL = (1 - alpha) * beta, cBR = alpha * beta;
       const unsigned oTL = (unsigned)iyT * W + ixL, oTR = (unsigned)iyT * W + ixR;
       const unsigned oBL = (unsigned)iyB * W + ixL, oBR = (unsigned)iyB * W + ixR;
-      const float* im = image + ((size_t)n * ictot + ic0) * wh;
+      const float* im = image + (SLICED ? (size_t)n * ictot + ic0 : (size_t)n * C) * wh;
       for (int c = c0; c < c1; ++c) {
         const float* p = im + (size_t)c * wh;
         // :110-114, contracted like nvcc does: mul + 3 fma
@@ -229,8 +230,11 @@ FN2_API int fn2_flow_warp_forward_slices(const float* image, int image_channels,
   const float fill = (fill_value == FN2_FILL_ZERO) ? 0.f : __builtin_bit_cast(float, 0xFFE00000u);   // flow_warp_layer.cu:372-375
   const long long groups = (long long)N * cgroups;
   const dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)(groups < 65535 ? groups : 65535));
-  hipLaunchKernelGGL(flow_warp_fwd, grid, dim3(256), 0, as_stream(stream), image, flow, warped, N, C, H, W, cgroups, fill,
-                     image_channels, image_c0, top_channels, top_c0, flow_channels, flow_c0);
+  const bool sliced = image_channels != C || top_channels != C || flow_channels != 2;
+  if (sliced) hipLaunchKernelGGL((flow_warp_fwd<true>), grid, dim3(256), 0, as_stream(stream), image, flow, warped, N, C, H, W, cgroups, fill,
+                                 image_channels, image_c0, top_channels, top_c0, flow_channels, flow_c0);
+  else hipLaunchKernelGGL((flow_warp_fwd<false>), grid, dim3(256), 0, as_stream(stream), image, flow, warped, N, C, H, W, cgroups, fill,
+                          image_channels, image_c0, top_channels, top_c0, flow_channels, flow_c0);
   return check_launch("flow_warp_forward");
 }
 
