@@ -165,8 +165,10 @@ FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   return FN2_OK;
 }
 
-// impl: 0 = automatic, 1 = generic kernels, 3 = general (dword LDS-DMA) MFMA forward even where the paired-parity kernel
-// applies, 64 + bits = ablation of the general MFMA forward (FN2_ABLATION builds: 1 no MFMA, 2 no staging loads, 4 no stores)
+// impl: 0 = automatic, 1 = generic kernels, 3 = general (dword LDS-DMA) MFMA forward even where the paired-parity kernel applies,
+// 5 / 6 = first / second generation of the MFMA backward, 7 / 8 / 9 = profiling builds of the paired-parity forward (3/8 of the MFMAs, no
+// MFMAs, half the staging: wrong results), 13 = paired-parity forward without the SIMD plan, 14 = no zero-fill workgroups (profiling, wrong
+// output), 64 + bits = ablation of the general MFMA forward (FN2_ABLATION builds: 1 no MFMA, 2 no staging loads, 4 no stores)
 FN2_API int fn2_debug_set_correlation_impl(int impl) {
   g_force_generic = (impl == 1);
   fn2::g_corr1d_force_generic = (impl == 1);
