@@ -21,7 +21,7 @@ EXPORTS = [
     "fn2_channel_norm_forward", "fn2_channel_norm_forward_slices", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward", "fn2_upsample_flow_deconv_forward_into",
-    "fn2_predict_flow_conv_backward_workspace_bytes", "fn2_predict_flow_conv_backward", "fn2_upsample_flow_deconv_backward_workspace_bytes", "fn2_upsample_flow_deconv_backward",
+    "fn2_predict_flow_conv_backward_supported", "fn2_predict_flow_conv_backward_workspace_bytes", "fn2_predict_flow_conv_backward", "fn2_upsample_flow_deconv_backward_workspace_bytes", "fn2_upsample_flow_deconv_backward",
     "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward", "fn2_bias_leaky_relu_backward_slices",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
@@ -122,6 +122,7 @@ def lib():
     L.fn2_predict_flow_conv_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_predict_flow_conv_workspace_bytes.restype = sz
     L.fn2_predict_flow_conv_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_predict_flow_conv_backward_supported.argtypes = [i, i, i, i]
     L.fn2_predict_flow_conv_backward_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_predict_flow_conv_backward_workspace_bytes.restype = sz
     L.fn2_predict_flow_conv_backward.argtypes = [fp, i, i, fp, fp, fp, fp, fp, i, i, i, i, i, vp, sz, vp]

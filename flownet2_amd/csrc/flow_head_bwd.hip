@@ -224,23 +224,34 @@ __global__ void __launch_bounds__(64) uf_finalize(const float* __restrict__ part
 
 using namespace fn2;
 
-// rows per band: a function of the geometry only (the summation order depends on it)
-static int pf_rb(int N, int C, int H) {
-  int best = fhb::kRBMax;
+// rows per band: a function of the geometry only (the summation order depends on it).  Only heights whose [2][rb + 2][W + 2] band fits
+// the 60 KB of LDS a workgroup may take are candidates (wide maps get shorter bands: 1024x512 at 1/4 resolution, W = 256, C = 194 would
+// prefer rb = 32 = 70 KB and takes 16); 0 = not even one row fits (W > 2558).
+constexpr size_t kPfLdsMax = 60 * 1024;
+static size_t pf_lds(int rb, int W) { return sizeof(float) * 2 * (size_t)(rb + 2) * (size_t)(W + 2); }
+static int pf_rb(int N, int C, int H, int W) {
+  int best = 0;
   long long best_cost = -1;
-  for (int rb = fhb::kRBMax; rb >= 8; rb /= 2) {       // rounds of ~2 workgroups per CU x rows a workgroup walks (+ halo)
+  for (int rb = fhb::kRBMax; rb >= 1; rb /= 2) {       // rounds of ~2 workgroups per CU x rows a workgroup walks (+ halo)
+    if (pf_lds(rb, W) > kPfLdsMax) continue;
+    if (rb < 8 && best > 0) break;                      // bands shorter than 8 rows only where nothing taller fits
     const long long blocks = (long long)N * ((H + rb - 1) / rb) * ((C + fhb::kCG - 1) / fhb::kCG);
     const long long cost = ((blocks + 511) / 512) * (long long)((rb < H ? rb : H) + 2);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rb; }
   }
   return best;
 }
-static int pf_bands(int N, int C, int H) { const int rb = pf_rb(N, C, H); return (H + rb - 1) / rb; }
+static int pf_bands(int N, int C, int H, int W) { const int rb = pf_rb(N, C, H, W); return rb > 0 ? (H + rb - 1) / rb : 0; }
+
+FN2_API int fn2_predict_flow_conv_backward_supported(int N, int C, int H, int W) {
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (long long)H * W >= (1ll << 31) || N > 65535) return 0;
+  const int bands = pf_bands(N, C, H, W);
+  return bands > 0 && (long long)N * bands <= 65535;
+}
 
 FN2_API size_t fn2_predict_flow_conv_backward_workspace_bytes(int N, int C, int H, int W) {
-  (void)W;
-  if (N <= 0 || C <= 0 || H <= 0) return 0;
-  const size_t parts = (size_t)N * pf_bands(N, C, H);
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t parts = (size_t)N * pf_bands(N, C, H, W);
   return sizeof(float) * (parts * 18 * (size_t)C + parts * 2);
 }
 
@@ -256,12 +267,12 @@ FN2_API int fn2_predict_flow_conv_backward(const float* bottom, int bottom_chann
   if (weight_diff || bias_diff) {
     const size_t need = fn2_predict_flow_conv_backward_workspace_bytes(N, C, H, W);
     if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "predict_flow_conv_backward: workspace too small (%zu < %zu)", workspace_bytes, need);
-    const int rb = pf_rb(N, C, H), bands = pf_bands(N, C, H), parts = N * bands;
+    const int rb = pf_rb(N, C, H, W), bands = pf_bands(N, C, H, W), parts = N * bands;
+    if (rb == 0) return fail(FN2_ERR_UNSUPPORTED, "predict_flow_conv_backward: rows of %d pixels are too wide for the LDS band", W);
     if (parts > 65535) return fail(FN2_ERR_UNSUPPORTED, "predict_flow_conv_backward: too many parts");
     float* partial = reinterpret_cast<float*>(workspace);
     float* bpart = partial + (size_t)parts * 18 * C;
-    const size_t lds = sizeof(float) * 2 * (rb + 2) * (size_t)(W + 2);
-    if (lds > 60 * 1024) return fail(FN2_ERR_UNSUPPORTED, "predict_flow_conv_backward: rows too wide for the LDS band");
+    const size_t lds = pf_lds(rb, W);
     hipLaunchKernelGGL(fhb::pf_wgrad, dim3((unsigned)((C + fhb::kCG - 1) / fhb::kCG), (unsigned)parts), dim3(256), lds, st, bottom, bottom_channels, bottom_c0,
                        top_diff, partial, bpart, C, H, W, bands, rb);
     hipLaunchKernelGGL(fhb::pf_finalize, dim3((unsigned)C), dim3(64), 0, st, partial, bpart, weight_diff, bias_diff, C, parts, accumulate);

@@ -223,7 +223,7 @@ def predict_flow_conv(x, weight, bias=None):
     if _needs_grad(x, weight, bias):
         if not _train_fast_forward():
             return torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=1)
-        if _own_head_bwd():
+        if _own_head_bwd() and ops.predict_flow_conv_backward_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3]):
             return _PredictFlow.apply(x, weight, bias)
         return _OwnForwardConv.apply(x, weight, bias, run, 1, 1, 0.0, False, False)
     return run(x, weight, bias)

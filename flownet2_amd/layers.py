@@ -472,8 +472,9 @@ class DataAugmentationLayer(Layer):
     `augmentation_param` (dicts: rand_type / exp / mean / spread / prob ...) through flownet2_amd/augment.py -- the reference's control
     flow with numpy's random stream (`augmentation_param.seed`, ours), since boost's cannot be reproduced.
     Mean: `augmentation_param.mean` (3 values) with `mean_per_pixel: false` (.cpp:142-151), or the blobs a trained model carries
-    (`set_mean(per_channel=...)` = blobs_[2], `set_mean(per_pixel=...)` = blobs_[1], .cu:592-621); the running re-computation of the
-    mean over the first `recompute_mean` iterations is training-time state of the reference layer and is not reproduced."""
+    (`adjust_blobs`, cpp:162-205: only a layer with `recompute_mean > 0` takes them); `set_mean` is an explicit override of ours.  The
+    running re-computation of the mean over the first `recompute_mean` iterations (.cu:593-621) keeps blobs_[0..2] as num_iter_ /
+    mean_pixel_ / mean_channel_."""
 
     def type(self): return "DataAugmentation"
     def AllowBackward(self): return False                                            # hpp:29
@@ -484,7 +485,11 @@ class DataAugmentationLayer(Layer):
         self.mean_ = None
         self.mean_mode_ = ops.MEAN_NONE
         self.num_iter_ = 0                                                            # blobs_[0], .cu:349-351
-        self.seed_ = int(self.layer_param_.augmentation_param.get("seed", 0))         # ours: key of the counter-based streams
+        # ours: key of the counter-based streams.  caffe.proto has no seed field; the reference draws from the process-wide cuRAND / boost
+        # generators, so every layer instance gets its OWN noise and coefficients (data_augmentation_layer.cu:578-587): the layer name is
+        # mixed into the key, else img0s_aug and img1s_aug would add the same per-pixel noise field to both frames of a pair
+        import zlib
+        self.seed_ = (int(self.layer_param_.augmentation_param.get("seed", 0)) ^ zlib.crc32(str(self.layer_param_.name).encode())) & 0x7fffffff
         self.mean_pixel_ = None                                                       # blobs_[1] / blobs_[2]: the running means of recompute_mean
         self.mean_channel_ = None
 
@@ -501,6 +506,37 @@ class DataAugmentationLayer(Layer):
         # counter-based stream: the draws of iteration i are a function of (seed, i) alone (prefetchable, restartable)
         return augment.draw_batch(augment.make_rng(self.seed_, self.num_iter_), self._generators(), bottom[0].num(), bottom[0].width(),
                                   bottom[0].height(), self.cropped_width_, self.cropped_height_, discount=disc)
+
+    def adjust_blobs(self, blobs):
+        """CustomCopyBlobs of Net::CopyTrainedLayersFrom (net.cpp:769-781) -> adjust_blobs, data_augmentation_layer.cpp:162-205.  `blobs`: the
+        source layer's blobs [iteration count, per-pixel mean, per-channel mean].  Nothing is taken unless this layer re-computes its mean
+        (`recompute_mean > 0`) and the source carries at least two blobs: a layer with `recompute_mean: 0` subtracts the `mean` of its own
+        proto (or nothing), whatever the .caffemodel holds.  Otherwise the iteration count comes back (so that a count beyond
+        recompute_mean freezes the mean) and, with mean_per_pixel: false, blobs[2]; with mean_per_pixel: true, blobs[1] and its
+        per-channel average -- or, when the source mean has another size, the source's per-channel average expanded over the plane."""
+        ap = self.layer_param_.augmentation_param
+        if not (int(ap.get("recompute_mean", 0)) > 0 and len(blobs) >= 2):
+            return False
+        import numpy as np
+        dev = getattr(self, "device_", None) or torch.device("cpu")
+        b1 = np.ascontiguousarray(blobs[1], np.float32)
+        b1 = b1.reshape((1,) * (4 - b1.ndim) + b1.shape) if b1.ndim < 4 else b1
+        channels, ch, cw = self.channels_, self.cropped_height_, self.cropped_width_
+        CHECK(channels == b1.shape[1], "data augmentation mean: channel count of the source blob differs")          # cpp:166
+        self.num_iter_ = int(np.asarray(blobs[0], np.float32).reshape(-1)[0])                                      # cpp:172
+        if self.mean_pixel_ is None:
+            self.mean_pixel_ = torch.zeros((channels, ch, cw), dtype=torch.float32, device=dev)
+        if not ap.get("mean_per_pixel", True):
+            CHECK(len(blobs) >= 3, "data augmentation mean: the source layer has no per-channel mean blob")
+            self.mean_channel_ = torch.from_numpy(np.ascontiguousarray(blobs[2], np.float32).reshape(-1)[:channels].copy()).to(dev)   # cpp:175-183
+        elif (b1.shape[2], b1.shape[3]) == (ch, cw):
+            self.mean_pixel_ = torch.from_numpy(b1[0].copy()).to(dev)                                              # cpp:186-189
+            self.mean_channel_ = (self.mean_pixel_ * (1.0 / (ch * cw))).sum(dim=(1, 2))
+        else:
+            src = torch.from_numpy(b1[0].copy()).to(dev)                                                           # cpp:191-199
+            self.mean_channel_ = (src * (1.0 / (b1.shape[2] * b1.shape[3]))).sum(dim=(1, 2))
+            self.mean_pixel_ = self.mean_channel_.view(-1, 1, 1).expand(channels, ch, cw).contiguous()
+        return True
 
     def set_mean(self, per_channel=None, per_pixel=None):
         CHECK((per_channel is None) != (per_pixel is None), "give exactly one of per_channel / per_pixel")
@@ -520,6 +556,7 @@ class DataAugmentationLayer(Layer):
             CHECK(height >= self.cropped_height_, "crop height greater than original")                  # cpp:104
         else:
             self.cropped_width_, self.cropped_height_ = width, height
+        self.channels_ = channels
         top[0].Reshape(num, channels, self.cropped_height_, self.cropped_width_)                        # cpp:108
         if self.output_params_:
             top[1].Reshape(num, ops.AUG_NUM_PARAMS, 1, 1)                                               # cpp:121-126
@@ -543,7 +580,9 @@ class DataAugmentationLayer(Layer):
             out = _wrap(ops.data_augmentation_forward, self.params_, bottom[0].data, coeffs, None)
             if self.mean_pixel_ is None:
                 self.mean_pixel_ = torch.zeros(out.shape[1:], dtype=torch.float32, device=out.device)     # blobs_[1], cpp:113-116
+            if self.mean_channel_ is None:
                 self.mean_channel_ = torch.zeros(out.shape[1], dtype=torch.float32, device=out.device)    # blobs_[2]
+            self.mean_pixel_, self.mean_channel_ = self.mean_pixel_.to(out.device), self.mean_channel_.to(out.device)
             if self.num_iter_ <= recompute:
                 # scal(i - 1); axpy(1 / num) per sample; scal(1 / i); gemv(1 / area) -> per-channel mean   (:600-606)
                 self.mean_pixel_.mul_(float(self.num_iter_ - 1))

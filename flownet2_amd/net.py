@@ -157,9 +157,9 @@ class Net:
                 ignored.append(name)                                                     # "Ignoring source layer", net.cpp:763
                 continue
             blobs = src["blobs"]
-            if layer.layer_param_.type == "DataAugmentation":                             # CustomCopyBlobs: iteration count, per-pixel mean, per-channel mean
-                if len(blobs) >= 3:
-                    layer.set_mean(per_channel=torch.from_numpy(np.ascontiguousarray(blobs[2], np.float32).reshape(-1)).to(self.device_))
+            if layer.layer_param_.type == "DataAugmentation":                             # DoesUseCustomCopyBlobs: net.cpp:769-781
+                layer.device_ = self.device_
+                layer.adjust_blobs(blobs)                                                 # data_augmentation_layer.cpp:162-205
                 continue
             CHECK(len(blobs) == len(layer.blobs_), f"Incompatible number of blobs for layer {name}")          # net.cpp:779-780
             for k, (dst, b) in enumerate(zip(layer.blobs_, blobs)):
@@ -198,7 +198,8 @@ class Net:
                 t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t, np.float32))
                 b = self.blobs[n]
                 CHECK(list(t.shape) == b.shape(), f"input '{n}' has shape {tuple(t.shape)}, the net expects {tuple(b.shape())}")
-                b.data = t.to(device=self.device_, dtype=torch.float32).contiguous()
+                d = t.to(device=self.device_, dtype=torch.float32).contiguous()
+                b.data = d.clone() if d.data_ptr() == t.data_ptr() else d      # the net owns its input blobs: in-place layers must not write into the caller's tensor
         unknown = [k for k in inputs if k not in self.inputs]
         CHECK(not unknown, "Input blob arguments do not match net inputs: " + ", ".join(unknown))          # pycaffe.py:_Net_forward
         with torch.no_grad():

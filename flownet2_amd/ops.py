@@ -344,6 +344,10 @@ def scale_shift_forward(x, scale, shift=None, out=None, out_c0=0):
     return out
 
 
+def predict_flow_conv_backward_supported(N, C, H, W) -> bool:
+    return bool(_lib.lib().fn2_predict_flow_conv_backward_supported(int(N), int(C), int(H), int(W)))
+
+
 def predict_flow_conv_backward(x, weight, top_diff, need_x=True, need_w=True, need_b=True):
     """Backward of predict_flow (Convolution{3,1,1} C -> 2): (bottom_diff, weight_diff, bias_diff), None where not needed.  `x` may be a
     channel slice (blob, c0, C)."""

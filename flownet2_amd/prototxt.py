@@ -9,8 +9,8 @@ reference's runner.
 The grammar handled is protobuf's text format as these files use it: `key: scalar`, `key { ... }`, `key: { ... }`, `key: [a, b]`,
 `# comments`, strings in single or double quotes with the C escapes, numbers (decimal, hex, octal, floats incl. `inf` / `nan` /
 exponent / trailing `f`), identifiers (enum names, true / false).  A message is a `Message`: an ordered multi-map (every field may
-repeat).  No schema: whether a field is repeated is the READER's knowledge (REPEATED below = the repeated fields of caffe.proto that
-occur in these nets); `to_dict` folds a message into the plain dicts flownet2_amd.layers.LayerParameter carries.
+repeat).  No schema beyond which fields repeat in which message type (REPEATED_IN below, from caffe.proto); `to_dict` folds a
+message into the plain dicts flownet2_amd.layers.LayerParameter carries.
 """
 from __future__ import annotations
 
@@ -237,18 +237,40 @@ def unresolved(text: str) -> List[str]:
 
 
 # ---- Message -> plain dicts ------------------------------------------------------------------------------------------
-# repeated fields of caffe.proto that these nets use (everything else folds to its last value)
-REPEATED = {"bottom", "top", "loss_weight", "param", "blobs", "include", "exclude", "propagate_down", "input", "input_shape", "input_dim",
-            "dim", "layer", "layers", "coeff", "slice_point", "mean", "diag_val", "shape",
-            "chromatic_eigvec", "stage", "not_stage", "data", "encoding"}
-# fields that are repeated only inside one message type (ConvolutionParameter's, caffe.proto:573-580; CorrelationParameter's are scalars)
-REPEATED_IN = {"convolution_param": {"kernel_size", "pad", "stride", "dilation"}}
+# The repeated fields of caffe.proto, per MESSAGE TYPE: the key is the field name through which the message is reached ("" = the root
+# NetParameter).  A field name alone does not decide it: `mean` is `repeated float` in AugmentationParameter (caffe.proto:498) and an
+# `optional float` in RandomGeneratorParameter (caffe.proto:610: `translate { rand_type: "uniform" mean: 0 spread: 0.4 }`), `param` is a
+# ParamSpec list in LayerParameter and a string list in V1LayerParameter, `shape` repeats in InputParameter and not in ReshapeParameter.
+_LAYER_REPEATED = {"bottom", "top", "loss_weight", "param", "blobs", "include", "exclude", "propagate_down"}
+REPEATED_IN = {
+    "": {"input", "input_shape", "input_dim", "layer", "layers"},                                      # NetParameter, caffe.proto:66-98
+    "layer": _LAYER_REPEATED,                                                                          # LayerParameter, :315-349
+    "layers": _LAYER_REPEATED | {"blobs_lr", "weight_decay", "blob_share_mode"},                       # V1LayerParameter, :1533-1590
+    "input_shape": {"dim"}, "shape": {"dim"},                                                          # BlobShape, :7
+    "blobs": {"data", "diff", "double_data", "double_diff"},                                           # BlobProto, :12-15
+    "state": {"stage"}, "include": {"stage", "not_stage"}, "exclude": {"stage", "not_stage"},          # NetState / NetStateRule, :262-280
+    "augmentation_param": {"mean", "chromatic_eigvec"},                                                # AugmentationParameter, :498-504
+    "weight_filler": {"diag_val"}, "bias_filler": {"diag_val"}, "data_filler": {"diag_val"},           # FillerParameter, :63
+    "convolution_param": {"kernel_size", "pad", "stride", "dilation"},                                 # ConvolutionParameter, :853-859
+    "eltwise_param": {"coeff"},                                                                        # EltwiseParameter, :1018
+    "slice_param": {"slice_point"},                                                                    # SliceParameter, :1438
+    "data_param": {"slice_point", "encoding", "subtract"},                                             # DataParameter, :979-983
+    "dummy_data_param": {"data_filler", "shape", "num", "channels", "height", "width"},                # DummyDataParameter, :1001-1008
+    "input_param": {"shape"},                                                                          # InputParameter, :1155
+    "mean_param": {"value"},                                                                           # MeanParameter, :687
+    "transform_param": {"mean_value"},                                                                 # TransformationParameter, :715
+    "crop_param": {"offset"},                                                                          # CropParameter, :915
+    "lpq_loss_param": {"pq_episode_starts_at_iter", "p", "q"},                                         # LpqLossParameter, :599-601
+}
+# every name that is repeated somewhere (kept for callers that only ask "can this field repeat at all")
+REPEATED = set().union(*REPEATED_IN.values())
 
 
 def to_dict(m: Message, parent: str = "") -> Dict[str, Any]:
-    """Nested plain dict: sub-messages become dicts, repeated fields (and any field that occurs more than once) become lists."""
+    """Nested plain dict: sub-messages become dicts; the repeated fields of the message type reached through `parent` become lists
+    (also with one or no bracket), and so does any other field that occurs more than once."""
     out: Dict[str, Any] = {}
-    rep = REPEATED | REPEATED_IN.get(parent, set())
+    rep = REPEATED_IN.get(parent, ())
     for key in m.keys():
         vals = [to_dict(v, key) if isinstance(v, Message) else v for v in m.all(key)]
         out[key] = vals if (key in rep or len(vals) > 1) else vals[0]

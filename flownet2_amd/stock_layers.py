@@ -268,6 +268,7 @@ class ConcatLayer(Layer):
         top[0].Reshape(*shape)
 
     def Forward_gpu(self, bottom, top):
+        # one bottom: the top SHARES the bottom's storage, like the reference (concat_layer.cpp:50-53 ShareData / ShareDiff)
         top[0].data = bottom[0].data if len(bottom) == 1 else torch.cat([b.data for b in bottom], self.axis_)
 
 
@@ -300,8 +301,14 @@ class SliceLayer(Layer):
 
     def Forward_gpu(self, bottom, top):
         x = bottom[0].data
+        if len(top) == 1:                                   # slice_layer.cpp:69-72: one top shares the bottom's storage
+            top[0].data = x
+            return
         for i, t in enumerate(top):
-            t.data = x.narrow(self.axis_, self.cuts_[i], self.cuts_[i + 1] - self.cuts_[i]).contiguous()
+            # every top owns its storage (slice_layer.cpp:76-95 copies): a narrow() that is already contiguous (batch 1, or a slice along
+            # axis 0) is a VIEW of the bottom, and an in-place layer behind it would write through into the bottom and the other tops
+            y = x.narrow(self.axis_, self.cuts_[i], self.cuts_[i + 1] - self.cuts_[i])
+            t.data = y.clone() if y.is_contiguous() else y.contiguous()
 
 
 class SilenceLayer(Layer):

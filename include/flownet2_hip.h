@@ -252,7 +252,10 @@ int fn2_upsample_flow_deconv_forward(const float* in, const float* weight, const
  *                     bottom [N, 2, H, W], top_diff [N, 2, 2H, 2W].
  * Any of bottom_diff / weight_diff / bias_diff may be NULL (= propagate_down false).  accumulate != 0 adds into weight_diff / bias_diff
  * like the reference (the solver clears the diffs once per iteration); bottom_diff is always overwritten.  Workspace: the per-part
- * partial sums (only needed for weight_diff / bias_diff). */
+ * partial sums (only needed for weight_diff / bias_diff).
+ * fn2_predict_flow_conv_backward_supported: 1 when the weight-gradient kernel has a row band that fits LDS for this geometry (the band height
+ * is a function of N, C, H and W: rows of up to 2,558 pixels), 0 otherwise -- ask before routing a layer here. */
+int fn2_predict_flow_conv_backward_supported(int N, int C, int H, int W);
 size_t fn2_predict_flow_conv_backward_workspace_bytes(int N, int C, int H, int W);
 int fn2_predict_flow_conv_backward(const float* bottom, int bottom_channels, int bottom_c0, const float* weight, const float* top_diff,
                                    float* bottom_diff, float* weight_diff, float* bias_diff, int N, int C, int H, int W,

@@ -91,8 +91,25 @@ def infer_prototxt(model, template_path, img0, img1, device):
     return n.blobs["predict_flow_final"].data
 
 
+def _positionals(argv):
+    """Positional arguments of either form: the values of the value-taking options are not positionals."""
+    takes_value = {"--gpu", "--weights", "--net"}
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+        elif a in takes_value:
+            skip = True
+        elif not a.startswith("-"):
+            out.append(a)
+    return out
+
+
 def main():
-    if len([a for a in sys.argv[1:] if not a.startswith("-")]) >= 5 and "--net" not in sys.argv:
+    # the reference's argument form (run-flownet.py:12-18: caffemodel deployproto img0 img1 out) is recognised by its second positional,
+    # the deploy prototxt (template) -- not by counting tokens: `--weights w.npz --gpu 1 a.png b.png out.flo` has five non-dash tokens too
+    pos = _positionals(sys.argv[1:])
+    if len(pos) >= 5 and pos[1].endswith((".prototxt", ".template")) and "--net" not in sys.argv:
         ap = argparse.ArgumentParser()
         ap.add_argument("caffemodel", help="path to model (or seed:S / seed:C / seed:2)")
         ap.add_argument("deployproto", help="path to deploy prototxt template")

@@ -187,6 +187,28 @@ def test_device_noise_effect_matches_the_twin_and_is_gaussian():
 
 
 @pytest.mark.gpu
+def test_two_augmentation_layers_add_independent_noise():
+    """The reference draws the noise of every layer instance from the process-wide generator (data_augmentation_layer.cu:578-587): the
+    two frames of a pair (img0s_aug / img1s_aug, identical default parameters, same iteration) must not receive the same noise field."""
+    from flownet2_amd.layers import Blob, LayerParameter, LayerRegistry
+    img = np.full((2, 3, 64, 96), 0.5, np.float32)
+    co = np.zeros((2, 42, 1, 1), np.float32)
+    co[:, 41] = 0.05
+    fields = []
+    for name in ("img0s_aug", "img1s_aug", "img0s_aug"):
+        layer = LayerRegistry.CreateLayer(LayerParameter(name=name, type="DataAugmentation", phase="TRAIN",
+                                                         augmentation_param=dict(crop_width=96, crop_height=64, max_multiplier=1.0)))
+        bottom, top = [Blob(2, 3, 64, 96), Blob(2, 42, 1, 1)], [Blob()]
+        bottom[0].data, bottom[1].data = torch.from_numpy(img).cuda(), torch.from_numpy(co)
+        layer.SetUp(bottom, top)
+        layer.Forward(bottom, top)
+        fields.append((top[0].data.cpu().numpy() - 0.5).astype(np.float64))
+    assert fields[0].std() > 0.04 and fields[1].std() > 0.04
+    assert abs(np.corrcoef(fields[0].ravel(), fields[1].ravel())[0, 1]) < 0.03          # two layers: independent
+    assert np.array_equal(fields[0], fields[2])                                         # the same layer name and iteration: reproducible
+
+
+@pytest.mark.gpu
 def test_recompute_mean_is_layer_state_like_the_reference():
     """data_augmentation_layer.cu:593-621: over the first `recompute_mean` iterations the per-pixel mean is the running average of the
     batch means of the augmented images, the per-channel mean its average over the area; afterwards it is frozen; every iteration

@@ -39,6 +39,17 @@ def test_oracle_exports_cpu_twins():
         assert hasattr(L, name + "_cpu"), name + "_cpu"
 
 
+def test_predict_flow_backward_band_respects_lds():
+    """The weight-gradient band of predict_flow's backward is chosen among the heights that fit 60 KB of LDS (host logic, no GPU): FlowNetC at
+    1024x512 batch 8 (Convolution5 head: C = 194, 128x256) used to pick 32 rows = 70 KB and fail mid-training."""
+    L = _lib.lib()
+    assert L.fn2_predict_flow_conv_backward_supported(8, 194, 128, 256) == 1
+    assert L.fn2_predict_flow_conv_backward_supported(8, 194, 80, 112) == 1 and L.fn2_predict_flow_conv_backward_supported(1, 18, 12, 1000) == 1
+    assert L.fn2_predict_flow_conv_backward_supported(1, 16, 8, 3000) == 0 and L.fn2_predict_flow_conv_backward_supported(0, 16, 8, 8) == 0
+    # workspace = (18 C + 2) floats per (sample, band): 128 rows of 256 pixels take 16-row bands (8 * 18 * 258 * 4 = 148 KB for 32 rows)
+    assert L.fn2_predict_flow_conv_backward_workspace_bytes(8, 194, 128, 256) == 4 * 8 * 8 * (18 * 194 + 2)
+
+
 def test_shape_function_matches_reference_reshape_and_rejects_bad_params():
     # FlowNetC: correlation_layer.cpp:52-73 with K=1, md=20, pad=20, s1=1, s2=2
     assert ops.correlation_out_shape(ops.corr_params(20, 1, 20, 1, 2), 256, 40, 56) == (441, 40, 56)

@@ -1047,7 +1047,7 @@ def test_own_data_gradient_of_1x1_and_small_map_layers(case):
     assert float((gx.double() - ref).abs().max()) <= 1e-5 * scale
 
 
-@pytest.mark.parametrize("shape", [(2, 194, 24, 40), (1, 1026, 10, 14), (3, 37, 5, 7), (2, 16, 17, 23)])
+@pytest.mark.parametrize("shape", [(2, 194, 24, 40), (1, 1026, 10, 14), (3, 37, 5, 7), (2, 16, 17, 23), (1, 20, 40, 300), (1, 18, 12, 1000)])
 def test_predict_flow_conv_backward(shape):
     """Own backward of predict_flow (Convolution{3,1,1} C -> 2): weight, bias and bottom gradients vs the double-accumulating oracle twin
     (1e-5 * scale), reading the bottom from a channel slice, deterministic run to run, and through autograd against conv2d."""

@@ -82,16 +82,105 @@ def test_nets_build_from_the_templates_and_take_the_weights(kind, nlayers):
     assert sum(1 for l in relus if not l.folded_) == (0 if kind == "S" else 1)
     n.reshape_inputs(3)
     assert n.blobs["predict_flow_final"].shape() == [3, 2, 200, 436]
-    # CopyTrainedLayersFrom: by layer name, shapes CHECKed, unknown source layers ignored, DataAugmentation means by their blobs
+    # CopyTrainedLayersFrom: by layer name, shapes CHECKed, unknown source layers ignored, DataAugmentation through adjust_blobs
     src = {"conv1" if kind == "S" else "conv1a": {"blobs": [np.full((64, 6 if kind == "S" else 3, 7, 7), 2.0, np.float32), np.ones((1, 1, 1, 64), np.float32)]},
            "img0s_aug": {"blobs": [np.zeros(1, np.float32), np.zeros((1, 3, 2, 2), np.float32), np.array([.1, .2, .3], np.float32).reshape(1, 3, 1, 1)]},
            "not_in_this_net": {"blobs": [np.zeros(3, np.float32)]}}
     assert n.CopyTrainedLayersFrom(src) == ["not_in_this_net"]
     first = n.layer_by_name("conv1" if kind == "S" else "conv1a")
     assert float(first.blobs_[0].data[3, 1, 2, 2]) == 2.0 and float(first.blobs_[1].data[5]) == 1.0
-    np.testing.assert_allclose(n.layer_by_name("img0s_aug").mean_.numpy(), [.1, .2, .3])
+    # recompute_mean: 0 in the deploy templates -> adjust_blobs takes NOTHING from the model (data_augmentation_layer.cpp:165): the proto mean stays
+    aug = n.layer_by_name("img0s_aug")
+    assert aug.mean_host_ == [0.411, 0.433, 0.45] and aug.mean_ is None and aug.num_iter_ == 0 and aug.mean_channel_ is None
     with pytest.raises(CheckError, match="shape mismatch"):
         n.CopyTrainedLayersFrom({"conv2" if kind == "S" else "conv2a": {"blobs": [np.zeros((128, 64, 3, 3), np.float32), np.zeros(128, np.float32)]}})
+
+
+def test_train_style_augmentation_param_parses_and_draws():
+    """`mean` is a repeated float in AugmentationParameter (caffe.proto:498) and an optional float in RandomGeneratorParameter (:610): a
+    TRAIN-phase layer with generator sub-messages must come out of the reader in a form augment.draw_batch can use."""
+    from flownet2_amd import augment
+    from flownet2_amd.layers import LayerParameter
+    text = """
+      layer { name: "img0s_aug" type: "DataAugmentation" bottom: "img0" top: "img0_aug" top: "img0_aug_params"
+        augmentation_param {
+          max_multiplier: 1 augment_during_test: false recompute_mean: 1000 mean_per_pixel: false
+          translate { rand_type: "uniform_bernoulli" exp: false mean: 0 spread: 0.4 prob: 1.0 }
+          rotate { rand_type: "uniform_bernoulli" exp: false mean: 0 spread: 0.4 prob: 1.0 }
+          zoom { rand_type: "uniform_bernoulli" exp: true mean: 0.2 spread: 0.4 prob: 1.0 }
+          squeeze { rand_type: "uniform_bernoulli" exp: true mean: 0 spread: 0.3 prob: 1.0 }
+          lmult_pow { rand_type: "uniform_bernoulli" exp: true mean: -0.2 spread: 0.4 prob: 1.0 }
+          lmult_mult { rand_type: "uniform_bernoulli" exp: true mean: 0.0 spread: 0.4 prob: 1.0 }
+          lmult_add { rand_type: "uniform_bernoulli" exp: false mean: 0 spread: 0.03 prob: 1.0 }
+          noise { rand_type: "uniform_bernoulli" exp: false mean: 0.03 spread: 0.03 prob: 1.0 }
+          crop_width: 448 crop_height: 320
+          chromatic_eigvec: 0.51 chromatic_eigvec: 0.56 chromatic_eigvec: 0.65 chromatic_eigvec: 0.79 chromatic_eigvec: 0.01
+          chromatic_eigvec: -0.62 chromatic_eigvec: 0.35 chromatic_eigvec: -0.83 chromatic_eigvec: 0.44
+        } }
+      layer { name: "img1s_aug" type: "DataAugmentation" bottom: "img1" bottom: "aug_params1" top: "img1_aug"
+        augmentation_param { max_multiplier: 1 mean_per_pixel: false mean: [0.4, 0.41] mean: 0.42 crop_width: 448 crop_height: 320 } }
+    """
+    d = prototxt.to_dict(prototxt.parse(text))
+    ap0, ap1 = (l["augmentation_param"] for l in d["layer"])
+    assert ap0["translate"]["mean"] == 0 and ap0["zoom"]["mean"] == 0.2 and isinstance(ap0["noise"]["mean"], float)      # scalars in the generators
+    assert len(ap0["chromatic_eigvec"]) == 9 and ap1["mean"] == [0.4, 0.41, 0.42]                                        # lists in the parameter
+    gens = {k: v for k, v in LayerParameter.from_dict(d["layer"][0]).augmentation_param.items() if isinstance(v, dict)}
+    co = augment.draw_batch(augment.make_rng(3, 1), gens, 4, 512, 384, 448, 320)
+    assert co.shape == (4, 42) and np.isfinite(co).all() and len({tuple(r) for r in co.round(6)}) == 4
+    for c in co:                                                                    # the draws respect the generators' ranges
+        k = augment.array_to_coeff(c)
+        assert abs(k["angle"]) <= 0.4 + 1e-6 and math.exp(0.2 - 0.4) - 1e-5 <= k["zoom_x"] * k["zoom_y"] and 0.0 <= k["noise"] <= 0.06 + 1e-6
+
+
+def test_data_augmentation_adjust_blobs_follows_the_reference():
+    """data_augmentation_layer.cpp:162-205 through Net.CopyTrainedLayersFrom (net.cpp:769-781)."""
+    def build(recompute, per_pixel, crop=(6, 8)):
+        return fnet.Net('input: "a" input_shape { dim: 2 dim: 3 dim: 6 dim: 8 } layer { name: "aug" type: "DataAugmentation" bottom: "a" top: "b" '
+                        'augmentation_param { crop_width: %d crop_height: %d recompute_mean: %d mean_per_pixel: %s mean: 0.1 mean: 0.2 mean: 0.3 } }'
+                        % (crop[1], crop[0], recompute, "true" if per_pixel else "false"), device="cpu")
+    rng = np.random.default_rng(0)
+    pix = rng.random((1, 3, 6, 8)).astype(np.float32)
+    src = {"aug": {"blobs": [np.array([1234.0], np.float32), pix, np.array([.5, .6, .7], np.float32).reshape(1, 3, 1, 1)]}}
+    a = build(0, False)
+    a.CopyTrainedLayersFrom(src)                                   # recompute_mean: 0 -> nothing is taken, the proto mean is what the layer subtracts
+    l = a.layer_by_name("aug")
+    assert l.num_iter_ == 0 and l.mean_channel_ is None and l.mean_host_ == [0.1, 0.2, 0.3]
+    b = build(5, False)
+    b.CopyTrainedLayersFrom(src)                                   # per-channel: iteration count + blobs[2]
+    l = b.layer_by_name("aug")
+    assert l.num_iter_ == 1234
+    np.testing.assert_array_equal(l.mean_channel_.numpy(), np.array([.5, .6, .7], np.float32))
+    c = build(5, True)
+    c.CopyTrainedLayersFrom(src)                                   # per-pixel, same size: blobs[1] and its per-channel average
+    l = c.layer_by_name("aug")
+    np.testing.assert_array_equal(l.mean_pixel_.numpy(), pix[0])
+    np.testing.assert_allclose(l.mean_channel_.numpy(), pix[0].mean((1, 2)), rtol=1e-6)
+    e = build(5, True, crop=(4, 4))
+    e.CopyTrainedLayersFrom(src)                                   # per-pixel, another size: the source's channel average expanded over the plane
+    l = e.layer_by_name("aug")
+    assert tuple(l.mean_pixel_.shape) == (3, 4, 4)
+    np.testing.assert_allclose(l.mean_pixel_.numpy(), np.broadcast_to(pix[0].mean((1, 2)).reshape(3, 1, 1), (3, 4, 4)), rtol=1e-6)
+    f = build(5, True)
+    f.CopyTrainedLayersFrom({"aug": {"blobs": [np.array([7.0], np.float32)]}})      # "no blobs to copy"
+    assert f.layer_by_name("aug").num_iter_ == 0
+    with pytest.raises(CheckError, match="channel count"):
+        build(5, True).CopyTrainedLayersFrom({"aug": {"blobs": [np.zeros(1, np.float32), np.zeros((1, 2, 6, 8), np.float32)]}})
+
+
+def test_slice_tops_own_their_storage_and_inputs_are_copied():
+    """A top must not alias its bottom where the reference copies (slice_layer.cpp:76-95): an in-place layer behind a Slice of a batch-1
+    blob would otherwise write through into the bottom.  One top / one bottom share storage like the reference (ShareData)."""
+    n = fnet.Net('input: "a" input_shape { dim: 1 dim: 4 dim: 2 dim: 2 } '
+                 'layer { name: "s" type: "Slice" bottom: "a" top: "lo" top: "hi" slice_param { axis: 1 slice_point: 2 } } '
+                 'layer { name: "c" type: "Concat" bottom: "hi" top: "hi_c" }', device="cpu")
+    x = torch.arange(16, dtype=torch.float32).reshape(1, 4, 2, 2)
+    n.forward(a=x)
+    a, lo, hi, hic = (n.blobs[k].data for k in ("a", "lo", "hi", "hi_c"))
+    assert a.data_ptr() != x.data_ptr()                                                    # the net owns its input blob
+    assert lo.data_ptr() != a.data_ptr() and hi.untyped_storage().data_ptr() != a.untyped_storage().data_ptr()
+    assert hic.data_ptr() == hi.data_ptr()                                                 # concat_layer.cpp:50-53
+    lo.mul_(-1.0)
+    assert torch.equal(a, x) and torch.equal(hi, x[:, 2:])
 
 
 def test_net_errors_are_the_references():

@@ -35,3 +35,13 @@ def test_groups_read_every_file_once_and_keep_order():
         for k, e in enumerate(ents):
             assert float(i0[k, 0, 0, 0]) == ord(e[2][0]) and float(i1[k, 0, 0, 0]) == ord(e[2][0]) + 1
     assert list(m.groups_of([], 4, read)) == []
+
+
+def test_reference_argument_form_is_detected_by_the_prototxt_positional():
+    """scripts/run_flownet.py: `caffemodel deployproto img0 img1 out` (run-flownet.py:12-18) vs the built-in form with options."""
+    spec = importlib.util.spec_from_file_location("run_flownet", os.path.join(ROOT, "scripts", "run_flownet.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m._positionals(["--weights", "w.npz", "--gpu", "1", "a.png", "b.png", "out.flo"]) == ["a.png", "b.png", "out.flo"]
+    ref = m._positionals(["m.caffemodel", "deploy.prototxt.template", "a.png", "b.png", "out.flo", "--gpu", "2", "--verbose"])
+    assert ref == ["m.caffemodel", "deploy.prototxt.template", "a.png", "b.png", "out.flo"] and ref[1].endswith((".prototxt", ".template"))
