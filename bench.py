@@ -127,14 +127,18 @@ def corr_roofline(device, batch, h, w, iters):
                 break
         except Exception:
             pass
-    # `achieved` / `frac` follow the committed rocprofv3 kernel trace of this exact kernel and shape when there is one (the
-    # profiler's clocks: the figure profiles/ can be checked against); the live hipEvent figure of THIS run is achieved_live / frac_live
-    tf_prof = alg_flops / (profiled["us_per_launch"] * 1e-6) / 1e12 if profiled else None
+    # `achieved` / `frac` are what THIS run measured (HIP events on the launch stream around `iters` back-to-back launches).  The same
+    # fraction from the newest committed rocprofv3 kernel trace of this exact kernel and shape rides along as frac_profiled (the figure
+    # profiles/ can be checked against); `frac_agrees_with_profile` says whether the two are within 3 % of each other -- a committed
+    # profile of an older build of the kernel must not speak for this one.
+    frac_live = tf / F32_MFMA_PEAK_TFLOPS
+    agrees = (abs(profiled["frac"] - frac_live) <= 0.03 * frac_live) if profiled else None
     return {
         "kernel": "corr_fwd (K=1,md=20,s2=2) [%d,%d,%d,%d]" % (batch, C, H, W),
-        "bound": "mfma", "achieved": round(tf_prof if profiled else tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": profiled["frac"] if profiled else round(tf / F32_MFMA_PEAK_TFLOPS, 4),
-        "frac_source": (profiled["source"] + " (rocprofv3 kernel trace)") if profiled else "live hipEvent timing (no committed profile of this shape)",
+        "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(frac_live, 4),
+        "frac_source": "live hipEvent timing of this run (%d back-to-back launches after 1500 untimed ones)" % iters,
+        "frac_agrees_with_profile": agrees,
         "achieved_live": round(tf, 3), "frac_live": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
         "frac_profiled": profiled["frac"] if profiled else None, "profiled": profiled,
         "traffic": traffic, "traffic_detail": traffic_detail,
@@ -143,6 +147,20 @@ def corr_roofline(device, batch, h, w, iters):
         "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
         "note": "exact-fp32 correlation is FMA-bound (59 flop/B > machine balance); hbm = algorithmic bytes / time",
     }
+
+
+def step_mfma_busy():
+    """Matrix-pipe utilisation of the whole FlowNetC step from the newest committed counter pass (profiles/rNN_step_mfma.json, written by
+    scripts/summarize_profiles.py from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py`):
+    counters cannot be read from inside this process."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_mfma.json")), reverse=True):
+        try:
+            pj = json.load(open(f))
+            return {"mfma_busy_step": round(pj["mfma_busy_step"], 4), "mfma_busy_step_source": "profiles/" + os.path.basename(f)}
+        except Exception:
+            pass
+    return {"mfma_busy_step": None, "mfma_busy_step_source": None}
 
 
 def step_percentiles(marks):
@@ -194,19 +212,53 @@ def spawn_ranks(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0):
+class CudaRuntime:
+    """What run_workload needs from the device side: the operator backend of the graphs, synchronisation, timing events, the optimizer.
+    The product runtime is this one (HIP kernels through flownet2_amd.functional, HIP events, fused Adam); tests/test_bench_ranks.py
+    drives the same run_workload -- its rank logic, barriers, max-over-ranks timing, per-rank inputs and the gradient exchange -- with a
+    CPU stand-in over the gloo backend."""
+    backend = Fn
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def optimizer(self, plist):
+        return torch.optim.Adam(plist, lr=1e-5, fused=True)     # one multi-tensor kernel for the 48 parameter blobs (Caffe's AdamSolver: one kernel per blob)
+
+
+def check_ranks(world, gpus, device):
+    """The launcher must have started exactly --gpus ranks and the collective library must have connected all of them (one all-reduce
+    of ones): a number reported for N GPUs from fewer ranks would be wrong by construction."""
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks")
+    seen = parallel.ranks_seen(device)
+    if seen != world:
+        raise SystemExit(f"bench.py: all-reduce of ones returned {seen}, expected {world}")
+    return seen
+
+
+def rank_seed(rank):
+    return 1234 + rank              # every rank its own synthetic batch (weak scaling: per-GPU work fixed)
+
+
+def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0, rt=None):
     """W untimed warm-up steps (+ untimed settling steps until `settle_s` seconds of back-to-back stepping have passed: the chip
     needs ~25 ms of load to come back to its steady clocks, and a short run otherwise sits inside that ramp), then EXACTLY `steps`
     timed steps between barrier + synchronize on both sides.  Returns the measurements and what the caller needs for the oracle leg."""
+    rt = rt or CudaRuntime()
+    be = rt.backend
     P_cpu = nets.init_params("C", seed=0) if net == "C" else nets.init_params_flownet2(seed=0)   # same weights on every rank
     P = {k: v.to(device) for k, v in P_cpu.items()}
-    img0, img1 = synth_batch(B, H, W, seed=1234 + rank, device=device)
+    img0, img1 = synth_batch(B, H, W, seed=rank_seed(rank), device=device)
 
     if mode == "train":
         for v in P.values():
             v.requires_grad_(True)
         plist = list(P.values())
-        opt = torch.optim.Adam(plist, lr=1e-5, fused=True)      # one multi-tensor kernel for the 48 parameter blobs (Caffe's AdamSolver: one kernel per blob)
+        opt = rt.optimizer(plist)
         gt = torch.randn(B, 2, H, W, device=device) * 5
         gt[torch.rand(B, 1, H, W, device=device).expand(-1, 2, -1, -1) < 0.05] = float("nan")
         parallel.broadcast_params(plist, src=0)
@@ -218,7 +270,7 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         def step():
             exchange.zero_grad()
             pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
-            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], Fn), gt, Fn)
+            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], be), gt, be)
             loss.backward()
             exchange.finish()
             opt.step()
@@ -227,8 +279,8 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         def step():
             with torch.no_grad():
                 if net == "2":
-                    return nets.flownet2_deploy_forward(P, img0, img1, Fn)
-                return nets.deploy_forward("C", P, img0, img1, Fn)
+                    return nets.flownet2_deploy_forward(P, img0, img1, be)
+                return nets.deploy_forward("C", P, img0, img1, be)
 
     out = None
     for _ in range(warmup):
@@ -237,7 +289,7 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
     if use_graph:
         # One step = ~130 kernels: captured once (hipGraph through torch's CUDAGraph; same kernels, order and buffers)
         # and replayed, which removes the host launch path.  The warm-up above has run every lazy initialisation.
-        torch.cuda.synchronize()
+        rt.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = step()
@@ -248,7 +300,7 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
     # Everything the host has to do before the timed region happens BEFORE the settling steps (event objects, a full garbage collection: a
     # few milliseconds in which the device would sit idle and fall back to its low clocks), so that the synchronisation in front of the
     # timed region is followed by the first timed launch at once.
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks = [rt.event() for _ in range(steps + 1)]
     # The cyclic collector is paused for the K timed steps (config.python_gc): a generation-2 pass over the interpreter's objects
     # takes milliseconds -- two steps of the batch-1 configuration -- and has nothing to collect here (no reference cycles in a step).
     import gc
@@ -256,17 +308,26 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
     if gc_was_on:
         gc.collect()
         gc.disable()
+    # cold figure: the same K steps timed straight after the W warm-up steps, with NO settling steps in between (the clock ramp of the
+    # first ~25 ms of load is inside it) -- reported as value_cold next to the steady-clock headline; rank-local, no barrier
+    rt.synchronize()
+    t_c = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    rt.synchronize()
+    elapsed_cold = time.perf_counter() - t_c
     # settling: untimed steps, back to back, until the chip has been under this load for settle_s seconds
-    torch.cuda.synchronize()
+    rt.synchronize()
     settle_steps, t_s = 0, time.perf_counter()
     while warmup > 0 and time.perf_counter() - t_s < settle_s and settle_steps < 2000:
         for _ in range(16):
             step_fn()
         settle_steps += 16
-        torch.cuda.synchronize()
+        rt.synchronize()
+    settling_s = time.perf_counter() - t_s
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    rt.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(steps):
@@ -274,15 +335,16 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         if r is not None:
             out = r
         marks[i + 1].record()                  # per-step spread (device time); the headline stays the host clock around all K steps
-    torch.cuda.synchronize()
+    rt.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if gc_was_on:
         gc.enable()
     elapsed = parallel.max_over_ranks(elapsed, device)
-    return {"elapsed": elapsed, "marks": marks, "out": out, "P_cpu": P_cpu, "img0": img0, "img1": img1, "use_graph": use_graph,
-            "gc_paused": gc_was_on, "settle_steps": settle_steps}
+    elapsed_cold = parallel.max_over_ranks(elapsed_cold, device)
+    return {"elapsed": elapsed, "params": P, "marks": marks, "out": out, "P_cpu": P_cpu, "img0": img0, "img1": img1, "use_graph": use_graph,
+            "gc_paused": gc_was_on, "settle_steps": settle_steps, "settling_s": settling_s, "elapsed_cold": elapsed_cold}
 
 
 def flownet2_epe_vs_cpu(P_cpu, img0, img1, flow_gpu):
@@ -335,11 +397,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    ranks_seen = parallel.ranks_seen(device)            # what RCCL actually connected (one all-reduce of ones)
-    if ranks_seen != world:
-        raise SystemExit(f"bench.py: all-reduce of ones returned {ranks_seen}, expected {world}")
+    ranks_seen = check_ranks(world, args.gpus, device)  # what RCCL actually connected (one all-reduce of ones)
 
     B, H, W = args.batch, args.height, args.width
     m = run_workload(args.net, args.mode, B, H, W, args.steps, args.warmup, device, world, rank, args.bucket_mb, args.graph)
@@ -352,6 +410,9 @@ def main():
             "metric": "image-pairs/sec " + ("FlowNetC " if args.net == "C" else "FlowNet2 (CSS+SD+fusion) ") + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
             "value": round(pairs / elapsed, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            # the same K steps timed straight after the W warm-up steps (no settling steps: clock ramp included), and what came between
+            "value_cold": round(pairs / m["elapsed_cold"], 2), "ms_per_step_cold": round(m["elapsed_cold"] / args.steps * 1e3, 4),
+            "settling_s": round(m["settling_s"], 3), "untimed_steps_before_timed_region": args.warmup + args.steps + m["settle_steps"],
             "ms_per_step_p10_p50_p90": step_percentiles(marks), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
@@ -363,6 +424,8 @@ def main():
                        "untimed_settling_steps_after_warmup": m["settle_steps"], "ranks_seen_by_rccl": ranks_seen},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
+        if args.mode == "fwd" and args.net == "C" and (B, H, W) == (8, 320, 448):
+            res.update(step_mfma_busy())
         if world == 1:
             res["roofline"] = corr_roofline(device, B, H, W, args.corr_iters)
             if args.mode == "fwd" and args.net == "C" and not args.no_cpu_baseline:

@@ -130,6 +130,11 @@ if os.path.exists(pmc_path):
     for gui_k, name, u, n in rows[:16]:
         lines.append("| `%s` | %d | %.1f | %.1f |" % (short(name, 90), n, 100 * gui_k / tot_gui, 100 * u))
     lines += ["", "All MFMA kernels of the run together: **%.1f %%** matrix-pipe utilisation." % (100 * tot_busy / tot_gui)]
+    # bench.py reports this figure as `mfma_busy_step` (it cannot read counters from inside its own process)
+    json.dump({"tag": tag, "workload": "FlowNetC deploy forward, batch 8 @448x320", "mfma_busy_step": tot_busy / tot_gui,
+               "kernels": [{"kernel": short(name, 90), "dispatches": n, "share_of_cycles": gui_k / tot_gui, "mfma_busy": u} for gui_k, name, u, n in rows[:16]],
+               "source": "profiles/%s_rocprof_summary.md (--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE pass over bench.py)" % tag},
+              open(os.path.join(OUT, f"{tag}_step_mfma.json"), "w"), indent=1)
 
 lines += ["", "bench line of the unprofiled run in the same session:", "```", open(os.path.join(R, "bench.json")).read().strip(), "```", ""]
 open(os.path.join(OUT, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
