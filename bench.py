@@ -379,7 +379,32 @@ def extras(device, args):
                            "conv_tflops": round(nets.conv_flops("C", 320, 448) * 8 * 3 * 20 / m["elapsed"] / 1e12, 2)}
     del m
     torch.cuda.empty_cache()
+    if not args.no_cpu_baseline:
+        ex["train_448x320"].update(train_parity(device))
     return ex
+
+
+def train_parity(device, B=8, H=320, W=448):
+    """Checker leg of the training configuration (after the timing, never inside it): loss and every parameter gradient of ONE training
+    step with production routing against the fp64 comparator oracle/fp64_graph.py (float64 autograd graph, none of the product's
+    kernels), at the configuration's own size.  grad_rel_l2_vs_ref = ||g - g64|| / ||g64|| over all 39 M gradient values."""
+    from oracle import fp64_graph
+    P = nets.init_params("C", seed=0)
+    Pd = {k: v.to(device).requires_grad_(True) for k, v in P.items()}
+    img0, img1 = synth_batch(B, H, W, seed=4321, device=device)
+    g = torch.Generator().manual_seed(9)
+    gt = torch.randn(B, 2, H, W, generator=g) * 5
+    gt[(torch.rand(B, 1, H, W, generator=g) < 0.05).expand(-1, 2, -1, -1)] = float("nan")
+    pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
+    loss = nets.multiscale_loss(nets.flownet_c_core(Pd, pre[0], pre[1], Fn), gt.to(device), Fn)
+    loss.backward()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    loss64, g64 = fp64_graph.flownetc_train_reference(P, img0, img1, gt, device=device)
+    a = fp64_graph.grad_agreement({k: v.grad for k, v in Pd.items()}, g64)
+    return {"grad_rel_l2_vs_ref": a["all"], "grad_rel_l2_vs_ref_worst_param": [a["worst_name"], a["worst"]], "grad_rel_l2_vs_ref_median_param": a["median"],
+            "loss_rel_err_vs_ref": abs(float(loss.detach()) - loss64) / max(1.0, abs(loss64)),
+            "ref": "oracle/fp64_graph.py: float64 autograd graph on the same inputs (%.1f s)" % (time.time() - t0)}
 
 
 def main():

@@ -1,0 +1,105 @@
+"""BASELINE config 4 at its own size: one FlowNetC training step at batch 8 @448x320 with PRODUCTION routing (own forward kernels inside
+autograd, own weight-gradient / transposed-convolution / Winograd data-gradient kernels, fused bias + ReLU backward, flow-head
+backward kernels, correlation backward) against the pinned fp64 comparator oracle/fp64_graph.py: loss and EVERY parameter gradient.
+
+The comparator itself is pinned on the CPU (no GPU): its correlation against the independent fp64 re-derivation of tests/ref_torch64.py
+incl. autograd gradients, and the whole fp64 graph against the C oracle's forward / backward restatements of the reference kernels
+(the differentiable CPU backend of tests/test_parallel.py) at a size the host finishes in seconds."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import fp64_graph  # noqa: E402
+
+
+def _batch(N, H, W, seed, nan_frac=0.05):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, (N, 3, H, W)).astype(np.float32)
+    b = np.clip(np.roll(a, (3, -5), (2, 3)) + rng.normal(0, 2, a.shape), 0, 255).astype(np.float32)
+    gt = (rng.standard_normal((N, 2, H, W)) * 5).astype(np.float32)
+    gt[np.broadcast_to(rng.random((N, 1, H, W)) < nan_frac, gt.shape)] = np.nan            # config 4: 5 % of the pixels without ground truth
+    return torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(gt)
+
+
+def test_fp64_correlation_matches_the_independent_rederivation():
+    import ref_torch64
+    g = torch.Generator().manual_seed(0)
+    for (N, C, H, W, pad, md, s2) in [(2, 5, 9, 11, 4, 4, 2), (1, 3, 8, 8, 3, 3, 1), (1, 4, 10, 12, 6, 4, 2)]:
+        b0 = torch.randn(N, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        b1 = torch.randn(N, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+        top = fp64_graph._Corr64.apply(b0, b1, pad, md, s2)
+        ref = ref_torch64.correlation(b0, b1, pad, 1, md, 1, s2)
+        assert top.shape == ref.shape and float((top - ref).abs().max()) < 1e-13
+        w = torch.randn(top.shape, generator=g, dtype=torch.float64)
+        g0, g1 = torch.autograd.grad((top * w).sum(), (b0, b1))
+        r0, r1 = torch.autograd.grad((ref * w).sum(), (b0, b1))
+        assert float((g0 - r0).abs().max()) < 1e-13 and float((g1 - r1).abs().max()) < 1e-13
+
+
+def test_fp64_graph_is_pinned_by_the_oracle_restatements():
+    """The fp64 comparator vs the fp32 CPU graph built from the C oracle's restatements of the reference's forward AND backward kernels
+    (correlation_layer.cu:45-249, l1loss_layer.cu:67-190, downsample_layer.cu:15-72) + torch-CPU fp32 convolutions: same loss, every
+    parameter gradient within fp32 rounding (the fp32 side's; measured 1e-6 .. 2e-5 per parameter)."""
+    from test_parallel import _cpu_train_backend
+    from flownet2_amd import nets
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    P = nets.init_params("C", seed=3)
+    a, b, gt = _batch(1, 128, 128, 11)
+    loss64, g64 = fp64_graph.flownetc_train_reference(P, a, b, gt, device="cpu")
+    P32 = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    be = _cpu_train_backend()
+    pre = [(im * (1.0 / 255.0)) - 0.43 for im in (a, b)]
+    loss32 = nets.multiscale_loss(nets.flownet_c_core(P32, pre[0], pre[1], be), gt, be)
+    loss32.backward()
+    assert abs(float(loss32.detach()) - loss64) <= 2e-6 * max(1.0, abs(loss64))
+    agree = fp64_graph.grad_agreement({k: v.grad for k, v in P32.items()}, g64)
+    assert set(g64) == set(P) and agree["all"] <= 2e-5 and agree["worst"] <= 2e-4, (agree["all"], agree["worst_name"], agree["worst"])
+
+
+@pytest.mark.gpu
+def test_flownetc_training_step_at_config4_size_matches_fp64():
+    """Batch 8 @448x320, production routing (what `bench.py --mode train` executes): loss within 1e-5 relative, every one of the 48
+    parameter gradients within 1e-4 in relative L2 of the fp64 comparator."""
+    from flownet2_amd import functional as Fn, nets
+    dev = torch.device("cuda:0")
+    P = nets.init_params("C", seed=0)
+    a, b, gt = _batch(8, 320, 448, 4)
+    Pd = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
+    routes = []
+
+    def run():
+        for v in Pd.values():
+            v.grad = None
+        pre = [(im.to(dev) * (1.0 / 255.0)) - 0.43 for im in (a, b)]
+        loss = nets.multiscale_loss(nets.flownet_c_core(Pd, pre[0], pre[1], Fn), gt.to(dev), Fn)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach())
+    run()                                                   # first use: the kernels time their tile variants (same bits whichever wins)
+    os.environ["FN2_TRACE_BWD"] = "1"
+    try:
+        import contextlib, io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            loss = run()
+        routes = [l for l in buf.getvalue().splitlines() if l.startswith("bwd on the library")]
+    finally:
+        os.environ.pop("FN2_TRACE_BWD", None)
+    grads = {k: v.grad.detach().clone() for k, v in Pd.items()}
+    loss64, g64 = fp64_graph.flownetc_train_reference(P, a, b, gt, device=dev)
+    assert set(grads) == set(g64) and len(g64) == len(P)
+    assert abs(loss - loss64) <= 1e-5 * max(1.0, abs(loss64)), (loss, loss64)
+    agree = fp64_graph.grad_agreement(grads, g64)
+    bad = {k: v for k, v in agree["per_param"].items() if v > 1e-4}
+    print("config-4 gradient agreement vs fp64: all %.2e, median %.2e, worst %s %.2e; library backward calls: %d" %
+          (agree["all"], agree["median"], agree["worst_name"], agree["worst"], len(routes)))
+    assert not bad, bad
+    assert agree["all"] <= 3e-5
+    assert not routes, routes                              # row a12: no convolution gradient of the step is handed to MIOpen / rocBLAS
