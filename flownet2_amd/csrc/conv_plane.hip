@@ -400,7 +400,9 @@ static int launch(const Args& a, hipStream_t st) {
 // (MODE, S, MW, NP, WM, WN, CQ, VEC)
 #define FN2_CP_TILES(X, S, VEC) \
   X(0, S, 2, 9, 2, 2, 2, VEC) X(0, S, 2, 5, 2, 2, 2, VEC) X(0, S, 2, 7, 2, 2, 2, VEC) X(0, S, 4, 5, 1, 4, 2, VEC) X(0, S, 2, 9, 1, 4, 1, VEC) \
-  X(0, S, 4, 9, 1, 4, 1, VEC) X(0, S, 2, 9, 1, 4, 2, VEC) X(0, S, 4, 4, 2, 2, 2, VEC)
+  X(0, S, 4, 9, 1, 4, 1, VEC) X(0, S, 2, 9, 1, 4, 2, VEC) X(0, S, 4, 4, 2, 2, 2, VEC) \
+  /* eight waves on one staged window (two per SIMD where LDS leaves room for one workgroup only) */ \
+  X(0, S, 2, 9, 2, 4, 2, VEC) X(0, S, 2, 5, 2, 4, 2, VEC) X(0, S, 2, 5, 4, 2, 2, VEC)
 #define FN2_DP_TILES(X, VEC) \
   X(1, 1, 2, 9, 1, 1, 2, VEC) X(1, 1, 2, 9, 1, 1, 1, VEC) X(1, 1, 4, 9, 1, 1, 1, VEC) X(1, 1, 4, 9, 1, 1, 2, VEC) X(1, 1, 2, 5, 1, 1, 2, VEC) \
   X(1, 1, 4, 5, 1, 1, 2, VEC) X(1, 1, 2, 7, 1, 1, 2, VEC) X(1, 1, 4, 7, 1, 1, 1, VEC)
