@@ -45,6 +45,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
              "-Wall", "-Wno-unused-function"]
     if os.environ.get("FN2_ABLATION"):
         flags.append("-DFN2_ABLATION=1")
+    # per-file flags: conv_wino.hip writes its packed-fp32 pairs out by hand; clang's SLP vectoriser adds pairs of its own there and
+    # pays for each with v_mov_b32 to assemble the operands (26 moves per 32 MFMAs in the round-3 build of the k loop)
+    per_file = {"conv_wino.hip": ["-fno-slp-vectorize"]}
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -52,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "flownet2_hip.h")]
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs):
             continue
-        cmd = [hipcc()] + flags + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc()] + flags + per_file.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -112,74 +112,56 @@ __device__ __forceinline__ void stage_chunk_tab(__amdgpu_buffer_rsrc_t rsU, __am
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Operands of one k-step (channel quad) of one tile block as they come out of LDS: U for the 16 positions, and the 4x4 input patch
-// d[i][0..3] of row i as two register PAIRS of neighbours: lo[i] = (d[i][0], d[i][1]), hi[i] = (d[i][2], d[i][3]) (window columns dcol + 1
-// .. dcol + 4, dcol even: two 4-byte-aligned 8-byte LDS reads per row).  On pairs both stages of B^T d B are packed-fp32 instructions
-// (v_pk_add_f32: two fp32 additions per lane and instruction): 16 VALU instructions per patch instead of 32 -- the matrix pipe and the
-// vector ALU do not overlap on this chip, every VALU instruction in the k loop is matrix time lost.  (hipcc's own
-// vectoriser found some of the pairs in the scalar form, and paid for them with up to 20 v_mov_b32 per patch to assemble the operands.)
-using f32x2_a4 = float __attribute__((ext_vector_type(2), aligned(4)));
-struct WOps { f32x4 u[4]; f32x2 lo[4]; f32x2 hi[4]; };
-
-using lds_f32x2_a4 = __attribute__((address_space(3))) const f32x2_a4;
-using lds_cf = __attribute__((address_space(3))) const float;
-
-// the same through an LDS address held as a 32-bit integer (see `dofs` in wino_body)
-template <class K>
-__device__ __forceinline__ void wino_load_patch(WOps& o, unsigned lds_addr) {
-  lds_cf* dp = reinterpret_cast<lds_cf*>((uintptr_t)lds_addr);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    o.lo[i] = *reinterpret_cast<lds_f32x2_a4*>(dp + i * K::RS);
-    o.hi[i] = *reinterpret_cast<lds_f32x2_a4*>(dp + i * K::RS + 2);
-  }
-}
-
-template <class K>
-__device__ __forceinline__ void wino_load_patch(WOps& o, const float* dp) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {           // dp: the lane's first patch element; patch columns 0 .. 3 = window columns dcol + 1 .. dcol + 4
-    o.lo[i] = *reinterpret_cast<const f32x2_a4*>(dp + i * K::RS);
-    o.hi[i] = *reinterpret_cast<const f32x2_a4*>(dp + i * K::RS + 2);
-  }
-}
+// d[i][0..3] of row i as a dword, the ALIGNED 8-byte pair m[i] = (d[i][1], d[i][2]) and a dword (window columns dcol + 1 .. dcol + 4, dcol
+// even).  The inner columns are transformed with packed-fp32 instructions on the pairs (two additions per lane and instruction); the
+// matrix pipe and the vector ALU do not overlap on this chip, every VALU instruction in the k loop is matrix time lost.
+// (Pairs of NEIGHBOURS (d0, d1), (d2, d3) would make both stages packed -- 16 instructions per patch -- but they sit at odd dword
+// addresses: the misaligned 8-byte LDS reads ran every variant 1.6-2.7x slower; measured in round 4 and dropped.  hipcc's own vectoriser
+// found some pairs in the all-scalar form of rounds 2-3 and paid for them with up to 20 v_mov_b32 per patch to assemble the operands.)
+struct WOps { f32x4 u[4]; float d0[4]; f32x2 m[4]; float d3[4]; };
 
 template <class K, class P>
-__device__ __forceinline__ void wino_load(WOps& o, const float* ub, P dp) {
+__device__ __forceinline__ void wino_load_patch(WOps& o, P dp) {           // dp: window column dcol of the lane's first patch row
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {           // patch columns 0 .. 3 = window columns dcol + 1 .. dcol + 4: dword, aligned pair, dword
+    o.d0[i] = dp[i * K::RS + 1];
+    o.m[i] = *reinterpret_cast<const f32x2*>(dp + i * K::RS + 2);
+    o.d3[i] = dp[i * K::RS + 4];
+  }
+}
+
+template <class K>
+__device__ __forceinline__ void wino_load(WOps& o, const float* ub, const float* dp) {
 #pragma unroll
   for (int pq = 0; pq < 4; ++pq) o.u[pq] = *reinterpret_cast<const f32x4*>(ub + pq * 256);
   wino_load_patch<K>(o, dp);
 }
 
-// (L.x - H.x, L.y + H.x) = (v[i][0], v[i][1]) of row i from L = (w[i][0], w[i][1]), H = (w[i][2], w[i][3])
-__device__ __forceinline__ f32x2 pk_v01(f32x2 l, f32x2 h) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(l), "v"(h));
-  return r;
-}
-// (H.x - L.y, L.y - H.y) = (v[i][2], v[i][3]); the second is issued as (-H.y) + L.y: the same IEEE sum
-__device__ __forceinline__ f32x2 pk_v23(f32x2 l, f32x2 h) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(h), "v"(l));
-  return r;
-}
-
 // V = B^T d B, rows first.  Per element the operations of the scalar form, in its order (the oracle twin's):
 //   w[0][j] = d[0][j] - d[2][j], w[1][j] = d[1][j] + d[2][j], w[2][j] = d[2][j] - d[1][j], w[3][j] = d[1][j] - d[3][j]
 //   v[i][0] = w[i][0] - w[i][2], v[i][1] = w[i][1] + w[i][2], v[i][2] = w[i][2] - w[i][1], v[i][3] = w[i][1] - w[i][3]
-// v[4 i + j] is the A operand of Winograd position (i, j).
+// The inner columns j = 1, 2 travel as the pair M = (w[i][1], w[i][2]): stage one is four packed additions; in stage two
+// (v[i][1], v[i][2]) = (M.x + M.y, M.y - M.x) is ONE v_pk_fma_f32 (M.x, M.x) * (1, -1) + (M.y, M.y) -- x * 1 + y and x * -1 + y are the
+// IEEE sum and difference, bit for bit -- with the lane selections in op_sel and the constant in scalar registers (the compiler's own
+// instruction selection: no inline assembly, so its hazard handling between the vector ALU and the matrix pipe stays in charge).
+// 24 VALU instructions per patch instead of 32 + operand moves.  v[4 i + j] is the A operand of Winograd position (i, j).
 __device__ __forceinline__ void wino_transform(const WOps& o, float (&v)[16]) {
-  f32x2 wl[4], wh[4];
-  wl[0] = o.lo[0] - o.lo[2]; wh[0] = o.hi[0] - o.hi[2];
-  wl[1] = o.lo[1] + o.lo[2]; wh[1] = o.hi[1] + o.hi[2];
-  wl[2] = o.lo[2] - o.lo[1]; wh[2] = o.hi[2] - o.hi[1];
-  wl[3] = o.lo[1] - o.lo[3]; wh[3] = o.hi[1] - o.hi[3];
+  const f32x2 pm = {1.0f, -1.0f};
+  f32x2 wm[4];
+  float w0[4], w3[4];
+  wm[0] = o.m[0] - o.m[2]; w0[0] = o.d0[0] - o.d0[2]; w3[0] = o.d3[0] - o.d3[2];
+  wm[1] = o.m[1] + o.m[2]; w0[1] = o.d0[1] + o.d0[2]; w3[1] = o.d3[1] + o.d3[2];
+  wm[2] = o.m[2] - o.m[1]; w0[2] = o.d0[2] - o.d0[1]; w3[2] = o.d3[2] - o.d3[1];
+  wm[3] = o.m[1] - o.m[3]; w0[3] = o.d0[1] - o.d0[3]; w3[3] = o.d3[1] - o.d3[3];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const f32x2 a = pk_v01(wl[i], wh[i]), b = pk_v23(wl[i], wh[i]);
-    v[4 * i + 0] = a[0];
-    v[4 * i + 1] = a[1];
-    v[4 * i + 2] = b[0];
-    v[4 * i + 3] = b[1];
+    const f32x2 inner = __builtin_elementwise_fma(__builtin_shufflevector(wm[i], wm[i], 0, 0), pm, __builtin_shufflevector(wm[i], wm[i], 1, 1));
+    v[4 * i + 0] = w0[i] - wm[i][1];
+    v[4 * i + 1] = inner[0];
+    v[4 * i + 2] = inner[1];
+    // w[i][1] - w[i][3], written as w[i][3] * -1 + w[i][1] (the same IEEE difference): a subtraction here would look like the twin of
+    // the one two lines up to hipcc's vectoriser, which then packs the two at the price of four v_mov_b32 to assemble its operands
+    v[4 * i + 3] = __builtin_fmaf(w3[i], -1.0f, wm[i][0]);
   }
 }
 
@@ -247,18 +229,14 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
     //   VALU work in the MFMA issue gaps), and the LDS reads of k+2 are in flight.  The barrier that publishes chunk c+1 and frees
     //   chunk c's buffer sits between the two k-steps of chunk c, when every wave holds (c, q1) in registers.
     const float* ub0 = smem + (wm * K::CQ * 4) * 256 + lane * 4;           // U slab of this wave's channel group, k-step q0
-    // first patch element of this lane (window column dcol + 1).  The index is made opaque to the optimiser: it would otherwise split the
-    // constant part of dbase (the U slab in front of the window: 16 KB) off into the instruction offsets, which the paired LDS reads of
-    // the patch rows (ds_read2_b64: 8-bit offsets in 8-byte units) cannot hold -- four extra address additions per k-step
-    unsigned dofs = lds_base + 4u * (unsigned)(dbase + 1);                 // LDS byte address
-    asm volatile("" : "+v"(dofs));
+    const float* dp0 = smem + dbase;
     float vA[16], vB[16];
     WOps LA, LB;
     wait_vm0();
     __builtin_amdgcn_s_barrier();
     if (a.nchunks > 1) stage_chunk<K>(rsU, rsW, voff, lds_base + 4u * (unsigned)K::BUF, wave, chunk_u, chunk_w);
-    wino_load<K>(LA, ub0, dofs);
-    wino_load<K>(LB, ub0 + 4 * 256, dofs + 16u * K::CS);
+    wino_load<K>(LA, ub0, dp0);
+    wino_load<K>(LB, ub0 + 4 * 256, dp0 + 4 * K::CS);
     wino_transform(LA, vA);
     for (int c = 0; c < a.nchunks; ++c) {
       const bool more = c + 1 < a.nchunks;
@@ -280,7 +258,7 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
           const unsigned* tab = reinterpret_cast<const unsigned*>(smem + 2 * K::BUF) + (wave * 64 + ln);
           stage_chunk_tab<K>(rsU, rsW, tab, 16u * ln, a.kquads, lds_base + 4u * (unsigned)((c & 1) * K::BUF), wave, (unsigned)(c + 2) * chunk_u, (unsigned)(c + 2) * chunk_w);
         }
-        wino_load<K>(LA, ub0 + nb * K::BUF, dofs + 4u * (unsigned)(nb * K::BUF));
+        wino_load<K>(LA, ub0 + nb * K::BUF, dp0 + nb * K::BUF);
       }
       __builtin_amdgcn_sched_barrier(0);
       // k-step (c, q1); (c + 1, q0) is transformed in its shadow, (c + 1, q1) goes into flight
@@ -288,9 +266,7 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
       if (more) {
         wino_transform(LA, vA);
         __builtin_amdgcn_sched_barrier(0);
-        unsigned o1 = dofs + 4u * (unsigned)(nb * K::BUF + 4 * K::CS);       // one address for the four paired row reads of k-step q1 (see dofs)
-        asm volatile("" : "+v"(o1));
-        wino_load<K>(LB, ub0 + nb * K::BUF + 4 * 256, o1);
+        wino_load<K>(LB, ub0 + nb * K::BUF + 4 * 256, dp0 + nb * K::BUF + 4 * K::CS);
       }
     }
   } else {
@@ -313,7 +289,7 @@ __device__ __forceinline__ void wino_body(const Args& a, int g, int bx, int by, 
       for (int m = 0; m < MT; ++m) {
         // the 4x4 patch of channel 4 q + kq under tile (ty, tx) of block m, then V = B^T d B
         WOps po;
-        wino_load_patch<K>(po, sb + dbase + q * 4 * K::CS + m * 2 * K::TGX + 1);
+        wino_load_patch<K>(po, sb + dbase + q * 4 * K::CS + m * 2 * K::TGX);
         float v[16];
         wino_transform(po, v);
 #pragma unroll

@@ -68,6 +68,9 @@ class Blob:
     def num_axes(self):
         return len(self._shape)
 
+    def shape_string(self) -> str:                        # blob.hpp:56-63
+        return "".join("%d " % d for d in self._shape) + "(%d)" % self.count()
+
     def count(self):
         n = 1
         for s in self._shape:
@@ -172,6 +175,8 @@ class Layer:
     def ExactNumTopBlobs(self): return -1
     def MinTopBlobs(self): return -1
     def MaxTopBlobs(self): return -1
+    def EqualNumBottomTopBlobs(self) -> bool: return False   # layer.hpp:293
+    def AutoTopBlobs(self) -> bool: return False              # layer.hpp:303 (loss layers: loss_layer.hpp:40)
     def AllowBackward(self) -> bool: return True      # layer.hpp:322-324
 
     # --- layer.hpp:69-76 -----------------------------------------------------------------------
@@ -195,6 +200,8 @@ class Layer:
             CHECK(self.MinTopBlobs() <= len(top), f"{t} Layer produces at least {self.MinTopBlobs()} top blob(s) as output.")
         if self.MaxTopBlobs() >= 0:
             CHECK(self.MaxTopBlobs() >= len(top), f"{t} Layer produces at most {self.MaxTopBlobs()} top blob(s) as output.")
+        if self.EqualNumBottomTopBlobs():
+            CHECK(len(bottom) == len(top), f"{t} Layer produces one top blob as output for each bottom blob input.")   # layer.hpp:433-437
 
     def SetLossWeights(self, top):                         # layer.hpp:444-458
         lw = list(self.layer_param_.loss_weight)
@@ -383,6 +390,7 @@ class L1LossLayer(Layer):
     def MinBottomBlobs(self): return 1
     def MaxBottomBlobs(self): return 2
     def ExactNumTopBlobs(self): return 1
+    def AutoTopBlobs(self): return True                   # LossLayer, loss_layer.hpp:40: a prototxt may leave the top out
 
     def LayerSetUp(self, bottom, top):
         if not self.layer_param_.loss_weight:        # LossLayer::LayerSetUp, loss_layer.cpp:8-13

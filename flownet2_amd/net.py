@@ -27,17 +27,29 @@ from . import prototxt
 from .layers import Blob, CHECK, CheckError, Layer, LayerParameter, LayerRegistry
 
 
-def _phase_ok(lp: LayerParameter, phase: str) -> bool:
-    """NetStateRule, phase only (net.cpp:272-330): any include rule must match; no exclude rule may match."""
-    inc, exc = lp.include, lp.exclude
-    if inc:
-        if not any(str(r.get("phase", phase)) == phase for r in inc):
-            return False
-    return not any("phase" in r and str(r["phase"]) == phase for r in exc)
+def _state_meets_rule(state: Dict, rule: Dict) -> bool:
+    """Net::StateMeetsRule, net.cpp:319-382: phase, min_level / max_level, every `stage` present, no `not_stage` present."""
+    if "phase" in rule and str(rule["phase"]) != state["phase"]:
+        return False
+    if "min_level" in rule and state["level"] < int(rule["min_level"]):
+        return False
+    if "max_level" in rule and state["level"] > int(rule["max_level"]):
+        return False
+    if any(str(s) not in state["stage"] for s in rule.get("stage", [])):
+        return False
+    return not any(str(s) in state["stage"] for s in rule.get("not_stage", []))
+
+
+def _layer_included(lp: LayerParameter, state: Dict) -> bool:
+    """Net::FilterNet, net.cpp:290-317: no include rules -> included unless an exclude rule is met; else included iff an include rule is met."""
+    CHECK(not (lp.include and lp.exclude), "Specify either include rules or exclude rules; not both.")      # net.cpp:297-298
+    if not lp.include:
+        return not any(_state_meets_rule(state, r) for r in lp.exclude)
+    return any(_state_meets_rule(state, r) for r in lp.include)
 
 
 class Net:
-    def __init__(self, proto_text: str, phase: str = "TEST", device=None, backend=None):
+    def __init__(self, proto_text: str, phase: str = "TEST", device=None, backend=None, level: int = 0, stages=()):
         self.phase_ = phase
         self.device_ = torch.device(device) if device is not None else torch.device("cuda")
         self.backend_ = backend
@@ -55,10 +67,18 @@ class Net:
         self._shared: Dict[str, Blob] = {}
         self._available: List[str] = []
         self._init_inputs()
+        # NetState: the phase the net is built for, plus the level / stages of the prototxt's own `state { }` and the caller's (the
+        # reference merges them the same way: caffe.cpp / pycaffe pass level and stages, net.cpp:290-292 reads param.state())
+        st = self.param_.get("state", {}) or {}
+        self.state_ = {"phase": phase, "level": int(level or st.get("level", 0)), "stage": [str(x) for x in list(st.get("stage", [])) + list(stages)]}
+        self.learnable_: List[Blob] = []                # learnable parameter blobs, owners only (net.cpp:484-505)
+        self.params_lr_: List[float] = []
+        self.params_decay_: List[float] = []
+        self._owner: Dict[str, tuple] = {}
         last_writer: Dict[str, int] = {}
         for ld in self.param_.get("layer", []):
             lp = LayerParameter.from_dict(ld, phase)
-            if not _phase_ok(lp, phase):
+            if not _layer_included(lp, self.state_):
                 continue
             self._append_layer(lp, last_writer)
         self.outputs = list(self._available)            # blobs nobody consumed (net.cpp:221-230)
@@ -80,6 +100,8 @@ class Net:
             self._available.append(n)
 
     def _append_layer(self, lp: LayerParameter, last_writer: Dict[str, int]):
+        if lp.propagate_down:
+            CHECK(len(lp.propagate_down) == len(lp.bottom), "propagate_down param must be specified either 0 or bottom_size times ")   # net.cpp:77-82
         bottom = []
         for b in lp.bottom:
             CHECK(b in self.blobs, f"Unknown bottom blob '{b}' (layer '{lp.name}', bottom index {len(bottom)})")   # net.cpp:433-434
@@ -101,27 +123,59 @@ class Net:
         if lp.type == "Input":
             for t in lp.top:
                 self.inputs.append(t)
-        # parameter sharing: a ParamSpec name seen before hands over that owner's blob (net.cpp:451-540)
+        # AutoTopBlobs (loss layers): anonymous tops the prototxt did not name; nobody can consume them (net.cpp:116-130)
+        if layer.AutoTopBlobs():
+            while len(top) < max(layer.MinTopBlobs(), layer.ExactNumTopBlobs()):
+                top.append(Blob(device=self.device_))
         layer.SetUp(bottom, top)
-        for k, spec in enumerate(lp.param):
-            pname = str(spec.get("name", "")) if isinstance(spec, dict) else ""
-            if not pname or k >= len(layer.blobs_):
+        # parameter sharing: a ParamSpec name seen before hands over that owner's blob (Net::AppendParam, net.cpp:451-540)
+        CHECK(len(lp.param) <= len(layer.blobs_), f"Too many params specified for layer {lp.name}")           # net.cpp:163-165
+        for k in range(len(layer.blobs_)):
+            spec = lp.param[k] if k < len(lp.param) and isinstance(lp.param[k], dict) else {}
+            pname = str(spec.get("name", ""))
+            lr, decay = float(spec.get("lr_mult", 1.0)), float(spec.get("decay_mult", 1.0))
+            if not pname or pname not in self._owner:
+                if pname:
+                    self._owner[pname] = (lp.name, len(self.learnable_))
+                    self._shared[pname] = layer.blobs_[k]
+                self.learnable_.append(layer.blobs_[k])
+                self.params_lr_.append(lr)
+                self.params_decay_.append(decay)
                 continue
-            if pname in self._shared:
-                CHECK(self._shared[pname].shape() == layer.blobs_[k].shape(),
-                      f"Cannot share param '{pname}' with layer '{lp.name}'; shape mismatch.")                 # net.cpp:503-530
-                layer.blobs_[k] = self._shared[pname]
-            else:
-                self._shared[pname] = layer.blobs_[k]
-        # executor peephole: ReLU in place on the top of the Convolution / Deconvolution directly in front of it
+            owner_name, lid = self._owner[pname]
+            mine, owner = layer.blobs_[k], self._shared[pname]
+            if str(spec.get("share_mode", "STRICT")) == "PERMISSIVE":                                            # net.cpp:503-512
+                CHECK(mine.count() == owner.count(),
+                      f"Cannot share param '{pname}' owned by layer '{owner_name}' with layer '{lp.name}'; count mismatch.  Owner layer param "
+                      f"shape is {owner.shape_string()}; sharing layer shape is {mine.shape_string()}")
+            else:                                                                                               # net.cpp:513-520
+                CHECK(mine.shape() == owner.shape(),
+                      f"Cannot share param '{pname}' owned by layer '{owner_name}' with layer '{lp.name}'; shape mismatch.  Owner layer param "
+                      f"shape is {owner.shape_string()}; sharing layer expects shape {mine.shape_string()}")
+            if "lr_mult" in spec:                                                                               # net.cpp:524-531
+                CHECK(lr == self.params_lr_[lid], f"Shared param '{pname}' has mismatched lr_mult.")
+            if "decay_mult" in spec:                                                                            # net.cpp:532-540
+                CHECK(decay == self.params_decay_[lid], f"Shared param '{pname}' has mismatched decay_mult.")
+            layer.blobs_[k] = owner
+        # executor peephole: a ReLU in place on a top of the Convolution / Deconvolution in front of it -- directly, or behind the ReLUs
+        # that were folded for the other tops of the same layer (the siamese towers: one Convolution with two bottoms and two tops,
+        # then ReLU on top a, ReLU on top b) -- is applied by that layer's own kernel
         if lp.type == "ReLU" and len(lp.bottom) == 1 and lp.top == lp.bottom:
             w = last_writer.get(lp.bottom[0])
-            if w is not None and w == len(self.layers) - 1 and self.layers[w].layer_param_.type in ("Convolution", "Deconvolution") \
-                    and len(self.layers[w].layer_param_.top) == 1:
-                self.layers[w].fused_relu_ = layer.negative_slope_
+            between = range(w + 1, len(self.layers)) if w is not None else []
+            if w is not None and self.layers[w].layer_param_.type in ("Convolution", "Deconvolution") \
+                    and self.layers[w].layer_param_.top.index(lp.bottom[0]) not in self.layers[w].fused_relu_tops_ \
+                    and all(getattr(self.layers[j], "folded_", False) and last_writer.get(self.layers[j].layer_param_.top[0]) == w for j in between):
+                self.layers[w].fused_relu_tops_[self.layers[w].layer_param_.top.index(lp.bottom[0])] = layer.negative_slope_
                 layer.folded_ = True
-        for t in lp.top:
-            last_writer[t] = len(self.layers)
+                lp_is_folded = True
+            else:
+                lp_is_folded = False
+        else:
+            lp_is_folded = False
+        if not lp_is_folded:                            # a folded ReLU leaves its blob to the convolution that now writes the activated values
+            for t in lp.top:
+                last_writer[t] = len(self.layers)
         self.layers.append(layer)
         self.layer_names.append(lp.name)
         self.bottoms_.append(bottom)

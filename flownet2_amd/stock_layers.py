@@ -69,6 +69,7 @@ class _ConvBase(Layer):
 
     def MinBottomBlobs(self): return 1
     def MinTopBlobs(self): return 1
+    def EqualNumBottomTopBlobs(self): return True                                        # base_conv_layer.hpp:29
 
     def _geom(self):
         cp = self.layer_param_.convolution_param
@@ -87,7 +88,7 @@ class _ConvBase(Layer):
 
     def LayerSetUp(self, bottom, top):
         self.num_output_, self.kernel_, self.pad_, self.stride_, self.bias_term_ = self._geom()
-        self.fused_relu_ = None                 # negative slope of an in-place ReLU folded in by the executor
+        self.fused_relu_tops_ = {}              # top index -> negative slope of an in-place ReLU folded in by the executor
         cin = bottom[0].channels()
         cp = self.layer_param_.convolution_param
         if not self.blobs_:                                                               # base_conv_layer.cpp:125-152
@@ -108,10 +109,36 @@ class _ConvBase(Layer):
 
     def Reshape(self, bottom, top):
         cin = self.blobs_[0].shape(0) if self.transposed else self.blobs_[0].shape(1)
-        for b, t in zip(bottom, top):
-            CHECK(b.channels() == cin, "Input size incompatible with convolution kernel.")  # base_conv_layer.cpp:196
-            ho, wo = self._out_hw(b.height(), b.width())
-            t.Reshape(b.num(), self.num_output_, ho, wo)
+        CHECK(bottom[0].channels() == cin, "Input size incompatible with convolution kernel.")   # base_conv_layer.cpp:191-192
+        for b in bottom[1:]:                                                                     # base_conv_layer.cpp:194-197
+            CHECK(b.shape() == bottom[0].shape(), "All inputs must have the same shape.")
+        ho, wo = self._out_hw(bottom[0].height(), bottom[0].width())
+        for t in top:                                                                            # one weight blob, applied to every bottom
+            t.Reshape(bottom[0].num(), self.num_output_, ho, wo)
+
+    @property
+    def fused_relu_(self):
+        """Negative slope of the folded ReLU when EVERY top has one with the same slope (the only case the single-top code paths and the
+        batched siamese launch ask about), else None."""
+        v = set(self.fused_relu_tops_.get(i) for i in range(len(self.layer_param_.top)))
+        return next(iter(v)) if len(v) == 1 and None not in v else None
+
+    def _slope(self, i):
+        return self.fused_relu_tops_.get(i)
+
+    def _forward_all(self, bottom, top, one):
+        """`one(x, slope) -> y` on every (bottom, top) pair (base_conv_layer.cpp: the loop over bottom.size() in Forward_gpu,
+        conv_layer.cu:12-22).  Several bottoms with one activation (the siamese towers of FlowNetC: one Convolution, two bottoms, two
+        tops) run as ONE launch on the bottoms stacked along the batch axis -- the kernels are per-sample -- and the tops are the
+        halves of its output."""
+        if len(bottom) > 1 and len({self._slope(i) for i in range(len(top))}) == 1 and bottom[0].data.is_cuda:
+            n = bottom[0].num()
+            y = one(torch.cat([b.data for b in bottom], 0), self._slope(0))
+            for i, t in enumerate(top):
+                t.data = y[i * n:(i + 1) * n]
+            return
+        for i, (b, t) in enumerate(zip(bottom, top)):
+            t.data = one(b.data, self._slope(i))
 
     def _backend(self):
         if self.backend_ is not None:
@@ -128,17 +155,17 @@ class ConvolutionLayer(_ConvBase):
         be = self._backend()
         w, b = self.blobs_[0].data, (self.blobs_[1].data if self.bias_term_ else None)
         k, s, p = self.kernel_, self.stride_, self.pad_
-        for bt, tp in zip(bottom, top):
-            x = bt.data
-            if k == 1 and s == 1 and p == 0 and self.fused_relu_ is None and b is not None and getattr(self, "diagonal_", None) is not None:
+
+        def one(x, slope):
+            if k == 1 and s == 1 and p == 0 and slope is None and getattr(self, "diagonal_", None) is not None:
                 # the deploy tail's SCALE convolution (weight_filler diagonal, run-flownet.py:47-48): y[c] = diag[c] x[c] + 0 x[other]
-                tp.data = x * self.diagonal_.view(1, -1, 1, 1) + b.view(1, -1, 1, 1) if bool((b != 0).any()) else x * self.diagonal_.view(1, -1, 1, 1)
-            elif k == 3 and s == 1 and p == 1 and self.num_output_ == 2 and self.fused_relu_ is None and hasattr(be, "predict_flow_conv"):
-                tp.data = be.predict_flow_conv(x, w, b)                                   # the predict_flow heads (csrc/flow_head.hip)
-            else:
-                y = nets.conv_forward(x, w, b if b is not None else torch.zeros(self.num_output_, device=x.device), s, p,
-                                      self.fused_relu_ is not None, be, slope=self.fused_relu_)
-                tp.data = y
+                y = x * self.diagonal_.view(1, -1, 1, 1)
+                return y + b.view(1, -1, 1, 1) if (b is not None and bool((b != 0).any())) else y
+            if k == 3 and s == 1 and p == 1 and self.num_output_ == 2 and slope is None and hasattr(be, "predict_flow_conv"):
+                return be.predict_flow_conv(x, w, b)                                      # the predict_flow heads (csrc/flow_head.hip)
+            return nets.conv_forward(x, w, b if b is not None else torch.zeros(self.num_output_, device=x.device), s, p,
+                                     slope is not None, be, slope=slope)
+        self._forward_all(bottom, top, one)
 
     def note_weights_changed(self):
         """After the weights were (re)loaded: a 1x1 weight that is diagonal is applied as a per-channel scale (exactly what the zero
@@ -162,16 +189,16 @@ class DeconvolutionLayer(_ConvBase):
         be = self._backend()
         w, b = self.blobs_[0].data, (self.blobs_[1].data if self.bias_term_ else None)
         k, s, p = self.kernel_, self.stride_, self.pad_
-        for bt, tp in zip(bottom, top):
-            x = bt.data
-            if (k, s, p) == (4, 2, 1) and w.shape[0] == 2 and w.shape[1] == 2 and self.fused_relu_ is None and hasattr(be, "upsample_flow_deconv"):
-                tp.data = be.upsample_flow_deconv(x, w, b)                                # the upsample_flow heads (csrc/flow_head.hip)
-            elif (k, s, p) == (4, 2, 1):
+
+        def one(x, slope):
+            if (k, s, p) == (4, 2, 1) and w.shape[0] == 2 and w.shape[1] == 2 and slope is None and hasattr(be, "upsample_flow_deconv"):
+                return be.upsample_flow_deconv(x, w, b)                                   # the upsample_flow heads (csrc/flow_head.hip)
+            if (k, s, p) == (4, 2, 1):
                 bb = b if b is not None else torch.zeros(self.num_output_, device=x.device)
-                tp.data = nets.deconv_forward(x, w, bb, self.fused_relu_ is not None, be, slope=self.fused_relu_)
-            else:
-                y = torch.nn.functional.conv_transpose2d(x, w, b, stride=s, padding=p)
-                tp.data = torch.nn.functional.leaky_relu(y, self.fused_relu_) if self.fused_relu_ is not None else y
+                return nets.deconv_forward(x, w, bb, slope is not None, be, slope=slope)
+            y = torch.nn.functional.conv_transpose2d(x, w, b, stride=s, padding=p)
+            return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y
+        self._forward_all(bottom, top, one)
 
     def note_weights_changed(self):
         pass
