@@ -24,12 +24,14 @@ EXPORTS = [
     "fn2_predict_flow_conv_backward_supported", "fn2_predict_flow_conv_backward_workspace_bytes", "fn2_predict_flow_conv_backward", "fn2_upsample_flow_deconv_backward_workspace_bytes", "fn2_upsample_flow_deconv_backward",
     "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward", "fn2_bias_leaky_relu_backward_slices",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
+    "fn2_conv_k7s2_wgrad_supported", "fn2_conv_k7s2_wgrad_ksplit", "fn2_conv_k7s2_wgrad_workspace_bytes", "fn2_conv_k7s2_wgrad",
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
     "fn2_conv_mfma_num_variants", "fn2_debug_set_conv_variant",
     "fn2_caffemodel_index", "fn2_caffemodel_read_blob",
     "fn2_conv_wino_supported", "fn2_conv_wino_packed_floats", "fn2_conv_wino_pack_weights", "fn2_conv_wino_forward",
     "fn2_conv_wino_num_variants", "fn2_debug_set_wino_variant",
     "fn2_conv_plane_supported", "fn2_conv_plane_ksplit", "fn2_conv_plane_workspace_bytes", "fn2_conv_plane_forward",
+    "fn2_conv_plane_k_supported", "fn2_conv_plane_k_ksplit", "fn2_conv_plane_k_workspace_bytes", "fn2_conv_plane_k_forward",
     "fn2_conv_plane_num_variants", "fn2_debug_set_plane_variant", "fn2_debug_set_plane_ksplit", "fn2_set_batch_invariant", "fn2_get_batch_invariant",
     "fn2_deconv_plane_supported", "fn2_deconv_plane_ksplit", "fn2_deconv_plane_workspace_bytes", "fn2_deconv_plane_packed_floats",
     "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_forward",
@@ -159,6 +161,16 @@ def lib():
     L.fn2_conv_plane_workspace_bytes.argtypes = [i] * 7
     L.fn2_conv_plane_workspace_bytes.restype = sz
     L.fn2_conv_plane_forward.argtypes = [fp, fp, fp, fp] + [i] * 12 + [C.c_float, vp, sz, vp]
+    L.fn2_conv_k7s2_wgrad_supported.argtypes = [i] * 5
+    L.fn2_conv_k7s2_wgrad_ksplit.argtypes = [i] * 5
+    L.fn2_conv_k7s2_wgrad_workspace_bytes.argtypes = [i] * 5
+    L.fn2_conv_k7s2_wgrad_workspace_bytes.restype = sz
+    L.fn2_conv_k7s2_wgrad.argtypes = [fp, fp, fp] + [i] * 6 + [vp, sz, vp]
+    L.fn2_conv_plane_k_supported.argtypes = [i] * 8
+    L.fn2_conv_plane_k_ksplit.argtypes = [i] * 8
+    L.fn2_conv_plane_k_workspace_bytes.argtypes = [i] * 8
+    L.fn2_conv_plane_k_workspace_bytes.restype = sz
+    L.fn2_conv_plane_k_forward.argtypes = [fp, fp, fp, fp] + [i] * 13 + [C.c_float, vp, sz, vp]
     L.fn2_debug_set_plane_variant.argtypes = [i]
     L.fn2_debug_set_plane_ksplit.argtypes = [i]
     L.fn2_set_batch_invariant.argtypes = [i]

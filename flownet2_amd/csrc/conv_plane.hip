@@ -72,12 +72,12 @@ struct Args {
   float slope; int relu;
 };
 
-template <int MODE_, int S_, int MW_, int NP_, int WM_, int WN_, int CQ_, int VEC_>
+template <int MODE_, int S_, int MW_, int NP_, int WM_, int WN_, int CQ_, int VEC_, int KS_ = 3>
 struct Cfg {
-  static constexpr int MODE = MODE_, S = S_, MW = MW_, NP = NP_, WM = WM_, WN = WN_, CQ = CQ_, VEC = VEC_;
+  static constexpr int MODE = MODE_, S = S_, MW = MW_, NP = NP_, WM = WM_, WN = WN_, CQ = CQ_, VEC = VEC_, KS = KS_;
   static constexpr int NCLS = MODE == 1 ? 4 : 1;      // parity classes = waves sharing a pixel block
   static constexpr int NW = NCLS * WM * WN, THREADS = 64 * NW;
-  static constexpr int TAP = MODE == 1 ? 2 : 3;       // taps per axis
+  static constexpr int TAP = MODE == 1 ? 2 : KS;      // taps per axis (convolution: 3, or 4 for the 4x4 / 2 data gradient of a Deconvolution)
   static constexpr int PADL = VEC == 4 ? 4 : 1;       // window columns left of x = 0
   static constexpr int KSC = CQ * TAP * TAP;
   static constexpr int NBUFA = (KSC % 9 == 0 && KSC > 9) ? 9 : (KSC % 8 == 0) ? 8 : (KSC % 4 == 0) ? 4 : 3;   // weight-operand ring (k-steps)
@@ -85,6 +85,7 @@ struct Cfg {
   static_assert(KSC % NBUFA == 0, "ring phase must repeat per chunk");
   static_assert(NBUFA - 1 <= kSpare, "prefetch distance");
   static_assert(MODE == 0 || S == 1, "the deconvolution reads its input at stride 1");
+  static_assert(KS == 3 || (KS == 4 && MODE == 0 && S == 2), "tap classes: 3x3 / 1, 3x3 / 2, 4x4 / 2");
 };
 
 // q / d for the small non-negative values of the index decodes (q < 2^16, d < 2^16); m = ceil(2^32 / d), d == 1 has no 32-bit m
@@ -335,7 +336,7 @@ __global__ void pack_deconv_weights(const float* __restrict__ w, float* __restri
 }
 
 struct Variant {
-  int mode, s, mw, np, wm, wn, cq, vec;
+  int mode, s, mw, np, wm, wn, cq, vec, ks;
   int (*fn)(const Args&, hipStream_t);
 };
 
@@ -353,7 +354,7 @@ static bool plan(const Variant& v, Args& a) {
     if (span < prow) { prow = span; a.band = 1; }
   }
   if (v.mode == 0) {
-    const int wr_need = (prow - 1) * v.s + 3;
+    const int wr_need = (prow - 1) * v.s + v.ks;
     a.wr = (!a.band && a.Hin + 2 * a.pad < wr_need) ? a.Hin + 2 * a.pad : wr_need;
   } else {
     a.wr = prow + 2;
@@ -407,8 +408,11 @@ static int launch(const Args& a, hipStream_t st) {
   X(1, 1, 2, 9, 1, 1, 2, VEC) X(1, 1, 2, 9, 1, 1, 1, VEC) X(1, 1, 4, 9, 1, 1, 1, VEC) X(1, 1, 4, 9, 1, 1, 2, VEC) X(1, 1, 2, 5, 1, 1, 2, VEC) \
   X(1, 1, 4, 5, 1, 1, 2, VEC) X(1, 1, 2, 7, 1, 1, 2, VEC) X(1, 1, 4, 7, 1, 1, 1, VEC)
 #define FN2_CP_LIST(X) FN2_CP_TILES(X, 1, 1) FN2_CP_TILES(X, 1, 4) FN2_CP_TILES(X, 2, 1) FN2_CP_TILES(X, 2, 4) FN2_DP_TILES(X, 1) FN2_DP_TILES(X, 4)
-#define FN2_CP_ROW(MODE, S, MW, NP, WM, WN, CQ, VEC) {MODE, S, MW, NP, WM, WN, CQ, VEC, &launch<Cfg<MODE, S, MW, NP, WM, WN, CQ, VEC>>},
-static const Variant kVariants[] = {FN2_CP_LIST(FN2_CP_ROW)};
+#define FN2_CP_ROW(MODE, S, MW, NP, WM, WN, CQ, VEC) {MODE, S, MW, NP, WM, WN, CQ, VEC, MODE == 1 ? 4 : 3, &launch<Cfg<MODE, S, MW, NP, WM, WN, CQ, VEC>>},
+// 4x4 taps at stride 2 (the data gradient of a Deconvolution{4, 2, 1} on a small map: deconv_layer.cu:52-56 = forward_gpu_gemm of top_diff)
+#define FN2_CP4_TILES(X, VEC) X(2, 9, 2, 2, 2, VEC) X(2, 5, 2, 2, 2, VEC) X(4, 5, 1, 4, 2, VEC) X(2, 5, 2, 4, 2, VEC)
+#define FN2_CP4_ROW(MW, NP, WM, WN, CQ, VEC) {0, 2, MW, NP, WM, WN, CQ, VEC, 4, &launch<Cfg<0, 2, MW, NP, WM, WN, CQ, VEC, 4>>},
+static const Variant kVariants[] = {FN2_CP_LIST(FN2_CP_ROW) FN2_CP4_TILES(FN2_CP4_ROW, 1) FN2_CP4_TILES(FN2_CP4_ROW, 4)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int g_forced_variant = -1;
@@ -435,7 +439,7 @@ static double variant_cost(const Variant& v, const Args& a) {
 }
 
 // One forward call of either mode: pick the variant (forced / autotuned / cost model), launch, reduce the K parts.
-static int forward(Args a, int mode, int stride, void* workspace, size_t workspace_bytes, const char* what, hipStream_t st) {
+static int forward(Args a, int mode, int stride, int ks, void* workspace, size_t workspace_bytes, const char* what, hipStream_t st) {
   const int Po = a.Hout * a.Wout;
   if (a.ksplit > 1) {
     const size_t need = sizeof(float) * (size_t)a.ksplit * a.N * a.Cout * Po;
@@ -446,7 +450,7 @@ static int forward(Args a, int mode, int stride, void* workspace, size_t workspa
   auto run = [&](int i) -> int {
     const Variant& v = kVariants[i];
     Args t = a;
-    if (v.mode != mode || v.s != stride || !plan(v, t)) return FN2_ERR_UNSUPPORTED;
+    if (v.mode != mode || v.s != stride || v.ks != ks || !plan(v, t)) return FN2_ERR_UNSUPPORTED;
     return v.fn(t, st);
   };
   int best = -1;
@@ -458,16 +462,16 @@ static int forward(Args a, int mode, int stride, void* workspace, size_t workspa
       static TuneCache cache_conv("conv_plane", kNumVariants), cache_deconv("deconv_plane", kNumVariants);
       auto usable = [&](int i) -> bool {
         Args t = a;
-        return kVariants[i].mode == mode && kVariants[i].s == stride && plan(kVariants[i], t);
+        return kVariants[i].mode == mode && kVariants[i].s == stride && kVariants[i].ks == ks && plan(kVariants[i], t);
       };
-      const TuneKey key{a.N, a.Cin, a.Hin, a.Win, a.Cout, stride, a.pad, a.ksplit, a.in_ctot == a.Cin, a.out_ctot == a.Cout};
+      const TuneKey key{a.N, a.Cin, a.Hin, a.Win, a.Cout, stride + 16 * ks, a.pad, a.ksplit, a.in_ctot == a.Cin, a.out_ctot == a.Cout};
       best = autotune_pick(mode == 0 ? cache_conv : cache_deconv, key, kNumVariants, st, run, usable);
     }
     if (best < 0) {
       double bc = 0;
       for (int i = 0; i < kNumVariants; ++i) {
         Args t = a;
-        if (kVariants[i].mode != mode || kVariants[i].s != stride || !plan(kVariants[i], t)) continue;
+        if (kVariants[i].mode != mode || kVariants[i].s != stride || kVariants[i].ks != ks || !plan(kVariants[i], t)) continue;
         const double c = variant_cost(kVariants[i], t);
         if (best < 0 || c < bc) { best = i; bc = c; }
       }
@@ -486,10 +490,10 @@ static int forward(Args a, int mode, int stride, void* workspace, size_t workspa
   return FN2_OK;
 }
 
-static bool supported(const Args& a, int mode, int stride) {
+static bool supported(const Args& a, int mode, int stride, int ks) {
   for (int i = 0; i < kNumVariants; ++i) {
     Args t = a;
-    if (kVariants[i].mode == mode && kVariants[i].s == stride && plan(kVariants[i], t)) return true;
+    if (kVariants[i].mode == mode && kVariants[i].s == stride && kVariants[i].ks == ks && plan(kVariants[i], t)) return true;
   }
   return false;
 }
@@ -499,70 +503,89 @@ static bool supported(const Args& a, int mode, int stride) {
 
 using namespace fn2;
 
-// ------------------------------------------------------------------------------------------------ convolution 3x3
-static bool plane_geometry_ok(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
+// ------------------------------------------------------------------------------------------------ convolution 3x3 (and 4x4 / 2)
+static bool plane_geometry_ok(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
   if (N <= 0 || Cin <= 0 || Cin % 8 != 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 64 != 0) return false;
   if ((stride != 1 && stride != 2) || pad < 0 || pad > 1) return false;
-  if (Hin + 2 * pad < 3 || Win + 2 * pad < 3) return false;
+  if (!(kernel == 3 || (kernel == 4 && stride == 2 && pad == 1))) return false;
+  if (Hin + 2 * pad < kernel || Win + 2 * pad < kernel) return false;
   if ((long long)N * Cin * Hin * Win >= (1ll << 28)) return false;
   return true;
 }
 
-static void fill_args(cp::Args& a, int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
+static void fill_args(cp::Args& a, int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
   a.N = N; a.Cin = Cin; a.Hin = Hin; a.Win = Win; a.Cout = Cout; a.pad = pad;
-  a.Hout = (Hin + 2 * pad - 3) / stride + 1; a.Wout = (Win + 2 * pad - 3) / stride + 1;
+  a.Hout = (Hin + 2 * pad - kernel) / stride + 1; a.Wout = (Win + 2 * pad - kernel) / stride + 1;
   a.P = a.Hout * a.Wout; a.Wp = a.Wout;
   a.units = ((Cin + 3) / 4 + 1) / 2;
   a.ksplit = cp::ksplit_for((long long)cp::cdiv(order_batch(N) * a.P, 16) * (Cout / 16), a.units);
-  a.ksteps = a.units * 2 * 9 + cp::kSpare;                        // fn2_conv_mfma_pack_weights: whole chunks of 2 quads + 8 spare k-steps
+  a.ksteps = a.units * 2 * kernel * kernel + cp::kSpare;          // fn2_conv_mfma_pack_weights: whole chunks of 2 quads + 8 spare k-steps
   a.class_stride = 0;
 }
 
-FN2_API int fn2_conv_plane_supported(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
-  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, stride, pad)) return 0;
+FN2_API int fn2_conv_plane_k_supported(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
+  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, kernel, stride, pad)) return 0;
   cp::Args a{};
-  fill_args(a, N, Cin, Hin, Win, Cout, stride, pad);
-  return cp::supported(a, 0, stride) ? 1 : 0;
+  fill_args(a, N, Cin, Hin, Win, Cout, kernel, stride, pad);
+  return cp::supported(a, 0, stride, kernel) ? 1 : 0;
 }
 
-FN2_API int fn2_conv_plane_ksplit(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
-  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, stride, pad)) return 0;
+FN2_API int fn2_conv_plane_k_ksplit(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
+  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, kernel, stride, pad)) return 0;
   cp::Args a{};
-  fill_args(a, N, Cin, Hin, Win, Cout, stride, pad);
+  fill_args(a, N, Cin, Hin, Win, Cout, kernel, stride, pad);
   return a.ksplit;
 }
 
-FN2_API size_t fn2_conv_plane_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
-  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, stride, pad)) return 0;
+FN2_API size_t fn2_conv_plane_k_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
+  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, kernel, stride, pad)) return 0;
   cp::Args a{};
-  fill_args(a, N, Cin, Hin, Win, Cout, stride, pad);
+  fill_args(a, N, Cin, Hin, Win, Cout, kernel, stride, pad);
   return a.ksplit > 1 ? sizeof(float) * (size_t)a.ksplit * N * Cout * a.P : 0;
+}
+
+FN2_API int fn2_conv_plane_supported(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
+  return fn2_conv_plane_k_supported(N, Cin, Hin, Win, Cout, 3, stride, pad);
+}
+FN2_API int fn2_conv_plane_ksplit(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
+  return fn2_conv_plane_k_ksplit(N, Cin, Hin, Win, Cout, 3, stride, pad);
+}
+FN2_API size_t fn2_conv_plane_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout, int stride, int pad) {
+  return fn2_conv_plane_k_workspace_bytes(N, Cin, Hin, Win, Cout, 3, stride, pad);
 }
 
 FN2_API int fn2_debug_set_plane_variant(int v) { cp::g_forced_variant = v; return FN2_OK; }
 FN2_API int fn2_debug_set_plane_ksplit(int k) { cp::g_forced_ksplit = k; return FN2_OK; }
 FN2_API int fn2_conv_plane_num_variants(void) { return cp::kNumVariants; }
 
-FN2_API int fn2_conv_plane_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
-                                   int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
-                                   int Cout, int top_channels, int top_c0, int stride, int pad,
-                                   int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream) {
+FN2_API int fn2_conv_plane_k_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                                     int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                     int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
+                                     int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream) {
   if (N < 0) return fail(FN2_ERR_INVALID_ARG, "conv_plane: bad batch");
   if (N == 0) return FN2_OK;
   if (!bottom || !packed_weight || !top) return fail(FN2_ERR_INVALID_ARG, "conv_plane: null blob");
-  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, stride, pad))
-    return fail(FN2_ERR_UNSUPPORTED, "conv_plane: unsupported geometry (N %d, Cin %d, %dx%d, Cout %d, s %d p %d)", N, Cin, Hin, Win, Cout, stride, pad);
+  if (!plane_geometry_ok(N, Cin, Hin, Win, Cout, kernel, stride, pad))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_plane: unsupported geometry (N %d, Cin %d, %dx%d, Cout %d, k %d s %d p %d)", N, Cin, Hin, Win, Cout, kernel, stride, pad);
   if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels)
     return fail(FN2_ERR_INVALID_ARG, "conv_plane: channel slice outside the blob");
   if (((reinterpret_cast<uintptr_t>(bottom) | reinterpret_cast<uintptr_t>(top) | reinterpret_cast<uintptr_t>(packed_weight)) & 15) != 0)
     return fail(FN2_ERR_UNSUPPORTED, "conv_plane: blobs must be 16-byte aligned");
   if ((long long)bottom_channels * Hin * Win * 4 * N >= 0x7ffffff0ll) return fail(FN2_ERR_UNSUPPORTED, "conv_plane: bottom blob too large");
   cp::Args a{};
-  fill_args(a, N, Cin, Hin, Win, Cout, stride, pad);
+  fill_args(a, N, Cin, Hin, Win, Cout, kernel, stride, pad);
   a.in = bottom; a.wp = packed_weight; a.bias = bias; a.out = top;
   a.in_ctot = bottom_channels; a.in_c0 = bottom_c0; a.out_ctot = top_channels; a.out_c0 = top_c0;
   a.slope = negative_slope; a.relu = relu;
-  return cp::forward(a, 0, stride, workspace, workspace_bytes, "conv_plane", as_stream(stream));
+  return cp::forward(a, 0, stride, kernel, workspace, workspace_bytes, "conv_plane", as_stream(stream));
+}
+
+FN2_API int fn2_conv_plane_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                                   int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                   int Cout, int top_channels, int top_c0, int stride, int pad,
+                                   int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream) {
+  return fn2_conv_plane_k_forward(bottom, packed_weight, bias, top, N, Cin, Hin, Win, bottom_channels, bottom_c0, Cout, top_channels, top_c0,
+                                  3, stride, pad, relu, negative_slope, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ deconvolution 4x4 / 2
@@ -586,7 +609,7 @@ FN2_API int fn2_deconv_plane_supported(int N, int Cin, int Hin, int Win, int Cou
   if (!deconv_geometry_ok(N, Cin, Hin, Win, Cout)) return 0;
   cp::Args a{};
   fill_deconv_args(a, N, Cin, Hin, Win, Cout);
-  return cp::supported(a, 1, 1) ? 1 : 0;
+  return cp::supported(a, 1, 1, 4) ? 1 : 0;
 }
 
 FN2_API int fn2_deconv_plane_ksplit(int N, int Cin, int Hin, int Win, int Cout) {
@@ -636,5 +659,5 @@ FN2_API int fn2_deconv_plane_forward(const float* bottom, const float* packed_we
   a.in = bottom; a.wp = packed_weight; a.bias = bias; a.out = top;
   a.in_ctot = bottom_channels; a.in_c0 = bottom_c0; a.out_ctot = top_channels; a.out_c0 = top_c0;
   a.slope = negative_slope; a.relu = relu;
-  return cp::forward(a, 1, 1, workspace, workspace_bytes, "deconv_plane", as_stream(stream));
+  return cp::forward(a, 1, 1, 4, workspace, workspace_bytes, "deconv_plane", as_stream(stream));
 }

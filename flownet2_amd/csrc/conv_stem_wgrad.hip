@@ -1,0 +1,235 @@
+// Weight gradient of the 7x7 / stride 2 / pad 3 stem convolution (conv1 of every FlowNet: 3, 6 or 12 bottom channels -> 64) on
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chains), NCHW in, Caffe weight layout out, deterministic.
+//
+//     dw[co][ci][ky][kx] (+)= sum_{n, y, x}  top_diff[n][co][y][x] * bottom[n][ci][2 y + ky - 3][2 x + kx - 3]        (zero outside bottom)
+//
+// Reference: ConvolutionLayer::Backward_gpu -> weight_gpu_gemm (src/caffe/layers/conv_layer.cu:40-52, base_conv_layer.cpp:368-384: per
+// SAMPLE im2col_gpu + cublasSgemm(top_diff x col^T) accumulated into weight_diff with beta = 1).
+//
+// Why its own kernel: csrc/conv_wgrad.hip tiles (top channels) x (BOTTOM CHANNELS) with one accumulator tile per tap -- 3 bottom channels
+// fill 3 / 16 of a tile and 49 taps are 49 tiles.  Here the N axis of the GEMM is the TAP axis: M = 16 top channels, N = 16 consecutive
+// taps t = (ci * 7 + ky) * 7 + kx (147 taps = 10 tiles at 3 channels: 92 % filled), K = pixels, 4 consecutive x of one row per k-step.
+//   * wave w of a workgroup owns top channels 16 w .. 16 w + 15 and ALL tap tiles: per k-step one `top_diff` operand and NT `bottom`
+//     operands (one ds_read_b32 at lane base + immediate each: lane (tap, k) reads window[ci][2 r + ky][2 (4 xq + k) + kx + 1]) for NT MFMAs;
+//   * a workgroup walks a contiguous range of UNITS (sample, pair of output rows, 32-pixel x segment), unit by unit: the unit's top_diff tile
+//     [64][2 rows x 32 px, padded to 68] and the bottom window [ci][9 rows][72 columns] arrive by 16-byte LDS-DMA straight from NCHW (rows /
+//     columns outside the maps are out of range for the buffer descriptor: 0.0f = the zero padding; the 68-dword channel stride keeps the 16
+//     channels of an operand read on 16 different banks), two buffers, one barrier per unit;
+//   * every workgroup ("part") writes its accumulator tiles as they are; stem_wgrad_finalize adds the parts in part order into the weight
+//     layout.  Summation order (restated by the oracle twin fn2_conv_k7s2_wgrad_cpu): per part one fma chain over the part's pixels in
+//     (unit, row, x) order, parts added in part order; the number of parts is a function of the geometry only (fn2_conv_k7s2_wgrad_ksplit).
+#include "fn2_common.hpp"
+
+namespace fn2 {
+namespace sw {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+using lds_vf = const volatile __attribute__((address_space(3))) float*;
+
+constexpr int kCout = 64, kR = 2, kXT = 32;
+constexpr int kDS = kR * kXT + 4;                 // top_diff channel stride in LDS (dwords): 64 data + 4 padding
+constexpr int kDSlots = kCout * (kDS / 4);        // 16-byte slots of the top_diff tile: 64 x 17
+constexpr int kWC = 2 * kXT + 8;                  // window columns: bottom x = 2 x0 - 4 .. 2 x0 + 67
+constexpr int kWR = 2 * (kR - 1) + 7;             // window rows: bottom y = 2 y0 - 3 .. 2 y0 + 5
+constexpr unsigned kOOB = 0x7ffffff0u;
+
+template <int CIN> struct Geo {
+  static constexpr int TAPS = CIN * 49, NT = (TAPS + 15) / 16;
+  static constexpr int CSW = kWR * kWC;                                  // window channel stride (dwords)
+  static constexpr int WSlots = CIN * kWR * (kWC / 4);
+  static constexpr int D_RUNS = (kDSlots + 63) / 64, W_RUNS = (WSlots + 63) / 64;
+  static constexpr int D_DW = D_RUNS * 256, W_DW = W_RUNS * 256;         // whole 1 KiB runs
+  static constexpr int BUF = D_DW + W_DW;
+  static constexpr int RPW_D = (D_RUNS + 3) / 4, RPW_W = (W_RUNS + 3) / 4;
+};
+
+struct Args {
+  const float* d; const float* b; float* slab;
+  int N, H, W, Ho, Wo, nyb, nsx, units, parts;
+};
+
+__device__ __forceinline__ void unit_decode(const Args& a, int u, int& n, int& y0, int& x0) {
+  const int sx = u % a.nsx; u /= a.nsx;
+  const int yb = u % a.nyb;
+  n = u / a.nyb; y0 = kR * yb; x0 = kXT * sx;
+}
+
+template <int CIN>
+__device__ __forceinline__ void stage_unit(const Args& a, int u, unsigned dst, int wave, int lane) {
+  using G = Geo<CIN>;
+  int n, y0, x0;
+  unit_decode(a, u, n, y0, x0);
+  const size_t planeD = (size_t)a.Ho * a.Wo, planeB = (size_t)a.H * a.W;
+  const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d + (size_t)n * kCout * planeD), 0,
+                                                                        (unsigned)(4u * kCout * planeD), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b + (size_t)n * CIN * planeB), 0,
+                                                                        (unsigned)(4u * CIN * planeB), 0x00020000);
+#pragma unroll
+  for (int i = 0; i < G::RPW_D; ++i) {
+    const int run = i * 4 + wave;
+    if (run < G::D_RUNS) {
+      const int s = run * 64 + lane, co = s / (kDS / 4), q = s % (kDS / 4);        // slot q of channel co: q = 8 r + x / 4, q == 16: padding
+      const int r = q >> 3, x = x0 + 4 * (q & 7);
+      const bool ok = s < kDSlots && q < 16 && y0 + r < a.Ho && x < a.Wo;
+      const unsigned voff = ok ? 4u * (unsigned)(co * planeD + (size_t)(y0 + r) * a.Wo + x) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, voff, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < G::RPW_W; ++i) {
+    const int run = i * 4 + wave;
+    if (run < G::W_RUNS) {
+      const int s = run * 64 + lane, ci = s / (kWR * (kWC / 4)), rem = s % (kWR * (kWC / 4));
+      const int row = rem / (kWC / 4), q = rem % (kWC / 4);
+      const int gy = 2 * y0 - 3 + row, gx = 2 * x0 - 4 + 4 * q;
+      const bool ok = s < G::WSlots && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const unsigned voff = ok ? 4u * (unsigned)(ci * planeB + (size_t)gy * a.W + gx) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(uintptr_t)(dst + 4u * G::D_DW + 1024u * (unsigned)run), 16, voff, 0, 0, 0);
+    }
+  }
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(256) stem_wgrad(Args a) {
+  using G = Geo<CIN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int part = blockIdx.x;
+  const int u0 = (int)((long long)part * a.units / a.parts), u1 = (int)((long long)(part + 1) * a.units / a.parts);
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+
+  // operand lane bases (LDS byte addresses within a buffer): A = top_diff, lane (channel m, pixel k); B = bottom, lane (tap n, pixel k)
+  const int m = lane & 15, k = lane >> 4;
+  const unsigned a_base = 4u * (unsigned)((16 * wave + m) * kDS + k);
+  unsigned b_base[G::NT];
+#pragma unroll
+  for (int nt = 0; nt < G::NT; ++nt) {
+    int t = 16 * nt + m;
+    if (t >= G::TAPS) t = G::TAPS - 1;                         // padding taps read any valid address; their columns are never stored
+    const int ci = t / 49, ky = (t % 49) / 7, kx = t % 7;
+    b_base[nt] = 4u * (unsigned)(G::D_DW + ci * G::CSW + ky * kWC + kx + 1 + 2 * k);
+  }
+  f32x4 acc[G::NT];
+#pragma unroll
+  for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (u0 < u1) stage_unit<CIN>(a, u0, lds_base, wave, lane);
+  for (int u = u0; u < u1; ++u) {
+    const int buf = (u - u0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of unit u has landed ...
+    __builtin_amdgcn_s_barrier();                             // ... and everybody's; everybody is done reading the other buffer
+    if (u + 1 < u1) stage_unit<CIN>(a, u + 1, lds_base + 4u * (unsigned)((buf ^ 1) * G::BUF), wave, lane);
+    const unsigned ab = lds_base + 4u * (unsigned)(buf * G::BUF) + a_base;
+    const unsigned bb = lds_base + 4u * (unsigned)(buf * G::BUF);
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+#pragma unroll
+      for (int xq = 0; xq < kXT / 4; ++xq) {
+        const float av = ((lds_vf)(uintptr_t)ab)[r * kXT + 4 * xq];
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt) {
+          const float bv = ((lds_vf)(uintptr_t)(bb + b_base[nt]))[2 * r * kWC + 8 * xq];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // slab[part][co][NT * 16]: lane (row block rb = lane >> 4, tap column lane & 15) holds rows 4 rb .. 4 rb + 3 of every tile
+  float* out = a.slab + (size_t)part * kCout * (G::NT * 16);
+#pragma unroll
+  for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(16 * wave + 4 * (lane >> 4) + r) * (G::NT * 16) + 16 * nt + (lane & 15)] = acc[nt][r];
+}
+
+// dw[co][t] (+)= ((part 0 + part 1) + part 2) + ...
+__global__ void stem_wgrad_finalize(const float* __restrict__ slab, float* __restrict__ dw, int taps, int ntw, int parts, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kCout * taps) return;
+  const int co = i / taps, t = i % taps;
+  const float* p = slab + (size_t)co * ntw + t;
+  const size_t stride = (size_t)kCout * ntw;
+  float s = p[0];
+  for (int k = 1; k < parts; ++k) s += p[(size_t)k * stride];
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+static bool geometry_ok(int N, int Cin, int H, int W, int Cout) {
+  return N > 0 && (Cin == 3 || Cin == 6 || Cin == 12) && Cout == kCout && H >= 1 && W >= 8 && W % 8 == 0 &&
+         (long long)N * Cin * H * W < (1ll << 28) && (long long)N * Cout * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) < (1ll << 28);
+}
+
+static void fill(Args& a, int N, int H, int W) {
+  a.N = N; a.H = H; a.W = W;
+  a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+  a.nyb = (a.Ho + kR - 1) / kR; a.nsx = (a.Wo + kXT - 1) / kXT;
+  a.units = N * a.nyb * a.nsx;
+  // parts: three workgroups per CU when there is that much work, at least 4 units each; a function of the geometry only
+  const int n1 = order_batch(N) * a.nyb * a.nsx;
+  int parts = 768;
+  if (parts > n1 / 4) parts = n1 / 4;
+  if (parts < 1) parts = 1;
+  a.parts = parts > a.units ? a.units : parts;
+}
+
+template <int CIN>
+static int launch(Args a, float* dw, int accumulate, hipStream_t st) {
+  using G = Geo<CIN>;
+  constexpr size_t lds = sizeof(float) * 2 * G::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((stem_wgrad<CIN>), dim3((unsigned)a.parts), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(stem_wgrad_finalize, dim3((kCout * G::TAPS + 255) / 256), dim3(256), 0, st, a.slab, dw, G::TAPS, G::NT * 16, a.parts, accumulate);
+  return check_launch("conv_k7s2_wgrad");
+}
+
+}  // namespace sw
+}  // namespace fn2
+
+using namespace fn2;
+
+FN2_API int fn2_conv_k7s2_wgrad_supported(int N, int Cin, int Hin, int Win, int Cout) {
+  return sw::geometry_ok(N, Cin, Hin, Win, Cout) ? 1 : 0;
+}
+
+FN2_API int fn2_conv_k7s2_wgrad_ksplit(int N, int Cin, int Hin, int Win, int Cout) {
+  if (!sw::geometry_ok(N, Cin, Hin, Win, Cout)) return 0;
+  sw::Args a{};
+  sw::fill(a, N, Hin, Win);
+  return a.parts;
+}
+
+FN2_API size_t fn2_conv_k7s2_wgrad_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout) {
+  if (!sw::geometry_ok(N, Cin, Hin, Win, Cout)) return 0;
+  sw::Args a{};
+  sw::fill(a, N, Hin, Win);
+  return sizeof(float) * (size_t)a.parts * sw::kCout * (((Cin * 49 + 15) / 16) * 16);
+}
+
+FN2_API int fn2_conv_k7s2_wgrad(const float* top_diff, const float* bottom, float* weight_diff, int N, int Cin, int Hin, int Win, int Cout,
+                                int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0) return fail(FN2_ERR_INVALID_ARG, "conv_k7s2_wgrad: bad batch");
+  if (!top_diff || !bottom || !weight_diff) return fail(FN2_ERR_INVALID_ARG, "conv_k7s2_wgrad: null blob");
+  if (N == 0) {
+    if (!accumulate) (void)hipMemsetAsync(weight_diff, 0, sizeof(float) * (size_t)Cout * Cin * 49, as_stream(stream));
+    return FN2_OK;
+  }
+  if (!sw::geometry_ok(N, Cin, Hin, Win, Cout))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_wgrad: needs Cin in {3,6,12}, Cout == 64, width %% 8 == 0 (got Cin %d, Cout %d, %dx%d)", Cin, Cout, Hin, Win);
+  if (((reinterpret_cast<uintptr_t>(top_diff) | reinterpret_cast<uintptr_t>(bottom)) & 15) != 0)
+    return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_wgrad: blobs must be 16-byte aligned");
+  const size_t need = fn2_conv_k7s2_wgrad_workspace_bytes(N, Cin, Hin, Win, Cout);
+  if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "conv_k7s2_wgrad: workspace of %zu bytes needed", need);
+  sw::Args a{};
+  sw::fill(a, N, Hin, Win);
+  a.d = top_diff; a.b = bottom; a.slab = static_cast<float*>(workspace);
+  hipStream_t st = as_stream(stream);
+  if (Cin == 3) return sw::launch<3>(a, weight_diff, accumulate, st);
+  if (Cin == 6) return sw::launch<6>(a, weight_diff, accumulate, st);
+  return sw::launch<12>(a, weight_diff, accumulate, st);
+}

@@ -448,6 +448,9 @@ def _own_bwd_weight(d, x, w, stride, pad, transposed):
     if os.environ.get("FN2_OWN_WGRAD", "1") == "0" or not d.is_cuda:
         return None
     k = w.shape[2]
+    if (not transposed and k == 7 and w.shape[3] == 7 and stride == 2 and pad == 3 and d.is_contiguous() and x.is_contiguous()
+            and ops.conv_k7s2_wgrad_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0])):
+        return ops.conv_k7s2_wgrad(d, x)             # the stem: taps, not bottom channels, on the GEMM's N axis (csrc/conv_stem_wgrad.hip)
     a, b = (x, d) if transposed else (d, x)          # `a`: the map at the convolution's OUTPUT resolution
     if w.shape[3] != k or min(a.shape[1], b.shape[1]) < 16:
         return None
@@ -492,23 +495,34 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
         if not (k == 4 and stride == 2 and pad == 1) or Cout % 4 != 0:
             return None
         Cp = (Cin + 63) // 64 * 64
-        if not ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
-            return None
 
         def make():
             wt = w.detach()
             if Cp != Cin:
                 wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 4, 4))], 0)
             return ops.conv_mfma_pack_weights(wt.contiguous())
-        gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 4, 2, 1, False, 0.0)
+        if ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
+            gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 4, 2, 1, False, 0.0)
+        elif Cout % 8 == 0 and ops.conv_plane_k_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
+            # small maps whose width is not a multiple of 4 (deconv5: top_diff 10x14 -> bottom_diff 5x7): the small-map kernel with 4x4 taps
+            gx = ops.conv_plane_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 2, 1, relu=False, kernel=4)
+        else:
+            return None
         return gx[:, :Cin] if Cp != Cin else gx
     Cout, Cin = w.shape[0], w.shape[1]
     if stride == 2 and (k, pad) in ((5, 2), (3, 1)) and x_shape is not None and Cin % 64 == 0:
         H, W = int(x_shape[2]), int(x_shape[3])
-        if not ops.tconv_supported(Cout, d.shape[2], d.shape[3], Cin, H, W, k, pad):
-            return None
-        pw = _cached_pack(_PACKED_T, w, "tconv", lambda: ops.tconv_pack_weights(w.detach()))
-        return ops.tconv_forward(d.contiguous(), pw, None, Cin, k, pad, out_hw=(H, W))
+        if ops.tconv_supported(Cout, d.shape[2], d.shape[3], Cin, H, W, k, pad):
+            pw = _cached_pack(_PACKED_T, w, "tconv", lambda: ops.tconv_pack_weights(w.detach()))
+            return ops.tconv_forward(d.contiguous(), pw, None, Cin, k, pad, out_hw=(H, W))
+        if k == 3 and (H, W) == (2 * d.shape[2], 2 * d.shape[3]) and ops.deconv_plane_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cin):
+            # small maps whose width is not a multiple of 4 (conv5, conv6: top_diff 10x14 / 5x7): the transposed 3x3 / 2 / 1 convolution IS the
+            # Deconvolution{4, 2, 1} whose fourth tap row and column are zero (Y = 2 y - 1 + ky in both) -- the small-map deconvolution kernel
+            # on the weight blob padded to 4x4 (16 taps computed for 9: these layers are 1-2 % of a training step)
+            pw = _cached_pack(_PACKED_T, w, "tconv-plane",
+                              lambda: ops.deconv_plane_pack_weights(torch.nn.functional.pad(w.detach(), (0, 1, 0, 1)).contiguous()))
+            return ops.deconv_plane_forward(d.contiguous(), pw, None, Cin, relu=False)
+        return None
     if k == 1 and stride == 1 and pad == 0:
         # 1x1 (conv_redir): bottom_diff = W^T x top_diff, the 1x1 / GEMM form of conv_mfma on the transposed weight
         Cp = (Cin + 31) // 32 * 32

@@ -385,6 +385,28 @@ def conv_k7s2_relu_supported(Cin, Hin, Win, Cout) -> bool:
     return bool(_lib.lib().fn2_conv_k7s2_relu_supported(int(Cin), int(Hin), int(Win), int(Cout)))
 
 
+def conv_k7s2_wgrad_supported(N, Cin, Hin, Win, Cout) -> bool:
+    return bool(_lib.lib().fn2_conv_k7s2_wgrad_supported(int(N), int(Cin), int(Hin), int(Win), int(Cout)))
+
+
+def conv_k7s2_wgrad_ksplit(N, Cin, Hin, Win, Cout) -> int:
+    return int(_lib.lib().fn2_conv_k7s2_wgrad_ksplit(int(N), int(Cin), int(Hin), int(Win), int(Cout)))
+
+
+def conv_k7s2_wgrad(top_diff, bottom):
+    """weight_diff [Cout, Cin, 7, 7] of the 7x7 / 2 / 3 stem convolution (csrc/conv_stem_wgrad.hip); top_diff [N, 64, Ho, Wo], bottom [N, Cin, H, W]."""
+    d, x = _chk(top_diff, "top.diff"), _chk(bottom, "bottom[0]")
+    N, Cin, H, W = x.shape
+    Cout = d.shape[1]
+    if tuple(d.shape) != (N, Cout, (H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        raise ValueError(f"conv_k7s2_wgrad: top_diff {tuple(d.shape)} does not belong to a bottom of {tuple(x.shape)}")
+    dw = torch.empty((Cout, Cin, 7, 7), device=x.device, dtype=torch.float32)
+    need = int(_lib.lib().fn2_conv_k7s2_wgrad_workspace_bytes(N, Cin, H, W, Cout))
+    ws = _plane_workspace(x.device, need) if need else None
+    check(_lib.lib().fn2_conv_k7s2_wgrad(_ptr(d), _ptr(x), _ptr(dw), N, Cin, H, W, Cout, 0, _ptr(ws), need, _stream()))
+    return dw
+
+
 def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
     """leaky_relu(Convolution{kernel 7, stride 2, pad 3}(x) + bias): conv1 + ReLU1 of the FlowNet encoders, one kernel."""
     x, w = _chk(x, "bottom[0]"), _chk(weight, "weight")
@@ -503,13 +525,21 @@ def _plane_workspace(device, need):
     return ws
 
 
-def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
-    """act(Convolution{3, stride, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] for small feature maps
-    (csrc/conv_plane.hip); packed_weight = conv_mfma_pack_weights(weight)."""
+def conv_plane_k_supported(N, Cin, Hin, Win, Cout, kernel, stride, pad) -> bool:
+    return bool(_lib.lib().fn2_conv_plane_k_supported(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad)))
+
+
+def conv_plane_k_ksplit(N, Cin, Hin, Win, Cout, kernel, stride, pad) -> int:
+    return int(_lib.lib().fn2_conv_plane_k_ksplit(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad)))
+
+
+def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None, kernel=3):
+    """act(Convolution{kernel, stride, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] for small feature maps
+    (csrc/conv_plane.hip); kernel 3, or 4 with stride 2 / pad 1; packed_weight = conv_mfma_pack_weights(weight)."""
     x = _chk(x, "bottom[0]")
     N, Ctot, H, W = x.shape
     Cin = Ctot - in_c0 if Cin is None else Cin
-    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    Ho, Wo = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
     if out is None:
         out = torch.empty((N, Cout, Ho, Wo), device=x.device, dtype=torch.float32)
     else:
@@ -518,11 +548,11 @@ def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, neg
             raise ValueError(f"conv_plane: top blob {tuple(out.shape)} does not match [{N},*,{Ho},{Wo}]")
     b = _chk(bias, "bias", ndim=1) if bias is not None else None
     pw = _chk(packed_weight, "packed weight", ndim=1)
-    need = int(_lib.lib().fn2_conv_plane_workspace_bytes(N, Cin, H, W, Cout, stride, pad))
+    need = int(_lib.lib().fn2_conv_plane_k_workspace_bytes(N, Cin, H, W, Cout, kernel, stride, pad))
     ws = _plane_workspace(x.device, need) if need else None
-    check(_lib.lib().fn2_conv_plane_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
-                                            stride, pad, int(bool(relu)), C.c_float(float(negative_slope)),
-                                            _ptr(ws if need else None), need, _stream()))
+    check(_lib.lib().fn2_conv_plane_k_forward(_ptr(x), _ptr(pw), _ptr(b), _ptr(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                              kernel, stride, pad, int(bool(relu)), C.c_float(float(negative_slope)),
+                                              _ptr(ws if need else None), need, _stream()))
     return out
 
 

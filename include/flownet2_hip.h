@@ -312,6 +312,17 @@ int fn2_bias_leaky_relu_backward_slices(const float* top_data, const float* top_
 int fn2_conv_k7s2_relu_supported(int Cin, int Hin, int Win, int Cout);
 int fn2_conv_k7s2_relu_forward(const float* bottom, const float* weight, const float* bias, float* top,
                                int N, int Cin, int Hin, int Win, int Cout, float negative_slope, void* stream);
+/* Weight gradient of the same stem (round 4; csrc/conv_stem_wgrad.hip) <- ConvolutionLayer::Backward_gpu -> weight_gpu_gemm,
+ * src/caffe/layers/conv_layer.cu:40-52, base_conv_layer.cpp:368-384 (per sample im2col + SGEMM(top_diff x col^T), beta = 1):
+ *   weight_diff[co][ci][ky][kx] (+)= sum_{n, y, x} top_diff[n][co][y][x] * bottom[n][ci][2 y + ky - 3][2 x + kx - 3]
+ * on the fp32 MFMA with the TAP axis as the GEMM's N axis (3 bottom channels would fill 3 / 16 of a channel tile), deterministic: the
+ * pixels are cut into fn2_conv_k7s2_wgrad_ksplit() parts whose partial sums (workspace) are added in part order.  Cin in {3, 6, 12},
+ * Cout == 64, width % 8 == 0, both blobs 16-byte aligned and contiguous.  accumulate != 0 adds into weight_diff like the reference. */
+int fn2_conv_k7s2_wgrad_supported(int N, int Cin, int Hin, int Win, int Cout);
+int fn2_conv_k7s2_wgrad_ksplit(int N, int Cin, int Hin, int Win, int Cout);
+size_t fn2_conv_k7s2_wgrad_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout);
+int fn2_conv_k7s2_wgrad(const float* top_diff, const float* bottom, float* weight_diff, int N, int Cin, int Hin, int Win, int Cout,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Direct convolution of the FlowNet encoders on the fp32 matrix cores, fused with its bias and (optionally) its ReLU:
@@ -377,6 +388,17 @@ int fn2_conv_plane_forward(const float* bottom, const float* packed_weight, cons
                            int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                            int Cout, int top_channels, int top_c0, int stride, int pad,
                            int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream);
+/* The same kernel with a `kernel` argument: 3 (as above) or 4 with stride 2 / pad 1 -- the DATA GRADIENT of a Deconvolution{4, 2, 1}
+ * on a small map (DeconvolutionLayer::Backward_gpu, deconv_layer.cu:52-56: forward_gpu_gemm of top_diff = the 4x4 / 2 / 1 CONVOLUTION of
+ * top_diff with the layer's weight blob [Cin_deconv = output channels here][Cout_deconv = input channels here][4][4], packed by
+ * fn2_conv_mfma_pack_weights); maps whose width is not a multiple of 4 included (deconv5 of FlowNetC: 10x14 -> 5x7). */
+int fn2_conv_plane_k_supported(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
+int fn2_conv_plane_k_ksplit(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
+size_t fn2_conv_plane_k_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
+int fn2_conv_plane_k_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                             int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                             int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
+                             int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream);
 int fn2_conv_plane_num_variants(void);
 int fn2_debug_set_plane_variant(int variant);    /* as fn2_debug_set_conv_variant (no split-tail forms) */
 int fn2_debug_set_plane_ksplit(int ksplit);      /* > 0: force the number of K parts (changes the summation order); 0: by geometry */

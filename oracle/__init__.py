@@ -278,18 +278,28 @@ def conv_mfma_forward(x, packed, bias, Cout, kernel, stride, pad, relu=True, neg
     return out
 
 
-def conv_plane_forward(x, packed, bias, Cout, stride, pad, ksplit, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
-    """CPU twin of fn2_conv_plane_forward (packed = conv_mfma_pack_weights(weight [Cout, Cin, 3, 3])); ksplit = fn2_conv_plane_ksplit()."""
+def conv_plane_forward(x, packed, bias, Cout, stride, pad, ksplit, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None, kernel=3):
+    """CPU twin of fn2_conv_plane_k_forward (packed = conv_mfma_pack_weights(weight [Cout, Cin, kernel, kernel])); ksplit = fn2_conv_plane_k_ksplit()."""
     x = _f32(x)
     N, Ctot, H, W = x.shape
     Cin = Ctot - in_c0 if Cin is None else Cin
-    Ho, Wo = (H + 2 * pad - 3) // stride + 1, (W + 2 * pad - 3) // stride + 1
+    Ho, Wo = (H + 2 * pad - kernel) // stride + 1, (W + 2 * pad - kernel) // stride + 1
     if out is None:
         out = np.zeros((N, Cout, Ho, Wo), np.float32)
     bias = _f32(bias) if bias is not None else None
-    _check(lib().fn2_conv_plane_forward_cpu(_p(x), _p(packed), _p(bias), _p(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
-                                            stride, pad, int(bool(relu)), C.c_float(negative_slope), int(ksplit)), "conv_plane_forward")
+    _check(lib().fn2_conv_plane_k_forward_cpu(_p(x), _p(packed), _p(bias), _p(out), N, Cin, H, W, Ctot, in_c0, Cout, out.shape[1], out_c0,
+                                              int(kernel), stride, pad, int(bool(relu)), C.c_float(negative_slope), int(ksplit)), "conv_plane_forward")
     return out
+
+
+def conv_k7s2_wgrad(top_diff, bottom, parts):
+    """CPU twin of fn2_conv_k7s2_wgrad: weight gradient [Cout, Cin, 7, 7] of the 7x7 / 2 / 3 stem; parts = fn2_conv_k7s2_wgrad_ksplit()."""
+    d, b = _f32(top_diff), _f32(bottom)
+    N, Cout = d.shape[:2]
+    Cin, H, W = b.shape[1:]
+    dw = np.zeros((Cout, Cin, 7, 7), np.float32)
+    _check(lib().fn2_conv_k7s2_wgrad_cpu(_p(d), _p(b), _p(dw), N, Cin, H, W, Cout, 0, int(parts)), "conv_k7s2_wgrad")
+    return dw
 
 
 def scale_shift_forward(x, scale, shift=None, out=None, out_c0=0):

@@ -1023,15 +1023,16 @@ FN2_API int fn2_conv_mfma_forward_cpu(const float* bottom, const float* packed, 
  * channel quads (channel quad, ky, kx, channel within the quad), then the parts added in part order, then bias and ReLU.  Part p
  * covers the 2-quad units [p U / ksplit, (p + 1) U / ksplit), U = ceil(quads / 2).
  * ksplit is what fn2_conv_plane_ksplit() reports for the layer (passed in: the oracle does not link the HIP library). */
-FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
-                                       int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
-                                       int Cout, int top_channels, int top_c0, int stride, int pad,
-                                       int relu, float negative_slope, int ksplit) {
+FN2_API int fn2_conv_plane_k_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
+                                         int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                         int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
+                                         int relu, float negative_slope, int ksplit) {
   if (N < 0 || Cin < 1 || Cin % 4 != 0 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 64 != 0 || stride < 1 || pad < 0 || ksplit < 1) return FN2_ERR_INVALID_ARG;
+  if (kernel != 3 && kernel != 4) return FN2_ERR_INVALID_ARG;
   if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
-  const int quads = Cin / 4, units = (quads + 1) / 2, kalloc = conv_mfma_ksteps(Cin, 3) + 8;
+  const int quads = Cin / 4, units = (quads + 1) / 2, kalloc = conv_mfma_ksteps(Cin, kernel) + 8;
   if (ksplit > units) return FN2_ERR_INVALID_ARG;
-  const int Ho = (Hin + 2 * pad - 3) / stride + 1, Wo = (Win + 2 * pad - 3) / stride + 1;
+  const int Ho = (Hin + 2 * pad - kernel) / stride + 1, Wo = (Win + 2 * pad - kernel) / stride + 1;
 #pragma omp parallel for collapse(2)
   for (int n = 0; n < N; ++n)
     for (int co = 0; co < Cout; ++co) {
@@ -1043,9 +1044,9 @@ FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed,
             float acc = 0.f;
             const int q0 = 2 * (int)((long long)part * units / ksplit), q1 = 2 * (int)((long long)(part + 1) * units / ksplit);
             for (int cq = q0; cq < q1; ++cq)
-              for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) {
-                  const int ks = (cq * 3 + ky) * 3 + kx;
+              for (int ky = 0; ky < kernel; ++ky)
+                for (int kx = 0; kx < kernel; ++kx) {
+                  const int ks = (cq * kernel + ky) * kernel + kx;
                   const int yi = stride * y - pad + ky, xi = stride * x - pad + kx;
                   for (int kq = 0; kq < 4; ++kq) {
                     float v = 0.f;
@@ -1060,6 +1061,52 @@ FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed,
           if (relu) t = t > 0.f ? t : t * negative_slope;
           top[(((size_t)n * top_channels + top_c0 + co) * Ho + y) * Wo + x] = t;
         }
+    }
+  return FN2_OK;
+}
+
+FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
+                                       int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                                       int Cout, int top_channels, int top_c0, int stride, int pad,
+                                       int relu, float negative_slope, int ksplit) {
+  return fn2_conv_plane_k_forward_cpu(bottom, packed, bias, top, N, Cin, Hin, Win, bottom_channels, bottom_c0, Cout, top_channels, top_c0,
+                                      3, stride, pad, relu, negative_slope, ksplit);
+}
+
+/* CPU twin of fn2_conv_k7s2_wgrad (csrc/conv_stem_wgrad.hip): weight gradient of the 7x7 / 2 / 3 stem convolution,
+ * ConvolutionLayer::Backward_gpu -> weight_gpu_gemm (conv_layer.cu:40-52, base_conv_layer.cpp:368-384), in the kernel's summation order:
+ * units (sample, pair of output rows, 32-pixel x segment) in order; part p covers units [p U / parts, (p + 1) U / parts) and is one fmaf
+ * chain over its pixels in (unit, row, x) order -- pixels beyond the map count as zeros, like the kernel's zero-filled tile --; the parts
+ * are added in part order.  parts = fn2_conv_k7s2_wgrad_ksplit() (passed in: the oracle does not link the HIP library). */
+FN2_API int fn2_conv_k7s2_wgrad_cpu(const float* top_diff, const float* bottom, float* weight_diff, int N, int Cin, int Hin, int Win, int Cout,
+                                    int accumulate, int parts) {
+  if (!top_diff || !bottom || !weight_diff || N < 1 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || parts < 1) return FN2_ERR_INVALID_ARG;
+  const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1, R = 2, XT = 32;
+  const int nyb = (Ho + R - 1) / R, nsx = (Wo + XT - 1) / XT, units = N * nyb * nsx, taps = Cin * 49;
+  if (parts > units) return FN2_ERR_INVALID_ARG;
+#pragma omp parallel for collapse(2)
+  for (int co = 0; co < Cout; ++co)
+    for (int t = 0; t < taps; ++t) {
+      const int ci = t / 49, ky = (t % 49) / 7, kx = t % 7;
+      float sum = 0.f;
+      for (int part = 0; part < parts; ++part) {
+        const int u0 = (int)((long long)part * units / parts), u1 = (int)((long long)(part + 1) * units / parts);
+        float acc = 0.f;
+        for (int u = u0; u < u1; ++u) {
+          const int sx = u % nsx, yb = (u / nsx) % nyb, n = u / (nsx * nyb);
+          for (int r = 0; r < R; ++r)
+            for (int xx = 0; xx < XT; ++xx) {
+              const int y = R * yb + r, x = XT * sx + xx;
+              const float d = (y < Ho && x < Wo) ? top_diff[(((size_t)n * Cout + co) * Ho + y) * Wo + x] : 0.f;
+              const int by = 2 * y - 3 + ky, bx = 2 * x - 3 + kx;
+              const float b = (by >= 0 && by < Hin && bx >= 0 && bx < Win) ? bottom[(((size_t)n * Cin + ci) * Hin + by) * Win + bx] : 0.f;
+              acc = fmaf(d, b, acc);
+            }
+        }
+        sum = part == 0 ? acc : sum + acc;
+      }
+      float* o = weight_diff + (size_t)co * taps + t;
+      *o = accumulate ? *o + sum : sum;
     }
   return FN2_OK;
 }

@@ -40,6 +40,55 @@ def test_oracle_plane_conv_matches_fp64_convolution(case):
     assert np.array_equal(oracle.conv_plane_forward(x, pw, b, Cout, s, p, 1), oracle.conv_mfma_forward(x, pw, b, Cout, 3, s, p))
 
 
+CASES_K4 = [  # N, Cin, H, W, Cout: Convolution{4, 2, 1} = the data gradient of a Deconvolution{4, 2, 1} (deconv5 of FlowNetC: 10x14 -> 5x7)
+    (3, 16, 10, 14, 64), (8, 8, 10, 14, 128), (2, 16, 12, 24, 64), (1, 8, 20, 28, 64), (5, 24, 6, 10, 64), (2, 8, 7, 9, 64)]
+
+
+@pytest.mark.parametrize("case", CASES_K4[:4])
+def test_oracle_plane_conv_k4s2_matches_fp64_convolution(case):
+    N, Cin, H, W, Cout = case
+    x, w, b = rnd((N, Cin, H, W), 21), rnd((Cout, Cin, 4, 4), 22, 0.2), rnd((Cout,), 23)
+    pw = oracle.conv_mfma_pack_weights(w)
+    for ksplit in (1, 2) if Cin >= 16 else (1,):
+        got = oracle.conv_plane_forward(x, pw, b, Cout, 2, 1, ksplit, False, 0.1, kernel=4)
+        want = torch64(x, w, b, 2, 1, False)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert np.array_equal(oracle.conv_plane_forward(x, pw, b, Cout, 2, 1, 1, kernel=4), oracle.conv_mfma_forward(x, pw, b, Cout, 4, 2, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES_K4)
+def test_hip_plane_conv_k4s2_equals_oracle_bitwise_in_every_variant(case):
+    from flownet2_amd import ops
+    N, Cin, H, W, Cout = case
+    x, w, b = rnd((N, Cin, H, W), 31), rnd((Cout, Cin, 4, 4), 32, 0.2), rnd((Cout,), 33)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    pw = ops.conv_mfma_pack_weights(dv(w))
+    pwh = pw.cpu().numpy()
+    assert ops.conv_plane_k_supported(N, Cin, H, W, Cout, 4, 2, 1) and not ops.conv_plane_k_supported(N, Cin, H, W, Cout, 4, 1, 1)
+    ran = 0
+    try:
+        for ksplit in (0, 1, 2):
+            ops.set_plane_ksplit(ksplit)
+            ks = ops.conv_plane_k_ksplit(N, Cin, H, W, Cout, 4, 2, 1)
+            want = oracle.conv_plane_forward(x, pwh, b, Cout, 2, 1, ks, True, 0.1, kernel=4)
+            for v in range(ops.plane_num_variants()):
+                ops.set_plane_variant(v)
+                try:
+                    got = ops.conv_plane_forward(dv(x), pw, dv(b), Cout, 2, 1, True, 0.1, kernel=4)
+                except flownet2_amd.Fn2Error:
+                    continue                              # a 3x3 / deconvolution variant, or the other DMA width
+                ran += 1
+                assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"variant {v}, ksplit {ks}"
+            ops.set_plane_variant(-1)
+            got = ops.conv_plane_forward(dv(x), pw, None, Cout, 2, 1, False, 0.1, kernel=4)
+            assert np.array_equal(got.cpu().numpy(), oracle.conv_plane_forward(x, pwh, None, Cout, 2, 1, ks, False, 0.1, kernel=4))
+    finally:
+        ops.set_plane_variant(-1)
+        ops.set_plane_ksplit(0)
+    assert ran >= 2
+
+
 def test_oracle_plane_conv_channel_slices():
     x, w, b = rnd((2, 20, 6, 9), 4), rnd((64, 8, 3, 3), 5, 0.2), rnd((64,), 6)
     pw = oracle.conv_mfma_pack_weights(w)

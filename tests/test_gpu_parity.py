@@ -1047,6 +1047,37 @@ def test_own_data_gradient_of_1x1_and_small_map_layers(case):
     assert float((gx.double() - ref).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("case", [((8, 512, 20, 28), (512, 512, 3, 3)), ((8, 512, 10, 14), (1024, 512, 3, 3)), ((2, 64, 20, 28), (128, 64, 3, 3))])
+def test_own_data_gradient_of_stride2_layers_on_small_maps(case):
+    """bottom_diff of conv5 / conv6 (3x3 / 2 / 1 on 20x28 and 10x14 bottoms: top_diff maps of 10x14 and 5x7, widths that are no multiple of
+    4) on the small-map deconvolution kernel with the weight blob zero-padded to 4x4, against fp64 autograd: <= 1e-5 * scale."""
+    from flownet2_amd import functional as Fn
+    xs, ws = case
+    w = dev(rand(ws, 350, 0.02))
+    d = dev(rand((xs[0], ws[0], xs[2] // 2, xs[3] // 2), 351))
+    assert not ops.tconv_supported(ws[0], d.shape[2], d.shape[3], ws[1], xs[2], xs[3], 3, 1)      # not the transposed-convolution kernel's: W % 4 != 0
+    gx = Fn._own_bwd_data(d, w, 2, 1, False, xs)
+    assert gx is not None and tuple(gx.shape) == xs
+    x64 = torch.zeros(xs, dtype=torch.float64, device="cuda", requires_grad=True)
+    (ref,) = torch.autograd.grad(torch.nn.functional.conv2d(x64, w.double(), None, stride=2, padding=1), x64, d.double())
+    assert float((gx.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", [((8, 1024, 5, 7), 512), ((2, 72, 5, 7), 64), ((3, 1026, 6, 10), 256)])
+def test_own_data_gradient_of_a_deconvolution_on_a_small_map(case):
+    """bottom_diff of deconv5 (Deconvolution{4, 2, 1}, 5x7 -> 10x14: deconv_layer.cu:52-56) = the 4x4 / 2 / 1 convolution of top_diff on the
+    small-map kernel (bottom channel counts that are no multiple of 64 are padded and cut), against fp64 autograd: <= 1e-5 * scale."""
+    from flownet2_amd import functional as Fn
+    xs, cout = case
+    w = dev(rand((xs[1], cout, 4, 4), 360, 0.02))
+    d = dev(rand((xs[0], cout, 2 * xs[2], 2 * xs[3]), 361))
+    gx = Fn._own_bwd_data(d, w, 2, 1, True, xs)
+    assert gx is not None and tuple(gx.shape) == xs
+    x64 = torch.zeros(xs, dtype=torch.float64, device="cuda", requires_grad=True)
+    (ref,) = torch.autograd.grad(torch.nn.functional.conv_transpose2d(x64, w.double(), None, stride=2, padding=1), x64, d.double())
+    assert float((gx.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [(2, 194, 24, 40), (1, 1026, 10, 14), (3, 37, 5, 7), (2, 16, 17, 23), (1, 20, 40, 300), (1, 18, 12, 1000)])
 def test_predict_flow_conv_backward(shape):
     """Own backward of predict_flow (Convolution{3,1,1} C -> 2): weight, bias and bottom gradients vs the double-accumulating oracle twin
