@@ -348,7 +348,7 @@ def _conv_mfma_pick(x, weight, stride, pad):
         # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
         if own or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
             return "wino"
-    if (k == 3 and (force or Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "1200"))) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
+    if (k == 3 and (force or Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "8000"))) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
             and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad) and (N == x.shape[0] or ops.conv_plane_supported(x.shape[0], Cin, H, W, Cout, stride, pad))):
         # the encoder layers from 1/16 resolution down (conv4 .. conv6_1): whole planes or row bands in LDS, pixels of several samples per MFMA
         # tile, split K.  Up to 1200 output pixels per sample it is level with or ahead of the im2col + GEMM route (bench A/B: 2.317 vs 2.324 ms)
@@ -363,7 +363,7 @@ def _conv_mfma_pick(x, weight, stride, pad):
     # 6.20 ms on the own kernels (scripts/probes/fn2_toggle_bench.sh; batch 4 at 768x384: 10.71 / 10.68, FlowNetC batch 8: 2.40 / 2.40).
     # FN2_CONV_SMALL=own keeps such layers on the own kernels (Winograd where it applies, else direct); batch-invariant mode always does.
     if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not own:
-        if os.environ.get("FN2_CONV_SMALL", "lib") == "lib":
+        if os.environ.get("FN2_CONV_SMALL", "own") == "lib":
             return None
         if k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad):
             return "wino"
@@ -674,6 +674,15 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     if _needs_grad(x, weight_t, bias, weight):
         if weight is None or not _train_fast_forward():
             return None
-        run = lambda xx, ww, bb: run_t(xx, ww.reshape(Cin, cout * kernel * kernel).t().contiguous(), bb)
+        def run(xx, ww, bb):
+            # ww is the parameter itself (autograd does not record inside _OwnForwardConv.forward): its transposed view and the packed
+            # operands are cached on it until the optimizer writes it.  Planes whose size is no multiple of 4 (deconv5: 5x7) are not the
+            # 1x1 / GEMM kernel's: the small-map deconvolution kernel computes them without a column matrix (and without a library GEMM)
+            if xx.is_cuda and (kernel, stride, pad) == (4, 2, 1) and (H * W) % 4 != 0 and os.environ.get("FN2_DECONV_PLANE", "auto") != "0" \
+                    and ops.deconv_plane_supported(N, Cin, H, W, cout):
+                blob, c0 = _channel_slice(xx)
+                return ops.deconv_plane_forward(blob, _packed_deconv_weight(ww), bb, cout, True, negative_slope, in_c0=c0, Cin=Cin)
+            wt = _cached_pack(_PACKED_T, ww, "deconv-wt", lambda: ww.detach().reshape(Cin, cout * kernel * kernel).t().contiguous())
+            return run_t(xx, wt, bb)
         return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, True)
     return run_t(x, weight_t, bias)

@@ -1077,7 +1077,8 @@ FN2_API int fn2_conv_plane_forward_cpu(const float* bottom, const float* packed,
  * ConvolutionLayer::Backward_gpu -> weight_gpu_gemm (conv_layer.cu:40-52, base_conv_layer.cpp:368-384), in the kernel's summation order:
  * units (sample, pair of output rows, 32-pixel x segment) in order; part p covers units [p U / parts, (p + 1) U / parts) and is one fmaf
  * chain over its pixels in (unit, row, x) order -- pixels beyond the map count as zeros, like the kernel's zero-filled tile --; the parts
- * are added in part order.  parts = fn2_conv_k7s2_wgrad_ksplit() (passed in: the oracle does not link the HIP library). */
+ * are added in 16 contiguous segments (part by part inside a segment, then the segment sums in order: stem_wgrad_finalize).
+ * parts = fn2_conv_k7s2_wgrad_ksplit() (passed in: the oracle does not link the HIP library). */
 FN2_API int fn2_conv_k7s2_wgrad_cpu(const float* top_diff, const float* bottom, float* weight_diff, int N, int Cin, int Hin, int Win, int Cout,
                                     int accumulate, int parts) {
   if (!top_diff || !bottom || !weight_diff || N < 1 || Cin < 1 || Hin < 1 || Win < 1 || Cout < 1 || parts < 1) return FN2_ERR_INVALID_ARG;
@@ -1089,21 +1090,29 @@ FN2_API int fn2_conv_k7s2_wgrad_cpu(const float* top_diff, const float* bottom, 
     for (int t = 0; t < taps; ++t) {
       const int ci = t / 49, ky = (t % 49) / 7, kx = t % 7;
       float sum = 0.f;
-      for (int part = 0; part < parts; ++part) {
-        const int u0 = (int)((long long)part * units / parts), u1 = (int)((long long)(part + 1) * units / parts);
-        float acc = 0.f;
-        for (int u = u0; u < u1; ++u) {
-          const int sx = u % nsx, yb = (u / nsx) % nyb, n = u / (nsx * nyb);
-          for (int r = 0; r < R; ++r)
-            for (int xx = 0; xx < XT; ++xx) {
-              const int y = R * yb + r, x = XT * sx + xx;
-              const float d = (y < Ho && x < Wo) ? top_diff[(((size_t)n * Cout + co) * Ho + y) * Wo + x] : 0.f;
-              const int by = 2 * y - 3 + ky, bx = 2 * x - 3 + kx;
-              const float b = (by >= 0 && by < Hin && bx >= 0 && bx < Win) ? bottom[(((size_t)n * Cin + ci) * Hin + by) * Win + bx] : 0.f;
-              acc = fmaf(d, b, acc);
-            }
+      int first_seg = 1;
+      for (int seg = 0; seg < 16; ++seg) {            /* 16 contiguous segments of parts: part by part inside, then the segment sums in order */
+        const int p0 = (int)((long long)seg * parts / 16), p1 = (int)((long long)(seg + 1) * parts / 16);
+        if (p0 >= p1) continue;
+        float ssum = 0.f;
+        for (int part = p0; part < p1; ++part) {
+          const int u0 = (int)((long long)part * units / parts), u1 = (int)((long long)(part + 1) * units / parts);
+          float acc = 0.f;
+          for (int u = u0; u < u1; ++u) {
+            const int sx = u % nsx, yb = (u / nsx) % nyb, n = u / (nsx * nyb);
+            for (int r = 0; r < R; ++r)
+              for (int xx = 0; xx < XT; ++xx) {
+                const int y = R * yb + r, x = XT * sx + xx;
+                const float d = (y < Ho && x < Wo) ? top_diff[(((size_t)n * Cout + co) * Ho + y) * Wo + x] : 0.f;
+                const int by = 2 * y - 3 + ky, bx = 2 * x - 3 + kx;
+                const float b = (by >= 0 && by < Hin && bx >= 0 && bx < Win) ? bottom[(((size_t)n * Cin + ci) * Hin + by) * Win + bx] : 0.f;
+                acc = fmaf(d, b, acc);
+              }
+          }
+          ssum = part == p0 ? acc : ssum + acc;
         }
-        sum = part == 0 ? acc : sum + acc;
+        sum = first_seg ? ssum : sum + ssum;
+        first_seg = 0;
       }
       float* o = weight_diff + (size_t)co * taps + t;
       *o = accumulate ? *o + sum : sum;

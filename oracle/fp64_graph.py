@@ -96,10 +96,65 @@ def backend64():
     return be
 
 
-def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43):
+class record_relu_branches:
+    """Context manager around a forward pass of nets.flownet_c_core in ANY backend: records, in execution order, which side of the kink
+    every leaky-ReLU output of the graph is on (the activated outputs of nets._conv / nets._deconv with act = True, and the plain
+    F.leaky_relu calls of the graph itself: the correlation's ReLU).  `branches` is the list flownetc_train_reference(masks=...) takes.
+
+    Why: a leaky ReLU is piecewise linear.  An fp32 and an fp64 evaluation of the same net disagree about the SIGN of the few
+    pre-activations that are within rounding of zero (about one in 10^6: a handful among the 5 M outputs of conv3_1 at batch 8), and each
+    such unit changes its whole upstream gradient by a factor of ten -- 10^-3 in the relative L2 of a layer's gradient, whatever the
+    kernels' accuracy (measured in round 4: the library's fp32 kernels sit at 1.3e-3 from the plain fp64 graph on conv1's weights).
+    Evaluating the fp64 comparator on the branch the fp32 run took removes that term: what is left is rounding."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        from flownet2_amd import nets
+        self.branches = []
+        self._oc, self._od, self._lr = nets._conv, nets._deconv, F.leaky_relu
+        depth = [0]
+
+        def conv(x, P, name, stride, pad, act=True, backend=None):
+            depth[0] += 1
+            try:
+                y = self._oc(x, P, name, stride, pad, act, backend)
+            finally:
+                depth[0] -= 1
+            if act:
+                self.branches.append((name, (y.detach() > 0).cpu()))
+            return y
+
+        def deconv(x, P, name, act=True, backend=None):
+            depth[0] += 1
+            try:
+                y = self._od(x, P, name, act, backend)
+            finally:
+                depth[0] -= 1
+            if act:
+                self.branches.append((name, (y.detach() > 0).cpu()))
+            return y
+
+        def leaky_relu(x, negative_slope=0.01, inplace=False):
+            if depth[0] == 0:                                   # a ReLU of the graph itself (not one inside a convolution's fallback path)
+                self.branches.append(("relu", (x.detach() > 0).cpu()))
+            return self._lr(x, negative_slope, inplace)
+        nets._conv, nets._deconv, F.leaky_relu = conv, deconv, leaky_relu
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        from flownet2_amd import nets
+        nets._conv, nets._deconv, F.leaky_relu = self._oc, self._od, self._lr
+        return False
+
+
+def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43, masks=None):
     """loss (float) and {parameter name: float64 gradient on the CPU} of one FlowNetC training step exactly as bench.py --mode train
     states it: pre-processing im / 255 - mean, nets.flownet_c_core, nets.multiscale_loss against `gt` (NaN = no ground truth).
-    P: {name: fp32 tensor}; img0 / img1: raw [N, 3, H, W]; gt: [N, 2, H, W]."""
+    P: {name: fp32 tensor}; img0 / img1: raw [N, 3, H, W]; gt: [N, 2, H, W].
+    masks = record_relu_branches(...).branches of another run: every leaky ReLU takes the branch recorded there instead of the sign of
+    its own input (y = x * (1 | slope) by the recorded mask): the fp64 value and gradient of the piecewise-linear function that run evaluated."""
+    import torch.nn.functional as F
     from flownet2_amd import nets
     dev = torch.device(device) if device is not None else img0.device
     P64 = {k: v.detach().to(device=dev, dtype=torch.float64).requires_grad_(True) for k, v in P.items()}
@@ -107,7 +162,19 @@ def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43):
     g = gt.detach().to(device=dev, dtype=torch.float64)
     be = backend64()
     pre = [(im * (1.0 / 255.0)) - mean for im in (i0, i1)]
-    loss = nets.multiscale_loss(nets.flownet_c_core(P64, pre[0], pre[1], be), g, be)
+    lr, todo = F.leaky_relu, list(masks) if masks is not None else None
+
+    def pinned(x, negative_slope=0.01, inplace=False):
+        name, m = todo.pop(0)
+        assert tuple(m.shape) == tuple(x.shape), (name, tuple(m.shape), tuple(x.shape))
+        return x * torch.where(m.to(x.device), 1.0, float(negative_slope)).to(x.dtype)
+    if todo is not None:
+        F.leaky_relu = pinned
+    try:
+        loss = nets.multiscale_loss(nets.flownet_c_core(P64, pre[0], pre[1], be), g, be)
+    finally:
+        F.leaky_relu = lr
+    assert not todo, "recorded ReLU branches left over: the two graphs differ"
     loss.backward()
     return float(loss.detach()), {k: v.grad.detach().cpu() for k, v in P64.items() if v.grad is not None}
 

@@ -25,11 +25,14 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTI
 # calibration of FETCH_SIZE / WRITE_SIZE on streaming kernels of known byte count (dword per lane, like the staging loads)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/cal_fetch -o cal -- python scripts/hbm_calibrate.py > $R/cal_stdout.txt 2>/dev/null
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/cal_write -o cal -- python scripts/hbm_calibrate.py > /dev/null 2>&1
-# custom-layer micro-benchmarks (own kernel trace), their host baselines, and the training input pipeline
+# custom-layer micro-benchmarks (own kernel trace), their host baselines, and the training input pipeline (FN2_PROFILE_LIGHT=1 skips them
+# and the per-family counter passes at the end: a round that did not touch those kernels keeps the previous round's files)
+if [ "${FN2_PROFILE_LIGHT:-0}" != "1" ]; then
 python scripts/layer_microbench.py > gpurun_out/layer_microbench.txt 2>/dev/null
 python tests/cpu_baselines.py >> gpurun_out/layer_microbench.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/layers -o lay -- python scripts/layer_microbench.py > /dev/null 2>&1
 timeout 300 python scripts/train_pipeline.py --iters 8 2>/dev/null | tail -11 > gpurun_out/train_pipeline.txt
+fi
 python bench.py > $R/bench.json 2> $R/bench.err
 # the other configurations of BASELINE.json (FlowNet2 at 768x384 batch 4 and 1024x448 batch 1, FlowNetC training step) and the
 # per-variant convolution timings
@@ -42,12 +45,21 @@ timeout 300 python scripts/conv_bench.py --net C --layers conv4,conv5,conv5_1,co
 timeout 300 python scripts/deconv_bench.py --net C > $R/deconv_bench_C.txt 2>&1
 # kernel table of the FlowNet2 step (768x384, batch 4)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench2 -o bench2 -- python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench2b1 -o bench2b1 -- python bench.py --net 2 --batch 1 --height 448 --width 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+f=$(find $R/bench2b1 -name "*_kernel_stats.csv" | head -1); [ -n "$f" ] && python scripts/nonfn2_kernels.py $f > $R/bench2b1_nonfn2.txt 2>&1
 # matrix-pipe counters of the convolution kernels alone (a counter pass of its own)
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_conv -o conv -- env FN2_AUTOTUNE=0 python scripts/conv_bench.py --net C --layers conv2,conv3_1 --iters 3 > /dev/null 2>&1
 # round 3: kernel table of the FlowNetC TRAINING step, the weight-gradient / transposed-convolution micro-benchmarks, SQ counters of the weight-gradient kernel
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/train -o t -- python bench.py --mode train --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $R/train_profiled.json 2>/dev/null
 python scripts/summarize_train_trace.py $R/train/t_kernel_stats.csv > $R/train_kernels.txt 2>&1
+if [ "${FN2_PROFILE_LIGHT:-0}" != "1" ]; then
 timeout 300 python scripts/wgrad_bench.py > $R/wgrad_bench.txt 2>&1
 timeout 300 python scripts/tconv_bench.py > $R/tconv_bench.txt 2>&1
 bash scripts/wgrad_pmc.sh $TAG/wgrad_pmc conv2,conv3_1 > $R/wgrad_counters.txt 2>&1
+fi
+# library-dispatch audit: the kernels of each traced configuration that are not fn2:: ones
+for t in bench bench2 train; do
+  f=$(find $R/$t -name "*_kernel_stats.csv" | head -1)
+  [ -n "$f" ] && python scripts/nonfn2_kernels.py $f > $R/${t}_nonfn2.txt 2>&1
+done
 tail -c 300 $R/bench.json

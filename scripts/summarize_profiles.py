@@ -150,6 +150,10 @@ for src, dst in (("conv_plane_bench_C.txt", "conv_plane_bench_flownetc.txt"), ("
                  ("wgrad_counters.txt", "wgrad_counters.txt")):
     if os.path.exists(os.path.join(R, src)):
         shutil.copyfile(os.path.join(R, src), os.path.join(OUT, f"{tag}_{dst}"))
+for src, dst in (("bench_nonfn2.txt", "nonfn2_flownetc_fwd.txt"), ("bench2_nonfn2.txt", "nonfn2_flownet2_b4.txt"), ("bench2b1_nonfn2.txt", "nonfn2_flownet2_b1.txt"),
+                 ("train_nonfn2.txt", "nonfn2_train.txt")):
+    if os.path.exists(os.path.join(R, src)):
+        shutil.copyfile(os.path.join(R, src), os.path.join(OUT, f"{tag}_{dst}"))
 k2 = os.path.join(R, "bench2", "bench2_kernel_stats.csv")
 if os.path.exists(k2):
     rows2 = kernel_stats(k2)

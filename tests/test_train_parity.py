@@ -56,23 +56,35 @@ def test_fp64_graph_is_pinned_by_the_oracle_restatements():
     P32 = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     be = _cpu_train_backend()
     pre = [(im * (1.0 / 255.0)) - 0.43 for im in (a, b)]
-    loss32 = nets.multiscale_loss(nets.flownet_c_core(P32, pre[0], pre[1], be), gt, be)
+    with fp64_graph.record_relu_branches() as rec:
+        loss32 = nets.multiscale_loss(nets.flownet_c_core(P32, pre[0], pre[1], be), gt, be)
     loss32.backward()
     assert abs(float(loss32.detach()) - loss64) <= 2e-6 * max(1.0, abs(loss64))
     agree = fp64_graph.grad_agreement({k: v.grad for k, v in P32.items()}, g64)
     assert set(g64) == set(P) and agree["all"] <= 2e-5 and agree["worst"] <= 2e-4, (agree["all"], agree["worst_name"], agree["worst"])
+    # the same on the piecewise-linear branch the fp32 run took (16 leaky ReLUs, recorded in execution order): rounding only
+    assert [n for n, _ in rec.branches] == ["conv1", "conv2", "conv3", "conv_redir", "relu", "conv3_1", "conv4", "conv4_1", "conv5", "conv5_1",
+                                            "conv6", "conv6_1", "deconv5", "deconv4", "deconv3", "deconv2"]
+    loss_p, g_p = fp64_graph.flownetc_train_reference(P, a, b, gt, device="cpu", masks=rec.branches)
+    pinned = fp64_graph.grad_agreement({k: v.grad for k, v in P32.items()}, g_p)
+    assert abs(float(loss32.detach()) - loss_p) <= 2e-6 * max(1.0, abs(loss_p))
+    assert pinned["all"] <= min(1e-5, agree["all"] * 1.01) and pinned["worst"] <= 5e-5, (pinned["all"], agree["all"], pinned["worst_name"], pinned["worst"])
 
 
 @pytest.mark.gpu
 def test_flownetc_training_step_at_config4_size_matches_fp64():
-    """Batch 8 @448x320, production routing (what `bench.py --mode train` executes): loss within 1e-5 relative, every one of the 48
-    parameter gradients within 1e-4 in relative L2 of the fp64 comparator."""
+    """Batch 8 @448x320, production routing (what `bench.py --mode train` executes) against the fp64 comparator.
+    (1) On the piecewise-linear branch the fp32 run took (oracle/fp64_graph.record_relu_branches: the same sign for every leaky ReLU):
+        loss within 1e-5 relative, EVERY one of the 48 parameter gradients within 1e-4 in relative L2, all 39 M values together within 3e-5.
+    (2) Against the plain fp64 graph (its own ReLU signs) the few units whose pre-activation is within rounding of zero dominate: reported
+        next to the same figure for the library's fp32 kernels (MIOpen / rocBLAS through torch), bounded by 2e-3 per parameter and by twice the
+        library's error over all values.
+    (3) No gradient of the step is computed by a library kernel."""
     from flownet2_amd import functional as Fn, nets
     dev = torch.device("cuda:0")
     P = nets.init_params("C", seed=0)
     a, b, gt = _batch(8, 320, 448, 4)
     Pd = {k: v.to(dev).requires_grad_(True) for k, v in P.items()}
-    routes = []
 
     def run():
         for v in Pd.values():
@@ -87,19 +99,57 @@ def test_flownetc_training_step_at_config4_size_matches_fp64():
     try:
         import contextlib, io
         buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
+        with contextlib.redirect_stdout(buf), fp64_graph.record_relu_branches() as rec:
             loss = run()
         routes = [l for l in buf.getvalue().splitlines() if l.startswith("bwd on the library")]
     finally:
         os.environ.pop("FN2_TRACE_BWD", None)
     grads = {k: v.grad.detach().clone() for k, v in Pd.items()}
+    assert len(rec.branches) == 16 and [n for n, _ in rec.branches][:6] == ["conv1", "conv2", "conv3", "conv_redir", "relu", "conv3_1"]
+    loss_p, g_p = fp64_graph.flownetc_train_reference(P, a, b, gt, device=dev, masks=rec.branches)
     loss64, g64 = fp64_graph.flownetc_train_reference(P, a, b, gt, device=dev)
-    assert set(grads) == set(g64) and len(g64) == len(P)
-    assert abs(loss - loss64) <= 1e-5 * max(1.0, abs(loss64)), (loss, loss64)
-    agree = fp64_graph.grad_agreement(grads, g64)
-    bad = {k: v for k, v in agree["per_param"].items() if v > 1e-4}
-    print("config-4 gradient agreement vs fp64: all %.2e, median %.2e, worst %s %.2e; library backward calls: %d" %
-          (agree["all"], agree["median"], agree["worst_name"], agree["worst"], len(routes)))
+    assert set(grads) == set(g64) == set(g_p) and len(g64) == len(P)
+    pinned, plain = fp64_graph.grad_agreement(grads, g_p), fp64_graph.grad_agreement(grads, g64)
+    # the yardstick for the plain comparison: the SAME graph with every convolution, deconvolution, activation and their gradients done by the
+    # library in fp32 (FN2_CONV_MFMA=none ... and the stock bias / leaky-ReLU ops), against both comparators
+    keep, keep_env = Fn.conv_bias_leaky_relu, {k: os.environ.get(k) for k in ("FN2_CONV_MFMA", "FN2_OWN_WGRAD", "FN2_OWN_DGRAD", "FN2_OWN_HEAD_BWD", "FN2_CONV_MFMA_TRAIN")}
+    Fn.conv_bias_leaky_relu = lambda y, bb, s=0.1: torch.nn.functional.leaky_relu(y + bb.view(1, -1, 1, 1), s)
+    os.environ.update(FN2_CONV_MFMA="none", FN2_OWN_WGRAD="0", FN2_OWN_DGRAD="0", FN2_OWN_HEAD_BWD="0", FN2_CONV_MFMA_TRAIN="0")
+    try:
+        with fp64_graph.record_relu_branches() as rec_lib:
+            run()
+        g_lib = {k: v.grad.detach().clone() for k, v in Pd.items()}
+    finally:
+        Fn.conv_bias_leaky_relu = keep
+        for k, v in keep_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    lib_plain = fp64_graph.grad_agreement(g_lib, g64)
+    lib_pinned = fp64_graph.grad_agreement(g_lib, fp64_graph.flownetc_train_reference(P, a, b, gt, device=dev, masks=rec_lib.branches)[1])
+    flips = sum(int((m0 != m1).sum()) for (_, m0), (_, m1) in zip(rec.branches, rec_lib.branches))
+    lines = ["relative L2 error of the parameter gradients, FlowNetC training step, batch 8 @448x320 (tests/test_train_parity.py)",
+             "parameter                     own | same-branch fp64   own | plain fp64   library fp32 | same-branch   library fp32 | plain"]
+    for k in sorted(pinned["per_param"], key=lambda q: -pinned["per_param"][q]):
+        lines.append("%-28s  %.2e               %.2e         %.2e                   %.2e" %
+                     (k, pinned["per_param"][k], plain["per_param"][k], lib_pinned["per_param"][k], lib_plain["per_param"][k]))
+    lines.append("all parameters together       %.2e               %.2e         %.2e                   %.2e" % (pinned["all"], plain["all"], lib_pinned["all"], lib_plain["all"]))
+    lines.append("median parameter              %.2e               %.2e         %.2e                   %.2e" % (pinned["median"], plain["median"], lib_pinned["median"], lib_plain["median"]))
+    lines.append("loss: own %.9g, same-branch fp64 %.9g, plain fp64 %.9g; ReLU units on different sides in the own and the library run: %d of %d; "
+                 "library backward calls of the own path: %d" % (loss, loss_p, loss64, flips, sum(m.numel() for _, m in rec.branches), len(routes)))
+    report = "\n".join(lines)
+    print(report)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "train_parity_config4.txt"), "w").write(report + "\n")
+    # (1) rounding only
+    assert abs(loss - loss_p) <= 1e-5 * max(1.0, abs(loss_p)), (loss, loss_p)
+    bad = {k: v for k, v in pinned["per_param"].items() if v > 1e-4}
     assert not bad, bad
-    assert agree["all"] <= 3e-5
-    assert not routes, routes                              # row a12: no convolution gradient of the step is handed to MIOpen / rocBLAS
+    assert pinned["all"] <= 3e-5 and pinned["median"] <= 2e-5, (pinned["all"], pinned["median"])
+    # (2) the plain fp64 graph
+    assert abs(loss - loss64) <= 1e-5 * max(1.0, abs(loss64)), (loss, loss64)
+    assert plain["worst"] <= 2e-3 and plain["all"] <= 2.0 * lib_plain["all"] + 1e-5, (plain["worst_name"], plain["worst"], plain["all"], lib_plain["all"])
+    # (3) row a12
+    assert not routes, routes
