@@ -75,7 +75,8 @@ def test_fp64_graph_is_pinned_by_the_oracle_restatements():
 def test_flownetc_training_step_at_config4_size_matches_fp64():
     """Batch 8 @448x320, production routing (what `bench.py --mode train` executes) against the fp64 comparator.
     (1) On the piecewise-linear branch the fp32 run took (oracle/fp64_graph.record_relu_branches: the same sign for every leaky ReLU):
-        loss within 1e-5 relative, EVERY one of the 48 parameter gradients within 1e-4 in relative L2, all 39 M values together within 3e-5.
+        loss within 1e-6 relative, EVERY one of the 48 parameter gradients within 1e-5 in relative L2 (measured: worst 2.1e-6, conv1's
+        weights -- the library's fp32 kernels: 2.1e-6), all 39 M values together within 3e-6 (measured 7.2e-7; library 7.4e-7).
     (2) Against the plain fp64 graph (its own ReLU signs) the few units whose pre-activation is within rounding of zero dominate: reported
         next to the same figure for the library's fp32 kernels (MIOpen / rocBLAS through torch), bounded by 2e-3 per parameter and by twice the
         library's error over all values.
@@ -144,10 +145,10 @@ def test_flownetc_training_step_at_config4_size_matches_fp64():
     if os.path.isdir(out):
         open(os.path.join(out, "train_parity_config4.txt"), "w").write(report + "\n")
     # (1) rounding only
-    assert abs(loss - loss_p) <= 1e-5 * max(1.0, abs(loss_p)), (loss, loss_p)
-    bad = {k: v for k, v in pinned["per_param"].items() if v > 1e-4}
+    assert abs(loss - loss_p) <= 1e-6 * max(1.0, abs(loss_p)), (loss, loss_p)
+    bad = {k: v for k, v in pinned["per_param"].items() if v > 1e-5}
     assert not bad, bad
-    assert pinned["all"] <= 3e-5 and pinned["median"] <= 2e-5, (pinned["all"], pinned["median"])
+    assert pinned["all"] <= 3e-6 and pinned["median"] <= 3e-6, (pinned["all"], pinned["median"])
     # (2) the plain fp64 graph
     assert abs(loss - loss64) <= 1e-5 * max(1.0, abs(loss64)), (loss, loss64)
     assert plain["worst"] <= 2e-3 and plain["all"] <= 2.0 * lib_plain["all"] + 1e-5, (plain["worst_name"], plain["worst"], plain["all"], lib_plain["all"])
