@@ -1,17 +1,17 @@
-"""Per-step kernel table of a traced training run (rocprofv3 --kernel-trace --stats): steps are counted by the calls of the Adam
-multi-tensor kernel group / the correlation forward kernel."""
+"""Per-step kernel table of a traced training run (rocprofv3 --kernel-trace --stats): steps are counted by the calls of the
+stem kernels (one launch per step)."""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
+# steps = calls of a kernel that runs exactly once per training step: the stem's weight gradient (round 4), else the stem's forward kernel
 steps = None
-for r in rows:
-    if "corr_fwd_pair" in r["Name"]:
-        steps = int(r["Calls"])
+for pat in ("stem_wgrad", "conv_k7s2_relu<3"):
+    hit = [int(r["Calls"]) for r in rows if pat in r["Name"]]
+    if hit:
+        steps = max(hit)
+        break
 steps = steps or 1
-# the correlation micro-benchmark of bench.py launches the forward kernel (10 + 200 + 8) more times
-if steps > 218:
-    steps -= 218
 tot = sum(float(r["TotalDurationNs"]) for r in rows if "corr_fwd_pair" not in r["Name"])
 cats = {}
 
