@@ -138,13 +138,25 @@ class record_relu_branches:
             if depth[0] == 0:                                   # a ReLU of the graph itself (not one inside a convolution's fallback path)
                 self.branches.append(("relu", (x.detach() > 0).cpu()))
             return self._lr(x, negative_slope, inplace)
+        from flownet2_amd import functional as Fn
+        self._cri = Fn.correlation_relu_into
+
+        def correlation_relu_into(b0, b1, out, out_c0, negative_slope, **kw):
+            r = self._cri(b0, b1, out, out_c0, negative_slope, **kw)
+            if r is not None:                                   # inference-style fused route (frozen towers): the activated planes sit in the blob
+                nch = (2 * (kw.get("max_displacement", 0) // kw.get("stride_2", 1)) + 1) ** 2
+                self.branches.append(("relu", (out[:, out_c0:out_c0 + nch].detach() > 0).cpu()))
+            return r
+        Fn.correlation_relu_into = correlation_relu_into
         nets._conv, nets._deconv, F.leaky_relu = conv, deconv, leaky_relu
         return self
 
     def __exit__(self, *exc):
         import torch.nn.functional as F
         from flownet2_amd import nets
+        from flownet2_amd import functional as Fn
         nets._conv, nets._deconv, F.leaky_relu = self._oc, self._od, self._lr
+        Fn.correlation_relu_into = self._cri
         return False
 
 
@@ -162,18 +174,32 @@ def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43, masks=No
     g = gt.detach().to(device=dev, dtype=torch.float64)
     be = backend64()
     pre = [(im * (1.0 / 255.0)) - mean for im in (i0, i1)]
-    lr, todo = F.leaky_relu, list(masks) if masks is not None else None
+    lr, oc, od = F.leaky_relu, nets._conv, nets._deconv
+    todo = dict(masks) if masks is not None else None          # by layer name ("relu": the correlation's): the two runs may order them differently
+    if masks is not None:
+        assert len(todo) == len(masks), "a layer name occurs twice among the recorded branches"
+    current = [None]
+
+    def named(fn):
+        def wrapped(x, P_, name, *a, **k):
+            prev, current[0] = current[0], name
+            try:
+                return fn(x, P_, name, *a, **k)
+            finally:
+                current[0] = prev
+        return wrapped
 
     def pinned(x, negative_slope=0.01, inplace=False):
-        name, m = todo.pop(0)
+        name = current[0] or "relu"
+        m = todo.pop(name)
         assert tuple(m.shape) == tuple(x.shape), (name, tuple(m.shape), tuple(x.shape))
         return x * torch.where(m.to(x.device), 1.0, float(negative_slope)).to(x.dtype)
     if todo is not None:
-        F.leaky_relu = pinned
+        F.leaky_relu, nets._conv, nets._deconv = pinned, named(oc), named(od)
     try:
         loss = nets.multiscale_loss(nets.flownet_c_core(P64, pre[0], pre[1], be), g, be)
     finally:
-        F.leaky_relu = lr
+        F.leaky_relu, nets._conv, nets._deconv = lr, oc, od
     assert not todo, "recorded ReLU branches left over: the two graphs differ"
     loss.backward()
     return float(loss.detach()), {k: v.grad.detach().cpu() for k, v in P64.items() if v.grad is not None}

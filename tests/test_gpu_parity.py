@@ -797,68 +797,51 @@ def test_own_winograd_data_gradient_matches_autograd(case):
 
 
 def test_training_gradients_fused_path_matches_stock_ops():
-    """One FlowNetC training loss (multi-scale L1, NaN ground truth) differentiated twice: with the fused bias + leaky ReLU
-    autograd function, and with the stock torch ops in its place.  Every parameter gradient must agree."""
+    """One small FlowNetC training loss (1 x 128 x 192, multi-scale L1, NaN ground truth) with the own kernels FORCED at this size (Winograd,
+    small-map, direct, weight / data gradients, fused bias + ReLU backward), against the fp64 comparator on the run's own ReLU branch
+    (oracle/fp64_graph.py; the batch-8 @448x320 form with production routing is tests/test_train_parity.py): every parameter gradient within
+    1e-5 in relative L2.  Round 3 compared own vs library kernels here and needed 5e-2 on the worst parameter: what it saw were the few ReLU
+    units that two fp32 runs put on different sides of zero, not kernel error.  Second half: a partially frozen net (encoder frozen,
+    refinement trainable, grad mode on) -- the in-place Concat-blob route is an inference route and must not be taken (it would drop the
+    upsampled-flow gradient path and leave blob channels unwritten: round-2 advisor finding); its gradients are the same numbers."""
     from flownet2_amd import functional as Fn, nets
+    from oracle import fp64_graph
     P = nets.init_params("C", seed=3)
     g = torch.Generator().manual_seed(5)
-    im0, im1 = (torch.rand(1, 3, 128, 192, generator=g) - 0.5 for _ in range(2))
+    im0, im1 = (torch.rand(1, 3, 128, 192, generator=g) * 255.0 for _ in range(2))
     gt = torch.randn(1, 2, 128, 192, generator=g) * 4
     gt[:, :, :10, :20] = float("nan")
 
-    def grads(stock, trainable=lambda k: True):
-        # stock: library convolutions + stock bias / ReLU ops everywhere; otherwise the training graph as bench.py --mode train runs
-        # it: own MFMA forward kernels inside autograd functions (forced on at this small size) + the fused bias / ReLU function
+    def grads(trainable=lambda k: True):
         Pd = {k: v.cuda().clone().requires_grad_(bool(trainable(k))) for k, v in P.items()}
-        keep, keep_env = Fn.conv_bias_leaky_relu, os.environ.get("FN2_CONV_MFMA")
-        if stock:
-            Fn.conv_bias_leaky_relu = lambda y, b, s=0.1: torch.nn.functional.leaky_relu(y + b.view(1, -1, 1, 1), s)
-            os.environ["FN2_CONV_MFMA"] = "none"
-        else:
-            os.environ["FN2_CONV_MFMA"] = "force"
+        keep_env = os.environ.get("FN2_CONV_MFMA")
+        os.environ["FN2_CONV_MFMA"] = "force"
         try:
-            loss = nets.multiscale_loss(nets.flownet_c_core(Pd, im0.cuda(), im1.cuda(), Fn), gt.cuda(), Fn)
+            pre = [(im.cuda() * (1.0 / 255.0)) - 0.43 for im in (im0, im1)]
+            with fp64_graph.record_relu_branches() as rec:
+                loss = nets.multiscale_loss(nets.flownet_c_core(Pd, pre[0], pre[1], Fn), gt.cuda(), Fn)
             loss.backward()
         finally:
-            Fn.conv_bias_leaky_relu = keep
             if keep_env is None:
                 os.environ.pop("FN2_CONV_MFMA", None)
             else:
                 os.environ["FN2_CONV_MFMA"] = keep_env
-        return float(loss.detach()), {k: v.grad.detach().cpu() for k, v in Pd.items() if v.grad is not None}
+        return float(loss.detach()), {k: v.grad.detach() for k, v in Pd.items() if v.grad is not None}, rec.branches
 
-    l_fused, g_fused = grads(False)
-    l_stock, g_stock = grads(True)
-    assert abs(l_fused - l_stock) <= 1e-5 * max(1.0, abs(l_stock))
-    assert g_fused.keys() == g_stock.keys() and len(g_fused) > 40
-    # The two graphs run the library convolutions twice, and the library does not always pick the same kernels for both: measured over
-    # repeated runs (scripts/probes/grad_agreement_loop.py) the agreement is either ~7e-7 in relative L2 over all gradients, or 4.7e-6
-    # with one transposed-convolution weight gradient at 5e-4.  A wrong backward formula is off by O(1).  Criteria: all parameters
-    # together agree to 2e-3 in relative L2, the typical parameter to 1e-4, no parameter is off by more than 5e-2.
-    rel = {}
-    num = den = 0.0
-    for k in g_stock:
-        d = (g_fused[k] - g_stock[k]).double()
-        n2, d2 = float(g_stock[k].double().pow(2).sum()), float(d.pow(2).sum())
-        rel[k] = (d2 / max(n2, 1e-30)) ** 0.5
-        num, den = num + d2, den + n2
-    worst = max(rel, key=rel.get)
-    print(f"gradient agreement: all {(num / den) ** 0.5:.2e}, median {float(np.median(list(rel.values()))):.2e}, worst {worst} {rel[worst]:.2e}")
-    assert (num / den) ** 0.5 <= 2e-3, f"all gradients together: relative L2 error {(num / den) ** 0.5:.3e}"
-    assert float(np.median(list(rel.values()))) <= 1e-4, f"median relative L2 error {float(np.median(list(rel.values()))):.3e}"
-    assert rel[worst] <= 5e-2, f"{worst}: relative L2 error {rel[worst]:.3e}"
-    # Partially frozen net (encoder frozen, refinement trainable, grad mode on): the in-place Concat-blob route is an inference route
-    # and must not be taken -- it would drop the upsampled-flow gradient path and leave blob channels unwritten (round-2 advisor finding).
+    loss, got, branches = grads()
+    loss64, ref = fp64_graph.flownetc_train_reference(P, im0, im1, gt, device="cuda", masks=branches)
+    assert abs(loss - loss64) <= 1e-6 * max(1.0, abs(loss64)) and got.keys() == ref.keys() and len(got) == len(P)
+    agree = fp64_graph.grad_agreement(got, ref)
+    print("gradient agreement (own kernels forced, 1x128x192) vs same-branch fp64: all %.2e, median %.2e, worst %s %.2e" %
+          (agree["all"], agree["median"], agree["worst_name"], agree["worst"]))
+    assert agree["worst"] <= 1e-5 and agree["all"] <= 5e-6, (agree["worst_name"], agree["worst"], agree["all"])
     dec = lambda k: k.startswith(("deconv", "Convolution", "upsample_flow"))
-    l_f, g_f = grads(False, dec)
-    l_s, g_s = grads(True, dec)
-    assert abs(l_f - l_s) <= 1e-5 * max(1.0, abs(l_s))
-    assert g_f.keys() == g_s.keys() and all(dec(k) for k in g_f) and len(g_f) >= 20
-    num = sum(float((g_f[k] - g_s[k]).double().pow(2).sum()) for k in g_s)
-    den = sum(float(g_s[k].double().pow(2).sum()) for k in g_s)
-    assert (num / den) ** 0.5 <= 2e-3, f"frozen encoder: relative L2 error {(num / den) ** 0.5:.3e}"
-    up = "upsample_flow6to5.w"
-    assert float(g_f[up].abs().sum()) > 0 and float((g_f[up] - g_s[up]).norm() / g_s[up].norm()) <= 5e-2
+    loss_f, got_f, branches_f = grads(dec)
+    assert abs(loss_f - loss) <= 1e-6 * max(1.0, abs(loss)) and all(dec(k) for k in got_f) and len(got_f) >= 20
+    ref_f = fp64_graph.flownetc_train_reference(P, im0, im1, gt, device="cuda", masks=branches_f)[1]
+    agree_f = fp64_graph.grad_agreement(got_f, {k: ref_f[k] for k in got_f})
+    assert agree_f["worst"] <= 1e-5, (agree_f["worst_name"], agree_f["worst"])
+    assert float(got_f["upsample_flow6to5.w"].abs().sum()) > 0
 
 
 @pytest.mark.parametrize("case", [(2, 64, 24, 40, 20, 1, 20, 1, 2, 0), (1, 16, 12, 16, 4, 1, 4, 1, 1, 0), (1, 8, 11, 13, 4, 3, 2, 1, 2, 1),
