@@ -78,14 +78,14 @@ struct Cfg {
   static constexpr int NCLS = MODE == 1 ? 4 : 1;      // parity classes = waves sharing a pixel block
   static constexpr int NW = NCLS * WM * WN, THREADS = 64 * NW;
   static constexpr int TAP = MODE == 1 ? 2 : KS;      // taps per axis (convolution: 3, or 4 for the 4x4 / 2 data gradient of a Deconvolution)
-  static constexpr int PADL = VEC == 4 ? 4 : 1;       // window columns left of x = 0
+  static constexpr int PADL = VEC == 4 ? 4 : (KS_ == 5 ? 2 : 1);       // window columns left of x = 0 (>= pad)
   static constexpr int KSC = CQ * TAP * TAP;
-  static constexpr int NBUFA = (KSC % 9 == 0 && KSC > 9) ? 9 : (KSC % 8 == 0) ? 8 : (KSC % 4 == 0) ? 4 : 3;   // weight-operand ring (k-steps)
+  static constexpr int NBUFA = KS_ == 5 ? 5 : (KSC % 9 == 0 && KSC > 9) ? 9 : (KSC % 8 == 0) ? 8 : (KSC % 4 == 0) ? 4 : 3;   // weight-operand ring (k-steps)
   static constexpr int CAP = 16 * NP * WN;            // pixel slots of a workgroup
   static_assert(KSC % NBUFA == 0, "ring phase must repeat per chunk");
   static_assert(NBUFA - 1 <= kSpare, "prefetch distance");
   static_assert(MODE == 0 || S == 1, "the deconvolution reads its input at stride 1");
-  static_assert(KS == 3 || (KS == 4 && MODE == 0 && S == 2), "tap classes: 3x3 / 1, 3x3 / 2, 4x4 / 2");
+  static_assert(KS == 3 || ((KS == 4 || KS == 5) && MODE == 0 && S == 2), "tap classes: 3x3 / 1, 3x3 / 2, 4x4 / 2, 5x5 / 2");
 };
 
 // q / d for the small non-negative values of the index decodes (q < 2^16, d < 2^16); m = ceil(2^32 / d), d == 1 has no 32-bit m
@@ -344,7 +344,7 @@ struct Variant {
 static bool plan(const Variant& v, Args& a) {
   if (a.Cout % (16 * v.mw * v.wm) != 0) return false;
   if (v.vec == 4 && a.Win % 4 != 0) return false;
-  const int padl = v.vec == 4 ? 4 : 1;
+  const int padl = v.vec == 4 ? 4 : (v.ks == 5 ? 2 : 1);
   const int cap = 16 * v.np * v.wn;
   a.cap = cap;
   int prow = v.mode == 0 ? a.Hout : a.Hin;                            // pixel rows a workgroup touches: all of them, or (several
@@ -359,7 +359,7 @@ static bool plan(const Variant& v, Args& a) {
   } else {
     a.wr = prow + 2;
   }
-  const int wc = padl + a.Win + 1;
+  const int wc = padl + a.Win + (v.ks == 5 ? 2 : 1);                    // columns right of the map a tap can reach
   a.rs = v.vec == 4 ? cdiv(wc, 4) * 4 : wc;
   a.cs = up_mod(a.wr * a.rs, 16, 32);
   a.slots_c = a.cs / v.vec;
@@ -412,7 +412,13 @@ static int launch(const Args& a, hipStream_t st) {
 // 4x4 taps at stride 2 (the data gradient of a Deconvolution{4, 2, 1} on a small map: deconv_layer.cu:52-56 = forward_gpu_gemm of top_diff)
 #define FN2_CP4_TILES(X, VEC) X(2, 9, 2, 2, 2, VEC) X(2, 5, 2, 2, 2, VEC) X(4, 5, 1, 4, 2, VEC) X(2, 5, 2, 4, 2, VEC)
 #define FN2_CP4_ROW(MW, NP, WM, WN, CQ, VEC) {0, 2, MW, NP, WM, WN, CQ, VEC, 4, &launch<Cfg<0, 2, MW, NP, WM, WN, CQ, VEC, 4>>},
-static const Variant kVariants[] = {FN2_CP_LIST(FN2_CP_ROW) FN2_CP4_TILES(FN2_CP4_ROW, 1) FN2_CP4_TILES(FN2_CP4_ROW, 4)};
+// 5x5 taps at stride 2 / pad 2 (conv2 / conv3 of the encoders when ONE sample has to fill the chip: FlowNet2 at batch 1 -- the direct kernel
+// of conv_mfma.hip has no K split and ran conv3 [1,128,112,256] -> 256 at 66 TFLOP/s, behind the library's 81); one channel quad per chunk: a
+// row band of a 256-pixel-wide map is 12 KB per channel
+#define FN2_CP5_TILES(X, VEC) X(2, 9, 2, 2, 1, VEC) X(2, 5, 2, 2, 1, VEC) X(4, 5, 1, 4, 1, VEC) X(2, 9, 1, 4, 1, VEC) X(2, 7, 2, 2, 1, VEC) X(4, 4, 2, 2, 1, VEC)
+#define FN2_CP5_ROW(MW, NP, WM, WN, CQ, VEC) {0, 2, MW, NP, WM, WN, CQ, VEC, 5, &launch<Cfg<0, 2, MW, NP, WM, WN, CQ, VEC, 5>>},
+static const Variant kVariants[] = {FN2_CP_LIST(FN2_CP_ROW) FN2_CP4_TILES(FN2_CP4_ROW, 1) FN2_CP4_TILES(FN2_CP4_ROW, 4)
+                                    FN2_CP5_TILES(FN2_CP5_ROW, 1) FN2_CP5_TILES(FN2_CP5_ROW, 4)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int g_forced_variant = -1;
@@ -506,8 +512,8 @@ using namespace fn2;
 // ------------------------------------------------------------------------------------------------ convolution 3x3 (and 4x4 / 2)
 static bool plane_geometry_ok(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {
   if (N <= 0 || Cin <= 0 || Cin % 8 != 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || Cout % 64 != 0) return false;
-  if ((stride != 1 && stride != 2) || pad < 0 || pad > 1) return false;
-  if (!(kernel == 3 || (kernel == 4 && stride == 2 && pad == 1))) return false;
+  if ((stride != 1 && stride != 2) || pad < 0 || pad > 2) return false;
+  if (!((kernel == 3 && pad <= 1) || (kernel == 4 && stride == 2 && pad == 1) || (kernel == 5 && stride == 2 && pad == 2))) return false;
   if (Hin + 2 * pad < kernel || Win + 2 * pad < kernel) return false;
   if ((long long)N * Cin * Hin * Win >= (1ll << 28)) return false;
   return true;

@@ -353,6 +353,13 @@ def _conv_mfma_pick(x, weight, stride, pad):
         # the encoder layers from 1/16 resolution down (conv4 .. conv6_1): whole planes or row bands in LDS, pixels of several samples per MFMA
         # tile, split K.  Up to 1200 output pixels per sample it is level with or ahead of the im2col + GEMM route (bench A/B: 2.317 vs 2.324 ms)
         return "plane"
+    if (k == 5 and stride == 2 and pad == 2 and os.environ.get("FN2_CONV_PLANE5", "1") != "0"
+            and N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "8000"))
+            and ops.conv_plane_k_supported(x.shape[0], Cin, H, W, Cout, 5, 2, 2)):
+        # conv3 of the encoders when one sample is the whole batch (FlowNet2 at 1024x448, batch 1: [1,128,112,256] -> 256): 7168 accumulator
+        # tiles cannot fill the chip without a K split, which the direct kernel does not have (179 us against the library's 145;
+        # scripts/probes/small_layer_routes.py)
+        return "plane"
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None
     if k == 1 and os.environ.get("FN2_CONV_1X1", "1") != "0":
@@ -393,7 +400,7 @@ def _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out=
                                      in_c0=c0, Cin=Cin)
     if kind == "plane":
         return ops.conv_plane_forward(blob, _packed_conv_weight(weight), bias, Cout, stride, pad, act, negative_slope, out=out, out_c0=out_c0,
-                                      in_c0=c0, Cin=Cin)
+                                      in_c0=c0, Cin=Cin, kernel=k)
     return ops.conv_mfma_forward(blob, _packed_conv_weight(weight), bias, Cout, k, stride, pad, act, negative_slope,
                                  out=out, out_c0=out_c0, in_c0=c0, Cin=Cin)
 

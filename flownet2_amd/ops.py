@@ -535,7 +535,7 @@ def conv_plane_k_ksplit(N, Cin, Hin, Win, Cout, kernel, stride, pad) -> int:
 
 def conv_plane_forward(x, packed_weight, bias, Cout, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None, kernel=3):
     """act(Convolution{kernel, stride, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] for small feature maps
-    (csrc/conv_plane.hip); kernel 3, or 4 with stride 2 / pad 1; packed_weight = conv_mfma_pack_weights(weight)."""
+    (csrc/conv_plane.hip); kernel 3, 4 with stride 2 / pad 1, or 5 with stride 2 / pad 2; packed_weight = conv_mfma_pack_weights(weight)."""
     x = _chk(x, "bottom[0]")
     N, Ctot, H, W = x.shape
     Cin = Ctot - in_c0 if Cin is None else Cin

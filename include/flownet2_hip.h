@@ -391,7 +391,9 @@ int fn2_conv_plane_forward(const float* bottom, const float* packed_weight, cons
 /* The same kernel with a `kernel` argument: 3 (as above) or 4 with stride 2 / pad 1 -- the DATA GRADIENT of a Deconvolution{4, 2, 1}
  * on a small map (DeconvolutionLayer::Backward_gpu, deconv_layer.cu:52-56: forward_gpu_gemm of top_diff = the 4x4 / 2 / 1 CONVOLUTION of
  * top_diff with the layer's weight blob [Cin_deconv = output channels here][Cout_deconv = input channels here][4][4], packed by
- * fn2_conv_mfma_pack_weights); maps whose width is not a multiple of 4 included (deconv5 of FlowNetC: 10x14 -> 5x7). */
+ * fn2_conv_mfma_pack_weights); maps whose width is not a multiple of 4 included (deconv5 of FlowNetC: 10x14 -> 5x7) -- or 5 with
+ * stride 2 / pad 2: conv2 / conv3 of the encoders (FlowNet2_deploy.prototxt.template: Convolution{kernel_size 5, stride 2, pad 2}) when ONE
+ * sample has to fill the chip (FlowNet2 at batch 1: conv3 [1,128,112,256] -> 256 needs the K split the direct kernel does not have). */
 int fn2_conv_plane_k_supported(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
 int fn2_conv_plane_k_ksplit(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
 size_t fn2_conv_plane_k_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);

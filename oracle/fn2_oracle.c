@@ -1028,7 +1028,7 @@ FN2_API int fn2_conv_plane_k_forward_cpu(const float* bottom, const float* packe
                                          int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,
                                          int relu, float negative_slope, int ksplit) {
   if (N < 0 || Cin < 1 || Cin % 4 != 0 || Hin < 1 || Win < 1 || Cout < 1 || Cout % 64 != 0 || stride < 1 || pad < 0 || ksplit < 1) return FN2_ERR_INVALID_ARG;
-  if (kernel != 3 && kernel != 4) return FN2_ERR_INVALID_ARG;
+  if (kernel != 3 && kernel != 4 && kernel != 5) return FN2_ERR_INVALID_ARG;
   if (bottom_c0 < 0 || bottom_c0 + Cin > bottom_channels || top_c0 < 0 || top_c0 + Cout > top_channels) return FN2_ERR_INVALID_ARG;
   const int quads = Cin / 4, units = (quads + 1) / 2, kalloc = conv_mfma_ksteps(Cin, kernel) + 8;
   if (ksplit > units) return FN2_ERR_INVALID_ARG;

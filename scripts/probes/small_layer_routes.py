@@ -15,6 +15,7 @@ B1 = [  # name, N, Cin, H, W, Cout, k, s, p     batch 1 @1024x448
     ("C.conv3_1", 1, 473, 56, 128, 256, 3, 1, 1), ("S.conv3_1", 1, 256, 56, 128, 256, 3, 1, 1), ("conv4", 1, 256, 56, 128, 512, 3, 2, 1),
     ("conv4_1", 1, 512, 28, 64, 512, 3, 1, 1), ("conv5", 1, 512, 28, 64, 512, 3, 2, 1), ("conv5_1", 1, 512, 14, 32, 512, 3, 1, 1),
     ("conv6", 1, 512, 14, 32, 1024, 3, 2, 1), ("conv6_1", 1, 1024, 7, 16, 1024, 3, 1, 1),
+    ("conv2", 1, 64, 224, 512, 128, 5, 2, 2), ("conv3", 1, 128, 112, 256, 256, 5, 2, 2), ("S.conv1", 1, 12, 448, 1024, 64, 7, 2, 3),
     ("sd_conv1_1", 1, 64, 224, 512, 128, 3, 1, 1), ("sd_conv2", 1, 128, 224, 512, 128, 3, 2, 1), ("sd_conv2_1", 1, 128, 112, 256, 128, 3, 1, 1),
     ("sd_conv3", 1, 128, 112, 256, 256, 3, 2, 1), ("sd_ic4", 1, 770, 28, 64, 256, 3, 1, 1), ("sd_ic3", 1, 386, 56, 128, 128, 3, 1, 1), ("sd_ic2", 1, 194, 112, 256, 64, 3, 1, 1)]
 B4 = [("conv3_1", 4, 256, 48, 96, 256, 3, 1, 1), ("conv4_1", 4, 512, 24, 48, 512, 3, 1, 1), ("conv5_1", 4, 512, 12, 24, 512, 3, 1, 1), ("conv6_1", 4, 1024, 6, 12, 1024, 3, 1, 1)]
@@ -43,13 +44,16 @@ for name, N, Cin, H, W, Cout, k, s, p in (B4 if "--b4" in sys.argv else B1):
     with torch.no_grad():
         kind = Fn._conv_mfma_pick(x, w, s, p)
         t_own = timeit(lambda: Fn.conv_mfma_relu(x, w, b, s, p, 0.1, True))
-        t_lib = timeit(lambda: Fn.conv_gemm_relu(x, w, b, s, p, 0.1))
+        if k == 3:
+            t_lib = timeit(lambda: Fn.conv_gemm_relu(x, w, b, s, p, 0.1))
+        else:           # what FN2_CONV_SMALL=lib runs for 5x5 / 7x7 layers: MIOpen's convolution + the fused bias / activation pass
+            t_lib = timeit(lambda: Fn.conv_bias_leaky_relu(torch.nn.functional.conv2d(x, w, None, stride=s, padding=p), b, 0.1))
         alts = {}
         for alt in ("wino", "plane", "direct"):
             try:
                 if alt == "wino" and not (s == 1 and ops.conv_wino_supported(Cin, H, W, Cout, p)):
                     continue
-                if alt == "plane" and not ops.conv_plane_supported(N, Cin, H, W, Cout, s, p):
+                if alt == "plane" and not ops.conv_plane_k_supported(N, Cin, H, W, Cout, k, s, p):
                     continue
                 if alt == "direct" and not ops.conv_mfma_supported(Cin, H, W, Cout, k, s, p):
                     continue
@@ -62,13 +66,13 @@ for name, N, Cin, H, W, Cout, k, s, p in (B4 if "--b4" in sys.argv else B1):
             for ksp in (1, 2, 4, 8, 16):
                 ops.set_plane_ksplit(ksp)
                 try:
-                    used = ops.conv_plane_ksplit(N, Cin, H, W, Cout, s, p)
+                    used = ops.conv_plane_k_ksplit(N, Cin, H, W, Cout, k, s, p)
                     if used == ksp:
-                        ks_txt += " k%d:%.0f" % (ksp, timeit(lambda: ops.conv_plane_forward(x, pw, b, Cout, s, p, True, 0.1), 15, 3))
+                        ks_txt += " k%d:%.0f" % (ksp, timeit(lambda: ops.conv_plane_forward(x, pw, b, Cout, s, p, True, 0.1, kernel=k), 15, 3))
                 except flownet2_amd.Fn2Error:
                     pass
             ops.set_plane_ksplit(0)
-            ks_txt = " | plane own-split k%d;%s" % (ops.conv_plane_ksplit(N, Cin, H, W, Cout, s, p), ks_txt)
+            ks_txt = " | plane own-split k%d;%s" % (ops.conv_plane_k_ksplit(N, Cin, H, W, Cout, k, s, p), ks_txt)
     best = min([t_own, t_lib] + list(alts.values()))
     tot["own"] += t_own; tot["lib"] += t_lib; tot["best"] += best
     print("%-11s [%d,%d,%d,%d]->%d s%d %6.2f GF | route %-6s %7.1f us %5.1f TF | im2col+lib GEMM %7.1f us | %s%s" % (

@@ -56,6 +56,56 @@ def test_oracle_plane_conv_k4s2_matches_fp64_convolution(case):
     assert np.array_equal(oracle.conv_plane_forward(x, pw, b, Cout, 2, 1, 1, kernel=4), oracle.conv_mfma_forward(x, pw, b, Cout, 4, 2, 1))
 
 
+CASES_K5 = [  # N, Cin, H, W, Cout: Convolution{5, 2, 2} (conv2 / conv3 of the encoders) on one or two samples
+    (1, 16, 28, 64, 64), (1, 8, 15, 29, 64), (2, 24, 16, 24, 128), (1, 16, 56, 128, 64), (3, 8, 9, 13, 64), (1, 32, 30, 256, 64)]
+
+
+@pytest.mark.parametrize("case", CASES_K5[:3])
+def test_oracle_plane_conv_k5s2_matches_fp64_convolution(case):
+    N, Cin, H, W, Cout = case
+    x, w, b = rnd((N, Cin, H, W), 41), rnd((Cout, Cin, 5, 5), 42, 0.2), rnd((Cout,), 43)
+    pw = oracle.conv_mfma_pack_weights(w)
+    for ksplit in (1, 2) if Cin >= 16 else (1,):
+        got = oracle.conv_plane_forward(x, pw, b, Cout, 2, 2, ksplit, False, 0.1, kernel=5)
+        want = torch64(x, w, b, 2, 2, False)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert np.array_equal(oracle.conv_plane_forward(x, pw, b, Cout, 2, 2, 1, kernel=5), oracle.conv_mfma_forward(x, pw, b, Cout, 5, 2, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES_K5)
+def test_hip_plane_conv_k5s2_equals_oracle_bitwise_in_every_variant(case):
+    from flownet2_amd import ops
+    N, Cin, H, W, Cout = case
+    x, w, b = rnd((N, Cin, H, W), 51), rnd((Cout, Cin, 5, 5), 52, 0.2), rnd((Cout,), 53)
+    dv = lambda a: torch.from_numpy(a).cuda()
+    pw = ops.conv_mfma_pack_weights(dv(w))
+    pwh = pw.cpu().numpy()
+    assert ops.conv_plane_k_supported(N, Cin, H, W, Cout, 5, 2, 2) and not ops.conv_plane_k_supported(N, Cin, H, W, Cout, 5, 1, 2)
+    assert not ops.conv_plane_k_supported(N, Cin, H, W, Cout, 5, 2, 1)
+    ran = 0
+    try:
+        for ksplit in (0, 1, 2):
+            ops.set_plane_ksplit(ksplit)
+            ks = ops.conv_plane_k_ksplit(N, Cin, H, W, Cout, 5, 2, 2)
+            want = oracle.conv_plane_forward(x, pwh, b, Cout, 2, 2, ks, True, 0.1, kernel=5)
+            for v in range(ops.plane_num_variants()):
+                ops.set_plane_variant(v)
+                try:
+                    got = ops.conv_plane_forward(dv(x), pw, dv(b), Cout, 2, 2, True, 0.1, kernel=5)
+                except flownet2_amd.Fn2Error:
+                    continue                              # another tap class, the other DMA width, or a window beyond the LDS
+                ran += 1
+                assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"variant {v}, ksplit {ks}"
+            ops.set_plane_variant(-1)
+            got = ops.conv_plane_forward(dv(x), pw, None, Cout, 2, 2, False, 0.1, kernel=5)
+            assert np.array_equal(got.cpu().numpy(), oracle.conv_plane_forward(x, pwh, None, Cout, 2, 2, ks, False, 0.1, kernel=5))
+    finally:
+        ops.set_plane_variant(-1)
+        ops.set_plane_ksplit(0)
+    assert ran >= 2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES_K4)
 def test_hip_plane_conv_k4s2_equals_oracle_bitwise_in_every_variant(case):
