@@ -25,14 +25,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from flownet2_amd import functional as Fn   # noqa: E402
-from flownet2_amd import nets, ops, parallel, tuning   # noqa: E402
+from flownet2_amd import nets, ops, parallel   # noqa: E402
 
 CONV_STACK_NOTE = ("own fp32 MFMA kernels for every layer, no library GEMM or convolution in the forward step: direct 5x5/2 (conv2, conv3), "
                    "Winograd F(2x2,3x3) for 3x3/1 (conv3_1, conv4_1), small-map kernel with deterministic split-K (conv4 .. conv6_1), 1x1 "
                    "(conv_redir; the weight^T x bottom GEMM of the 4x4/2 deconvolutions + own col2im/bias/ReLU pass into the concat blob), "
                    "7x7/2 stem, flow heads; no Concat copies, no element-wise glue kernels; train mode: own weight-gradient (fp32 MFMA, "
-                   "deterministic split) and data-gradient kernels (Winograd, transposed 5x5/2 and 3x3/2, 4x4/2 as convolution) for the bulk "
-                   "layers, library for the stem / 2-channel heads / smallest maps")
+                   "deterministic split) and data-gradient kernels (Winograd, transposed 5x5/2 and 3x3/2, 4x4/2 as convolution) for every "
+                   "layer incl. the stem, the 2-channel heads and the smallest maps")
+
+
+def LIB_FALLBACKS():
+    """Convolution / Deconvolution calls of this process that left the own kernels (functional.lib_conv2d / lib_conv_transpose2d)."""
+    from flownet2_amd import functional as Fn
+    return int(Fn.LIBRARY_FALLBACKS[0])
+
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md "Chip-level parameters" (spec; 6290 measured copy)
 F32_MFMA_PEAK_TFLOPS = 157.3    # same table: dense f32-input MFMA peak (= f32 vector peak)
 
@@ -52,7 +59,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the FlowNet2 768x384 / 1024x448 and train-step legs reported under `extra`")
     ap.add_argument("--graph", action="store_true", help="capture a forward step into a hipGraph and replay it (measured: no gain, the step is not launch-bound)")
-    ap.add_argument("--conv-search", action="store_true", help="let MIOpen's find step time its candidate kernels during warm-up (measured: no gain for this net)")
     ap.add_argument("--corr-iters", type=int, default=200)
     ap.add_argument("--bucket-mb", type=int, default=48, help="gradient all-reduce bucket size (train mode)")
     return ap.parse_args()
@@ -423,7 +429,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); cuda not available")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    torch.backends.cudnn.benchmark = bool(args.conv_search)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
@@ -449,7 +454,7 @@ def main():
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
                        "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
                        "conv_stack": CONV_STACK_NOTE + " (%.1f GFLOP/step/GPU)" % conv_gf,
-                       "tuned_gemm_table_accepted": tuning.active(),
+                       "library_conv_fallbacks": LIB_FALLBACKS(),
                        "launch": "hipGraph replay" if m["use_graph"] else "host launches", "python_gc": "paused for the timed steps" if m["gc_paused"] else "on",
                        "untimed_settling_steps_after_warmup": m["settle_steps"], "ranks_seen_by_rccl": ranks_seen},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),

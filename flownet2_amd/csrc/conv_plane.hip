@@ -361,9 +361,9 @@ static bool plan(const Variant& v, Args& a) {
   }
   const int wc = padl + a.Win + (v.ks == 5 ? 2 : 1);                    // columns right of the map a tap can reach
   a.rs = v.vec == 4 ? cdiv(wc, 4) * 4 : wc;
-  a.cs = up_mod(a.wr * a.rs, 16, 32);
+  const int plane_dw = a.wr * a.rs < 64 * v.vec ? 64 * v.vec : a.wr * a.rs;     // at least one whole 64-slot DMA run (a 2x3 map has 20 dwords)
+  a.cs = up_mod(plane_dw, 16, 32);
   a.slots_c = a.cs / v.vec;
-  if (a.slots_c < 64) return false;
   a.npr = cdiv(a.slots_c, 64);
   if (a.npr > kNPR) return false;
   int img = 1;

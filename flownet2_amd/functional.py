@@ -11,7 +11,6 @@ import os
 import torch
 
 from . import ops
-from . import tuning
 
 
 _BATCH_INVARIANT = [False]
@@ -20,37 +19,41 @@ _BATCH_INVARIANT = [False]
 def set_batch_invariant(on: bool = True):
     """Make the bits of a sample independent of the batch it is computed in (scripts/run_flownet_many.py: one .flo per pair, whatever
     the batching and the sharding over GPUs -- run-flownet-many.py:27-81).  The own kernels are batch-invariant by construction except
-    for the K split of the small-map kernels (fn2_set_batch_invariant fixes it to the one-sample value); the library calls that are
-    left (rocBLAS / hipBLASLt GEMMs, MIOpen convolutions of small layers) choose their kernels -- and with them the summation order --
-    by problem size, so in this mode they run sample by sample."""
+    for the K split of the small-map kernels (fn2_set_batch_invariant fixes it to the one-sample value).  The library convolution that
+    remains as the fallback for layer shapes outside FlowNet's families (`fallback_conv2d`: none of the five BASELINE configurations
+    reaches it) chooses its kernels -- and with them the summation order -- by problem size, so in this mode it runs sample by sample."""
     _BATCH_INVARIANT[0] = bool(on)
     ops.set_batch_invariant(bool(on))
-    from . import nets
-    nets._BATCH_INVARIANT_ROUTES[0] = bool(on)
 
 
 def batch_invariant() -> bool:
     return _BATCH_INVARIANT[0]
 
 
-def _matmul_per_sample(w2d, x3d):
-    """w2d [M, K] x x3d [N, K, P] -> [N, M, P]; one GEMM per sample in batch-invariant mode."""
-    if not _BATCH_INVARIANT[0]:
-        return torch.matmul(w2d, x3d)          # (a batch of one included: a 3-D operand takes the batched-GEMM path, another kernel)
-    out = torch.empty((x3d.shape[0], w2d.shape[0], x3d.shape[2]), device=x3d.device, dtype=x3d.dtype)
-    for n in range(x3d.shape[0]):
-        torch.matmul(w2d, x3d[n], out=out[n])
-    return out
+LIBRARY_FALLBACKS = [0]      # calls that left the own kernels (tests and the profile audits assert 0 on the BASELINE configurations)
+
+
+def _note_fallback(what, x, w):
+    LIBRARY_FALLBACKS[0] += 1
+    if os.environ.get("FN2_STRICT") == "1":
+        raise RuntimeError("flownet2_amd: no own kernel for %s bottom %s weight %s (FN2_STRICT=1)" % (what, tuple(x.shape), tuple(w.shape)))
+    if os.environ.get("FN2_TRACE_FALLBACK") == "1":
+        print("library fallback: %s bottom %s weight %s" % (what, tuple(x.shape), tuple(w.shape)), flush=True)
 
 
 def lib_conv2d(x, w, b, stride, pad):
-    """The library convolution of a layer no own kernel serves (MIOpen through torch); sample by sample in batch-invariant mode."""
+    """Last resort for a Convolution no own kernel serves (a layer shape outside FlowNet's families, or CPU tensors): the library's
+    convolution through torch, counted in LIBRARY_FALLBACKS for CUDA tensors; sample by sample in batch-invariant mode."""
+    if x.is_cuda:
+        _note_fallback("Convolution{stride %d, pad %d}" % (stride, pad), x, w)
     if not _BATCH_INVARIANT[0] or not x.is_cuda:
         return torch.nn.functional.conv2d(x, w, b, stride=stride, padding=pad)
     return torch.cat([torch.nn.functional.conv2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
 
 
 def lib_conv_transpose2d(x, w, b, stride, pad):
+    if x.is_cuda:
+        _note_fallback("Deconvolution{stride %d, pad %d}" % (stride, pad), x, w)
     if not _BATCH_INVARIANT[0] or not x.is_cuda:
         return torch.nn.functional.conv_transpose2d(x, w, b, stride=stride, padding=pad)
     return torch.cat([torch.nn.functional.conv_transpose2d(x[n:n + 1], w, b, stride=stride, padding=pad) for n in range(x.shape[0])], 0)
@@ -336,45 +339,35 @@ def _conv_mfma_pick(x, weight, stride, pad):
     if not x.is_cuda or not _mfma_conv_enabled(k, stride):
         return None
     force = os.environ.get("FN2_CONV_MFMA", "") == "force"
-    own = force             # lift the work thresholds below which the library is faster
+    wino_first = force      # tests: the Winograd kernel wherever it applies, the small-map kernel whatever the map size
     N, _, H, W = x.shape
     if _BATCH_INVARIANT[0]:
-        # the route (and with it the arithmetic) must not depend on the batch: decide as for one sample, and take the own kernels
-        # wherever they apply -- they are batch-invariant by construction, the library's choices are its own business
-        N, own = 1, True
+        # the route (and with it the arithmetic) must not depend on the batch: decide as for one sample
+        N, wino_first = 1, True
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    if (k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)):
-        # accumulator blocks (16 channels x an 8x8-pixel block of tiles): below ~1000 the launch cannot fill 1024 SIMDs and the
-        # library's GEMM route wins (profiles/r02_conv_bench_*.txt: 12x24 maps lose, 20x28 maps win by 1.6x)
-        if own or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000:
-            return "wino"
-    if (k == 3 and (force or Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "8000"))) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
+    wino_ok = k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)
+    # accumulator blocks of the Winograd kernel (16 channels x an 8x8-pixel block of tiles): from ~1000 on the launch fills the 1024 SIMDs
+    # and it is the fastest kernel of a 3x3 / 1 layer (profiles/r02_conv_bench_*.txt: 20x28 maps win by 1.6x, 12x24 maps lose)
+    if wino_ok and (wino_first or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000):
+        return "wino"
+    maxpix = int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "8000"))
+    if (k == 3 and (force or Ho * Wo <= maxpix) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
             and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad) and (N == x.shape[0] or ops.conv_plane_supported(x.shape[0], Cin, H, W, Cout, stride, pad))):
-        # the encoder layers from 1/16 resolution down (conv4 .. conv6_1): whole planes or row bands in LDS, pixels of several samples per MFMA
-        # tile, split K.  Up to 1200 output pixels per sample it is level with or ahead of the im2col + GEMM route (bench A/B: 2.317 vs 2.324 ms)
+        # the encoder layers from 1/16 resolution down (conv4 .. conv6_1; at batch 1 from 1/8 down): whole planes or row bands in LDS,
+        # pixels of several samples per MFMA tile, split K
         return "plane"
     if (k == 5 and stride == 2 and pad == 2 and os.environ.get("FN2_CONV_PLANE5", "1") != "0"
-            and N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and Ho * Wo <= int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "8000"))
+            and N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and Ho * Wo <= maxpix
             and ops.conv_plane_k_supported(x.shape[0], Cin, H, W, Cout, 5, 2, 2)):
         # conv3 of the encoders when one sample is the whole batch (FlowNet2 at 1024x448, batch 1: [1,128,112,256] -> 256): 7168 accumulator
-        # tiles cannot fill the chip without a K split, which the direct kernel does not have (179 us against the library's 145;
+        # tiles cannot fill the chip without a K split, which the direct kernel does not have (120 us against 180;
         # scripts/probes/small_layer_routes.py)
         return "plane"
+    if wino_ok:
+        return "wino"       # a 3x3 / 1 layer too large for the small-map kernel and too small to fill the chip: still 2.25x fewer multiplies
     if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
         return None
-    if k == 1 and os.environ.get("FN2_CONV_1X1", "1") != "0":
-        return "direct"     # conv_redir: the alternative is a library GEMM + a bias / activation pass + a copy into the Concat blob
-    # accumulator tiles (16 channels x 4x4 pixels) per CU: below ~64 the launch cannot fill 256 CUs x 4 SIMDs with waves that are
-    # large enough to run the matrix pipes efficiently (scripts/conv_bench.py, profiles/), and the im2col + library GEMM route (split-K
-    # GEMMs) is faster: FlowNet2 at batch 1, 1024x448, where most 3x3 layers are "small" by this measure, runs 5.72 ms with it against
-    # 6.20 ms on the own kernels (scripts/probes/fn2_toggle_bench.sh; batch 4 at 768x384: 10.71 / 10.68, FlowNetC batch 8: 2.40 / 2.40).
-    # FN2_CONV_SMALL=own keeps such layers on the own kernels (Winograd where it applies, else direct); batch-invariant mode always does.
-    if N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and not own:
-        if os.environ.get("FN2_CONV_SMALL", "own") == "lib":
-            return None
-        if k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad):
-            return "wino"
-    return "direct"
+    return "direct"         # 5x5 / 2, 3x3 / 2 on large maps, 7x7 / 2 on whole channel quads, 1x1 (conv_redir; the GEMM of a Deconvolution)
 
 
 def _channel_slice(x):
@@ -599,30 +592,6 @@ def _no_grad_needed(*ts):
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts))
 
 
-def conv_gemm_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True):
-    """Convolution + bias + leaky ReLU the way the reference computes it -- im2col, one (batched) library GEMM, bias --
-    with our batched im2col and fused bias/activation pass around rocBLAS/hipBLASLt.  Used for the layers where that
-    beats the library's direct convolution on gfx950 (nets._use_gemm_conv).  With autograd active the same forward runs inside
-    _OwnForwardConv."""
-    tuning.enable()
-    N, Cin, H, W = x.shape
-    Cout, k = weight.shape[0], weight.shape[2]
-    Hc, Wc = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-
-    def run(xx, ww, bb):
-        col = ops.im2col_forward(xx.contiguous(), k, pad, stride)                   # [N, Cin*k*k, Hc*Wc]
-        y = _matmul_per_sample(ww.reshape(Cout, Cin * k * k), col).view(N, Cout, Hc, Wc)
-        if act:
-            return ops.bias_leaky_relu_(y, bb, negative_slope)
-        return y.add_(bb.view(1, -1, 1, 1)) if bb is not None else y          # a convolution without ReLU (FlowNet-SD's inter-convolutions)
-
-    if _needs_grad(x, weight, bias):
-        if not _train_fast_forward():
-            return None
-        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, act, False)
-    return run(x, weight, bias)
-
-
 _PACKED_D = {}
 
 
@@ -645,8 +614,8 @@ def deconv_mfma_relu(x, weight, bias, negative_slope=0.1, act=True, out=None, ou
     mode = os.environ.get("FN2_DECONV_PLANE", "auto")
     if not x.is_cuda or mode == "0" or _needs_grad(x, weight, bias):
         return None
-    if mode == "auto" and ((x.shape[2] * x.shape[3]) % 4 == 0 or os.environ.get("FN2_DECONV_GEMM", "own") != "own"):
-        return None        # the GEMM route (own 1x1 MFMA kernel, or the library's with FN2_DECONV_GEMM=lib) serves it; odd planes (5x7) stay here
+    if mode == "auto" and (x.shape[2] * x.shape[3]) % 4 == 0 and _deconv_gemm_supported(x, weight.shape[1], 4):
+        return None        # the GEMM route (own 1x1 MFMA kernel + col2im pass) serves it; odd planes (5x7) and maps it does not take stay here
     Cin, Cout = weight.shape[:2]
     if tuple(weight.shape[2:]) != (4, 4) or not ops.deconv_plane_supported(x.shape[0], Cin, x.shape[2], x.shape[3], Cout):
         return None
@@ -654,26 +623,26 @@ def deconv_mfma_relu(x, weight, bias, negative_slope=0.1, act=True, out=None, ou
     return ops.deconv_plane_forward(blob, _packed_deconv_weight(weight), bias, Cout, act, negative_slope, out=out, out_c0=out_c0, in_c0=c0, Cin=Cin)
 
 
+def _deconv_gemm_supported(x, cout, kernel):
+    return x.is_cuda and (cout * kernel * kernel) % 32 == 0 and ops.conv_mfma_supported(x.shape[1], x.shape[2], x.shape[3], cout * kernel * kernel, 1, 1, 0)
+
+
 def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negative_slope=0.1, weight=None, out=None, out_c0=0):
-    """Deconvolution + bias + leaky ReLU as the reference computes it -- weight^T x bottom (one batched library GEMM), then
-    col2im -- with the bias and activation folded into our col2im pass.  weight_t = weight.view(Cin, Cout*k*k).t().contiguous()
-    (cached by the caller; rebuilt from `weight` when autograd is active, inside _OwnForwardConv).  Returns None if autograd is
-    needed and `weight` was not given."""
-    tuning.enable()
+    """Deconvolution + bias + leaky ReLU as the reference computes it -- weight^T x bottom (base_conv_layer.cpp:375-384: one GEMM, here the
+    own 1x1 MFMA kernel), then col2im -- with the bias and activation folded into our col2im pass.
+    weight_t = weight.view(Cin, Cout*k*k).t().contiguous() (cached by the caller; rebuilt from `weight` when autograd is active, inside
+    _OwnForwardConv).  Returns None if the kernel does not apply, or autograd is needed and `weight` was not given."""
     N, Cin, H, W = x.shape
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
+    if not _deconv_gemm_supported(x, cout, kernel):
+        return None
 
     def run_t(xx, wt, bb, out=None, out_c0=0):
-        col = None
-        if xx.is_cuda and os.environ.get("FN2_DECONV_GEMM", "own") == "own" and (cout * kernel * kernel) % 32 == 0 \
-                and ops.conv_mfma_supported(Cin, H, W, cout * kernel * kernel, 1, 1, 0):
-            # weight^T x bottom (base_conv_layer.cpp:375-384) as a 1x1 convolution with Cout * k * k output channels on the own MFMA kernel
-            # (csrc/conv_mfma.hip, kernel_size 1): the column matrix [N, Cout*k*k, H*W] without a library call
-            blob, c0 = _channel_slice(xx)
-            pw = _cached_pack(_PACKED_T, wt, "deconv-gemm", lambda: ops.conv_mfma_pack_weights(wt.detach().reshape(cout * kernel * kernel, Cin, 1, 1)))
-            col = ops.conv_mfma_forward(blob, pw, None, cout * kernel * kernel, 1, 1, 0, False, 0.0, in_c0=c0, Cin=Cin).view(N, cout * kernel * kernel, H * W)
-        if col is None:
-            col = _matmul_per_sample(wt, xx.contiguous().view(N, Cin, H * W))     # [N, Cout*k*k, H*W]
+        # weight^T x bottom as a 1x1 convolution with Cout * k * k output channels on the own MFMA kernel (csrc/conv_mfma.hip,
+        # kernel_size 1): the column matrix [N, Cout*k*k, H*W]
+        blob, c0 = _channel_slice(xx)
+        pw = _cached_pack(_PACKED_T, wt, "deconv-gemm", lambda: ops.conv_mfma_pack_weights(wt.detach().reshape(cout * kernel * kernel, Cin, 1, 1)))
+        col = ops.conv_mfma_forward(blob, pw, None, cout * kernel * kernel, 1, 1, 0, False, 0.0, in_c0=c0, Cin=Cin).view(N, cout * kernel * kernel, H * W)
         return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope, out=out, out_c0=out_c0)
 
     if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)

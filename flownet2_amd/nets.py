@@ -117,11 +117,6 @@ def conv_forward(x, w, b, stride, pad, act, backend, slope=None):
         if y is not None:
             _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
-    if w.shape[2] == 3 and backend is not None and hasattr(backend, "conv_gemm_relu") and _use_gemm_conv(x, stride):
-        y = backend.conv_gemm_relu(x, w, P[name + ".b"], stride, pad, slope, act)
-        if y is not None:
-            _LAST_ROUTE[0] = "im2col + library GEMM"
-            return y
     conv2d = getattr(backend, "lib_conv2d", None) or (lambda xx, ww, bb, s, p: F.conv2d(xx, ww, bb, stride=s, padding=p))
     if act and backend is not None and hasattr(backend, "conv_bias_leaky_relu"):
         return backend.conv_bias_leaky_relu(conv2d(x, w, None, stride, pad), P[name + ".b"], slope)
@@ -155,21 +150,6 @@ def _transposed_deconv_weight(w):
                w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous())
         _WT_CACHE[key] = hit
     return hit[2]
-
-
-def _use_gemm_conv(x, stride):
-    """3x3 layers for which im2col + one batched fp32 GEMM beats MIOpen's direct kernels on gfx950
-    (scripts/probes/im2col_gemm_probe.py, gemm_route_shapes_probe.py: FlowNetC and FlowNet2 shapes): every layer with at
-    least 64 input channels whose column matrix (written and read once) stays below 128 MB -- the GEMM runs at 85-125
-    TFLOP/s against 35-95 for the direct kernels; at 170 MB it is a tie, at 300 MB the column traffic loses."""
-    n, c, h, w = x.shape
-    if _BATCH_INVARIANT_ROUTES[0]:
-        n = 1               # batch-invariant mode (functional.set_batch_invariant): the route must not depend on the batch size
-    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-    return c >= 64 and 4 * n * c * 9 * ho * wo <= (128 << 20)
-
-
-_BATCH_INVARIANT_ROUTES = [False]
 
 
 def _deconv(x, P, name, act=True, backend=None):

@@ -29,6 +29,17 @@ LAYERS_2 = [  # FlowNet2 batch 4 @768x384 (FlowNetS stage)
     ("conv5_1", 4, 512, 12, 24, 512, 3, 1, 1), ("conv6", 4, 512, 12, 24, 1024, 3, 2, 1), ("conv6_1", 4, 1024, 6, 12, 1024, 3, 1, 1)]
 
 
+
+def lib_gemm_conv(x, w, b, s, p):
+    """The route these layers took until round 4, kept HERE as the A/B reference only: own im2col, one batched library GEMM, own bias +
+    ReLU pass (the product no longer calls a library GEMM)."""
+    N, Cin, H, W = x.shape
+    Cout, k = w.shape[0], w.shape[2]
+    col = ops.im2col_forward(x, k, p, s)
+    y = torch.matmul(w.reshape(Cout, Cin * k * k), col).view(N, Cout, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1)
+    return ops.bias_leaky_relu_(y, b, 0.1)
+
+
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm):
         fn()
@@ -64,7 +75,7 @@ def main():
         t_lib = timeit(lambda: Fn.conv_bias_leaky_relu(F.conv2d(x, w, None, stride=s, padding=p), b, 0.1), a.iters)
         line = f"{name:8s} [{N},{Cin},{H},{W}]->{Cout} k{k}s{s}  {gf:6.2f} GF | MIOpen+bias/act {t_lib:7.1f} us {gf / t_lib * 1e3:6.1f} TF"
         if k == 3:
-            t_gemm = timeit(lambda: Fn.conv_gemm_relu(x, w, b, s, p, 0.1), a.iters)
+            t_gemm = timeit(lambda: lib_gemm_conv(x, w, b, s, p), a.iters)
             line += f" | im2col+GEMM {t_gemm:7.1f} us {gf / t_gemm * 1e3:6.1f} TF"
         print(line, flush=True)
         if k == 3 and s == 1 and ops.conv_wino_supported(Cin, H, W, Cout, p):

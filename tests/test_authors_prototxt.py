@@ -182,12 +182,14 @@ def test_authors_style_net_computes_the_flow_of_nets_py(w, h, batch):
     i0 = torch.from_numpy(rng.integers(0, 256, (batch, 3, h, w)).astype(np.float32)).cuda()
     i1 = torch.from_numpy(np.roll(i0.cpu().numpy(), (1, -2), (2, 3)).copy()).cuda()
     Fn.set_batch_invariant(True)
+    fallbacks = Fn.LIBRARY_FALLBACKS[0]
     try:
         n = _build(w, h, "cuda")
         if batch != 1:
             n.reshape_inputs(batch)
         assert n.CopyTrainedLayersFrom(caffemodel.read_caffemodel(v1_caffemodel(P))) == []
         got = n.forward(img0=i0, img1=i1)["predict_flow_final"]
+        assert Fn.LIBRARY_FALLBACKS[0] == fallbacks, "a layer of the authors'-style net left the own kernels"
         with torch.no_grad():
             want = nets.deploy_forward("C", Pd, i0, i1, Fn, mean=torch.from_numpy(MEAN).cuda())
         again = n.forward(img0=i0, img1=i1)["predict_flow_final"]

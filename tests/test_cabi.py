@@ -153,15 +153,3 @@ def test_flo_bytes_roundtrip_on_synthetic_blobs(tmp_path):      # the reference-
         f.write(raw[:-4])
     with pytest.raises(ValueError, match="corrupted"):
         flo.read_flo(p)
-
-
-def test_tuned_gemm_table_is_well_formed():
-    """flownet2_amd/tuning/gemm_gfx950.csv: TunableOp validators for gfx950 + one line per GEMM shape; look-up only."""
-    from flownet2_amd import tuning
-    lines = [l.strip().split(",") for l in open(tuning.CSV) if l.strip()]
-    validators = {l[1]: l[2] for l in lines if l[0] == "Validator"}
-    assert validators.get("GCN_ARCH_NAME", "").startswith("gfx950") and "HIPBLASLT_VERSION" in validators and "ROCBLAS_VERSION" in validators
-    entries = [l for l in lines if l[0] != "Validator"]
-    assert len(entries) >= 9 and all(len(l) == 4 and l[0].startswith("Gemm") and float(l[3]) > 0 for l in entries)
-    assert len({l[1] for l in entries}) == len(entries), "one selection per GEMM shape"
-    assert tuning.enable() is False or True      # no GPU here: must not raise

@@ -13,7 +13,8 @@ import oracle
 
 CASES = [  # N, Cin, H, W, Cout, s, p    (odd widths -> dword DMA, widths % 4 == 0 -> 16-byte DMA; ragged batches; one sample larger than a tile block)
     (8, 16, 5, 7, 64, 1, 1), (3, 8, 10, 14, 128, 1, 1), (5, 16, 10, 14, 64, 2, 1), (2, 8, 20, 28, 64, 2, 1), (2, 16, 12, 24, 64, 1, 1),
-    (1, 8, 40, 56, 64, 2, 1), (3, 24, 6, 12, 64, 1, 0), (2, 8, 14, 32, 128, 1, 1), (1, 32, 24, 48, 64, 2, 1), (7, 8, 7, 16, 64, 2, 1)]
+    (1, 8, 40, 56, 64, 2, 1), (3, 24, 6, 12, 64, 1, 0), (2, 8, 14, 32, 128, 1, 1), (1, 32, 24, 48, 64, 2, 1), (7, 8, 7, 16, 64, 2, 1),
+    (2, 16, 4, 6, 64, 1, 1), (2, 16, 4, 6, 128, 2, 1), (2, 24, 2, 3, 64, 1, 1), (1, 8, 3, 4, 64, 1, 1), (1, 8, 1, 1, 64, 1, 1)]      # planes smaller than one 64-slot DMA run (a 192x128 image at 1/32 .. 1/64)
 
 
 def rnd(shape, seed, scale=1.0):
@@ -57,7 +58,8 @@ def test_oracle_plane_conv_k4s2_matches_fp64_convolution(case):
 
 
 CASES_K5 = [  # N, Cin, H, W, Cout: Convolution{5, 2, 2} (conv2 / conv3 of the encoders) on one or two samples
-    (1, 16, 28, 64, 64), (1, 8, 15, 29, 64), (2, 24, 16, 24, 128), (1, 16, 56, 128, 64), (3, 8, 9, 13, 64), (1, 32, 30, 256, 64)]
+    (1, 16, 28, 64, 64), (1, 8, 15, 29, 64), (2, 24, 16, 24, 128), (1, 16, 56, 128, 64), (3, 8, 9, 13, 64), (1, 32, 30, 256, 64),
+    (2, 16, 28, 64, 64), (4, 16, 64, 96, 128), (4, 32, 32, 48, 256), (3, 8, 20, 36, 64)]      # row bands of several samples
 
 
 @pytest.mark.parametrize("case", CASES_K5[:3])
@@ -228,7 +230,8 @@ def test_conv_plane_at_flownet_shapes(layer):
 
 # ------------------------------------------------------------------------------------------------ deconvolution 4x4 / stride 2 / pad 1
 DECONV_CASES = [  # N, Cin, H, W, Cout     (Cin not a multiple of 4 / 8: the refinement stages concatenate 2 flow channels)
-    (8, 16, 5, 7, 64), (3, 10, 10, 14, 128), (2, 26, 20, 28, 64), (1, 6, 40, 56, 64), (2, 16, 6, 12, 64), (5, 32, 7, 16, 64), (1, 9, 12, 24, 128)]
+    (8, 16, 5, 7, 64), (3, 10, 10, 14, 128), (2, 26, 20, 28, 64), (1, 6, 40, 56, 64), (2, 16, 6, 12, 64), (5, 32, 7, 16, 64), (1, 9, 12, 24, 128),
+    (2, 16, 2, 3, 64), (1, 10, 1, 1, 64), (3, 8, 4, 6, 128)]      # planes smaller than one DMA run
 
 
 def torch64_deconv(x, w, b, relu):

@@ -292,8 +292,11 @@ def test_hip_kernels_match_reference_kernels(gold):
         x, w, b = MG.stock_inputs("upsample_flow")
         close(ops.upsample_flow_deconv_forward(dev(x), dev(w), dev(b)).cpu().numpy(), gold["stock_upsample_flow"], 2e-6)
         x, w, b = MG.stock_inputs("deconv")
-        wt = dev(w).reshape(w.shape[0], -1).t().contiguous()
-        close(Fn.deconv_gemm_relu(dev(x), wt, dev(b), w.shape[1]).cpu().numpy(), gold["stock_deconv_relu"], 1e-5)
-        x, w, b = MG.stock_inputs("conv3x3")
-        close(Fn.conv_gemm_relu(dev(x), dev(w), dev(b), 2, 1, 0.1).cpu().numpy(), gold["stock_conv3x3s2_relu"], 1e-5)
+        # 12 -> 8 / 12 -> 16 channels on 5x7 / 9x11 maps: outside every own kernel family (whole channel quads, 16-channel groups): the
+        # layers' last resort, the library convolution + our bias / ReLU pass
+        from flownet2_amd import nets
+        with torch.no_grad():
+            close(nets.deconv_forward(dev(x), dev(w), dev(b), True, Fn).cpu().numpy(), gold["stock_deconv_relu"], 1e-5)
+            x, w, b = MG.stock_inputs("conv3x3")
+            close(nets.conv_forward(dev(x), dev(w), dev(b), 2, 1, True, Fn).cpu().numpy(), gold["stock_conv3x3s2_relu"], 1e-5)
         close(ops.bias_leaky_relu_(dev(gold["stock_conv3x3s2_nobias"]), dev(b), 0.1).cpu().numpy(), gold["stock_conv3x3s2_relu"], 1e-6)

@@ -510,16 +510,20 @@ def test_deconv_via_gemm_and_col2im(case, relu):
     assert_close(got, ref.numpy().astype(np.float32), 3e-6, "deconv via col2im vs torch fp64")
 
 
-def test_gemm_conv_paths_match_library_convolutions():
-    """functional.conv_gemm_relu / deconv_gemm_relu (im2col + library GEMM + our passes) vs MIOpen's direct kernels."""
+def test_small_conv_and_gemm_deconv_paths_match_library_convolutions():
+    """functional.conv_mfma_relu on a small map (the layers that went to im2col + a library GEMM until round 4) and deconv_gemm_relu
+    (own 1x1 MFMA kernel + our col2im pass) vs MIOpen's direct kernels; no call leaves the own kernels."""
     from flownet2_amd import functional as Fn
-    x, w, b = dev(rand((2, 64, 10, 14), 64)), dev(rand((96, 64, 3, 3), 65, 0.05)), dev(rand((96,), 66))
+    x, w, b = dev(rand((2, 64, 10, 14), 64)), dev(rand((128, 64, 3, 3), 65, 0.05)), dev(rand((128,), 66))
+    before = Fn.LIBRARY_FALLBACKS[0]
     for stride in (1, 2):
         ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1), 0.1)
-        got = Fn.conv_gemm_relu(x, w, b, stride, 1, 0.1)
-        assert_close(host(got), host(ref), 1e-5, "conv via im2col + GEMM")
-        plain = Fn.conv_gemm_relu(x, w, b, stride, 1, 0.1, act=False)           # FlowNet-SD's inter-convolutions: no ReLU
-        assert_close(host(plain), host(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)), 1e-5, "conv via im2col + GEMM, no ReLU")
+        got = Fn.conv_mfma_relu(x, w, b, stride, 1, 0.1, True)
+        assert got is not None
+        assert_close(host(got), host(ref), 1e-5, "small-map conv")
+        plain = Fn.conv_mfma_relu(x, w, b, stride, 1, 0.1, False)           # FlowNet-SD's inter-convolutions: no ReLU
+        assert_close(host(plain), host(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)), 1e-5, "small-map conv, no ReLU")
+    assert Fn.LIBRARY_FALLBACKS[0] == before
     wd = dev(rand((64, 32, 4, 4), 67, 0.05)); bd = dev(rand((32,), 68))
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv_transpose2d(x, wd, bd, stride=2, padding=1), 0.1)
     got = Fn.deconv_gemm_relu(x, wd.reshape(64, 32 * 16).t().contiguous(), bd, 32)
@@ -629,9 +633,11 @@ def test_flownet2_full_size_epe_production_routing(batch, h, w):
     i0 = torch.from_numpy(rng.integers(0, 256, (batch, 3, h, w)).astype(np.float32))
     i1 = torch.from_numpy(np.clip(np.roll(i0.numpy(), (3, -5), (2, 3)) + rng.normal(0, 2, i0.shape), 0, 255).astype(np.float32))
     Pd = {k: v.cuda() for k, v in P.items()}
+    fallbacks = Fn.LIBRARY_FALLBACKS[0]
     with torch.no_grad():
         out = nets.flownet2_deploy_forward(Pd, i0.cuda(), i1.cuda(), Fn).cpu()
         ref = nets.flownet2_deploy_forward(P, i0, i1, cpu_backend)
+    assert Fn.LIBRARY_FALLBACKS[0] == fallbacks, "a Convolution / Deconvolution of FlowNet2 left the own kernels"
     assert tuple(out.shape) == (batch, 2, h, w)
     err = ((out - ref) ** 2).sum(1).sqrt()
     epe = float(err.mean())

@@ -197,11 +197,11 @@ def test_reference_stock_layers_pin_the_fast_paths():
     want = ref.convolution(x, w, b, kernel=4, stride=2, pad=1, deconv=True)
     close(hv(ops.upsample_flow_deconv_forward(dv(x), dv(w), dv(b))), want, 2e-6, "upsample_flow")
     close(oracle.upsample_flow_deconv_forward(x, w, b), want, 2e-6, "upsample_flow oracle")
-    # GEMM route: 3x3 stride 1 / 2 + ReLU, 4x4/2 deconvolution + ReLU
-    x, w, b = rnd((2, 64, 10, 14), 39), rnd((96, 64, 3, 3), 40, 0.05), rnd((96,), 41)
+    # small maps: 3x3 stride 1 / 2 + ReLU (small-map / Winograd kernels), 4x4/2 deconvolution + ReLU (1x1 MFMA kernel + col2im)
+    x, w, b = rnd((2, 64, 10, 14), 39), rnd((128, 64, 3, 3), 40, 0.05), rnd((128,), 41)
     for stride in (1, 2):
         want = ref.convolution(x, w, b, kernel=3, stride=stride, pad=1, relu=True)
-        close(hv(Fn.conv_gemm_relu(dv(x), dv(w), dv(b), stride, 1, 0.1)), want, 1e-5, "conv via im2col + GEMM")
+        close(hv(Fn.conv_mfma_relu(dv(x), dv(w), dv(b), stride, 1, 0.1, True)), want, 1e-5, "conv on the small-map kernels")
         col = oracle.im2col_forward(x, 3, 1, stride)
         np.testing.assert_array_equal(hv(ops.im2col_forward(dv(x), 3, 1, stride)), col)
     wd, bd = rnd((64, 32, 4, 4), 42, 0.05), rnd((32,), 43)
