@@ -9,6 +9,10 @@
 
 #include <cmath>
 
+// No implicit a * b + c fusion in this file: the three LINEAR kernels (per output pixel, lean, integer up-sampling) must round the
+// coefficient products and their sums alike to stay bit-identical to each other; the fused steps are the explicit fmaf() calls.
+#pragma clang fp contract(off)
+
 namespace fn2 {
 
 __device__ __forceinline__ float bicubic_coeff(float x_) {   // :14-20
@@ -145,6 +149,213 @@ __global__ void __launch_bounds__(256) resample_interp(const float* __restrict__
   }
 }
 
+// LINEAR up-sampling by any factor, the identity included (fx, fy <= 1: unit tap scale ax == ay == 1, radius 2 on both axes).
+// The triangle kernel has support 1, so of the 25 taps the reference visits (:75-92) at most 2 x 2 carry a non-zero coefficient: the
+// columns / rows on either side of the source position.  The other in-image taps enter with coefficient +0: for FINITE samples
+// fmaf(+0, tap, sum) == sum bit for bit (the running sum starts at +0 and can never become -0), and wsum likewise -- so they matter
+// only when a sample is NaN / Inf (0 * NaN poisons the sum in the reference).  A workgroup therefore scans the input footprint of its
+// 16 x 64 output tile once (coalesced; it also pulls the rows into the cache), and
+//   * every sample finite (any real image or flow): 4 loads + 4 fmaf per output, in the reference's tap order;
+//   * otherwise: the 25-tap loop of resample_interp, tap for tap.
+// Same bits as resample_interp<false, true, EXTRA> in both cases (tests/test_gpu_parity.py: random sizes, NaN / Inf planted).
+// The chip retires ~40 T lane-instructions/s against 8 TB/s: at 8 bytes per output a streaming kernel that wants a third of the HBM peak
+// has ~100 instructions per output, so everything that depends on the pixel only (tap offsets, the 4 coefficient products, wsum) is
+// computed once per thread and reused for its rows and planes; per output and plane there are 4 loads, 4 fmaf, the division, the store.
+constexpr int kLeanTW = 64, kLeanTH = 32, kLeanRows = 8, kLeanPlanes = 2;     // output tile of a workgroup: 64 columns x 32 rows, thread (tx, ty) takes rows ty, ty + 4, ...
+constexpr int kLeanFR = kLeanTH + 6, kLeanLW = 80;                              // footprint rows (tile + 2 + 3 + rounding), LDS row stride (>= 76 columns)
+constexpr int kLeanScanVec = 3, kLeanScanScalar = 11;                           // footprint <= 38 rows x 76 (70) columns: 16-byte / 4-byte scan items per thread
+
+// The exact rows of resample_linear_lean: resample_interp's 25-tap loop for output column x_out, rows y_first, y_first + 4, ... <= y_last.
+// Not inlined: its loop-invariant coefficient set-up would otherwise be hoisted in front of the plane loop of the caller and executed by
+// every thread of every tile (it was: 250 of the kernel's 400 set-up instructions), for a path real inputs never take.
+template <bool EXTRA>
+__device__ __attribute__((noinline)) void resample_exact_rows(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dst2,
+                                                               const ResampleArgs& a, int x_out, bool live_x, int y_first, int y_last) {
+  const float x_in = x_out * a.fx + a.fy / 2.0f - 0.5f;   // :62
+  const int xr = (int)roundf(x_in);
+  float px[5]; unsigned xo[5], mx = 0u;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int x = xr - 2 + i;
+    const bool okx = x >= 0 && x < a.Win;
+    px[i] = okx ? a.ax * triangle_coeff(a.ax * (x_in - x)) * a.ay : 0.f;
+    xo[i] = okx ? (unsigned)x : 0u;
+    mx |= (okx ? 1u : 0u) << i;
+  }
+  for (int y_out = y_first; y_out <= y_last; y_out += 4) {
+    const float y_in = y_out * a.fy + a.fx / 2.0f - 0.5f;   // :63
+    const int yr = (int)roundf(y_in);
+    float ky[5]; unsigned yo[5], my = 0u;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int y = yr - 2 + j;
+      const bool oky = y >= 0 && y < a.Hin;
+      ky[j] = oky ? triangle_coeff(a.ay * (y_in - y)) : 0.f;
+      yo[j] = oky ? (unsigned)y * a.Win : 0u;
+      my |= (oky ? 1u : 0u) << j;
+    }
+    float sum = 0.f, ws = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const float wt = px[i] * ky[j];
+        const float tap = ((mx >> i) & (my >> j) & 1u) ? src[yo[j] + xo[i]] : 0.f;
+        sum = fmaf(wt, EXTRA ? scaled(tap, a.in_scale) : tap, sum);
+        ws += wt;
+      }
+    const float v = (!ws) ? 0.f : (sum / ws);   // :93
+    if (live_x) {
+      dst[(size_t)y_out * a.Wout + x_out] = v;
+      if (EXTRA && dst2) dst2[(size_t)y_out * a.Wout + x_out] = scaled(v, a.out2_scale);
+    }
+  }
+}
+
+template <bool EXTRA>
+__global__ void __launch_bounds__(256) resample_linear_lean(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ out2, ResampleArgs a) {
+  using f2 = __attribute__((ext_vector_type(2))) float;
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const unsigned hw_out = (unsigned)a.Hout * a.Wout, hw_in = (unsigned)a.Hin * a.Win;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * kLeanTW, y0 = blockIdx.y * kLeanTH;
+  const bool live_x = x0 + tx < a.Wout;
+  const int x_out = live_x ? x0 + tx : a.Wout - 1;     // idle columns compute the last one (valid addresses), store nothing
+  const int xh_out = min(x0 + kLeanTW, a.Wout) - 1, yh_out = min(y0 + kLeanTH, a.Hout) - 1;
+  // ---- footprint of the tile: the rows / columns its 5 x 5 windows can touch (window centre = round(source position); monotonic maps).
+  // Computed first, from the tile corners alone, so that the loads below are in flight while the coefficient tables are built.
+  int fx0 = max((int)roundf(x0 * a.fx + a.fy / 2.0f - 0.5f) - 2, 0), fx1 = min((int)roundf(xh_out * a.fx + a.fy / 2.0f - 0.5f) + 2, a.Win - 1);
+  const int fy0 = max((int)roundf(y0 * a.fy + a.fx / 2.0f - 0.5f) - 2, 0), fy1 = min((int)roundf(yh_out * a.fy + a.fx / 2.0f - 0.5f) + 2, a.Hin - 1);
+  const bool vec = (a.Win & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;       // 16-byte copies of whole aligned column quads
+  if (vec) { fx0 &= ~3; fx1 |= 3; }
+  const unsigned ncol = vec ? (unsigned)(fx1 - fx0 + 1) >> 2 : (unsigned)(fx1 - fx0 + 1);     // items per footprint row (<= 20 / <= 70)
+  const unsigned nitem = ncol * (unsigned)(fy1 - fy0 + 1);
+  const unsigned magic = 0xffffffffu / ncol + 1u;                                               // idx / ncol == umulhi(idx, magic) for idx < 2^16
+  const int c_lo = blockIdx.z * kLeanPlanes;
+  // ---- the footprint of every plane of the group goes to LDS in one sweep of coalesced loads (each sample leaves the L2 once; the four
+  // taps of an output are LDS reads); on the way 0 * sample is summed up: NaN exactly when a sample is NaN / Inf (the reference's own
+  // poisoning term).  Static trip counts: all loads are in flight before the first is waited for.
+  f4 v[kLeanScanVec][kLeanPlanes];
+  if (vec) {
+#pragma unroll
+    for (int it = 0; it < kLeanScanVec; ++it) {
+      const unsigned idx = threadIdx.x + 256u * it;
+      const unsigned r = __umulhi(idx, magic), q = idx - r * ncol;
+      const size_t goff = (size_t)(fy0 + (int)r) * a.Win + fx0 + 4 * q;
+#pragma unroll
+      for (int pl = 0; pl < kLeanPlanes; ++pl)
+        v[it][pl] = idx < nitem ? *reinterpret_cast<const f4*>(in + (size_t)min(c_lo + pl, a.NC - 1) * hw_in + goff) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // ---- coefficient tables of the tile, one entry per thread: 64 columns, 32 rows (the expressions of resample_interp: same bits).
+  // Entry = first tap c (taps c, c + 1: the only ones with |pos - tap| < 1) and the two coefficients (0 for a tap outside the image).
+  __shared__ int s_c[kLeanTW + kLeanTH];
+  __shared__ float s_k[kLeanTW + kLeanTH][2];
+  __shared__ unsigned s_bad;                       // bit pl: plane pl of this workgroup has a NaN / Inf under the tile
+  if (threadIdx.x == 255) s_bad = 0u;
+  if (threadIdx.x < kLeanTW + kLeanTH) {
+    const bool col = threadIdx.x < kLeanTW;
+    const int o = col ? min(x0 + (int)threadIdx.x, a.Wout - 1) : min(y0 + (int)threadIdx.x - kLeanTW, a.Hout - 1);
+    const float pos = col ? o * a.fx + a.fy / 2.0f - 0.5f      // :62
+                          : o * a.fy + a.fx / 2.0f - 0.5f;     // :63
+    const int r = (int)roundf(pos);
+    const int c = pos >= (float)r ? r : r - 1;
+    const int lim = col ? a.Win : a.Hin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = c + i;
+      const bool ok = t >= 0 && t < lim;
+      const float k = col ? a.ax * triangle_coeff(a.ax * (pos - t)) * a.ay : triangle_coeff(a.ay * (pos - t));
+      s_k[threadIdx.x][i] = ok ? k : 0.f;
+    }
+    s_c[threadIdx.x] = c;
+  }
+  __syncthreads();
+  const int cx = s_c[tx];
+  const float pxl[2] = {s_k[tx][0], s_k[tx][1]};
+  __shared__ __attribute__((aligned(16))) float s_img[kLeanPlanes][kLeanFR * kLeanLW];
+  f2 poison[kLeanPlanes];
+#pragma unroll
+  for (int pl = 0; pl < kLeanPlanes; ++pl) poison[pl] = f2{0.f, 0.f};
+  if (vec) {
+#pragma unroll
+    for (int it = 0; it < kLeanScanVec; ++it) {
+      const unsigned idx = threadIdx.x + 256u * it;
+      const unsigned r = __umulhi(idx, magic), q = idx - r * ncol;
+#pragma unroll
+      for (int pl = 0; pl < kLeanPlanes; ++pl) {
+        f4 t = v[it][pl];
+        if constexpr (EXTRA) t *= a.in_scale;
+        poison[pl] = __builtin_elementwise_fma(f2{0.f, 0.f}, f2{t[0], t[1]}, poison[pl]);
+        poison[pl] = __builtin_elementwise_fma(f2{0.f, 0.f}, f2{t[2], t[3]}, poison[pl]);
+        if (idx < nitem) *reinterpret_cast<f4*>(&s_img[pl][r * kLeanLW + 4 * q]) = t;
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int it = 0; it < kLeanScanScalar; ++it) {
+      const unsigned idx = threadIdx.x + 256u * it;
+      const unsigned r = __umulhi(idx, magic), q = idx - r * ncol;
+      const size_t goff = (size_t)(fy0 + (int)r) * a.Win + fx0 + q;
+#pragma unroll
+      for (int pl = 0; pl < kLeanPlanes; ++pl) {
+        float t = idx < nitem ? in[(size_t)min(c_lo + pl, a.NC - 1) * hw_in + goff] : 0.f;
+        if constexpr (EXTRA) t = scaled(t, a.in_scale);
+        poison[pl][0] = fmaf(0.f, t, poison[pl][0]);
+        if (idx < nitem) s_img[pl][r * kLeanLW + q] = t;
+      }
+    }
+  }
+  unsigned badmask = 0u;
+#pragma unroll
+  for (int pl = 0; pl < kLeanPlanes; ++pl) {
+    const float p = poison[pl][0] + poison[pl][1];
+    badmask |= (p != p ? 1u : 0u) << pl;
+  }
+  if (badmask) atomicOr(&s_bad, badmask);
+  __syncthreads();
+  const unsigned verdict = s_bad;
+  // ---- rows: per row the four coefficient products in the reference's order and their sum, shared by the planes; a tap outside the
+  // image has coefficient 0 and reads a (finite) sample of the footprint instead
+  const int xl0 = min(max(cx, 0), a.Win - 1) - fx0, xl1 = min(max(cx + 1, 0), a.Win - 1) - fx0;
+  char* dstb[kLeanPlanes]; char* dst2b[kLeanPlanes];
+#pragma unroll
+  for (int pl = 0; pl < kLeanPlanes; ++pl) {
+    const int c = min(c_lo + pl, a.NC - 1);
+    dstb[pl] = reinterpret_cast<char*>(out + (EXTRA ? top_plane(c, a.C, a.octot, a.oc0) : (size_t)c) * hw_out);
+    dst2b[pl] = (EXTRA && out2) ? reinterpret_cast<char*>(out2 + top_plane(c, a.C, a.o2ctot, a.o2c0) * hw_out) : nullptr;
+  }
+  if (verdict) {      // a NaN / Inf somewhere under this tile: those planes take the 25 taps of the reference, zero coefficients included
+#pragma unroll
+    for (int pl = 0; pl < kLeanPlanes; ++pl)
+      if (c_lo + pl < a.NC && ((verdict >> pl) & 1u))
+        resample_exact_rows<EXTRA>(in + (size_t)(c_lo + pl) * hw_in, reinterpret_cast<float*>(dstb[pl]), reinterpret_cast<float*>(dst2b[pl]), a, x_out, live_x,
+                                   y0 + ty, yh_out);
+  }
+#pragma unroll
+  for (int k = 0; k < kLeanRows; ++k) {
+    const int row = kLeanTW + ty + 4 * k;
+    const int y_out = y0 + ty + 4 * k;
+    const int cy = s_c[row];
+    const f2 kyv = *reinterpret_cast<const f2*>(&s_k[row][0]);
+    const int yl0 = (min(max(cy, 0), a.Hin - 1) - fy0) * kLeanLW, yl1 = (min(max(cy + 1, 0), a.Hin - 1) - fy0) * kLeanLW;
+    const float w0 = pxl[0] * kyv[0], w1 = pxl[1] * kyv[0], w2 = pxl[0] * kyv[1], w3 = pxl[1] * kyv[1];
+    const float wsum = (((0.f + w0) + w1) + w2) + w3;
+    const unsigned boff = 4u * ((unsigned)y_out * (unsigned)a.Wout + (unsigned)x_out);       // < 2^31 * 4: checked by the launcher
+    const bool live = live_x && y_out <= yh_out;
+#pragma unroll
+    for (int pl = 0; pl < kLeanPlanes; ++pl) {
+      const float t0 = s_img[pl][yl0 + xl0], t1 = s_img[pl][yl0 + xl1], t2 = s_img[pl][yl1 + xl0], t3 = s_img[pl][yl1 + xl1];   // (already scaled)
+      const float sum = fmaf(w3, t3, fmaf(w2, t2, fmaf(w1, t1, fmaf(w0, t0, 0.f))));
+      const float v = (!wsum) ? 0.f : (sum / wsum);   // :93
+      if (live && c_lo + pl < a.NC && !((verdict >> pl) & 1u)) {
+        *reinterpret_cast<float*>(dstb[pl] + boff) = v;
+        if (EXTRA && dst2b[pl]) *reinterpret_cast<float*>(dst2b[pl] + boff) = scaled(v, a.out2_scale);
+      }
+    }
+  }
+}
+
 // LINEAR up-sampling by an exact integer factor F on both axes (the x4 flow up-sampling behind every FlowNet2 stage and the deploy
 // head).  With fx = fy = 1 / F the F x F outputs of one INPUT pixel (i, j) share their tap window: x_in = j + (ph + 0.5) / F - 0.5
 // rounds to j for every phase, so the reference's loop (:75-92) visits the same 5 x 5 input taps for all of them and only the
@@ -264,7 +475,7 @@ FN2_API int fn2_resample_forward_slices(const float* in, float in_scale, float* 
   a.ay = 1.0f / (antialias ? a.fy : 1.0f);                      // :72
   a.rx = (a.fx < 1.0f) ? 2 : (int)std::ceil((float)kernel_width / a.ax);   // :73
   a.ry = (a.fy < 1.0f) ? 2 : (int)std::ceil((float)kernel_width / a.ay);   // :74
-  if ((long long)Hout * Wout >= (1ll << 31) || (long long)Hin * Win >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "resample: plane too large");
+  if ((long long)Hout * Wout >= (1ll << 29) || (long long)Hin * Win >= (1ll << 29)) return fail(FN2_ERR_UNSUPPORTED, "resample: plane too large");      // 32-bit byte offsets inside a plane
   const unsigned bx = (unsigned)(((long long)Hout * Wout + 255) / 256);
   // planes per thread: amortise the per-pixel work, but keep >= ~2k workgroups in flight
   a.ppt = 1;
@@ -290,6 +501,14 @@ FN2_API int fn2_resample_forward_slices(const float* in, float in_scale, float* 
     return check_launch("resample_forward");
   }
   const bool ex = in_scale != 1.0f || out2 || top_channels != C;
+  if (type == FN2_RESAMPLE_LINEAR && fast && a.ax == 1.0f && a.ay == 1.0f && a.rx == 2 && a.ry == 2 && a.fx <= 1.0f && a.fy <= 1.0f && !g_resample_generic) {
+    const unsigned gx = (unsigned)((Wout + kLeanTW - 1) / kLeanTW), gy = (unsigned)((Hout + kLeanTH - 1) / kLeanTH);
+    const unsigned gz = (unsigned)((a.NC + kLeanPlanes - 1) / kLeanPlanes);
+    if (gy > 65535u || gz > 65535u) return fail(FN2_ERR_UNSUPPORTED, "resample: too many tiles / planes");
+    if (ex) hipLaunchKernelGGL((resample_linear_lean<true>), dim3(gx, gy, gz), dim3(256), 0, st, in, out, out2, a);
+    else hipLaunchKernelGGL((resample_linear_lean<false>), dim3(gx, gy, gz), dim3(256), 0, st, in, out, out2, a);
+    return check_launch("resample_forward");
+  }
 #define FN2_RS(K_) do { if (ex) hipLaunchKernelGGL((K_<true>), grid, dim3(256), 0, st, in, out, out2, a); \
                         else hipLaunchKernelGGL((K_<false>), grid, dim3(256), 0, st, in, out, out2, a); } while (0)
 #define FN2_RSI(C_, F_) do { if (ex) hipLaunchKernelGGL((resample_interp<C_, F_, true>), grid, dim3(256), 0, st, in, out, out2, a); \

@@ -25,7 +25,10 @@ def timeit(f, iters=100, rounds=5):
     torch.cuda.synchronize()
     return statistics.median(marks[r].elapsed_time(marks[r + 1]) / iters * 1e3 for r in range(rounds))
 rows = []
+ONLY = [w for w in os.environ.get("FN2_MB_ONLY", "").split(",") if w]      # substrings: run only the matching workloads
 def add(name, f, nbytes):
+    if ONLY and not any(w in name for w in ONLY):
+        return
     t = timeit(f)
     rows.append((name, t, nbytes, nbytes / t / 1e3))
 g = torch.Generator(device=dev).manual_seed(0)

@@ -318,6 +318,36 @@ def test_resample_integer_upsampling_path_equals_the_per_pixel_kernel(shape):
     assert_close(np.nan_to_num(got, nan=0.0, posinf=0.0, neginf=0.0), np.nan_to_num(orc, nan=0.0, posinf=0.0, neginf=0.0), 1e-6, "resample x%d vs oracle" % F)
 
 
+@pytest.mark.parametrize("shape", [((24, 48), (24, 48)), ((436, 1024), (448, 1024)), ((30, 40), (32, 64)), ((9, 12), (9, 12)), ((6, 8), (24, 32)),
+                                   ((50, 37), (64, 64)), ((17, 23), (33, 70)), ((1, 1), (5, 9)), ((3, 200), (4, 256)), ((40, 30), (40, 33)),
+                                   ((16, 20), (16, 10)), ((20, 16), (10, 16))])
+@pytest.mark.parametrize("poison", [False, True])
+def test_resample_lean_linear_path_equals_the_per_pixel_kernel(shape, poison):
+    """LINEAR with unit tap scale (identity, up-sampling, non-antialiased calls) runs 4 taps per output when the workgroup's input
+    footprint is finite, the reference's 25-tap loop (resample_layer.cu:75-92) otherwise: same BITS as the per-output-pixel kernel either
+    way, NaN / Inf poisoning through zero-coefficient taps included."""
+    (Hin, Win), (Hout, Wout) = shape
+    x = rand((2, 3, Hin, Win), 93)
+    if poison:
+        x[0, 1, Hin // 2, Win // 3] = np.nan
+        x[1, 2, Hin - 1, Win - 1] = np.inf
+        x[1, 0, 0, 0] = -np.inf
+    for antialias in (False, True):
+        got = host(ops.resample_forward(dev(x), Hout, Wout, ops.LINEAR, antialias))
+        ops.set_resample_generic(True)
+        try:
+            want = host(ops.resample_forward(dev(x), Hout, Wout, ops.LINEAR, antialias))
+        finally:
+            ops.set_resample_generic(False)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+        if poison:
+            assert np.isnan(want).any() and not np.isnan(want).all()
+        elif (Hin, Win) == (Hout, Wout):
+            np.testing.assert_array_equal(got, x)
+
+
 def test_resample_rejects_area():
     import flownet2_amd
     with pytest.raises(flownet2_amd.Fn2Error):
