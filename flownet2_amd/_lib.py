@@ -18,6 +18,7 @@ EXPORTS = [
     "fn2_flow_warp_forward", "fn2_flow_warp_forward_slices", "fn2_flow_warp_backward_workspace_bytes", "fn2_flow_warp_backward",
     "fn2_resample_forward", "fn2_resample_forward_slices",
     "fn2_l1loss_workspace_bytes", "fn2_l1loss_forward", "fn2_l1loss_backward",
+    "fn2_l1loss_multi_workspace_bytes", "fn2_l1loss_multi_sync_bytes", "fn2_l1loss_forward_multi", "fn2_l1loss_backward_multi",
     "fn2_channel_norm_forward", "fn2_channel_norm_forward_slices", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward", "fn2_upsample_flow_deconv_forward_into",
@@ -81,6 +82,11 @@ class L1LossParams(C.Structure):
                 ("normalize_by_num_entries", C.c_int), ("epsilon", C.c_float), ("plateau", C.c_float)]
 
 
+class L1LossScale(C.Structure):
+    _fields_ = [("bottom0", C.c_void_p), ("bottom1", C.c_void_p), ("bottom0_diff", C.c_void_p), ("bottom1_diff", C.c_void_p),
+                ("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("loss_weight", C.c_float)]
+
+
 _lib = None
 
 
@@ -117,6 +123,12 @@ def lib():
     L.fn2_l1loss_workspace_bytes.restype = sz
     L.fn2_l1loss_forward.argtypes = [C.POINTER(L1LossParams), fp, fp, fp, i, i, i, i, vp, sz, vp]
     L.fn2_l1loss_backward.argtypes = [C.POINTER(L1LossParams), fp, fp, C.c_float, fp, fp, i, i, i, i, vp, sz, vp]
+    L.fn2_l1loss_multi_workspace_bytes.argtypes = [i]
+    L.fn2_l1loss_multi_workspace_bytes.restype = sz
+    L.fn2_l1loss_multi_sync_bytes.argtypes = []
+    L.fn2_l1loss_multi_sync_bytes.restype = sz
+    L.fn2_l1loss_forward_multi.argtypes = [C.POINTER(L1LossParams), i, C.POINTER(L1LossScale), fp, fp, vp, sz, vp, vp]
+    L.fn2_l1loss_backward_multi.argtypes = [C.POINTER(L1LossParams), i, C.POINTER(L1LossScale), fp, vp, sz, vp]
     L.fn2_channel_norm_forward.argtypes = [fp, fp, i, i, i, i, vp]
     L.fn2_channel_norm_forward_slices.argtypes = [fp, i, i, fp, i, i, fp, i, i, i, i, i, i, vp]
     L.fn2_channel_norm_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]

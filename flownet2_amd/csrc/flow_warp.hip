@@ -134,16 +134,28 @@ __global__ void __launch_bounds__(kWarpGatherThreads) warp_bwd_gather(const floa
       for (int j = 0; j < 8; ++j) if (c0 + j < c1) acc[j] += gsrc[(size_t)j * wh] * w;
     };
     // collect the candidate sources: lists of the cells (y, x), (y, x-1), (y-1, x), (y-1, x-1)
+    // (the four list heads are loaded together and the lists walked side by side: one memory latency per list LEVEL instead of one per
+    // list element -- the order the candidates arrive in does not matter, they are sorted below)
     int cnt = 0;
     bool overflow = false;
+    int e[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const int cy = y - (d >> 1), cx = x - (d & 1);
-      if (cy < 0 || cx < 0) continue;
-      for (int e = hd[(unsigned)cy * W + cx]; e >= 0; e = nx[e]) {
-        if (cnt < kWarpListMax) srcs[cnt][tid] = e; else overflow = true;
-        ++cnt;
-      }
+      e[d] = (cy < 0 || cx < 0) ? -1 : hd[(unsigned)cy * W + cx];
+    }
+    while ((e[0] & e[1] & e[2] & e[3]) != -1 && (e[0] >= 0 || e[1] >= 0 || e[2] >= 0 || e[3] >= 0)) {
+      int nxt[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) nxt[d] = e[d] >= 0 ? nx[e[d]] : -1;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        if (e[d] >= 0) {
+          if (cnt < kWarpListMax) srcs[cnt][tid] = e[d]; else overflow = true;
+          ++cnt;
+        }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) e[d] = nxt[d];
     }
     if (!overflow) {
       for (int i = 1; i < cnt; ++i) {                  // insertion sort, ascending source index
@@ -180,7 +192,10 @@ __global__ void __launch_bounds__(256) warp_bwd_flow(const float* __restrict__ i
   for (unsigned g = blockIdx.y; g < (unsigned)N * cgroups; g += gridDim.y) {
     const int n = g / cgroups, cg = g - n * cgroups;
     const WarpTap t = warp_taps(x, y, flow[(size_t)(2 * n) * wh + pix], flow[(size_t)(2 * n + 1) * wh + pix], H, W);
-    if (!t.inside) continue;                                             // diffs stay 0 (:478-479)
+    if (!t.inside) {                                                     // diffs are 0 (:478-479)
+      if (cgroups == 1) { flow_diff[(size_t)(2 * n) * wh + pix] = 0.f; flow_diff[(size_t)(2 * n + 1) * wh + pix] = 0.f; }      // (no memset in front of this form)
+      continue;
+    }
     float du = 0.f, dv = 0.f;
     const int c0 = cg * cpg, c1 = min(C, c0 + cpg);
     for (int c = c0; c < c1; ++c) {
@@ -280,12 +295,13 @@ FN2_API int fn2_flow_warp_backward(const float* image, const float* flow, const 
     if (hipMemsetAsync(image_diff, 0, sizeof(float) * wh * C * N, st) != hipSuccess)       // :507
       return fail(FN2_ERR_LAUNCH, "flow_warp_backward: hipMemsetAsync failed");
   }
-  if (hipMemsetAsync(flow_diff, 0, sizeof(float) * wh * 2 * N, st) != hipSuccess)          // :479 / :508
-    return fail(FN2_ERR_LAUNCH, "flow_warp_backward: hipMemsetAsync failed");
+  // channels per thread: all of them for image-like blobs (plain stores: every pixel is written, no memset), 8 for feature blobs
+  const int cpg = C <= 16 ? C : 8;
+  const int cgroups = (C + cpg - 1) / cpg;
+  if (!propagate_flow || cgroups > 1 || N > 65535)                                           // :479 / :508
+    if (hipMemsetAsync(flow_diff, 0, sizeof(float) * wh * 2 * N, st) != hipSuccess)
+      return fail(FN2_ERR_LAUNCH, "flow_warp_backward: hipMemsetAsync failed");
   if (propagate_flow) {
-    // channels per thread: all of them for image-like blobs (plain stores), 8 for feature blobs
-    const int cpg = C <= 16 ? C : 8;
-    const int cgroups = (C + cpg - 1) / cpg;
     const long long groups = (long long)N * cgroups;
     hipLaunchKernelGGL(warp_bwd_flow, dim3(bx, (unsigned)(groups < 65535 ? groups : 65535)), dim3(256), 0, st, image, flow, warped_diff,
                        flow_diff, N, C, H, W, cgroups, cpg);

@@ -179,6 +179,39 @@ def l1_loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, n
     return _L1Loss.apply(b0.contiguous(), b1.contiguous() if b1 is not None else None, p)
 
 
+class _L1LossMulti(torch.autograd.Function):
+    """All loss layers of a net: forward and backward one launch each, the weighted sum included; the upstream gradient stays on the
+    device (no host read of a device scalar: _L1Loss's float(g) drains the stream once per layer)."""
+
+    @staticmethod
+    def forward(ctx, params, weights, n, *blobs):
+        b0, b1 = list(blobs[:n]), list(blobs[n:])
+        total, losses, ws = ops.l1loss_forward_multi(params, b0, b1, weights)
+        ctx.params, ctx.weights, ctx.n, ctx.ws = params, weights, n, ws
+        ctx.save_for_backward(*blobs)
+        ctx.mark_non_differentiable(losses)
+        return total, losses
+
+    @staticmethod
+    def backward(ctx, g, _g_losses):
+        n = ctx.n
+        blobs = ctx.saved_tensors
+        b0, b1 = list(blobs[:n]), list(blobs[n:])
+        need1 = any(ctx.needs_input_grad[3 + n:])
+        d0, d1 = ops.l1loss_backward_multi(ctx.params, b0, b1, ctx.weights, g.contiguous(), ctx.ws, need1=need1)
+        grads = [d if ctx.needs_input_grad[3 + k] else None for k, d in enumerate(d0)]
+        grads += [d if ctx.needs_input_grad[3 + n + k] else None for k, d in enumerate(d1)]
+        return (None, None, None) + tuple(grads)
+
+
+def l1_loss_multi(preds, targets, weights, l2_per_location=False, l2_prescale_by_channels=False, normalize_by_num_entries=False,
+                  epsilon=1e-2, plateau=0.0):
+    """sum_k weights[k] * L1Loss(preds[k], targets[k]) -- the loss layers of a training net -- as (total, per-scale losses)."""
+    p = ops.l1_params(l2_per_location, l2_prescale_by_channels, normalize_by_num_entries, epsilon, plateau)
+    blobs = [t.contiguous() for t in preds] + [t.contiguous() for t in targets]
+    return _L1LossMulti.apply(p, tuple(float(w) for w in weights), len(preds), *blobs)
+
+
 class _PredictFlow(torch.autograd.Function):
     """predict_flow (Convolution{3,1,1} C -> 2): own forward (csrc/flow_head.hip) and own backward (csrc/flow_head_bwd.hip: weight,
     bias and bottom gradients as streaming kernels over NCHW -- a 2-channel side cannot feed a matrix tile)."""

@@ -418,6 +418,12 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
 def multiscale_loss(flows, gt_flow, backend):
     """Training loss: per scale Downsample(GT * 0.05) -> L1Loss{l2_per_location, normalize_by_num_entries}."""
     gt = gt_flow * (1.0 / FLOW_SCALE)
+    if hasattr(backend, "l1_loss_multi") and gt.is_cuda:
+        # the five loss layers in one launch per direction, the weighted sum (Net::ForwardFromTo's loss += ...) included
+        scales = list(LOSS_WEIGHTS.items())
+        preds = [flows[s] for s, _ in scales]
+        tgts = [backend.downsample(gt, p.shape[2], p.shape[3]) for p in preds]
+        return backend.l1_loss_multi(preds, tgts, [w for _, w in scales], l2_per_location=True, normalize_by_num_entries=True)[0]
     total = 0.0
     for s, w in LOSS_WEIGHTS.items():
         pred = flows[s]

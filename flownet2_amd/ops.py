@@ -239,6 +239,54 @@ def l1loss_backward(p: L1LossParams, bottom0, bottom1, top_diff: float, workspac
     return d0, d1
 
 
+_L1_SYNC = {}       # (device, stream) -> the zeroed arrival counters of fn2_l1loss_forward_multi (every call leaves them zero)
+
+
+def _l1_scales(bottoms0, bottoms1, weights, diffs0=None, diffs1=None):
+    n = len(bottoms0)
+    arr = (_lib.L1LossScale * n)()
+    for k in range(n):
+        b0 = _chk(bottoms0[k], "bottom[0]")
+        b1 = _chk(bottoms1[k], "bottom[1]") if bottoms1 is not None and bottoms1[k] is not None else None
+        if b1 is not None and b1.shape != b0.shape:
+            raise ValueError("L1Loss: bottom blobs must have the same shape")
+        N, Cc, H, W = b0.shape
+        arr[k].bottom0, arr[k].bottom1 = b0.data_ptr(), (b1.data_ptr() if b1 is not None else None)
+        arr[k].bottom0_diff = diffs0[k].data_ptr() if diffs0 is not None else None
+        arr[k].bottom1_diff = diffs1[k].data_ptr() if diffs1 is not None and diffs1[k] is not None else None
+        arr[k].N, arr[k].C, arr[k].H, arr[k].W = N, Cc, H, W
+        arr[k].loss_weight = float(weights[k])
+    return arr
+
+
+def l1loss_forward_multi(p: L1LossParams, bottoms0, bottoms1, weights):
+    """Every L1Loss layer of a net in one launch (csrc/l1loss.hip: l1loss_fwd_multi).  Returns (total [0-axis device tensor] =
+    sum_k weights[k] * loss_k in list order, losses [n], workspace); per scale bit-identical to l1loss_forward."""
+    n = len(bottoms0)
+    dev = bottoms0[0].device
+    ws = torch.empty(int(_lib.lib().fn2_l1loss_multi_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    key = (dev.index, int(torch.cuda.current_stream().cuda_stream))
+    sync = _L1_SYNC.get(key)
+    if sync is None:
+        sync = _L1_SYNC[key] = torch.zeros(int(_lib.lib().fn2_l1loss_multi_sync_bytes()), dtype=torch.uint8, device=dev)
+    losses = torch.empty((n,), device=dev, dtype=torch.float32)
+    total = torch.empty((), device=dev, dtype=torch.float32)
+    arr = _l1_scales(bottoms0, bottoms1, weights)
+    check(_lib.lib().fn2_l1loss_forward_multi(C.byref(p), n, arr, _ptr(losses), _ptr(total), _ptr(ws), ws.numel(), _ptr(sync), _stream()))
+    return total, losses, ws
+
+
+def l1loss_backward_multi(p: L1LossParams, bottoms0, bottoms1, weights, total_diff, workspace, need1=False):
+    """Gradients of every scale for d(objective) / d(total) = total_diff (a DEVICE scalar tensor, or None for 1) in one launch."""
+    n = len(bottoms0)
+    d0 = [torch.empty_like(b) for b in bottoms0]
+    d1 = [torch.empty_like(b) if (need1 and bottoms1 is not None and bottoms1[k] is not None) else None for k, b in enumerate(bottoms0)]
+    arr = _l1_scales(bottoms0, bottoms1, weights, d0, d1)
+    td = _chk(total_diff.reshape(1), "total_diff", ndim=1) if total_diff is not None else None
+    check(_lib.lib().fn2_l1loss_backward_multi(C.byref(p), n, arr, _ptr(td), _ptr(workspace), workspace.numel(), _stream()))
+    return d0, d1
+
+
 def channel_norm_forward(x):
     x = _chk(x, "bottom[0]")
     N, Cc, H, W = x.shape

@@ -202,6 +202,27 @@ int fn2_l1loss_backward(const fn2_l1loss_params* p, const float* bottom0, const 
                         int N, int C, int H, int W,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* All L1Loss layers of a net in ONE launch per direction (FlowNet's training prototxts hold five: flow_loss2 .. flow_loss6, each with
+ * its loss_weight; Net::ForwardFromTo adds loss_weight * loss in layer order, net.cpp:565-579 / layer.hpp:434-440).  Per scale the
+ * results are bit-identical to fn2_l1loss_forward / fn2_l1loss_backward with top_diff = loss_weight * total_diff[0].
+ *   losses: DEVICE float[nscales] or NULL; total: DEVICE float[1] = sum_s loss_weight[s] * loss[s] (scale order, float) or NULL;
+ *   total_diff: DEVICE float[1] (the objective's derivative w.r.t. total; NULL = 1): no host read of a device scalar anywhere;
+ *   workspace: fn2_l1loss_multi_workspace_bytes(nscales), filled by the forward, read by the backward;
+ *   sync: fn2_l1loss_multi_sync_bytes() of device memory that is ZERO before the first call (every call leaves it zero; one per
+ *   stream that may run a forward concurrently). */
+typedef struct fn2_l1loss_scale {
+  const float* bottom0; const float* bottom1;   /* bottom1 may be NULL */
+  float* bottom0_diff; float* bottom1_diff;     /* backward only; bottom1_diff may be NULL */
+  int N, C, H, W;
+  float loss_weight;
+} fn2_l1loss_scale;
+size_t fn2_l1loss_multi_workspace_bytes(int nscales);
+size_t fn2_l1loss_multi_sync_bytes(void);
+int fn2_l1loss_forward_multi(const fn2_l1loss_params* p, int nscales, const fn2_l1loss_scale* scales, float* losses, float* total,
+                             void* workspace, size_t workspace_bytes, void* sync, void* stream);
+int fn2_l1loss_backward_multi(const fn2_l1loss_params* p, int nscales, const fn2_l1loss_scale* scales, const float* total_diff,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ChannelNorm  (type: "ChannelNorm")
  *   forward <- ChannelNormLayer::Forward_gpu, src/caffe/layers/channel_norm_layer.cu:50-67

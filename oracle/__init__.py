@@ -172,6 +172,44 @@ def l1loss_backward(p: L1Params, b0, b1, top_diff, normalize_coeff):
     return d0, d1
 
 
+class L1Scale(C.Structure):
+    _fields_ = [("bottom0", C.c_void_p), ("bottom1", C.c_void_p), ("bottom0_diff", C.c_void_p), ("bottom1_diff", C.c_void_p),
+                ("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("loss_weight", C.c_float)]
+
+
+def _l1_scales(b0s, b1s, weights, d0s=None, d1s=None):
+    arr = (L1Scale * len(b0s))()
+    for k, b0 in enumerate(b0s):
+        arr[k].bottom0 = b0.ctypes.data
+        arr[k].bottom1 = b1s[k].ctypes.data if b1s[k] is not None else None
+        arr[k].bottom0_diff = d0s[k].ctypes.data if d0s is not None else None
+        arr[k].bottom1_diff = d1s[k].ctypes.data if d1s is not None and d1s[k] is not None else None
+        arr[k].N, arr[k].C, arr[k].H, arr[k].W = b0.shape
+        arr[k].loss_weight = float(weights[k])
+    return arr
+
+
+def l1loss_forward_multi(p: L1Params, b0s, b1s, weights):
+    """(total, losses [n], norms [n]) of the loss layers of a net, net.cpp:565-579 order."""
+    b0s = [_f32(b) for b in b0s]
+    b1s = [_f32(b) if b is not None else None for b in b1s]
+    n = len(b0s)
+    losses, norms, total = np.empty(n, np.float32), np.empty(n, np.float32), C.c_float()
+    _check(lib().fn2_l1loss_forward_multi_cpu(C.byref(p), n, _l1_scales(b0s, b1s, weights), _p(losses), _p(norms), C.byref(total)), "l1loss_forward_multi")
+    return total.value, losses, norms
+
+
+def l1loss_backward_multi(p: L1Params, b0s, b1s, weights, total_diff, norms):
+    b0s = [_f32(b) for b in b0s]
+    b1s = [_f32(b) if b is not None else None for b in b1s]
+    d0s = [np.empty_like(b) for b in b0s]
+    d1s = [np.empty_like(b) if b1s[k] is not None else None for k, b in enumerate(b0s)]
+    norms = np.ascontiguousarray(norms, np.float32)
+    _check(lib().fn2_l1loss_backward_multi_cpu(C.byref(p), len(b0s), _l1_scales(b0s, b1s, weights, d0s, d1s), C.c_float(total_diff), _p(norms)),
+           "l1loss_backward_multi")
+    return d0s, d1s
+
+
 def channel_norm_forward(x):
     x = _f32(x)
     N, Cc, H, W = x.shape

@@ -739,6 +739,39 @@ FN2_API int fn2_l1loss_backward_cpu(const fn2_l1loss_params* p, const float* b0,
   return FN2_OK;
 }
 
+/* Every L1Loss layer of a net at once (fn2_l1loss_forward_multi / _backward_multi): the layers one by one, then
+ * Net::ForwardFromTo's  loss += layer_loss  (net.cpp:565-579) with layer_loss = caffe_cpu_dot(top_data, loss_weight) (layer.hpp:434-440)
+ * -- a float product and a float sum per layer, in layer order.  norms[s] = the layer's normalize_coeff (what the HIP path keeps in
+ * its workspace between forward and backward). */
+FN2_API int fn2_l1loss_forward_multi_cpu(const fn2_l1loss_params* p, int nscales, const fn2_l1loss_scale* sc, float* losses, float* norms,
+                                         float* total) {
+  if (!p || !sc || nscales < 1) return FN2_ERR_INVALID_ARG;
+  volatile float t = 0.f;
+  for (int s = 0; s < nscales; ++s) {
+    float loss = 0.f, norm = 0.f;
+    const int rc = fn2_l1loss_forward_cpu(p, sc[s].bottom0, sc[s].bottom1, &loss, &norm, sc[s].N, sc[s].C, sc[s].H, sc[s].W);
+    if (rc) return rc;
+    if (losses) losses[s] = loss;
+    if (norms) norms[s] = norm;
+    volatile float prod = sc[s].loss_weight * loss;      /* rounded to float before the sum (no fused multiply-add) */
+    t = t + prod;
+  }
+  if (total) *total = t;
+  return FN2_OK;
+}
+
+FN2_API int fn2_l1loss_backward_multi_cpu(const fn2_l1loss_params* p, int nscales, const fn2_l1loss_scale* sc, float total_diff,
+                                          const float* norms) {
+  if (!p || !sc || !norms || nscales < 1) return FN2_ERR_INVALID_ARG;
+  for (int s = 0; s < nscales; ++s) {
+    volatile float top_diff = sc[s].loss_weight * total_diff;        /* the layer's top[0]->cpu_diff()[0] (l1loss_layer.cu:155) */
+    const int rc = fn2_l1loss_backward_cpu(p, sc[s].bottom0, sc[s].bottom1, top_diff, norms[s], sc[s].bottom0_diff,
+                                           sc[s].bottom1 ? sc[s].bottom1_diff : 0, sc[s].N, sc[s].C, sc[s].H, sc[s].W);
+    if (rc) return rc;
+  }
+  return FN2_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * ChannelNorm: channel_norm_layer.cpp:43-69 / .cu:16-47.
  * ---------------------------------------------------------------------------------------------- */

@@ -55,6 +55,16 @@ for (h, w) in [(80, 112), (5, 7)]:
     add(f"L1Loss fwd [8,2,{h},{w}]", lambda: ops.l1loss_forward(p, a, b, ws), 4 * 2 * 8 * 2 * h * w)
     ops.l1loss_forward(p, a, b, ws)
     add(f"L1Loss bwd [8,2,{h},{w}]", lambda: ops.l1loss_backward(p, a, b, 1.0, ws), 4 * 4 * 8 * 2 * h * w)
+# the five loss layers of config A's training net in ONE launch per direction (fn2_l1loss_forward_multi / _backward_multi)
+sc = [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]
+pa = [torch.randn(8, 2, h, w, device=dev, generator=g) for h, w in sc]; pb = [torch.randn(8, 2, h, w, device=dev, generator=g) for h, w in sc]
+p = ops.l1_params(l2_per_location=True, normalize_by_num_entries=True)
+lw = [0.005, 0.01, 0.02, 0.08, 0.32]
+nb = sum(4 * 2 * 8 * 2 * h * w for h, w in sc)
+add("L1Loss fwd, all 5 scales [8,2,80,112]..[8,2,5,7], one launch", lambda: ops.l1loss_forward_multi(p, pa, pb, lw), nb)
+_, _, wsm = ops.l1loss_forward_multi(p, pa, pb, lw)
+one = torch.ones((), device=dev)
+add("L1Loss bwd, all 5 scales, one launch", lambda: ops.l1loss_backward_multi(p, pa, pb, lw, one, wsm), 2 * nb)
 x = torch.randn(4, 3, 384, 768, device=dev, generator=g)
 add("ChannelNorm fwd [4,3,384,768]", lambda: ops.channel_norm_forward(x), 4 * 4 * 384 * 768 * 4)
 gt = torch.randn(8, 2, 320, 448, device=dev, generator=g)

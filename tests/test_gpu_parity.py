@@ -391,6 +391,53 @@ def test_l1loss(kw, two, shape):
     assert float(loss2) == float(loss)
 
 
+@pytest.mark.parametrize("kw", [dict(l2_per_location=True, normalize_by_num_entries=True), dict(), dict(l2_per_location=True, l2_prescale_by_channels=True, plateau=0.3)])
+@pytest.mark.parametrize("shapes", [[(8, 2, 80, 112), (8, 2, 40, 56), (8, 2, 20, 28), (8, 2, 10, 14), (8, 2, 5, 7)], [(2, 3, 9, 11)],
+                                    [(1, 2, 320, 448), (3, 1, 1, 1), (2, 2, 64, 64), (1, 4, 7, 5), (2, 2, 33, 17), (1, 2, 200, 300), (4, 2, 8, 8), (1, 1, 2, 2)]])
+def test_l1loss_multi_equals_the_single_layer_kernels_bitwise(kw, shapes):
+    """fn2_l1loss_forward_multi / _backward_multi (every loss layer of a net in one launch per direction, the weighted sum included):
+    per scale the BITS of fn2_l1loss_forward / fn2_l1loss_backward with top_diff = loss_weight * total_diff, the total = the float sum
+    of loss_weight * loss in layer order (net.cpp:565-579); twice in a row (the arrival counters reset themselves), NaN masks included."""
+    from flownet2_amd import functional as Fn
+    n = len(shapes)
+    weights = [0.005 * 2 ** k + 0.001 * k for k in range(n)]
+    preds = [rand(sh, 300 + k) for k, sh in enumerate(shapes)]
+    gts = [rand(sh, 400 + k) for k, sh in enumerate(shapes)]
+    gts[0][0, :, 0, 0] = np.nan
+    if shapes[-1][2] * shapes[-1][3] > 4:
+        gts[-1][-1, 0, 1, 1] = np.nan
+    p = ops.l1_params(**kw)
+    dp, dg = [dev(a) for a in preds], [dev(a) for a in gts]
+    single = [ops.l1loss_forward(p, dp[k], dg[k]) for k in range(n)]
+    want_total = np.float32(0.0)
+    for k in range(n):
+        want_total = np.float32(want_total + np.float32(np.float32(weights[k]) * np.float32(float(single[k][0]))))
+    gval = 0.75
+    for rep in range(2):
+        total, losses, ws = ops.l1loss_forward_multi(p, dp, dg, weights)
+        assert [float(v) for v in losses.cpu()] == [float(single[k][0]) for k in range(n)]
+        assert np.float32(float(total)) == want_total
+        d0, d1 = ops.l1loss_backward_multi(p, dp, dg, weights, torch.tensor(gval, device="cuda"), ws, need1=True)
+        for k in range(n):
+            top_diff = float(np.float32(np.float32(weights[k]) * np.float32(gval)))
+            w0, w1 = ops.l1loss_backward(p, dp[k], dg[k], top_diff, single[k][1])
+            assert torch.equal(d0[k], w0) and torch.equal(d1[k], w1), (k, rep)
+    # the oracle twin (fn2_l1loss_forward_multi_cpu): same layer order, float sum
+    po = oracle.l1_params(**kw)
+    ot, ol, onorm = oracle.l1loss_forward_multi(po, preds, gts, weights)
+    assert abs(float(total) - ot) <= 1e-6 * max(1.0, abs(ot))
+    od0, _ = oracle.l1loss_backward_multi(po, preds, gts, weights, gval, onorm)
+    for k in range(n):
+        assert_close(host(d0[k]), od0[k], 1e-6, "multi l1 diff %d" % k)
+    # through autograd: the graph of nets.multiscale_loss
+    leaves = [t.clone().requires_grad_(True) for t in dp]
+    tot, _ = Fn.l1_loss_multi(leaves, dg, weights, **kw)
+    (tot * gval).backward()
+    for k in range(n):
+        top_diff = float(np.float32(np.float32(weights[k]) * np.float32(gval)))
+        assert torch.equal(leaves[k].grad, ops.l1loss_backward(p, dp[k], dg[k], top_diff, single[k][1])[0])
+
+
 def test_l1loss_layer_api():
     shape = (4, 2, 10, 14)
     pred, gt = rand(shape, 19), rand(shape, 20)

@@ -356,3 +356,26 @@ def test_im2col_col2im_oracle():
     colr = rng.standard_normal((2, 5 * 16, 42)).astype(np.float32)
     fold = torch.nn.functional.fold(torch.from_numpy(colr).double(), (12, 14), 4, padding=1, stride=2).numpy()
     np.testing.assert_allclose(oracle.col2im_bias_relu_forward(colr, None, 2, 5, 12, 14, 4, 1, 2, relu=False), fold, rtol=0, atol=2e-6)
+
+
+def test_l1loss_multi_is_the_layers_one_by_one_plus_the_net_sum():
+    """oracle.l1loss_forward_multi / _backward_multi (the twins of fn2_l1loss_*_multi): per layer the single-layer oracle, total = the
+    float sum of loss_weight * loss in layer order (net.cpp:565-579)."""
+    rng = np.random.default_rng(7)
+    shapes = [(2, 2, 20, 28), (2, 2, 10, 14), (2, 2, 5, 7)]
+    preds = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    gts = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    gts[1][0, :, 2, 2] = np.nan
+    w = [0.005, 0.01, 0.32]
+    p = oracle.l1_params(l2_per_location=True, normalize_by_num_entries=True)
+    total, losses, norms = oracle.l1loss_forward_multi(p, preds, gts, w)
+    want = np.float32(0)
+    for k in range(3):
+        l, nrm = oracle.l1loss_forward(p, preds[k], gts[k])
+        assert losses[k] == np.float32(l) and norms[k] == np.float32(nrm)
+        want = np.float32(want + np.float32(np.float32(w[k]) * np.float32(l)))
+    assert np.float32(total) == want
+    d0s, d1s = oracle.l1loss_backward_multi(p, preds, gts, w, 0.5, norms)
+    for k in range(3):
+        r0, r1 = oracle.l1loss_backward(p, preds[k], gts[k], float(np.float32(np.float32(w[k]) * np.float32(0.5))), float(norms[k]))
+        assert np.array_equal(d0s[k], r0) and np.array_equal(d1s[k], r1)
