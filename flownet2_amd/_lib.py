@@ -26,7 +26,7 @@ EXPORTS = [
     "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward", "fn2_bias_leaky_relu_backward_slices",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_conv_k7s2_wgrad_supported", "fn2_conv_k7s2_wgrad_ksplit", "fn2_conv_k7s2_wgrad_workspace_bytes", "fn2_conv_k7s2_wgrad",
-    "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_forward",
+    "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_pack_weights_view", "fn2_conv_mfma_forward",
     "fn2_conv_mfma_num_variants", "fn2_debug_set_conv_variant",
     "fn2_caffemodel_index", "fn2_caffemodel_read_blob",
     "fn2_conv_wino_supported", "fn2_conv_wino_packed_floats", "fn2_conv_wino_pack_weights", "fn2_conv_wino_forward",
@@ -160,6 +160,7 @@ def lib():
     L.fn2_conv_mfma_packed_floats.argtypes = [i, i, i]
     L.fn2_conv_mfma_packed_floats.restype = sz
     L.fn2_conv_mfma_pack_weights.argtypes = [fp, fp, i, i, i, vp]
+    L.fn2_conv_mfma_pack_weights_view.argtypes = [fp, fp, i, i, i, i, i, C.c_longlong, C.c_longlong, i, vp]
     L.fn2_conv_mfma_forward.argtypes = [fp, fp, fp, fp] + [i] * 13 + [C.c_float, vp]
     L.fn2_debug_set_conv_variant.argtypes = [i]
     L.fn2_conv_wino_supported.argtypes = [i] * 5

@@ -268,6 +268,56 @@ __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wp
   }
 }
 
+// The same packing from a strided VIEW of a weight blob, through LDS: logical element (co, ci, tap) of a [Cout][Cin][KS][KS] operand is
+//   src[co * s_co + ci * s_ci + (flip ? T - 1 - tap : tap)]   for co < src_co and ci < src_ci,   0 beyond (channel padding).
+// That covers, without a layout pass in front: the blob as it is (s_co = Cin T, s_ci = T), its channel axes swapped (a Deconvolution's
+// blob read as a Convolution's, the transposed convolutions of the data gradients: s_co = T, s_ci = src_co T), the 180-degree rotation of
+// a 3x3 data gradient (flip), zero channels up to the kernels' group sizes, and the [Cout 16][Cin] GEMM operand of a Deconvolution
+// (T = 1, s_co = 1, s_ci = Cout 16).  A training step repacks every weight after every update (39 M floats, two forms each): the
+// gather form above reads 4 bytes per 64-byte line (17-56 us per blob, 0.53 ms per step plus 0.35 ms of torch transposes / cats / fills
+// in front of it); here a workgroup reads runs of the source's fastest axis, turns them in LDS and writes whole 1 KiB k-steps.
+constexpr int kPackTileFloats = 8192;                     // LDS tile: 64 output channels x QT channel quads x T taps
+__global__ void __launch_bounds__(256) pack_weights_view(const float* __restrict__ w, float* __restrict__ wp, int Cin, int KS, int ksteps, int kalloc,
+                                                         int src_co, int src_ci, long long s_co, long long s_ci, int flip, int QT) {
+  extern __shared__ float tile[];                         // [64][4 * QT][T] (+ 1 float per channel row against bank conflicts)
+  const int T = KS * KS, grp = blockIdx.x, cq0 = blockIdx.y * QT;
+  const int cil = 4 * QT, row = cil * T + 1;
+  const int co0 = 64 * grp, ci0 = 4 * cq0;
+  const int nquads = ksteps / T;                          // channel quads of the packed operand (incl. zero padding quads)
+  const int total = 64 * cil * T;
+  if (s_ci == (long long)T) {                             // source runs along (ci, tap) for a fixed co
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int col = i / (cil * T), e = i - col * (cil * T), c = e / T;
+      const int co = co0 + col, ci = ci0 + c;
+      tile[col * row + e] = (co < src_co && ci < src_ci) ? w[(size_t)co * s_co + (size_t)ci0 * T + e] : 0.f;
+    }
+  } else if (s_co == (long long)T) {                      // source runs along (co, tap) for a fixed ci
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int c = i / (64 * T), e = i - c * (64 * T), col = e / T, t = e - col * T;
+      const int co = co0 + col, ci = ci0 + c;
+      tile[col * row + c * T + t] = (co < src_co && ci < src_ci) ? w[(size_t)ci * s_ci + (size_t)co0 * T + e] : 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int col = i / (cil * T), e = i - col * (cil * T), c = e / T, t = e - c * T;
+      const int co = co0 + col, ci = ci0 + c;
+      tile[col * row + e] = (co < src_co && ci < src_ci) ? w[(size_t)co * s_co + (size_t)ci * s_ci + t] : 0.f;
+    }
+  }
+  __syncthreads();
+  // k-step ks = cq * T + tap: 256 floats [lane = kq * 16 + co % 16][j = co / 16]
+  const int nq = min(QT, nquads - cq0);
+  float* dst = wp + ((size_t)grp * kalloc + (size_t)cq0 * T) * 256;
+  for (int i = threadIdx.x; i < nq * T * 256; i += 256) {
+    const int j = i & 3, lane = (i >> 2) & 63, ks = i >> 8;
+    const int cq = ks / T, tap = ks - cq * T;
+    const int col = 16 * j + (lane & 15), c = 4 * cq + (lane >> 4);
+    dst[i] = tile[col * row + c * T + (flip ? T - 1 - tap : tap)];
+  }
+  if (cq0 + QT >= nquads)                                 // the spare k-steps behind the group
+    for (int i = threadIdx.x; i < (kalloc - ksteps) * 256; i += 256) wp[((size_t)grp * kalloc + ksteps) * 256 + i] = 0.f;
+}
+
 constexpr int kSpare = 8;          // spare (zero) k-steps behind every group: the weight prefetch runs NBUFA - 1 k-steps ahead
 constexpr int kChunkQuads = 2;     // k-steps are padded to a whole number of chunks of at most this many channel quads (8 for 1x1 kernels)
 
@@ -404,14 +454,32 @@ FN2_API size_t fn2_conv_mfma_packed_floats(int Cout, int Cin, int kernel) {
   return (size_t)((Cout + 63) / 64) * (cv::ksteps_for(Cin, kernel) + cv::kSpare) * 256;
 }
 
+FN2_API int fn2_conv_mfma_pack_weights_view(const float* weight, float* packed, int Cout, int Cin, int kernel, int src_cout, int src_cin,
+                                            long long stride_cout, long long stride_cin, int flip, void* stream);
+
 FN2_API int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int Cout, int Cin, int kernel, void* stream) {
   if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights: null blob");
   if (Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || (kernel != 1 && kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7))
     return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights: needs Cout %% 32 == 0 and kernel_size 1, 3, 4, 5 or 7 (got Cout %d, kernel %d)", Cout, kernel);
-  const int ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare;
-  const long long total = (long long)((Cout + 63) / 64) * kalloc * 256;
-  hipLaunchKernelGGL(cv::pack_weights, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), weight, packed, Cout, Cin, kernel, ksteps, kalloc);
-  return check_launch("conv_mfma_pack_weights");
+  return fn2_conv_mfma_pack_weights_view(weight, packed, Cout, Cin, kernel, Cout, Cin, (long long)Cin * kernel * kernel, (long long)kernel * kernel, 0, stream);
+}
+
+FN2_API int fn2_conv_mfma_pack_weights_view(const float* weight, float* packed, int Cout, int Cin, int kernel, int src_cout, int src_cin,
+                                            long long stride_cout, long long stride_cin, int flip, void* stream) {
+  if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights_view: null blob");
+  if (Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || (kernel != 1 && kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7))
+    return fail(FN2_ERR_UNSUPPORTED, "conv_mfma_pack_weights_view: needs Cout %% 32 == 0 and kernel_size 1, 3, 4, 5 or 7 (got Cout %d, kernel %d)", Cout, kernel);
+  if (src_cout < 1 || src_cout > Cout || src_cin < 1 || src_cin > Cin || stride_cout < 1 || stride_cin < 1)
+    return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights_view: bad source view (%d of %d, %d of %d channels, strides %lld / %lld)", src_cout, Cout,
+                src_cin, Cin, stride_cout, stride_cin);
+  const int T = kernel * kernel, ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare, nquads = ksteps / T;
+  int QT = cv::kPackTileFloats / (64 * 4 * T);
+  if (QT < 1) QT = 1;
+  if (QT > 8) QT = 8;
+  const size_t lds = sizeof(float) * 64 * (size_t)(4 * QT * T + 1);
+  hipLaunchKernelGGL(cv::pack_weights_view, dim3((unsigned)((Cout + 63) / 64), (unsigned)cv::cdiv(nquads, QT)), dim3(256), lds, as_stream(stream), weight, packed,
+                     Cin, kernel, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, QT);
+  return check_launch("conv_mfma_pack_weights_view");
 }
 
 FN2_API int fn2_conv_mfma_supported(int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad) {

@@ -323,7 +323,7 @@ def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
     return run(x, weight, bias)
 
 
-_PACKED = {}     # id(weight tensor) -> (weak reference, _version, packed copy): one repack per weight update, not per forward
+_PACKED = {}     # id(weight tensor) -> (weak reference, _version, packed copy) of FROZEN weights (see _cached)
 
 
 def invalidate_weight_caches():
@@ -337,14 +337,24 @@ def invalidate_weight_caches():
     nets._WT_CACHE.clear()
 
 
-def _packed_conv_weight(w):
+def _cached(cache, key, w, make):
+    """make() for weight tensor w, remembered under `key` while w is alive and unwritten.  Writes are noticed through `_version` -- which
+    fused optimizers do NOT touch (torch.optim.Adam(fused=True) leaves it at 0: scripts/probes/stale_pack_probe.py, round 4: the cached
+    operands of step 1 served every later step) -- so a tensor that requires grad is never cached, and seeing it in that state drops what
+    an earlier, frozen life of the same tensor left behind: a trainable parameter is repacked whenever it is used."""
     import weakref
-    key = id(w)
-    hit = _PACKED.get(key)
+    if w.requires_grad:
+        cache.pop(key, None)
+        return make()
+    hit = cache.get(key)
     if hit is None or hit[0]() is not w or hit[1] != w._version:
-        hit = (weakref.ref(w, lambda _r, k=key: _PACKED.pop(k, None)), w._version, ops.conv_mfma_pack_weights(w.detach()))
-        _PACKED[key] = hit
+        hit = (weakref.ref(w, lambda _r, k=key: cache.pop(k, None)), w._version, make())
+        cache[key] = hit
     return hit[2]
+
+
+def _packed_conv_weight(w):
+    return _cached(_PACKED, id(w), w, lambda: ops.conv_mfma_pack_weights(w.detach()))
 
 
 def _mfma_conv_enabled(kernel, stride):
@@ -357,13 +367,7 @@ _PACKED_U = {}
 
 
 def _packed_wino_weight(w):
-    import weakref
-    key = id(w)
-    hit = _PACKED_U.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != w._version:
-        hit = (weakref.ref(w, lambda _r, k=key: _PACKED_U.pop(k, None)), w._version, ops.conv_wino_pack_weights(w.detach()))
-        _PACKED_U[key] = hit
-    return hit[2]
+    return _cached(_PACKED_U, id(w), w, lambda: ops.conv_wino_pack_weights(w.detach()))
 
 
 def _conv_mfma_pick(x, weight, stride, pad):
@@ -498,13 +502,7 @@ _PACKED_T = {}     # tconv / deconv-data-gradient packings, keyed like _PACKED
 
 
 def _cached_pack(cache, w, tag, make):
-    import weakref
-    key = (id(w), tag)
-    hit = cache.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != w._version:
-        hit = (weakref.ref(w, lambda _r, k=key: cache.pop(k, None)), w._version, make())
-        cache[key] = hit
-    return hit[2]
+    return _cached(cache, (id(w), tag), w, make)
 
 
 def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
@@ -529,11 +527,8 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
             return None
         Cp = (Cin + 63) // 64 * 64
 
-        def make():
-            wt = w.detach()
-            if Cp != Cin:
-                wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 4, 4))], 0)
-            return ops.conv_mfma_pack_weights(wt.contiguous())
+        def make():                 # the blob as it is, as a [Cp][Cout][4][4] Convolution operand (channels beyond Cin: zero)
+            return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cp, Cout, 4, Cin, Cout, Cout * 16, 16)
         if ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
             gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 4, 2, 1, False, 0.0)
         elif Cout % 8 == 0 and ops.conv_plane_k_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
@@ -562,11 +557,8 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
         if not ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 1, 1, 0):
             return None
 
-        def make_1x1():
-            wt = w.detach().transpose(0, 1)                              # [Cin, Cout, 1, 1]
-            if Cp != Cin:
-                wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 1, 1))], 0)
-            return ops.conv_mfma_pack_weights(wt.contiguous())
+        def make_1x1():             # [Cp][Cout][1][1]: the blob with its channel axes swapped, output channels zero-padded
+            return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cp, Cout, 1, Cin, Cout, 1, Cin)
         gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "1x1-dgrad", make_1x1), None, Cp, 1, 1, 0, False, 0.0)
         return gx[:, :Cin] if Cp != Cin else gx
     if mode == "none" or k != 3 or stride != 1 or pad != 1:
@@ -580,11 +572,8 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
         if Cout % 8 != 0 or not ops.conv_plane_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cq, 1, 1):
             return None
 
-        def make_plane():
-            wt = w.detach().flip(2, 3).transpose(0, 1)
-            if Cq != Cin:
-                wt = torch.cat([wt, wt.new_zeros((Cq - Cin, Cout, 3, 3))], 0)
-            return ops.conv_mfma_pack_weights(wt.contiguous())
+        def make_plane():           # [Cq][Cout][3][3]: rotated by 180 degrees, channel axes swapped, output channels zero-padded
+            return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cq, Cout, 3, Cin, Cout, 9, Cin * 9, flip=True)
         gx = ops.conv_plane_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "plane-dgrad", make_plane), None, Cq, 1, 1, False, 0.0)
         return gx[:, :Cin] if Cq != Cin else gx
 
@@ -629,13 +618,7 @@ _PACKED_D = {}
 
 
 def _packed_deconv_weight(w):
-    import weakref
-    key = id(w)
-    hit = _PACKED_D.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != w._version:
-        hit = (weakref.ref(w, lambda _r, k=key: _PACKED_D.pop(k, None)), w._version, ops.deconv_plane_pack_weights(w.detach().contiguous()))
-        _PACKED_D[key] = hit
-    return hit[2]
+    return _cached(_PACKED_D, id(w), w, lambda: ops.deconv_plane_pack_weights(w.detach().contiguous()))
 
 
 def deconv_mfma_relu(x, weight, bias, negative_slope=0.1, act=True, out=None, out_c0=0):
@@ -667,19 +650,28 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     _OwnForwardConv).  Returns None if the kernel does not apply, or autograd is needed and `weight` was not given."""
     N, Cin, H, W = x.shape
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
-    if not _deconv_gemm_supported(x, cout, kernel):
+    gemm_ok = _deconv_gemm_supported(x, cout, kernel)
+    # planes the 1x1 / GEMM kernel does not take (deconv5: 5x7) are the small-map deconvolution kernel's -- no column matrix at all
+    plane_ok = bool(x.is_cuda and (kernel, stride, pad) == (4, 2, 1) and os.environ.get("FN2_DECONV_PLANE", "auto") != "0"
+                    and ops.deconv_plane_supported(N, Cin, H, W, cout))
+    if not gemm_ok and not plane_ok:
         return None
 
-    def run_t(xx, wt, bb, out=None, out_c0=0):
+    def run_t(xx, wt, bb, out=None, out_c0=0, ww=None):
         # weight^T x bottom as a 1x1 convolution with Cout * k * k output channels on the own MFMA kernel (csrc/conv_mfma.hip,
-        # kernel_size 1): the column matrix [N, Cout*k*k, H*W]
+        # kernel_size 1): the column matrix [N, Cout*k*k, H*W].  Its operand is packed from the transposed copy wt, or (ww given: the
+        # layer's own [Cin][Cout][k][k] blob) straight from the blob through the strided view -- no transposed copy at all
         blob, c0 = _channel_slice(xx)
-        pw = _cached_pack(_PACKED_T, wt, "deconv-gemm", lambda: ops.conv_mfma_pack_weights(wt.detach().reshape(cout * kernel * kernel, Cin, 1, 1)))
+        M = cout * kernel * kernel
+        if ww is not None:
+            pw = _cached_pack(_PACKED_T, ww, "deconv-gemm", lambda: ops.conv_mfma_pack_weights_view(ww.detach().contiguous(), M, Cin, 1, M, Cin, 1, M))
+        else:
+            pw = _cached_pack(_PACKED_T, wt, "deconv-gemm", lambda: ops.conv_mfma_pack_weights(wt.detach().reshape(M, Cin, 1, 1)))
         col = ops.conv_mfma_forward(blob, pw, None, cout * kernel * kernel, 1, 1, 0, False, 0.0, in_c0=c0, Cin=Cin).view(N, cout * kernel * kernel, H * W)
         return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope, out=out, out_c0=out_c0)
 
     if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)
-        return None if _needs_grad(x, weight_t, bias, weight) else run_t(x, weight_t, bias, out, out_c0)
+        return None if (_needs_grad(x, weight_t, bias, weight) or not gemm_ok) else run_t(x, weight_t, bias, out, out_c0)
     if _needs_grad(x, weight_t, bias, weight):
         if weight is None or not _train_fast_forward():
             return None
@@ -687,11 +679,14 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
             # ww is the parameter itself (autograd does not record inside _OwnForwardConv.forward): its transposed view and the packed
             # operands are cached on it until the optimizer writes it.  Planes whose size is no multiple of 4 (deconv5: 5x7) are not the
             # 1x1 / GEMM kernel's: the small-map deconvolution kernel computes them without a column matrix (and without a library GEMM)
-            if xx.is_cuda and (kernel, stride, pad) == (4, 2, 1) and (H * W) % 4 != 0 and os.environ.get("FN2_DECONV_PLANE", "auto") != "0" \
-                    and ops.deconv_plane_supported(N, Cin, H, W, cout):
+            if plane_ok and ((H * W) % 4 != 0 or not gemm_ok):
                 blob, c0 = _channel_slice(xx)
                 return ops.deconv_plane_forward(blob, _packed_deconv_weight(ww), bb, cout, True, negative_slope, in_c0=c0, Cin=Cin)
-            wt = _cached_pack(_PACKED_T, ww, "deconv-wt", lambda: ww.detach().reshape(Cin, cout * kernel * kernel).t().contiguous())
-            return run_t(xx, wt, bb)
+            return run_t(xx, None, bb, ww=ww)
         return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, True)
+    if not gemm_ok:                    # (inference reaches the small-map kernel through deconv_mfma_relu before it comes here)
+        if weight is None:
+            return None
+        blob, c0 = _channel_slice(x)
+        return ops.deconv_plane_forward(blob, _packed_deconv_weight(weight), bias, cout, True, negative_slope, in_c0=c0, Cin=Cin)
     return run_t(x, weight_t, bias)

@@ -485,6 +485,25 @@ def conv_mfma_pack_weights(weight):
     return packed
 
 
+def conv_mfma_pack_weights_view(blob, Cout, Cin, kernel, src_cout, src_cin, stride_cout, stride_cin, flip=False):
+    """The operand fn2_conv_mfma_forward reads for the strided [Cout][Cin][k][k] VIEW of a contiguous weight blob: element (co, ci, tap) =
+    blob.flatten()[co * stride_cout + ci * stride_cin + (k*k - 1 - tap if flip else tap)] for co < src_cout, ci < src_cin, 0 beyond --
+    channel-swapped, rotated and zero-padded operands in one launch (csrc/conv_mfma.hip: pack_weights_view)."""
+    w = _chk(blob, "weight", ndim=blob.dim())
+    if not w.is_contiguous():
+        raise ValueError("conv_mfma_pack_weights_view: the blob itself must be contiguous (the view is described by the strides)")
+    n = _lib.lib().fn2_conv_mfma_packed_floats(int(Cout), int(Cin), int(kernel))
+    if n == 0:
+        raise ValueError(f"conv_mfma: unsupported operand [{Cout},{Cin},{kernel},{kernel}]")
+    last = (src_cout - 1) * stride_cout + (src_cin - 1) * stride_cin + kernel * kernel - 1
+    if last >= w.numel():
+        raise ValueError("conv_mfma_pack_weights_view: the view reaches beyond the blob")
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_lib.lib().fn2_conv_mfma_pack_weights_view(_ptr(w), _ptr(packed), int(Cout), int(Cin), int(kernel), int(src_cout), int(src_cin),
+                                                     int(stride_cout), int(stride_cin), int(bool(flip)), _stream()))
+    return packed
+
+
 def conv_mfma_forward(x, packed_weight, bias, Cout, kernel, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0,
                       in_c0=0, Cin=None):
     """act(Convolution{kernel, stride, pad}(x[:, in_c0:in_c0+Cin]) + bias) -> out[:, out_c0:out_c0+Cout] (a new blob if out is None)."""
@@ -611,7 +630,9 @@ def tconv_supported(Cin, Hin, Win, Cout, Hout, Wout, kernel, pad) -> bool:
 def tconv_pack_weights(weight):
     """weight [Cin, Cout, k, k] (Caffe's Deconvolution blob; for a data gradient the Convolution's own [Cout_conv, Cin_conv, k, k] blob)
     -> the MFMA operand order fn2_tconv_forward reads: fn2_conv_mfma_pack_weights of the [Cout][Cin][k][k] view."""
-    return conv_mfma_pack_weights(weight.transpose(0, 1).contiguous())
+    w = weight.detach().contiguous()
+    A, B, k, _ = w.shape                                    # operand [Cout = B][Cin = A][k][k]: the blob with its channel axes swapped
+    return conv_mfma_pack_weights_view(w, B, A, k, B, A, k * k, B * k * k)
 
 
 def tconv_forward(x, packed_weight, bias, Cout, kernel, pad, out_hw=None, relu=False, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):

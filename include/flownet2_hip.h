@@ -363,6 +363,14 @@ int fn2_conv_k7s2_wgrad(const float* top_diff, const float* bottom, float* weigh
 int fn2_conv_mfma_supported(int Cin, int Hin, int Win, int Cout, int kernel, int stride, int pad);
 size_t fn2_conv_mfma_packed_floats(int Cout, int Cin, int kernel);
 int fn2_conv_mfma_pack_weights(const float* weight, float* packed, int Cout, int Cin, int kernel, void* stream);
+/* The same operand from a strided VIEW of a weight blob: logical element (co, ci, ky, kx) of the [Cout][Cin][k][k] operand =
+ * weight[co * stride_cout + ci * stride_cin + (flip ? k*k - 1 - (ky*k + kx) : ky*k + kx)] for co < src_cout, ci < src_cin, 0 beyond.
+ * One launch instead of transpose / flip / zero-pad passes in front of the packing: the channel-swapped blob of a data gradient
+ * (ConvolutionLayer::Backward_gpu, conv_layer.cu:53-57; DeconvolutionLayer::Backward_gpu, deconv_layer.cu:52-56), its 180-degree
+ * rotation (3x3 / stride 1), channel padding up to the kernels' group sizes, and the [Cout k k][Cin] GEMM operand of a
+ * Deconvolution (kernel 1, stride_cout 1, stride_cin Cout k k: base_conv_layer.cpp:375-384's weight^T). */
+int fn2_conv_mfma_pack_weights_view(const float* weight, float* packed, int Cout, int Cin, int kernel, int src_cout, int src_cin,
+                                    long long stride_cout, long long stride_cin, int flip, void* stream);
 int fn2_conv_mfma_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
                           int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                           int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,

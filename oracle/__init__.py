@@ -303,6 +303,19 @@ def conv_mfma_pack_weights(weight):
     return packed
 
 
+def conv_mfma_pack_weights_view(blob, Cout, Cin, kernel, src_cout, src_cin, stride_cout, stride_cin, flip=False):
+    """The packed operand of the strided [Cout][Cin][k][k] view of `blob` (any contiguous float array)."""
+    w = _f32(blob)
+    L = lib()
+    L.fn2_conv_mfma_packed_floats_cpu.restype = C.c_size_t
+    n = L.fn2_conv_mfma_packed_floats_cpu(Cout, Cin, kernel)
+    assert n > 0, "unsupported weight shape"
+    packed = np.empty(n, np.float32)
+    _check(L.fn2_conv_mfma_pack_weights_view_cpu(_p(w), _p(packed), Cout, Cin, kernel, src_cout, src_cin, C.c_longlong(stride_cout),
+                                                  C.c_longlong(stride_cin), int(bool(flip))), "conv_mfma_pack_weights_view")
+    return packed
+
+
 def conv_mfma_forward(x, packed, bias, Cout, kernel, stride, pad, relu=True, negative_slope=0.1, out=None, out_c0=0, in_c0=0, Cin=None):
     x, packed = _f32(x), _f32(packed)
     bias = _f32(bias) if bias is not None else None

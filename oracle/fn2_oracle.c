@@ -1015,6 +1015,24 @@ FN2_API int fn2_conv_mfma_pack_weights_cpu(const float* weight, float* packed, i
   return FN2_OK;
 }
 
+/* fn2_conv_mfma_pack_weights_view: the operand of the [Cout][Cin][k][k] VIEW of a blob -- element (co, ci, tap) =
+ * weight[co * stride_cout + ci * stride_cin + (flip ? k*k - 1 - tap : tap)] for co < src_cout and ci < src_cin, 0 beyond. */
+FN2_API int fn2_conv_mfma_pack_weights_view_cpu(const float* weight, float* packed, int Cout, int Cin, int kernel, int src_cout, int src_cin,
+                                                long long stride_cout, long long stride_cin, int flip) {
+  if (!weight || !packed || Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || (kernel != 1 && kernel != 3 && kernel != 4 && kernel != 5 && kernel != 7)) return FN2_ERR_INVALID_ARG;
+  if (src_cout < 1 || src_cout > Cout || src_cin < 1 || src_cin > Cin || stride_cout < 1 || stride_cin < 1) return FN2_ERR_INVALID_ARG;
+  const int ksteps = conv_mfma_ksteps(Cin, kernel), kalloc = ksteps + 8, kk = kernel * kernel;
+  for (int g = 0; g < (Cout + 63) / 64; ++g)
+    for (int ks = 0; ks < kalloc; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int co = 64 * g + 16 * j + (lane & 15), ci = 4 * (ks / kk) + (lane >> 4), tap = ks % kk;
+          packed[(((size_t)g * kalloc + ks) * 64 + lane) * 4 + j] =
+              (ks < ksteps && ci < src_cin && co < src_cout) ? weight[(size_t)co * stride_cout + (size_t)ci * stride_cin + (flip ? kk - 1 - tap : tap)] : 0.f;
+        }
+  return FN2_OK;
+}
+
 FN2_API int fn2_conv_mfma_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,
                                       int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                                       int Cout, int top_channels, int top_c0, int kernel, int stride, int pad,

@@ -587,6 +587,20 @@ def test_deconv_via_gemm_and_col2im(case, relu):
     assert_close(got, ref.numpy().astype(np.float32), 3e-6, "deconv via col2im vs torch fp64")
 
 
+def test_hip_packed_operand_of_a_strided_view_equals_the_oracle_bitwise():
+    """fn2_conv_mfma_pack_weights_view (LDS-tiled, one launch) vs its oracle twin and vs the plain packing of the tensor torch would have
+    materialised: every form the training step uses (as it is, channel axes swapped, zero-padded, rotated, the Deconvolution's GEMM operand)."""
+    from test_oracle import VIEWS
+    for shape, Cout, Cin, sco, sci, st_co, st_ci, flip, expr in VIEWS + [((512, 1024, 3, 3), 1024, 512, 1024, 512, 9, 1024 * 9, True, None),
+                                                                         ((256, 130, 5, 5), 256, 130, 256, 130, 130 * 25, 25, False, None)]:
+        w = rand(shape, 77, 1.0)
+        k = 1 if (shape[2] == 4 and Cout == 128 and Cin == 10) else shape[2]
+        got = host(ops.conv_mfma_pack_weights_view(dev(w), Cout, Cin, k, sco, sci, st_co, st_ci, flip))
+        assert np.array_equal(got, oracle.conv_mfma_pack_weights_view(w, Cout, Cin, k, sco, sci, st_co, st_ci, flip)), shape
+        if expr is not None:
+            assert np.array_equal(got, host(ops.conv_mfma_pack_weights(expr(dev(w)).contiguous()))), shape
+
+
 def test_small_conv_and_gemm_deconv_paths_match_library_convolutions():
     """functional.conv_mfma_relu on a small map (the layers that went to im2col + a library GEMM until round 4) and deconv_gemm_relu
     (own 1x1 MFMA kernel + our col2im pass) vs MIOpen's direct kernels; no call leaves the own kernels."""

@@ -379,3 +379,24 @@ def test_l1loss_multi_is_the_layers_one_by_one_plus_the_net_sum():
     for k in range(3):
         r0, r1 = oracle.l1loss_backward(p, preds[k], gts[k], float(np.float32(np.float32(w[k]) * np.float32(0.5))), float(norms[k]))
         assert np.array_equal(d0s[k], r0) and np.array_equal(d1s[k], r1)
+
+
+VIEWS = [  # blob shape [A][B][k][k], operand Cout, Cin, src_cout, src_cin, stride_cout, stride_cin, flip, the torch expression it equals
+    ((64, 24, 3, 3), 64, 24, 64, 24, 24 * 9, 9, False, lambda w: w),
+    ((40, 64, 5, 5), 64, 40, 64, 40, 25, 64 * 25, False, lambda w: w.transpose(0, 1)),
+    ((70, 12, 4, 4), 128, 12, 70, 12, 12 * 16, 16, False, lambda w: torch.cat([w, w.new_zeros((58, 12, 4, 4))], 0)),
+    ((32, 20, 1, 1), 32, 32, 20, 32, 1, 20, False, lambda w: torch.cat([w.transpose(0, 1), w.new_zeros((12, 32, 1, 1))], 0)),
+    ((16, 50, 3, 3), 64, 16, 50, 16, 9, 50 * 9, True, lambda w: torch.cat([w.flip(2, 3).transpose(0, 1), w.new_zeros((14, 16, 3, 3))], 0)),
+    ((10, 8, 4, 4), 128, 10, 128, 10, 1, 128, False, lambda w: w.reshape(10, 128).t().reshape(128, 10, 1, 1))]
+
+
+@pytest.mark.parametrize("view", VIEWS)
+def test_packed_operand_of_a_strided_view_equals_packing_the_materialised_tensor(view):
+    """oracle.conv_mfma_pack_weights_view (twin of fn2_conv_mfma_pack_weights_view): transposed / rotated / zero-padded operands and the GEMM
+    operand of a Deconvolution straight from the blob == conv_mfma_pack_weights of the tensor torch would have materialised."""
+    shape, Cout, Cin, sco, sci, st_co, st_ci, flip, expr = view
+    w = np.random.default_rng(5).standard_normal(shape).astype(np.float32)
+    k = 1 if (shape[2] == 4 and Cout == 128 and Cin == 10) else shape[2]
+    got = oracle.conv_mfma_pack_weights_view(w, Cout, Cin, k, sco, sci, st_co, st_ci, flip)
+    want = oracle.conv_mfma_pack_weights(expr(torch.from_numpy(w)).contiguous().numpy())
+    assert np.array_equal(got, want)

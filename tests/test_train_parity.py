@@ -95,7 +95,9 @@ def test_flownetc_training_step_at_config4_size_matches_fp64():
         loss.backward()
         torch.cuda.synchronize()
         return float(loss.detach())
+    fallbacks = Fn.LIBRARY_FALLBACKS[0]
     run()                                                   # first use: the kernels time their tile variants (same bits whichever wins)
+    assert Fn.LIBRARY_FALLBACKS[0] == fallbacks, "a layer of the training step left the own kernels"
     os.environ["FN2_TRACE_BWD"] = "1"
     try:
         import contextlib, io
@@ -154,3 +156,37 @@ def test_flownetc_training_step_at_config4_size_matches_fp64():
     assert plain["worst"] <= 2e-3 and plain["all"] <= 2.0 * lib_plain["all"] + 1e-5, (plain["worst_name"], plain["worst"], plain["all"], lib_plain["all"])
     # (3) row a12
     assert not routes, routes
+
+
+@pytest.mark.gpu
+def test_fused_optimizer_updates_reach_the_packed_weights():
+    """torch.optim.Adam(fused=True) writes the parameters without touching `_version` (the key of the packed-operand caches): until round
+    4 every training step after the first ran on the operands packed in step 1.  Trainable parameters are repacked on every use now:
+    the losses of four steps equal those of a run that drops every cache before each forward, and they move."""
+    from flownet2_amd import functional as Fn, nets
+
+    def run(invalidate):
+        P = {k: v.cuda().requires_grad_(True) for k, v in nets.init_params("C", seed=0).items()}
+        opt = torch.optim.Adam(list(P.values()), lr=1e-3, fused=True)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        a = torch.rand(2, 3, 128, 192, device="cuda", generator=g)
+        b = torch.rand(2, 3, 128, 192, device="cuda", generator=g)
+        gt = torch.randn(2, 2, 128, 192, device="cuda", generator=g)
+        out = []
+        for _ in range(4):
+            if invalidate:
+                Fn.invalidate_weight_caches()
+            opt.zero_grad(set_to_none=True)
+            loss = nets.multiscale_loss(nets.flownet_c_core(P, a - 0.43, b - 0.43, Fn), gt, Fn)
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        # and the frozen copy of the trained net computes with the trained weights
+        with torch.no_grad():
+            Pf = {k: v.detach() for k, v in P.items()}
+            out.append(float(nets.multiscale_loss(nets.flownet_c_core(Pf, a - 0.43, b - 0.43, Fn), gt, Fn)))
+        return out
+
+    cached, fresh = run(False), run(True)
+    assert cached == fresh, (cached, fresh)
+    assert len(set(cached)) == len(cached), cached
