@@ -35,7 +35,7 @@ EXPORTS = [
     "fn2_conv_plane_k_supported", "fn2_conv_plane_k_ksplit", "fn2_conv_plane_k_workspace_bytes", "fn2_conv_plane_k_forward",
     "fn2_conv_plane_num_variants", "fn2_debug_set_plane_variant", "fn2_debug_set_plane_ksplit", "fn2_set_batch_invariant", "fn2_get_batch_invariant",
     "fn2_deconv_plane_supported", "fn2_deconv_plane_ksplit", "fn2_deconv_plane_workspace_bytes", "fn2_deconv_plane_packed_floats",
-    "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_forward",
+    "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_pack_weights_k", "fn2_deconv_plane_forward",
     "fn2_tconv_supported", "fn2_tconv_forward", "fn2_tconv_num_variants", "fn2_debug_set_tconv_variant",
     "fn2_debug_set_wgrad_buffers", "fn2_debug_set_wgrad_chunk", "fn2_conv_wgrad_supported", "fn2_conv_wgrad_ksplit", "fn2_conv_wgrad_workspace_bytes", "fn2_conv_wgrad",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
@@ -205,6 +205,7 @@ def lib():
     L.fn2_deconv_plane_packed_floats.argtypes = [i, i]
     L.fn2_deconv_plane_packed_floats.restype = sz
     L.fn2_deconv_plane_pack_weights.argtypes = [fp, fp, i, i, vp]
+    L.fn2_deconv_plane_pack_weights_k.argtypes = [fp, fp, i, i, i, vp]
     L.fn2_deconv_plane_forward.argtypes = [fp, fp, fp, fp] + [i] * 10 + [C.c_float, vp, sz, vp]
     L.fn2_caffemodel_index.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), i, C.POINTER(C.c_int)]
     L.fn2_caffemodel_read_blob.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), fp, sz]

@@ -276,46 +276,70 @@ __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wp
 // (T = 1, s_co = 1, s_ci = Cout 16).  A training step repacks every weight after every update (39 M floats, two forms each): the
 // gather form above reads 4 bytes per 64-byte line (17-56 us per blob, 0.53 ms per step plus 0.35 ms of torch transposes / cats / fills
 // in front of it); here a workgroup reads runs of the source's fastest axis, turns them in LDS and writes whole 1 KiB k-steps.
-constexpr int kPackTileFloats = 8192;                     // LDS tile: 64 output channels x QT channel quads x T taps
-__global__ void __launch_bounds__(256) pack_weights_view(const float* __restrict__ w, float* __restrict__ wp, int Cin, int KS, int ksteps, int kalloc,
-                                                         int src_co, int src_ci, long long s_co, long long s_ci, int flip, int QT) {
-  extern __shared__ float tile[];                         // [64][4 * QT][T] (+ 1 float per channel row against bank conflicts)
-  const int T = KS * KS, grp = blockIdx.x, cq0 = blockIdx.y * QT;
-  const int cil = 4 * QT, row = cil * T + 1;
+// (KS and with it every divisor of the index decodes is a template parameter: with run-time divisors the kernel spent its time in
+// 32-bit divisions -- 21 us per blob, slower than the gather it replaced.)
+template <int KS> struct PackTile {
+  static constexpr int T = KS * KS;
+  static constexpr int QT = KS == 1 ? 8 : KS == 3 ? 3 : KS == 4 ? 2 : 1;      // channel quads per workgroup tile (<= 8192 floats; 7x7: 12544).  Twice the tile
+                                                                                // (runs of 0.9-1.2 KB, 2 workgroups per CU) was 1.7x SLOWER: the kernel lives on workgroups in flight
+  static constexpr int CIL = 4 * QT, ROW = CIL * T + 1;                          // + 1 float per output-channel row against bank conflicts
+  static constexpr int LDS_FLOATS = 64 * ROW;
+};
+
+template <int KS, int ORDER>      // ORDER 0: source runs along (ci, tap) for a fixed co; 1: along (co, tap) for a fixed ci; 2: any strides
+__global__ void __launch_bounds__(256) pack_weights_view(const float* __restrict__ w, float* __restrict__ wp, int ksteps, int kalloc,
+                                                         int src_co, int src_ci, long long s_co, long long s_ci, int flip) {
+  using P = PackTile<KS>;
+  constexpr int T = P::T, QT = P::QT, CIL = P::CIL, ROW = P::ROW;
+  __shared__ float tile[P::LDS_FLOATS];                   // [64][4 * QT][T]
+  const int grp = blockIdx.x, cq0 = blockIdx.y * QT;
   const int co0 = 64 * grp, ci0 = 4 * cq0;
   const int nquads = ksteps / T;                          // channel quads of the packed operand (incl. zero padding quads)
-  const int total = 64 * cil * T;
-  if (s_ci == (long long)T) {                             // source runs along (ci, tap) for a fixed co
-    for (int i = threadIdx.x; i < total; i += 256) {
-      const int col = i / (cil * T), e = i - col * (cil * T), c = e / T;
-      const int co = co0 + col, ci = ci0 + c;
-      tile[col * row + e] = (co < src_co && ci < src_ci) ? w[(size_t)co * s_co + (size_t)ci0 * T + e] : 0.f;
+  constexpr int TOTAL = 64 * CIL * T;
+  if constexpr (ORDER == 0) {
+    const float* src = w + (size_t)co0 * s_co + (size_t)ci0 * T;
+#pragma unroll
+    for (int i = threadIdx.x; i < TOTAL; i += 256) {      // (all loads of the thread in flight at once: TOTAL / 256 <= 49)
+      const int col = i / (CIL * T), e = i - col * (CIL * T), c = e / T;
+      tile[col * ROW + e] = (co0 + col < src_co && ci0 + c < src_ci) ? src[(size_t)col * s_co + e] : 0.f;
     }
-  } else if (s_co == (long long)T) {                      // source runs along (co, tap) for a fixed ci
-    for (int i = threadIdx.x; i < total; i += 256) {
+  } else if constexpr (ORDER == 1) {
+    const float* src = w + (size_t)ci0 * s_ci + (size_t)co0 * T;
+#pragma unroll
+    for (int i = threadIdx.x; i < TOTAL; i += 256) {      // (all loads of the thread in flight at once: TOTAL / 256 <= 49)
       const int c = i / (64 * T), e = i - c * (64 * T), col = e / T, t = e - col * T;
-      const int co = co0 + col, ci = ci0 + c;
-      tile[col * row + c * T + t] = (co < src_co && ci < src_ci) ? w[(size_t)ci * s_ci + (size_t)co0 * T + e] : 0.f;
+      tile[col * ROW + c * T + t] = (co0 + col < src_co && ci0 + c < src_ci) ? src[(size_t)c * s_ci + e] : 0.f;
     }
   } else {
-    for (int i = threadIdx.x; i < total; i += 256) {
-      const int col = i / (cil * T), e = i - col * (cil * T), c = e / T, t = e - c * T;
-      const int co = co0 + col, ci = ci0 + c;
-      tile[col * row + e] = (co < src_co && ci < src_ci) ? w[(size_t)co * s_co + (size_t)ci * s_ci + t] : 0.f;
+#pragma unroll
+    for (int i = threadIdx.x; i < TOTAL; i += 256) {      // (all loads of the thread in flight at once: TOTAL / 256 <= 49)
+      const int col = i / (CIL * T), e = i - col * (CIL * T), c = e / T, t = e - c * T;
+      tile[col * ROW + e] = (co0 + col < src_co && ci0 + c < src_ci) ? w[(size_t)(co0 + col) * s_co + (size_t)(ci0 + c) * s_ci + t] : 0.f;
     }
   }
   __syncthreads();
   // k-step ks = cq * T + tap: 256 floats [lane = kq * 16 + co % 16][j = co / 16]
   const int nq = min(QT, nquads - cq0);
   float* dst = wp + ((size_t)grp * kalloc + (size_t)cq0 * T) * 256;
-  for (int i = threadIdx.x; i < nq * T * 256; i += 256) {
-    const int j = i & 3, lane = (i >> 2) & 63, ks = i >> 8;
+  const int j = threadIdx.x & 3, lane = threadIdx.x >> 2;
+  const float* trow = tile + (16 * j + (lane & 15)) * ROW + (lane >> 4) * T;
+#pragma unroll
+  for (int ks = 0; ks < QT * T; ++ks) {
     const int cq = ks / T, tap = ks - cq * T;
-    const int col = 16 * j + (lane & 15), c = 4 * cq + (lane >> 4);
-    dst[i] = tile[col * row + c * T + (flip ? T - 1 - tap : tap)];
+    if (cq < nq) dst[ks * 256 + threadIdx.x] = trow[4 * cq * T + (flip ? T - 1 - tap : tap)];
   }
   if (cq0 + QT >= nquads)                                 // the spare k-steps behind the group
     for (int i = threadIdx.x; i < (kalloc - ksteps) * 256; i += 256) wp[((size_t)grp * kalloc + ksteps) * 256 + i] = 0.f;
+}
+
+template <int KS>
+static void launch_pack_view(const float* w, float* wp, int Cout, int ksteps, int kalloc, int src_co, int src_ci, long long s_co, long long s_ci, int flip,
+                             hipStream_t st) {
+  using P = PackTile<KS>;
+  const dim3 grid((unsigned)((Cout + 63) / 64), (unsigned)cdiv(ksteps / P::T, P::QT));
+  if (s_ci == (long long)P::T) hipLaunchKernelGGL((pack_weights_view<KS, 0>), grid, dim3(256), 0, st, w, wp, ksteps, kalloc, src_co, src_ci, s_co, s_ci, flip);
+  else if (s_co == (long long)P::T) hipLaunchKernelGGL((pack_weights_view<KS, 1>), grid, dim3(256), 0, st, w, wp, ksteps, kalloc, src_co, src_ci, s_co, s_ci, flip);
+  else hipLaunchKernelGGL((pack_weights_view<KS, 2>), grid, dim3(256), 0, st, w, wp, ksteps, kalloc, src_co, src_ci, s_co, s_ci, flip);
 }
 
 constexpr int kSpare = 8;          // spare (zero) k-steps behind every group: the weight prefetch runs NBUFA - 1 k-steps ahead
@@ -472,13 +496,15 @@ FN2_API int fn2_conv_mfma_pack_weights_view(const float* weight, float* packed, 
   if (src_cout < 1 || src_cout > Cout || src_cin < 1 || src_cin > Cin || stride_cout < 1 || stride_cin < 1)
     return fail(FN2_ERR_INVALID_ARG, "conv_mfma_pack_weights_view: bad source view (%d of %d, %d of %d channels, strides %lld / %lld)", src_cout, Cout,
                 src_cin, Cin, stride_cout, stride_cin);
-  const int T = kernel * kernel, ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare, nquads = ksteps / T;
-  int QT = cv::kPackTileFloats / (64 * 4 * T);
-  if (QT < 1) QT = 1;
-  if (QT > 8) QT = 8;
-  const size_t lds = sizeof(float) * 64 * (size_t)(4 * QT * T + 1);
-  hipLaunchKernelGGL(cv::pack_weights_view, dim3((unsigned)((Cout + 63) / 64), (unsigned)cv::cdiv(nquads, QT)), dim3(256), lds, as_stream(stream), weight, packed,
-                     Cin, kernel, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, QT);
+  const int ksteps = cv::ksteps_for(Cin, kernel), kalloc = ksteps + cv::kSpare;
+  hipStream_t st = as_stream(stream);
+  switch (kernel) {
+    case 1: cv::launch_pack_view<1>(weight, packed, Cout, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, st); break;
+    case 3: cv::launch_pack_view<3>(weight, packed, Cout, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, st); break;
+    case 4: cv::launch_pack_view<4>(weight, packed, Cout, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, st); break;
+    case 5: cv::launch_pack_view<5>(weight, packed, Cout, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, st); break;
+    default: cv::launch_pack_view<7>(weight, packed, Cout, ksteps, kalloc, src_cout, src_cin, stride_cout, stride_cin, flip ? 1 : 0, st); break;
+  }
   return check_launch("conv_mfma_pack_weights_view");
 }
 

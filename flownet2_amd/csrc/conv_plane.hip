@@ -316,22 +316,37 @@ __global__ void plane_reduce(const float* __restrict__ part, const float* __rest
   }
 }
 
-// weight [Cin][Cout][4][4] (Caffe's deconvolution blob) -> packed [class][Cout/64][k-steps + spare][64][4]:
-// lane (co, kq), element j <-> W[4 cq + kq][64 g + 16 j + co][ky(py, a')][kx(px, b')], k-step = (cq * 2 + a') * 2 + b'
-__global__ void pack_deconv_weights(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int ksteps, int kalloc) {
-  const long long total = 4ll * (Cout / 64) * kalloc * 256;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
-    long long r = i >> 8;
-    const int ks = (int)(r % kalloc); r /= kalloc;
-    const int grp = (int)(r % (Cout / 64)), cls = (int)(r / (Cout / 64));
-    const int co = 64 * grp + 16 * j + (lane & 15), kq = lane >> 4;
-    const int cq = ks / 4, ta = (ks >> 1) & 1, tb = ks & 1, py = cls >> 1, px = cls & 1;
-    const int ky = py == 0 ? (ta == 0 ? 3 : 1) : (ta == 0 ? 2 : 0), kx = px == 0 ? (tb == 0 ? 3 : 1) : (tb == 0 ? 2 : 0);
-    const int ci = 4 * cq + kq;
-    float v = 0.f;
-    if (ks < ksteps && ci < Cin) v = w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
-    wp[i] = v;
+// weight [Cin][Cout][SK][SK] (Caffe's deconvolution blob; SK = 3: a 3x3 blob read as the 4x4 one whose fourth tap row and column are zero --
+// the transposed 3x3 / 2 / 1 convolution of a data gradient) -> packed [class][Cout/64][k-steps + spare][64][4]:
+// lane (co, kq), element j <-> W[4 cq + kq][64 g + 16 j + co][ky(py, a')][kx(px, b')], k-step = (cq * 2 + a') * 2 + b'.
+// A workgroup turns 64 output channels x 2 channel quads through LDS: per input channel ONE contiguous run of 64 SK^2 floats in, whole
+// 1 KiB k-steps out (the gather form of rounds 2-3 read 4 bytes per 64-byte line: 56 us for deconv5's blob, once per training step).
+template <int SK>
+__global__ void __launch_bounds__(256) pack_deconv_weights(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int ksteps, int kalloc) {
+  constexpr int T = SK * SK, ROW = 8 * T + 1;             // tile [64 co][8 ci][T]
+  __shared__ float tile[64 * ROW];
+  const int grp = blockIdx.x, u = blockIdx.y;             // unit u = channel quads 2u, 2u + 1
+  const int co0 = 64 * grp, ci0 = 8 * u, ngrp = Cout / 64;
+#pragma unroll
+  for (int i = threadIdx.x; i < 8 * 64 * T; i += 256) {
+    const int c = i / (64 * T), e = i - c * (64 * T), col = e / T, t = e - col * T;
+    tile[col * ROW + c * T + t] = (ci0 + c < Cin) ? w[((size_t)(ci0 + c) * Cout + co0) * T + e] : 0.f;
+  }
+  __syncthreads();
+  const int j = threadIdx.x & 3, lane = threadIdx.x >> 2;
+  const float* trow = tile + (16 * j + (lane & 15)) * ROW + (lane >> 4) * T;
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    float* dst = wp + (((size_t)cls * ngrp + grp) * kalloc + (size_t)8 * u) * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                         // k-steps 8 u + k: cq = 2 u + k / 4
+      const int q = k >> 2, ta = (k >> 1) & 1, tb = k & 1;
+      const int ky = py == 0 ? (ta == 0 ? 3 : 1) : (ta == 0 ? 2 : 0), kx = px == 0 ? (tb == 0 ? 3 : 1) : (tb == 0 ? 2 : 0);
+      dst[k * 256] = (ky < SK && kx < SK) ? trow[4 * q * T + ky * SK + kx] : 0.f;
+    }
+    if (8 * (u + 1) >= ksteps)                            // the spare k-steps behind the group
+      for (int i = threadIdx.x; i < (kalloc - ksteps) * 256; i += 256) wp[(((size_t)cls * ngrp + grp) * kalloc + ksteps) * 256 + i] = 0.f;
   }
 }
 
@@ -637,13 +652,19 @@ FN2_API size_t fn2_deconv_plane_packed_floats(int Cin, int Cout) {
   return 4 * (size_t)(Cout / 64) * ((((Cin + 3) / 4 + 1) / 2) * 2 * 4 + cp::kSpare) * 256;
 }
 
-FN2_API int fn2_deconv_plane_pack_weights(const float* weight, float* packed, int Cin, int Cout, void* stream) {
+FN2_API int fn2_deconv_plane_pack_weights_k(const float* weight, float* packed, int Cin, int Cout, int src_kernel, void* stream) {
   if (!weight || !packed) return fail(FN2_ERR_INVALID_ARG, "deconv_plane_pack_weights: null blob");
   if (Cin <= 0 || Cout <= 0 || Cout % 64 != 0) return fail(FN2_ERR_UNSUPPORTED, "deconv_plane_pack_weights: needs Cout %% 64 == 0 (got %d)", Cout);
-  const int ksteps = (((Cin + 3) / 4 + 1) / 2) * 2 * 4, kalloc = ksteps + cp::kSpare;
-  const long long total = 4ll * (Cout / 64) * kalloc * 256;
-  hipLaunchKernelGGL(cp::pack_deconv_weights, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), weight, packed, Cin, Cout, ksteps, kalloc);
+  if (src_kernel != 3 && src_kernel != 4) return fail(FN2_ERR_UNSUPPORTED, "deconv_plane_pack_weights: the blob has 4x4 taps, or 3x3 (zero-padded to 4x4)");
+  const int units = ((Cin + 3) / 4 + 1) / 2, ksteps = units * 2 * 4, kalloc = ksteps + cp::kSpare;
+  const dim3 grid((unsigned)(Cout / 64), (unsigned)units);
+  if (src_kernel == 4) hipLaunchKernelGGL((cp::pack_deconv_weights<4>), grid, dim3(256), 0, as_stream(stream), weight, packed, Cin, Cout, ksteps, kalloc);
+  else hipLaunchKernelGGL((cp::pack_deconv_weights<3>), grid, dim3(256), 0, as_stream(stream), weight, packed, Cin, Cout, ksteps, kalloc);
   return check_launch("deconv_plane_pack_weights");
+}
+
+FN2_API int fn2_deconv_plane_pack_weights(const float* weight, float* packed, int Cin, int Cout, void* stream) {
+  return fn2_deconv_plane_pack_weights_k(weight, packed, Cin, Cout, 4, stream);
 }
 
 FN2_API int fn2_deconv_plane_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,

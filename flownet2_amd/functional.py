@@ -547,8 +547,7 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
             # small maps whose width is not a multiple of 4 (conv5, conv6: top_diff 10x14 / 5x7): the transposed 3x3 / 2 / 1 convolution IS the
             # Deconvolution{4, 2, 1} whose fourth tap row and column are zero (Y = 2 y - 1 + ky in both) -- the small-map deconvolution kernel
             # on the weight blob padded to 4x4 (16 taps computed for 9: these layers are 1-2 % of a training step)
-            pw = _cached_pack(_PACKED_T, w, "tconv-plane",
-                              lambda: ops.deconv_plane_pack_weights(torch.nn.functional.pad(w.detach(), (0, 1, 0, 1)).contiguous()))
+            pw = _cached_pack(_PACKED_T, w, "tconv-plane", lambda: ops.deconv_plane_pack_weights(w.detach().contiguous()))     # (3x3 -> zero taps: in the kernel)
             return ops.deconv_plane_forward(d.contiguous(), pw, None, Cin, relu=False)
         return None
     if k == 1 and stride == 1 and pad == 0:

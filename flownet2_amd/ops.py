@@ -704,14 +704,16 @@ def deconv_plane_ksplit(N, Cin, Hin, Win, Cout) -> int:
 
 
 def deconv_plane_pack_weights(weight):
-    """weight [Cin, Cout, 4, 4] (Caffe's deconvolution blob) -> per-parity-class MFMA operand order (once per weight update)."""
+    """weight [Cin, Cout, 4, 4] (Caffe's deconvolution blob) -> per-parity-class MFMA operand order (once per weight update).  A
+    [Cin, Cout, 3, 3] blob is read as the 4x4 one whose fourth tap row and column are zero (the transposed 3x3 / 2 / 1 convolution of a
+    data gradient on a small map), without a padded copy."""
     w = _chk(weight, "weight")
     Cin, Cout, k, k2 = w.shape
     n = _lib.lib().fn2_deconv_plane_packed_floats(Cin, Cout)
-    if k != 4 or k2 != 4 or n == 0:
+    if k not in (3, 4) or k2 != k or n == 0:
         raise ValueError(f"deconv_plane: unsupported weight shape {tuple(w.shape)}")
     packed = torch.empty(n, device=w.device, dtype=torch.float32)
-    check(_lib.lib().fn2_deconv_plane_pack_weights(_ptr(w), _ptr(packed), Cin, Cout, _stream()))
+    check(_lib.lib().fn2_deconv_plane_pack_weights_k(_ptr(w), _ptr(packed), Cin, Cout, k, _stream()))
     return packed
 
 

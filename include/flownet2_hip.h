@@ -458,6 +458,9 @@ int fn2_deconv_plane_ksplit(int N, int Cin, int Hin, int Win, int Cout);
 size_t fn2_deconv_plane_workspace_bytes(int N, int Cin, int Hin, int Win, int Cout);
 size_t fn2_deconv_plane_packed_floats(int Cin, int Cout);
 int fn2_deconv_plane_pack_weights(const float* weight, float* packed, int Cin, int Cout, void* stream);
+/* src_kernel 4: as above; 3: a [Cin][Cout][3][3] blob read as the 4x4 blob whose fourth tap row and column are zero -- the transposed
+ * 3x3 / 2 / 1 convolution that is the data gradient of conv5 / conv6 (conv_layer.cu:53-57) on maps the 16-byte kernels do not take. */
+int fn2_deconv_plane_pack_weights_k(const float* weight, float* packed, int Cin, int Cout, int src_kernel, void* stream);
 int fn2_deconv_plane_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
                              int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                              int Cout, int top_channels, int top_c0, int relu, float negative_slope,

@@ -398,13 +398,13 @@ def deconv_plane_pack_weights(weight):
     """weight [Cin, Cout, 4, 4] (Caffe's deconvolution blob) -> the per-parity-class MFMA operand order of fn2_deconv_plane_forward."""
     w = _f32(weight)
     Cin, Cout = w.shape[:2]
-    assert w.shape[2:] == (4, 4)
+    assert w.shape[2:] in ((4, 4), (3, 3))           # 3x3: read as the 4x4 blob whose fourth tap row / column are zero
     L = lib()
     L.fn2_deconv_plane_packed_floats_cpu.restype = C.c_size_t
     n = L.fn2_deconv_plane_packed_floats_cpu(Cin, Cout)
     assert n > 0, "unsupported weight shape"
     packed = np.empty(n, np.float32)
-    _check(L.fn2_deconv_plane_pack_weights_cpu(_p(w), _p(packed), Cin, Cout), "deconv_plane_pack_weights")
+    _check(L.fn2_deconv_plane_pack_weights_k_cpu(_p(w), _p(packed), Cin, Cout, int(w.shape[2])), "deconv_plane_pack_weights")
     return packed
 
 

@@ -1289,9 +1289,10 @@ FN2_API size_t fn2_deconv_plane_packed_floats_cpu(int Cin, int Cout) {
 
 static int deconv_tap(int parity, int t) { return parity == 0 ? (t == 0 ? 3 : 1) : (t == 0 ? 2 : 0); }
 
-FN2_API int fn2_deconv_plane_pack_weights_cpu(const float* weight, float* packed, int Cin, int Cout) {
-  if (!weight || !packed || Cin <= 0 || Cout <= 0 || Cout % 64 != 0) return FN2_ERR_INVALID_ARG;
-  const int ksteps = deconv_plane_ksteps(Cin), kalloc = ksteps + 8;
+/* src_kernel 4: the Deconvolution{4, 2, 1} blob; 3: a [Cin][Cout][3][3] blob read as the 4x4 one whose fourth tap row / column are zero */
+FN2_API int fn2_deconv_plane_pack_weights_k_cpu(const float* weight, float* packed, int Cin, int Cout, int src_kernel) {
+  if (!weight || !packed || Cin <= 0 || Cout <= 0 || Cout % 64 != 0 || (src_kernel != 3 && src_kernel != 4)) return FN2_ERR_INVALID_ARG;
+  const int ksteps = deconv_plane_ksteps(Cin), kalloc = ksteps + 8, sk = src_kernel;
   for (int cls = 0; cls < 4; ++cls)
     for (int g = 0; g < Cout / 64; ++g)
       for (int ks = 0; ks < kalloc; ++ks)
@@ -1300,9 +1301,13 @@ FN2_API int fn2_deconv_plane_pack_weights_cpu(const float* weight, float* packed
             const int co = 64 * g + 16 * j + (lane & 15), ci = 4 * (ks / 4) + (lane >> 4);
             const int ky = deconv_tap(cls >> 1, (ks >> 1) & 1), kx = deconv_tap(cls & 1, ks & 1);
             packed[((((size_t)cls * (Cout / 64) + g) * kalloc + ks) * 64 + lane) * 4 + j] =
-                (ks < ksteps && ci < Cin) ? weight[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.f;
+                (ks < ksteps && ci < Cin && ky < sk && kx < sk) ? weight[(((size_t)ci * Cout + co) * sk + ky) * sk + kx] : 0.f;
           }
   return FN2_OK;
+}
+
+FN2_API int fn2_deconv_plane_pack_weights_cpu(const float* weight, float* packed, int Cin, int Cout) {
+  return fn2_deconv_plane_pack_weights_k_cpu(weight, packed, Cin, Cout, 4);
 }
 
 FN2_API int fn2_deconv_plane_forward_cpu(const float* bottom, const float* packed, const float* bias, float* top,

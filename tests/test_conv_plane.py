@@ -422,3 +422,19 @@ def test_hip_plane_deconv_random_geometries_equal_oracle_bitwise():
             ops.set_plane_variant(-1)
         ran += 1
     assert ran >= 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(16, 64, 4), (10, 128, 4), (26, 64, 3), (512, 256, 3), (9, 64, 3)])
+def test_hip_deconv_weight_packing_equals_the_oracle_bitwise(shape):
+    """fn2_deconv_plane_pack_weights_k (LDS-tiled): the 4x4 blob, and a 3x3 blob read as the 4x4 one with a zero fourth tap row / column
+    (== packing torch's zero-padded copy)."""
+    from flownet2_amd import ops
+    Cin, Cout, k = shape
+    w = rnd((Cin, Cout, k, k), 61)
+    got = ops.deconv_plane_pack_weights(torch.from_numpy(w).cuda()).cpu().numpy()
+    assert np.array_equal(got, oracle.deconv_plane_pack_weights(w))
+    if k == 3:
+        padded = F.pad(torch.from_numpy(w), (0, 1, 0, 1)).contiguous()
+        assert np.array_equal(got, ops.deconv_plane_pack_weights(padded.cuda()).cpu().numpy())
+        assert np.array_equal(got, oracle.deconv_plane_pack_weights(padded.numpy()))
