@@ -12,8 +12,8 @@ mkdir -p $R
 # profiled runs below launch no candidates
 export FN2_AUTOTUNE_CACHE=$PWD/$R/autotune.txt
 rm -f $FN2_AUTOTUNE_CACHE
-# warm MIOpen's find-db so the profiled run shows steady-state kernels only
-python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+# the unprofiled bench line first (what the driver runs, on a box that has done nothing else yet); it also records the autotune picks
+python bench.py > $R/bench.json 2> $R/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $R/bench_profiled.json 2>/dev/null
 # 6000 forward launches (0.25 s): the chip needs ~25 ms of load (the first ~500 launches) to reach its steady clocks -- a 200-launch run
 # (rounds 1-2) sat inside that ramp and read 47 us for a kernel that runs at 41.3 us from launch 500 on; the average below includes the ramp
@@ -33,7 +33,6 @@ python tests/cpu_baselines.py >> gpurun_out/layer_microbench.txt 2>/dev/null
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/layers -o lay -- python scripts/layer_microbench.py > /dev/null 2>&1
 timeout 300 python scripts/train_pipeline.py --iters 8 2>/dev/null | tail -11 > gpurun_out/train_pipeline.txt
 fi
-python bench.py > $R/bench.json 2> $R/bench.err
 # the other configurations of BASELINE.json (FlowNet2 at 768x384 batch 4 and 1024x448 batch 1, FlowNetC training step) and the
 # per-variant convolution timings
 python bench.py --net 2 --batch 4 --height 384 --width 768 --steps 60 --warmup 8 --no-cpu-baseline --no-extras > $R/bench_flownet2.json 2>/dev/null
