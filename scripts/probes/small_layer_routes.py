@@ -18,6 +18,8 @@ B1 = [  # name, N, Cin, H, W, Cout, k, s, p     batch 1 @1024x448
     ("conv2", 1, 64, 224, 512, 128, 5, 2, 2), ("conv3", 1, 128, 112, 256, 256, 5, 2, 2), ("S.conv1", 1, 12, 448, 1024, 64, 7, 2, 3),
     ("sd_conv1_1", 1, 64, 224, 512, 128, 3, 1, 1), ("sd_conv2", 1, 128, 224, 512, 128, 3, 2, 1), ("sd_conv2_1", 1, 128, 112, 256, 128, 3, 1, 1),
     ("sd_conv3", 1, 128, 112, 256, 256, 3, 2, 1), ("sd_ic4", 1, 770, 28, 64, 256, 3, 1, 1), ("sd_ic3", 1, 386, 56, 128, 128, 3, 1, 1), ("sd_ic2", 1, 194, 112, 256, 64, 3, 1, 1)]
+C8 = [("conv4", 8, 256, 40, 56, 512, 3, 2, 1), ("conv5", 8, 512, 20, 28, 512, 3, 2, 1), ("conv5_1", 8, 512, 10, 14, 512, 3, 1, 1),
+      ("conv6", 8, 512, 10, 14, 1024, 3, 2, 1), ("conv6_1", 8, 1024, 5, 7, 1024, 3, 1, 1), ("conv4_1", 8, 512, 20, 28, 512, 3, 1, 1)]      # FlowNetC, batch 8 @448x320
 B4 = [("conv3_1", 4, 256, 48, 96, 256, 3, 1, 1), ("conv4_1", 4, 512, 24, 48, 512, 3, 1, 1), ("conv5_1", 4, 512, 12, 24, 512, 3, 1, 1), ("conv6_1", 4, 1024, 6, 12, 1024, 3, 1, 1)]
 
 
@@ -47,7 +49,7 @@ def timeit(fn, iters=30, warm=5):
 
 g = torch.Generator(device="cuda").manual_seed(0)
 tot = {"own": 0.0, "lib": 0.0, "best": 0.0}
-for name, N, Cin, H, W, Cout, k, s, p in (B4 if "--b4" in sys.argv else B1):
+for name, N, Cin, H, W, Cout, k, s, p in (B4 if "--b4" in sys.argv else C8 if "--c8" in sys.argv else B1):
     x = torch.randn(N, Cin, H, W, device="cuda", generator=g)
     w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * (2.0 / (Cin * k * k)) ** 0.5
     b = torch.randn(Cout, device="cuda", generator=g) * 0.1
