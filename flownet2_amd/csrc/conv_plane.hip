@@ -234,22 +234,27 @@ conv_plane(Args a) {
         for (int p = 0; p < NP; ++p) b[kx][p] = wk[base[p] + kx];
     };
     lds_step(0, bb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    // Issue order pinned group by group: the MW MFMAs that share a pixel operand, then ONE LDS read of the next step's operands.  A read
+    // issued between MFMAs is free (scripts/probes/mfma_32x32_probe.hip: 153.9 TFLOP/s with one ds_read_b32 per MFMA, 154.1 without); the
+    // block of TAP * NP reads the compiler forms when left alone leaves the matrix pipe one queued instruction deep for ~170 cycles a step.
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
-      if (st + 1 < NSTEP) lds_step(st + 1, bb[(st + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
+      const float* wkn = win + (((st + 1) / TAP) * 4 * a.cs + ((st + 1) % TAP) * a.rs);
 #pragma unroll
       for (int kx = 0; kx < TAP; ++kx) {
         const int ks = st * TAP + kx;
         wreg[(ks + K::NBUFA - 1) % K::NBUFA] = wload(ks0 + ks + K::NBUFA - 1);
         const WV w = wreg[ks % K::NBUFA];
 #pragma unroll
-        for (int j = 0; j < MW; ++j)
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-          for (int p = 0; p < NP; ++p)
+          for (int j = 0; j < MW; ++j)
             acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(bb[st & 1][kx][p], wget<MW>(w, j), acc[j][p], 0, 0, 0);
+          if (st + 1 < NSTEP) bb[(st + 1) & 1][kx][p] = wkn[base[p] + kx];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
