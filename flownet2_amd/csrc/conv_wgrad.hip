@@ -244,6 +244,43 @@ __global__ void __launch_bounds__(256) wgrad_finalize(const float* __restrict__ 
   }
 }
 
+// The same sums through LDS, one workgroup per (channel block, wave, ma, nb) group of T tap tiles: the slab hands a thread element
+// (m, n) of every tap tile -- weight elements T floats apart per lane and Cb * T apart per register, i.e. one 4-byte write per 32-byte
+// sector in the kernel above (0.28 ms per training step for 157 MB of gradients: 8x write amplification) -- while the weight layout is
+// contiguous over (cb, tap) for a fixed ca: 16 runs of 16 * T floats per group.  Parts are added in part order as above: same bits.
+template <int T>
+__global__ void __launch_bounds__(256) wgrad_finalize_tiled(const float* __restrict__ slab, float* __restrict__ dw, SlabMap m, int Ca, int Cb, int nblk_b,
+                                                            int ksplit, long long slab_part, int accumulate) {
+  __shared__ float tile[256 * T + 16];                    // [m][n][T], rows of 16 * T + 1 floats
+  constexpr int ROW = 16 * T + 1;
+  unsigned g = blockIdx.x;
+  const int nb = (int)(g % m.NB); g /= m.NB;
+  const int ma = (int)(g % m.MA); g /= m.MA;
+  const int wave = (int)(g & 3);
+  const int blk = (int)(g >> 2);
+  const int wmi = wave % m.WM, wni = wave / m.WM;
+  const int ca0 = (blk / nblk_b) * m.CA + (wmi * m.MA + ma) * 16;
+  const int cb0 = (blk % nblk_b) * m.CB + (wni * m.NB + nb) * 16;
+  if (ca0 >= Ca || cb0 >= Cb) return;                     // a group of padding channels only
+  const int lane = threadIdx.x >> 2, reg = threadIdx.x & 3;
+  const int mm = 4 * (lane >> 4) + reg, nn = lane & 15;
+  const float* p = slab + (((size_t)blk * 4 + wave) * m.TILES + (size_t)(ma * m.NB + nb) * T) * 256 + threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float s = p[(size_t)t * 256];
+    for (int k = 1; k < ksplit; ++k) s += p[(size_t)k * (size_t)slab_part + (size_t)t * 256];
+    tile[mm * ROW + nn * T + t] = s;
+  }
+  __syncthreads();
+  const int ncb = min(16, Cb - cb0);                      // real `b` channels of the group: a run of ncb * T floats per `a` channel
+#pragma unroll 1
+  for (int row = 0; row < 16; ++row) {
+    if (ca0 + row >= Ca) break;
+    float* o = dw + ((size_t)(ca0 + row) * Cb + cb0) * T;
+    for (int r = threadIdx.x; r < ncb * T; r += 256) o[r] = accumulate ? o[r] + tile[row * ROW + r] : tile[row * ROW + r];
+  }
+}
+
 // [planes][H][W] -> [planes][H][Wp] (Wp = W rounded up to 4, zeros behind the row): rows of odd / narrow maps become 16-byte aligned
 __global__ void __launch_bounds__(256) pad_width(const float* __restrict__ in, float* __restrict__ out, long long rows, int W, int Wp,
                                                  int C, int ctot, int c0, int H) {
@@ -398,6 +435,20 @@ FN2_API int fn2_conv_wgrad(const float* a, const float* b, float* dw,
   const int rc = v.fn(g, st);
   if (rc != FN2_OK) return rc;
   const long long quads = (long long)p.slab_floats / 4;
+  const long long groups = (long long)p.nblk_a * p.nblk_b * 4 * v.map.MA * v.map.NB;
+  static const bool tiled = [] { const char* e = getenv("FN2_WGRAD_FINALIZE"); return !(e && e[0] == 'g'); }();      // "gather": the per-element kernel
+  // (a group is T * 256 floats summed over ksplit parts by one workgroup: only where that still leaves >= 8 workgroups per CU -- the layers
+  // with megabytes of weights and few parts; conv2's 64 parts x 32 groups are the per-element kernel's)
+  if (tiled && groups >= 2048 && groups < (1ll << 31) && (v.map.T == 1 || v.map.T == 9 || v.map.T == 16 || v.map.T == 25)) {
+    const dim3 grid((unsigned)groups);
+    switch (v.map.T) {
+      case 1: hipLaunchKernelGGL((wg::wgrad_finalize_tiled<1>), grid, dim3(256), 0, st, slab, dw, v.map, Ca, Cb, p.nblk_b, p.ksplit, g.slab_part, accumulate ? 1 : 0); break;
+      case 9: hipLaunchKernelGGL((wg::wgrad_finalize_tiled<9>), grid, dim3(256), 0, st, slab, dw, v.map, Ca, Cb, p.nblk_b, p.ksplit, g.slab_part, accumulate ? 1 : 0); break;
+      case 16: hipLaunchKernelGGL((wg::wgrad_finalize_tiled<16>), grid, dim3(256), 0, st, slab, dw, v.map, Ca, Cb, p.nblk_b, p.ksplit, g.slab_part, accumulate ? 1 : 0); break;
+      default: hipLaunchKernelGGL((wg::wgrad_finalize_tiled<25>), grid, dim3(256), 0, st, slab, dw, v.map, Ca, Cb, p.nblk_b, p.ksplit, g.slab_part, accumulate ? 1 : 0); break;
+    }
+    return check_launch("conv_wgrad_finalize");
+  }
   hipLaunchKernelGGL(wg::wgrad_finalize, dim3(blocks_for(quads, 256, 8192)), dim3(256), 0, st, slab, dw, v.map, Ca, Cb, p.nblk_b, quads, p.ksplit,
                      g.slab_part, accumulate ? 1 : 0);
   return check_launch("conv_wgrad_finalize");
