@@ -437,9 +437,10 @@ FN2_API int fn2_conv_wgrad(const float* a, const float* b, float* dw,
   const long long quads = (long long)p.slab_floats / 4;
   const long long groups = (long long)p.nblk_a * p.nblk_b * 4 * v.map.MA * v.map.NB;
   static const bool tiled = [] { const char* e = getenv("FN2_WGRAD_FINALIZE"); return !(e && e[0] == 'g'); }();      // "gather": the per-element kernel
-  // (a group is T * 256 floats summed over ksplit parts by one workgroup: only where that still leaves >= 8 workgroups per CU -- the layers
+  static const long long g_tiled_min = [] { const char* e = getenv("FN2_WGRAD_TILED_MIN"); return e ? atoll(e) : 1024ll; }();
+  // (a group is T * 256 floats summed over ksplit parts by one workgroup: only where that still leaves >= 4 workgroups per CU (measured: 512 loses on conv4 / conv3_1, 1024 wins on deconv4) -- the layers
   // with megabytes of weights and few parts; conv2's 64 parts x 32 groups are the per-element kernel's)
-  if (tiled && groups >= 2048 && groups < (1ll << 31) && (v.map.T == 1 || v.map.T == 9 || v.map.T == 16 || v.map.T == 25)) {
+  if (tiled && groups >= g_tiled_min && groups < (1ll << 31) && (v.map.T == 1 || v.map.T == 9 || v.map.T == 16 || v.map.T == 25)) {
     const dim3 grid((unsigned)groups);
     switch (v.map.T) {
       case 1: hipLaunchKernelGGL((wg::wgrad_finalize_tiled<1>), grid, dim3(256), 0, st, slab, dw, v.map, Ca, Cb, p.nblk_b, p.ksplit, g.slab_part, accumulate ? 1 : 0); break;
