@@ -308,7 +308,7 @@ static int launch(const Args& a, hipStream_t st) {
 }
 
 struct Variant {
-  int ks, s, xt, db;
+  int ks, s, xt, r, db;
   int ca, cb, tiles;
   SlabMap map;
   int (*fn)(const Args&, hipStream_t);
@@ -321,9 +321,11 @@ struct Variant {
 #define FN2_WG_LIST(X) \
   FN2_WG_CLASS(X, 1, 1, 2, 4, 1, 4) FN2_WG_CLASS(X, 3, 1, 2, 2, 2, 2) FN2_WG_CLASS(X, 3, 2, 2, 2, 2, 2) \
   FN2_WG_CLASS(X, 4, 2, 2, 1, 2, 2) FN2_WG_CLASS(X, 5, 2, 2, 1, 2, 2) \
-  X(3, 1, 2, 2, 2, 2, 56, 1, 1) X(3, 1, 2, 2, 2, 2, 56, 1, 0)
+  X(3, 1, 2, 2, 2, 2, 56, 1, 1) X(3, 1, 2, 2, 2, 2, 56, 1, 0) \
+  /* chunks of 5 rows x 8 pixels: one whole 5x7 sample (conv6_1, deconv5: the 4-row chunks spend 8 row slots on 5 rows) */ \
+  X(3, 1, 2, 2, 2, 2, 8, 5, 1) X(4, 2, 2, 1, 2, 2, 8, 5, 1)        /* (3x3 / 2: its 11-row `b` window does not fit twice into the LDS) */
 #define FN2_WG_ROW(KS, S, MA, NB, WM, WN, XT, R, DB) \
-  {KS, S, XT, DB, Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>::CA, Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>::CB, Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>::TILES, \
+  {KS, S, XT, R, DB, Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>::CA, Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>::CB, Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>::TILES, \
    slab_map<Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>>(), &launch<Cfg<KS, S, MA, NB, WM, WN, XT, R, DB>>},
 static const Variant kVariants[] = {FN2_WG_LIST(FN2_WG_ROW)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
@@ -334,13 +336,19 @@ int g_forced_xt = 0;           // fn2_debug_set_wgrad_chunk: forces the chunk wi
 inline int round4(int v) { return (v + 3) / 4 * 4; }
 
 // chunk width for a (padded) row width: whole small rows, 28-pixel pieces of wide ones (56 for the 3x3 / 1 class when it divides better)
-static int pick_variant(int KS, int S, int Wa) {
+static int pick_variant(int KS, int S, int Wa, int Ha) {
   int xt = Wa <= 8 ? 8 : Wa <= 16 ? 16 : 28;
+  // rows per chunk: the class default (4 / 2 / 1 for 8 / 16 / 28+ pixels), or 5 where the map has 5 rows (a sample = one chunk).  The
+  // accumulation order is (n, y, x) whatever the chunk shape: the padding slots add exact zeros
+  const int want_r = (xt == 8 && Ha % 5 == 0 && g_forced_xt == 0) ? 5 : 0;
   if (KS == 3 && S == 1 && Wa >= 56 && cdiv_c(Wa, 56) * 56 <= cdiv_c(Wa, 28) * 28) xt = 56;
   if (g_forced_xt > 0 && (g_forced_xt >= 28 || g_forced_xt >= Wa)) xt = g_forced_xt;     // (chunks of several rows need whole rows)
   const int db = g_forced_db >= 0 ? g_forced_db : 1;      // two buffers: measured faster on every FlowNetC layer (and the 5x5 one-buffer kernel spills)
+  if (want_r)
+    for (int i = 0; i < kNumVariants; ++i)
+      if (kVariants[i].ks == KS && kVariants[i].s == S && kVariants[i].xt == xt && kVariants[i].db == db && kVariants[i].r == want_r) return i;
   for (int i = 0; i < kNumVariants; ++i)
-    if (kVariants[i].ks == KS && kVariants[i].s == S && kVariants[i].xt == xt && kVariants[i].db == db) return i;
+    if (kVariants[i].ks == KS && kVariants[i].s == S && kVariants[i].xt == xt && kVariants[i].db == db && kVariants[i].r != 5) return i;
   return -1;
 }
 
@@ -353,7 +361,7 @@ static bool make_plan(Plan& p, int N, int Ca, int Ha, int Wa, int Cb, int Hb, in
   if (N <= 0 || Ca <= 0 || Ha <= 0 || Wa <= 0 || Cb <= 0 || Hb <= 0 || Wb <= 0) return false;
   if (pad < 0 || pad > 4 || pad > KS - 1) return false;
   p.Wap = round4(Wa); p.Wbp = round4(Wb);
-  p.variant = pick_variant(KS, S, p.Wap);
+  p.variant = pick_variant(KS, S, p.Wap, Ha);
   if (p.variant < 0) return false;
   const Variant& v = kVariants[p.variant];
   if ((long long)v.ca * Ha * p.Wap >= (1ll << 28) || (long long)v.cb * Hb * p.Wbp >= (1ll << 28)) return false;   // descriptor range
