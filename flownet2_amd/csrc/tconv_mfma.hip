@@ -162,19 +162,26 @@ __device__ __forceinline__ void tconv_body(const Args& a, int g, int bx, int by,
     if (c + 1 < a.nchunks) stage(c + 1, buf ^ 1);
     const float* win = smem + buf * K::BUF + bbase;
     const int ks0 = c * K::KSC;
+    // operand reads one k-step ahead, ONE read behind the MW MFMAs of every patch (pinned: a block of NP reads in front of the MFMAs
+    // leaves the matrix pipe a single queued instruction deep while it issues; csrc/conv_plane.hip, DESIGN 3.4 c)
+    float b[2][NP];
+    auto tap_off = [](int ks) { const int cq = ks / (KS * KS), ky = (ks / KS) % KS, kx = ks % KS; return cq * 4 * K::CS + P::d_of(ky) * K::RS + P::d_of(kx); };
+#pragma unroll
+    for (int p = 0; p < NP; ++p) b[0][p] = win[tap_off(0) + 4 * p];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < K::KSC; ++ks) {
       wreg[(ks + K::NBUFA - 1) % K::NBUFA] = wload(ks0 + ks + K::NBUFA - 1);      // the packed array carries spare k-steps
-      const int cq = ks / (KS * KS), ky = (ks / KS) % KS, kx = ks % KS;
+      const int ky = (ks / KS) % KS, kx = ks % KS;
       const int cls = 2 * P::par_of(ky) + P::par_of(kx);
-      float b[NP];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) b[p] = win[cq * 4 * K::CS + P::d_of(ky) * K::RS + P::d_of(kx) + 4 * p];
       const WV w = wreg[ks % K::NBUFA];
 #pragma unroll
-      for (int j = 0; j < MW; ++j)
+      for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) acc[cls][j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[p], wget<MW>(w, j), acc[cls][j][p], 0, 0, 0);
+        for (int j = 0; j < MW; ++j) acc[cls][j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ks & 1][p], wget<MW>(w, j), acc[cls][j][p], 0, 0, 0);
+        if (ks + 1 < K::KSC) b[(ks + 1) & 1][p] = win[tap_off(ks + 1 < K::KSC ? ks + 1 : ks) + 4 * p];
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
