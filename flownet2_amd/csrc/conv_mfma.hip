@@ -53,9 +53,10 @@ struct Args {
 
 // P16 (1x1 kernels only): the M tile is 16 CONSECUTIVE pixels of one row instead of a 4x4 patch -- the launcher flattens every plane into
 // one row of H * W pixels (a 1x1 convolution has no spatial window), so no tile hangs over an image edge: the plain-GEMM form.
-template <int KS_, int S_, int MW_, int NP_, int WM_, int WNX_, int WNY_, int CQ_, int P16_ = 0>
+template <int KS_, int S_, int MW_, int NP_, int WM_, int WNX_, int WNY_, int CQ_, int P16_ = 0, int PIN_ = 0>
 struct Cfg {
   static constexpr int KS = KS_, S = S_, MW = MW_, NP = NP_, WM = WM_, WNX = WNX_, WNY = WNY_, CQ = CQ_, P16 = P16_;
+  static constexpr int PIN = PIN_;      // 1: operand reads pinned one behind each patch's MFMAs, a k-step ahead (else the compiler's order)
   static constexpr int NW = WM * WNX * WNY, THREADS = 64 * NW;
   static constexpr int PADL = 4;                                     // window columns left of S * x0 (16-byte aligned start)
   static constexpr int TW = (P16 ? 16 : 4) * NP * WNX, TH = (P16 ? 1 : 4) * WNY;   // output pixels of a workgroup tile
@@ -165,6 +166,29 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
     if (c + 1 < a.nchunks) stage(c + 1, buf ^ 1);
     const float* win = smem + buf * K::BUF + bbase;
     const int ks0 = c * K::KSC;
+    if constexpr (K::PIN) {
+      // operand reads one k-step ahead, ONE read behind the MW MFMAs of every patch, order pinned (a block of NP reads in front of a
+      // k-step's MFMAs leaves the matrix pipe a single queued instruction deep while it issues: csrc/conv_plane.hip, DESIGN 3.4 c).
+      // A variant of its own: conv3 [16,128,80,112] gains (434 -> 412 us), conv2 [16,64,160,224] loses (428 -> 490): the autotuner
+      // decides per layer, the bits are the same.
+      float b[2][NP];
+      auto tap_off = [](int ks) { const int cq = ks / (KS * KS), ky = (ks / KS) % KS, kx = ks % KS; return cq * 4 * K::CS + ky * K::RS + kx; };
+#pragma unroll
+      for (int p = 0; p < NP; ++p) b[0][p] = win[tap_off(0) + PW * S * p];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < K::KSC; ++ks) {
+        wreg[(ks + K::NBUFA - 1) % K::NBUFA] = wload(ks0 + ks + K::NBUFA - 1);
+        const WV w = wreg[ks % K::NBUFA];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+          for (int j = 0; j < MW; ++j) acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ks & 1][p], wget<MW>(w, j), acc[j][p], 0, 0, 0);
+          if (ks + 1 < K::KSC) b[(ks + 1) & 1][p] = win[tap_off(ks + 1 < K::KSC ? ks + 1 : ks) + PW * S * p];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < K::KSC; ++ks) {
       wreg[(ks + K::NBUFA - 1) % K::NBUFA] = wload(ks0 + ks + K::NBUFA - 1);      // the packed array carries NBUFA spare k-steps
@@ -177,6 +201,7 @@ __device__ __forceinline__ void conv_body(const Args& a, int g, int bx, int by, 
       for (int j = 0; j < MW; ++j)
 #pragma unroll
         for (int p = 0; p < NP; ++p) acc[j][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[p], wget<MW>(w, j), acc[j][p], 0, 0, 0);
+    }
     }
   }
 
@@ -433,6 +458,8 @@ template <class K> struct TailFn<K, 1> { static constexpr int (*fn)(const Args&,
   {KS, S, MW, NP, WM, WNX, WNY, 0, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>>, TailFn<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ>, TAIL>::fn},
 #define FN2_CV_ROW16(MW, NP, WM, WNX, WNY, TAIL) \
   {1, 1, MW, NP, WM, WNX, WNY, 1, &launch<Cfg<1, 1, MW, NP, WM, WNX, WNY, 8, 1>>, TailFn<Cfg<1, 1, MW, NP, WM, WNX, WNY, 8, 1>, TAIL>::fn},
+#define FN2_CV_PIN(KS, S, MW, NP, WM, WNX, WNY, CQ, P16, TAIL) \
+  {KS, S, MW, NP, WM, WNX, WNY, P16, &launch<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ, P16, 1>>, TailFn<Cfg<KS, S, MW, NP, WM, WNX, WNY, CQ, P16, 1>, TAIL>::fn},
 static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)
   /* 1x1 on flattened planes (16-pixel row tiles): TW = 16 NP WNX pixels */
   /* (WNY = 1: a flattened plane has one row) */
@@ -442,7 +469,11 @@ static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)
   /* planes of 140 (10x14) / 288 (12x24) pixels: 9 x 16 = 144 */
   FN2_CV_ROW16(2, 9, 4, 1, 1, 1) FN2_CV_ROW16(2, 9, 2, 2, 1, 1) FN2_CV_ROW16(2, 3, 2, 2, 1, 1) FN2_CV_ROW16(4, 3, 1, 4, 1, 0)
   /* 256-channel workgroup tiles (36 / 28 accumulator tiles per wave): fewer re-reads of the pixel operand by the big-M deconvolution GEMMs */
-  FN2_CV_ROW16(4, 9, 4, 1, 1, 0) FN2_CV_ROW16(4, 9, 2, 2, 1, 0) FN2_CV_ROW16(4, 7, 4, 1, 1, 0)};
+  FN2_CV_ROW16(4, 9, 4, 1, 1, 0) FN2_CV_ROW16(4, 9, 2, 2, 1, 0) FN2_CV_ROW16(4, 7, 4, 1, 1, 0)
+  /* pinned issue order (Cfg::PIN): the 5x5 / 2 tiles the encoders pick and the GEMM tiles of the deconvolutions */
+  FN2_CV_PIN(5, 2, 2, 7, 2, 2, 1, 1, 0, 1) FN2_CV_PIN(5, 2, 2, 7, 2, 1, 2, 1, 0, 1)
+  FN2_CV_PIN(1, 1, 4, 9, 4, 1, 1, 8, 1, 0) FN2_CV_PIN(1, 1, 2, 9, 4, 1, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 2, 5, 2, 2, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 4, 7, 4, 1, 1, 8, 1, 0)
+  FN2_CV_PIN(1, 1, 2, 7, 2, 2, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 2, 3, 2, 2, 1, 8, 1, 1)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int g_forced_variant = -1;       // >= 0: plain launch of that variant; >= 1000: its split-tail launch
