@@ -473,7 +473,10 @@ static const Variant kVariants[] = {FN2_CV_LIST(FN2_CV_ROW)
   /* pinned issue order (Cfg::PIN): the 5x5 / 2 tiles the encoders pick and the GEMM tiles of the deconvolutions */
   FN2_CV_PIN(5, 2, 2, 7, 2, 2, 1, 1, 0, 1) FN2_CV_PIN(5, 2, 2, 7, 2, 1, 2, 1, 0, 1)
   FN2_CV_PIN(1, 1, 4, 9, 4, 1, 1, 8, 1, 0) FN2_CV_PIN(1, 1, 2, 9, 4, 1, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 2, 5, 2, 2, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 4, 7, 4, 1, 1, 8, 1, 0)
-  FN2_CV_PIN(1, 1, 2, 7, 2, 2, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 2, 3, 2, 2, 1, 8, 1, 1)};
+  FN2_CV_PIN(1, 1, 2, 7, 2, 2, 1, 8, 1, 1) FN2_CV_PIN(1, 1, 2, 3, 2, 2, 1, 8, 1, 1)
+  FN2_CV_PIN(3, 1, 2, 7, 2, 2, 1, 2, 0, 1) FN2_CV_PIN(3, 1, 2, 6, 2, 2, 1, 2, 0, 1) FN2_CV_PIN(3, 2, 2, 7, 2, 1, 2, 2, 0, 1) FN2_CV_PIN(3, 2, 2, 6, 2, 2, 1, 2, 0, 1)
+  FN2_CV_PIN(4, 2, 2, 7, 2, 2, 1, 2, 0, 1) FN2_CV_PIN(4, 2, 2, 6, 2, 2, 1, 2, 0, 1) FN2_CV_PIN(5, 2, 2, 6, 2, 2, 1, 1, 0, 1)
+  FN2_CV_PIN(7, 2, 2, 6, 2, 2, 1, 1, 0, 1) FN2_CV_PIN(7, 2, 4, 6, 1, 2, 2, 1, 0, 0)};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int g_forced_variant = -1;       // >= 0: plain launch of that variant; >= 1000: its split-tail launch
