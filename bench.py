@@ -250,7 +250,7 @@ def rank_seed(rank):
     return 1234 + rank              # every rank its own synthetic batch (weak scaling: per-GPU work fixed)
 
 
-def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0, rt=None):
+def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0, rt=None, local_grads=False):
     """W untimed warm-up steps (+ untimed settling steps until `settle_s` seconds of back-to-back stepping have passed: the chip
     needs ~25 ms of load to come back to its steady clocks, and a short run otherwise sits inside that ramp), then EXACTLY `steps`
     timed steps between barrier + synchronize on both sides.  Returns the measurements and what the caller needs for the oracle leg."""
@@ -271,7 +271,9 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         # the ONE exchange of the path: sum-all-reduce of the fp32 gradients (39.18 M floats = 156.7 MB) over RCCL, scaled by
         # 1/world (parallel.cpp:377), in reverse-order buckets launched from gradient hooks while backward is still running;
         # identical Adam step on every rank
-        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20)
+        # local_grads: the SAME step without the collective (every rank keeps its own gradients) -- the comparison leg from which
+        # train_leg() reports how much of the all-reduce is not hidden behind backward
+        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20, local_only=local_grads)
 
         def step():
             exchange.zero_grad()
@@ -349,8 +351,14 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         gc.enable()
     elapsed = parallel.max_over_ranks(elapsed, device)
     elapsed_cold = parallel.max_over_ranks(elapsed_cold, device)
-    return {"elapsed": elapsed, "params": P, "marks": marks, "out": out, "P_cpu": P_cpu, "img0": img0, "img1": img1, "use_graph": use_graph,
-            "gc_paused": gc_was_on, "settle_steps": settle_steps, "settling_s": settling_s, "elapsed_cold": elapsed_cold}
+    res = {"elapsed": elapsed, "params": P, "marks": marks, "out": out, "P_cpu": P_cpu, "img0": img0, "img1": img1, "use_graph": use_graph,
+           "gc_paused": gc_was_on, "settle_steps": settle_steps, "settling_s": settling_s, "elapsed_cold": elapsed_cold}
+    if mode == "train":
+        res["n_buckets"] = len(exchange.buckets)
+        res["buckets_launched_inside_backward"] = exchange.launched_in_backward      # of the last timed step
+        res["exchange_world"] = exchange.world
+        exchange.remove()
+    return res
 
 
 def flownet2_epe_vs_cpu(P_cpu, img0, img1, flow_gpu):
@@ -378,22 +386,48 @@ def extras(device, args):
             ex[key]["cpu_oracle_seconds_per_batch"] = round(secs, 2)
         del m
         torch.cuda.empty_cache()
-    m = run_workload("C", "train", 8, 320, 448, 20, 5, device, 1, 0, bucket_mb=args.bucket_mb)
-    ex["train_448x320"] = {"metric": "image-pairs/sec FlowNetC fwd+bwd+allreduce+Adam at 448x320", "value": round(8 * 20 / m["elapsed"], 2),
-                           "unit": "image-pairs/s", "batch": 8, "steps": 20, "warmup": 5, "ms_per_step": round(m["elapsed"] / 20 * 1e3, 4),
-                           "ms_per_step_p10_p50_p90": step_percentiles(m["marks"]), "dtype": "f32", "loss": float(m["out"]),
-                           "conv_tflops": round(nets.conv_flops("C", 320, 448) * 8 * 3 * 20 / m["elapsed"] / 1e12, 2)}
-    del m
-    torch.cuda.empty_cache()
+    ex["train_448x320"] = train_leg(device, 1, 0, args.bucket_mb)
     if not args.no_cpu_baseline:
         ex["train_448x320"].update(train_parity(device))
     return ex
 
 
+def train_leg(device, world, rank, bucket_mb=48, B=8, H=320, W=448, steps=20, warmup=5, settle_s=1.0, rt=None):
+    """BASELINE config 4 (FlowNetC fwd + bwd + gradient all-reduce + Adam, batch 8 per GPU) on EVERY rank of the job: with world > 1 this is
+    the leg that exercises the one collective of the path (parallel.GradientExchange: reverse-order buckets launched from gradient hooks over
+    RCCL; the reference: P2PSync::on_gradients_ready, parallel.cpp:325-380, effective batch x world, docs/multigpu.md:11).  Collective
+    calls inside: every rank must call it.  ms_per_step is the max over ranks; with world > 1 the same step is timed once more with
+    world-local gradients (no collective), and allreduce_ms_exposed = the difference = the part of the exchange backward does not hide."""
+    m = run_workload("C", "train", B, H, W, steps, warmup, device, world, rank, bucket_mb=bucket_mb, settle_s=settle_s, rt=rt)
+    ms = m["elapsed"] / steps * 1e3
+    leg = {"metric": "image-pairs/sec FlowNetC fwd+bwd+allreduce+Adam at %dx%d" % (W, H), "value": round(world * B * steps / m["elapsed"], 2),
+           "unit": "image-pairs/s", "n_gpus": world, "batch": B, "global_batch": B * world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
+           "ms_per_step_p10_p50_p90": step_percentiles(m["marks"]), "dtype": "f32", "loss": float(m["out"].detach()),
+           "conv_tflops": round(nets.conv_flops("C", H, W) * B * 3 * steps / m["elapsed"] / 1e12, 2),
+           "parallelism": "dp%d (one fp32 sum-all-reduce of %.1f MB per step in %d buckets <= %d MB, scaled by 1/%d)" % (
+               world, 4e-6 * nets.num_params(m["P_cpu"]), m["n_buckets"], bucket_mb, world),
+           "grad_buckets": m["n_buckets"], "buckets_launched_inside_backward": m["buckets_launched_inside_backward"],
+           "library_conv_fallbacks": LIB_FALLBACKS()}
+    del m
+    if device.type == "cuda":
+        torch.cuda.empty_cache()
+    if world > 1:
+        ml = run_workload("C", "train", B, H, W, steps, warmup, device, world, rank, bucket_mb=bucket_mb, settle_s=settle_s, rt=rt, local_grads=True)
+        ms_local = ml["elapsed"] / steps * 1e3
+        leg["ms_per_step_local_gradients"] = round(ms_local, 4)
+        leg["allreduce_ms_exposed"] = round(ms - ms_local, 4)
+        leg["ranks_seen_by_rccl"] = parallel.ranks_seen(device)
+        del ml
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
+    return leg
+
+
+
 def train_parity(device, B=8, H=320, W=448):
     """Checker leg of the training configuration (after the timing, never inside it): loss and every parameter gradient of ONE training
     step with production routing against the fp64 comparator oracle/fp64_graph.py (float64 autograd graph, none of the product's
-    kernels), at the configuration's own size.  grad_rel_l2_vs_ref = ||g - g64|| / ||g64|| over all 39 M gradient values."""
+    kernels), at the configuration's own size.  grad_rel_l2_* = ||g - g64|| / ||g64|| over all 39 M gradient values."""
     from oracle import fp64_graph
     P = nets.init_params("C", seed=0)
     Pd = {k: v.to(device).requires_grad_(True) for k, v in P.items()}
@@ -409,13 +443,22 @@ def train_parity(device, B=8, H=320, W=448):
     t0 = time.time()
     grads = {k: v.grad for k, v in Pd.items()}
     loss_p, g_p = fp64_graph.flownetc_train_reference(P, img0, img1, gt, device=device, masks=rec.branches)
-    loss64, g64 = fp64_graph.flownetc_train_reference(P, img0, img1, gt, device=device)
-    a, b = fp64_graph.grad_agreement(grads, g_p), fp64_graph.grad_agreement(grads, g64)
-    return {"grad_rel_l2_vs_ref": a["all"], "grad_rel_l2_vs_ref_worst_param": [a["worst_name"], a["worst"]], "grad_rel_l2_vs_ref_median_param": a["median"],
-            "loss_rel_err_vs_ref": abs(float(loss.detach()) - loss_p) / max(1.0, abs(loss_p)),
+    with fp64_graph.record_relu_branches() as rec64:
+        loss64, g64 = fp64_graph.flownetc_train_reference(P, img0, img1, gt, device=device)
+    # yardstick: the SAME torch graph in fp32 on the library's kernels (none of ours) against the plain fp64 graph
+    _, g_lib = fp64_graph.flownetc_train_reference(P, img0, img1, gt, device=device, dtype=torch.float32)
+    a, b, lib = fp64_graph.grad_agreement(grads, g_p), fp64_graph.grad_agreement(grads, g64), fp64_graph.grad_agreement(g_lib, g64)
+    flips, units = fp64_graph.relu_sign_flips(rec.branches, rec64.branches)
+    return {"grad_rel_l2_vs_fp64_same_relu_branch": a["all"], "grad_rel_l2_vs_fp64_same_relu_branch_worst_param": [a["worst_name"], a["worst"]],
+            "grad_rel_l2_vs_fp64_same_relu_branch_median_param": a["median"],
+            "loss_rel_err_vs_fp64_same_relu_branch": abs(float(loss.detach()) - loss_p) / max(1.0, abs(loss_p)),
             "grad_rel_l2_vs_plain_fp64": b["all"], "grad_rel_l2_vs_plain_fp64_worst_param": [b["worst_name"], b["worst"]],
-            "ref": "oracle/fp64_graph.py: float64 autograd graph on the same inputs, every leaky ReLU on the branch the fp32 run took "
-                   "(vs_plain_fp64: with its own ReLU signs -- the handful of units within rounding of zero dominate that figure) (%.1f s)" % (time.time() - t0)}
+            "relu_sign_flips_vs_plain_fp64": flips, "relu_units": units,
+            "library_fp32_grad_rel_l2_vs_plain_fp64": lib["all"], "library_fp32_grad_rel_l2_vs_plain_fp64_worst_param": [lib["worst_name"], lib["worst"]],
+            "ref": "oracle/fp64_graph.py: float64 autograd graph on the same inputs (none of the product's kernels).  ..._same_relu_branch: every leaky "
+                   "ReLU of the fp64 graph on the branch the fp32 run took = the rounding error of the product's kernels; ..._vs_plain_fp64: the fp64 "
+                   "graph with its own ReLU signs -- the relu_sign_flips units (pre-activations within rounding of zero) dominate that figure, "
+                   "for the library's fp32 kernels (library_fp32_...: the same torch graph in float32) as for ours (%.1f s)" % (time.time() - t0)}
 
 
 def main():
@@ -438,6 +481,15 @@ def main():
     m = run_workload(args.net, args.mode, B, H, W, args.steps, args.warmup, device, world, rank, args.bucket_mb, args.graph)
     elapsed, marks, out, P_cpu, img0, img1 = m["elapsed"], m["marks"], m["out"], m["P_cpu"], m["img0"], m["img1"]
 
+    headline = args.mode == "fwd" and args.net == "C" and (B, H, W) == (8, 320, 448)
+    multi_rank_train = None
+    if world > 1 and headline and not args.no_extras:
+        # The multi-rank line carries the leg that runs the path's one collective: BASELINE config 4 on all ranks, after the headline's
+        # timed region (every rank calls it: barriers and all-reduces inside).  The forward headline above stays embarrassingly parallel.
+        keep = {k: m[k] for k in ("settle_steps", "settling_s", "elapsed_cold", "use_graph", "gc_paused")}
+        m = dict(keep)
+        torch.cuda.empty_cache()
+        multi_rank_train = train_leg(device, world, rank, args.bucket_mb)
     if rank == 0:
         pairs = world * B * args.steps
         conv_gf = (nets.conv_flops("C", H, W) if args.net == "C" else nets.flownet2_conv_flops(H, W)) * B / 1e9
@@ -469,11 +521,12 @@ def main():
                 res["epe_vs_cpu_oracle"] = epe
             elif args.mode == "fwd" and args.net == "2" and not args.no_cpu_baseline:
                 res["epe_vs_cpu_oracle"], _ = flownet2_epe_vs_cpu(P_cpu, img0, img1, out)
-            headline = args.mode == "fwd" and args.net == "C" and (B, H, W) == (8, 320, 448)
             if headline and not args.no_extras:
                 del m, out
                 torch.cuda.empty_cache()
                 res["extra"] = extras(device, args)
+        if multi_rank_train is not None:
+            res["extra"] = {"train_448x320": multi_rank_train}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

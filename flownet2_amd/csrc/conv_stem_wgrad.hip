@@ -240,10 +240,11 @@ template <int CIN>
 static int launch(Args a, float* dw, int accumulate, hipStream_t st) {
   using G = Geo<CIN>;
   constexpr size_t lds = sizeof(float) * 2 * G::BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // 70 / 104 KB of dynamic LDS (above the 64 KB default): set per launch -- the attribute belongs to the CURRENT device's copy of the
+  // function, a per-process latch would leave every device after the first without it -- and checked
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_wgrad: %zu bytes of dynamic LDS refused by the runtime", lds);
   }
   hipLaunchKernelGGL((stem_wgrad<CIN>), dim3((unsigned)a.parts), dim3(256), lds, st, a);
   hipLaunchKernelGGL(stem_wgrad_finalize, dim3((kCout * G::TAPS + 15) / 16), dim3(256), 0, st, a.slab, dw, G::TAPS, G::NT * 16, a.parts, accumulate);

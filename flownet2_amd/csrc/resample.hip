@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) resample_linear_lean(const float* __restr
   if (vec) { fx0 &= ~3; fx1 |= 3; }
   const unsigned ncol = vec ? (unsigned)(fx1 - fx0 + 1) >> 2 : (unsigned)(fx1 - fx0 + 1);     // items per footprint row (<= 20 / <= 70)
   const unsigned nitem = ncol * (unsigned)(fy1 - fy0 + 1);
-  const unsigned magic = 0xffffffffu / ncol + 1u;                                               // idx / ncol == umulhi(idx, magic) for idx < 2^16
+  const unsigned magic = 0xffffffffu / ncol + 1u;                                               // idx / ncol == umulhi(idx, magic) for idx < 2^16; ncol == 1 wraps to 0: handled at the uses
   const int c_lo = blockIdx.z * kLeanPlanes;
   // ---- the footprint of every plane of the group goes to LDS in one sweep of coalesced loads (each sample leaves the L2 once; the four
   // taps of an output are LDS reads); on the way 0 * sample is summed up: NaN exactly when a sample is NaN / Inf (the reference's own
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) resample_linear_lean(const float* __restr
 #pragma unroll
     for (int it = 0; it < kLeanScanVec; ++it) {
       const unsigned idx = threadIdx.x + 256u * it;
-      const unsigned r = __umulhi(idx, magic), q = idx - r * ncol;
+      const unsigned r = ncol == 1u ? idx : __umulhi(idx, magic), q = idx - r * ncol;
       const size_t goff = (size_t)(fy0 + (int)r) * a.Win + fx0 + 4 * q;
 #pragma unroll
       for (int pl = 0; pl < kLeanPlanes; ++pl)
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) resample_linear_lean(const float* __restr
 #pragma unroll
     for (int it = 0; it < kLeanScanVec; ++it) {
       const unsigned idx = threadIdx.x + 256u * it;
-      const unsigned r = __umulhi(idx, magic), q = idx - r * ncol;
+      const unsigned r = ncol == 1u ? idx : __umulhi(idx, magic), q = idx - r * ncol;
 #pragma unroll
       for (int pl = 0; pl < kLeanPlanes; ++pl) {
         f4 t = v[it][pl];
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) resample_linear_lean(const float* __restr
 #pragma unroll 4
     for (int it = 0; it < kLeanScanScalar; ++it) {
       const unsigned idx = threadIdx.x + 256u * it;
-      const unsigned r = __umulhi(idx, magic), q = idx - r * ncol;
+      const unsigned r = ncol == 1u ? idx : __umulhi(idx, magic), q = idx - r * ncol;
       const size_t goff = (size_t)(fy0 + (int)r) * a.Win + fx0 + q;
 #pragma unroll
       for (int pl = 0; pl < kLeanPlanes; ++pl) {

@@ -330,6 +330,7 @@ def invalidate_weight_caches():
     """Drop every packed / transposed weight copy.  The caches notice in-place writes through the tensor itself (`_version`), but not
     writes through `.data` or a checkpoint load into `.data`: call this after such a write (parallel.broadcast_params does)."""
     from . import nets
+    _bump_weight_generation()
     _PACKED.clear()
     _PACKED_U.clear()
     _PACKED_D.clear()
@@ -337,18 +338,40 @@ def invalidate_weight_caches():
     nets._WT_CACHE.clear()
 
 
+_WEIGHT_GENERATION = [0]     # bumped by every torch optimizer step (global post-step hook below) and by invalidate_weight_caches()
+
+
+def weight_generation() -> int:
+    return _WEIGHT_GENERATION[0]
+
+
+def _bump_weight_generation(*_a, **_k):
+    _WEIGHT_GENERATION[0] += 1
+
+
+try:        # every torch.optim.Optimizer.step() of this process, fused ones included (they write the parameters WITHOUT bumping `_version`)
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook
+    _reg_step_hook(_bump_weight_generation)
+    _HAVE_STEP_HOOK = True
+except Exception:       # pragma: no cover - torch without the global hook: trainable tensors are never cached (round-4 behaviour)
+    _HAVE_STEP_HOOK = False
+
+
 def _cached(cache, key, w, make):
     """make() for weight tensor w, remembered under `key` while w is alive and unwritten.  Writes are noticed through `_version` -- which
     fused optimizers do NOT touch (torch.optim.Adam(fused=True) leaves it at 0: scripts/probes/stale_pack_probe.py, round 4: the cached
-    operands of step 1 served every later step) -- so a tensor that requires grad is never cached, and seeing it in that state drops what
-    an earlier, frozen life of the same tensor left behind: a trainable parameter is repacked whenever it is used."""
+    operands of step 1 served every later step).  For a tensor that requires grad the entry therefore also carries the weight GENERATION,
+    a counter every torch optimizer step bumps through the global post-step hook above: a trainable parameter is repacked once per
+    optimizer step (not once per use), and inference under no_grad with default nn.Parameter weights keeps its packs.  Writes through
+    `.data` / a custom optimizer that is not a torch.optim.Optimizer need invalidate_weight_caches()."""
     import weakref
-    if w.requires_grad:
+    if w.requires_grad and not _HAVE_STEP_HOOK:
         cache.pop(key, None)
         return make()
+    gen = _WEIGHT_GENERATION[0] if w.requires_grad else -1
     hit = cache.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != w._version:
-        hit = (weakref.ref(w, lambda _r, k=key: cache.pop(k, None)), w._version, make())
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[3] != gen:
+        hit = (weakref.ref(w, lambda _r, k=key: cache.pop(k, None)), w._version, make(), gen)
         cache[key] = hit
     return hit[2]
 
@@ -395,7 +418,8 @@ def _conv_mfma_pick(x, weight, stride, pad):
         return "plane"
     if (k == 5 and stride == 2 and pad == 2 and os.environ.get("FN2_CONV_PLANE5", "1") != "0"
             and N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and Ho * Wo <= maxpix
-            and ops.conv_plane_k_supported(x.shape[0], Cin, H, W, Cout, 5, 2, 2)):
+            and ops.conv_plane_k_supported(x.shape[0], Cin, H, W, Cout, 5, 2, 2)
+            and (N == x.shape[0] or ops.conv_plane_k_supported(N, Cin, H, W, Cout, 5, 2, 2))):      # batch-invariant mode: the same kernel at batch 1 and batch B
         # conv3 of the encoders when one sample is the whole batch (FlowNet2 at 1024x448, batch 1: [1,128,112,256] -> 256): 7168 accumulator
         # tiles cannot fill the chip without a K split, which the direct kernel does not have (120 us against 180;
         # scripts/probes/small_layer_routes.py)
@@ -470,6 +494,9 @@ class _OwnForwardConv(torch.autograd.Function):
             print("bwd on the library: x %s w %s stride %d pad %d transposed %s -> %s%s" % (tuple(x.shape), tuple(w.shape), stride, pad, transposed,
                                                                                           "data " if lib_x else "", "weight" if lib_w else ""), flush=True)
         if lib_x or lib_w:
+            if x.is_cuda:       # counted like the forward's last resort: `library_conv_fallbacks: 0` in the bench line covers backward too
+                _note_fallback("%s backward{stride %d, pad %d}%s%s" % ("Deconvolution" if transposed else "Convolution", stride, pad,
+                                                                       " data" if lib_x else "", " weight" if lib_w else ""), x, w)
             gxl, gwl, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
                                                               [lib_x, lib_w, False])
             gx, gw = (gxl if lib_x else gx), (gwl if lib_w else gw)

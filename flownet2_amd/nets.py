@@ -142,18 +142,10 @@ _WT_CACHE: Dict[int, tuple] = {}      # id(weight tensor) -> (weak reference to 
 def _transposed_deconv_weight(w):
     """weight [Cin, Cout, 4, 4] -> [Cout*16, Cin] contiguous (the A operand of the deconvolution GEMM).  Cached per
     parameter tensor OBJECT (the entry dies with the tensor, so a new tensor that reuses the id or the storage address
-    never sees it) and rebuilt when the tensor is modified in place (torch bumps `_version`); never cached for a tensor that
-    requires grad (fused optimizers write without touching `_version`: functional._cached)."""
-    key = id(w)
-    if w.requires_grad:
-        _WT_CACHE.pop(key, None)
-        return w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous()
-    hit = _WT_CACHE.get(key)
-    if hit is None or hit[0]() is not w or hit[1] != w._version:
-        hit = (weakref.ref(w, lambda _r, k=key: _WT_CACHE.pop(k, None)), w._version,
-               w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous())
-        _WT_CACHE[key] = hit
-    return hit[2]
+    never sees it) and rebuilt when the tensor is modified in place (torch bumps `_version`) or -- for a tensor that requires
+    grad -- when an optimizer has stepped since (functional._cached: fused optimizers write without touching `_version`)."""
+    from . import functional as Fn
+    return Fn._cached(_WT_CACHE, id(w), w, lambda: w.detach().reshape(w.shape[0], w.shape[1] * 16).t().contiguous())
 
 
 def _deconv(x, P, name, act=True, backend=None):

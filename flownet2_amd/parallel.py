@@ -58,9 +58,12 @@ class GradientExchange:
     fixed latency, so buckets are few and large (default 48 MB: FlowNetC's 156.7 MB travel as 4 buckets; the first leaves
     after the decoder, ~25 % into backward).  Gradients stay fp32 (parity with the reference)."""
 
-    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20):
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20, local_only: bool = False):
+        """local_only: keep the gradients of this rank (no collective, no bucket copies) although the process group has several ranks --
+        the comparison step bench.py times to report how much of the all-reduce is NOT hidden behind backward."""
         self.params = [p for p in params if p.requires_grad]
-        self.world = world()
+        self.world = 1 if local_only else world()
+        self.launched_in_backward = 0       # buckets whose all-reduce left from a gradient hook during the last backward pass
         self.buckets: List[dict] = []
         cur, size = [], 0
         for p in reversed(self.params):
@@ -151,6 +154,7 @@ class GradientExchange:
                 b["work"].wait()
                 b["flat"].mul_(1.0 / self.world)
         n = sum(1 for b in self.buckets if b["pending"] == 0)
+        self.launched_in_backward = n
         self.reset()
         return n           # buckets whose exchange was launched from inside backward
 

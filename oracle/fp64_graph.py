@@ -160,18 +160,20 @@ class record_relu_branches:
         return False
 
 
-def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43, masks=None):
+def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43, masks=None, dtype=torch.float64):
     """loss (float) and {parameter name: float64 gradient on the CPU} of one FlowNetC training step exactly as bench.py --mode train
     states it: pre-processing im / 255 - mean, nets.flownet_c_core, nets.multiscale_loss against `gt` (NaN = no ground truth).
     P: {name: fp32 tensor}; img0 / img1: raw [N, 3, H, W]; gt: [N, 2, H, W].
     masks = record_relu_branches(...).branches of another run: every leaky ReLU takes the branch recorded there instead of the sign of
-    its own input (y = x * (1 | slope) by the recorded mask): the fp64 value and gradient of the piecewise-linear function that run evaluated."""
+    its own input (y = x * (1 | slope) by the recorded mask): the fp64 value and gradient of the piecewise-linear function that run evaluated.
+    dtype = torch.float32 turns the same torch graph into the LIBRARY-fp32 yardstick (torch's fp32 conv2d / conv_transpose2d = MIOpen on the
+    GPU box, none of the product's kernels): how far a stock fp32 implementation sits from the fp64 graph on the same inputs."""
     import torch.nn.functional as F
     from flownet2_amd import nets
     dev = torch.device(device) if device is not None else img0.device
-    P64 = {k: v.detach().to(device=dev, dtype=torch.float64).requires_grad_(True) for k, v in P.items()}
-    i0, i1 = (im.detach().to(device=dev, dtype=torch.float64) for im in (img0, img1))
-    g = gt.detach().to(device=dev, dtype=torch.float64)
+    P64 = {k: v.detach().to(device=dev, dtype=dtype).requires_grad_(True) for k, v in P.items()}
+    i0, i1 = (im.detach().to(device=dev, dtype=dtype) for im in (img0, img1))
+    g = gt.detach().to(device=dev, dtype=dtype)
     be = backend64()
     pre = [(im * (1.0 / 255.0)) - mean for im in (i0, i1)]
     lr, oc, od = F.leaky_relu, nets._conv, nets._deconv
@@ -203,6 +205,13 @@ def flownetc_train_reference(P, img0, img1, gt, device=None, mean=0.43, masks=No
     assert not todo, "recorded ReLU branches left over: the two graphs differ"
     loss.backward()
     return float(loss.detach()), {k: v.grad.detach().cpu() for k, v in P64.items() if v.grad is not None}
+
+
+def relu_sign_flips(branches_a, branches_b):
+    """(units whose leaky ReLU took different branches in two recorded runs, units in all) -- by layer name, as record_relu_branches lists them."""
+    a, b = dict(branches_a), dict(branches_b)
+    assert a.keys() == b.keys(), (sorted(a), sorted(b))
+    return int(sum(int((a[k] != b[k]).sum()) for k in a)), int(sum(a[k].numel() for k in a))
 
 
 def grad_agreement(grads, ref):

@@ -91,10 +91,23 @@ def _worker(rank, world, port, out, gpus_claimed):
         dist.destroy_process_group()
 
 
-def _run(tmp_path, world, gpus_claimed):
+def _leg_worker(rank, world, port, out, gpus_claimed):
+    """bench.train_leg -- the leg a multi-rank bench line carries under extra.train_448x320 -- on every rank, at a CPU-sized shape."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        leg = bench.train_leg(torch.device("cpu"), world, rank, bucket_mb=24, B=1, H=128, W=128, steps=2, warmup=1, settle_s=0.0, rt=StubRuntime())
+        torch.save({"rank": rank, "leg": leg}, os.path.join(out, f"b_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(tmp_path, world, gpus_claimed, worker=None):
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), gpus_claimed)) for r in range(world)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, world, port, str(tmp_path), gpus_claimed)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -121,6 +134,21 @@ def test_bench_train_rank_logic_world2(tmp_path):
         assert torch.equal(r0["params"][k], r1["params"][k]), k
         moved += int(not torch.equal(r0["params"][k], P0[k]))
     assert moved >= len(P0) - 2
+
+
+def test_multi_rank_bench_line_carries_the_train_leg_world2(tmp_path):
+    """world > 1: extra.train_448x320 comes from train_leg run on ALL ranks -- the gradient all-reduce is inside the timed steps, the same
+    step is timed again with world-local gradients, and the line says how many buckets left from inside backward."""
+    r0, r1 = _run(tmp_path, 2, 2, worker=_leg_worker)
+    for r in (r0, r1):
+        leg = r["leg"]
+        assert leg["n_gpus"] == 2 and leg["global_batch"] == 2 and leg["ranks_seen_by_rccl"] == 2
+        assert leg["grad_buckets"] >= 2 and 1 <= leg["buckets_launched_inside_backward"] <= leg["grad_buckets"]
+        assert leg["ms_per_step"] > 0 and leg["ms_per_step_local_gradients"] > 0
+        assert abs(leg["allreduce_ms_exposed"] - (leg["ms_per_step"] - leg["ms_per_step_local_gradients"])) < 1e-3
+        assert "dp2" in leg["parallelism"] and leg["library_conv_fallbacks"] == 0
+    # max over ranks: both ranks report the same times
+    assert r0["leg"]["ms_per_step"] == r1["leg"]["ms_per_step"] and r0["leg"]["ms_per_step_local_gradients"] == r1["leg"]["ms_per_step_local_gradients"]
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus(tmp_path):

@@ -320,7 +320,11 @@ def test_resample_integer_upsampling_path_equals_the_per_pixel_kernel(shape):
 
 @pytest.mark.parametrize("shape", [((24, 48), (24, 48)), ((436, 1024), (448, 1024)), ((30, 40), (32, 64)), ((9, 12), (9, 12)), ((6, 8), (24, 32)),
                                    ((50, 37), (64, 64)), ((17, 23), (33, 70)), ((1, 1), (5, 9)), ((3, 200), (4, 256)), ((40, 30), (40, 33)),
-                                   ((16, 20), (16, 10)), ((20, 16), (10, 16))])
+                                   ((16, 20), (16, 10)), ((20, 16), (10, 16)),
+                                   # one item per footprint row (a single aligned column quad / a single column): width-4 maps on the 16-byte path,
+                                   # width-1 maps on the scalar path, several footprint rows each; and up-sampling factors >= 32, where an edge tile's
+                                   # footprint is one quad
+                                   ((4, 4), (6, 6)), ((7, 4), (7, 4)), ((5, 1), (9, 1)), ((6, 1), (6, 3)), ((3, 8), (96, 256)), ((2, 4), (80, 160))])
 @pytest.mark.parametrize("poison", [False, True])
 def test_resample_lean_linear_path_equals_the_per_pixel_kernel(shape, poison):
     """LINEAR with unit tap scale (identity, up-sampling, non-antialiased calls) runs 4 taps per output when the workgroup's input
