@@ -226,8 +226,6 @@ def lib():
     L.fn2_data_augmentation_forward.argtypes = [C.POINTER(DataAugParams), fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
-    if hasattr(L, "fn2_debug_correlation_persist_plan"):
-        L.fn2_debug_correlation_persist_plan.argtypes = [i, i, i, C.POINTER(C.c_uint), i]
     if hasattr(L, "fn2_debug_correlation_units_plan"):
         L.fn2_debug_correlation_units_plan.argtypes = [i, i, i, i, C.POINTER(C.c_uint), i]
     if hasattr(L, "fn2_debug_set_resample_generic"):

@@ -158,7 +158,7 @@ static int g_force_generic = 0;
 
 using namespace fn2;
 
-namespace fn2 { extern int g_corr_persist_flags; extern int g_corr_persist; extern int g_corr_units; extern int g_corr_units_lds; extern int g_corr_units_abl; extern int g_corr_units_flags; extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; } }
+namespace fn2 { extern int g_corr_units; extern int g_corr_units_lds; extern int g_corr_units_abl; extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; } }
 
 FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   fn2::g_corr_dbg = reinterpret_cast<unsigned long long*>(device_buffer);
@@ -172,13 +172,9 @@ FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
 // 19 = corr_fwd_pair (second generation) where the unit kernel applies, 20 + policy = the unit kernel with a task policy
 // (correlation_units.hip: 0 automatic, k = tasks per image row, + 16 image order), 60 + policy = the same with 16 KB of extra LDS (two workgroups per CU)
 FN2_API int fn2_debug_set_correlation_impl(int impl) {
-  fn2::g_corr_persist_flags = (impl >= 170 && impl < 186) ? impl - 170 : 0;      // 170 + flags: the persistent kernel with parts switched off (profiling, wrong results)
-  fn2::g_corr_persist = (impl == 17 || (impl >= 170 && impl < 186)) ? 1 : 0;      // 17 = the persistent kernel (opt-in: 51 us against the unit kernel's 39.5 at config A, profiles/r05_corr_notes.md)
   fn2::g_corr_units = impl == 19 ? 0 : (impl >= 20 && impl < 52) ? 1 + (impl - 20) : 1;
   fn2::g_corr_units_lds = impl == 60 ? 16384 : impl == 61 ? 65536 : 0;          // 60 / 61: two / one workgroup per CU (extra dynamic LDS)
   fn2::g_corr_units_abl = (impl >= 100 && impl < 164) ? impl - 100 : 0;
-  fn2::g_corr_units_flags = (impl >= 200 && impl < 264) ? (impl - 200) & 3 : 0;      // 200 + 4 * policy + flags: the unit kernel with Args::flags
-  if (impl >= 200 && impl < 264) fn2::g_corr_units = 1 + ((impl - 200) >> 2);            // FN2_ABLATION builds: 100 + bits, ablation of the unit kernel (policy 0)
   g_force_generic = (impl == 1);
   fn2::g_corr1d_force_generic = (impl == 1);
   fn2::g_corr_force_dword = (impl == 3);
@@ -189,10 +185,6 @@ FN2_API int fn2_debug_set_correlation_impl(int impl) {
   fn2::g_corr_simd_plan = (impl != 13);                  // 13 = corr_fwd_pair without the SIMD plan (wave w takes patch column w)
   fn2::g_corr_ablation = (impl >= 64 && impl < 100) ? impl - 64 : 0;
   return FN2_OK;
-}
-
-FN2_API int fn2_debug_correlation_persist_plan(int N, int H, int W, unsigned* out_words, int max_words) {
-  return fn2::corr_fwd_persist_plan_words(N, H, W, out_words, max_words);
 }
 
 FN2_API int fn2_debug_correlation_units_plan(int N, int H, int W, int policy, unsigned* out_words, int max_words) {
@@ -231,7 +223,6 @@ FN2_API int fn2_correlation_forward_fused(const fn2_corr_params* p, const float*
   if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation_forward: NULL blob pointer");
   hipStream_t st = as_stream(stream);
   const bool plain = fn2::g_corr_force_dword == 0 && fn2::g_corr_proj == 0 && fn2::g_corr_ablation == 0 && fn2::g_corr_skip_dead == 0 && fn2::g_corr_simd_plan != 0;
-  if (!g_force_generic && plain && corr_fwd_persist_supported(g, bottom0, bottom1, top)) return corr_fwd_persist_launch(g, bottom0, bottom1, top, st);
   if (!g_force_generic && plain && corr_fwd_units_supported(g, bottom0, bottom1, top)) return corr_fwd_units_launch(g, bottom0, bottom1, top, st);
   if (!g_force_generic && corr_fwd_mfma_supported(g)) return corr_fwd_mfma_launch(g, bottom0, bottom1, top, st);
   const long long total = (long long)N * g.topC * g.topH * g.topW;

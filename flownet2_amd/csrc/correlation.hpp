@@ -20,10 +20,6 @@ int corr_fwd_mfma_launch(const CorrGeom& g, const float* b0, const float* b1, fl
 // third-generation forward of the FlowNetC instance (correlation_units.hip): unit lists, loader wave; corr_fwd_pair serves what it does not take
 bool corr_fwd_units_supported(const CorrGeom& g, const float* b0, const float* b1, const float* top);
 int corr_fwd_units_launch(const CorrGeom& g, const float* b0, const float* b1, float* top, hipStream_t st);
-// persistent form (correlation_persist.hip): one workgroup per CU walks a host-planned task list; applies where a plan exists
-bool corr_fwd_persist_supported(const CorrGeom& g, const float* b0, const float* b1, const float* top);
-int corr_fwd_persist_launch(const CorrGeom& g, const float* b0, const float* b1, float* top, hipStream_t st);
-int corr_fwd_persist_plan_words(int N, int H, int W, unsigned* out, int max_words);
 int corr_fwd_units_plan_words(int N, int H, int W, int policy, unsigned* out, int max_words);
 bool corr_bwd_mfma_supported(const CorrGeom& g);
 int corr_bwd_mfma_launch(const CorrGeom& g, int which, const float* other, const float* top_diff, float* out, hipStream_t st);

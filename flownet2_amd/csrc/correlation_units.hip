@@ -67,7 +67,7 @@ struct Args {
   int G;                 // > 0: 8 % N == 0, a sample is striped over G = 8 / N XCDs; 0: contiguous ranges of the global lists
   int ctot, c0, relu; float slope;
   int nseg;
-  int flags;             // experiment hook (bit 0: s_setprio 3 for the epilogue)
+  int reserved;
   // Segment task = a contiguous run of the (patch, b) sequence of an image row (patch-major; b = 0 .. 5):
   //  w0 = p0 | patches << 8 | s0 << 16 | nb << 24          first patch, patches touched (<= 4), first second-map tile, tiles staged (odd)
   //  w1 = first unit of consumer wave 0 .. 3 (bytes)        w2 = units of consumer wave 0 .. 3 (bytes)
@@ -149,7 +149,6 @@ __device__ __forceinline__ void consume(float* smem, const Args& g, int lane, in
       }
     }
   }
-  if (g.flags & 1) __builtin_amdgcn_s_setprio(3);
 #ifdef FN2_ABLATION
   t_bar = __builtin_amdgcn_s_memtime();
 #endif
@@ -314,7 +313,6 @@ corr_fwd_units(const float* __restrict__ b0, const float* __restrict__ b1, float
   [[maybe_unused]] unsigned long long t_bar = 0, t_sync = 0;
   if (wave == CONS) {
     load_task<ABL>(a_n, b_n, g, lds_base, lane, py, I, a, p0, s0, na, nb, w4 & 0xffffu, sw[3] & 0xffffu);
-    if (g.flags & 1) __builtin_amdgcn_s_setprio(3);
 #ifdef FN2_ABLATION
     t_bar = __builtin_amdgcn_s_memtime();
 #endif
@@ -442,8 +440,8 @@ static void live_range(int I, int Hc, int& alo, int& ahi) {          // live N p
   if (4 * I >= Hc) { alo = 0; ahi = -1; }
 }
 
-// policy: 0 = as many tasks per image row as make the launch ONE round of the chip (768 workgroup slots: three per CU), 1 .. 15 = that
-// many tasks per image row; + 16: task order inside a sample = image order instead of most-units-first.
+// policy: 0 = automatic (below), 1 .. 15 = that many tasks per image row (tests / profiling); + 16: task order inside a sample = image
+// order instead of most-units-first.
 static bool build_plan(int N, int H, int W, int policy, Plan& pl) {
   pl.N = N; pl.H = H; pl.W = W; pl.policy = policy; pl.ok = false;
   Args& g = pl.a;
@@ -474,16 +472,23 @@ static bool build_plan(int N, int H, int W, int policy, Plan& pl) {
   for (int k = 0; k < L; ++k) { const int s = k / NBT + k % NBT; livek[k] = (s >= 2 && s <= smax); U_row += livek[k]; }
   if (U_row == 0) return false;
   int nseg;
-  if ((policy & 15) != 0) nseg = policy & 15;
+  const bool automatic = (policy & 15) == 0;
+  if (!automatic) nseg = policy & 15;
   else {
-    const double total = (double)N * rows_live.size() * U_row;
-    const double target = std::max(4.0, total / 768.0);     // units per task for one round at three workgroups per CU
-    nseg = (int)(U_row / target + 0.5);
+    // ONE round of the chip (768 workgroup slots: three per CU) of the largest tasks that fit a workgroup: the launch has no second,
+    // half-empty round (measured at config A: 1,152 tasks of 15 / 12 / 9 units 40.2 us, 768 of 18 units 39.4) and every task ends within the
+    // same K loop.  Geometries whose rows would need more than 768 tasks of <= 20 units keep corr_fwd_pair (config B: 960 tasks 50.9 us
+    // against 42.8), geometries with few rows are cut finer (config D, 72 rows: 720 tasks of 9 units).
+    const long long rows_all = (long long)N * (long long)rows_live.size();
+    nseg = (int)std::min<long long>(MAXSEG, 768 / std::max<long long>(1, rows_all));
+    nseg = std::min(nseg, std::max(1, U_row / 8));          // ... but no task below eight units (two per consumer wave)
+    if (nseg < 1 || (U_row + nseg - 1) / nseg > CONS * MAXNU) return false;
   }
   nseg = std::max(1, std::min(nseg, MAXSEG));
   int units_of[MAXSEG];
   for (;; ++nseg) {                                         // more, smaller tasks until every task fits (patches, staged tiles, units per wave)
     if (nseg > MAXSEG || nseg > U_row) return false;
+    if (automatic && (long long)N * (long long)rows_live.size() * nseg > 768) return false;
     std::memset(g.seg, 0, sizeof(g.seg));
     bool fits = true;
     int k0 = 0, done = 0;
@@ -582,7 +587,6 @@ static const Plan& plan_for(int N, int H, int W, int policy) {
 }  // namespace cu3
 
 extern unsigned long long* g_corr_dbg;
-int g_corr_units_flags = 0;    // experiment hook: Args::flags
 int g_corr_units_abl = 0;      // FN2_ABLATION builds: ablation bits of corr_fwd_units
 int g_corr_units = 1;          // test / profiling hook (fn2_debug_set_correlation_impl): 0 = corr_fwd_pair where both apply, 1 + policy = this kernel
 int g_corr_units_lds = 0;      // profiling hook: extra dynamic LDS per workgroup (bytes) -- fewer workgroups per CU
@@ -610,7 +614,6 @@ int corr_fwd_units_launch(const CorrGeom& cg, const float* b0, const float* b1, 
   if (!pl.ok) return fail(FN2_ERR_UNSUPPORTED, "correlation: no unit plan for %d x %d x %d", cg.N, cg.H, cg.W);
   cu3::Args a = pl.a;
   a.C = cg.C; a.ctot = cg.top_ctot; a.c0 = cg.top_c0; a.relu = cg.relu; a.slope = cg.slope;
-  a.flags = g_corr_units_flags;
 #ifdef FN2_ABLATION
   static const int env_pad = getenv("FN2_CORR_LDS_PAD") ? atoi(getenv("FN2_CORR_LDS_PAD")) : 0;     // profiling builds: fewer workgroups per CU
   const size_t lds = sizeof(float) * cu3::LDS_FLOATS + (size_t)(g_corr_units_lds ? g_corr_units_lds : env_pad);

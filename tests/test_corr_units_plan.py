@@ -138,128 +138,3 @@ def test_flownetc_shape_is_one_round_of_equal_tasks():
     _, upw = walk(a)
     assert all(sorted(u) == [4, 4, 5, 5] for u in upw) and len(upw) == 768
 
-
-# ---------------------------------------------------------------------------------------------------------------------------------------
-# persistent form (csrc/correlation_persist.hip): one workgroup per CU walks a task list; the storer wave zero-fills the dead N patch rows
-P_HEAD, MAXT, MAXWG = 13, 4, 256
-
-
-def persist_plan(N, H, W):
-    L = _lib.lib()
-    n = L.fn2_debug_correlation_persist_plan(N, H, W, None, 0)
-    if n == 0:
-        return None
-    buf = (C.c_uint * n)()
-    assert L.fn2_debug_correlation_persist_plan(N, H, W, buf, n) == n
-    w = np.frombuffer(buf, dtype=np.uint32).copy()
-    head = w[:P_HEAD].view(np.int32)
-    a = dict(N=int(head[0]), H=int(head[2]), W=int(head[3]), G=int(head[4]), RN=int(head[9]), ND=int(head[10]), ZP=int(head[11]))
-    a["seg"] = w[P_HEAD:P_HEAD + MAXSEG * SEGW].reshape(MAXSEG, SEGW)
-    a["task"] = w[P_HEAD + MAXSEG * SEGW:P_HEAD + MAXSEG * SEGW + MAXWG * MAXT // 2].view(np.uint16).reshape(MAXWG, MAXT)
-    return a
-
-
-def dead_task(H, z):
-    NI = ((H + 1) // 2 + 3) // 4
-    for py in range(2):
-        Hc = (H - py + 1) // 2
-        for I in range(NI):
-            if 4 * I >= Hc:
-                continue
-            lo_num, hi_num = R - 3 - 4 * I, Hc - 1 + R - 4 * I
-            alo = 0 if lo_num <= 0 else (lo_num + 3) // 4
-            ahi = -1 if hi_num < 0 else min(hi_num // 4, NBT - 1)
-            nlive = ahi - alo + 1 if ahi >= alo else 0
-            ndead = NBT - nlive
-            if z < ndead:
-                return py, I, (z if (nlive == 0 or z < alo) else z + nlive)
-            z -= ndead
-    return None
-
-
-def persist_walk(a):
-    N, H, W = a["N"], a["H"], a["W"]
-    cnt = np.zeros((N, D, D, H, W), np.int32)
-    oo_of = np.arange(16 * D) % D
-    loads = []
-    for blk in range(256):
-        xcd, j = blk & 7, blk >> 3
-        n, w = xcd // a["G"], (xcd % a["G"]) * 32 + j
-        wave_units = [0] * 8
-        for t in range(MAXT):
-            e = int(a["task"][w][t])
-            if e == 0xffff:
-                assert all(int(a["task"][w][u]) == 0xffff for u in range(t, MAXT))
-                break
-            py, I, aa, segI, rot = e & 1, (e >> 1) & 31, (e >> 6) & 7, (e >> 9) & 15, (e >> 13) & 3
-            sw = [int(v) for v in a["seg"][segI]]
-            p0, npp, s0, nb = sw[0] & 255, (sw[0] >> 8) & 255, (sw[0] >> 16) & 255, sw[0] >> 24
-            na = (sw[4] >> 16) & 15
-            assert nb % 2 == 1 and na % 2 == 1 and na >= npp and 1 <= npp <= 4 and na + nb <= a["RN"] <= 12
-            nus = [(sw[2] >> (8 * wv)) & 255 for wv in range(4)] + [(sw[15] >> (8 * wv)) & 255 for wv in range(4)]
-            u0s = [(sw[1] >> (8 * wv)) & 255 for wv in range(4)] + [(sw[14] >> (8 * wv)) & 255 for wv in range(4)]
-            assert u0s[0] == 0 and all(u0s[k + 1] == u0s[k] + nus[k] for k in range(7)) and max(nus) <= 3
-            for wv in range(8):
-                wave_units[wv] += nus[((wv + rot) & 3) + (wv & 4)]
-            written = np.zeros((16 * D, 8 * npp), np.int32)
-            own = np.zeros((16 * D, 8 * npp), bool)
-            for k in range(sum(nus)):
-                byte = (sw[6 + (k >> 2)] >> (8 * (k & 3))) & 255
-                pl, sl = byte >> 4, byte & 15
-                b = sl + s0 - (pl + p0)
-                br = (sw[5] >> (6 * pl)) & 63
-                assert pl < npp and sl < nb and 0 <= b < NBT and (br & 7) <= b <= (br >> 3)
-                written[:, 8 * pl:8 * pl + 8] += PAT[b]
-            for k in range(sw[3] >> 16):
-                byte = (sw[11 + (k >> 2)] >> (8 * (k & 3))) & 255
-                written[:, 8 * (byte >> 4):8 * (byte >> 4) + 8] += PAT[byte & 15]
-            for pl in range(npp):
-                br = (sw[5] >> (6 * pl)) & 63
-                for xl in range(8):
-                    q = (oo_of + (xl >> 1)) >> 2
-                    own[:, 8 * pl + xl] = (q >= (br & 7)) & (q <= (br >> 3))
-            assert (written[own] == 1).all()
-            for rowid in range(16 * D):
-                blk_, oo = divmod(rowid, D)
-                rmi, rni = blk_ >> 2, blk_ & 3
-                qq, y = 4 * aa + rni - rmi, 2 * (4 * I + rmi) + py
-                if 0 <= qq < D and y < H:
-                    for xl in range(8 * npp):
-                        if 8 * p0 + xl < W and own[rowid, xl]:
-                            cnt[n, qq, oo, y, 8 * p0 + xl] += 1
-        loads.append(wave_units)
-        # the storer's zero quarters
-        for zq in range(a["ZP"]):
-            piece = w * a["ZP"] + zq
-            if piece >= 4 * a["ND"]:
-                continue
-            py, I, aa = dead_task(H, piece >> 2)
-            zmi = piece & 3
-            y = 2 * (4 * I + zmi) + py
-            for rni in range(4):
-                qq = 4 * aa + rni - zmi
-                if 0 <= qq < D and y < H:
-                    cnt[n, qq, :, y, :] += 1
-    return cnt, loads
-
-
-@pytest.mark.parametrize("shape", [(8, 40, 56), (4, 48, 96), (1, 56, 128), (2, 16, 24), (8, 24, 32), (1, 24, 192)])
-def test_persistent_plan_writes_every_output_element_exactly_once(shape):
-    a = persist_plan(*shape)
-    if a is None:
-        pytest.skip("no persistent plan for this geometry (the one-task-per-workgroup kernels serve it)")
-    cnt, loads = persist_walk(a)
-    assert cnt.min() == 1 and cnt.max() == 1
-    tot = [sum(l) for l in loads]
-    assert max(tot) - min(tot) <= 1, "workgroups of a launch carry the same number of units"
-
-
-def test_persistent_plan_of_the_flownetc_shape():
-    """[8,256,40,56]: 54 units per CU as tasks of 20 / 16 / 18 (1.5 image rows), 14 / 14 / 13 / 13 units per SIMD (two consumer waves each), a light
-    pair on the storer's SIMD."""
-    a = persist_plan(8, 40, 56)
-    assert a is not None and a["G"] == 1 and a["RN"] == 12
-    _, loads = persist_walk(a)
-    assert all(sum(l) == 54 for l in loads)
-    simd = [[l[k] + l[k + 4] for k in range(4)] for l in loads]          # consumer waves k and k + 4 share a SIMD
-    assert all(sorted(v) == [13, 13, 14, 14] and v[3] == 13 for v in simd), sorted(set(tuple(v) for v in simd))

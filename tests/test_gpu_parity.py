@@ -1034,6 +1034,31 @@ def test_correlation_simd_plan_changes_no_bit(shape):
     assert_close(host(outs[0]), oracle.correlation_forward(oracle.corr_params(20, 1, 20, 1, 2), host(b0), host(b1)), 2e-6, "vs oracle")
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 40, 56), (4, 64, 48, 96), (1, 32, 56, 128), (2, 64, 16, 24), (3, 32, 11, 20), (1, 32, 5, 8), (16, 32, 9, 12), (5, 96, 30, 44)])
+@pytest.mark.parametrize("policy", [0, 2, 3, 5, 8, 11, 16 + 4])
+def test_correlation_unit_kernel_is_bitwise_the_paired_parity_kernel(shape, policy):
+    """Round 5: corr_fwd_units (csrc/correlation_units.hip: units dealt by count to four consumer waves, a loader wave, segment tasks that may
+    split a patch between two workgroups, stored by halves) against corr_fwd_pair: how an image row is cut into tasks, which wave multiplies
+    a unit and which workgroup stores an element cannot change a bit -- every task policy, plain and with the ReLU / Concat-slice epilogue,
+    over a poisoned output blob (an element nobody writes would stay NaN)."""
+    N, C, H, W = shape
+    b0, b1 = dev(rand(shape, 501)), dev(rand(shape, 502))
+    p = ops.corr_params(20, 1, 20, 1, 2)
+    ops.set_correlation_impl(19)
+    try:
+        want = ops.correlation_forward(p, b0, b1)
+        wide = torch.full((N, 441 + 9, H, W), 7.0, device="cuda")
+        want_f = ops.correlation_forward(p, b0, b1, out=wide.clone(), out_c0=5, relu=True, negative_slope=0.1)
+        ops.set_correlation_impl(20 + policy)
+        got = ops.correlation_forward(p, b0, b1, out=torch.full_like(want, float("nan")))
+        got_f = ops.correlation_forward(p, b0, b1, out=wide.clone(), out_c0=5, relu=True, negative_slope=0.1)
+    finally:
+        ops.set_correlation_impl(0)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert torch.equal(got_f.view(torch.int32), want_f.view(torch.int32))
+    assert_close(host(got), oracle.correlation_forward(oracle.corr_params(20, 1, 20, 1, 2), host(b0), host(b1)), 2e-6, "vs oracle")
+
+
 # ---- channel-slice forms of FlowWarp / ChannelNorm / Resample (round 3) ---------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 3, 24, 40), (1, 5, 17, 23), (3, 3, 64, 96)])
 def test_flow_warp_slices_is_bitwise_the_plain_layer(shape):
