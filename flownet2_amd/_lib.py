@@ -38,6 +38,8 @@ EXPORTS = [
     "fn2_deconv_plane_pack_weights", "fn2_deconv_plane_pack_weights_k", "fn2_deconv_plane_forward",
     "fn2_tconv_supported", "fn2_tconv_forward", "fn2_tconv_num_variants", "fn2_debug_set_tconv_variant",
     "fn2_debug_set_wgrad_buffers", "fn2_debug_set_wgrad_chunk", "fn2_conv_wgrad_supported", "fn2_conv_wgrad_ksplit", "fn2_conv_wgrad_workspace_bytes", "fn2_conv_wgrad",
+    "fn2_conv_route", "fn2_conv_packed_weight_floats", "fn2_conv_pack_weights", "fn2_conv_workspace_bytes", "fn2_conv_forward",
+    "fn2_deconv_route", "fn2_deconv_packed_weight_floats", "fn2_deconv_pack_weights", "fn2_deconv_workspace_bytes", "fn2_deconv_forward",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
@@ -59,6 +61,11 @@ class CaffemodelEntry(C.Structure):
     _fields_ = [("name_off", C.c_size_t), ("name_len", C.c_size_t), ("type_off", C.c_size_t), ("type_len", C.c_size_t),
                 ("v1_type", C.c_longlong), ("v1", C.c_int), ("blob_index", C.c_int), ("num_axes", C.c_int), ("dim", C.c_longlong * 8),
                 ("count", C.c_size_t), ("is_double", C.c_int), ("blob_off", C.c_size_t), ("blob_len", C.c_size_t)]
+
+
+class ConvDesc(C.Structure):
+    """fn2_conv_desc (include/flownet2_hip.h): the geometry the library routes a Convolution / Deconvolution by."""
+    _fields_ = [("N", C.c_int), ("Cin", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cout", C.c_int), ("kernel", C.c_int), ("stride", C.c_int), ("pad", C.c_int)]
 
 
 class CorrParams(C.Structure):
@@ -224,6 +231,15 @@ def lib():
     L.fn2_data_augmentation_workspace_bytes.argtypes = [i]
     L.fn2_data_augmentation_workspace_bytes.restype = sz
     L.fn2_data_augmentation_forward.argtypes = [C.POINTER(DataAugParams), fp, fp, fp, fp, i, i, i, i, vp, sz, vp]
+    dp = C.POINTER(ConvDesc)
+    for pre in ("fn2_conv", "fn2_deconv"):
+        getattr(L, pre + "_route").argtypes = [dp, i]
+        getattr(L, pre + "_packed_weight_floats").argtypes = [dp, i]
+        getattr(L, pre + "_packed_weight_floats").restype = sz
+        getattr(L, pre + "_pack_weights").argtypes = [dp, i, fp, fp, vp]
+        getattr(L, pre + "_workspace_bytes").argtypes = [dp, i]
+        getattr(L, pre + "_workspace_bytes").restype = sz
+        getattr(L, pre + "_forward").argtypes = [dp, i, fp, i, i, fp, fp, fp, i, i, i, C.c_float, vp, sz, vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
     if hasattr(L, "fn2_debug_correlation_units_plan"):

@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-parameter -Wno-unused-function -I$HERE/compat -I$ROOT/include"
 $HIPCC $FLAGS -x hip -c "$HERE/fn2_caffe_layers.cpp" -o "$OUT/fn2_caffe_layers.o"
-$HIPCC $FLAGS -DFN2_SHIM_L1LOSS=1 -x hip -c "$ROOT/oracle/ref_shim.cpp" -o "$OUT/shim.o"
+$HIPCC $FLAGS -DFN2_SHIM_L1LOSS=1 -DFN2_SHIM_CONV_REGISTRY=1 -x hip -c "$ROOT/oracle/ref_shim.cpp" -o "$OUT/shim.o"
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfn2_caffe_adapter_test.so" "$OUT/fn2_caffe_layers.o" "$OUT/shim.o" \
   -L"$ROOT/flownet2_amd" -lflownet2_hip -Wl,-rpath,'$ORIGIN/../../..'
 echo "built $OUT/libfn2_caffe_adapter_test.so"

@@ -100,15 +100,29 @@ class DownsampleParameter {
 
 // Messages of the stock layers the reference's L1LossLayer is composed from (l1loss_layer.cpp:19-62): only the oracle/_ref
 // build of that layer reads them (caffe.proto: FillerParameter, EltwiseParameter, PowerParameter, ConvolutionParameter).
-class FillerParameter {
+enum FillerParameter_VarianceNorm { FillerParameter_VarianceNorm_FAN_IN = 0, FillerParameter_VarianceNorm_FAN_OUT = 1, FillerParameter_VarianceNorm_AVERAGE = 2 };
+class FillerParameter {            // caffe.proto:43-64
  public:
+  typedef FillerParameter_VarianceNorm VarianceNorm;
   const std::string& type() const { return type_; }
   float value() const { return value_; }
+  float min() const { return min_; }
+  float max() const { return max_; }
+  float mean() const { return mean_; }
+  float std() const { return std_; }
+  int sparse() const { return sparse_; }
+  VarianceNorm variance_norm() const { return variance_norm_; }
+  int diag_val_size() const { return (int)diag_val_.size(); }
+  float diag_val(int i) const { return diag_val_[i]; }
+  void add_diag_val(float v) { diag_val_.push_back(v); }
   void set_type(const std::string& v) { type_ = v; }
   void set_value(float v) { value_ = v; }
  private:
   std::string type_ = "constant";
-  float value_ = 0.f;
+  float value_ = 0.f, min_ = 0.f, max_ = 1.f, mean_ = 0.f, std_ = 1.f;
+  int sparse_ = -1;
+  VarianceNorm variance_norm_ = FillerParameter_VarianceNorm_FAN_IN;
+  std::vector<float> diag_val_;
 };
 
 enum EltwiseParameter_EltwiseOp { EltwiseParameter_EltwiseOp_PROD = 0, EltwiseParameter_EltwiseOp_SUM = 1, EltwiseParameter_EltwiseOp_MAX = 2 };

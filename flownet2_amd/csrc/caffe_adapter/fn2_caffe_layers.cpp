@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "caffe/blob.hpp"
+#include "caffe/filler.hpp"
 #include "caffe/layer.hpp"
 #include "caffe/layer_factory.hpp"
 #include "caffe/proto/caffe.pb.h"
@@ -394,6 +395,105 @@ class DownsampleLayer : public Layer<Dtype> {
   int top_width_, top_height_;
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Convolution / Deconvolution as plug-ins: one class for both (transposed_ tells them apart), the kernel family picked by the LIBRARY from
+// the layer's geometry (fn2_conv_route / fn2_deconv_route, csrc/conv_route.cpp -- the routing the benchmarks ran with).
+//   <- ConvolutionLayer / DeconvolutionLayer (conv_layer.cpp:8-40, deconv_layer.cpp:8-45) over BaseConvolutionLayer::LayerSetUp / Reshape
+//      (base_conv_layer.cpp:14-253): same convolution_param fields (num_output, kernel_size, stride, pad, bias_term, weight / bias fillers),
+//      same blob shapes -- weight [num_output, C, k, k] (Deconvolution: [C, num_output, k, k]), bias [num_output] --, same top shape.
+// Scope: square kernels, group 1, dilation 1, one bottom / top pair, the geometries the library has a kernel for (every Convolution and
+// Deconvolution of the FlowNet graphs); anything else aborts in Reshape with a message naming the layer -- keep the stock class for those
+// (INTEGRATION.md shows the two-line factory that falls back to it).  The packed weight operand is rebuilt in every Forward (Caffe has no
+// "weights changed" signal below Solver::ApplyUpdate; ~20 us per layer).  Backward stays the stock layer's: training through Caffe keeps
+// BaseConvolutionLayer's GEMM gradients (or derives this class from it); the own gradient kernels are reached through the C ABI
+// (fn2_conv_wgrad, fn2_tconv_forward, ...) and the Python mirror.
+template <typename Dtype>
+class Fn2ConvolutionLayer : public Layer<Dtype> {
+ public:
+  explicit Fn2ConvolutionLayer(const LayerParameter& param, bool transposed) : Layer<Dtype>(param), transposed_(transposed) {}
+  virtual void LayerSetUp(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    const ConvolutionParameter& cp = this->layer_param_.convolution_param();
+    CHECK(cp.kernel_size_size() == 1 && !cp.has_kernel_h() && !cp.has_kernel_w()) << "square kernel_size required";
+    CHECK_LE(cp.stride_size(), 1); CHECK_LE(cp.pad_size(), 1); CHECK_LE(cp.dilation_size(), 1);
+    CHECK(cp.dilation_size() == 0 || cp.dilation(0) == 1) << "dilation 1 only";
+    CHECK_EQ(cp.group(), 1u) << "group 1 only";
+    kernel_ = (int)cp.kernel_size(0);
+    stride_ = cp.stride_size() ? (int)cp.stride(0) : 1;
+    pad_ = cp.pad_size() ? (int)cp.pad(0) : 0;
+    num_output_ = (int)cp.num_output();
+    CHECK_GT(num_output_, 0);
+    bias_term_ = cp.bias_term();
+    channels_ = bottom[0]->channels();
+    if (this->blobs_.size() == 0) {
+      this->blobs_.resize(bias_term_ ? 2 : 1);
+      // base_conv_layer.cpp:125-139: [conv_out_channels, conv_in_channels / group, k, k]; for a Deconvolution the roles are swapped
+      const int d0 = transposed_ ? channels_ : num_output_, d1 = transposed_ ? num_output_ : channels_;
+      this->blobs_[0].reset(new Blob<Dtype>(d0, d1, kernel_, kernel_));
+      shared_ptr<Filler<Dtype> > wf(GetFiller<Dtype>(cp.weight_filler()));
+      wf->Fill(this->blobs_[0].get());
+      if (bias_term_) {
+        this->blobs_[1].reset(new Blob<Dtype>(vector<int>{num_output_}));
+        shared_ptr<Filler<Dtype> > bf(GetFiller<Dtype>(cp.bias_filler()));
+        bf->Fill(this->blobs_[1].get());
+      }
+    }
+    this->param_propagate_down_.resize(this->blobs_.size(), true);
+  }
+  virtual void Reshape(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    CHECK_EQ(bottom[0]->channels(), channels_) << "Input size incompatible with convolution kernel.";
+    desc_.N = bottom[0]->num(); desc_.Cin = channels_; desc_.Hin = bottom[0]->height(); desc_.Win = bottom[0]->width();
+    desc_.Cout = num_output_; desc_.kernel = kernel_; desc_.stride = stride_; desc_.pad = pad_;
+    int oh, ow;
+    if (transposed_) {      // deconv_layer.cpp:8-24
+      oh = stride_ * (desc_.Hin - 1) + kernel_ - 2 * pad_; ow = stride_ * (desc_.Win - 1) + kernel_ - 2 * pad_;
+      route_ = fn2_deconv_route(&desc_, 0);
+    } else {                // conv_layer.cpp:8-23
+      oh = (desc_.Hin + 2 * pad_ - kernel_) / stride_ + 1; ow = (desc_.Win + 2 * pad_ - kernel_) / stride_ + 1;
+      route_ = fn2_conv_route(&desc_, 0);
+    }
+    if (route_ == 0)
+      LOG(FATAL) << this->layer_param_.name() << ": libflownet2_hip has no kernel for " << type() << "{kernel " << kernel_ << ", stride " << stride_
+                 << ", pad " << pad_ << "} " << channels_ << " -> " << num_output_ << " on " << desc_.Hin << " x " << desc_.Win << "; keep the stock layer for it";
+    top[0]->Reshape(desc_.N, num_output_, oh, ow);
+    const size_t pf = transposed_ ? fn2_deconv_packed_weight_floats(&desc_, route_) : fn2_conv_packed_weight_floats(&desc_, route_);
+    const size_t wb = transposed_ ? fn2_deconv_workspace_bytes(&desc_, route_) : fn2_conv_workspace_bytes(&desc_, route_);
+    packed_.Reshape(vector<int>{(int)pf});
+    workspace_.Reshape(vector<int>{(int)((wb + 3) / 4) + 4});
+  }
+  virtual inline const char* type() const { return transposed_ ? "Deconvolution" : "Convolution"; }
+  virtual inline int ExactNumBottomBlobs() const { return 1; }
+  virtual inline int ExactNumTopBlobs() const { return 1; }
+
+ protected:
+  virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
+  virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    const float* w = f32(this->blobs_[0]->gpu_data());
+    const float* b = bias_term_ ? f32(this->blobs_[1]->gpu_data()) : nullptr;
+    float* pk = f32(packed_.mutable_gpu_data());
+    void* ws = workspace_.mutable_gpu_data();
+    const size_t wsb = sizeof(Dtype) * (size_t)workspace_.count();
+    if (transposed_) {
+      FN2_CALL(fn2_deconv_pack_weights(&desc_, route_, w, pk, kStream));
+      FN2_CALL(fn2_deconv_forward(&desc_, route_, f32(bottom[0]->gpu_data()), channels_, 0, pk, b, f32(top[0]->mutable_gpu_data()), num_output_, 0,
+                                  0, 0.f, ws, wsb, kStream));
+    } else {
+      FN2_CALL(fn2_conv_pack_weights(&desc_, route_, w, pk, kStream));
+      FN2_CALL(fn2_conv_forward(&desc_, route_, f32(bottom[0]->gpu_data()), channels_, 0, pk, b, f32(top[0]->mutable_gpu_data()), num_output_, 0,
+                                0, 0.f, ws, wsb, kStream));
+    }
+  }
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) {
+    LOG(FATAL) << type() << " plug-in: forward only -- train through the stock layer's Backward_gpu (INTEGRATION.md)";
+  }
+  bool transposed_, bias_term_ = true;
+  int kernel_ = 0, stride_ = 1, pad_ = 0, num_output_ = 0, channels_ = 0, route_ = 0;
+  fn2_conv_desc desc_;
+  Blob<Dtype> packed_, workspace_;
+};
+template <typename Dtype> shared_ptr<Layer<Dtype> > Creator_Fn2Convolution(const LayerParameter& p) { return shared_ptr<Layer<Dtype> >(new Fn2ConvolutionLayer<Dtype>(p, false)); }
+template <typename Dtype> shared_ptr<Layer<Dtype> > Creator_Fn2Deconvolution(const LayerParameter& p) { return shared_ptr<Layer<Dtype> >(new Fn2ConvolutionLayer<Dtype>(p, true)); }
+
 INSTANTIATE_CLASS(CorrelationLayer);
 REGISTER_LAYER_CLASS(Correlation);
 INSTANTIATE_CLASS(Correlation1DLayer);
@@ -410,5 +510,10 @@ INSTANTIATE_CLASS(ChannelNormLayer);
 REGISTER_LAYER_CLASS(ChannelNorm);
 INSTANTIATE_CLASS(DownsampleLayer);
 REGISTER_LAYER_CLASS(Downsample);
+// one type string can be registered once (layer_factory.hpp:69-70): in a Caffe tree these two REPLACE GetConvolutionLayer /
+// REGISTER_LAYER_CLASS(Deconvolution) of layer_factory.cpp:38-70 / deconv_layer.cpp:79-80 (or wrap them: INTEGRATION.md)
+INSTANTIATE_CLASS(Fn2ConvolutionLayer);
+REGISTER_LAYER_CREATOR(Convolution, Creator_Fn2Convolution);
+REGISTER_LAYER_CREATOR(Deconvolution, Creator_Fn2Deconvolution);
 
 }  // namespace caffe

@@ -248,18 +248,11 @@ class _UpsampleFlow(torch.autograd.Function):
         return dx, dw, db
 
 
-def _own_head_bwd():
-    return os.environ.get("FN2_OWN_HEAD_BWD", "1") != "0"
-
-
 def predict_flow_conv(x, weight, bias=None):
-    """predict_flow (Convolution{3,1,1} -> 2 channels): own forward kernel; with autograd active own backward kernels too
-    (FN2_OWN_HEAD_BWD=0: backward through _OwnForwardConv, i.e. the library)."""
+    """predict_flow (Convolution{3,1,1} -> 2 channels): own forward kernel; with autograd active own backward kernels too."""
     run = lambda xx, ww, bb: ops.predict_flow_conv_forward(xx.contiguous(), ww.contiguous(), bb)
     if _needs_grad(x, weight, bias):
-        if not _train_fast_forward():
-            return torch.nn.functional.conv2d(x, weight, bias, stride=1, padding=1)
-        if _own_head_bwd() and ops.predict_flow_conv_backward_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3]):
+        if ops.predict_flow_conv_backward_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3]):
             return _PredictFlow.apply(x, weight, bias)
         return _OwnForwardConv.apply(x, weight, bias, run, 1, 1, 0.0, False, False)
     return run(x, weight, bias)
@@ -380,12 +373,6 @@ def _packed_conv_weight(w):
     return _cached(_PACKED, id(w), w, lambda: ops.conv_mfma_pack_weights(w.detach()))
 
 
-def _mfma_conv_enabled(kernel, stride):
-    """FN2_CONV_MFMA: "all" (default), "none", or a comma list of k<kernel>s<stride> classes, e.g. "k5s2,k3s1"."""
-    sel = os.environ.get("FN2_CONV_MFMA", "all")
-    return sel in ("all", "force") or (sel != "none" and ("k%ds%d" % (kernel, stride)) in sel.split(","))
-
-
 _PACKED_U = {}
 
 
@@ -393,42 +380,21 @@ def _packed_wino_weight(w):
     return _cached(_PACKED_U, id(w), w, lambda: ops.conv_wino_pack_weights(w.detach()))
 
 
+_ROUTE_FORCE = [False]
+
+
+def set_route_force(on: bool = True):
+    """Test hook (FN2_ROUTE_FORCE of fn2_conv_route): the Winograd kernel wherever it applies, the small-map kernel whatever the map size."""
+    _ROUTE_FORCE[0] = bool(on)
+
+
 def _conv_mfma_pick(x, weight, stride, pad):
-    """Which own kernel serves this layer: "wino", "plane", "direct" or None (see conv_mfma_relu)."""
-    Cout, Cin, k, _ = weight.shape
-    if not x.is_cuda or not _mfma_conv_enabled(k, stride):
+    """Which own kernel serves this layer: "wino", "plane", "direct" or None.  The decision is the library's (fn2_conv_route,
+    csrc/conv_route.cpp: thresholds, batch-invariant mode), the same one the Caffe adapter's Convolution gets."""
+    Cout, Cin, k, k2 = weight.shape
+    if not x.is_cuda or k != k2:
         return None
-    force = os.environ.get("FN2_CONV_MFMA", "") == "force"
-    wino_first = force      # tests: the Winograd kernel wherever it applies, the small-map kernel whatever the map size
-    N, _, H, W = x.shape
-    if _BATCH_INVARIANT[0]:
-        # the route (and with it the arithmetic) must not depend on the batch: decide as for one sample
-        N, wino_first = 1, True
-    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    wino_ok = k == 3 and stride == 1 and os.environ.get("FN2_CONV_WINO", "1") != "0" and ops.conv_wino_supported(Cin, H, W, Cout, pad)
-    # accumulator blocks of the Winograd kernel (16 channels x an 8x8-pixel block of tiles): from ~1000 on the launch fills the 1024 SIMDs
-    # and it is the fastest kernel of a 3x3 / 1 layer (profiles/r02_conv_bench_*.txt: 20x28 maps win by 1.6x, 12x24 maps lose)
-    if wino_ok and (wino_first or N * ((Ho + 7) // 8) * ((Wo + 7) // 8) * (Cout // 16) >= 1000):
-        return "wino"
-    maxpix = int(os.environ.get("FN2_CONV_PLANE_MAXPIX", "8000"))
-    if (k == 3 and (force or Ho * Wo <= maxpix) and os.environ.get("FN2_CONV_PLANE", "1") != "0"
-            and ops.conv_plane_supported(N, Cin, H, W, Cout, stride, pad) and (N == x.shape[0] or ops.conv_plane_supported(x.shape[0], Cin, H, W, Cout, stride, pad))):
-        # the encoder layers from 1/16 resolution down (conv4 .. conv6_1; at batch 1 from 1/8 down): whole planes or row bands in LDS,
-        # pixels of several samples per MFMA tile, split K
-        return "plane"
-    if (k == 5 and stride == 2 and pad == 2 and os.environ.get("FN2_CONV_PLANE5", "1") != "0"
-            and N * ((Ho + 3) // 4) * ((Wo + 3) // 4) * (Cout // 16) < 64 * 256 and Ho * Wo <= maxpix
-            and ops.conv_plane_k_supported(x.shape[0], Cin, H, W, Cout, 5, 2, 2)
-            and (N == x.shape[0] or ops.conv_plane_k_supported(N, Cin, H, W, Cout, 5, 2, 2))):      # batch-invariant mode: the same kernel at batch 1 and batch B
-        # conv3 of the encoders when one sample is the whole batch (FlowNet2 at 1024x448, batch 1: [1,128,112,256] -> 256): 7168 accumulator
-        # tiles cannot fill the chip without a K split, which the direct kernel does not have (120 us against 180;
-        # scripts/probes/small_layer_routes.py)
-        return "plane"
-    if wino_ok:
-        return "wino"       # a 3x3 / 1 layer too large for the small-map kernel and too small to fill the chip: still 2.25x fewer multiplies
-    if not ops.conv_mfma_supported(Cin, H, W, Cout, k, stride, pad):
-        return None
-    return "direct"         # 5x5 / 2, 3x3 / 2 on large maps, 7x7 / 2 on whole channel quads, 1x1 (conv_redir; the GEMM of a Deconvolution)
+    return ops.conv_route(x.shape[0], Cin, x.shape[2], x.shape[3], Cout, k, stride, pad, force=_ROUTE_FORCE[0])
 
 
 def _channel_slice(x):
@@ -506,10 +472,10 @@ class _OwnForwardConv(torch.autograd.Function):
 def _own_bwd_weight(d, x, w, stride, pad, transposed):
     """weight_diff of a Convolution (ConvolutionLayer::Backward_gpu -> weight_gpu_gemm, conv_layer.cu:40-52) or Deconvolution
     (deconv_layer.cu:36-50, the roles of the two blobs swapped) on the own fp32 MFMA kernel (csrc/conv_wgrad.hip): NCHW in, weight
-    layout out, no layout transposes, deterministic.  FN2_OWN_WGRAD=0 hands it back to the library.  Returns None when the kernel does
+    layout out, no layout transposes, deterministic.  Returns None when the kernel does
     not apply (tap classes 1/1, 3/1, 3/2, 4/2, 5/2; layers with fewer than 16 output channels -- the 2-channel flow heads -- stay
     with the library: a 16-wide MFMA tile would be 8x padding)."""
-    if os.environ.get("FN2_OWN_WGRAD", "1") == "0" or not d.is_cuda:
+    if not d.is_cuda:
         return None
     k = w.shape[2]
     if (not transposed and k == 7 and w.shape[3] == 7 and stride == 2 and pad == 3 and d.is_contiguous() and x.is_contiguous()
@@ -540,11 +506,9 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
       * Convolution 5x5 / 2 / 2 and 3x3 / 2 / 1: the transposed convolution of top_diff with the weight blob as it is (csrc/tconv_mfma.hip);
       * Deconvolution 4x4 / 2 / 1: the 4x4 / 2 / 1 CONVOLUTION of top_diff with the weight blob as it is (csrc/conv_mfma.hip), output
         channels padded to a multiple of 64.
-    FN2_OWN_DGRAD=0 hands everything back to the library; FN2_WINO_BWD: "all" (default), "odd" or "none" for the Winograd case.
     Returns None when no own kernel applies."""
-    if os.environ.get("FN2_OWN_DGRAD", "1") == "0" or not d.is_cuda:
+    if not d.is_cuda:
         return None
-    mode = os.environ.get("FN2_WINO_BWD", "all")
     k, k2 = w.shape[2], w.shape[3]
     if k != k2:
         return None
@@ -587,9 +551,7 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
             return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cp, Cout, 1, Cin, Cout, 1, Cin)
         gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "1x1-dgrad", make_1x1), None, Cp, 1, 1, 0, False, 0.0)
         return gx[:, :Cin] if Cp != Cin else gx
-    if mode == "none" or k != 3 or stride != 1 or pad != 1:
-        return None
-    if mode == "odd" and Cin % 8 == 0:
+    if k != 3 or stride != 1 or pad != 1:
         return None
     Cp = (Cin + 15) // 16 * 16
     if not ops.conv_wino_supported(Cout, d.shape[2], d.shape[3], Cp, 1):
@@ -616,10 +578,6 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def _train_fast_forward():
-    return os.environ.get("FN2_CONV_MFMA_TRAIN", "1") != "0"
-
-
 def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
     """Convolution + bias (+ leaky ReLU) as ONE MFMA kernel, NCHW in and out, optionally written into a channel slice of `out`:
     Winograd F(2x2, 3x3) for 3x3 / stride 1 / pad 1 (csrc/conv_wino.hip), the direct kernel otherwise (csrc/conv_mfma.hip).
@@ -629,7 +587,7 @@ def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, o
     if kind is None:
         return None
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        if out is not None or os.environ.get("FN2_CONV_MFMA_TRAIN", "1") == "0":
+        if out is not None:
             return None
         return _OwnForwardConv.apply(x, weight, bias, lambda xx, ww, bb: _conv_mfma_run(kind, xx, ww, bb, stride, pad, negative_slope, act),
                                      stride, pad, negative_slope, act, False)
@@ -650,16 +608,13 @@ def _packed_deconv_weight(w):
 def deconv_mfma_relu(x, weight, bias, negative_slope=0.1, act=True, out=None, out_c0=0):
     """Deconvolution{4, 2, 1} + bias (+ leaky ReLU) as ONE MFMA kernel (csrc/conv_plane.hip, one output parity class per wave), NCHW in
     and out, optionally written into a channel slice of `out` (the consumer's Concat blob).  weight: Caffe's [Cin, Cout, 4, 4] blob.
-    Opt-in (FN2_DECONV_PLANE=1): on the FlowNet shapes the library GEMM (130+ TFLOP/s) + our col2im pass is 5-25 % faster than this
-    kernel (profiles/r02_deconv_bench.txt).  Returns None when the kernel does not apply or a gradient is needed: the caller then
-    takes the GEMM + col2im route."""
-    mode = os.environ.get("FN2_DECONV_PLANE", "auto")
-    if not x.is_cuda or mode == "0" or _needs_grad(x, weight, bias):
+    The library routes (fn2_deconv_route): on the FlowNet shapes the GEMM (own 1x1 MFMA kernel) + our col2im pass is 5-25 % faster than this
+    kernel (profiles/r02_deconv_bench_flownetc.txt), so it serves the planes the GEMM kernel does not take (5x7) .  Returns None when the
+    library picks the GEMM route, the kernel does not apply, or a gradient is needed: the caller then takes the GEMM + col2im route."""
+    if not x.is_cuda or _needs_grad(x, weight, bias):
         return None
-    if mode == "auto" and (x.shape[2] * x.shape[3]) % 4 == 0 and _deconv_gemm_supported(x, weight.shape[1], 4):
-        return None        # the GEMM route (own 1x1 MFMA kernel + col2im pass) serves it; odd planes (5x7) and maps it does not take stay here
     Cin, Cout = weight.shape[:2]
-    if tuple(weight.shape[2:]) != (4, 4) or not ops.deconv_plane_supported(x.shape[0], Cin, x.shape[2], x.shape[3], Cout):
+    if tuple(weight.shape[2:]) != (4, 4) or ops.deconv_route(x.shape[0], Cin, x.shape[2], x.shape[3], Cout) != "plane":
         return None
     blob, c0 = _channel_slice(x)
     return ops.deconv_plane_forward(blob, _packed_deconv_weight(weight), bias, Cout, act, negative_slope, out=out, out_c0=out_c0, in_c0=c0, Cin=Cin)
@@ -678,8 +633,7 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     Ho, Wo = (H - 1) * stride - 2 * pad + kernel, (W - 1) * stride - 2 * pad + kernel
     gemm_ok = _deconv_gemm_supported(x, cout, kernel)
     # planes the 1x1 / GEMM kernel does not take (deconv5: 5x7) are the small-map deconvolution kernel's -- no column matrix at all
-    plane_ok = bool(x.is_cuda and (kernel, stride, pad) == (4, 2, 1) and os.environ.get("FN2_DECONV_PLANE", "auto") != "0"
-                    and ops.deconv_plane_supported(N, Cin, H, W, cout))
+    plane_ok = bool(x.is_cuda and (kernel, stride, pad) == (4, 2, 1) and ops.deconv_plane_supported(N, Cin, H, W, cout))
     if not gemm_ok and not plane_ok:
         return None
 
@@ -699,7 +653,7 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
     if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)
         return None if (_needs_grad(x, weight_t, bias, weight) or not gemm_ok) else run_t(x, weight_t, bias, out, out_c0)
     if _needs_grad(x, weight_t, bias, weight):
-        if weight is None or not _train_fast_forward():
+        if weight is None:
             return None
         def run(xx, ww, bb):
             # ww is the parameter itself (autograd does not record inside _OwnForwardConv.forward): its transposed view and the packed

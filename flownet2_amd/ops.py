@@ -469,6 +469,23 @@ def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
     return out
 
 
+CONV_ROUTES = {0: None, 1: "direct", 2: "wino", 3: "plane"}
+DECONV_ROUTES = {0: None, 1: "gemm", 2: "plane"}
+
+
+def conv_route(N, Cin, Hin, Win, Cout, kernel, stride, pad, force=False):
+    """Which kernel family the LIBRARY picks for Convolution{kernel, stride, pad} Cin -> Cout on [N, Cin, Hin, Win] (fn2_conv_route,
+    csrc/conv_route.cpp -- the same decision the Caffe adapter gets): "wino", "plane", "direct" or None."""
+    d = _lib.ConvDesc(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad))
+    return CONV_ROUTES[int(_lib.lib().fn2_conv_route(C.byref(d), 1 if force else 0))]
+
+
+def deconv_route(N, Cin, Hin, Win, Cout, kernel=4, stride=2, pad=1):
+    """fn2_deconv_route: "gemm" (weight^T x bottom on the 1x1 kernel + col2im), "plane" (parity classes, small maps) or None."""
+    d = _lib.ConvDesc(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad))
+    return DECONV_ROUTES[int(_lib.lib().fn2_deconv_route(C.byref(d), 0))]
+
+
 def conv_mfma_supported(Cin, Hin, Win, Cout, kernel, stride, pad) -> bool:
     return bool(_lib.lib().fn2_conv_mfma_supported(int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad)))
 

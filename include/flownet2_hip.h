@@ -467,6 +467,41 @@ int fn2_deconv_plane_forward(const float* bottom, const float* packed_weight, co
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Convolution / Deconvolution by DESCRIPTOR: the library picks the kernel family (csrc/conv_route.cpp).
+ *   <- ConvolutionLayer / DeconvolutionLayer::{LayerSetUp, Reshape, Forward_gpu} (base_conv_layer.cpp:14-253 shapes, conv_layer.cu:8-23,
+ *      deconv_layer.cu:8-26) + the in-place ReLU that follows them in the FlowNet graphs (relu_layer.cu:8-27).
+ *   One decision function for every caller (the Python mirror and the Caffe adapter ask it): fn2_conv_route() returns which family serves
+ *   Convolution{kernel, stride, pad} Cin -> Cout on [N, Cin, Hin, Win] -- Winograd F(2x2,3x3), the small-map kernel (deterministic K split),
+ *   the direct kernel -- or NONE (the caller keeps its library layer).  The weight operand is packed per ROUTE
+ *   (fn2_conv_packed_weight_floats / fn2_conv_pack_weights: once per weight update, LayerSetUp / after Solver::ApplyUpdate), the forward takes
+ *   channel slices on both blobs like the kernels it dispatches to.  FN2_ROUTE_FORCE (tests): Winograd wherever it applies, the small-map
+ *   kernel whatever the map size.  fn2_set_batch_invariant(1): the route is decided as for ONE sample.
+ *   Deconvolution{4, 2, 1} (weight blob [Cin][Cout][4][4], top [N, Cout, 2 Hin, 2 Win]): GEMM (weight^T x bottom on the 1x1 form of the
+ *   direct kernel into a column matrix in the WORKSPACE, then col2im + bias + ReLU in one pass) or the parity-class small-map kernel.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fn2_conv_desc {
+  int N, Cin, Hin, Win;      /* bottom [N, Cin, Hin, Win] (a channel slice of a wider blob is given to the forward call) */
+  int Cout, kernel, stride, pad;
+} fn2_conv_desc;
+enum { FN2_CONV_ROUTE_NONE = 0, FN2_CONV_ROUTE_DIRECT = 1, FN2_CONV_ROUTE_WINOGRAD = 2, FN2_CONV_ROUTE_PLANE = 3 };
+enum { FN2_DECONV_ROUTE_NONE = 0, FN2_DECONV_ROUTE_GEMM = 1, FN2_DECONV_ROUTE_PLANE = 2 };
+enum { FN2_ROUTE_FORCE = 1 };
+int fn2_conv_route(const fn2_conv_desc* desc, int flags);
+size_t fn2_conv_packed_weight_floats(const fn2_conv_desc* desc, int route);
+int fn2_conv_pack_weights(const fn2_conv_desc* desc, int route, const float* weight, float* packed, void* stream);
+size_t fn2_conv_workspace_bytes(const fn2_conv_desc* desc, int route);
+int fn2_conv_forward(const fn2_conv_desc* desc, int route, const float* bottom, int bottom_channels, int bottom_c0,
+                     const float* packed_weight, const float* bias, float* top, int top_channels, int top_c0,
+                     int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream);
+int fn2_deconv_route(const fn2_conv_desc* desc, int flags);
+size_t fn2_deconv_packed_weight_floats(const fn2_conv_desc* desc, int route);
+int fn2_deconv_pack_weights(const fn2_conv_desc* desc, int route, const float* weight, float* packed, void* stream);
+size_t fn2_deconv_workspace_bytes(const fn2_conv_desc* desc, int route);
+int fn2_deconv_forward(const fn2_conv_desc* desc, int route, const float* bottom, int bottom_channels, int bottom_c0,
+                       const float* packed_weight, const float* bias, float* top, int top_channels, int top_c0,
+                       int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Transposed convolution, stride 2 (fp32 MFMA, NCHW, no column matrix / col2im):
  *     top[n][top_c0 + co][Y][X] = act(bias[co] + sum_{ci,ky,kx: Y = 2y - pad + ky, X = 2x - pad + kx} bottom[n][bottom_c0 + ci][y][x] * W[ci][co][ky][kx])
  *   <- DeconvolutionLayer::Forward_gpu, src/caffe/layers/deconv_layer.cu:8-26 (backward_gpu_gemm + col2im_gpu, base_conv_layer.cpp:375-393,

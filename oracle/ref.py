@@ -163,6 +163,24 @@ def convolution(x, weight, bias=None, kernel=3, stride=1, pad=1, deconv=False, r
     return out
 
 
+def convolution_by_registry(x, weight, bias=None, kernel=3, stride=1, pad=1, deconv=False):
+    """Convolution / Deconvolution created by prototxt type string through LayerRegistry -- in the ADAPTER library these are the plug-ins of
+    flownet2_amd/csrc/caffe_adapter (use("adapter") first)."""
+    x, weight = _f(x), _f(weight)
+    bias = _f(bias) if bias is not None else None
+    N, Cc, H, W = x.shape
+    num_output = weight.shape[1] if deconv else weight.shape[0]
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.fn2ref_convolution_by_registry.argtypes = [C.c_int] * 6 + [C.c_float, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, C.POINTER(C.c_int)]
+    shape = (C.c_int * 4)()
+    args = (int(deconv), kernel, stride, pad, num_output, 0, 0.0, _p(x), N, Cc, H, W, _p(weight), _p(bias))
+    _chk(L.fn2ref_convolution_by_registry(*args, None, shape))
+    out = np.empty(tuple(shape), np.float32)
+    _chk(L.fn2ref_convolution_by_registry(*args, _p(out), shape))
+    return out
+
+
 def custom_data(records, batch_size, slice_points=(), encodings=(), scale=1.0, subtract=(), range_start=0, range_end=-1,
                 n_forward=1, with_labels=False):
     """The reference's CustomDataLayer (custom_data_layer.cpp) over an in-memory stand-in for LMDB.  records: list of (key, value

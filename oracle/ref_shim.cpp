@@ -269,6 +269,40 @@ int fn2ref_convolution(int deconv, int kernel, int stride, int pad, int num_outp
 }
 #endif
 
+#ifdef FN2_SHIM_CONV_REGISTRY
+// Convolution / Deconvolution created BY TYPE STRING through LayerRegistry (the adapter build: its plug-ins registered "Convolution" and
+// "Deconvolution"): square kernel, given weights and optional bias.  Same argument list as fn2ref_convolution (relu must be 0).
+extern "C" __attribute__((visibility("default")))
+int fn2ref_convolution_by_registry(int deconv, int kernel, int stride, int pad, int num_output, int relu, float negative_slope,
+                                   const float* x, int N, int C, int H, int W, const float* weight, const float* bias /* nullable */,
+                                   float* out /* nullable */, int* out_shape /* [4] */) {
+  return guard([&] {
+    (void)negative_slope;
+    CHECK(relu == 0) << "the registry-driven convolution shim has no ReLU";
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_name("conv_under_test");
+    lp.set_type(deconv ? "Deconvolution" : "Convolution");
+    ConvolutionParameter* cp = lp.mutable_convolution_param();
+    cp->set_num_output(num_output); cp->add_kernel_size(kernel); cp->add_stride(stride); cp->add_pad(pad);
+    cp->set_bias_term(bias != nullptr);
+    cp->mutable_weight_filler()->set_type("constant");
+    cp->mutable_bias_filler()->set_type("constant");
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    Blob<float> bot(N, C, H, W), top;
+    fill(bot, x);
+    vector<Blob<float>*> bottom{&bot}, tops{&top};
+    layer->SetUp(bottom, tops);
+    fill(*layer->blobs()[0], weight);
+    if (bias) fill(*layer->blobs()[1], bias);
+    layer->Forward(bottom, tops);
+    CUDA_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 4; ++i) out_shape[i] = top.shape(i);
+    if (out) fetch(top, out);
+  });
+}
+#endif
+
 #ifdef FN2_SHIM_L1LOSS
 
 // The reference's L1LossLayer (oracle/_ref: built with its stock sub-layers, see oracle/README.md) or the adapter's.

@@ -125,3 +125,42 @@ def test_adapter_compiles_against_the_reference_headers(tmp_path):
     out = subprocess.run(["bash", script, str(tmp_path / "adapter.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert os.path.getsize(str(tmp_path / "adapter.o")) > 10000
+
+
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, kernel, stride, pad, deconv): every Convolution / Deconvolution class of the FlowNet graphs, at sizes the reference's
+    # im2col + SGEMM stand-in finishes quickly -- one per kernel family the library routes to
+    (2, 64, 24, 32, 128, 5, 2, 2, False),      # conv2 / conv3 class: direct kernel
+    (2, 64, 16, 24, 64, 3, 1, 1, False),       # conv3_1 class: Winograd or the small-map kernel (the library decides)
+    (2, 64, 16, 24, 128, 3, 2, 1, False),      # conv4 class
+    (1, 256, 8, 12, 32, 1, 1, 0, False),       # conv_redir: 1x1
+    (2, 128, 8, 12, 64, 4, 2, 1, True),        # deconv class: GEMM + col2im
+    (2, 128, 5, 7, 64, 4, 2, 1, True),         # deconv5: a 5x7 plane, the parity-class kernel
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_adapter_convolution_plugins_match_the_reference_layers(case):
+    """Round 5: "Convolution" / "Deconvolution" created BY TYPE STRING through LayerRegistry are the adapter's plug-ins (the kernel family is
+    picked inside libflownet2_hip.so, fn2_conv_route / fn2_deconv_route); the same blobs through the reference's own ConvolutionLayer /
+    DeconvolutionLayer (oracle/_ref: conv_layer.cpp, deconv_layer.cpp, base_conv_layer.cpp, im2col.cu compiled in place)."""
+    if not (ref.available() and ref.adapter_available()):
+        pytest.skip("reference / adapter libraries not built")
+    N, Cin, H, W, Cout, k, s, p, deconv = case
+    x = rnd((N, Cin, H, W), 11)
+    w = rnd((Cin, Cout, k, k) if deconv else (Cout, Cin, k, k), 12, 0.1)
+    b = rnd((Cout,), 13)
+    ref.use("ref")
+    want = ref.convolution(x, w, b, kernel=k, stride=s, pad=p, deconv=deconv)
+    ref.use("adapter")
+    try:
+        got = ref.convolution_by_registry(x, w, b, kernel=k, stride=s, pad=p, deconv=deconv)
+        got_nb = ref.convolution_by_registry(x, w, None, kernel=k, stride=s, pad=p, deconv=deconv)
+    finally:
+        ref.use("ref")
+    assert got.shape == want.shape
+    # fp32 sums of Cin k k products in different orders (and Winograd's transforms): the tolerance of the reference's own conv tests (1e-4)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(got_nb, want - b.reshape(1, -1, 1, 1), rtol=0, atol=1e-4 * scale)

@@ -694,16 +694,12 @@ def test_flownet2_stack_end_to_end_epe():
     assert np.isfinite(epe) and epe <= 1e-4, epe
     # the same with every convolution that CAN run on the own MFMA kernels forced onto them (at this small size the work
     # thresholds keep most of them on the library): Winograd / direct kernels, Concat blobs written in place, channel-slice inputs
-    keep = os.environ.get("FN2_CONV_MFMA")
-    os.environ["FN2_CONV_MFMA"] = "force"
+    Fn.set_route_force(True)            # FN2_ROUTE_FORCE of fn2_conv_route
     try:
         with torch.no_grad():
             forced = nets.flownet2_deploy_forward(Pd, i0.cuda(), i1.cuda(), Fn).cpu()
     finally:
-        if keep is None:
-            os.environ.pop("FN2_CONV_MFMA", None)
-        else:
-            os.environ["FN2_CONV_MFMA"] = keep
+        Fn.set_route_force(False)
     epe = float(((forced - ref) ** 2).sum(1).sqrt().mean())
     assert np.isfinite(epe) and epe <= 1e-4, epe
     # non-64-multiple target size exercises the ADAPTED/TARGET resample pair and the SCALE factors
@@ -882,15 +878,7 @@ def test_own_winograd_data_gradient_matches_autograd(case):
     from flownet2_amd import functional as Fn
     N, Cin, H, W, Cout = case
     x, w, d = rand((N, Cin, H, W), 71), rand((Cout, Cin, 3, 3), 72, 0.2), rand((N, Cout, H, W), 73)
-    keep = os.environ.get("FN2_WINO_BWD")
-    os.environ["FN2_WINO_BWD"] = "all"
-    try:
-        got = Fn._own_bwd_data(dev(d), dev(w), 1, 1, False)
-    finally:
-        if keep is None:
-            os.environ.pop("FN2_WINO_BWD", None)
-        else:
-            os.environ["FN2_WINO_BWD"] = keep
+    got = Fn._own_bwd_data(dev(d), dev(w), 1, 1, False)
     assert got is not None and tuple(got.shape) == (N, Cin, H, W)
     want = torch.nn.grad.conv2d_input((N, Cin, H, W), torch.from_numpy(w).double(), torch.from_numpy(d).double(), stride=1, padding=1).numpy()
     assert_close(host(got.contiguous()), want.astype(np.float32), 4e-6, "winograd data gradient vs fp64")
@@ -915,18 +903,14 @@ def test_training_gradients_fused_path_matches_stock_ops():
 
     def grads(trainable=lambda k: True):
         Pd = {k: v.cuda().clone().requires_grad_(bool(trainable(k))) for k, v in P.items()}
-        keep_env = os.environ.get("FN2_CONV_MFMA")
-        os.environ["FN2_CONV_MFMA"] = "force"
+        Fn.set_route_force(True)
         try:
             pre = [(im.cuda() * (1.0 / 255.0)) - 0.43 for im in (im0, im1)]
             with fp64_graph.record_relu_branches() as rec:
                 loss = nets.multiscale_loss(nets.flownet_c_core(Pd, pre[0], pre[1], Fn), gt.cuda(), Fn)
             loss.backward()
         finally:
-            if keep_env is None:
-                os.environ.pop("FN2_CONV_MFMA", None)
-            else:
-                os.environ["FN2_CONV_MFMA"] = keep_env
+            Fn.set_route_force(False)
         return float(loss.detach()), {k: v.grad.detach() for k, v in Pd.items() if v.grad is not None}, rec.branches
 
     loss, got, branches = grads()
