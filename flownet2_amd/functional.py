@@ -264,11 +264,7 @@ def upsample_flow_deconv(x, weight, bias=None, out=None, out_c0=0):
         return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias, out=out, out_c0=out_c0)
     run = lambda xx, ww, bb: ops.upsample_flow_deconv_forward(xx.contiguous(), ww.contiguous(), bb)
     if _needs_grad(x, weight, bias):
-        if not _train_fast_forward():
-            return torch.nn.functional.conv_transpose2d(x, weight, bias, stride=2, padding=1)
-        if _own_head_bwd():
-            return _UpsampleFlow.apply(x, weight, bias)
-        return _OwnForwardConv.apply(x, weight, bias, run, 2, 1, 0.0, False, True)
+        return _UpsampleFlow.apply(x, weight, bias)
     return run(x, weight, bias)
 
 
@@ -310,8 +306,6 @@ def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
         return None
     run = lambda xx, ww, bb: ops.conv_k7s2_relu_forward(xx.contiguous(), ww.contiguous(), bb, negative_slope)
     if _needs_grad(x, weight, bias):
-        if not _train_fast_forward():
-            return None
         return _OwnForwardConv.apply(x, weight, bias, run, 2, 3, negative_slope, True, False)
     return run(x, weight, bias)
 
