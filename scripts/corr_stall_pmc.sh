@@ -12,7 +12,7 @@ for d in ("p1", "p2"):
     for f in glob.glob("$R/%s/**/*counter_collection.csv" % d, recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "corr_fwd_pair" in r["Kernel_Name"]:
+            if "corr_fwd_" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in sorted(acc.items()):
             print("%-26s %16.0f (n=%d)" % (c, sum(v) / len(v), len(v)))

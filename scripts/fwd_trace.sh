@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open("$R/fwd/f_kernel_stats.csv")))
 steps = 25 + 4 * 8       # warm-up + timed + untimed settling steps are not known exactly: normalise by the stem kernel's calls
 for r in rows:
     if "conv_k7s2_relu" in r["Name"]: steps = int(r["Calls"])
-tot = sum(float(r["TotalDurationNs"]) for r in rows if "corr_fwd_pair" not in r["Name"])
+tot = sum(float(r["TotalDurationNs"]) for r in rows if "corr_fwd_" not in r["Name"])
 print("steps %d, GPU time per step %.3f ms (correlation kernel excluded)" % (steps, tot / 1e6 / steps))
 for r in rows[:40]:
     print("%-110s %5.1f/step %8.1f us avg %8.1f us/step" % (r["Name"][:110], int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e3 / steps))

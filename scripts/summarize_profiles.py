@@ -41,7 +41,7 @@ corr_avg_us = None
 for r in ks[:6]:
     lines.append("| `%s` | %s | %.2f | %.2f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
                                                               float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    if ("corr_fwd_pair" in r["Name"] or "corr_fwd_glds" in r["Name"] or "corr_fwd_mfma" in r["Name"]):
+    if ("corr_fwd_units" in r["Name"] or "corr_fwd_pair" in r["Name"] or "corr_fwd_glds" in r["Name"] or "corr_fwd_mfma" in r["Name"]):
         corr_avg_us = float(r["AverageNs"]) / 1e3
 lines += ["", "stdout of the same run:", "```", open(os.path.join(R, "corr_stdout.txt")).read().strip(), "```", ""]
 
@@ -61,7 +61,7 @@ sq = counters(os.path.join(R, "pmc_sq", "corr_counter_collection.csv"), "corr_fw
 fetch_bytes = f["FETCH_SIZE"] * 1024.0 * fetch_factor
 write_bytes = w["WRITE_SIZE"] * 1024.0 * write_factor
 alg = 4.0 * 8 * 40 * 56 * (2 * 256 + 441)
-lines += ["## HBM traffic of the correlation forward kernel (`corr_fwd_pair<10>`) at [8,256,40,56] (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
+lines += ["## HBM traffic of the correlation forward kernel (`corr_fwd_units`) at [8,256,40,56] (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes)", "",
           "Calibration (MI355X_MICROARCH.md, HBM section: FETCH_SIZE/WRITE_SIZE are in KiB and FETCH_SIZE under-reports on gfx950;",
           "calibrate on a known byte count in the same access width): `scripts/hbm_calibrate.py`", "",
           "| kernel | known read B | FETCH_SIZE KiB | bytes / (FETCH_SIZE*1024) | known write B | WRITE_SIZE KiB | bytes / (WRITE_SIZE*1024) |", "|---|---|---|---|---|---|---|"]
@@ -191,7 +191,7 @@ if os.path.exists(pmc_conv):
                                                               100 * busy / (1024.0 * gui_k) if gui_k else 0, conf / act if act else 0))
     open(os.path.join(OUT, f"{tag}_conv_counters.md"), "w").write("\n".join(cl) + "\n")
 
-summary = {"tag": tag, "kernel": "corr_fwd_pair<10> [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
+summary = {"tag": tag, "kernel": "corr_fwd_units [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
            "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "fetch_correction": fetch_factor,
            "write_correction": write_factor, "hbm_read_bytes": fetch_bytes, "hbm_write_bytes": write_bytes,
            "traffic_bytes_per_launch": fetch_bytes + write_bytes, "algorithmic_bytes_per_launch": alg,

@@ -12,7 +12,7 @@ for pat in ("stem_wgrad", "conv_k7s2_relu<3"):
         steps = max(hit)
         break
 steps = steps or 1
-tot = sum(float(r["TotalDurationNs"]) for r in rows if "corr_fwd_pair" not in r["Name"])
+tot = sum(float(r["TotalDurationNs"]) for r in rows if "corr_fwd_" not in r["Name"])
 cats = {}
 
 
@@ -32,7 +32,7 @@ def cat(n):
 
 
 for r in rows:
-    if "corr_fwd_pair" in r["Name"]:
+    if "corr_fwd_" in r["Name"]:
         continue
     c = cat(r["Name"])
     cats[c] = cats.get(c, 0) + float(r["TotalDurationNs"])
