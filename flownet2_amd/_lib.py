@@ -40,6 +40,9 @@ EXPORTS = [
     "fn2_debug_set_wgrad_buffers", "fn2_debug_set_wgrad_chunk", "fn2_conv_wgrad_supported", "fn2_conv_wgrad_ksplit", "fn2_conv_wgrad_workspace_bytes", "fn2_conv_wgrad",
     "fn2_conv_route", "fn2_conv_packed_weight_floats", "fn2_conv_pack_weights", "fn2_conv_workspace_bytes", "fn2_conv_forward",
     "fn2_deconv_route", "fn2_deconv_packed_weight_floats", "fn2_deconv_pack_weights", "fn2_deconv_workspace_bytes", "fn2_deconv_forward",
+    "fn2_conv_backward_data_route", "fn2_conv_backward_data_packed_weight_floats", "fn2_conv_backward_data_pack_workspace_bytes",
+    "fn2_conv_backward_data_pack_weights", "fn2_conv_backward_data_workspace_bytes", "fn2_conv_backward_data_computed_channels", "fn2_conv_backward_data",
+    "fn2_conv_backward_weights_supported", "fn2_conv_backward_weights_workspace_bytes", "fn2_conv_backward_weights", "fn2_conv_backward_bias",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
     "fn2_datum_parse", "fn2_datum_float_data", "fn2_datum_serialize",
     "fn2_custom_data_sample_bytes", "fn2_custom_data_encode_sample", "fn2_custom_data_stage_records", "fn2_custom_data_decode_forward",
@@ -240,6 +243,21 @@ def lib():
         getattr(L, pre + "_workspace_bytes").argtypes = [dp, i]
         getattr(L, pre + "_workspace_bytes").restype = sz
         getattr(L, pre + "_forward").argtypes = [dp, i, fp, i, i, fp, fp, fp, i, i, i, C.c_float, vp, sz, vp]
+    L.fn2_conv_backward_data_route.argtypes = [dp, i]
+    L.fn2_conv_backward_data_packed_weight_floats.argtypes = [dp, i, i]
+    L.fn2_conv_backward_data_packed_weight_floats.restype = sz
+    L.fn2_conv_backward_data_pack_workspace_bytes.argtypes = [dp, i, i]
+    L.fn2_conv_backward_data_pack_workspace_bytes.restype = sz
+    L.fn2_conv_backward_data_pack_weights.argtypes = [dp, i, i, fp, fp, vp, sz, vp]
+    L.fn2_conv_backward_data_workspace_bytes.argtypes = [dp, i, i]
+    L.fn2_conv_backward_data_workspace_bytes.restype = sz
+    L.fn2_conv_backward_data_computed_channels.argtypes = [dp, i, i]
+    L.fn2_conv_backward_data.argtypes = [dp, i, i, fp, i, i, fp, fp, i, i, i, vp, sz, vp]
+    L.fn2_conv_backward_weights_supported.argtypes = [dp, i]
+    L.fn2_conv_backward_weights_workspace_bytes.argtypes = [dp, i]
+    L.fn2_conv_backward_weights_workspace_bytes.restype = sz
+    L.fn2_conv_backward_weights.argtypes = [dp, i, fp, i, i, fp, i, i, fp, i, vp, sz, vp]
+    L.fn2_conv_backward_bias.argtypes = [fp, i, i, fp, i, i, i, i, i, vp, sz, vp]
     if hasattr(L, "fn2_debug_set_correlation_impl"):
         L.fn2_debug_set_correlation_impl.argtypes = [i]
     if hasattr(L, "fn2_debug_correlation_units_plan"):

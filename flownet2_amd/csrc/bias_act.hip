@@ -42,6 +42,8 @@ constexpr int kBwdChunks = 8;      // blocks per (n, c) plane
 
 // top_diff may be a channel slice of a wider blob (the gradient of a Concat arrives as one: concat_layer.cu:62-90 hands every bottom its
 // range of top_diff): plane (n, c) of it starts at ((n * dctot + dc0 + c) * hw)
+// MASK = false: the bias gradient alone (a Convolution without a fused ReLU: top_data / bottom_diff unused).
+template <bool MASK>
 __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restrict__ top_data, const float* __restrict__ top_diff,
                                                            float* __restrict__ bottom_diff, float* __restrict__ partial,
                                                            unsigned hw, float slope, int C, int dctot, int dc0) {
@@ -51,8 +53,11 @@ __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restri
   const size_t dbase = ((size_t)(plane / (unsigned)C) * dctot + dc0 + plane % (unsigned)C) * hw;
   float acc = 0.f;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < hw; i += gridDim.x * 256u) {
-    const float g = top_diff[dbase + i] * (top_data[base + i] > 0.f ? 1.f : slope);
-    bottom_diff[base + i] = g;
+    float g = top_diff[dbase + i];
+    if constexpr (MASK) {
+      g *= top_data[base + i] > 0.f ? 1.f : slope;
+      bottom_diff[base + i] = g;
+    }
     acc += g;
   }
 #pragma unroll
@@ -66,7 +71,7 @@ __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restri
 // then a fixed-shape butterfly -- deterministic; a thread per channel walked N * chunks dependent loads (9.6 us per call, 15 calls per
 // FlowNetC training step)
 __global__ void __launch_bounds__(256) bias_diff_finalize(const float* __restrict__ partial, float* __restrict__ bias_diff,
-                                                          int N, int C, int chunks) {
+                                                          int N, int C, int chunks, int accumulate) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
   const int total = N * chunks;
@@ -77,7 +82,7 @@ __global__ void __launch_bounds__(256) bias_diff_finalize(const float* __restric
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-  if (lane == 0) bias_diff[c] = acc;
+  if (lane == 0) bias_diff[c] = accumulate ? bias_diff[c] + acc : acc;
 }
 
 }  // namespace fn2
@@ -103,10 +108,28 @@ FN2_API int fn2_bias_leaky_relu_backward_slices(const float* top_data, const flo
   if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "bias_leaky_relu_backward: workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(bias_leaky_relu_bwd, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
+  hipLaunchKernelGGL(bias_leaky_relu_bwd<true>, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
                      (unsigned)hw, negative_slope, C, diff_channels, diff_c0);
-  if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks);
+  if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks, 0);
   return check_launch("bias_leaky_relu_backward");
+}
+
+FN2_API int fn2_conv_backward_bias(const float* top_diff, int diff_channels, int diff_c0, float* bias_diff, int N, int C, int H, int W,
+                                   int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0) return fail(FN2_ERR_INVALID_ARG, "conv_backward_bias: bad shape [%d,%d,%d,%d]", N, C, H, W);
+  if (diff_c0 < 0 || diff_c0 + C > diff_channels) return fail(FN2_ERR_INVALID_ARG, "conv_backward_bias: top_diff slice outside its blob");
+  if (N == 0) return FN2_OK;
+  if (!top_diff || !bias_diff) return fail(FN2_ERR_INVALID_ARG, "conv_backward_bias: null blob");
+  const long long planes = (long long)N * C, hw = (long long)H * W;
+  if (planes > 65535 || hw >= (1ll << 32)) return fail(FN2_ERR_UNSUPPORTED, "conv_backward_bias: blob too large");
+  const size_t need = fn2_bias_leaky_relu_backward_workspace_bytes(N, C, H, W);
+  if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "conv_backward_bias: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(bias_leaky_relu_bwd<false>, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, nullptr, top_diff, nullptr, partial,
+                     (unsigned)hw, 1.0f, C, diff_channels, diff_c0);
+  hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks, accumulate);
+  return check_launch("conv_backward_bias");
 }
 
 FN2_API int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, float* bottom_diff, float* bias_diff,

@@ -15,6 +15,7 @@
 // flow_warp_layer.hpp, l1_loss_layer.hpp, channel_norm_layer.hpp, downsample_layer.hpp,
 // src/caffe/layers/resample_layer.hpp) so that the class is recognisable; the bodies are new.
 // Only Dtype = float is instantiated: the C ABI is fp32 (the reference's tools use float, tools/caffe.cpp:203).
+#include <algorithm>
 #include <cmath>
 #include <type_traits>
 #include <vector>
@@ -456,8 +457,19 @@ class Fn2ConvolutionLayer : public Layer<Dtype> {
                  << ", pad " << pad_ << "} " << channels_ << " -> " << num_output_ << " on " << desc_.Hin << " x " << desc_.Win << "; keep the stock layer for it";
     top[0]->Reshape(desc_.N, num_output_, oh, ow);
     const size_t pf = transposed_ ? fn2_deconv_packed_weight_floats(&desc_, route_) : fn2_conv_packed_weight_floats(&desc_, route_);
-    const size_t wb = transposed_ ? fn2_deconv_workspace_bytes(&desc_, route_) : fn2_conv_workspace_bytes(&desc_, route_);
+    size_t wb = transposed_ ? fn2_deconv_workspace_bytes(&desc_, route_) : fn2_conv_workspace_bytes(&desc_, route_);
     packed_.Reshape(vector<int>{(int)pf});
+    // backward: the library's own routes (csrc/conv_route.cpp); one scratch blob serves every call of the layer (they run in stream order)
+    bwd_route_ = fn2_conv_backward_data_route(&desc_, transposed_);
+    bwd_weights_ = fn2_conv_backward_weights_supported(&desc_, transposed_) != 0;
+    const int tr = transposed_ ? 1 : 0;
+    wb = std::max(wb, fn2_bias_leaky_relu_backward_workspace_bytes(desc_.N, num_output_, oh, ow));
+    wb = std::max(wb, fn2_conv_backward_weights_workspace_bytes(&desc_, tr));
+    if (bwd_route_ != FN2_BWD_ROUTE_NONE) {
+      wb = std::max(wb, fn2_conv_backward_data_workspace_bytes(&desc_, tr, bwd_route_));
+      wb = std::max(wb, fn2_conv_backward_data_pack_workspace_bytes(&desc_, tr, bwd_route_));
+      packed_bwd_.Reshape(vector<int>{(int)fn2_conv_backward_data_packed_weight_floats(&desc_, tr, bwd_route_)});
+    }
     workspace_.Reshape(vector<int>{(int)((wb + 3) / 4) + 4});
   }
   virtual inline const char* type() const { return transposed_ ? "Deconvolution" : "Convolution"; }
@@ -483,13 +495,35 @@ class Fn2ConvolutionLayer : public Layer<Dtype> {
                                 0, 0.f, ws, wsb, kStream));
     }
   }
-  virtual void Backward_gpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) {
-    LOG(FATAL) << type() << " plug-in: forward only -- train through the stock layer's Backward_gpu (INTEGRATION.md)";
+  // conv_layer.cu:26-60 / deconv_layer.cu:27-58: bias_diff += sum of top_diff (backward_gpu_bias), weight_diff += ... (weight_gpu_gemm, beta = 1:
+  // the solver clears the parameter diffs once per iteration), bottom_diff = ... (backward_gpu_gemm / forward_gpu_gemm: overwritten)
+  virtual void Backward_gpu(const vector<Blob<Dtype>*>& top, const vector<bool>& propagate_down, const vector<Blob<Dtype>*>& bottom) {
+    const int tr = transposed_ ? 1 : 0;
+    const float* td = f32(top[0]->gpu_diff());
+    void* ws = workspace_.mutable_gpu_data();
+    const size_t wsb = sizeof(Dtype) * (size_t)workspace_.count();
+    if (bias_term_ && this->param_propagate_down_[1])
+      FN2_CALL(fn2_conv_backward_bias(td, num_output_, 0, f32(this->blobs_[1]->mutable_gpu_diff()), desc_.N, num_output_, top[0]->height(), top[0]->width(),
+                                      1, ws, wsb, kStream));
+    if (this->param_propagate_down_[0]) {
+      if (!bwd_weights_)
+        LOG(FATAL) << this->layer_param_.name() << ": libflownet2_hip has no weight-gradient kernel for this " << type() << "; keep the stock layer for it";
+      FN2_CALL(fn2_conv_backward_weights(&desc_, tr, f32(bottom[0]->gpu_data()), channels_, 0, td, num_output_, 0, f32(this->blobs_[0]->mutable_gpu_diff()),
+                                         1, ws, wsb, kStream));
+    }
+    if (propagate_down[0]) {
+      if (bwd_route_ == FN2_BWD_ROUTE_NONE)
+        LOG(FATAL) << this->layer_param_.name() << ": libflownet2_hip has no data-gradient kernel for this " << type() << "; keep the stock layer for it";
+      float* pk = f32(packed_bwd_.mutable_gpu_data());
+      FN2_CALL(fn2_conv_backward_data_pack_weights(&desc_, tr, bwd_route_, f32(this->blobs_[0]->gpu_data()), pk, ws, wsb, kStream));
+      // bottom_room = channels_: a Caffe blob has no room for the channel groups the kernels round up to (the result goes through the scratch)
+      FN2_CALL(fn2_conv_backward_data(&desc_, tr, bwd_route_, td, num_output_, 0, pk, f32(bottom[0]->mutable_gpu_diff()), channels_, 0, channels_, ws, wsb, kStream));
+    }
   }
-  bool transposed_, bias_term_ = true;
-  int kernel_ = 0, stride_ = 1, pad_ = 0, num_output_ = 0, channels_ = 0, route_ = 0;
+  bool transposed_, bias_term_ = true, bwd_weights_ = false;
+  int kernel_ = 0, stride_ = 1, pad_ = 0, num_output_ = 0, channels_ = 0, route_ = 0, bwd_route_ = 0;
   fn2_conv_desc desc_;
-  Blob<Dtype> packed_, workspace_;
+  Blob<Dtype> packed_, packed_bwd_, workspace_;
 };
 template <typename Dtype> shared_ptr<Layer<Dtype> > Creator_Fn2Convolution(const LayerParameter& p) { return shared_ptr<Layer<Dtype> >(new Fn2ConvolutionLayer<Dtype>(p, false)); }
 template <typename Dtype> shared_ptr<Layer<Dtype> > Creator_Fn2Deconvolution(const LayerParameter& p) { return shared_ptr<Layer<Dtype> >(new Fn2ConvolutionLayer<Dtype>(p, true)); }

@@ -571,7 +571,8 @@ static bool build_plan(int N, int H, int W, int policy, Plan& pl) {
   return true;
 }
 
-static const Plan& plan_for(int N, int H, int W, int policy) {
+// Returned BY VALUE under the lock (3 KB): the cache may evict an entry while another host thread still launches with it.
+static Plan plan_for(int N, int H, int W, int policy) {
   static std::mutex mu;
   static std::vector<Plan*> cache;
   std::lock_guard<std::mutex> lock(mu);
@@ -602,7 +603,7 @@ bool corr_fwd_units_supported(const CorrGeom& g, const float* b0, const float* b
 
 // test hook: the plan of a geometry as raw 32-bit words (tests/test_corr_units_plan.py walks it on the CPU: every output element written exactly once)
 int corr_fwd_units_plan_words(int N, int H, int W, int policy, unsigned* out, int max_words) {
-  const cu3::Plan& pl = cu3::plan_for(N, H, W, policy);
+  const cu3::Plan pl = cu3::plan_for(N, H, W, policy);
   if (!pl.ok) return 0;
   const int nw = (int)(sizeof(cu3::Args) / 4);
   if (out && max_words >= nw + 1) { std::memcpy(out, &pl.a, sizeof(cu3::Args)); out[nw] = pl.grid; }
@@ -610,7 +611,7 @@ int corr_fwd_units_plan_words(int N, int H, int W, int policy, unsigned* out, in
 }
 
 int corr_fwd_units_launch(const CorrGeom& cg, const float* b0, const float* b1, float* top, hipStream_t st) {
-  const cu3::Plan& pl = cu3::plan_for(cg.N, cg.H, cg.W, g_corr_units - 1);
+  const cu3::Plan pl = cu3::plan_for(cg.N, cg.H, cg.W, g_corr_units - 1);
   if (!pl.ok) return fail(FN2_ERR_UNSUPPORTED, "correlation: no unit plan for %d x %d x %d", cg.N, cg.H, cg.W);
   cu3::Args a = pl.a;
   a.C = cg.C; a.ctot = cg.top_ctot; a.c0 = cg.top_c0; a.relu = cg.relu; a.slope = cg.slope;

@@ -463,29 +463,46 @@ class _OwnForwardConv(torch.autograd.Function):
         return gx, gw, db, None, None, None, None, None, None
 
 
+def _layer_desc(w, stride, pad, transposed, x_shape=None, d_shape=None):
+    """fn2_conv_desc of the layer that owns weight blob w ([Cout, Cin, k, k]; Deconvolution: [Cin, Cout, k, k]) from its bottom shape, or --
+    where that is unambiguous (stride 1; Deconvolution{4, 2, 1}) -- from the shape of its top_diff."""
+    k = int(w.shape[2])
+    if w.shape[3] != k:
+        return None
+    Cin, Cout = (int(w.shape[0]), int(w.shape[1])) if transposed else (int(w.shape[1]), int(w.shape[0]))
+    if x_shape is not None:
+        N, H, W = int(x_shape[0]), int(x_shape[2]), int(x_shape[3])
+    elif transposed and d_shape[2] % 2 == 0 and d_shape[3] % 2 == 0:
+        N, H, W = int(d_shape[0]), int(d_shape[2]) // 2, int(d_shape[3]) // 2
+    elif not transposed and stride == 1:
+        N, H, W = int(d_shape[0]), int(d_shape[2]) - 1 + k - 2 * pad, int(d_shape[3]) - 1 + k - 2 * pad
+    else:
+        return None
+    if H < 1 or W < 1:
+        return None
+    return ops.conv_desc(N, Cin, H, W, Cout, k, stride, pad)
+
+
 def _own_bwd_weight(d, x, w, stride, pad, transposed):
     """weight_diff of a Convolution (ConvolutionLayer::Backward_gpu -> weight_gpu_gemm, conv_layer.cu:40-52) or Deconvolution
-    (deconv_layer.cu:36-50, the roles of the two blobs swapped) on the own fp32 MFMA kernel (csrc/conv_wgrad.hip): NCHW in, weight
-    layout out, no layout transposes, deterministic.  Returns None when the kernel does
-    not apply (tap classes 1/1, 3/1, 3/2, 4/2, 5/2; layers with fewer than 16 output channels -- the 2-channel flow heads -- stay
-    with the library: a 16-wide MFMA tile would be 8x padding)."""
+    (deconv_layer.cu:36-50, the roles of the two blobs swapped) on the own fp32 MFMA kernels: NCHW in, weight layout out, no layout
+    transposes, deterministic.  Which kernel (the stem's taps-on-N kernel, csrc/conv_stem_wgrad.hip, or csrc/conv_wgrad.hip) is the library's
+    decision (fn2_conv_backward_weights, csrc/conv_route.cpp -- the Caffe adapter's Backward_gpu calls the same function).  Returns None when
+    no own kernel applies (tap classes 1/1, 3/1, 3/2, 4/2, 5/2 and the stem; layers with fewer than 16 channels on either side -- the
+    2-channel flow heads -- have kernels of their own)."""
     if not d.is_cuda:
         return None
-    k = w.shape[2]
-    if (not transposed and k == 7 and w.shape[3] == 7 and stride == 2 and pad == 3 and d.is_contiguous() and x.is_contiguous()
-            and ops.conv_k7s2_wgrad_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], w.shape[0])):
-        return ops.conv_k7s2_wgrad(d, x)             # the stem: taps, not bottom channels, on the GEMM's N axis (csrc/conv_stem_wgrad.hip)
-    a, b = (x, d) if transposed else (d, x)          # `a`: the map at the convolution's OUTPUT resolution
-    if w.shape[3] != k or min(a.shape[1], b.shape[1]) < 16:
+    desc = _layer_desc(w, stride, pad, transposed, x_shape=x.shape)
+    if desc is None or not ops.conv_backward_weights_supported(desc, transposed):
         return None
-    if not ops.conv_wgrad_supported(a.shape[0], a.shape[1], a.shape[2], a.shape[3], b.shape[1], b.shape[2], b.shape[3], k, stride, pad):
-        return None
-    ab, a0 = _channel_slice(a)
-    bb, b0 = _channel_slice(b)
-    return ops.conv_wgrad(ab, bb, k, stride, pad, a_c0=a0, Ca=a.shape[1], b_c0=b0, Cb=b.shape[1])
+    if (not transposed and desc.kernel == 7) and not (d.is_contiguous() and x.is_contiguous()):
+        d, x = d.contiguous(), x.contiguous()           # the stem kernel reads whole blobs
+    xb, x0 = _channel_slice(x)
+    db, d0 = _channel_slice(d)
+    return ops.conv_backward_weights(xb, db, desc, transposed, bottom_c0=x0, top_c0=d0)
 
 
-_PACKED_T = {}     # tconv / deconv-data-gradient packings, keyed like _PACKED
+_PACKED_T = {}     # data-gradient packings and the deconvolution GEMM operand, keyed like _PACKED
 
 
 def _cached_pack(cache, w, tag, make):
@@ -494,78 +511,23 @@ def _cached_pack(cache, w, tag, make):
 
 def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
     """bottom_diff on the own kernels (ConvolutionLayer::Backward_gpu, conv_layer.cu:53-57: backward_gpu_gemm = weight^T x top_diff +
-    col2im; DeconvolutionLayer::Backward_gpu, deconv_layer.cu:52-56: forward_gpu_gemm of top_diff):
-      * Convolution 3x3 / stride 1 / pad 1: the same convolution of top_diff with the weights rotated by 180 degrees and their channel
-        axes swapped -- the Winograd kernel (csrc/conv_wino.hip) on a repacked weight, output channels padded to a multiple of 16;
-      * Convolution 5x5 / 2 / 2 and 3x3 / 2 / 1: the transposed convolution of top_diff with the weight blob as it is (csrc/tconv_mfma.hip);
-      * Deconvolution 4x4 / 2 / 1: the 4x4 / 2 / 1 CONVOLUTION of top_diff with the weight blob as it is (csrc/conv_mfma.hip), output
-        channels padded to a multiple of 64.
-    Returns None when no own kernel applies."""
+    col2im; DeconvolutionLayer::Backward_gpu, deconv_layer.cu:52-56: forward_gpu_gemm of top_diff).  The kernel is the library's choice
+    (fn2_conv_backward_data_route, csrc/conv_route.cpp: Winograd on the rotated weights for 3x3 / 1, the transposed-convolution kernel for the
+    stride-2 layers, the 4x4 / 2 convolution for a Deconvolution, the small-map kernels on 10x14 / 5x7 maps, the 1x1 kernel on the transposed
+    weight); its operand is packed once per weight version.  Returns None when no own kernel applies."""
     if not d.is_cuda:
         return None
-    k, k2 = w.shape[2], w.shape[3]
-    if k != k2:
+    desc = _layer_desc(w, stride, pad, transposed, x_shape=x_shape, d_shape=d.shape)
+    if desc is None:
         return None
-    if transposed:
-        Cin, Cout = w.shape[0], w.shape[1]                       # the layer's bottom / top channels
-        if not (k == 4 and stride == 2 and pad == 1) or Cout % 4 != 0:
-            return None
-        Cp = (Cin + 63) // 64 * 64
-
-        def make():                 # the blob as it is, as a [Cp][Cout][4][4] Convolution operand (channels beyond Cin: zero)
-            return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cp, Cout, 4, Cin, Cout, Cout * 16, 16)
-        if ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
-            gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 4, 2, 1, False, 0.0)
-        elif Cout % 8 == 0 and ops.conv_plane_k_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cp, 4, 2, 1):
-            # small maps whose width is not a multiple of 4 (deconv5: top_diff 10x14 -> bottom_diff 5x7): the small-map kernel with 4x4 taps
-            gx = ops.conv_plane_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "deconv-dgrad", make), None, Cp, 2, 1, relu=False, kernel=4)
-        else:
-            return None
-        return gx[:, :Cin] if Cp != Cin else gx
-    Cout, Cin = w.shape[0], w.shape[1]
-    if stride == 2 and (k, pad) in ((5, 2), (3, 1)) and x_shape is not None and Cin % 64 == 0:
-        H, W = int(x_shape[2]), int(x_shape[3])
-        if ops.tconv_supported(Cout, d.shape[2], d.shape[3], Cin, H, W, k, pad):
-            pw = _cached_pack(_PACKED_T, w, "tconv", lambda: ops.tconv_pack_weights(w.detach()))
-            return ops.tconv_forward(d.contiguous(), pw, None, Cin, k, pad, out_hw=(H, W))
-        if k == 3 and (H, W) == (2 * d.shape[2], 2 * d.shape[3]) and ops.deconv_plane_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cin):
-            # small maps whose width is not a multiple of 4 (conv5, conv6: top_diff 10x14 / 5x7): the transposed 3x3 / 2 / 1 convolution IS the
-            # Deconvolution{4, 2, 1} whose fourth tap row and column are zero (Y = 2 y - 1 + ky in both) -- the small-map deconvolution kernel
-            # on the weight blob padded to 4x4 (16 taps computed for 9: these layers are 1-2 % of a training step)
-            pw = _cached_pack(_PACKED_T, w, "tconv-plane", lambda: ops.deconv_plane_pack_weights(w.detach().contiguous()))     # (3x3 -> zero taps: in the kernel)
-            return ops.deconv_plane_forward(d.contiguous(), pw, None, Cin, relu=False)
+    route = ops.conv_backward_data_route(desc, transposed)
+    if route == 0:
         return None
-    if k == 1 and stride == 1 and pad == 0:
-        # 1x1 (conv_redir): bottom_diff = W^T x top_diff, the 1x1 / GEMM form of conv_mfma on the transposed weight
-        Cp = (Cin + 31) // 32 * 32
-        if not ops.conv_mfma_supported(Cout, d.shape[2], d.shape[3], Cp, 1, 1, 0):
-            return None
-
-        def make_1x1():             # [Cp][Cout][1][1]: the blob with its channel axes swapped, output channels zero-padded
-            return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cp, Cout, 1, Cin, Cout, 1, Cin)
-        gx = ops.conv_mfma_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "1x1-dgrad", make_1x1), None, Cp, 1, 1, 0, False, 0.0)
-        return gx[:, :Cin] if Cp != Cin else gx
-    if k != 3 or stride != 1 or pad != 1:
-        return None
-    Cp = (Cin + 15) // 16 * 16
-    if not ops.conv_wino_supported(Cout, d.shape[2], d.shape[3], Cp, 1):
-        # maps the Winograd kernel does not take (10x14, 5x7: conv5_1, conv6_1): the small-map kernel on the same rotated weights
-        Cq = (Cin + 63) // 64 * 64
-        if Cout % 8 != 0 or not ops.conv_plane_supported(d.shape[0], Cout, d.shape[2], d.shape[3], Cq, 1, 1):
-            return None
-
-        def make_plane():           # [Cq][Cout][3][3]: rotated by 180 degrees, channel axes swapped, output channels zero-padded
-            return ops.conv_mfma_pack_weights_view(w.detach().contiguous(), Cq, Cout, 3, Cin, Cout, 9, Cin * 9, flip=True)
-        gx = ops.conv_plane_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "plane-dgrad", make_plane), None, Cq, 1, 1, False, 0.0)
-        return gx[:, :Cin] if Cq != Cin else gx
-
-    def make_wino():
-        wt = w.detach().flip(2, 3).transpose(0, 1)                  # [Cin, Cout, 3, 3]: rot180, channel axes swapped
-        if Cp != Cin:
-            wt = torch.cat([wt, wt.new_zeros((Cp - Cin, Cout, 3, 3))], 0)
-        return ops.conv_wino_pack_weights(wt.contiguous())
-    gx = ops.conv_wino_forward(d.contiguous(), _cached_pack(_PACKED_T, w, "wino-dgrad", make_wino), None, Cp, 1, False, 0.0)
-    return gx[:, :Cin] if Cp != Cin else gx
+    key = (desc.N, desc.Hin, desc.Win)       # the route (and with it the operand's layout) is a function of the layer geometry
+    packed = _cached_pack(_PACKED_T, w, ("dgrad", route, bool(transposed), stride, pad) + key,
+                          lambda: ops.conv_backward_data_pack_weights(w.detach().contiguous(), desc, transposed, route))
+    db, d0 = _channel_slice(d)
+    return ops.conv_backward_data(db, packed, desc, transposed, route, top_c0=d0)
 
 
 def _needs_grad(*ts):

@@ -486,6 +486,87 @@ def deconv_route(N, Cin, Hin, Win, Cout, kernel=4, stride=2, pad=1):
     return DECONV_ROUTES[int(_lib.lib().fn2_deconv_route(C.byref(d), 0))]
 
 
+BWD_ROUTES = {0: None, 1: "wino", 2: "tconv", 3: "plane", 4: "direct", 5: "deconv_plane"}
+
+
+def conv_desc(N, Cin, Hin, Win, Cout, kernel, stride, pad):
+    """fn2_conv_desc: bottom [N, Cin, Hin, Win] of a Convolution{kernel, stride, pad} (Cin -> Cout) or of a Deconvolution{4, 2, 1}."""
+    return _lib.ConvDesc(int(N), int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad))
+
+
+def conv_backward_data_route(desc, transposed=False) -> int:
+    """Which own kernel computes bottom_diff of this layer (fn2_conv_backward_data_route; 0 = none, names: BWD_ROUTES)."""
+    return int(_lib.lib().fn2_conv_backward_data_route(C.byref(desc), int(bool(transposed))))
+
+
+def conv_backward_data_pack_weights(weight, desc, transposed, route):
+    """The layer's weight blob ([Cout, Cin, k, k]; Deconvolution: [Cin, Cout, 4, 4]) -> the operand its data-gradient kernel reads."""
+    w = _chk(weight, "weight")
+    L, tr = _lib.lib(), int(bool(transposed))
+    n = int(L.fn2_conv_backward_data_packed_weight_floats(C.byref(desc), tr, int(route)))
+    if n == 0:
+        raise ValueError("conv_backward_data_pack_weights: route %d is not this layer's" % route)
+    packed = torch.empty(n, device=w.device, dtype=torch.float32)
+    need = int(L.fn2_conv_backward_data_pack_workspace_bytes(C.byref(desc), tr, int(route)))
+    ws = torch.empty(need // 4, device=w.device, dtype=torch.float32) if need else None
+    check(L.fn2_conv_backward_data_pack_weights(C.byref(desc), tr, int(route), _ptr(w), _ptr(packed), _ptr(ws), need, _stream()))
+    return packed
+
+
+def conv_backward_data(top_diff, packed_weight, desc, transposed, route, top_c0=0):
+    """bottom_diff [N, Cin, Hin, Win] of the layer from top_diff (a blob, the layer's channels starting at top_c0).  The kernels compute
+    channels in groups: the result is the leading-channel VIEW of a blob that has room for them (no copy)."""
+    d = _chk(top_diff, "top_diff")
+    L, tr = _lib.lib(), int(bool(transposed))
+    Cp = int(L.fn2_conv_backward_data_computed_channels(C.byref(desc), tr, int(route)))
+    if Cp == 0:
+        raise ValueError("conv_backward_data: route %d is not this layer's" % route)
+    out = torch.empty((desc.N, Cp, desc.Hin, desc.Win), device=d.device, dtype=torch.float32)
+    need = int(L.fn2_conv_backward_data_workspace_bytes(C.byref(desc), tr, int(route)))
+    ws = _plane_workspace(d.device, need) if need else None
+    check(L.fn2_conv_backward_data(C.byref(desc), tr, int(route), _ptr(d), d.shape[1], int(top_c0), _ptr(packed_weight), _ptr(out), Cp, 0, Cp,
+                                   _ptr(ws), need, _stream()))
+    return out[:, :desc.Cin] if Cp != desc.Cin else out
+
+
+def conv_backward_weights_supported(desc, transposed=False) -> bool:
+    return bool(_lib.lib().fn2_conv_backward_weights_supported(C.byref(desc), int(bool(transposed))))
+
+
+def conv_backward_weights(bottom, top_diff, desc, transposed=False, out=None, accumulate=False, bottom_c0=0, top_c0=0):
+    """weight_diff of the layer ([Cout, Cin, k, k]; Deconvolution: [Cin, Cout, 4, 4]) (+)= ... (fn2_conv_backward_weights: the stem kernel or
+    csrc/conv_wgrad.hip, deterministic)."""
+    x, d = _chk(bottom, "bottom"), _chk(top_diff, "top_diff")
+    L, tr = _lib.lib(), int(bool(transposed))
+    k = desc.kernel
+    shape = (desc.Cin, desc.Cout, k, k) if transposed else (desc.Cout, desc.Cin, k, k)
+    if out is None:
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+        accumulate = False
+    else:
+        out = _chk(out, "weight diff")
+        if tuple(out.shape) != shape:
+            raise ValueError("conv_backward_weights: weight diff has the wrong shape")
+    need = int(L.fn2_conv_backward_weights_workspace_bytes(C.byref(desc), tr))
+    ws = _plane_workspace(x.device, need) if need else None
+    check(L.fn2_conv_backward_weights(C.byref(desc), tr, _ptr(x), x.shape[1], int(bottom_c0), _ptr(d), d.shape[1], int(top_c0), _ptr(out),
+                                      int(bool(accumulate)), _ptr(ws), need, _stream()))
+    return out
+
+
+def conv_backward_bias(top_diff, C_, top_c0=0, out=None, accumulate=False):
+    """bias_diff[c] (+)= sum over n, y, x of top_diff[n, top_c0 + c] (backward_gpu_bias, base_conv_layer.cpp:389-393), fixed order."""
+    d = _chk(top_diff, "top_diff")
+    N, Ctot, H, W = d.shape
+    if out is None:
+        out = torch.empty(C_, device=d.device, dtype=torch.float32)
+        accumulate = False
+    need = int(_lib.lib().fn2_bias_leaky_relu_backward_workspace_bytes(N, C_, H, W))
+    ws = _plane_workspace(d.device, need)
+    check(_lib.lib().fn2_conv_backward_bias(_ptr(d), Ctot, int(top_c0), _ptr(out), N, int(C_), H, W, int(bool(accumulate)), _ptr(ws), need, _stream()))
+    return out
+
+
 def conv_mfma_supported(Cin, Hin, Win, Cout, kernel, stride, pad) -> bool:
     return bool(_lib.lib().fn2_conv_mfma_supported(int(Cin), int(Hin), int(Win), int(Cout), int(kernel), int(stride), int(pad)))
 

@@ -501,6 +501,46 @@ int fn2_deconv_forward(const fn2_conv_desc* desc, int route, const float* bottom
                        const float* packed_weight, const float* bias, float* top, int top_channels, int top_c0,
                        int relu, float negative_slope, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward by descriptor (round 5).  `transposed` = 0: a Convolution (desc as for fn2_conv_route), 1: a Deconvolution{4, 2, 1} (desc as for
+ * fn2_deconv_route: Cin = bottom channels, Cout = top channels, top_diff is [N, Cout, 2 Hin, 2 Win]).  No activation inside: the ReLU of the
+ * FlowNet graphs is undone first (fn2_bias_leaky_relu_backward, which also reduces the bias gradient), as ReLULayer::Backward_gpu does in Caffe.
+ *   data gradient   <- ConvolutionLayer::Backward_gpu -> backward_gpu_gemm (weight^T x top_diff + col2im), conv_layer.cu:53-57,
+ *                      base_conv_layer.cpp:352-366; DeconvolutionLayer::Backward_gpu -> forward_gpu_gemm of top_diff, deconv_layer.cu:52-56.
+ *     fn2_conv_backward_data_route(): WINOGRAD (3x3 / 1 / 1: the forward Winograd kernel on the 180-degree-rotated, channel-swapped weights),
+ *     TCONV (5x5 / 2 / 2 and 3x3 / 2 / 1: stride-2 transposed convolution, csrc/tconv_mfma.hip), DECONV_PLANE (3x3 / 2 / 1 on maps whose width is
+ *     no multiple of 4: the small-map deconvolution kernel on the blob read as 4x4 with zero taps), PLANE (3x3 / 1 / 1 on maps the Winograd
+ *     kernel does not take; Deconvolution on small maps: the small-map kernel with 4x4 / 2 taps), DIRECT (1x1 on the transposed weight;
+ *     Deconvolution: its gradient IS the 4x4 / 2 / 1 convolution of top_diff), NONE.  The operand is packed per route
+ *     (fn2_conv_backward_data_pack_weights; the WINOGRAD route needs fn2_conv_backward_data_pack_workspace_bytes() of scratch for the rotated
+ *     blob).  bottom_diff is OVERWRITTEN (Caffe: col2im writes the blob).  The kernels compute channels in groups (16 / 32 / 64):
+ *     fn2_conv_backward_data_computed_channels() >= Cin of them, the surplus being zeros.  `bottom_room` = how many channels from bottom_c0 on
+ *     the call may overwrite: with room for the computed channels the kernel writes bottom_diff directly, otherwise (bottom_room = Cin: a
+ *     Caffe blob) the result goes through the workspace and its first Cin channels are copied (fn2_conv_backward_data_workspace_bytes covers
+ *     that and the K-split slabs).
+ *   weight gradient <- weight_gpu_gemm, conv_layer.cu:40-52 / deconv_layer.cu:36-50, base_conv_layer.cpp:368-384 (beta = 1: accumulate != 0
+ *     adds into weight_diff): fn2_conv_wgrad (every FlowNet class) or, for the 3-channel 7x7 / 2 stem, fn2_conv_k7s2_wgrad (contiguous blobs).
+ *   bias gradient   <- backward_gpu_bias, base_conv_layer.cpp:389-393 (beta = 1): fn2_conv_backward_bias; workspace
+ *     fn2_bias_leaky_relu_backward_workspace_bytes(N, C, H, W). */
+enum { FN2_BWD_ROUTE_NONE = 0, FN2_BWD_ROUTE_WINOGRAD = 1, FN2_BWD_ROUTE_TCONV = 2, FN2_BWD_ROUTE_PLANE = 3, FN2_BWD_ROUTE_DIRECT = 4,
+       FN2_BWD_ROUTE_DECONV_PLANE = 5 };
+int fn2_conv_backward_data_route(const fn2_conv_desc* desc, int transposed);
+size_t fn2_conv_backward_data_packed_weight_floats(const fn2_conv_desc* desc, int transposed, int route);
+size_t fn2_conv_backward_data_pack_workspace_bytes(const fn2_conv_desc* desc, int transposed, int route);
+int fn2_conv_backward_data_pack_weights(const fn2_conv_desc* desc, int transposed, int route, const float* weight, float* packed,
+                                        void* workspace, size_t workspace_bytes, void* stream);
+size_t fn2_conv_backward_data_workspace_bytes(const fn2_conv_desc* desc, int transposed, int route);
+int fn2_conv_backward_data_computed_channels(const fn2_conv_desc* desc, int transposed, int route);
+int fn2_conv_backward_data(const fn2_conv_desc* desc, int transposed, int route, const float* top_diff, int top_channels, int top_c0,
+                           const float* packed_weight, float* bottom_diff, int bottom_channels, int bottom_c0, int bottom_room,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int fn2_conv_backward_weights_supported(const fn2_conv_desc* desc, int transposed);
+size_t fn2_conv_backward_weights_workspace_bytes(const fn2_conv_desc* desc, int transposed);
+int fn2_conv_backward_weights(const fn2_conv_desc* desc, int transposed, const float* bottom, int bottom_channels, int bottom_c0,
+                              const float* top_diff, int top_channels, int top_c0, float* weight_diff, int accumulate,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int fn2_conv_backward_bias(const float* top_diff, int diff_channels, int diff_c0, float* bias_diff, int N, int C, int H, int W,
+                           int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Transposed convolution, stride 2 (fp32 MFMA, NCHW, no column matrix / col2im):
  *     top[n][top_c0 + co][Y][X] = act(bias[co] + sum_{ci,ky,kx: Y = 2y - pad + ky, X = 2x - pad + kx} bottom[n][bottom_c0 + ci][y][x] * W[ci][co][ky][kx])

@@ -1546,6 +1546,23 @@ FN2_API int fn2_bias_leaky_relu_backward_cpu(const float* top_data, const float*
   return FN2_OK;
 }
 
+/* Bias gradient alone: backward_cpu_bias (base_conv_layer.cpp:319-323: bias_diff += top_diff summed over the positions of every sample,
+ * the GEMV's beta = 1); top_diff may be a channel slice of a wider blob. */
+FN2_API int fn2_conv_backward_bias_cpu(const float* top_diff, int diff_channels, int diff_c0, float* bias_diff, int N, int C, int H, int W,
+                                       int accumulate) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || diff_c0 < 0 || diff_c0 + C > diff_channels) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  for (int c = 0; c < C; ++c) {
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) {
+      const size_t base = ((size_t)n * diff_channels + diff_c0 + c) * hw;
+      for (size_t i = 0; i < hw; ++i) acc += top_diff[base + i];
+    }
+    bias_diff[c] = accumulate ? bias_diff[c] + (float)acc : (float)acc;
+  }
+  return FN2_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * CustomData sample format.
  *   Datum: src/caffe/proto/caffe.proto:30-41, encoded by libprotobuf (third-party, version unpinned by the reference's

@@ -181,6 +181,26 @@ def convolution_by_registry(x, weight, bias=None, kernel=3, stride=1, pad=1, dec
     return out
 
 
+def convolution_backward(x, weight, bias, top_diff, weight_diff0=None, bias_diff0=None, kernel=3, stride=1, pad=1, deconv=False, by_registry=False):
+    """Forward + Backward of the reference's stock Convolution / Deconvolution (by_registry: of whatever LayerRegistry creates for the type
+    string -- the adapter's plug-ins after use("adapter")).  The parameter diffs start from weight_diff0 / bias_diff0 (the reference
+    accumulates into them).  Returns (bottom_diff, weight_diff, bias_diff or None)."""
+    x, weight, top_diff = _f(x), _f(weight), _f(top_diff)
+    bias = _f(bias) if bias is not None else None
+    N, Cc, H, W = x.shape
+    num_output = weight.shape[1] if deconv else weight.shape[0]
+    wd0 = _f(weight_diff0) if weight_diff0 is not None else np.zeros_like(weight)
+    bd0 = (_f(bias_diff0) if bias_diff0 is not None else np.zeros_like(bias)) if bias is not None else None
+    dx, dw = np.empty_like(x), np.empty_like(weight)
+    db = np.empty_like(bias) if bias is not None else None
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    fn = L.fn2ref_convolution_backward_by_registry if by_registry else L.fn2ref_convolution_backward
+    fn.argtypes = [C.c_int] * 5 + [fp, C.c_int, C.c_int, C.c_int, C.c_int] + [fp] * 8
+    _chk(fn(int(deconv), kernel, stride, pad, num_output, _p(x), N, Cc, H, W, _p(weight), _p(bias), _p(top_diff), _p(wd0), _p(bd0), _p(dx), _p(dw), _p(db)))
+    return dx, dw, db
+
+
 def custom_data(records, batch_size, slice_points=(), encodings=(), scale=1.0, subtract=(), range_start=0, range_end=-1,
                 n_forward=1, with_labels=False):
     """The reference's CustomDataLayer (custom_data_layer.cpp) over an in-memory stand-in for LMDB.  records: list of (key, value

@@ -226,6 +226,36 @@ int fn2ref_downsample(const float* in, int N, int C, int Hin, int Win, int Hout,
   });
 }
 
+
+// Forward + Backward of a Convolution / Deconvolution layer object: the parameter diffs start from the given values (the reference ACCUMULATES
+// into them: weight_gpu_gemm / backward_gpu_bias with beta = 1), bottom_diff is overwritten.
+static void conv_fwd_bwd(Layer<float>& layer, const float* x, int N, int C, int H, int W, const float* weight, const float* bias,
+                         const float* top_diff, const float* weight_diff0, const float* bias_diff0,
+                         float* bottom_diff, float* weight_diff, float* bias_diff) {
+  Blob<float> bot(N, C, H, W), top;
+  fill(bot, x);
+  vector<Blob<float>*> bottom{&bot}, tops{&top};
+  layer.SetUp(bottom, tops);
+  fill(*layer.blobs()[0], weight);
+  fill_diff(*layer.blobs()[0], weight_diff0);
+  if (bias) { fill(*layer.blobs()[1], bias); fill_diff(*layer.blobs()[1], bias_diff0); }
+  layer.Forward(bottom, tops);
+  fill_diff(top, top_diff);
+  layer.Backward(tops, vector<bool>{true}, bottom);
+  CUDA_CHECK(hipDeviceSynchronize());
+  fetch_diff(bot, bottom_diff);
+  fetch_diff(*layer.blobs()[0], weight_diff);
+  if (bias) fetch_diff(*layer.blobs()[1], bias_diff);
+}
+
+static void conv_param(LayerParameter& lp, int kernel, int stride, int pad, int num_output, bool bias) {
+  ConvolutionParameter* cp = lp.mutable_convolution_param();
+  cp->set_num_output(num_output); cp->add_kernel_size(kernel); cp->add_stride(stride); cp->add_pad(pad);
+  cp->set_bias_term(bias);
+  cp->mutable_weight_filler()->set_type("constant");
+  cp->mutable_bias_filler()->set_type("constant");
+}
+
 #ifdef FN2_SHIM_STOCK
 #include "caffe/layers/conv_layer.hpp"
 #include "caffe/layers/deconv_layer.hpp"
@@ -269,6 +299,23 @@ int fn2ref_convolution(int deconv, int kernel, int stride, int pad, int num_outp
 }
 #endif
 
+#ifdef FN2_SHIM_STOCK
+// The reference's ConvolutionLayer / DeconvolutionLayer::Backward_gpu (conv_layer.cu:26-60, deconv_layer.cu:27-58, base_conv_layer.cpp:352-393).
+extern "C" __attribute__((visibility("default")))
+int fn2ref_convolution_backward(int deconv, int kernel, int stride, int pad, int num_output, const float* x, int N, int C, int H, int W,
+                                const float* weight, const float* bias /* nullable */, const float* top_diff, const float* weight_diff0,
+                                const float* bias_diff0, float* bottom_diff, float* weight_diff, float* bias_diff) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    conv_param(lp, kernel, stride, pad, num_output, bias != nullptr);
+    shared_ptr<Layer<float> > layer;
+    if (deconv) layer.reset(new DeconvolutionLayer<float>(lp)); else layer.reset(new ConvolutionLayer<float>(lp));
+    conv_fwd_bwd(*layer, x, N, C, H, W, weight, bias, top_diff, weight_diff0, bias_diff0, bottom_diff, weight_diff, bias_diff);
+  });
+}
+#endif
+
 #ifdef FN2_SHIM_CONV_REGISTRY
 // Convolution / Deconvolution created BY TYPE STRING through LayerRegistry (the adapter build: its plug-ins registered "Convolution" and
 // "Deconvolution"): square kernel, given weights and optional bias.  Same argument list as fn2ref_convolution (relu must be 0).
@@ -299,6 +346,21 @@ int fn2ref_convolution_by_registry(int deconv, int kernel, int stride, int pad, 
     CUDA_CHECK(hipDeviceSynchronize());
     for (int i = 0; i < 4; ++i) out_shape[i] = top.shape(i);
     if (out) fetch(top, out);
+  });
+}
+// The same through LayerRegistry (the adapter's plug-ins): forward + Backward.
+extern "C" __attribute__((visibility("default")))
+int fn2ref_convolution_backward_by_registry(int deconv, int kernel, int stride, int pad, int num_output, const float* x, int N, int C, int H, int W,
+                                            const float* weight, const float* bias /* nullable */, const float* top_diff, const float* weight_diff0,
+                                            const float* bias_diff0, float* bottom_diff, float* weight_diff, float* bias_diff) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    LayerParameter lp;
+    lp.set_name("conv_under_test");
+    lp.set_type(deconv ? "Deconvolution" : "Convolution");
+    conv_param(lp, kernel, stride, pad, num_output, bias != nullptr);
+    shared_ptr<Layer<float> > layer = LayerRegistry<float>::CreateLayer(lp);
+    conv_fwd_bwd(*layer, x, N, C, H, W, weight, bias, top_diff, weight_diff0, bias_diff0, bottom_diff, weight_diff, bias_diff);
   });
 }
 #endif

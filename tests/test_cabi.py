@@ -36,7 +36,7 @@ def test_oracle_exports_cpu_twins():
                 or name.endswith("_batch_invariant") or name.endswith("_sync_bytes"):
             # (tile-variant hooks; ksplit is a launch-geometry query whose value the twins take as an argument)
             continue
-        if name in ("fn2_conv_route", "fn2_deconv_route", "fn2_conv_forward", "fn2_deconv_forward") or name.startswith(("fn2_conv_pack", "fn2_deconv_pack")):
+        if name in ("fn2_conv_route", "fn2_deconv_route", "fn2_conv_forward", "fn2_deconv_forward") or name.startswith(("fn2_conv_pack", "fn2_deconv_pack", "fn2_conv_backward_data", "fn2_conv_backward_weights")):
             # descriptor-level dispatchers (csrc/conv_route.cpp): no arithmetic of their own -- every kernel they route to has its twin
             continue
         assert hasattr(L, name + "_cpu"), name + "_cpu"

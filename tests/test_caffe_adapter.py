@@ -136,6 +136,8 @@ CONV_CASES = [
     (1, 256, 8, 12, 32, 1, 1, 0, False),       # conv_redir: 1x1
     (2, 128, 8, 12, 64, 4, 2, 1, True),        # deconv class: GEMM + col2im
     (2, 128, 5, 7, 64, 4, 2, 1, True),         # deconv5: a 5x7 plane, the parity-class kernel
+    (2, 72, 16, 24, 64, 3, 1, 1, False),       # bottom channels that are no multiple of the kernels' channel groups: the data gradient goes through the scratch
+    (2, 40, 10, 14, 64, 3, 1, 1, False),       # ... on a small map (the small-map kernel's route)
 ]
 
 
@@ -164,3 +166,35 @@ def test_adapter_convolution_plugins_match_the_reference_layers(case):
     scale = max(1.0, float(np.abs(want).max()))
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * scale)
     np.testing.assert_allclose(got_nb, want - b.reshape(1, -1, 1, 1), rtol=0, atol=1e-4 * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_adapter_convolution_plugins_backward_matches_the_reference_layers(case):
+    """Backward_gpu of the same plug-ins (bias, weight and data gradients on the library's own routes: fn2_conv_backward_bias / _weights / _data,
+    csrc/conv_route.cpp) against ConvolutionLayer / DeconvolutionLayer::Backward_gpu of the reference (conv_layer.cu:26-60, deconv_layer.cu:27-58,
+    base_conv_layer.cpp:352-393 compiled in place).  The parameter diffs start from non-zero values: both sides ACCUMULATE into them (beta = 1),
+    bottom_diff is overwritten."""
+    if not (ref.available() and ref.adapter_available()):
+        pytest.skip("reference / adapter libraries not built")
+    N, Cin, H, W, Cout, k, s, p, deconv = case
+    x = rnd((N, Cin, H, W), 21)
+    w = rnd((Cin, Cout, k, k) if deconv else (Cout, Cin, k, k), 22, 0.1)
+    b = rnd((Cout,), 23)
+    Ho, Wo = (s * (H - 1) + k - 2 * p, s * (W - 1) + k - 2 * p) if deconv else ((H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1)
+    g = rnd((N, Cout, Ho, Wo), 24)
+    wd0, bd0 = rnd(w.shape, 25), rnd(b.shape, 26)
+    ref.use("ref")
+    dx, dw, db = ref.convolution_backward(x, w, b, g, wd0, bd0, kernel=k, stride=s, pad=p, deconv=deconv)
+    ref.use("adapter")
+    try:
+        gx, gw, gb = ref.convolution_backward(x, w, b, g, wd0, bd0, kernel=k, stride=s, pad=p, deconv=deconv, by_registry=True)
+    finally:
+        ref.use("ref")
+    # fp32 sums of N Ho Wo (weights, bias) or Cout k k (data) products in different orders: 1e-4 of the result's scale, the tolerance of the
+    # reference's own convolution gradient tests (test_convolution_layer.cpp: 1e-3 relative through the gradient checker)
+    for name, got, want in (("bottom_diff", gx, dx), ("weight_diff", gw, dw), ("bias_diff", gb, db)):
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * scale, err_msg=name)
+    # accumulation really happened on both sides (the start values are O(1), the gradients O(10..1000))
+    assert float(np.abs(dw - wd0).max()) > 1e-2 and float(np.abs(gw - wd0).max()) > 1e-2
