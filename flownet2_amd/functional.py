@@ -438,29 +438,39 @@ class _OwnForwardConv(torch.autograd.Function):
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
         stride, pad, slope, act, has_bias, transposed = ctx.cfg
-        need_b = has_bias and ctx.needs_input_grad[2]
-        if act:
-            # the gradient of a Concat arrives as a channel-slice view of the Concat's top_diff: read in place (no .contiguous() copy)
-            gb, g0 = _channel_slice(g)
-            d, db = ops.bias_leaky_relu_backward(y, (gb, g0, g.shape[1]), slope, need_b)
-        else:
-            g = g.contiguous()
-            d, db = g, (g.sum((0, 2, 3)) if need_b else None)
-        need_x, need_w = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])
-        gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
-        gw = _own_bwd_weight(d, x, w, stride, pad, transposed) if need_w else None
-        lib_x, lib_w = need_x and gx is None, need_w and gw is None
-        if (lib_x or lib_w) and os.environ.get("FN2_TRACE_BWD") == "1":
-            print("bwd on the library: x %s w %s stride %d pad %d transposed %s -> %s%s" % (tuple(x.shape), tuple(w.shape), stride, pad, transposed,
-                                                                                          "data " if lib_x else "", "weight" if lib_w else ""), flush=True)
-        if lib_x or lib_w:
-            if x.is_cuda:       # counted like the forward's last resort: `library_conv_fallbacks: 0` in the bench line covers backward too
-                _note_fallback("%s backward{stride %d, pad %d}%s%s" % ("Deconvolution" if transposed else "Convolution", stride, pad,
-                                                                       " data" if lib_x else "", " weight" if lib_w else ""), x, w)
-            gxl, gwl, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
-                                                              [lib_x, lib_w, False])
-            gx, gw = (gxl if lib_x else gx), (gwl if lib_w else gw)
+        gx, gw, db = conv_backward(x, w, y if act else None, g, stride, pad, slope, transposed, bool(ctx.needs_input_grad[0]),
+                                   bool(ctx.needs_input_grad[1]), has_bias and ctx.needs_input_grad[2])
         return gx, gw, db, None, None, None, None, None, None
+
+
+def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, need_b):
+    """(bottom_diff, weight_diff, bias_diff) of a Convolution / Deconvolution (+ the leaky ReLU folded into it when `y`, the ACTIVATED
+    output, is given) from top_diff g -- ConvolutionLayer / DeconvolutionLayer::Backward_gpu (conv_layer.cu:26-60, deconv_layer.cu:27-58)
+    behind ReLULayer::Backward_gpu (relu_layer.cu:33-60).  One fused pass undoes the activation and reduces the bias gradient
+    (csrc/bias_act.hip, from the saved output), the two convolution gradients run on the library's own routes (fn2_conv_backward_*); a
+    geometry without an own kernel goes to the counted last resort (aten::convolution_backward).  Shared by the autograd function above
+    and by the prototxt executor's Convolution / Deconvolution mirrors (stock_layers.py)."""
+    if y is not None:
+        # the gradient of a Concat arrives as a channel-slice view of the Concat's top_diff: read in place (no .contiguous() copy)
+        gb, g0 = _channel_slice(g)
+        d, db = ops.bias_leaky_relu_backward(y, (gb, g0, g.shape[1]), slope, need_b)
+    else:
+        g = g.contiguous()
+        d, db = g, (g.sum((0, 2, 3)) if need_b else None)
+    gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
+    gw = _own_bwd_weight(d, x, w, stride, pad, transposed) if need_w else None
+    lib_x, lib_w = need_x and gx is None, need_w and gw is None
+    if (lib_x or lib_w) and os.environ.get("FN2_TRACE_BWD") == "1":
+        print("bwd on the library: x %s w %s stride %d pad %d transposed %s -> %s%s" % (tuple(x.shape), tuple(w.shape), stride, pad, transposed,
+                                                                                      "data " if lib_x else "", "weight" if lib_w else ""), flush=True)
+    if lib_x or lib_w:
+        if x.is_cuda:       # counted like the forward's last resort: `library_conv_fallbacks: 0` in the bench line covers backward too
+            _note_fallback("%s backward{stride %d, pad %d}%s%s" % ("Deconvolution" if transposed else "Convolution", stride, pad,
+                                                                   " data" if lib_x else "", " weight" if lib_w else ""), x, w)
+        gxl, gwl, _ = torch.ops.aten.convolution_backward(d, x, w, None, [stride, stride], [pad, pad], [1, 1], transposed, [0, 0], 1,
+                                                          [lib_x, lib_w, False])
+        gx, gw = (gxl if lib_x else gx), (gwl if lib_w else gw)
+    return gx, gw, db
 
 
 def _layer_desc(w, stride, pad, transposed, x_shape=None, d_shape=None):

@@ -158,10 +158,21 @@ class Layer:
         self.layer_param_ = param
         self.loss_: List[float] = []
         self.blobs_: List[Blob] = []          # learnable parameters (layer.hpp:288-291)
+        self.param_propagate_down_: List[bool] = []       # layer.hpp:327-341, set by Net::Init (net.cpp:173-185)
         self.backend_ = None                  # flownet2_amd.functional unless the Net was given another one (stock layers only)
 
     def blobs(self):
         return self.blobs_
+
+    def param_propagate_down(self, param_id: int) -> bool:                 # layer.hpp:327-331
+        return self.param_propagate_down_[param_id] if param_id < len(self.param_propagate_down_) else False
+
+    def set_param_propagate_down(self, param_id: int, value: bool):        # layer.hpp:336-341
+        if len(self.param_propagate_down_) <= param_id:
+            self.param_propagate_down_ += [True] * (param_id + 1 - len(self.param_propagate_down_))
+        self.param_propagate_down_[param_id] = bool(value)
+
+    def AllowForceBackward(self, bottom_index: int) -> bool: return True    # layer.hpp:314-316
 
     # --- interface subclasses implement -------------------------------------------------------
     def LayerSetUp(self, bottom: Sequence[Blob], top: Sequence[Blob]): pass

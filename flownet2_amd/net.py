@@ -11,8 +11,16 @@ runner (scripts/run-flownet.py:64-98), on the layer mirrors of this repository.
                                                     layers ignored; DataAugmentation's mean blobs come the same way
                                                     (data_augmentation_layer.cpp:162-205)
 
-Not reproduced: the automatic Split layers (net.cpp:46 InsertSplits -- only needed for gradient accumulation), backward, solver
-state.  One executor-level optimisation: a ReLU that runs in place on the top of the Convolution / Deconvolution directly in front
+    InsertSplits         util/insert_splits.cpp:12-86 a Split layer behind every top with more than one consumer (a loss weight counts as
+                                                    one) -- for nets built with backward (TRAIN phase by default): the consumers' diffs are
+                                                    summed by SplitLayer::Backward_gpu
+    need-backward flags  net.cpp:95-104,164-256     blob / layer / bottom flags from lr_mult, AllowBackward, propagate_down, the blobs under a
+                                                    loss, force_backward
+    Net::BackwardFromTo  net.cpp:592-602            layers in reverse order, Layer::Backward with the bottom flags
+    ClearParamDiffs / Update  net.cpp:949-967, 929-934   parameter diffs are ACCUMULATED by the layers and cleared per iteration
+
+Not reproduced: the Solver (learning-rate policies, momentum / Adam history, snapshots): `Update()` applies the diffs as they are, a caller
+scales them.  One executor-level optimisation: a ReLU that runs in place on the top of the Convolution / Deconvolution directly in front
 of it is folded into that layer (one fused kernel, as in nets.py); results are unchanged.
 """
 from __future__ import annotations
@@ -48,9 +56,73 @@ def _layer_included(lp: LayerParameter, state: Dict) -> bool:
     return any(_state_meets_rule(state, r) for r in lp.include)
 
 
+def _split_layer_name(layer_name: str, blob_name: str, blob_idx: int) -> str:            # insert_splits.cpp:111-117
+    return "%s_%s_%d_split" % (blob_name, layer_name, blob_idx)
+
+
+def _split_blob_name(layer_name: str, blob_name: str, blob_idx: int, split_idx: int) -> str:   # insert_splits.cpp:119-126
+    return "%s_%s_%d_split_%d" % (blob_name, layer_name, blob_idx, split_idx)
+
+
+def _insert_splits(lps: List[LayerParameter], net_inputs: List[str], phase: str) -> List[LayerParameter]:
+    """InsertSplits, util/insert_splits.cpp:12-86: every top (or legacy net input: pseudo-layer -1 named "input") that feeds more than one
+    bottom -- a non-zero loss weight counts as a consumer -- gets a Split layer behind it, and the consumers read its tops
+    `<blob>_<layer>_<top index>_split_<k>` in order of appearance."""
+    import copy
+    last_top: Dict[str, tuple] = {n: (-1, j) for j, n in enumerate(net_inputs)}
+    source: Dict[tuple, tuple] = {}
+    count: Dict[tuple, int] = {}
+    loss_w: Dict[tuple, float] = {}
+    names = {-1: "input"}
+    for i, lp in enumerate(lps):
+        names[i] = lp.name
+        for j, b in enumerate(lp.bottom):
+            CHECK(b in last_top, f"Unknown bottom blob '{b}' (layer '{lp.name}', bottom index {j})")
+            source[(i, j)] = last_top[b]
+            count[last_top[b]] = count.get(last_top[b], 0) + 1
+        for j, t in enumerate(lp.top):
+            last_top[t] = (i, j)
+        for j in range(min(len(lp.loss_weight), len(lp.top))):
+            idx = last_top[lp.top[j]]
+            loss_w[idx] = float(lp.loss_weight[j])
+            if loss_w[idx]:
+                count[idx] = count.get(idx, 0) + 1
+
+    def split_layer(layer_name, blob_name, j, n, lw):
+        d = {"name": _split_layer_name(layer_name, blob_name, j), "type": "Split", "bottom": [blob_name],
+             "top": [_split_blob_name(layer_name, blob_name, j, k) for k in range(n)]}
+        if lw:
+            d["loss_weight"] = [lw] + [0.0] * (n - 1)
+        return LayerParameter.from_dict(d, phase)
+
+    out: List[LayerParameter] = []
+    next_split: Dict[tuple, int] = {}
+    for j, n in enumerate(net_inputs):
+        if count.get((-1, j), 0) > 1:
+            out.append(split_layer("input", n, j, count[(-1, j)], 0.0))
+    for i, lp in enumerate(lps):
+        lp = copy.deepcopy(lp)
+        for j in range(len(lp.bottom)):
+            src = source[(i, j)]
+            if count.get(src, 0) > 1:
+                k = next_split.get(src, 0)
+                next_split[src] = k + 1
+                lp.bottom[j] = _split_blob_name(names[src[0]], lp.bottom[j], src[1], k)
+        out.append(lp)
+        for j, t in enumerate(lp.top):
+            if count.get((i, j), 0) > 1:
+                lw = loss_w.get((i, j), 0.0)
+                out.append(split_layer(lp.name, t, j, count[(i, j)], lw))
+                if lw:
+                    lp.loss_weight = []
+                    next_split[(i, j)] = next_split.get((i, j), 0) + 1
+    return out
+
+
 class Net:
-    def __init__(self, proto_text: str, phase: str = "TEST", device=None, backend=None, level: int = 0, stages=()):
+    def __init__(self, proto_text: str, phase: str = "TEST", device=None, backend=None, level: int = 0, stages=(), with_backward=None):
         self.phase_ = phase
+        self.with_backward_ = (phase == "TRAIN") if with_backward is None else bool(with_backward)
         self.device_ = torch.device(device) if device is not None else torch.device("cuda")
         self.backend_ = backend
         unresolved = prototxt.unresolved(proto_text)
@@ -76,12 +148,19 @@ class Net:
         self.params_decay_: List[float] = []
         self._owner: Dict[str, tuple] = {}
         last_writer: Dict[str, int] = {}
-        for ld in self.param_.get("layer", []):
-            lp = LayerParameter.from_dict(ld, phase)
-            if not _layer_included(lp, self.state_):
-                continue
+        lps = [lp for lp in (LayerParameter.from_dict(ld, phase) for ld in self.param_.get("layer", [])) if _layer_included(lp, self.state_)]
+        if self.with_backward_:
+            lps = _insert_splits(lps, list(self.inputs), phase)                                   # net.cpp:46
+        self.blob_need_backward_: Dict[int, bool] = {}          # by id(Blob), net.cpp blob_need_backward_
+        self.layer_need_backward_: List[bool] = []
+        self.bottom_need_backward_: List[List[bool]] = []
+        self.bottom_names_: List[List[str]] = []
+        self.top_names_: List[List[str]] = []
+        for lp in lps:
             self._append_layer(lp, last_writer)
         self.outputs = list(self._available)            # blobs nobody consumed (net.cpp:221-230)
+        self._finish_backward_flags()
+        self.loss_ = None
 
     # ---- construction --------------------------------------------------------------------------------------------------
     def _init_inputs(self):
@@ -103,11 +182,16 @@ class Net:
         if lp.propagate_down:
             CHECK(len(lp.propagate_down) == len(lp.bottom), "propagate_down param must be specified either 0 or bottom_size times ")   # net.cpp:77-82
         bottom = []
-        for b in lp.bottom:
+        need_backward = False
+        bnb = []
+        for j, b in enumerate(lp.bottom):
             CHECK(b in self.blobs, f"Unknown bottom blob '{b}' (layer '{lp.name}', bottom index {len(bottom)})")   # net.cpp:433-434
             bottom.append(self.blobs[b])
             if b in self._available:
                 self._available.remove(b)
+            nb = self.blob_need_backward_.get(id(self.blobs[b]), False)                          # AppendBottom, net.cpp:441-446
+            need_backward |= nb                                                                   # net.cpp:102-103
+            bnb.append(bool(lp.propagate_down[j]) if lp.propagate_down else nb)
         top = []
         for i, t in enumerate(lp.top):
             if i < len(lp.bottom) and lp.bottom[i] == t:
@@ -128,6 +212,20 @@ class Net:
             while len(top) < max(layer.MinTopBlobs(), layer.ExactNumTopBlobs()):
                 top.append(Blob(device=self.device_))
         layer.SetUp(bottom, top)
+        for k in range(len(layer.blobs_)):                                                        # net.cpp:166-185
+            spec = lp.param[k] if k < len(lp.param) and isinstance(lp.param[k], dict) else {}
+            pnb = float(spec.get("lr_mult", 1.0)) != 0 and layer.AllowBackward()
+            need_backward |= pnb
+            layer.set_param_propagate_down(k, pnb)
+        if not layer.AllowBackward():
+            need_backward = False
+        self.layer_need_backward_.append(need_backward)
+        self.bottom_need_backward_.append(bnb)
+        self.bottom_names_.append(list(lp.bottom))
+        self.top_names_.append(list(lp.top))
+        if need_backward:
+            for t in top:
+                self.blob_need_backward_[id(t)] = True
         # parameter sharing: a ParamSpec name seen before hands over that owner's blob (Net::AppendParam, net.cpp:451-540)
         CHECK(len(lp.param) <= len(layer.blobs_), f"Too many params specified for layer {lp.name}")           # net.cpp:163-165
         for k in range(len(layer.blobs_)):
@@ -256,10 +354,78 @@ class Net:
                 b.data = d.clone() if d.data_ptr() == t.data_ptr() else d      # the net owns its input blobs: in-place layers must not write into the caller's tensor
         unknown = [k for k in inputs if k not in self.inputs]
         CHECK(not unknown, "Input blob arguments do not match net inputs: " + ", ".join(unknown))          # pycaffe.py:_Net_forward
+        loss = None
         with torch.no_grad():
             for layer, bottom, top in zip(self.layers, self.bottoms_, self.tops_):
-                layer.Forward(bottom, top)
+                l = layer.Forward(bottom, top)                                      # net.cpp:546-557: loss += layer_loss
+                if torch.is_tensor(l):
+                    loss = l if loss is None else loss + l
+        self.loss_ = loss
         return OrderedDict((n, self.blobs[n].data) for n in self.outputs)
+
+    # ---- backward ------------------------------------------------------------------------------------------------------
+    def _finish_backward_flags(self):
+        """net.cpp:187-256: walk the layers backwards -- a layer whose tops are under no loss needs no backward, a layer all of whose tops
+        were marked to skip propagation needs none either; then force_backward."""
+        under_loss, skip = set(), set()
+        for i in range(len(self.layers) - 1, -1, -1):
+            layer = self.layers[i]
+            contributes, layer_skip = False, True
+            for k, t in enumerate(self.tops_[i]):
+                name = self.top_names_[i][k] if k < len(self.top_names_[i]) else None
+                if layer.loss(k) or (name is not None and name in under_loss):
+                    contributes = True
+                if name is None or name not in skip:
+                    layer_skip = False
+                if contributes and not layer_skip:
+                    break
+            if self.layer_need_backward_[i] and layer_skip:
+                self.layer_need_backward_[i] = False
+                self.bottom_need_backward_[i] = [False] * len(self.bottom_need_backward_[i])
+            if not contributes:
+                self.layer_need_backward_[i] = False
+            for j, name in enumerate(self.bottom_names_[i]):
+                if contributes:
+                    under_loss.add(name)
+                else:
+                    self.bottom_need_backward_[i][j] = False
+                if not self.bottom_need_backward_[i][j]:
+                    skip.add(name)
+        if bool(self.param_.get("force_backward", False)):                          # net.cpp:237-256
+            for i, layer in enumerate(self.layers):
+                self.layer_need_backward_[i] = True
+                for j in range(len(self.bottom_need_backward_[i])):
+                    self.bottom_need_backward_[i][j] = self.bottom_need_backward_[i][j] or layer.AllowForceBackward(j)
+                for k in range(len(layer.blobs_)):
+                    layer.set_param_propagate_down(k, True)
+
+    def Backward(self):
+        """Net::Backward -> BackwardFromTo(layers - 1, 0), net.cpp:592-602,696-722."""
+        CHECK(self.with_backward_, "this net was built without Split layers: construct it with phase TRAIN or with_backward=True")
+        with torch.no_grad():
+            for i in range(len(self.layers) - 1, -1, -1):
+                if self.layer_need_backward_[i]:
+                    self.layers[i].Backward(self.tops_[i], self.bottom_need_backward_[i], self.bottoms_[i])
+
+    def ClearParamDiffs(self):                                                      # net.cpp:949-967
+        for b in self.learnable_:
+            b.mutable_gpu_diff().zero_()
+
+    def ForwardBackward(self, **inputs):
+        """Net::ForwardBackward (net.hpp:89-94): the loss of the forward pass (a device scalar, or None for a net without loss layers)."""
+        self.forward(**inputs)
+        self.Backward()
+        return self.loss_
+
+    def Update(self):
+        """Net::Update -> Blob::Update, net.cpp:929-934, blob.cpp:166-188: data -= diff for every learnable parameter (the solver has
+        scaled the diffs by its learning rate before; there is no solver here)."""
+        with torch.no_grad():
+            for b in self.learnable_:
+                b.data.sub_(b.mutable_gpu_diff())
+        for layer in self.layers:
+            if hasattr(layer, "note_weights_changed"):
+                layer.note_weights_changed()
 
 
 def from_template(template_text: str, width: int, height: int, batch: int = 1, **kw) -> Net:

@@ -8,8 +8,10 @@
     Concat / Slice concat_layer.cpp:24-65 / slice_layer.cpp:24-88
     Silence, Input silence_layer.cu, input_layer.cpp
 
-Forward only where the training graph of this repository does not go through these classes (nets.py + autograd train; the executor
-is the deploy path of scripts/run-flownet.py).  Convolution / Deconvolution call the SAME routing functions as nets.py
+Backward_gpu of every class follows the reference's (conv_layer.cu:26-60, deconv_layer.cu:27-58, relu_layer.cu:33-60, eltwise_layer.cu:68-118,
+concat_layer.cu:47-74, slice_layer.cu:49-75, split_layer.cu:18-33, silence_layer.cu:16-27): top diffs in, bottom diffs OVERWRITTEN, parameter
+diffs ACCUMULATED -- Net.Backward (net.py) steps a TRAIN prototxt through them; the gradient kernels are the ones nets.py's autograd graph
+uses (functional.conv_backward and the flow-head kernels).  Convolution / Deconvolution call the SAME routing functions as nets.py
 (nets.conv_forward / deconv_forward and the flow-head kernels), so a prototxt-built net computes the same bits as nets.deploy_forward.
 A ReLU that directly follows a Convolution / Deconvolution in place is folded into that layer by the executor (`fused_relu_`): one
 kernel, as in nets.py.
@@ -131,14 +133,61 @@ class _ConvBase(Layer):
         conv_layer.cu:12-22).  Several bottoms with one activation (the siamese towers of FlowNetC: one Convolution, two bottoms, two
         tops) run as ONE launch on the bottoms stacked along the batch axis -- the kernels are per-sample -- and the tops are the
         halves of its output."""
+        self._stacked = None
         if len(bottom) > 1 and len({self._slope(i) for i in range(len(top))}) == 1 and bottom[0].data.is_cuda:
             n = bottom[0].num()
-            y = one(torch.cat([b.data for b in bottom], 0), self._slope(0))
+            x = torch.cat([b.data for b in bottom], 0)
+            y = one(x, self._slope(0))
             for i, t in enumerate(top):
                 t.data = y[i * n:(i + 1) * n]
+            self._stacked = (x, y)              # Backward_gpu runs the stacked batch as ONE launch per gradient, like the forward
             return
         for i, (b, t) in enumerate(zip(bottom, top)):
             t.data = one(b.data, self._slope(i))
+
+    def _accumulate(self, k, g):
+        """Parameter diffs accumulate (weight_gpu_gemm / backward_gpu_bias with beta = 1); Net.ClearParamDiffs zeroes them per iteration."""
+        if g is not None:
+            self.blobs_[k].mutable_gpu_diff().add_(g.reshape(self.blobs_[k].shape()))
+
+    def _backward_one(self, x, y, g, slope, need_x, head):
+        from . import functional as Fn, ops
+        w = self.blobs_[0].data
+        need_w = self.param_propagate_down(0)
+        need_b = self.bias_term_ and self.param_propagate_down(1)
+        if head == "predict" and slope is None and ops.predict_flow_conv_backward_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3]):
+            blob, c0 = Fn._channel_slice(x)
+            return ops.predict_flow_conv_backward((blob, c0, x.shape[1]), w, g.contiguous(), need_x, need_w, need_b)
+        if head == "upsample" and slope is None:
+            return ops.upsample_flow_deconv_backward(x.contiguous(), w, g.contiguous(), need_x, need_w, need_b)
+        return Fn.conv_backward(x, w, y if slope is not None else None, g, self.stride_, self.pad_, slope if slope is not None else 0.0,
+                                self.transposed, need_x, need_w, need_b)
+
+    def _head_kind(self):
+        return None
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        CHECK(self.backend_ is None, "Backward runs on the default backend (flownet2_amd.functional) only")
+        head = self._head_kind()
+        if getattr(self, "_stacked", None) is not None:
+            x, y = self._stacked
+            n = bottom[0].num()
+            g = torch.cat([t.mutable_gpu_diff() for t in top], 0)
+            gx, gw, db = self._backward_one(x, y, g, self._slope(0), any(propagate_down), head)
+            self._accumulate(0, gw)
+            if self.bias_term_:
+                self._accumulate(1, db)
+            for i, b in enumerate(bottom):
+                if propagate_down[i]:
+                    b.diff = gx[i * n:(i + 1) * n]
+            return
+        for i, (b, t) in enumerate(zip(bottom, top)):
+            gx, gw, db = self._backward_one(b.data, t.data, t.mutable_gpu_diff(), self._slope(i), bool(propagate_down[i]), head)
+            self._accumulate(0, gw)
+            if self.bias_term_:
+                self._accumulate(1, db)
+            if propagate_down[i]:
+                b.diff = gx
 
     def _backend(self):
         if self.backend_ is not None:
@@ -166,6 +215,9 @@ class ConvolutionLayer(_ConvBase):
             return nets.conv_forward(x, w, b if b is not None else torch.zeros(self.num_output_, device=x.device), s, p,
                                      slope is not None, be, slope=slope)
         self._forward_all(bottom, top, one)
+
+    def _head_kind(self):
+        return "predict" if (self.kernel_, self.stride_, self.pad_, self.num_output_) == (3, 1, 1, 2) else None
 
     def note_weights_changed(self):
         """After the weights were (re)loaded: a 1x1 weight that is diagonal is applied as a per-channel scale (exactly what the zero
@@ -200,6 +252,10 @@ class DeconvolutionLayer(_ConvBase):
             return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y
         self._forward_all(bottom, top, one)
 
+    def _head_kind(self):
+        w = self.blobs_[0].data
+        return "upsample" if (self.kernel_, self.stride_, self.pad_) == (4, 2, 1) and w.shape[0] == 2 and w.shape[1] == 2 else None
+
     def note_weights_changed(self):
         pass
 
@@ -229,6 +285,21 @@ class ReLULayer(Layer):
             top[0].data = ops.bias_leaky_relu_(y, None, self.negative_slope_)             # csrc/bias_act.hip, in place
         else:
             top[0].data = torch.nn.functional.leaky_relu(x, self.negative_slope_)
+
+    def Backward_gpu(self, top, propagate_down, bottom):                                  # relu_layer.cu:33-60
+        if not propagate_down[0]:
+            return
+        g = top[0].mutable_gpu_diff()
+        if self.folded_:                        # the producing Convolution undoes the activation in its own backward pass
+            bottom[0].diff = g
+            return
+        # in place the bottom data IS the top data; for a positive slope its sign is the input's (the reference reads bottom_data)
+        y = top[0].data
+        if y.is_cuda and y.is_contiguous():
+            from . import ops
+            bottom[0].diff = ops.bias_leaky_relu_backward(y, g.contiguous(), self.negative_slope_, False)[0]
+        else:
+            bottom[0].diff = g * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, self.negative_slope_))
 
 
 class EltwiseLayer(Layer):
@@ -274,6 +345,25 @@ class EltwiseLayer(Layer):
                     y = torch.add(y, x, alpha=ci)
         top[0].data = y
 
+    def Backward_gpu(self, top, propagate_down, bottom):                                  # eltwise_layer.cu:68-118
+        g = top[0].mutable_gpu_diff()
+        for i, b in enumerate(bottom):
+            if not propagate_down[i]:
+                continue
+            if self.op_ == "PROD":
+                d = g.clone()
+                for j, o in enumerate(bottom):
+                    if j != i:
+                        d = d * o.data
+                b.diff = d
+            elif self.op_ == "MAX":
+                first = torch.ones_like(g, dtype=torch.bool)
+                for j in range(i):
+                    first &= bottom[j].data < top[0].data              # the first bottom that holds the maximum takes the gradient (mask = argmax)
+                b.diff = g * ((b.data == top[0].data) & first).to(g.dtype)
+            else:
+                b.diff = g.clone() if self.coeffs_[i] == 1.0 else g * self.coeffs_[i]
+
 
 class ConcatLayer(Layer):
     def type(self): return "Concat"
@@ -297,6 +387,18 @@ class ConcatLayer(Layer):
     def Forward_gpu(self, bottom, top):
         # one bottom: the top SHARES the bottom's storage, like the reference (concat_layer.cpp:50-53 ShareData / ShareDiff)
         top[0].data = bottom[0].data if len(bottom) == 1 else torch.cat([b.data for b in bottom], self.axis_)
+
+    def Backward_gpu(self, top, propagate_down, bottom):                                  # concat_layer.cu:47-74
+        g = top[0].mutable_gpu_diff()
+        if len(bottom) == 1:
+            bottom[0].diff = g
+            return
+        off = 0
+        for i, b in enumerate(bottom):
+            n = b.shape(self.axis_)
+            if propagate_down[i]:
+                b.diff = g.narrow(self.axis_, off, n)       # a channel-slice VIEW of the Concat's top_diff: the consumers read it in place
+            off += n
 
 
 class SliceLayer(Layer):
@@ -337,6 +439,11 @@ class SliceLayer(Layer):
             y = x.narrow(self.axis_, self.cuts_[i], self.cuts_[i + 1] - self.cuts_[i])
             t.data = y.clone() if y.is_contiguous() else y.contiguous()
 
+    def Backward_gpu(self, top, propagate_down, bottom):                                  # slice_layer.cu:49-75
+        if not propagate_down[0]:
+            return
+        bottom[0].diff = top[0].mutable_gpu_diff() if len(top) == 1 else torch.cat([t.mutable_gpu_diff() for t in top], self.axis_)
+
 
 class SilenceLayer(Layer):
     def type(self): return "Silence"
@@ -344,6 +451,40 @@ class SilenceLayer(Layer):
     def ExactNumTopBlobs(self): return 0
     def Reshape(self, bottom, top): pass
     def Forward_gpu(self, bottom, top): pass
+
+    def Backward_gpu(self, top, propagate_down, bottom):                                  # silence_layer.cu:16-27
+        for i, b in enumerate(bottom):
+            if propagate_down[i]:
+                b.diff = torch.zeros_like(b.data)
+
+
+class SplitLayer(Layer):
+    """split_layer.cpp:8-27, split_layer.cu:8-33: every top SHARES the bottom's data; the bottom's diff is the sum of the tops' diffs (the first
+    two added, the rest accumulated in order).  Inserted by Net::Init (InsertSplits) wherever a blob has more than one consumer."""
+
+    def type(self): return "Split"
+    def ExactNumBottomBlobs(self): return 1
+    def MinTopBlobs(self): return 1
+
+    def Reshape(self, bottom, top):
+        for t in top:
+            CHECK(t is not bottom[0], "Split Layer does not allow in-place computation.")   # split_layer.cpp:13-18
+            t.ReshapeLike(bottom[0])
+
+    def Forward_gpu(self, bottom, top):
+        for t in top:
+            t.data = bottom[0].data
+
+    def Backward_gpu(self, top, propagate_down, bottom):
+        if not propagate_down[0]:
+            return
+        if len(top) == 1:
+            bottom[0].diff = top[0].mutable_gpu_diff().clone()
+            return
+        d = top[0].mutable_gpu_diff() + top[1].mutable_gpu_diff()
+        for t in top[2:]:
+            d = d + t.mutable_gpu_diff()
+        bottom[0].diff = d
 
 
 class InputLayer(Layer):
@@ -367,5 +508,5 @@ class InputLayer(Layer):
 
 
 for _name, _cls in (("Convolution", ConvolutionLayer), ("Deconvolution", DeconvolutionLayer), ("ReLU", ReLULayer), ("Eltwise", EltwiseLayer),
-                    ("Concat", ConcatLayer), ("Slice", SliceLayer), ("Silence", SilenceLayer), ("Input", InputLayer)):
+                    ("Concat", ConcatLayer), ("Slice", SliceLayer), ("Silence", SilenceLayer), ("Split", SplitLayer), ("Input", InputLayer)):
     L.REGISTER_LAYER_CLASS(_name, _cls)

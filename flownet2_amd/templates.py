@@ -97,6 +97,7 @@ def _tail(b: _Builder, flow_blob: str, scale_flow: float = nets.FLOW_SCALE):
 def _decoder(b: _Builder, p: str, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
     """nets._decoder: predict_flow6, then four stages Concat[skip, deconv, upsampled flow] -> predict_flow.  Returns the flow2 blob."""
     flow = b.conv(p + "Convolution1", conv6_1, p + "predict_flow6", 2, 3, 1, 1, relu=False)
+    b.preds = [(6, flow)]                   # (level, blob): the multi-scale predictions a TRAIN net hangs its loss layers on
     x = conv6_1
     names = [("deconv5", 512, "upsample_flow6to5", conv5_1, "Convolution2", 5), ("deconv4", 256, "upsample_flow5to4", conv4_1, "Convolution3", 4),
              ("deconv3", 128, "upsample_flow4to3", conv3_1, "Convolution4", 3), ("deconv2", 64, "upsample_flow3to2", conv2, "Convolution5", 2)]
@@ -105,6 +106,7 @@ def _decoder(b: _Builder, p: str, conv6_1, conv5_1, conv4_1, conv3_1, conv2):
         u = b.conv(p + uname, flow, p + uname.replace("upsample_flow", "upsampled_flow_"), 2, 4, 2, 1, relu=False, deconv=True)
         x = b.concat([skip, d, u], p + "concat%d" % lvl)
         flow = b.conv(p + pname, x, p + "predict_flow%d" % lvl, 2, 3, 1, 1, relu=False)
+        b.preds.append((lvl, flow))
     return flow
 
 
@@ -155,6 +157,25 @@ def flownet_c_template() -> str:
     b = _Builder("FlowNetC_deploy")
     a, bb = _head(b)
     _tail(b, _flownet_c(b, a, bb))
+    return b.text()
+
+
+def flownet_c_train_prototxt(batch: int, height: int, width: int) -> str:
+    """A TRAIN-phase FlowNetC in the reference's format (nets.flownet_c_core + nets.multiscale_loss as layers): pre-processed images and the
+    ground-truth flow as net inputs, the flow scaled by 1 / 20 (Eltwise), per prediction scale a Downsample to the prediction's size and an
+    L1Loss{l2_per_location, normalize_by_num_entries} with the scale's loss_weight.  Not a file of the reference tree (it ships no
+    prototxt): the layer types, parameter messages and the loss wiring are the reference's."""
+    b = _Builder("FlowNetC_train")
+    for n, c in (("img0_nomean", 3), ("img1_nomean", 3), ("flow_gt", 2)):
+        b.lines += ['input: "%s"' % n, "input_shape { dim: %d dim: %d dim: %d dim: %d }" % (batch, c, height, width)]
+    _flownet_c(b, "img0_nomean", "img1_nomean")
+    gt = b.eltwise(["flow_gt"], "flow_gt_scaled", [1.0 / nets.FLOW_SCALE])
+    for lvl, pred in b.preds:
+        ds = "flow_gt_scaled_%d" % lvl
+        b.layer("Downsample%d" % lvl, "Downsample", [gt, pred], [ds], "", "propagate_down: false propagate_down: false")
+        b.layer("flow_loss%d" % lvl, "L1Loss", [pred, ds], ["flow_loss%d" % lvl],
+                "l1_loss_param { l2_per_location: true normalize_by_num_entries: true } include { phase: TRAIN }",
+                "loss_weight: %r propagate_down: true propagate_down: false" % float(nets.LOSS_WEIGHTS[lvl]))
     return b.text()
 
 
