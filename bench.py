@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="capture a forward step into a hipGraph and replay it (measured: no gain, the step is not launch-bound)")
     ap.add_argument("--corr-iters", type=int, default=200)
     ap.add_argument("--bucket-mb", type=int, default=48, help="gradient all-reduce bucket size (train mode)")
+    ap.add_argument("--sd-stream", choices=["on", "off"], default="on", help="FlowNet2: FlowNet-SD on a second stream beside the CSS stack (nets.set_sd_side_stream)")
     return ap.parse_args()
 
 
@@ -383,7 +384,8 @@ def extras(device, args):
         ex[key] = {"metric": "image-pairs/sec FlowNet2 (CSS+SD+fusion) forward at %dx%d" % (W, H), "value": round(B * steps / m["elapsed"], 2),
                    "unit": "image-pairs/s", "batch": B, "steps": steps, "warmup": 5, "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
                    "ms_per_step_p10_p50_p90": p, "dtype": "f32",
-                   "conv_tflops": round(nets.flownet2_conv_flops(H, W) * B * steps / m["elapsed"] / 1e12, 2)}
+                   "conv_tflops": round(nets.flownet2_conv_flops(H, W) * B * steps / m["elapsed"] / 1e12, 2),
+                   "streams": "FlowNet-SD on a second HIP stream beside the FlowNetC -> S -> S stack" if args.sd_stream == "on" else "one"}
         if not args.no_cpu_baseline and not key.endswith("_batch4"):
             epe, secs = flownet2_epe_vs_cpu(m["P_cpu"], m["img0"], m["img1"], m["out"])
             ex[key]["epe_vs_cpu_oracle"] = epe
@@ -481,6 +483,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
     ranks_seen = check_ranks(world, args.gpus, device)  # what RCCL actually connected (one all-reduce of ones)
 
+    from flownet2_amd import nets as _nets
+    _nets.set_sd_side_stream(args.sd_stream)
     B, H, W = args.batch, args.height, args.width
     m = run_workload(args.net, args.mode, B, H, W, args.steps, args.warmup, device, world, rank, args.bucket_mb, args.graph)
     elapsed, marks, out, P_cpu, img0, img1 = m["elapsed"], m["marks"], m["out"], m["P_cpu"], m["img0"], m["img1"]

@@ -606,6 +606,28 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     return flow * scale.view(1, 2, 1, 1)
 
 
+_SD_STREAM = {"mode": "on", "streams": {}}
+
+
+def set_sd_side_stream(mode="on"):
+    """FlowNet-SD only reads the two images: it is independent of the FlowNetC -> S -> S stack until the fusion net.  "on" / True (default)
+    runs it on a second HIP stream beside that stack, "off" / False behind it.  Two LONG independent chains share the chip well -- the coarse
+    layers of either net leave CUs idle, most of all at batch 1: 5.38 -> 5.00 ms at batch 1 @1024x448, 10.31 -> 10.01 ms at batch 4 @768x384,
+    15.20 -> 14.75 ms at batch 4 @1024x448 (round 5) -- where a handful of small kernels beside a chip-filling GEMM did not (the flow heads on a
+    second stream, round 4).  Same kernels, same bits."""
+    _SD_STREAM["mode"] = {True: "on", False: "off", "auto": "on"}.get(mode, mode)
+
+
+def _sd_side_stream(dev, n_pixels):
+    mode = _SD_STREAM["mode"]
+    if mode == "off":
+        return None
+    st = _SD_STREAM["streams"].get(dev)
+    if st is None:
+        st = _SD_STREAM["streams"][dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean):
     """The same graph on the GPU backend without its glue passes: the Concat blobs are allocated once and every producer writes its
     channel slice (fn2_*_slices), the Eltwise scalings (x20 in front of a Resample, x0.05 behind it, img0 - warped in front of a
@@ -637,12 +659,23 @@ def _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean):
         backend.flow_warp_slices(B, flow, out=WARPED)
         backend.channel_norm_slices(A, minus=WARPED, out=(blob, 11, 1))
 
+    side = _sd_side_stream(dev, N * ah * aw)
+    sd_q = None
+    if side is not None:                            # FlowNet-SD beside the CSS stack (set_sd_side_stream)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)                      # `pair` is written
+        with torch.cuda.stream(side):
+            sd_q = flownet_sd_core(_Prefixed(P, "netsd_"), pair, backend)
     flow1_q = flownet_c_core(P, None, None, backend, towers=towers)[2]
     refine_input(flow1_q)
     flow2_q = flownet_s_core(_Prefixed(P, "net2_"), blob, backend)[2]
     refine_input(flow2_q)                           # net2's conv1 has read the blob (stream order): channels 6..11 are rewritten in place
     flow3_q = flownet_s_core(_Prefixed(P, "net3_"), blob, backend)[2]
-    sd_q = flownet_sd_core(_Prefixed(P, "netsd_"), pair, backend)
+    if side is not None:
+        main.wait_stream(side)
+        sd_q.record_stream(main)                    # allocated under the side stream, read (and freed) under this one
+    else:
+        sd_q = flownet_sd_core(_Prefixed(P, "netsd_"), pair, backend)
     backend.resample_slices(sd_q, ah, aw, type=1, in_scale=SD_FLOW_SCALE, out=(fuse, 3, 2))        # NEAREST into the fusion net (Appendix B)
     backend.resample_slices(flow3_q, ah, aw, type=1, in_scale=FLOW_SCALE, out=(fuse, 5, 2))
     backend.channel_norm_slices((fuse, 3, 2), out=(fuse, 7, 1))
