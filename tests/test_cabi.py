@@ -98,7 +98,7 @@ def test_ops_refuse_cpu_tensors_no_fallback():
 def test_layer_registry_and_blob_count_checks():
     assert LayerRegistry.LayerTypeList() == ["ChannelNorm", "Concat", "Convolution", "Correlation", "Correlation1D", "CustomData", "DataAugmentation",
                                              "Deconvolution", "Downsample", "Eltwise", "FlowAugmentation", "FlowWarp", "GenerateAugmentationParameters",
-                                             "Input", "L1Loss", "ReLU", "Resample", "Silence", "Slice"]
+                                             "Input", "L1Loss", "ReLU", "Resample", "Silence", "Slice", "Split"]
     with pytest.raises(CheckError, match="Unknown layer type"):
         LayerRegistry.CreateLayer(LayerParameter(type="Nope"))
     with pytest.raises(CheckError, match="already registered"):
