@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="capture a forward step into a hipGraph and replay it (measured: no gain, the step is not launch-bound)")
     ap.add_argument("--corr-iters", type=int, default=200)
     ap.add_argument("--bucket-mb", type=int, default=48, help="gradient all-reduce bucket size (train mode)")
+    ap.add_argument("--wgrad-side-pixels", type=int, default=36000, help="train mode, one rank: weight gradients of maps up to this many pixels on a second HIP stream (0 = off)")
     ap.add_argument("--sd-stream", choices=["on", "off"], default="on", help="FlowNet2: FlowNet-SD on a second stream beside the CSS stack (nets.set_sd_side_stream)")
     return ap.parse_args()
 
@@ -251,6 +252,9 @@ def rank_seed(rank):
     return 1234 + rank              # every rank its own synthetic batch (weak scaling: per-GPU work fixed)
 
 
+WGRAD_SIDE_PIXELS = [36000]       # --wgrad-side-pixels: GradientExchange's second stream for the weight gradients (single-rank jobs)
+
+
 def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0, rt=None, local_grads=False):
     """W untimed warm-up steps (+ untimed settling steps until `settle_s` seconds of back-to-back stepping have passed: the chip
     needs ~25 ms of load to come back to its steady clocks, and a short run otherwise sits inside that ramp), then EXACTLY `steps`
@@ -274,7 +278,7 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         # identical Adam step on every rank
         # local_grads: the SAME step without the collective (every rank keeps its own gradients) -- the comparison leg from which
         # train_leg() reports how much of the all-reduce is not hidden behind backward
-        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20, local_only=local_grads)
+        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20, local_only=local_grads, wgrad_side_pixels=WGRAD_SIDE_PIXELS[0])
 
         def step():
             exchange.zero_grad()
@@ -413,7 +417,9 @@ def train_leg(device, world, rank, bucket_mb=48, B=8, H=320, W=448, steps=20, wa
            "parallelism": "dp%d (one fp32 sum-all-reduce of %.1f MB per step in %d buckets <= %d MB, scaled by 1/%d)" % (
                world, 4e-6 * nets.num_params(m["P_cpu"]), m["n_buckets"], bucket_mb, world),
            "grad_buckets": m["n_buckets"], "buckets_launched_inside_backward": m["buckets_launched_inside_backward"],
-           "library_conv_fallbacks": LIB_FALLBACKS()}
+           "library_conv_fallbacks": LIB_FALLBACKS(),
+           "streams": ("weight gradients of maps <= %d px on a second HIP stream beside the data-gradient chain" % WGRAD_SIDE_PIXELS[0])
+                      if (world == 1 and WGRAD_SIDE_PIXELS[0] > 0 and device.type == "cuda") else "one"}
     del m
     if device.type == "cuda":
         torch.cuda.empty_cache()
@@ -485,6 +491,7 @@ def main():
 
     from flownet2_amd import nets as _nets
     _nets.set_sd_side_stream(args.sd_stream)
+    WGRAD_SIDE_PIXELS[0] = args.wgrad_side_pixels
     B, H, W = args.batch, args.height, args.width
     m = run_workload(args.net, args.mode, B, H, W, args.steps, args.warmup, device, world, rank, args.bucket_mb, args.graph)
     elapsed, marks, out, P_cpu, img0, img1 = m["elapsed"], m["marks"], m["out"], m["P_cpu"], m["img0"], m["img1"]

@@ -443,6 +443,53 @@ class _OwnForwardConv(torch.autograd.Function):
         return gx, gw, db, None, None, None, None, None, None
 
 
+_WGRAD_SIDE = {"pixels": 0, "streams": {}}
+_SIDE_PENDING = []          # (weight, address of its gradient computed under the side stream) of the running backward pass -- the address
+                            # only: a reference to the tensor would make autograd COPY it into .grad instead of moving it there
+
+
+def set_wgrad_side_stream(max_pixels: int = 0):
+    """Weight gradients beside the data-gradient chain (opt-in; parallel.GradientExchange switches it on for a single-rank job).  Nothing in a
+    backward pass reads a layer's weight gradient, and from 1/4 resolution down neither gradient kernel of a layer fills the chip: with
+    max_pixels > 0 the weight gradient of every layer whose top and bottom maps have at most that many pixels runs on a second HIP stream
+    (FlowNetC train step, batch 8 @448x320: 9.46-9.52 -> 9.33 ms with 36000 = every layer but the stem).  The main stream waits for it when the
+    backward pass ends (an autograd-engine callback; outside the engine -- the prototxt executor -- the gradient stays on the main stream).
+    Constraints, checked where they can be: the weight has no gradient yet (a pass that ACCUMULATES stays on the main stream) and feeds ONE
+    layer of the graph (the engine would add two gradients of a shared weight before the join); nothing reads `.grad` inside the pass
+    (gradient hooks: GradientExchange with several ranks keeps this off).  0 = off (default)."""
+    _WGRAD_SIDE["pixels"] = int(max_pixels)
+
+
+def _wgrad_side_stream(d, x, w):
+    if not _WGRAD_SIDE["pixels"] or not d.is_cuda or w.grad is not None or max(d.shape[2] * d.shape[3], x.shape[2] * x.shape[3]) > _WGRAD_SIDE["pixels"]:
+        return None
+    if not _SIDE_PENDING:       # first one of this pass: the join rides on the end of the backward pass
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        except RuntimeError:    # not inside the autograd engine (Net.Backward of the prototxt executor): nobody would join
+            return None
+    st = _WGRAD_SIDE["streams"].get(d.device)
+    if st is None:
+        st = _WGRAD_SIDE["streams"][d.device] = torch.cuda.Stream(device=d.device)
+    return st
+
+
+def join_side_streams():
+    """The current stream waits for the weight gradients computed beside it.  A gradient the engine COPIED or ADDED instead of moving it into
+    `.grad` was read before it was complete (a weight shared by two layers, a retained graph ...): that is an error, not a silent race."""
+    if not _SIDE_PENDING:
+        return
+    for dev, st in _WGRAD_SIDE["streams"].items():
+        torch.cuda.current_stream(dev).wait_stream(st)
+    pending = list(_SIDE_PENDING)
+    _SIDE_PENDING.clear()
+    for w, ptr in pending:
+        if ptr and w.grad is not None and w.grad.data_ptr() != ptr:
+            raise RuntimeError("functional.set_wgrad_side_stream: autograd did not move a weight gradient computed on the second stream into "
+                               ".grad as it was (shared weight? retained graph?): the result may have been read early.  Switch it off "
+                               "(set_wgrad_side_stream(0)) for this graph.")
+
+
 def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, need_b):
     """(bottom_diff, weight_diff, bias_diff) of a Convolution / Deconvolution (+ the leaky ReLU folded into it when `y`, the ACTIVATED
     output, is given) from top_diff g -- ConvolutionLayer / DeconvolutionLayer::Backward_gpu (conv_layer.cu:26-60, deconv_layer.cu:27-58)
@@ -458,7 +505,27 @@ def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, ne
         g = g.contiguous()
         d, db = g, (g.sum((0, 2, 3)) if need_b else None)
     gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
-    gw = _own_bwd_weight(d, x, w, stride, pad, transposed) if need_w else None
+    gw = None
+    if need_w:
+        side = _wgrad_side_stream(d, x, w)
+        if side is None:
+            gw = _own_bwd_weight(d, x, w, stride, pad, transposed)
+        else:
+            # the weight gradient of a small map is off the critical path (nothing in the backward pass reads it) and does not fill the chip:
+            # beside the data-gradient chain on a second stream; join_side_streams() before the optimizer / the gradient exchange reads it
+            main = torch.cuda.current_stream(d.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gw = _own_bwd_weight(d, x, w, stride, pad, transposed)
+            if gw is None:
+                main.wait_stream(side)
+                if not _SIDE_PENDING:
+                    _SIDE_PENDING.append((w, 0))          # keeps the queued callback's bookkeeping consistent (nothing to check)
+            else:
+                for t in (d, x):
+                    t.record_stream(side)                 # read under the side stream, freed under the main one
+                gw.record_stream(main)
+                _SIDE_PENDING.append((w, gw.data_ptr()))
     lib_x, lib_w = need_x and gx is None, need_w and gw is None
     if (lib_x or lib_w) and os.environ.get("FN2_TRACE_BWD") == "1":
         print("bwd on the library: x %s w %s stride %d pad %d transposed %s -> %s%s" % (tuple(x.shape), tuple(w.shape), stride, pad, transposed,

@@ -58,11 +58,16 @@ class GradientExchange:
     fixed latency, so buckets are few and large (default 48 MB: FlowNetC's 156.7 MB travel as 4 buckets; the first leaves
     after the decoder, ~25 % into backward).  Gradients stay fp32 (parity with the reference)."""
 
-    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20, local_only: bool = False):
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20, local_only: bool = False, wgrad_side_pixels: int = 36000):
         """local_only: keep the gradients of this rank (no collective, no bucket copies) although the process group has several ranks --
-        the comparison step bench.py times to report how much of the all-reduce is NOT hidden behind backward."""
+        the comparison step bench.py times to report how much of the all-reduce is NOT hidden behind backward.
+        wgrad_side_pixels: in a single-rank JOB the weight gradients of maps up to this size run on a second HIP stream beside the
+        data-gradient chain (functional.set_wgrad_side_stream; 0 = off).  With several ranks the gradient hooks below read every gradient the
+        moment it is produced, so it stays off (also for the local_only comparison leg: the two legs must differ by the collective alone)."""
         self.params = [p for p in params if p.requires_grad]
         self.world = 1 if local_only else world()
+        from . import functional
+        functional.set_wgrad_side_stream(wgrad_side_pixels if world() == 1 else 0)
         self.launched_in_backward = 0       # buckets whose all-reduce left from a gradient hook during the last backward pass
         self.buckets: List[dict] = []
         cur, size = [], 0
@@ -146,6 +151,8 @@ class GradientExchange:
             self._launch(b)
 
     def finish(self):
+        from . import functional
+        functional.join_side_streams()          # (already done by the engine's end-of-pass callback; idempotent)
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)

@@ -179,3 +179,47 @@ def test_fused_optimizer_updates_reach_the_packed_weights():
     cached, fresh = run(False), run(True)
     assert cached == fresh, (cached, fresh)
     assert len(set(cached)) == len(cached), cached
+
+
+@pytest.mark.gpu
+def test_weight_gradients_on_the_second_stream_are_the_same_bits():
+    """functional.set_wgrad_side_stream (round 5; parallel.GradientExchange switches it on for a single-rank job): the weight gradients of
+    every layer but the stem run on a second HIP stream beside the data-gradient chain and the main stream joins when the backward pass
+    ends.  Same kernels on the same operands: every gradient must have the bits of the one-stream pass, pass after pass (a missing
+    dependency between the streams shows up as a gradient that differs from run to run), through four fused-Adam steps, and also when the
+    gradients are ACCUMULATED by a second backward pass (which must stay on the main stream)."""
+    from flownet2_amd import functional as Fn, nets
+
+    def run(pixels, accumulate=False):
+        Fn.set_wgrad_side_stream(pixels)
+        try:
+            P = {k: v.cuda().requires_grad_(True) for k, v in nets.init_params("C", seed=2).items()}
+            opt = torch.optim.Adam(list(P.values()), lr=1e-3, fused=True)
+            g = torch.Generator(device="cuda").manual_seed(3)
+            a = torch.rand(4, 3, 192, 256, device="cuda", generator=g) - 0.43
+            b = torch.rand(4, 3, 192, 256, device="cuda", generator=g) - 0.43
+            gt = torch.randn(4, 2, 192, 256, device="cuda", generator=g) * 3
+            grads, losses = [], []
+            for it in range(4):
+                opt.zero_grad(set_to_none=True)
+                for _ in range(2 if accumulate else 1):
+                    loss = nets.multiscale_loss(nets.flownet_c_core(P, a, b, Fn), gt, Fn)
+                    loss.backward()
+                grads.append({k: v.grad.clone() for k, v in P.items()})
+                opt.step()
+                losses.append(float(loss.detach()))
+            return grads, losses
+        finally:
+            Fn.set_wgrad_side_stream(0)
+
+    ref_g, ref_l = run(0)
+    for attempt in range(3):
+        got_g, got_l = run(36000)
+        assert got_l == ref_l, (attempt, got_l, ref_l)
+        for it, (gg, rg) in enumerate(zip(got_g, ref_g)):
+            bad = [k for k in rg if not torch.equal(gg[k], rg[k])]
+            assert not bad, (attempt, it, bad)
+    acc_ref, _ = run(0, accumulate=True)
+    acc_got, _ = run(36000, accumulate=True)
+    for gg, rg in zip(acc_got, acc_ref):
+        assert all(torch.equal(gg[k], rg[k]) for k in rg)
