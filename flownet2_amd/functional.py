@@ -444,6 +444,7 @@ class _OwnForwardConv(torch.autograd.Function):
 
 
 _WGRAD_SIDE = {"pixels": 0, "streams": {}}
+_SIDE_TASK = [-1]           # autograd graph task the pending entries belong to
 _SIDE_PENDING = []          # (weight, address of its gradient computed under the side stream) of the running backward pass -- the address
                             # only: a reference to the tensor would make autograd COPY it into .grad instead of moving it there
 
@@ -463,11 +464,16 @@ def set_wgrad_side_stream(max_pixels: int = 0):
 def _wgrad_side_stream(d, x, w):
     if not _WGRAD_SIDE["pixels"] or not d.is_cuda or w.grad is not None or max(d.shape[2] * d.shape[3], x.shape[2] * x.shape[3]) > _WGRAD_SIDE["pixels"]:
         return None
-    if not _SIDE_PENDING:       # first one of this pass: the join rides on the end of the backward pass
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
-        except RuntimeError:    # not inside the autograd engine (Net.Backward of the prototxt executor): nobody would join
-            return None
+    task = torch._C._current_graph_task_id()
+    if task < 0:                # not inside the autograd engine (Net.Backward of the prototxt executor): nobody would join
+        return None
+    if task != _SIDE_TASK[0]:   # first one of this backward pass: the join rides on its end
+        if _SIDE_PENDING:       # a pass that died on the way (an exception in some backward) left entries behind: settle them first
+            _SIDE_PENDING.clear()
+            for dev, st in _WGRAD_SIDE["streams"].items():
+                torch.cuda.current_stream(dev).wait_stream(st)
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        _SIDE_TASK[0] = task
     st = _WGRAD_SIDE["streams"].get(d.device)
     if st is None:
         st = _WGRAD_SIDE["streams"][d.device] = torch.cuda.Stream(device=d.device)
@@ -477,6 +483,7 @@ def _wgrad_side_stream(d, x, w):
 def join_side_streams():
     """The current stream waits for the weight gradients computed beside it.  A gradient the engine COPIED or ADDED instead of moving it into
     `.grad` was read before it was complete (a weight shared by two layers, a retained graph ...): that is an error, not a silent race."""
+    _SIDE_TASK[0] = -1
     if not _SIDE_PENDING:
         return
     for dev, st in _WGRAD_SIDE["streams"].items():
@@ -519,8 +526,6 @@ def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, ne
                 gw = _own_bwd_weight(d, x, w, stride, pad, transposed)
             if gw is None:
                 main.wait_stream(side)
-                if not _SIDE_PENDING:
-                    _SIDE_PENDING.append((w, 0))          # keeps the queued callback's bookkeeping consistent (nothing to check)
             else:
                 for t in (d, x):
                     t.record_stream(side)                 # read under the side stream, freed under the main one
