@@ -303,6 +303,39 @@ def _skip_conv(x, P, name, stride, pad, dname, backend):
     return _conv_into_concat(x, P, name, stride, pad, P[dname + ".w"].shape[1] + 2, backend)
 
 
+TOWER_SPLIT_OPS = [True]      # A/B hook: False = plain slices of the stacked tower batch in the training graph
+
+
+class _SplitTowers(torch.autograd.Function):
+    """The stacked siamese batch [2N, ...] -> (first tower, second tower).  Two plain slices cost the backward pass two zero-fills of the
+    stacked shape, two strided copies and an add (SliceBackward twice, then the sum); here it is ONE concatenation of the two gradients."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n = x.shape[0] // 2
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat([ga, gb], 0)
+
+
+class _StackedAndFirstTower(torch.autograd.Function):
+    """The stacked batch as it is (for the next tower layer) AND its first tower (the skip connection into the refinement).  The skip's
+    gradient is added into the first half of the stacked gradient in place -- instead of a zero-fill of the stacked shape, a strided copy
+    and a full-size add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x[:x.shape[0] // 2]
+
+    @staticmethod
+    def backward(ctx, g_all, g_first):
+        g_all = g_all.contiguous()
+        g_all[:g_first.shape[0]].add_(g_first)      # g_all is this node's own input (the data gradient of the one layer that read output 0)
+        return g_all
+
+
 def flownet_c_core(P, img0, img1, backend, towers=None):
     """Pre-processed images [N,3,H,W] (H, W multiples of 64) -> {scale: flow prediction /20}.  `towers`: the two images already
     stacked along the batch axis [2N,3,H,W] (the deploy head writes them there directly)."""
@@ -312,8 +345,12 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
     # conv2 of BOTH towers goes into a [2N, 128 + 64 + 2, h, w] blob: its first N samples are the concat2 blob of the refinement
     blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend)
+    training = TOWER_SPLIT_OPS[0] and torch.is_grad_enabled() and c2.requires_grad
+    c2_first = None
+    if training and blob2 is None:
+        c2, c2_first = _StackedAndFirstTower.apply(c2)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
-    c3a, c3b = c3[:n], c3[n:]
+    c3a, c3b = _SplitTowers.apply(c3) if (training and c3.requires_grad) else (c3[:n], c3[n:])
     cat = redir = None
     cr = P["conv_redir.w"].shape[0]
     if hasattr(backend, "correlation_relu_into") and c3a.is_cuda:
@@ -340,7 +377,7 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     blob5, c51 = _skip_conv(c5, P, "conv5_1", 1, 1, "deconv5", backend)
     c6 = _conv(c51, P, "conv6", 2, 1, backend=backend)
     c61 = _conv(c6, P, "conv6_1", 1, 1, backend=backend)
-    skip2 = (blob2[:n], c2[:n]) if blob2 is not None else c2[:n]
+    skip2 = (blob2[:n], c2[:n]) if blob2 is not None else (c2_first if c2_first is not None else c2[:n])
     return _decoder(P, c61, (blob5, c51), (blob4, c41), (blob3, c31), skip2, backend)
 
 
