@@ -235,17 +235,20 @@ class _UpsampleFlow(torch.autograd.Function):
     """upsample_flow (Deconvolution{4,2,1} 2 -> 2): own forward and own backward (csrc/flow_head_bwd.hip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, into=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)
+        if into is None:
+            return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias)
+        ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias, out=into[0], out_c0=into[1])
+        return into[0][:, into[1]:into[1] + 2]          # (see _OwnForwardConv.forward)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         dx, dw, db = ops.upsample_flow_deconv_backward(x.contiguous(), w, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                                        ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def predict_flow_conv(x, weight, bias=None):
@@ -264,7 +267,7 @@ def upsample_flow_deconv(x, weight, bias=None, out=None, out_c0=0):
         return ops.upsample_flow_deconv_forward(x.contiguous(), weight.contiguous(), bias, out=out, out_c0=out_c0)
     run = lambda xx, ww, bb: ops.upsample_flow_deconv_forward(xx.contiguous(), ww.contiguous(), bb)
     if _needs_grad(x, weight, bias):
-        return _UpsampleFlow.apply(x, weight, bias)
+        return _UpsampleFlow.apply(x, weight, bias, None if out is None else (out, out_c0))
     return run(x, weight, bias)
 
 
@@ -426,10 +429,17 @@ class _OwnForwardConv(torch.autograd.Function):
     (aten::convolution_backward = MIOpen's bwd-data / bwd-weights kernels)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, runner, stride, pad, negative_slope, act, transposed):
+    def forward(ctx, x, weight, bias, runner, stride, pad, negative_slope, act, transposed, into=None):
         # autograd does not record inside forward(): the parameter OBJECT goes to the runner, so that the packed-weight caches
-        # (keyed on the parameter and its _version) hit until the optimizer writes the weight
-        y = runner(x, weight, bias)
+        # (keyed on the parameter and its _version) hit until the optimizer writes the weight.
+        # into = (blob, first channel): the runner writes its channels into that slice of the consumer's Concat blob (a plain buffer
+        # outside the graph; nets._ConcatInPlace ties the slices together) and the output is the slice view
+        if into is None:
+            y = runner(x, weight, bias)
+        else:
+            runner(x, weight, bias, into[0], into[1])
+            co = weight.shape[1] if transposed else weight.shape[0]
+            y = into[0][:, into[1]:into[1] + co]
         ctx.cfg = (stride, pad, negative_slope, act, bias is not None, transposed)
         ctx.save_for_backward(x, weight, y if act else None)
         return y
@@ -440,7 +450,7 @@ class _OwnForwardConv(torch.autograd.Function):
         stride, pad, slope, act, has_bias, transposed = ctx.cfg
         gx, gw, db = conv_backward(x, w, y if act else None, g, stride, pad, slope, transposed, bool(ctx.needs_input_grad[0]),
                                    bool(ctx.needs_input_grad[1]), has_bias and ctx.needs_input_grad[2])
-        return gx, gw, db, None, None, None, None, None, None
+        return gx, gw, db, None, None, None, None, None, None, None
 
 
 _WGRAD_SIDE = {"pixels": 0, "streams": {}}
@@ -625,10 +635,8 @@ def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, o
     if kind is None:
         return None
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        if out is not None:
-            return None
-        return _OwnForwardConv.apply(x, weight, bias, lambda xx, ww, bb: _conv_mfma_run(kind, xx, ww, bb, stride, pad, negative_slope, act),
-                                     stride, pad, negative_slope, act, False)
+        run = lambda xx, ww, bb, o=None, o0=0: _conv_mfma_run(kind, xx, ww, bb, stride, pad, negative_slope, act, o, o0)
+        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, act, False, None if out is None else (out, out_c0))
     return _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out, out_c0)
 
 
@@ -688,20 +696,20 @@ def deconv_gemm_relu(x, weight_t, bias, cout, kernel=4, stride=2, pad=1, negativ
         col = ops.conv_mfma_forward(blob, pw, None, cout * kernel * kernel, 1, 1, 0, False, 0.0, in_c0=c0, Cin=Cin).view(N, cout * kernel * kernel, H * W)
         return ops.col2im_bias_relu_forward(col, bb, N, cout, Ho, Wo, kernel, pad, stride, True, negative_slope, out=out, out_c0=out_c0)
 
-    if out is not None:                # the col2im pass writes straight into the consumer's Concat blob (inference only)
-        return None if (_needs_grad(x, weight_t, bias, weight) or not gemm_ok) else run_t(x, weight_t, bias, out, out_c0)
     if _needs_grad(x, weight_t, bias, weight):
         if weight is None:
             return None
-        def run(xx, ww, bb):
+        def run(xx, ww, bb, o=None, o0=0):
             # ww is the parameter itself (autograd does not record inside _OwnForwardConv.forward): its transposed view and the packed
             # operands are cached on it until the optimizer writes it.  Planes whose size is no multiple of 4 (deconv5: 5x7) are not the
             # 1x1 / GEMM kernel's: the small-map deconvolution kernel computes them without a column matrix (and without a library GEMM)
             if plane_ok and ((H * W) % 4 != 0 or not gemm_ok):
                 blob, c0 = _channel_slice(xx)
-                return ops.deconv_plane_forward(blob, _packed_deconv_weight(ww), bb, cout, True, negative_slope, in_c0=c0, Cin=Cin)
-            return run_t(xx, None, bb, ww=ww)
-        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, True)
+                return ops.deconv_plane_forward(blob, _packed_deconv_weight(ww), bb, cout, True, negative_slope, out=o, out_c0=o0, in_c0=c0, Cin=Cin)
+            return run_t(xx, None, bb, o, o0, ww=ww)
+        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, True, True, None if out is None else (out, out_c0))
+    if out is not None:                # the col2im pass writes straight into the consumer's Concat blob
+        return None if not gemm_ok else run_t(x, weight_t, bias, out, out_c0)
     if not gemm_ok:                    # (inference reaches the small-map kernel through deconv_mfma_relu before it comes here)
         if weight is None:
             return None

@@ -180,16 +180,19 @@ def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
     straight into it (ConcatLayer, concat_layer.cu:8-52, becomes a no-op for this input).  Returns (blob or None, the layer's output --
     a channel-slice view of the blob, or an ordinary tensor)."""
     w = P[name + ".w"]
-    # The blob route writes the later Concat inputs in place (deconvolution, upsampled flow) and discards what those calls return:
-    # it is an INFERENCE route.  With grad mode on and ANY parameter of the net trainable (a frozen encoder with a trainable decoder
-    # included) the stock graph runs instead.
+    # The blob route writes the later Concat inputs in place (deconvolution, upsampled flow).  Without autograd what those calls return is
+    # discarded.  With autograd (round 5, CONCAT_IN_PLACE_TRAINING) every producer is an autograd function whose output is its slice view
+    # of the blob -- a plain buffer outside the graph -- and _ConcatInPlace ties the slices together for the consumer: no Concat copy in a
+    # training step either.
+    training = torch.is_grad_enabled() and (x.requires_grad or _any_requires_grad(P))
     if (backend is not None and hasattr(backend, "conv_mfma_relu") and x.is_cuda and w.shape[2] in (3, 5)
-            and not (torch.is_grad_enabled() and (x.requires_grad or _any_requires_grad(P)))):
+            and (not training or (CONCAT_IN_PLACE_TRAINING[0] and hasattr(backend, "conv_backward")))):
         k = w.shape[2]
         ho, wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
         blob = torch.empty((x.shape[0], w.shape[0] + extra_channels, ho, wo), device=x.device, dtype=x.dtype)
-        if backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0) is not None:
-            return blob, blob[:, :w.shape[0]]
+        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0)
+        if y is not None:
+            return blob, (y if (training and y.requires_grad) else blob[:, :w.shape[0]])
     return None, _conv(x, P, name, stride, pad, backend=backend)
 
 
@@ -198,16 +201,21 @@ def _any_requires_grad(P) -> bool:
     return any(v.requires_grad for v in vals)
 
 
-def _stage_deconv(P, x, dname, blob, cs, cd, backend):
-    """ReLU(deconv(x)) written into channels [cs, cs + cd) of a refinement stage's Concat blob."""
+def _stage_deconv(P, x, dname, blob, cs, cd, backend, allow_copy=True):
+    """ReLU(deconv(x)) written into channels [cs, cs + cd) of a refinement stage's Concat blob.  Returns what the kernel wrapper
+    returned (with autograd: the slice view that carries the graph), or None after the copy fallback."""
     d = None
+    w = P[dname + ".w"]
+    training = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
     if hasattr(backend, "deconv_mfma_relu"):
-        d = backend.deconv_mfma_relu(x, P[dname + ".w"], P[dname + ".b"], NEG_SLOPE, True, out=blob, out_c0=cs)
-    if d is None and hasattr(backend, "deconv_gemm_relu") and P[dname + ".w"].shape[0] >= 64:
+        d = backend.deconv_mfma_relu(x, w, P[dname + ".b"], NEG_SLOPE, True, out=blob, out_c0=cs)
+    if d is None and hasattr(backend, "deconv_gemm_relu") and w.shape[0] >= 64:
         # GEMM (weight^T x bottom), then our col2im + bias + ReLU pass straight into the blob
-        d = backend.deconv_gemm_relu(x, _transposed_deconv_weight(P[dname + ".w"]), P[dname + ".b"], cd, 4, 2, 1, NEG_SLOPE, out=blob, out_c0=cs)
-    if d is None:
+        d = backend.deconv_gemm_relu(x, None if training else _transposed_deconv_weight(w), P[dname + ".b"], cd, 4, 2, 1, NEG_SLOPE,
+                                     weight=w if training else None, out=blob, out_c0=cs)
+    if d is None and allow_copy:
         blob[:, cs:cs + cd].copy_(_deconv(x, P, dname, backend=backend))
+    return d
 
 
 def _refine_stage(P, skip, x, dname, flow, uname, backend):
@@ -226,6 +234,14 @@ def _refine_stage(P, skip, x, dname, flow, uname, backend):
         return torch.cat([s, _deconv(x, P, dname, backend=backend), up(flow, uname)], 1)
     cs, cd = s.shape[1], P[dname + ".w"].shape[1]
     assert blob.shape[1] == cs + cd + 2
+    if torch.is_grad_enabled() and (s.requires_grad or x.requires_grad or flow.requires_grad):
+        # training: the three producers are autograd functions that wrote / write their slices; _ConcatInPlace hands the consumer the blob
+        d = _stage_deconv(P, x, dname, blob, cs, cd, backend, allow_copy=False)
+        u = up(flow, uname, out=blob, out_c0=cs + cd) if (d is not None and hasattr(backend, "upsample_flow_deconv")) else None
+        if d is None or u is None:          # a producer without an own kernel for this shape: the stock Concat (a copy) for this stage
+            return torch.cat([s, _deconv(x, P, dname, backend=backend), up(flow, uname)], 1)
+        part = lambda t, c0, c: t if t.requires_grad else blob[:, c0:c0 + c]      # (a frozen producer returned the blob it wrote into)
+        return _ConcatInPlace.apply(blob, s, part(d, cs, cd), part(u, cs + cd, 2))
     _stage_deconv(P, x, dname, blob, cs, cd, backend)
     if hasattr(backend, "upsample_flow_deconv"):
         up(flow, uname, out=blob, out_c0=cs + cd)
@@ -303,6 +319,28 @@ def _skip_conv(x, P, name, stride, pad, dname, backend):
     return _conv_into_concat(x, P, name, stride, pad, P[dname + ".w"].shape[1] + 2, backend)
 
 
+CONCAT_IN_PLACE_TRAINING = [True]      # A/B hook: False = torch.cat for the refinement Concats of a training graph (rounds 1-4)
+
+
+class _ConcatInPlace(torch.autograd.Function):
+    """Concat (concat_layer.cu:8-52 / :62-90) of tensors that already ARE consecutive channel slices of `blob`: nothing to copy forward, the
+    gradient of each is its slice of top_diff (a view: the producers' backward kernels read it in place)."""
+
+    @staticmethod
+    def forward(ctx, blob, *parts):
+        ctx.cuts = [p.shape[1] for p in parts]
+        assert sum(ctx.cuts) == blob.shape[1] and all(p.data_ptr() >= blob.data_ptr() for p in parts)
+        return blob.view_as(blob)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, c0 = [None], 0
+        for c in ctx.cuts:
+            out.append(g[:, c0:c0 + c])
+            c0 += c
+        return tuple(out)
+
+
 TOWER_SPLIT_OPS = [True]      # A/B hook: False = plain slices of the stacked tower batch in the training graph
 
 
@@ -347,7 +385,7 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend)
     training = TOWER_SPLIT_OPS[0] and torch.is_grad_enabled() and c2.requires_grad
     c2_first = None
-    if training and blob2 is None:
+    if training:
         c2, c2_first = _StackedAndFirstTower.apply(c2)
     c3 = _conv(c2, P, "conv3", 2, 2, backend=backend)
     c3a, c3b = _SplitTowers.apply(c3) if (training and c3.requires_grad) else (c3[:n], c3[n:])
@@ -377,7 +415,8 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     blob5, c51 = _skip_conv(c5, P, "conv5_1", 1, 1, "deconv5", backend)
     c6 = _conv(c51, P, "conv6", 2, 1, backend=backend)
     c61 = _conv(c6, P, "conv6_1", 1, 1, backend=backend)
-    skip2 = (blob2[:n], c2[:n]) if blob2 is not None else (c2_first if c2_first is not None else c2[:n])
+    c2s = c2_first if c2_first is not None else c2[:n]
+    skip2 = (blob2[:n], c2s) if blob2 is not None else c2s
     return _decoder(P, c61, (blob5, c51), (blob4, c41), (blob3, c31), skip2, backend)
 
 

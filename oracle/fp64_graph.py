@@ -148,6 +148,22 @@ class record_relu_branches:
                 self.branches.append(("relu", (out[:, out_c0:out_c0 + nch].detach() > 0).cpu()))
             return r
         Fn.correlation_relu_into = correlation_relu_into
+        # the layers that write straight into a refinement stage's Concat blob (nets._conv_into_concat, nets._stage_deconv: inference, and
+        # since round 5 the training graph too) do not pass through nets._conv / nets._deconv: record them where they run
+        self._cic, self._sd = nets._conv_into_concat, nets._stage_deconv
+
+        def conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
+            blob, y = self._cic(x, P, name, stride, pad, extra_channels, backend)
+            if blob is not None:                                # (else the fallback went through nets._conv above)
+                self.branches.append((name, (y.detach() > 0).cpu()))
+            return blob, y
+
+        def stage_deconv(P, x, dname, blob, cs, cd, backend, **kw):
+            d = self._sd(P, x, dname, blob, cs, cd, backend, **kw)
+            if d is not None:                                   # (else the copy fallback went through nets._deconv above)
+                self.branches.append((dname, (blob[:, cs:cs + cd].detach() > 0).cpu()))
+            return d
+        nets._conv_into_concat, nets._stage_deconv = conv_into_concat, stage_deconv
         nets._conv, nets._deconv, F.leaky_relu = conv, deconv, leaky_relu
         return self
 
@@ -156,6 +172,7 @@ class record_relu_branches:
         from flownet2_amd import nets
         from flownet2_amd import functional as Fn
         nets._conv, nets._deconv, F.leaky_relu = self._oc, self._od, self._lr
+        nets._conv_into_concat, nets._stage_deconv = self._cic, self._sd
         Fn.correlation_relu_into = self._cri
         return False
 
