@@ -17,7 +17,6 @@ import math
 import weakref
 from typing import Dict, Optional
 
-import os as _os
 
 import torch
 import torch.nn.functional as F
@@ -250,16 +249,6 @@ def _refine_stage(P, skip, x, dname, flow, uname, backend):
     return blob
 
 
-_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
-
-
-def _side_stream(device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _SIDE_STREAMS:
-        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[idx]
-
-
 def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
     """The refinement stages.  Every skip argument is a tensor or a pair (concat blob, tensor) from _conv_into_concat: with a blob the
     Concat layer (concat_layer.cu:8-52) has nothing to copy -- the skip convolution already wrote its channels there, and the
@@ -274,33 +263,10 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
     def stage(skip, x, dname, flow, uname):
         return _refine_stage(P, skip, x, dname, flow, uname, backend)
 
-    levels = [(conv5_1, "deconv5", "upsample_flow6to5", "Convolution1", 6), (conv4_1, "deconv4", "upsample_flow5to4", "Convolution2", 5),
-              (conv3_1, "deconv3", "upsample_flow4to3", "Convolution3", 4), (conv2, "deconv2", "upsample_flow3to2", "Convolution4", 3)]
-    if (conv6_1.is_cuda and not torch.is_grad_enabled() and _os.environ.get("FN2_HEAD_STREAM", "0") == "1"
-            and hasattr(backend, "predict_flow_conv") and hasattr(backend, "upsample_flow_deconv")
-            and all(isinstance(sk, tuple) and sk[0] is not None for sk, *_ in levels)):
-        # Inference with every Concat blob in place: at each level the flow head (predict_flow of the level above + its upsample_flow:
-        # three small kernels that cannot fill the chip) and the deconvolution (a GEMM + col2im that can) read the same tensor and write
-        # disjoint channel slices of the same blob -- with FN2_HEAD_STREAM=1 the head runs on a second HIP stream beside the deconvolution
-        # and the two join before the next level reads the blob.  Same kernels, same arguments, same bits (tests/test_prototxt.py against the
-        # layer-by-layer executor).  MEASURED AND NOT ADOPTED (round 4, off by default): 2.366 ms per FlowNetC step against 2.343 without
-        # (FlowNet2 b4 10.71 / 10.64, b1 5.90 / 5.83): the four fork / join event pairs cost more than the ~90 us of head kernels can hide
-        # behind GEMMs that already fill every CU.
-        main, side = torch.cuda.current_stream(conv6_1.device), _side_stream(conv6_1.device)
-        flows, x = {}, conv6_1
-        for skip, dname, uname, pname, lvl in levels:
-            blob, sk = skip
-            cs, cd = sk.shape[1], P[dname + ".w"].shape[1]
-            side.wait_stream(main)                                   # x (and the blob's skip slice) are complete
-            with torch.cuda.stream(side):
-                flow = pf(x, pname)
-                backend.upsample_flow_deconv(flow, P[uname + ".w"], P[uname + ".b"], out=blob, out_c0=cs + cd)
-            _stage_deconv(P, x, dname, blob, cs, cd, backend)        # on the main stream, concurrently
-            main.wait_stream(side)
-            flow.record_stream(main)                                 # allocated on the side stream, handed to the caller on the main one
-            flows[lvl], x = flow, blob
-        flows[2] = pf(x, "Convolution5")
-        return flows
+    # (Round 4 measured the flow head of every level on a second HIP stream beside that level's deconvolution: 2.366 ms per FlowNetC step against
+    # 2.343 without -- the fork / join event pairs cost more than ~90 us of head kernels can hide behind GEMMs that fill every CU.  The branch was
+    # removed in round 5; what a second stream pays for is LONG independent chains: FlowNet-SD beside the CSS stack, weight gradients beside data
+    # gradients.)
 
     flow6 = pf(conv6_1, "Convolution1")
     c5 = stage(conv5_1, conv6_1, "deconv5", flow6, "upsample_flow6to5")
