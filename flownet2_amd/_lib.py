@@ -23,7 +23,7 @@ EXPORTS = [
     "fn2_downsample_forward",
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward", "fn2_upsample_flow_deconv_forward_into",
     "fn2_predict_flow_conv_backward_supported", "fn2_predict_flow_conv_backward_workspace_bytes", "fn2_predict_flow_conv_backward", "fn2_upsample_flow_deconv_backward_workspace_bytes", "fn2_upsample_flow_deconv_backward",
-    "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward", "fn2_bias_leaky_relu_backward_slices",
+    "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward", "fn2_bias_leaky_relu_backward_slices", "fn2_bias_leaky_relu_backward_slices2",
     "fn2_conv_k7s2_relu_supported", "fn2_conv_k7s2_relu_forward",
     "fn2_conv_k7s2_wgrad_supported", "fn2_conv_k7s2_wgrad_ksplit", "fn2_conv_k7s2_wgrad_workspace_bytes", "fn2_conv_k7s2_wgrad",
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_pack_weights_view", "fn2_conv_mfma_forward",
@@ -161,6 +161,7 @@ def lib():
     L.fn2_bias_leaky_relu_backward_workspace_bytes.restype = sz
     L.fn2_bias_leaky_relu_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, C.c_float, vp, sz, vp]
     L.fn2_bias_leaky_relu_backward_slices.argtypes = [fp, fp, i, i, fp, fp, i, i, i, i, C.c_float, vp, sz, vp]
+    L.fn2_bias_leaky_relu_backward_slices2.argtypes = [fp, i, i, fp, i, i, fp, fp, i, i, i, i, C.c_float, vp, sz, vp]
     L.fn2_conv_k7s2_relu_supported.argtypes = [i, i, i, i]
     L.fn2_im2col_forward.argtypes = [fp, fp, i, i, i, i, i, i, i, vp]
     L.fn2_col2im_bias_relu_forward.argtypes = [fp, fp, fp, i, i, i, i, i, i, i, i, C.c_float, vp]

@@ -46,16 +46,17 @@ constexpr int kBwdChunks = 8;      // blocks per (n, c) plane
 template <bool MASK>
 __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restrict__ top_data, const float* __restrict__ top_diff,
                                                            float* __restrict__ bottom_diff, float* __restrict__ partial,
-                                                           unsigned hw, float slope, int C, int dctot, int dc0) {
+                                                           unsigned hw, float slope, int C, int dctot, int dc0, int yctot, int yc0) {
   __shared__ float red[4];
   const unsigned plane = blockIdx.y;
   const size_t base = (size_t)plane * hw;
   const size_t dbase = ((size_t)(plane / (unsigned)C) * dctot + dc0 + plane % (unsigned)C) * hw;
+  const size_t ybase = ((size_t)(plane / (unsigned)C) * yctot + yc0 + plane % (unsigned)C) * hw;       // top_data may be a channel slice too
   float acc = 0.f;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < hw; i += gridDim.x * 256u) {
     float g = top_diff[dbase + i];
     if constexpr (MASK) {
-      g *= top_data[base + i] > 0.f ? 1.f : slope;
+      g *= top_data[ybase + i] > 0.f ? 1.f : slope;
       bottom_diff[base + i] = g;
     }
     acc += g;
@@ -98,8 +99,16 @@ FN2_API size_t fn2_bias_leaky_relu_backward_workspace_bytes(int N, int C, int H,
 FN2_API int fn2_bias_leaky_relu_backward_slices(const float* top_data, const float* top_diff, int diff_channels, int diff_c0,
                                                 float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope,
                                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return fn2_bias_leaky_relu_backward_slices2(top_data, C, 0, top_diff, diff_channels, diff_c0, bottom_diff, bias_diff, N, C, H, W, negative_slope,
+                                              workspace, workspace_bytes, stream);
+}
+
+FN2_API int fn2_bias_leaky_relu_backward_slices2(const float* top_data, int data_channels, int data_c0, const float* top_diff, int diff_channels,
+                                                 int diff_c0, float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope,
+                                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (N < 0 || C <= 0 || H <= 0 || W <= 0) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: bad shape [%d,%d,%d,%d]", N, C, H, W);
   if (diff_c0 < 0 || diff_c0 + C > diff_channels) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: top_diff slice outside its blob");
+  if (data_c0 < 0 || data_c0 + C > data_channels) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: top_data slice outside its blob");
   if (N == 0) return FN2_OK;
   if (!top_data || !top_diff || !bottom_diff) return fail(FN2_ERR_INVALID_ARG, "bias_leaky_relu_backward: null blob");
   const long long planes = (long long)N * C, hw = (long long)H * W;
@@ -109,7 +118,7 @@ FN2_API int fn2_bias_leaky_relu_backward_slices(const float* top_data, const flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(bias_leaky_relu_bwd<true>, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
-                     (unsigned)hw, negative_slope, C, diff_channels, diff_c0);
+                     (unsigned)hw, negative_slope, C, diff_channels, diff_c0, data_channels, data_c0);
   if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks, 0);
   return check_launch("bias_leaky_relu_backward");
 }
@@ -127,7 +136,7 @@ FN2_API int fn2_conv_backward_bias(const float* top_diff, int diff_channels, int
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(bias_leaky_relu_bwd<false>, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, nullptr, top_diff, nullptr, partial,
-                     (unsigned)hw, 1.0f, C, diff_channels, diff_c0);
+                     (unsigned)hw, 1.0f, C, diff_channels, diff_c0, C, 0);
   hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks, accumulate);
   return check_launch("conv_backward_bias");
 }

@@ -441,13 +441,18 @@ class _OwnForwardConv(torch.autograd.Function):
             co = weight.shape[1] if transposed else weight.shape[0]
             y = into[0][:, into[1]:into[1] + co]
         ctx.cfg = (stride, pad, negative_slope, act, bias is not None, transposed)
-        ctx.save_for_backward(x, weight, y if act else None)
+        ctx.into = into
+        # the activated output is needed for the ReLU mask: a slice of a Concat blob is kept as the BLOB (a saved view comes back from autograd
+        # as a plain strided tensor that has forgotten its base: reading it in place needs the blob and the offset)
+        ctx.save_for_backward(x, weight, (into[0] if into is not None else y) if act else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
         stride, pad, slope, act, has_bias, transposed = ctx.cfg
+        if act and ctx.into is not None:
+            y = (y, ctx.into[1], w.shape[1] if transposed else w.shape[0])          # (blob, first channel, channels)
         gx, gw, db = conv_backward(x, w, y if act else None, g, stride, pad, slope, transposed, bool(ctx.needs_input_grad[0]),
                                    bool(ctx.needs_input_grad[1]), has_bias and ctx.needs_input_grad[2])
         return gx, gw, db, None, None, None, None, None, None, None
@@ -517,6 +522,9 @@ def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, ne
     if y is not None:
         # the gradient of a Concat arrives as a channel-slice view of the Concat's top_diff: read in place (no .contiguous() copy)
         gb, g0 = _channel_slice(g)
+        if not isinstance(y, tuple):                    # (a tuple: an output that lives in its consumer's Concat blob, read in place too)
+            yb, y0 = _channel_slice(y)
+            y = (yb, y0, y.shape[1])
         d, db = ops.bias_leaky_relu_backward(y, (gb, g0, g.shape[1]), slope, need_b)
     else:
         g = g.contiguous()

@@ -897,19 +897,20 @@ def col2im_bias_relu_forward(col, bias, N, Cc, H, W, kernel, pad, stride, relu=T
 
 
 def bias_leaky_relu_backward(top_data, top_diff, negative_slope=0.1, need_bias_diff=True):
-    """(bottom_diff, bias_diff): gradient of x -> leaky_relu(x + bias) given the OUTPUT blob and its gradient.  top_diff may be a channel
-    slice (blob, c0, C) of a wider blob -- the gradient a Concat hands its bottoms -- and is then read in place."""
-    y = _chk(top_data, "top.data")
+    """(bottom_diff, bias_diff): gradient of x -> leaky_relu(x + bias) given the OUTPUT blob and its gradient.  Either may be a channel slice
+    (blob, c0, C) of a wider blob -- the gradient a Concat hands its bottoms; an output that was written straight into its consumer's Concat
+    blob -- and is then read in place."""
+    y, yctot, yc0, Cc = _as_slice(top_data, "top.data")
     g, gctot, gc0, gC = _as_slice(top_diff, "top.diff")
-    N, Cc, H, W = y.shape
+    N, _, H, W = y.shape
     if gC != Cc or g.shape[0] != N or tuple(g.shape[2:]) != (H, W):
         raise ValueError("top.data and top.diff must have the same shape")
-    d = torch.empty_like(y)
+    d = torch.empty((N, Cc, H, W), device=y.device, dtype=torch.float32)
     db = torch.empty(Cc, device=y.device, dtype=torch.float32) if need_bias_diff else None
     nbytes = _lib.lib().fn2_bias_leaky_relu_backward_workspace_bytes(N, Cc, H, W)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=y.device)
-    check(_lib.lib().fn2_bias_leaky_relu_backward_slices(_ptr(y), _ptr(g), gctot, gc0, _ptr(d), _ptr(db), N, Cc, H, W,
-                                                         C.c_float(float(negative_slope)), _ptr(ws), nbytes, _stream()))
+    check(_lib.lib().fn2_bias_leaky_relu_backward_slices2(_ptr(y), yctot, yc0, _ptr(g), gctot, gc0, _ptr(d), _ptr(db), N, Cc, H, W,
+                                                          C.c_float(float(negative_slope)), _ptr(ws), nbytes, _stream()))
     return d, db
 
 

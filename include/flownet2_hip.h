@@ -319,6 +319,11 @@ int fn2_bias_leaky_relu_backward(const float* top_data, const float* top_diff, f
 int fn2_bias_leaky_relu_backward_slices(const float* top_data, const float* top_diff, int diff_channels, int diff_c0,
                                         float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope,
                                         void* workspace, size_t workspace_bytes, void* stream);
+/* ... and with top_data = channels [data_c0, data_c0 + C) of a [N, data_channels, H, W] blob as well: a layer whose output was written straight
+ * into its consumer's Concat blob (the refinement stages of a training graph, round 5). */
+int fn2_bias_leaky_relu_backward_slices2(const float* top_data, int data_channels, int data_c0, const float* top_diff, int diff_channels,
+                                         int diff_c0, float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope,
+                                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stem convolution of the FlowNet encoders, fused with its bias and ReLU:

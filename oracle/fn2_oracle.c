@@ -1546,6 +1546,23 @@ FN2_API int fn2_bias_leaky_relu_backward_cpu(const float* top_data, const float*
   return FN2_OK;
 }
 
+FN2_API int fn2_bias_leaky_relu_backward_slices_cpu(const float* top_data, const float* top_diff, int diff_channels, int diff_c0,
+                                                    float* bottom_diff, float* bias_diff, int N, int C, int H, int W, float negative_slope);
+/* ... with top_data a channel slice of a wider blob as well. */
+FN2_API int fn2_bias_leaky_relu_backward_slices2_cpu(const float* top_data, int data_channels, int data_c0, const float* top_diff,
+                                                     int diff_channels, int diff_c0, float* bottom_diff, float* bias_diff, int N, int C, int H,
+                                                     int W, float negative_slope) {
+  if (N < 0 || C < 1 || H < 1 || W < 1 || data_c0 < 0 || data_c0 + C > data_channels) return FN2_ERR_INVALID_ARG;
+  const size_t hw = (size_t)H * W;
+  float* y = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * C * hw);
+  if (!y) return FN2_ERR_INVALID_ARG;
+  for (int n = 0; n < N; ++n)
+    memcpy(y + (size_t)n * C * hw, top_data + ((size_t)n * data_channels + data_c0) * hw, sizeof(float) * C * hw);
+  const int rc = fn2_bias_leaky_relu_backward_slices_cpu(y, top_diff, diff_channels, diff_c0, bottom_diff, bias_diff, N, C, H, W, negative_slope);
+  free(y);
+  return rc;
+}
+
 /* Bias gradient alone: backward_cpu_bias (base_conv_layer.cpp:319-323: bias_diff += top_diff summed over the positions of every sample,
  * the GEMV's beta = 1); top_diff may be a channel slice of a wider blob. */
 FN2_API int fn2_conv_backward_bias_cpu(const float* top_diff, int diff_channels, int diff_c0, float* bias_diff, int N, int C, int H, int W,
