@@ -85,13 +85,38 @@ def correlation(b0, b1, pad=0, kernel_size=1, max_displacement=0, stride_1=1, st
     return _Correlation.apply(b0.contiguous(), b1.contiguous(), p)
 
 
-def correlation_relu_into(b0, b1, out, out_c0, negative_slope, pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1):
+class _CorrelationReluInto(torch.autograd.Function):
+    """Correlation + ReLU written into a channel slice of the consumer's Concat blob, with autograd: the backward pass undoes the ReLU from the
+    activated planes where they lie (csrc/bias_act.hip reads both slices in place) and runs the correlation's own backward kernels."""
+
+    @staticmethod
+    def forward(ctx, b0, b1, params, blob, c0, slope):
+        ops.correlation_forward(params, b0, b1, out=blob, out_c0=c0, relu=True, negative_slope=slope)
+        tc = ops.correlation_out_shape(params, b0.shape[1], b0.shape[2], b0.shape[3])[0]
+        ctx.cfg = (params, c0, tc, slope)
+        ctx.save_for_backward(b0, b1, blob)
+        return blob[:, c0:c0 + tc]
+
+    @staticmethod
+    def backward(ctx, g):
+        b0, b1, blob = ctx.saved_tensors
+        params, c0, tc, slope = ctx.cfg
+        gb, g0 = _channel_slice(g)
+        d, _ = ops.bias_leaky_relu_backward((blob, c0, tc), (gb, g0, tc), slope, False)
+        d0, d1 = ops.correlation_backward(params, b0, b1, d, need0=ctx.needs_input_grad[0], need1=ctx.needs_input_grad[1])
+        return d0, d1, None, None, None, None
+
+
+def correlation_relu_into(b0, b1, out, out_c0, negative_slope, pad=0, kernel_size=1, max_displacement=0, stride_1=1, stride_2=1, training=False):
     """Correlation + ReLU{negative_slope} written into the channel slice [out_c0, out_c0 + topC) of `out`: the cost volume lands
-    in the [conv_redir | corr] blob conv3_1 reads, without the separate activation and concat passes.  Inference only
-    (returns None when autograd needs the unfused graph)."""
-    if torch.is_grad_enabled() and (b0.requires_grad or b1.requires_grad):
-        return None
+    in the [conv_redir | corr] blob conv3_1 reads, without the separate activation and concat passes.  With autograd: only when the caller
+    asks for the graph-carrying form (training=True: the returned slice view carries the graph, nets._ConcatInPlace ties it to the blob);
+    otherwise None (the caller builds the unfused graph)."""
     p = ops.corr_params(pad, kernel_size, max_displacement, stride_1, stride_2, ops.MULTIPLY)
+    if torch.is_grad_enabled() and (b0.requires_grad or b1.requires_grad):
+        if not training:
+            return None
+        return _CorrelationReluInto.apply(b0.contiguous(), b1.contiguous(), p, out, out_c0, negative_slope)
     return ops.correlation_forward(p, b0.contiguous(), b1.contiguous(), out=out, out_c0=out_c0, relu=True, negative_slope=negative_slope)
 
 

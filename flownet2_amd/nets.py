@@ -195,6 +195,12 @@ def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
     return None, _conv(x, P, name, stride, pad, backend=backend)
 
 
+def _conv_into(x, P, name, stride, pad, blob, c0, backend):
+    """Convolution + bias + ReLU written into channels [c0, c0 + Cout) of `blob` by the own kernels, as an autograd function when a gradient
+    is needed (the returned slice view carries the graph); None when no own kernel takes the layer."""
+    return backend.conv_mfma_relu(x, P[name + ".w"], P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=c0)
+
+
 def _any_requires_grad(P) -> bool:
     vals = P.P.values() if isinstance(P, _Prefixed) else P.values()
     return any(v.requires_grad for v in vals)
@@ -361,8 +367,19 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
         # the correlation writes its 441 activated planes straight into the [conv_redir | corr] blob (no ReLU pass, no Concat pass), and
         # conv_redir (1x1: the own MFMA GEMM kernel) its 32 channels in front of them
         cat = torch.empty((n, cr + 441, c3a.shape[2], c3a.shape[3]), device=c3a.device, dtype=c3a.dtype)
-        if backend.correlation_relu_into(c3a, c3b, cat, cr, NEG_SLOPE, pad=20, kernel_size=1, max_displacement=20,
-                                         stride_1=1, stride_2=2) is None:
+        in_graph = (CONCAT_IN_PLACE_TRAINING[0] and torch.is_grad_enabled() and (c3a.requires_grad or c3b.requires_grad)
+                    and hasattr(backend, "conv_backward"))
+        if in_graph:
+            # training: both producers are autograd functions that write their slice of the blob (the fused correlation + ReLU; conv_redir)
+            redir = _conv_into(c3a, P, "conv_redir", 1, 0, cat, 0, backend)
+            corr = backend.correlation_relu_into(c3a, c3b, cat, cr, NEG_SLOPE, pad=20, kernel_size=1, max_displacement=20, stride_1=1, stride_2=2,
+                                                 training=True)
+            if redir is not None and redir.requires_grad:
+                cat = _ConcatInPlace.apply(cat, redir, corr)
+            else:                                       # conv_redir without an own kernel for this shape (or frozen): the stock Concat
+                cat = torch.cat([_conv(c3a, P, "conv_redir", 1, 0, backend=backend), corr], 1)
+        elif backend.correlation_relu_into(c3a, c3b, cat, cr, NEG_SLOPE, pad=20, kernel_size=1, max_displacement=20,
+                                           stride_1=1, stride_2=2) is None:
             cat = None
         else:
             into = None

@@ -163,6 +163,15 @@ class record_relu_branches:
             if d is not None:                                   # (else the copy fallback went through nets._deconv above)
                 self.branches.append((dname, (blob[:, cs:cs + cd].detach() > 0).cpu()))
             return d
+        self._ci = nets._conv_into
+
+        def conv_into(x, P, name, stride, pad, blob, c0, backend):
+            y = self._ci(x, P, name, stride, pad, blob, c0, backend)
+            if y is not None:
+                co = P[name + ".w"].shape[0]
+                self.branches.append((name, (blob[:, c0:c0 + co].detach() > 0).cpu()))
+            return y
+        nets._conv_into = conv_into
         nets._conv_into_concat, nets._stage_deconv = conv_into_concat, stage_deconv
         nets._conv, nets._deconv, F.leaky_relu = conv, deconv, leaky_relu
         return self
@@ -173,6 +182,7 @@ class record_relu_branches:
         from flownet2_amd import functional as Fn
         nets._conv, nets._deconv, F.leaky_relu = self._oc, self._od, self._lr
         nets._conv_into_concat, nets._stage_deconv = self._cic, self._sd
+        nets._conv_into = self._ci
         Fn.correlation_relu_into = self._cri
         return False
 
