@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--corr-iters", type=int, default=200)
     ap.add_argument("--bucket-mb", type=int, default=48, help="gradient all-reduce bucket size (train mode)")
     ap.add_argument("--wgrad-side-pixels", type=int, default=36000, help="train mode, one rank: weight gradients of maps up to this many pixels on a second HIP stream (0 = off)")
-    ap.add_argument("--sd-stream", choices=["on", "off"], default="on", help="FlowNet2: FlowNet-SD on a second stream beside the CSS stack (nets.set_sd_side_stream)")
+    ap.add_argument("--sd-stream", choices=["auto", "on", "off"], default="auto", help="FlowNet2: FlowNet-SD on a second stream beside the CSS stack (nets.set_sd_side_stream)")
     return ap.parse_args()
 
 
@@ -375,6 +375,13 @@ def flownet2_epe_vs_cpu(P_cpu, img0, img1, flow_gpu):
     return float(((flow_gpu.cpu() - ref) ** 2).sum(1).sqrt().mean()), time.time() - t0
 
 
+def _sd_on(args, shape):
+    if args.sd_stream != "auto":
+        return args.sd_stream == "on"
+    picks = [v for k, v in nets.sd_side_stream_picks().items() if k[1] == tuple(shape)]
+    return bool(picks[-1]) if picks else True
+
+
 def extras(device, args):
     """BASELINE configs 3, 5 (per-GPU leg) and 4 on the same GPU, after the headline: reported under `extra`, never as `value`."""
     ex = {}
@@ -383,13 +390,17 @@ def extras(device, args):
     # .flo bytes do not depend on the batch: batch-invariant mode)
     for key, (B, H, W, steps) in {"flownet2_768x384": (4, 384, 768, 20), "flownet2_1024x448": (1, 448, 1024, 30),
                                   "flownet2_1024x448_batch4": (4, 448, 1024, 12)}.items():
-        m = run_workload("2", "fwd", B, H, W, steps, 5, device, 1, 0)
+        # one pair per step is ~340 launches for 5 ms of GPU work on two streams: on a box with a slow host the step becomes launch-bound (5.65 ms
+        # seen once against 4.98): that leg replays a captured step (same kernels, same arguments; 4.97 against 4.98-5.00 ms on a fast host)
+        m = run_workload("2", "fwd", B, H, W, steps, 5, device, 1, 0, graph=(B == 1))
         p = step_percentiles(m["marks"])
         ex[key] = {"metric": "image-pairs/sec FlowNet2 (CSS+SD+fusion) forward at %dx%d" % (W, H), "value": round(B * steps / m["elapsed"], 2),
                    "unit": "image-pairs/s", "batch": B, "steps": steps, "warmup": 5, "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
                    "ms_per_step_p10_p50_p90": p, "dtype": "f32",
                    "conv_tflops": round(nets.flownet2_conv_flops(H, W) * B * steps / m["elapsed"] / 1e12, 2),
-                   "streams": "FlowNet-SD on a second HIP stream beside the FlowNetC -> S -> S stack" if args.sd_stream == "on" else "one"}
+                   "streams": ("FlowNet-SD on a second HIP stream beside the FlowNetC -> S -> S stack" if _sd_on(args, (B, 3, H, W)) else "one")
+                              + (" (picked by timing both layouts on the first calls)" if args.sd_stream == "auto" else ""),
+                   "launch": "hipGraph replay" if m["use_graph"] else "host launches"}
         if not args.no_cpu_baseline and not key.endswith("_batch4"):
             epe, secs = flownet2_epe_vs_cpu(m["P_cpu"], m["img0"], m["img1"], m["out"])
             ex[key]["epe_vs_cpu_oracle"] = epe

@@ -634,7 +634,7 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     if mean is None:
         mean = _const(img0.device, (0.411, 0.433, 0.45))
     if img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "resample_slices"):
-        return _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean)
+        return _flownet2_pick_streams(P, img0, img1, backend, neg_mean)
     if (ah, aw) == (H, W) and img0.is_cuda and not torch.is_grad_enabled() and hasattr(backend, "scale_shift"):
         # LINEAR Resample at equal size is the identity: scale and mean in one pass per image (two roundings, like the two layers)
         a = backend.scale_shift(img0, 1.0 / 255.0, neg_mean)
@@ -665,21 +665,60 @@ def flownet2_deploy_forward(P, img0, img1, backend, mean: Optional[torch.Tensor]
     return flow * scale.view(1, 2, 1, 1)
 
 
-_SD_STREAM = {"mode": "on", "streams": {}}
+_SD_STREAM = {"mode": "auto", "streams": {}, "picked": {}}
 
 
-def set_sd_side_stream(mode="on"):
-    """FlowNet-SD only reads the two images: it is independent of the FlowNetC -> S -> S stack until the fusion net.  "on" / True (default)
-    runs it on a second HIP stream beside that stack, "off" / False behind it.  Two LONG independent chains share the chip well -- the coarse
+def set_sd_side_stream(mode="auto"):
+    """FlowNet-SD only reads the two images: it is independent of the FlowNetC -> S -> S stack until the fusion net.  "on" / True
+    runs it on a second HIP stream beside that stack, "off" / False behind it; "auto" (default) times both layouts on the first calls of a
+    geometry -- like the kernels time their tile variants -- and keeps the faster (on most boxes the second stream; two boxes of the pool ran
+    batch 1 SLOWER with it: 5.65-5.72 against 5.35 ms, while batch 4 gained there too).  Two LONG independent chains share the chip well -- the coarse
     layers of either net leave CUs idle, most of all at batch 1: 5.38 -> 5.00 ms at batch 1 @1024x448, 10.31 -> 10.01 ms at batch 4 @768x384,
     15.20 -> 14.75 ms at batch 4 @1024x448 (round 5) -- where a handful of small kernels beside a chip-filling GEMM did not (the flow heads on a
     second stream, round 4).  Same kernels, same bits."""
-    _SD_STREAM["mode"] = {True: "on", False: "off", "auto": "on"}.get(mode, mode)
+    _SD_STREAM["mode"] = {True: "on", False: "off"}.get(mode, mode)
+    _SD_STREAM["picked"] = {}
 
 
-def _sd_side_stream(dev, n_pixels):
+def _flownet2_pick_streams(P, img0, img1, backend, neg_mean):
+    """set_sd_side_stream: "on" / "off" as told; "auto": call 0 of a geometry runs with the second stream (lazy initialisation, the kernels'
+    own variant timing), calls 1 .. 4 alternate the two layouts between device synchronisations and are timed, then the faster one stays
+    (the second stream unless it loses by more than 1 %).  Under graph capture nothing is timed (the second stream, or what was picked)."""
+    import time
     mode = _SD_STREAM["mode"]
-    if mode == "off":
+    run = lambda side: _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean, side)
+    if mode != "auto":
+        return run(mode == "on")
+    key = (img0.device, tuple(img0.shape))
+    st = _SD_STREAM["picked"].get(key)
+    if isinstance(st, bool):
+        return run(st)
+    if torch.cuda.is_current_stream_capturing():
+        return run(True)
+    if st is None:
+        st = _SD_STREAM["picked"][key] = {"n": 0, True: [], False: []}
+    n = st["n"]
+    st["n"] += 1
+    if n == 0:
+        return run(True)
+    side = n % 2 == 1
+    torch.cuda.synchronize(img0.device)
+    t0 = time.perf_counter()
+    out = run(side)
+    torch.cuda.synchronize(img0.device)
+    st[side].append(time.perf_counter() - t0)
+    if n >= 4:
+        _SD_STREAM["picked"][key] = min(st[True]) <= 1.01 * min(st[False])
+    return out
+
+
+def sd_side_stream_picks():
+    """{(device, image shape): True / False} of the geometries "auto" has decided (bench.py reports it)."""
+    return {k: v for k, v in _SD_STREAM["picked"].items() if isinstance(v, bool)}
+
+
+def _sd_side_stream(dev, on):
+    if not on:
         return None
     st = _SD_STREAM["streams"].get(dev)
     if st is None:
@@ -687,7 +726,7 @@ def _sd_side_stream(dev, n_pixels):
     return st
 
 
-def _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean):
+def _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean, sd_beside=True):
     """The same graph on the GPU backend without its glue passes: the Concat blobs are allocated once and every producer writes its
     channel slice (fn2_*_slices), the Eltwise scalings (x20 in front of a Resample, x0.05 behind it, img0 - warped in front of a
     ChannelNorm) ride in the kernels of their neighbours with the same roundings.  Per forward this removes 7 Concat copies and 19
@@ -718,7 +757,7 @@ def _flownet2_deploy_forward_slices(P, img0, img1, backend, neg_mean):
         backend.flow_warp_slices(B, flow, out=WARPED)
         backend.channel_norm_slices(A, minus=WARPED, out=(blob, 11, 1))
 
-    side = _sd_side_stream(dev, N * ah * aw)
+    side = _sd_side_stream(dev, sd_beside)
     sd_q = None
     if side is not None:                            # FlowNet-SD beside the CSS stack (set_sd_side_stream)
         main = torch.cuda.current_stream(dev)
