@@ -45,3 +45,49 @@ def test_fusion_inputs_carry_pixels(monkeypatch):
     x = seen["x"]                                   # [img0(3), flow_sd(2), flow_css(2), |flow_sd|, |flow_css|, err_sd, err_css]
     assert x.shape[1] == 11
     assert torch.allclose(x[:, 3:5], torch.full_like(x[:, 3:5], 0.05)) and torch.allclose(x[:, 5:7], torch.full_like(x[:, 5:7], 20.0))
+
+
+def test_training_graph_helpers_have_the_gradients_of_plain_slices_and_cat():
+    """nets._SplitTowers / _StackedAndFirstTower / _ConcatInPlace (round 5: the training graph's tower split and in-place Concats) against the
+    torch ops they replace -- same values, same gradients (CPU, float64)."""
+    import torch
+    from flownet2_amd import nets
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(6, 3, 4, 5, generator=g, dtype=torch.float64, requires_grad=True)
+    wa, wb = torch.randn(3, 3, 4, 5, generator=g, dtype=torch.float64), torch.randn(3, 3, 4, 5, generator=g, dtype=torch.float64)
+    a, b = nets._SplitTowers.apply(x * 1.0)
+    (a * wa).sum().add((b * wb).sum()).backward()
+    got = x.grad.clone(); x.grad = None
+    y = x * 1.0
+    ((y[:3] * wa).sum() + (y[3:] * wb).sum()).backward()
+    assert torch.equal(got, x.grad); x.grad = None
+    # the stacked batch for the next layer AND its first tower for the skip connection
+    full, first = nets._StackedAndFirstTower.apply(x * 1.0)
+    wf = torch.randn(6, 3, 4, 5, generator=g, dtype=torch.float64)
+    ((full * wf).sum() + (first * wa).sum()).backward()
+    got = x.grad.clone(); x.grad = None
+    y = x * 1.0
+    ((y * wf).sum() + (y[:3] * wa).sum()).backward()
+    assert torch.allclose(got, x.grad, rtol=0, atol=1e-15); x.grad = None
+    # Concat of producers that wrote their slices of one blob
+    blob = torch.zeros(2, 7, 3, 3, dtype=torch.float64)
+
+    class Into(torch.autograd.Function):            # a producer in the style of functional._OwnForwardConv(into=...)
+        @staticmethod
+        def forward(ctx, t, c0):
+            blob.data[:, c0:c0 + t.shape[1]] = t * 2.0        # like the kernels: a write autograd's version counter does not see
+            return blob[:, c0:c0 + t.shape[1]]
+
+        @staticmethod
+        def backward(ctx, gg):
+            return gg * 2.0, None
+    p = torch.randn(2, 3, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    q = torch.randn(2, 4, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    wc = torch.randn(2, 7, 3, 3, generator=g, dtype=torch.float64)
+    out = nets._ConcatInPlace.apply(blob, Into.apply(p, 0), Into.apply(q, 3))
+    assert torch.equal(out, torch.cat([p.detach() * 2, q.detach() * 2], 1))
+    (out * wc).sum().backward()
+    gp, gq = p.grad.clone(), q.grad.clone()
+    p.grad = q.grad = None
+    (torch.cat([p * 2.0, q * 2.0], 1) * wc).sum().backward()
+    assert torch.equal(gp, p.grad) and torch.equal(gq, q.grad)
