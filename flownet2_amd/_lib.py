@@ -28,7 +28,7 @@ EXPORTS = [
     "fn2_conv_k7s2_wgrad_supported", "fn2_conv_k7s2_wgrad_ksplit", "fn2_conv_k7s2_wgrad_workspace_bytes", "fn2_conv_k7s2_wgrad",
     "fn2_conv_mfma_supported", "fn2_conv_mfma_packed_floats", "fn2_conv_mfma_pack_weights", "fn2_conv_mfma_pack_weights_view", "fn2_conv_mfma_forward",
     "fn2_conv_mfma_num_variants", "fn2_debug_set_conv_variant",
-    "fn2_caffemodel_index", "fn2_caffemodel_read_blob",
+    "fn2_caffemodel_index", "fn2_caffemodel_read_blob", "fn2_hdf5_index", "fn2_hdf5_read_float",
     "fn2_conv_wino_supported", "fn2_conv_wino_packed_floats", "fn2_conv_wino_pack_weights", "fn2_conv_wino_forward",
     "fn2_conv_wino_num_variants", "fn2_debug_set_wino_variant",
     "fn2_conv_plane_supported", "fn2_conv_plane_ksplit", "fn2_conv_plane_workspace_bytes", "fn2_conv_plane_forward",
@@ -64,6 +64,13 @@ class CaffemodelEntry(C.Structure):
     _fields_ = [("name_off", C.c_size_t), ("name_len", C.c_size_t), ("type_off", C.c_size_t), ("type_len", C.c_size_t),
                 ("v1_type", C.c_longlong), ("v1", C.c_int), ("blob_index", C.c_int), ("num_axes", C.c_int), ("dim", C.c_longlong * 8),
                 ("count", C.c_size_t), ("is_double", C.c_int), ("blob_off", C.c_size_t), ("blob_len", C.c_size_t)]
+
+
+class Hdf5Entry(C.Structure):
+    """fn2_hdf5_entry (include/flownet2_hip.h)."""
+    _fields_ = [("path", C.c_char * 256), ("num_axes", C.c_int), ("dim", C.c_longlong * 8), ("count", C.c_size_t), ("type_class", C.c_int),
+                ("type_size", C.c_int), ("type_signed", C.c_int), ("big_endian", C.c_int), ("layout", C.c_int), ("num_filters", C.c_int),
+                ("header_off", C.c_size_t)]
 
 
 class ConvDesc(C.Structure):
@@ -220,6 +227,8 @@ def lib():
     L.fn2_deconv_plane_forward.argtypes = [fp, fp, fp, fp] + [i] * 10 + [C.c_float, vp, sz, vp]
     L.fn2_caffemodel_index.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), i, C.POINTER(C.c_int)]
     L.fn2_caffemodel_read_blob.argtypes = [vp, sz, C.POINTER(CaffemodelEntry), fp, sz]
+    L.fn2_hdf5_index.argtypes = [vp, sz, C.POINTER(Hdf5Entry), i, C.POINTER(C.c_int)]
+    L.fn2_hdf5_read_float.argtypes = [vp, sz, C.POINTER(Hdf5Entry), fp, sz]
     ip = C.POINTER(C.c_int)
     L.fn2_datum_parse.argtypes = [vp, sz, C.POINTER(DatumView)]
     L.fn2_datum_float_data.argtypes = [vp, sz, fp, sz]

@@ -65,7 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs + ["-lz"]      # zlib: csrc/hdf5_reader.cpp (gzip chunks)
     subprocess.check_call(cmd)
     return SO
 

@@ -49,9 +49,72 @@ def read_caffemodel(data: bytes) -> "OrderedDict[str, dict]":
     return out
 
 
+class Hdf5Layers(OrderedDict):
+    """{layer name: {"type": None, "blobs": [...]}} read from a `.caffemodel.h5`: a distinct type because Net::CopyTrainedLayersFromHDF5
+    (net.cpp:823-882) treats the blobs differently from the binaryproto route -- no CustomCopyBlobs for DataAugmentation layers, a missing
+    trailing blob is fine for a shared parameter, the source may hold FEWER blobs than the layer."""
+    route = "hdf5"
+
+
+def read_caffemodel_h5(data: bytes) -> Hdf5Layers:
+    """The `data/<layer name>/<blob index>` datasets of an HDF5 weight file (Net::ToHDF5's layout, net.cpp:896-950) in the order
+    CopyTrainedLayersFromHDF5 visits them (layer groups by name, H5_INDEX_NAME; blobs by index).  Datasets outside `data/` (the `diff`
+    group a solver snapshot carries) and non-numeric dataset names are not listed.  Integer and float64 datasets come back as float32
+    like H5LTread_dataset_float converts them (util/hdf5.cpp:56-63)."""
+    L = _lib.lib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    ptr = C.c_void_p(buf.ctypes.data)
+    n = C.c_int()
+    _check(L.fn2_hdf5_index(ptr, buf.size, None, 0, C.byref(n)))
+    entries = (_lib.Hdf5Entry * max(1, n.value))()
+    _check(L.fn2_hdf5_index(ptr, buf.size, entries, n.value, C.byref(n)))
+    has_data_group = False
+    found = {}
+    for i in range(n.value):
+        e = entries[i]
+        parts = e.path.decode("utf-8").split("/")               # "", "data", layer, index
+        has_data_group |= len(parts) >= 2 and parts[1] == "data"
+        if len(parts) != 4 or parts[1] != "data" or not parts[3].isdigit() or str(int(parts[3])) != parts[3]:
+            continue
+        arr = np.empty(e.count, np.float32)
+        _check(L.fn2_hdf5_read_float(ptr, buf.size, C.byref(e), arr.ctypes.data_as(C.c_void_p), arr.size))
+        found.setdefault(parts[2], {})[int(parts[3])] = arr.reshape(tuple(int(e.dim[k]) for k in range(e.num_axes)))
+    if not has_data_group and n.value:
+        raise Fn2Error(-1, "Error reading weights: the HDF5 file has no group 'data'")                  # net.cpp:830
+    out = Hdf5Layers()
+    for name in sorted(found):                              # byte order = H5_INDEX_NAME order
+        idx = found[name]
+        # the reference probes "0", "1", ... per TARGET blob (net.cpp:853-872); a hole ends what an index-ordered list can express
+        blobs = []
+        while len(blobs) in idx:
+            blobs.append(idx[len(blobs)])
+        out[name] = {"type": None, "blobs": blobs, "num_links": len(idx)}
+    return out
+
+
+def is_hdf5_name(path: str) -> bool:
+    """Net::CopyTrainedLayersFrom's dispatch (net.cpp:804-811): a file name that ends in ".h5" goes to the HDF5 reader."""
+    return len(path) >= 3 and path.endswith(".h5")
+
+
 def load_file(path: str):
     with open(path, "rb") as f:
-        return read_caffemodel(f.read())
+        data = f.read()
+    return read_caffemodel_h5(data) if is_hdf5_name(path) else read_caffemodel(data)
+
+
+def write_caffemodel_h5(path: str, layers) -> None:
+    """Net::ToHDF5 with write_diff = false (net.cpp:896-950): group `data`, a group per layer, its blobs as contiguous float32 datasets
+    "0", "1", ... (hdf5_save_nd_dataset -> H5LTmake_dataset_float, util/hdf5.cpp:81-101).  `layers`: {layer name: [arrays]} or the dict
+    read_caffemodel / read_caffemodel_h5 return.  A minimal writer of the classic file layout (superblock v0, v1 object headers,
+    symbol-table groups: what libhdf5 writes with default libver bounds); tests/test_hdf5.py reads its files back with this package's
+    reader AND checks them against files libhdf5 itself wrote."""
+    from . import _h5write
+    norm = OrderedDict()
+    for name, v in layers.items():
+        blobs = v["blobs"] if isinstance(v, dict) else v
+        norm[name] = {str(j): np.ascontiguousarray(b, np.float32) for j, b in enumerate(blobs)}
+    _h5write.write(path, {"data": norm})
 
 
 def _same_shape(src: np.ndarray, want: Tuple[int, ...]) -> bool:

@@ -557,6 +557,28 @@ class DataAugmentationLayer(Layer):
             self.mean_pixel_ = self.mean_channel_.view(-1, 1, 1).expand(channels, ch, cw).contiguous()
         return True
 
+    def load_blobs(self, blobs):
+        """The HDF5 weight route (Net::CopyTrainedLayersFromHDF5, net.cpp:853-872): hdf5_load_nd_dataset fills blobs_[0..2] with what the file
+        stores -- no adjust_blobs, no `recompute_mean` condition, no re-derivation of one mean from the other.  A layer that does not
+        re-compute its mean never reads those blobs (.cu:593-621 is the only reader), so the loaded values only matter with
+        `recompute_mean > 0`.  The per-pixel mean must have the layer's own crop size (the reference would reshape the blob to the
+        dataset's dims and index it with its own)."""
+        import numpy as np
+        dev = getattr(self, "device_", None) or torch.device("cpu")
+        CHECK(len(blobs) <= 3, f"Incompatible number of blobs for layer {self.layer_param_.name}")                # net.cpp:849-850
+        channels, ch, cw = self.channels_, self.cropped_height_, self.cropped_width_
+        if len(blobs) >= 1:
+            self.num_iter_ = int(np.asarray(blobs[0], np.float32).reshape(-1)[0])
+        if len(blobs) >= 2:
+            b1 = np.ascontiguousarray(blobs[1], np.float32)
+            CHECK(b1.size == channels * ch * cw, "data augmentation mean: the stored per-pixel mean has another size than this layer's crop")
+            self.mean_pixel_ = torch.from_numpy(b1.reshape(channels, ch, cw).copy()).to(dev)
+        if len(blobs) >= 3:
+            b2 = np.ascontiguousarray(blobs[2], np.float32).reshape(-1)
+            CHECK(b2.size == channels, "data augmentation mean: the stored per-channel mean has another channel count")
+            self.mean_channel_ = torch.from_numpy(b2.copy()).to(dev)
+        return True
+
     def set_mean(self, per_channel=None, per_pixel=None):
         CHECK((per_channel is None) != (per_pixel is None), "give exactly one of per_channel / per_pixel")
         self.mean_ = (per_channel if per_channel is not None else per_pixel).contiguous().float()

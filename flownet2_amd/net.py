@@ -297,11 +297,14 @@ class Net:
         blob.data = src_t.reshape(want).to(device=blob.device, dtype=torch.float32).contiguous()
 
     def CopyTrainedLayersFrom(self, source) -> List[str]:
-        """`source`: a .caffemodel path, or {layer name: {"blobs": [arrays]}} (flownet2_amd.caffemodel.read_caffemodel).  Returns the
-        ignored source layer names."""
+        """`source`: a .caffemodel / .caffemodel.h5 path (a name ending in ".h5" is read as HDF5, net.cpp:804-811), or
+        {layer name: {"blobs": [arrays]}} (flownet2_amd.caffemodel.read_caffemodel / read_caffemodel_h5).  Returns the ignored source layer
+        names."""
         if isinstance(source, str):
             from . import caffemodel
             source = caffemodel.load_file(source)
+        if getattr(source, "route", None) == "hdf5":
+            return self._copy_trained_layers_from_hdf5(source)
         ignored = []
         for name, src in source.items():
             layer = self.layer_by_name(name)
@@ -316,6 +319,42 @@ class Net:
             CHECK(len(blobs) == len(layer.blobs_), f"Incompatible number of blobs for layer {name}")          # net.cpp:779-780
             for k, (dst, b) in enumerate(zip(layer.blobs_, blobs)):
                 self._copy_blob(name, k, dst, b)
+            if hasattr(layer, "note_weights_changed"):
+                layer.note_weights_changed()
+        return ignored
+
+    def _copy_trained_layers_from_hdf5(self, source) -> List[str]:
+        """Net::CopyTrainedLayersFromHDF5, net.cpp:823-882.  What differs from the binaryproto route, all of it the reference's behaviour:
+        * NO CustomCopyBlobs: a DataAugmentation layer's three blobs (iteration count, per-pixel mean, per-channel mean) are loaded as
+          they are stored, whatever `recompute_mean` says (the binaryproto route only hands them to a layer that re-computes its mean and
+          re-derives one mean from the other, data_augmentation_layer.cpp:162-205);
+        * the source may hold FEWER blobs than the layer (CHECK_LE, :849-850); a missing blob is fine when that parameter is shared with
+          an earlier layer (:859-862), otherwise "Incompatible number of blobs";
+        * hdf5_load_nd_dataset reshapes the target blob to the dataset's dims without comparing shapes (util/hdf5.cpp:49-52).  Here the
+          element COUNT must agree and the layer keeps its own shape (a [1,1,1,C] bias dataset fills a [C] blob): a count mismatch would
+          leave the reference's layer computing on a blob of the wrong size."""
+        ignored = []
+        for name, src in source.items():
+            layer = self.layer_by_name(name)
+            if layer is None:
+                ignored.append(name)                                                     # "Ignoring source layer", net.cpp:836
+                continue
+            blobs = src["blobs"]
+            if layer.layer_param_.type == "DataAugmentation":
+                layer.device_ = self.device_
+                layer.load_blobs(blobs)
+                continue
+            CHECK(src.get("num_links", len(blobs)) <= len(layer.blobs_), f"Incompatible number of blobs for layer {name}")      # :849-850
+            specs = [str(s.get("name", "")) if isinstance(s, dict) else "" for s in layer.layer_param_.param]
+            for j, dst in enumerate(layer.blobs_):
+                if j >= len(blobs):
+                    shared = j < len(specs) and specs[j] and self._owner.get(specs[j], (name,))[0] != name
+                    CHECK(shared, f"Incompatible number of blobs for layer {name}")                                              # :859-866
+                    continue
+                b = np.asarray(blobs[j])
+                CHECK(b.size == dst.count(), f"Cannot copy param {j} weights from layer '{name}'; the HDF5 dataset holds {b.size} values "
+                      f"(shape {tuple(b.shape)}), the target param {dst.count()} (shape {dst.shape_string()})")
+                dst.data = torch.from_numpy(np.ascontiguousarray(b, np.float32)).reshape(dst.shape()).to(device=dst.device, dtype=torch.float32).contiguous()
             if hasattr(layer, "note_weights_changed"):
                 layer.note_weights_changed()
         return ignored

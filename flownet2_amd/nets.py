@@ -239,8 +239,10 @@ def _refine_stage(P, skip, x, dname, flow, uname, backend):
         return torch.cat([s, _deconv(x, P, dname, backend=backend), up(flow, uname)], 1)
     cs, cd = s.shape[1], P[dname + ".w"].shape[1]
     assert blob.shape[1] == cs + cd + 2
-    if torch.is_grad_enabled() and (s.requires_grad or x.requires_grad or flow.requires_grad):
-        # training: the three producers are autograd functions that wrote / write their slices; _ConcatInPlace hands the consumer the blob
+    stage_params = [P[n] for n in (dname + ".w", dname + ".b", uname + ".w", uname + ".b")]
+    if torch.is_grad_enabled() and (s.requires_grad or x.requires_grad or flow.requires_grad or any(p.requires_grad for p in stage_params)):
+        # training (also a partial freeze whose first trainable tensors are this stage's own deconvolution / up-sampling weights): the
+        # three producers are autograd functions that wrote / write their slices; _ConcatInPlace hands the consumer the blob
         d = _stage_deconv(P, x, dname, blob, cs, cd, backend, allow_copy=False)
         u = up(flow, uname, out=blob, out_c0=cs + cd) if (d is not None and hasattr(backend, "upsample_flow_deconv")) else None
         if d is None or u is None:          # a producer without an own kernel for this shape: the stock Concat (a copy) for this stage
@@ -341,8 +343,13 @@ class _StackedAndFirstTower(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_all, g_first):
-        g_all = g_all.contiguous()
-        g_all[:g_first.shape[0]].add_(g_first)      # g_all is this node's own input (the data gradient of the one layer that read output 0)
+        # g_all is the data gradient of the ONE layer that read output 0 (conv3's transposed convolution), produced for this node alone: both
+        # outputs are locals of flownet_c_core -- nobody outside can hang a tensor hook or retain_grad on them, and a retained graph
+        # recomputes g_all on its next pass -- so the skip gradient is added in place (a clone is 146 MB of traffic per step).  A gradient
+        # that arrives as a view of something else is NOT ours to write: copy then.
+        if g_all._base is not None or not g_all.is_contiguous():
+            g_all = g_all.clone(memory_format=torch.contiguous_format)
+        g_all[:g_first.shape[0]].add_(g_first)
         return g_all
 
 

@@ -634,6 +634,35 @@ int fn2_caffemodel_index(const void* buf, size_t len, fn2_caffemodel_entry* entr
 int fn2_caffemodel_read_blob(const void* buf, size_t len, const fn2_caffemodel_entry* entry, float* dst, size_t dst_floats);
 
 /* ------------------------------------------------------------------------------------------------
+ * .caffemodel.h5 reader (host code): the datasets of an HDF5 weight file
+ *   <- Net::CopyTrainedLayersFrom dispatches on the ".h5" suffix (src/caffe/net.cpp:804-811) to CopyTrainedLayersFromHDF5
+ *      (net.cpp:823-882): group "data", one group per layer name, datasets "0", "1", ... read by hdf5_load_nd_dataset
+ *      (src/caffe/util/hdf5.cpp:9-79: H5T_FLOAT / H5T_INTEGER accepted, converted to float; the blob takes the dataset's shape).
+ *      Net::ToHDF5 (net.cpp:896-950) writes that layout with H5LTmake_dataset_float (util/hdf5.cpp:81-101).
+ *   A native walk of the file format (the image has no libhdf5): superblock v0-v3, object headers v1 / v2, old-style groups
+ *   (v1 B-tree + local heap) and compact new-style groups, contiguous / compact / chunked layouts, deflate + shuffle filters,
+ *   IEEE float32 / float64 and 1-8 byte integers of either byte order.  Dense link storage (libver=latest, > 8 links) is refused.
+ *   fn2_hdf5_index lists every dataset of the file (absolute path, name order inside a group = H5_INDEX_NAME order,
+ *   util/hdf5.cpp:168-181) -- call with max_entries 0 to size the array; fn2_hdf5_read_float copies one dataset converted to
+ *   float (dst_floats must equal its element count).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fn2_hdf5_entry {
+  char path[256];                 /* "/data/conv1/0", NUL-terminated */
+  int num_axes;
+  long long dim[8];
+  size_t count;                   /* elements */
+  int type_class;                 /* 0 = H5T_INTEGER, 1 = H5T_FLOAT, other classes are listed but not readable */
+  int type_size;                  /* bytes per element in the file */
+  int type_signed;
+  int big_endian;
+  int layout;                     /* 0 compact, 1 contiguous, 2 chunked */
+  int num_filters;
+  size_t header_off;              /* the dataset's object header in the caller's buffer */
+} fn2_hdf5_entry;
+int fn2_hdf5_index(const void* buf, size_t len, fn2_hdf5_entry* entries, int max_entries, int* num_entries);
+int fn2_hdf5_read_float(const void* buf, size_t len, const fn2_hdf5_entry* entry, float* dst, size_t dst_floats);
+
+/* ------------------------------------------------------------------------------------------------
  * CustomData sample format  (type: "CustomData"; SURVEY.md 8f row 4: the on-disk format of the training sets)
  *   An LMDB value is a serialized `Datum` (src/caffe/proto/caffe.proto:30-41) whose `data` bytes hold, plane after plane,
  *   the slices named by DataParameter.slice_point / .encoding (caffe.proto:923-927, :979-980).  The FlyingChairs sets written by

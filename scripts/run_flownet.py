@@ -2,7 +2,7 @@
 """py3 re-authoring of the reference's inference driver (scripts/run-flownet.py:1-127) on the MI355X path.
 
     python scripts/run_flownet.py model.caffemodel deploy.prototxt.template img0 img1 out.flo     # the reference's argument order
-    python scripts/run_flownet.py [--net C|S|2] [--weights w.caffemodel|w.npz] img0 img1 out.flo   # built-in graph (flownet2_amd/nets.py)
+    python scripts/run_flownet.py [--net C|S|2] [--weights w.caffemodel|w.caffemodel.h5|w.npz] img0 img1 out.flo   # built-in graph (flownet2_amd/nets.py)
 
 First form: the template's $TARGET_WIDTH$ ... $SCALE_HEIGHT$ variables are substituted exactly as run-flownet.py:38-58 does, the net
 is built layer by layer from the prototxt through the layer registry (flownet2_amd.net.Net = caffe.Net of run-flownet.py:64) and the
@@ -13,7 +13,7 @@ flownet2_amd/prototxt_templates/.
 Same behaviour as the reference script: images are read as RGB, fed as BGR raw 0..255 floats, the net runs at the
 ADAPTED (x64) size and the flow is resampled / rescaled back to the TARGET size, and the result is written as .flo.
 Differences: no prototxt template / .caffemodel (neither is in the reference tree; the graph is flownet2_amd/nets.py,
-weights are a .caffemodel read by flownet2_amd.caffemodel, a name->array .npz in Caffe blob layout, or seeded random), and no "retry up to 5x on NaN" loop -- the
+weights are a .caffemodel / .caffemodel.h5 read by flownet2_amd.caffemodel, a name->array .npz in Caffe blob layout, or seeded random), and no "retry up to 5x on NaN" loop -- the
 reference needs it for a race in its kernels (run-flownet.py:72-96); these kernels are deterministic."""
 import argparse
 import os
@@ -41,7 +41,7 @@ def load_params(net, weights, device):
     net.cpp:752-800; the DataAugmentation layers' per-channel mean comes with it) or a name -> array .npz in Caffe blob layout."""
     P = nets.init_params_flownet2(0) if net == "2" else nets.init_params(net, 0)
     mean = None
-    if weights and weights.endswith(".caffemodel"):
+    if weights and (weights.endswith(".caffemodel") or weights.endswith(".h5")):       # ".h5": the HDF5 form, dispatched like net.cpp:804-811
         from flownet2_amd import caffemodel
         found, means, ignored = caffemodel.to_params(caffemodel.load_file(weights), P)
         for k, v in found.items():
