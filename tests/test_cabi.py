@@ -39,6 +39,10 @@ def test_oracle_exports_cpu_twins():
         if name in ("fn2_conv_route", "fn2_deconv_route", "fn2_conv_forward", "fn2_deconv_forward") or name.startswith(("fn2_conv_pack", "fn2_deconv_pack", "fn2_conv_backward_data", "fn2_conv_backward_weights")):
             # descriptor-level dispatchers (csrc/conv_route.cpp): no arithmetic of their own -- every kernel they route to has its twin
             continue
+        if name.startswith("fn2_hdf5_"):
+            # the HDF5 file format is libhdf5's (a third-party dependency of the reference, absent from its tree): the reader is pinned on
+            # files libhdf5 1.10.6 wrote and on the reference's own .h5 fixtures (tests/test_hdf5.py), not on a second restatement
+            continue
         assert hasattr(L, name + "_cpu"), name + "_cpu"
 
 
