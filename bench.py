@@ -179,26 +179,28 @@ def step_percentiles(marks):
     return [pick(0.1), pick(0.5), pick(0.9)]
 
 
-def cpu_baseline(P_cpu, img0, img1, flow_gpu, budget_s=20.0):
-    """Oracle leg: the same graph on the host (C oracle ops + torch-CPU fp32 conv), bounded sample."""
+def cpu_baseline(P_cpu, img0, img1, flow_gpu, budget_s=30.0, min_reps=9):
+    """Oracle leg: the same graph on the host (C oracle ops + torch-CPU fp32 conv), bounded sample: one untimed pass (page-in, thread pools),
+    then >= 9 timed repetitions (fewer only if the budget runs out); value = pairs / MEDIAN repetition, p10 / p90 beside it -- a shared
+    256-cpu host makes single repetitions vary by 2x."""
     import oracle
     from oracle import backend as cpu_backend
     i0, i1 = img0.cpu(), img1.cpu()
     n = i0.shape[0]
     with torch.no_grad():
-        t0 = time.time()
         flow_cpu = nets.deploy_forward("C", P_cpu, i0, i1, cpu_backend)
-        first = time.time() - t0
-        reps, total = 1, first
-        while total + first < budget_s and reps < 5:
+        times, t_all = [], time.time()
+        while len(times) < min_reps and (time.time() - t_all < budget_s or len(times) < 3):
             t0 = time.time()
             nets.deploy_forward("C", P_cpu, i0, i1, cpu_backend)
-            total += time.time() - t0
-            reps += 1
+            times.append(time.time() - t0)
     epe = float(((flow_gpu.cpu() - flow_cpu) ** 2).sum(1).sqrt().mean())
     cores = max(oracle.num_threads(), torch.get_num_threads())
-    return {"value": round(n * reps / total, 3), "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x FlowNetC deploy forward, batch {n} @{i0.shape[3]}x{i0.shape[2]}: C oracle "
+    ts = sorted(times)
+    q = lambda f: ts[min(len(ts) - 1, int(f * len(ts)))]
+    return {"value": round(n / q(0.5), 3), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "value_p10_p90": [round(n / q(0.9), 3), round(n / q(0.1), 3)], "repetitions": len(ts),
+            "sample": f"median of {len(ts)} x FlowNetC deploy forward (after one untimed pass), batch {n} @{i0.shape[3]}x{i0.shape[2]}: C oracle "
                       f"(restated reference kernels, OpenMP) + torch-CPU fp32 conv; {os.cpu_count()} host cpus"}, epe
 
 
@@ -255,7 +257,8 @@ def rank_seed(rank):
 WGRAD_SIDE_PIXELS = [36000]       # --wgrad-side-pixels: GradientExchange's second stream for the weight gradients (single-rank jobs)
 
 
-def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0, rt=None, local_grads=False):
+def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_mb=48, graph=False, settle_s=1.0, rt=None, local_grads=False,
+                 force_collective=False):
     """W untimed warm-up steps (+ untimed settling steps until `settle_s` seconds of back-to-back stepping have passed: the chip
     needs ~25 ms of load to come back to its steady clocks, and a short run otherwise sits inside that ramp), then EXACTLY `steps`
     timed steps between barrier + synchronize on both sides.  Returns the measurements and what the caller needs for the oracle leg."""
@@ -278,7 +281,8 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         # identical Adam step on every rank
         # local_grads: the SAME step without the collective (every rank keeps its own gradients) -- the comparison leg from which
         # train_leg() reports how much of the all-reduce is not hidden behind backward
-        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20, local_only=local_grads, wgrad_side_pixels=WGRAD_SIDE_PIXELS[0])
+        exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20, local_only=local_grads, wgrad_side_pixels=WGRAD_SIDE_PIXELS[0],
+                                             force_collective=force_collective)
 
         def step():
             exchange.zero_grad()
@@ -362,6 +366,8 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         res["n_buckets"] = len(exchange.buckets)
         res["buckets_launched_inside_backward"] = exchange.launched_in_backward      # of the last timed step
         res["exchange_world"] = exchange.world
+        res["exchange_collective"] = exchange.collective
+        res["gradient_bytes_copied_into_buckets"] = exchange.copied_bytes          # of the last step: what was NOT produced in its bucket slot
         exchange.remove()
     return res
 
@@ -401,6 +407,9 @@ def extras(device, args):
                    "streams": ("FlowNet-SD on a second HIP stream beside the FlowNetC -> S -> S stack" if _sd_on(args, (B, 3, H, W)) else "one")
                               + (" (picked by timing both layouts on the first calls)" if args.sd_stream == "auto" else ""),
                    "launch": "hipGraph replay" if m["use_graph"] else "host launches"}
+        tm = [v for k, v in nets.sd_side_stream_timings().items() if k[1] == (B, 3, H, W)]
+        if tm:
+            ex[key]["stream_layouts_timed_ms"] = tm[-1]            # what "auto" measured on THIS box when it picked (one synchronised forward each)
         if not args.no_cpu_baseline and not key.endswith("_batch4"):
             epe, secs = flownet2_epe_vs_cpu(m["P_cpu"], m["img0"], m["img1"], m["out"])
             ex[key]["epe_vs_cpu_oracle"] = epe
@@ -421,16 +430,22 @@ def train_leg(device, world, rank, bucket_mb=48, B=8, H=320, W=448, steps=20, wa
     world-local gradients (no collective), and allreduce_ms_exposed = the difference = the part of the exchange backward does not hide."""
     m = run_workload("C", "train", B, H, W, steps, warmup, device, world, rank, bucket_mb=bucket_mb, settle_s=settle_s, rt=rt)
     ms = m["elapsed"] / steps * 1e3
-    leg = {"metric": "image-pairs/sec FlowNetC fwd+bwd+allreduce+Adam at %dx%d" % (W, H), "value": round(world * B * steps / m["elapsed"], 2),
+    mb = 4e-6 * nets.num_params(m["P_cpu"])
+    if world > 1:
+        what, coll = "fwd+bwd+allreduce+Adam", "one fp32 sum-all-reduce of %.1f MB per step in %d buckets <= %d MB over RCCL, scaled by 1/%d" % (mb, m["n_buckets"], bucket_mb, world)
+    else:
+        what, coll = "fwd+bwd+Adam", "none (world 1): no collective is issued in a single-rank job; %.1f MB of gradients stay where the kernels wrote them" % mb
+    leg = {"metric": "image-pairs/sec FlowNetC %s at %dx%d" % (what, W, H), "value": round(world * B * steps / m["elapsed"], 2),
            "unit": "image-pairs/s", "n_gpus": world, "batch": B, "global_batch": B * world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
            "ms_per_step_p10_p50_p90": step_percentiles(m["marks"]), "dtype": "f32", "loss": float(m["out"].detach()),
            "conv_tflops": round(nets.conv_flops("C", H, W) * B * 3 * steps / m["elapsed"] / 1e12, 2),
-           "parallelism": "dp%d (one fp32 sum-all-reduce of %.1f MB per step in %d buckets <= %d MB, scaled by 1/%d)" % (
-               world, 4e-6 * nets.num_params(m["P_cpu"]), m["n_buckets"], bucket_mb, world),
+           "parallelism": "dp%d" % world, "collective": coll,
            "grad_buckets": m["n_buckets"], "buckets_launched_inside_backward": m["buckets_launched_inside_backward"],
+           "gradient_bytes_copied_into_buckets": m["gradient_bytes_copied_into_buckets"],
            "library_conv_fallbacks": LIB_FALLBACKS(),
-           "streams": ("weight gradients of maps <= %d px on a second HIP stream beside the data-gradient chain" % WGRAD_SIDE_PIXELS[0])
-                      if (world == 1 and WGRAD_SIDE_PIXELS[0] > 0 and device.type == "cuda") else "one"}
+           "streams": ("weight gradients of maps <= %d px on a second HIP stream beside the data-gradient chain%s" % (
+                           WGRAD_SIDE_PIXELS[0], "; a bucket's all-reduce is ordered behind that stream" if world > 1 else ""))
+                      if (WGRAD_SIDE_PIXELS[0] > 0 and device.type == "cuda") else "one"}
     del m
     if device.type == "cuda":
         torch.cuda.empty_cache()
@@ -443,7 +458,38 @@ def train_leg(device, world, rank, bucket_mb=48, B=8, H=320, W=448, steps=20, wa
         del ml
         if device.type == "cuda":
             torch.cuda.empty_cache()
+    elif device.type == "cuda" and rt is None and not (dist.is_available() and dist.is_initialized()):
+        leg["rccl_bucket_path_world1"] = rccl_world1_leg(device, bucket_mb, B, H, W, steps, warmup, settle_s, ms)
     return leg
+
+
+def rccl_world1_leg(device, bucket_mb, B, H, W, steps, warmup, settle_s, ms_local):
+    """The exchange as a multi-rank job runs it, on the one GPU this box has: a process group of ONE rank over the "nccl" (= RCCL) backend and
+    GradientExchange forced through its full bucket path (gradients produced in the flat bucket slots, hooks, one all_reduce per bucket on
+    RCCL's stream ordered behind the weight-gradient stream, wait).  An all-reduce over one rank moves no data between GPUs: the figure is
+    the cost of the PATH (flattened gradients, collective launches, stream ordering) against the local step -- not a scaling number."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+    except Exception as e:       # noqa: BLE001 -- a box without a usable RCCL: say so instead of failing the bench line
+        return {"error": "init_process_group('nccl', world_size=1) failed: %s" % str(e)[:200]}
+    try:
+        m = run_workload("C", "train", B, H, W, steps, warmup, device, 1, 0, bucket_mb=bucket_mb, settle_s=settle_s, force_collective=True)
+        ms = m["elapsed"] / steps * 1e3
+        return {"ms_per_step": round(ms, 4), "ms_per_step_local_gradients": round(ms_local, 4), "overhead_ms": round(ms - ms_local, 4),
+                "overhead_frac": round(ms / ms_local - 1.0, 4), "grad_buckets": m["n_buckets"],
+                "buckets_launched_inside_backward": m["buckets_launched_inside_backward"],
+                "gradient_bytes_copied_into_buckets": m["gradient_bytes_copied_into_buckets"],
+                "ranks_seen_by_rccl": parallel.ranks_seen(device), "librccl_mapped": "librccl" in open("/proc/self/maps").read(),
+                "note": "backend nccl (= RCCL), world_size 1, same process: the full bucket path of parallel.GradientExchange, no inter-GPU traffic"}
+    finally:
+        dist.destroy_process_group()
+        if device.type == "cuda":
+            torch.cuda.empty_cache()
 
 
 
@@ -520,7 +566,7 @@ def main():
         pairs = world * B * args.steps
         conv_gf = (nets.conv_flops("C", H, W) if args.net == "C" else nets.flownet2_conv_flops(H, W)) * B / 1e9
         res = {
-            "metric": "image-pairs/sec " + ("FlowNetC " if args.net == "C" else "FlowNet2 (CSS+SD+fusion) ") + ("forward" if args.mode == "fwd" else "fwd+bwd+allreduce+Adam") + " at %dx%d" % (W, H),
+            "metric": "image-pairs/sec " + ("FlowNetC " if args.net == "C" else "FlowNet2 (CSS+SD+fusion) ") + ("forward" if args.mode == "fwd" else ("fwd+bwd+allreduce+Adam" if world > 1 else "fwd+bwd+Adam")) + " at %dx%d" % (W, H),
             "value": round(pairs / elapsed, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             # the same K steps timed straight after the W warm-up steps (no settling steps: clock ramp included), and what came between
@@ -530,11 +576,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("FlowNetC" if args.net == "C" else "FlowNet2") + " %s (correlation max_disp=20 stride_2=2), batch %d/GPU @%dx%d, synthetic uint8-valued "
                                    "pairs, seeded random-init weights (%.2f M params)" % ("deploy forward" if args.mode == "fwd" else "train step", B, W, H, nets.num_params(P_cpu) / 1e6),
-                       "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else "dp%d (RCCL all-reduce)" % world,
+                       "global_batch": B * world, "parallelism": "replicas x%d (no data-path collective)" % world if args.mode == "fwd" else ("dp%d (RCCL all-reduce)" % world if world > 1 else "dp1 (collective: none, world 1)"),
                        "conv_stack": CONV_STACK_NOTE + " (%.1f GFLOP/step/GPU)" % conv_gf,
                        "library_conv_fallbacks": LIB_FALLBACKS(),
                        "launch": "hipGraph replay" if m["use_graph"] else "host launches", "python_gc": "paused for the timed steps" if m["gc_paused"] else "on",
-                       "untimed_settling_steps_after_warmup": m["settle_steps"], "ranks_seen_by_rccl": ranks_seen},
+                       "untimed_settling_steps_after_warmup": m["settle_steps"],
+                       "ranks_seen_by_rccl": ranks_seen if world > 1 else "no process group (world 1)"},
             "conv_tflops": round(conv_gf * (3 if args.mode == "train" else 1) * args.steps / elapsed / 1e3, 2),
         }
         if args.mode == "fwd" and args.net == "C" and (B, H, W) == (8, 320, 448):

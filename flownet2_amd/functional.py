@@ -380,7 +380,9 @@ def _cached(cache, key, w, make):
     optimizer step (not once per use), and inference under no_grad with default nn.Parameter weights keeps its packs.  Writes through
     `.data` / a custom optimizer that is not a torch.optim.Optimizer need invalidate_weight_caches()."""
     import weakref
-    if w.requires_grad and not _HAVE_STEP_HOOK:
+    if w.requires_grad and (not _HAVE_STEP_HOOK or (w.is_cuda and torch.cuda.is_current_stream_capturing())):
+        # (under hipGraph capture a trainable weight is packed INSIDE the graph: a replayed optimizer step fires no hook, and a pack left
+        # out of the capture would serve every replay the operands of capture time)
         cache.pop(key, None)
         return make()
     gen = _WEIGHT_GENERATION[0] if w.requires_grad else -1
@@ -483,6 +485,23 @@ class _OwnForwardConv(torch.autograd.Function):
         return gx, gw, db, None, None, None, None, None, None, None
 
 
+_GRAD_SLOT = [None]          # parallel.GradientExchange with a collective: weight tensor -> its slot of the flat all-reduce bucket (or None)
+
+
+def set_grad_slots(fn=None):
+    """fn(weight) -> a fresh fp32 view shaped like `weight` into the flat bucket its gradient travels in (or None).  The weight-gradient
+    kernels then write their result THERE (fn2_conv_backward_weights' `weight_diff` pointer) and autograd moves that view into `.grad`:
+    the gradient is produced in the bucket instead of being copied into it by the hook (156.7 MB read + written per FlowNetC step)."""
+    _GRAD_SLOT[0] = fn
+
+
+def _grad_slot(w):
+    fn = _GRAD_SLOT[0]
+    if fn is None or w.grad is not None:          # a pass that ACCUMULATES adds into what is there (AccumulateGrad), not into a fresh slot
+        return None
+    return fn(w)
+
+
 _WGRAD_SIDE = {"pixels": 0, "streams": {}}
 _SIDE_TASK = [-1]           # autograd graph task the pending entries belong to
 _SIDE_PENDING = []          # (weight, address of its gradient computed under the side stream) of the running backward pass -- the address
@@ -497,8 +516,23 @@ def set_wgrad_side_stream(max_pixels: int = 0):
     backward pass ends (an autograd-engine callback; outside the engine -- the prototxt executor -- the gradient stays on the main stream).
     Constraints, checked where they can be: the weight has no gradient yet (a pass that ACCUMULATES stays on the main stream) and feeds ONE
     layer of the graph (the engine would add two gradients of a shared weight before the join); nothing reads `.grad` inside the pass
-    (gradient hooks: GradientExchange with several ranks keeps this off).  0 = off (default)."""
+    (GradientExchange's hooks with a collective only COUNT the gradients and launch a bucket's all-reduce on the side stream itself, behind
+    the kernels that produce it: side_stream_for_collective).  0 = off (default)."""
     _WGRAD_SIDE["pixels"] = int(max_pixels)
+
+
+def side_stream_for_collective(device):
+    """The stream a gradient bucket's all-reduce has to be ordered behind when weight gradients run on the second stream: that stream, made
+    to wait for everything the main stream has been given so far (bias / flow-head / stem gradients are produced there).  The collective
+    library orders its own stream behind the CURRENT stream at launch, so the caller launches under `torch.cuda.stream(side)`.  None when
+    the second stream is not in use (the collective is then ordered behind the main stream as usual)."""
+    if not _WGRAD_SIDE["pixels"]:
+        return None
+    st = _WGRAD_SIDE["streams"].get(device)
+    if st is None:
+        return None
+    st.wait_stream(torch.cuda.current_stream(device))
+    return st
 
 
 def _wgrad_side_stream(d, x, w):
@@ -624,7 +658,7 @@ def _own_bwd_weight(d, x, w, stride, pad, transposed):
         d, x = d.contiguous(), x.contiguous()           # the stem kernel reads whole blobs
     xb, x0 = _channel_slice(x)
     db, d0 = _channel_slice(d)
-    return ops.conv_backward_weights(xb, db, desc, transposed, bottom_c0=x0, top_c0=d0)
+    return ops.conv_backward_weights(xb, db, desc, transposed, out=_grad_slot(w), bottom_c0=x0, top_c0=d0)
 
 
 _PACKED_T = {}     # data-gradient packings and the deconvolution GEMM operand, keyed like _PACKED

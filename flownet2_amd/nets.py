@@ -716,7 +716,14 @@ def _flownet2_pick_streams(P, img0, img1, backend, neg_mean):
     st[side].append(time.perf_counter() - t0)
     if n >= 4:
         _SD_STREAM["picked"][key] = min(st[True]) <= 1.01 * min(st[False])
+        _SD_STREAM.setdefault("timings_ms", {})[key] = {"second_stream": round(min(st[True]) * 1e3, 4), "one_stream": round(min(st[False]) * 1e3, 4)}
     return out
+
+
+def sd_side_stream_timings():
+    """{(device, image shape): {"second_stream": ms, "one_stream": ms}}: what "auto" measured (host clock around one synchronised forward,
+    best of two per layout) when it decided -- bench.py prints it so that a box where the second stream loses leaves a record."""
+    return dict(_SD_STREAM.get("timings_ms", {}))
 
 
 def sd_side_stream_picks():

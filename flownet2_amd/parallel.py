@@ -47,28 +47,37 @@ class GradientExchange:
     """Bucketed sum-all-reduce of the fp32 gradients, overlapped with backward; result scaled by 1/world (parallel.cpp:377).
 
     * The parameters (given in forward order) are cut into flat fp32 buckets in REVERSE order -- backward produces the
-      decoder's gradients first.  With world > 1 a gradient is copied into its bucket slot the moment it is produced and `.grad`
-      becomes a view of that slot (one copy instead of zero-fill + accumulate; see zero_grad()); with one rank nothing is copied.
+      decoder's gradients first.  With a collective the weight-gradient kernels write their result straight into the bucket slot
+      (functional.set_grad_slots: `.grad` becomes a view of the slot, nothing is copied); the few gradients that are not produced
+      by those kernels (biases, the 2-channel flow heads: 0.1 % of the bytes) are copied into their slots by the hook.  Without a
+      collective (one rank) nothing is flattened or copied.
     * A post-accumulate hook per parameter counts its bucket down; the last gradient of a bucket launches that bucket's
       `all_reduce(async_op=True)`: with the "nccl" (= RCCL) backend it runs on the communicator's own HIP stream behind an
-      event on the compute stream, so the exchange of bucket k overlaps the backward kernels of buckets k+1...
+      event on the stream it is launched under, so the exchange of bucket k overlaps the backward kernels of buckets k+1...
+    * The weight gradients run on a second HIP stream beside the data-gradient chain (functional.set_wgrad_side_stream) with ANY
+      number of ranks: a bucket's all-reduce is launched under that second stream after it has been made to wait for the main
+      stream (functional.side_stream_for_collective), i.e. behind every kernel that writes into the bucket, whichever stream ran it.
     * `finish()` (after `loss.backward()`) launches what has not been launched (parameters that got no gradient this step),
       waits, and scales by 1/world.
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is per-link bound and every collective pays a
     fixed latency, so buckets are few and large (default 48 MB: FlowNetC's 156.7 MB travel as 4 buckets; the first leaves
     after the decoder, ~25 % into backward).  Gradients stay fp32 (parity with the reference)."""
 
-    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20, local_only: bool = False, wgrad_side_pixels: int = 36000):
-        """local_only: keep the gradients of this rank (no collective, no bucket copies) although the process group has several ranks --
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 48 << 20, local_only: bool = False, wgrad_side_pixels: int = 36000,
+                 force_collective: bool = False):
+        """local_only: keep the gradients of this rank (no collective, no buckets) although the process group has several ranks --
         the comparison step bench.py times to report how much of the all-reduce is NOT hidden behind backward.
-        wgrad_side_pixels: in a single-rank JOB the weight gradients of maps up to this size run on a second HIP stream beside the
-        data-gradient chain (functional.set_wgrad_side_stream; 0 = off).  With several ranks the gradient hooks below read every gradient the
-        moment it is produced, so it stays off (also for the local_only comparison leg: the two legs must differ by the collective alone)."""
+        wgrad_side_pixels: the weight gradients of maps up to this size run on a second HIP stream beside the data-gradient chain
+        (functional.set_wgrad_side_stream; 0 = off) -- with one rank and with several.
+        force_collective: run the full bucket path (slots, hooks, all_reduce on the collective library's stream, wait, scale) although the
+        process group has ONE rank -- the GPU test that executes RCCL on a single-GPU box (tests/test_parallel.py)."""
         self.params = [p for p in params if p.requires_grad]
         self.world = 1 if local_only else world()
+        self.collective = (not local_only) and (world() > 1 or (force_collective and dist.is_available() and dist.is_initialized()))
         from . import functional
-        functional.set_wgrad_side_stream(wgrad_side_pixels if world() == 1 else 0)
+        functional.set_wgrad_side_stream(wgrad_side_pixels)
         self.launched_in_backward = 0       # buckets whose all-reduce left from a gradient hook during the last backward pass
+        self.copied_bytes = 0               # gradient bytes the hooks copied into their slots during the last iteration (not produced there)
         self.buckets: List[dict] = []
         cur, size = [], 0
         for p in reversed(self.params):
@@ -87,16 +96,27 @@ class GradientExchange:
             for p in b["params"]:
                 self._index[id(p)] = bi
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        functional.set_grad_slots(self._slot if self.collective else None)
         self.reset()
 
     def _close(self, ps):
         n = sum(p.numel() for p in ps)
-        flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
-        views, off = {}, 0
+        # (one rank, no collective: the bucket is bookkeeping only -- no flat buffer is allocated)
+        flat = torch.zeros(n if self.collective else 0, dtype=ps[0].dtype, device=ps[0].device)
+        span, off = {}, 0
         for p in ps:
-            views[id(p)] = flat[off:off + p.numel()].view_as(p)
+            span[id(p)] = (off, p.numel())
             off += p.numel()
-        self.buckets.append({"params": ps, "flat": flat, "views": views, "pending": len(ps), "work": None, "launched": False})
+        self.buckets.append({"params": ps, "flat": flat, "span": span, "pending": len(ps), "work": None, "launched": False})
+
+    def _slot(self, p):
+        """A fresh view of p's slot in its bucket (fresh: autograd moves a gradient into `.grad` only when nobody else holds the tensor)."""
+        bi = self._index.get(id(p))
+        if bi is None:
+            return None
+        b = self.buckets[bi]
+        off, n = b["span"][id(p)]
+        return b["flat"][off:off + n].view(p.shape)
 
     def reset(self):
         for b in self.buckets:
@@ -105,18 +125,30 @@ class GradientExchange:
     def zero_grad(self):
         """Start an iteration: the gradients are dropped (None), not zero-filled.  The first backward pass then hands its gradient
         tensors to the parameters as they are (autograd's AccumulateGrad moves the tensor in: no fill of 157 MB, no `grad += new` pass
-        over them -- 50 + 17 launches and 0.4 ms of a FlowNetC step at batch 8), and the gradient hook copies each into its slot of the
-        flat bucket and re-points `p.grad` at that slot (world > 1: the all-reduce needs them contiguous).  Further backward passes of
-        the same iteration (no_sync) find a gradient in place and accumulate into it -- into the bucket slot, where there is one."""
+        over them -- 50 + 17 launches and 0.4 ms of a FlowNetC step at batch 8); with a collective that tensor already IS the slot of the
+        flat bucket (see _slot).  Further backward passes of the same iteration (no_sync) find a gradient in place and accumulate into
+        it -- into the bucket slot."""
         for b in self.buckets:
             for p in b["params"]:
                 p.grad = None
+        self.copied_bytes = 0
         self.reset()
 
     def _launch(self, b):
         b["launched"] = True
-        if self.world > 1:
-            b["work"] = dist.all_reduce(b["flat"], async_op=True)
+        if not self.collective:
+            return
+        from . import functional
+        flat = b["flat"]
+        side = functional.side_stream_for_collective(flat.device) if flat.is_cuda else None
+        if side is None:
+            b["work"] = dist.all_reduce(flat, async_op=True)
+        else:
+            # weight gradients of this bucket may still be running on the second stream: the collective is ordered behind THAT stream
+            # (which has just been made to wait for the main one), and the main stream -- the data-gradient chain -- is not held up
+            with torch.cuda.stream(side):
+                b["work"] = dist.all_reduce(flat, async_op=True)
+            flat.record_stream(side)
 
     def no_sync(self):
         """Context manager for gradient ACCUMULATION (iter_size > 1 in the reference's solver: several backward passes before
@@ -139,11 +171,13 @@ class GradientExchange:
         if b["launched"]:
             raise RuntimeError("GradientExchange: a gradient arrived for a bucket whose all-reduce is already in flight (a second "
                                "backward() before finish()); wrap accumulation passes in no_sync()")
-        if self.world > 1:
-            view = b["views"][id(p)]
-            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+        if self.collective and p.grad is not None:
+            off, n = b["span"][id(p)]
+            if p.grad.data_ptr() != b["flat"].data_ptr() + off * b["flat"].element_size():
+                view = self._slot(p)            # not produced in its slot (a bias, a flow head, a library fallback): one copy
                 view.copy_(p.grad)
                 p.grad = view
+                self.copied_bytes += n * b["flat"].element_size()
         if self._defer:
             return
         b["pending"] -= 1
@@ -152,23 +186,26 @@ class GradientExchange:
 
     def finish(self):
         from . import functional
-        functional.join_side_streams()          # (already done by the engine's end-of-pass callback; idempotent)
+        n = sum(1 for b in self.buckets if b["pending"] == 0)          # buckets whose exchange was launched from inside backward
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
+        functional.join_side_streams()          # (already done by the engine's end-of-pass callback; idempotent)
         for b in self.buckets:
             if b["work"] is not None:
-                b["work"].wait()
-                b["flat"].mul_(1.0 / self.world)
-        n = sum(1 for b in self.buckets if b["pending"] == 0)
+                b["work"].wait()                # the current stream waits for the collective's stream
+                if self.world > 1:
+                    b["flat"].mul_(1.0 / self.world)
         self.launched_in_backward = n
         self.reset()
-        return n           # buckets whose exchange was launched from inside backward
+        return n
 
     def remove(self):
+        from . import functional
         for h in self._handles:
             h.remove()
         self._handles = []
+        functional.set_grad_slots(None)
 
 
 def allreduce_gradients(params: Sequence[torch.Tensor], bucket_bytes: int = 256 << 20) -> None:
@@ -210,8 +247,9 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def ranks_seen(device) -> int:
-    """One all-reduce of ones: the number of ranks the collective library actually connected."""
-    if world() == 1:
+    """One all-reduce of ones: the number of ranks the collective library actually connected.  Without a process group there is no
+    collective library in the job: 1 by definition (bench.py then says `"collective": "none (world 1)"`)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return 1
     t = torch.ones(1, dtype=torch.float32, device=device)
     dist.all_reduce(t)

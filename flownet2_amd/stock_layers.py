@@ -248,8 +248,8 @@ class DeconvolutionLayer(_ConvBase):
             if (k, s, p) == (4, 2, 1):
                 bb = b if b is not None else torch.zeros(self.num_output_, device=x.device)
                 return nets.deconv_forward(x, w, bb, slope is not None, be, slope=slope)
-            y = torch.nn.functional.conv_transpose2d(x, w, b, stride=s, padding=p)
-            return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y
+            y = be.lib_conv_transpose2d(x, w, b, s, p) if hasattr(be, "lib_conv_transpose2d") else torch.nn.functional.conv_transpose2d(x, w, b, stride=s, padding=p)
+            return torch.nn.functional.leaky_relu(y, slope) if slope is not None else y       # (a geometry outside FlowNet's: COUNTED in LIBRARY_FALLBACKS)
         self._forward_all(bottom, top, one)
 
     def _head_kind(self):
@@ -314,6 +314,7 @@ class EltwiseLayer(Layer):
         self.op_ = str(ep.get("operation", "SUM"))
         CHECK(not (self.op_ == "PROD" and coeff), "Eltwise layer only takes coefficients for summation.")             # cpp:15-17
         self.coeffs_ = [float(c) for c in coeff] if coeff else [1.0] * len(bottom)
+        self.stable_prod_grad_ = bool(ep.get("stable_prod_grad", True))                                               # caffe.proto: default true
 
     def Reshape(self, bottom, top):
         for b in bottom[1:]:
@@ -350,17 +351,21 @@ class EltwiseLayer(Layer):
         for i, b in enumerate(bottom):
             if not propagate_down[i]:
                 continue
-            if self.op_ == "PROD":
-                d = g.clone()
+            if self.op_ == "PROD" and not self.stable_prod_grad_:
+                b.diff = (top[0].data / b.data) * g                    # eltwise_layer.cu:109-111: top / bottom (0 / 0 = NaN there too), then x top_diff
+            elif self.op_ == "PROD":
+                d = None                                               # :97-108: the product of the OTHER bottoms, in order, then x top_diff
                 for j, o in enumerate(bottom):
                     if j != i:
-                        d = d * o.data
-                b.diff = d
+                        d = o.data.clone() if d is None else o.data * d
+                b.diff = g.clone() if d is None else d * g
             elif self.op_ == "MAX":
-                first = torch.ones_like(g, dtype=torch.bool)
-                for j in range(i):
-                    first &= bottom[j].data < top[0].data              # the first bottom that holds the maximum takes the gradient (mask = argmax)
-                b.diff = g * ((b.data == top[0].data) & first).to(g.dtype)
+                # MaxForward (eltwise_layer.cu:10-31) keeps the running top only where it is STRICTLY greater (`a > b`, else b): on a tie the
+                # LAST bottom that holds the maximum is recorded in the mask, and MaxBackward routes the gradient by that mask
+                last = torch.ones_like(g, dtype=torch.bool)
+                for j in range(i + 1, len(bottom)):
+                    last &= bottom[j].data < top[0].data
+                b.diff = g * ((b.data == top[0].data) & last).to(g.dtype)
             else:
                 b.diff = g.clone() if self.coeffs_[i] == 1.0 else g * self.coeffs_[i]
 

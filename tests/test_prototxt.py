@@ -237,3 +237,31 @@ def test_runner_with_the_references_argument_order(tmp_path):
     subprocess.check_call([sys.executable, run, "seed:S", templates.template_path("S"), pa, pb, str(tmp_path / "proto.flo")])
     subprocess.check_call([sys.executable, run, "--net", "S", pa, pb, str(tmp_path / "builtin.flo")])
     assert open(tmp_path / "proto.flo", "rb").read() == open(tmp_path / "builtin.flo", "rb").read()
+
+
+def test_eltwise_backward_follows_the_reference_mask_and_prod_forms():
+    """EltwiseLayer::Backward (eltwise_layer.cu:68-130) through a TRAIN net: MAX hands the gradient to the LAST bottom that holds the maximum
+    (MaxForward keeps the running top only where `a > b`, :16-29), PROD is the product of the other bottoms (stable_prod_grad, the default) or
+    top / bottom."""
+    import torch
+    from flownet2_amd import net as fnet
+    from flownet2_amd.layers import LayerRegistry, LayerParameter, Blob
+
+    def run(op, vals, extra=""):
+        lp = LayerParameter(name="e", type="Eltwise", bottom=["a", "b", "c"], top=["t"], eltwise_param=dict(operation=op, **({"stable_prod_grad": False} if extra else {})))
+        layer = LayerRegistry.CreateLayer(lp)
+        bottom = [Blob.from_tensor(torch.tensor(v, dtype=torch.float32).view(1, 1, 1, -1)) for v in vals]
+        top = [Blob(device="cpu")]
+        layer.SetUp(bottom, top)
+        layer.Forward(bottom, top)
+        top[0].diff = torch.tensor([1.0, 10.0, 100.0, 1000.0]).view(1, 1, 1, -1)
+        layer.Backward(top, [True, True, True], bottom)
+        return top[0].data.view(-1).tolist(), [b.diff.view(-1).tolist() for b in bottom]
+
+    t, d = run("MAX", [[1, 5, 2, 0], [1, 5, 3, 0], [0, 5, 3, -1]])
+    assert t == [1, 5, 3, 0]
+    assert d[0] == [0, 0, 0, 0] and d[1] == [1, 0, 0, 1000] and d[2] == [0, 10, 100, 0]     # ties go to the last maximal bottom
+    t, d = run("PROD", [[1, 2, 0, 4], [2, 3, 5, 0.5], [3, 4, 7, 2]])
+    assert t == [6, 24, 0, 4] and d[0] == [6, 120, 3500, 1000] and d[1] == [3, 80, 0, 8000] and d[2] == [2, 60, 0, 2000]
+    t, d = run("PROD", [[1, 2, 2, 4], [2, 3, 5, 0.5], [3, 4, 7, 2]], extra="unstable")
+    assert d[0] == [6, 120, 3500, 1000] and d[2] == [2, 60, 1000, 2000]
