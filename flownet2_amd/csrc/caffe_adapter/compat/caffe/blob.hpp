@@ -10,6 +10,8 @@
 
 namespace caffe {
 
+const int kMaxBlobAxes = 32;      // blob.hpp:12
+
 class SyncedMemory {
  public:
   explicit SyncedMemory(size_t size) : size_(size) {}
@@ -19,8 +21,10 @@ class SyncedMemory {
   void* mutable_cpu_data() { to_cpu(); head_ = HEAD_AT_CPU; return cpu_; }
   void* mutable_gpu_data() { to_gpu(); head_ = HEAD_AT_GPU; return gpu_; }
   size_t size() const { return size_; }
+  enum SyncedHead { UNINITIALIZED, HEAD_AT_CPU, HEAD_AT_GPU, SYNCED };      // syncedmem.hpp:62-63
+  SyncedHead head() { return head_; }
  private:
-  enum Head { UNINITIALIZED, HEAD_AT_CPU, HEAD_AT_GPU, SYNCED };
+  typedef SyncedHead Head;
   void to_cpu() {
     if (!cpu_) { cpu_ = std::calloc(size_ ? size_ : 1, 1); }
     if (head_ == HEAD_AT_GPU) { CUDA_CHECK(hipMemcpy(cpu_, gpu_, size_, hipMemcpyDeviceToHost)); head_ = SYNCED; }
@@ -118,6 +122,8 @@ class Blob {
   Dtype* mutable_gpu_diff() { CHECK(diff_); return (Dtype*)diff_->mutable_gpu_data(); }
   Dtype data_at(int n, int c, int h, int w) const { return cpu_data()[offset(n, c, h, w)]; }
   Dtype diff_at(int n, int c, int h, int w) const { return cpu_diff()[offset(n, c, h, w)]; }
+  const shared_ptr<SyncedMemory>& data() const { CHECK(data_); return data_; }      // blob.hpp:209-212
+  const shared_ptr<SyncedMemory>& diff() const { CHECK(diff_); return diff_; }
   void ShareData(const Blob& other) { CHECK_EQ(count_, other.count()); data_ = other.data_; }
   void ShareDiff(const Blob& other) { CHECK_EQ(count_, other.count()); diff_ = other.diff_; }
  protected:

@@ -199,6 +199,19 @@ class ReLUParameter {
   float negative_slope_ = 0.f;
 };
 
+// ConcatParameter, caffe.proto:780-789 (the adapter's FlowNetC timing driver chains the reference's own ConcatLayer between the plug-ins)
+class ConcatParameter {
+ public:
+  int axis() const { return axis_; }
+  void set_axis(int v) { axis_ = v; has_axis_ = true; }
+  bool has_axis() const { return has_axis_; }
+  bool has_concat_dim() const { return false; }
+  unsigned concat_dim() const { return 1; }
+ private:
+  int axis_ = 1;
+  bool has_axis_ = false;
+};
+
 // ---- data layers (oracle/_ref only: the reference's CustomData layer is compiled in place to pin the sample format) ----------
 // Datum, caffe.proto:30-41.  ParseFromArray is a plain proto2 wire reader (harness code: the product's reader is
 // fn2_datum_parse, pinned against the protobuf runtime by tests/test_sample_format.py).
@@ -539,6 +552,8 @@ class LayerParameter {
   PowerParameter* mutable_power_param() { return &power_param_; }
   const ConvolutionParameter& convolution_param() const { return convolution_param_; }
   ConvolutionParameter* mutable_convolution_param() { return &convolution_param_; }
+  const ConcatParameter& concat_param() const { return concat_param_; }
+  ConcatParameter* mutable_concat_param() { return &concat_param_; }
   const ReLUParameter& relu_param() const { return relu_param_; }
   ReLUParameter* mutable_relu_param() { return &relu_param_; }
   const CoeffScheduleParameter& coeff_schedule_param() const { return coeff_schedule_param_; }   // = 148 (DataAugmentation, oracle/_ref only)
@@ -568,6 +583,7 @@ class LayerParameter {
   PowerParameter power_param_;
   ConvolutionParameter convolution_param_;
   ReLUParameter relu_param_;
+  ConcatParameter concat_param_;
 };
 
 }  // namespace caffe

@@ -404,10 +404,18 @@ class DownsampleLayer : public Layer<Dtype> {
 //      same blob shapes -- weight [num_output, C, k, k] (Deconvolution: [C, num_output, k, k]), bias [num_output] --, same top shape.
 // Scope: square kernels, group 1, dilation 1, one bottom / top pair, the geometries the library has a kernel for (every Convolution and
 // Deconvolution of the FlowNet graphs); anything else aborts in Reshape with a message naming the layer -- keep the stock class for those
-// (INTEGRATION.md shows the two-line factory that falls back to it).  The packed weight operand is rebuilt in every Forward (Caffe has no
-// "weights changed" signal below Solver::ApplyUpdate; ~20 us per layer).  Backward stays the stock layer's: training through Caffe keeps
-// BaseConvolutionLayer's GEMM gradients (or derives this class from it); the own gradient kernels are reached through the C ABI
-// (fn2_conv_wgrad, fn2_tconv_forward, ...) and the Python mirror.
+// (INTEGRATION.md shows the two-line factory that falls back to it).
+// The packed weight operand (round 6): packed ONCE and kept while the weights provably have not changed -- Caffe has no "weights changed"
+// signal below Solver::ApplyUpdate, so the layer reads what SyncedMemory already records: the operand is reused iff the layer runs in the
+// TEST phase, the weight blob's memory is SYNCED on entry (no mutable_cpu_data / mutable_gpu_data since the last const access: a
+// CopyTrainedLayersFrom, a pycaffe `net.params[...]` write or a device-side update all leave HEAD_AT_CPU / HEAD_AT_GPU), its SyncedMemory is
+// not shared with another blob (a solver's test net shares the train net's weights, Net::ShareTrainedLayersWith: those are updated behind
+// this layer's back and re-synced by snapshots), and the device pointer is the one that was packed.  Everything else -- every TRAIN-phase
+// forward -- repacks.  fn2_caffe_adapter_stats() counts packs and reuses (tests/test_caffe_adapter.py).
+// Backward_gpu (conv_layer.cu:26-60 / deconv_layer.cu:27-58) runs the library's own gradient routes; parameter diffs are accumulated.
+struct Fn2AdapterStats { long long weight_packs, weight_pack_reuses; };
+inline Fn2AdapterStats& fn2_adapter_stats() { static Fn2AdapterStats s{0, 0}; return s; }
+
 template <typename Dtype>
 class Fn2ConvolutionLayer : public Layer<Dtype> {
  public:
@@ -464,6 +472,9 @@ class Fn2ConvolutionLayer : public Layer<Dtype> {
     bwd_weights_ = fn2_conv_backward_weights_supported(&desc_, transposed_) != 0;
     const int tr = transposed_ ? 1 : 0;
     wb = std::max(wb, fn2_bias_leaky_relu_backward_workspace_bytes(desc_.N, num_output_, oh, ow));
+    head_ = transposed_ ? route_ == FN2_DECONV_ROUTE_HEAD : route_ == FN2_CONV_ROUTE_HEAD;      // the 2-channel flow heads: kernels of their own, forward and backward
+    if (head_) wb = std::max(wb, transposed_ ? fn2_upsample_flow_deconv_backward_workspace_bytes(desc_.N, desc_.Hin, desc_.Win)
+                                             : fn2_predict_flow_conv_backward_workspace_bytes(desc_.N, channels_, desc_.Hin, desc_.Win));
     wb = std::max(wb, fn2_conv_backward_weights_workspace_bytes(&desc_, tr));
     if (bwd_route_ != FN2_BWD_ROUTE_NONE) {
       wb = std::max(wb, fn2_conv_backward_data_workspace_bytes(&desc_, tr, bwd_route_));
@@ -480,17 +491,26 @@ class Fn2ConvolutionLayer : public Layer<Dtype> {
   virtual void Forward_cpu(const vector<Blob<Dtype>*>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
   virtual void Backward_cpu(const vector<Blob<Dtype>*>&, const vector<bool>&, const vector<Blob<Dtype>*>&) { NOT_IMPLEMENTED; }
   virtual void Forward_gpu(const vector<Blob<Dtype>*>& bottom, const vector<Blob<Dtype>*>& top) {
+    // decided BEFORE gpu_data() touches the head state (see the class comment)
+    const bool untouched = this->blobs_[0]->data()->head() == SyncedMemory::SYNCED && this->blobs_[0]->data().use_count() == 1;
     const float* w = f32(this->blobs_[0]->gpu_data());
     const float* b = bias_term_ ? f32(this->blobs_[1]->gpu_data()) : nullptr;
+    const bool reuse = this->phase_ == TEST && untouched && packed_for_ == w && packed_route_ == route_ && packed_count_ == packed_.count();
     float* pk = f32(packed_.mutable_gpu_data());
     void* ws = workspace_.mutable_gpu_data();
     const size_t wsb = sizeof(Dtype) * (size_t)workspace_.count();
+    if (reuse) {
+      fn2_adapter_stats().weight_pack_reuses++;
+    } else {
+      if (transposed_) FN2_CALL(fn2_deconv_pack_weights(&desc_, route_, w, pk, kStream));
+      else FN2_CALL(fn2_conv_pack_weights(&desc_, route_, w, pk, kStream));
+      packed_for_ = w; packed_route_ = route_; packed_count_ = packed_.count();
+      fn2_adapter_stats().weight_packs++;
+    }
     if (transposed_) {
-      FN2_CALL(fn2_deconv_pack_weights(&desc_, route_, w, pk, kStream));
       FN2_CALL(fn2_deconv_forward(&desc_, route_, f32(bottom[0]->gpu_data()), channels_, 0, pk, b, f32(top[0]->mutable_gpu_data()), num_output_, 0,
                                   0, 0.f, ws, wsb, kStream));
     } else {
-      FN2_CALL(fn2_conv_pack_weights(&desc_, route_, w, pk, kStream));
       FN2_CALL(fn2_conv_forward(&desc_, route_, f32(bottom[0]->gpu_data()), channels_, 0, pk, b, f32(top[0]->mutable_gpu_data()), num_output_, 0,
                                 0, 0.f, ws, wsb, kStream));
     }
@@ -502,6 +522,21 @@ class Fn2ConvolutionLayer : public Layer<Dtype> {
     const float* td = f32(top[0]->gpu_diff());
     void* ws = workspace_.mutable_gpu_data();
     const size_t wsb = sizeof(Dtype) * (size_t)workspace_.count();
+    if (head_) {
+      // predict_flow* / upsample_flow*: one call computes the three gradients (csrc/flow_head_bwd.hip); parameter diffs accumulate, NULL = not wanted
+      float* bd = propagate_down[0] ? f32(bottom[0]->mutable_gpu_diff()) : nullptr;
+      float* wd = this->param_propagate_down_[0] ? f32(this->blobs_[0]->mutable_gpu_diff()) : nullptr;
+      float* db = (bias_term_ && this->param_propagate_down_[1]) ? f32(this->blobs_[1]->mutable_gpu_diff()) : nullptr;
+      const float* w = f32(this->blobs_[0]->gpu_data());
+      if (transposed_) {
+        FN2_CALL(fn2_upsample_flow_deconv_backward(f32(bottom[0]->gpu_data()), w, td, bd, wd, db, desc_.N, desc_.Hin, desc_.Win, 1, ws, wsb, kStream));
+      } else {
+        if (!fn2_predict_flow_conv_backward_supported(desc_.N, channels_, desc_.Hin, desc_.Win))
+          LOG(FATAL) << this->layer_param_.name() << ": libflownet2_hip has no backward kernel for this flow head; keep the stock layer for it";
+        FN2_CALL(fn2_predict_flow_conv_backward(f32(bottom[0]->gpu_data()), channels_, 0, w, td, bd, wd, db, desc_.N, channels_, desc_.Hin, desc_.Win, 1, ws, wsb, kStream));
+      }
+      return;
+    }
     if (bias_term_ && this->param_propagate_down_[1])
       FN2_CALL(fn2_conv_backward_bias(td, num_output_, 0, f32(this->blobs_[1]->mutable_gpu_diff()), desc_.N, num_output_, top[0]->height(), top[0]->width(),
                                       1, ws, wsb, kStream));
@@ -520,10 +555,12 @@ class Fn2ConvolutionLayer : public Layer<Dtype> {
       FN2_CALL(fn2_conv_backward_data(&desc_, tr, bwd_route_, td, num_output_, 0, pk, f32(bottom[0]->mutable_gpu_diff()), channels_, 0, channels_, ws, wsb, kStream));
     }
   }
-  bool transposed_, bias_term_ = true, bwd_weights_ = false;
+  bool transposed_, bias_term_ = true, bwd_weights_ = false, head_ = false;
   int kernel_ = 0, stride_ = 1, pad_ = 0, num_output_ = 0, channels_ = 0, route_ = 0, bwd_route_ = 0;
   fn2_conv_desc desc_;
   Blob<Dtype> packed_, packed_bwd_, workspace_;
+  const float* packed_for_ = nullptr;      // device pointer of the weights packed_ was built from
+  int packed_route_ = -1, packed_count_ = -1;
 };
 template <typename Dtype> shared_ptr<Layer<Dtype> > Creator_Fn2Convolution(const LayerParameter& p) { return shared_ptr<Layer<Dtype> >(new Fn2ConvolutionLayer<Dtype>(p, false)); }
 template <typename Dtype> shared_ptr<Layer<Dtype> > Creator_Fn2Deconvolution(const LayerParameter& p) { return shared_ptr<Layer<Dtype> >(new Fn2ConvolutionLayer<Dtype>(p, true)); }
@@ -551,3 +588,7 @@ REGISTER_LAYER_CREATOR(Convolution, Creator_Fn2Convolution);
 REGISTER_LAYER_CREATOR(Deconvolution, Creator_Fn2Deconvolution);
 
 }  // namespace caffe
+
+// weight operands packed / reused by the Convolution and Deconvolution plug-ins of this process (the cache of Fn2ConvolutionLayer)
+extern "C" __attribute__((visibility("default"))) long long fn2_caffe_adapter_weight_packs() { return caffe::fn2_adapter_stats().weight_packs; }
+extern "C" __attribute__((visibility("default"))) long long fn2_caffe_adapter_weight_pack_reuses() { return caffe::fn2_adapter_stats().weight_pack_reuses; }

@@ -32,6 +32,10 @@ FN2_API int fn2_conv_route(const fn2_conv_desc* d, int flags) {
   const int N = inv ? 1 : d->N;
   const bool wino_first = force || inv;
   const Out o = conv_out(d);
+  // the two geometry classes with kernels of their own (round 6: reachable by descriptor, so that the Caffe adapter's Convolution plug-in
+  // serves EVERY layer of the FlowNet graphs): the 7x7 / 2 stem on 3 / 6 / 12 input channels, and the 2-channel predict_flow heads
+  if (k == 7 && s == 2 && p == 3 && fn2_conv_k7s2_relu_supported(Cin, H, W, Cout)) return FN2_CONV_ROUTE_STEM;
+  if (k == 3 && s == 1 && p == 1 && Cout == 2) return FN2_CONV_ROUTE_HEAD;
   const bool wino_ok = k == 3 && s == 1 && fn2_conv_wino_supported(Cin, H, W, Cout, p) != 0;
   // accumulator blocks of the Winograd kernel (16 channels x an 8x8-pixel block of tiles): from ~1000 on the launch fills the 1024 SIMDs and
   // it is the fastest kernel of a 3x3 / 1 layer (20x28 maps win by 1.6x, 12x24 maps lose)
@@ -52,6 +56,7 @@ FN2_API size_t fn2_conv_packed_weight_floats(const fn2_conv_desc* d, int route) 
   if (!valid(d)) return 0;
   if (route == FN2_CONV_ROUTE_WINOGRAD) return fn2_conv_wino_packed_floats(d->Cout, d->Cin);
   if (route == FN2_CONV_ROUTE_DIRECT || route == FN2_CONV_ROUTE_PLANE) return fn2_conv_mfma_packed_floats(d->Cout, d->Cin, d->kernel);
+  if (route == FN2_CONV_ROUTE_STEM || route == FN2_CONV_ROUTE_HEAD) return (size_t)d->Cout * d->Cin * d->kernel * d->kernel;    // these kernels read the blob as it is
   return 0;
 }
 
@@ -59,10 +64,17 @@ FN2_API int fn2_conv_pack_weights(const fn2_conv_desc* d, int route, const float
   if (!valid(d) || !weight || !packed) return fn2::fail(FN2_ERR_INVALID_ARG, "conv_pack_weights: bad descriptor or NULL blob");
   if (route == FN2_CONV_ROUTE_WINOGRAD) return fn2_conv_wino_pack_weights(weight, packed, d->Cout, d->Cin, stream);
   if (route == FN2_CONV_ROUTE_DIRECT || route == FN2_CONV_ROUTE_PLANE) return fn2_conv_mfma_pack_weights(weight, packed, d->Cout, d->Cin, d->kernel, stream);
+  if (route == FN2_CONV_ROUTE_STEM || route == FN2_CONV_ROUTE_HEAD) {
+    if (weight != packed &&
+        hipMemcpyAsync(packed, weight, sizeof(float) * (size_t)d->Cout * d->Cin * d->kernel * d->kernel, hipMemcpyDeviceToDevice, fn2::as_stream(stream)) != hipSuccess)
+      return fn2::fail(FN2_ERR_LAUNCH, "conv_pack_weights: device copy of the weight blob failed");
+    return FN2_OK;
+  }
   return fn2::fail(FN2_ERR_UNSUPPORTED, "conv_pack_weights: no own kernel for this layer (route %d)", route);
 }
 
 FN2_API size_t fn2_conv_workspace_bytes(const fn2_conv_desc* d, int route) {
+  if (valid(d) && route == FN2_CONV_ROUTE_HEAD) return fn2_predict_flow_conv_workspace_bytes(d->N, d->Cin, d->Hin, d->Win);
   if (!valid(d) || route != FN2_CONV_ROUTE_PLANE) return 0;
   return d->kernel == 3 ? fn2_conv_plane_workspace_bytes(d->N, d->Cin, d->Hin, d->Win, d->Cout, d->stride, d->pad)
                         : fn2_conv_plane_k_workspace_bytes(d->N, d->Cin, d->Hin, d->Win, d->Cout, d->kernel, d->stride, d->pad);
@@ -85,6 +97,18 @@ FN2_API int fn2_conv_forward(const fn2_conv_desc* d, int route, const float* bot
     case FN2_CONV_ROUTE_DIRECT:
       return fn2_conv_mfma_forward(bottom, packed_weight, bias, top, d->N, d->Cin, d->Hin, d->Win, bottom_channels, bottom_c0, d->Cout, top_channels,
                                    top_c0, d->kernel, d->stride, d->pad, relu, negative_slope, stream);
+    case FN2_CONV_ROUTE_STEM:
+      if (bottom_channels != d->Cin || bottom_c0 != 0 || top_channels != d->Cout || top_c0 != 0)
+        return fn2::fail(FN2_ERR_UNSUPPORTED, "conv_forward: the stem kernel reads and writes whole blobs, not channel slices");
+      // the kernel always applies t > 0 ? t : t * slope: slope 1 is the identity (exactly: t * 1.0f == t) for a layer without a fused ReLU
+      return fn2_conv_k7s2_relu_forward(bottom, packed_weight, bias, top, d->N, d->Cin, d->Hin, d->Win, d->Cout, relu ? negative_slope : 1.0f, stream);
+    case FN2_CONV_ROUTE_HEAD: {
+      if (bottom_channels != d->Cin || bottom_c0 != 0 || top_channels != d->Cout || top_c0 != 0)
+        return fn2::fail(FN2_ERR_UNSUPPORTED, "conv_forward: the flow-head kernel reads and writes whole blobs, not channel slices");
+      const int rc = fn2_predict_flow_conv_forward(bottom, packed_weight, bias, top, d->N, d->Cin, d->Hin, d->Win, workspace, workspace_bytes, stream);
+      if (rc != FN2_OK || !relu) return rc;
+      return fn2_bias_leaky_relu_forward(top, nullptr, d->N, d->Cout, d->Hin, d->Win, negative_slope, stream);
+    }
     default:
       return fn2::fail(FN2_ERR_UNSUPPORTED, "conv_forward: no own kernel for Convolution{kernel %d, stride %d, pad %d} %d -> %d on %d x %d",
                        d->kernel, d->stride, d->pad, d->Cin, d->Cout, d->Hin, d->Win);
@@ -95,6 +119,7 @@ FN2_API int fn2_conv_forward(const fn2_conv_desc* d, int route, const float* bot
 FN2_API int fn2_deconv_route(const fn2_conv_desc* d, int flags) {
   (void)flags;
   if (!valid(d) || d->kernel != 4 || d->stride != 2 || d->pad != 1) return FN2_DECONV_ROUTE_NONE;
+  if (d->Cin == 2 && d->Cout == 2) return FN2_DECONV_ROUTE_HEAD;       // upsample_flow*: the 2-channel kernel (csrc/flow_head.hip)
   const int M = d->Cout * 16;
   // weight^T x bottom as the 1x1 / GEMM form of the direct kernel + our col2im / bias / ReLU pass: 5-25 % faster than the parity-class kernel
   // on every FlowNet map it takes (profiles/r02_deconv_bench_flownetc.txt); planes whose size is no multiple of 4 (deconv5: 5x7) are not its
@@ -108,6 +133,7 @@ FN2_API size_t fn2_deconv_packed_weight_floats(const fn2_conv_desc* d, int route
   if (!valid(d)) return 0;
   if (route == FN2_DECONV_ROUTE_GEMM) return fn2_conv_mfma_packed_floats(d->Cout * 16, d->Cin, 1);
   if (route == FN2_DECONV_ROUTE_PLANE) return fn2_deconv_plane_packed_floats(d->Cin, d->Cout);
+  if (route == FN2_DECONV_ROUTE_HEAD) return (size_t)d->Cin * d->Cout * 16;
   return 0;
 }
 
@@ -117,6 +143,11 @@ FN2_API int fn2_deconv_pack_weights(const fn2_conv_desc* d, int route, const flo
   // GEMM operand [M = Cout 16][Cin] straight from the [Cin][Cout][4][4] blob through the strided view (base_conv_layer.cpp:375-384's weight^T)
   if (route == FN2_DECONV_ROUTE_GEMM) return fn2_conv_mfma_pack_weights_view(weight, packed, M, d->Cin, 1, M, d->Cin, 1, M, 0, stream);
   if (route == FN2_DECONV_ROUTE_PLANE) return fn2_deconv_plane_pack_weights(weight, packed, d->Cin, d->Cout, stream);
+  if (route == FN2_DECONV_ROUTE_HEAD) {
+    if (weight != packed && hipMemcpyAsync(packed, weight, sizeof(float) * (size_t)d->Cin * d->Cout * 16, hipMemcpyDeviceToDevice, fn2::as_stream(stream)) != hipSuccess)
+      return fn2::fail(FN2_ERR_LAUNCH, "deconv_pack_weights: device copy of the weight blob failed");
+    return FN2_OK;
+  }
   return fn2::fail(FN2_ERR_UNSUPPORTED, "deconv_pack_weights: no own kernel for this layer (route %d)", route);
 }
 
@@ -143,6 +174,11 @@ FN2_API int fn2_deconv_forward(const fn2_conv_desc* d, int route, const float* b
   if (route == FN2_DECONV_ROUTE_PLANE)
     return fn2_deconv_plane_forward(bottom, packed_weight, bias, top, d->N, d->Cin, d->Hin, d->Win, bottom_channels, bottom_c0, d->Cout, top_channels,
                                     top_c0, relu, negative_slope, workspace, workspace_bytes, stream);
+  if (route == FN2_DECONV_ROUTE_HEAD) {
+    if (bottom_channels != 2 || bottom_c0 != 0) return fn2::fail(FN2_ERR_UNSUPPORTED, "deconv_forward: the flow-head kernel reads a whole 2-channel blob");
+    if (relu) return fn2::fail(FN2_ERR_UNSUPPORTED, "deconv_forward: the 2-channel flow-head kernel has no fused ReLU (the FlowNet graphs have none there)");
+    return fn2_upsample_flow_deconv_forward_into(bottom, packed_weight, bias, top, d->N, d->Hin, d->Win, top_channels, top_c0, stream);
+  }
   return fn2::fail(FN2_ERR_UNSUPPORTED, "deconv_forward: no own kernel for Deconvolution{kernel %d, stride %d, pad %d} %d -> %d on %d x %d",
                    d->kernel, d->stride, d->pad, d->Cin, d->Cout, d->Hin, d->Win);
 }

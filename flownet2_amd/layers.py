@@ -570,9 +570,15 @@ class DataAugmentationLayer(Layer):
         if len(blobs) >= 1:
             self.num_iter_ = int(np.asarray(blobs[0], np.float32).reshape(-1)[0])
         if len(blobs) >= 2:
+            # hdf5_load_nd_dataset reshapes blobs_[1] to whatever the dataset holds (util/hdf5.cpp:49-52).  Only a layer with mean_per_pixel
+            # ever indexes it (with its OWN crop size): there a stored mean of another size is refused; otherwise it is kept as stored
             b1 = np.ascontiguousarray(blobs[1], np.float32)
-            CHECK(b1.size == channels * ch * cw, "data augmentation mean: the stored per-pixel mean has another size than this layer's crop")
-            self.mean_pixel_ = torch.from_numpy(b1.reshape(channels, ch, cw).copy()).to(dev)
+            if b1.size == channels * ch * cw:
+                self.mean_pixel_ = torch.from_numpy(b1.reshape(channels, ch, cw).copy()).to(dev)
+            else:
+                CHECK(not self.layer_param_.augmentation_param.get("mean_per_pixel", True) or int(self.layer_param_.augmentation_param.get("recompute_mean", 0)) <= 0,
+                      "data augmentation mean: the stored per-pixel mean has another size than this layer's crop")
+                self.mean_pixel_ = torch.from_numpy(b1.copy()).to(dev)
         if len(blobs) >= 3:
             b2 = np.ascontiguousarray(blobs[2], np.float32).reshape(-1)
             CHECK(b2.size == channels, "data augmentation mean: the stored per-channel mean has another channel count")

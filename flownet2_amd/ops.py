@@ -469,8 +469,8 @@ def conv_k7s2_relu_forward(x, weight, bias=None, negative_slope=0.1):
     return out
 
 
-CONV_ROUTES = {0: None, 1: "direct", 2: "wino", 3: "plane"}
-DECONV_ROUTES = {0: None, 1: "gemm", 2: "plane"}
+CONV_ROUTES = {0: None, 1: "direct", 2: "wino", 3: "plane", 4: None, 5: None}     # 4 / 5: stem / flow head -- the graphs call those kernels by name (conv_k7s2_relu, predict_flow_conv)
+DECONV_ROUTES = {0: None, 1: "gemm", 2: "plane", 3: None}      # 3: the 2-channel upsample_flow head (upsample_flow_deconv)
 
 
 def conv_route(N, Cin, Hin, Win, Cout, kernel, stride, pad, force=False):

@@ -488,8 +488,12 @@ typedef struct fn2_conv_desc {
   int N, Cin, Hin, Win;      /* bottom [N, Cin, Hin, Win] (a channel slice of a wider blob is given to the forward call) */
   int Cout, kernel, stride, pad;
 } fn2_conv_desc;
-enum { FN2_CONV_ROUTE_NONE = 0, FN2_CONV_ROUTE_DIRECT = 1, FN2_CONV_ROUTE_WINOGRAD = 2, FN2_CONV_ROUTE_PLANE = 3 };
-enum { FN2_DECONV_ROUTE_NONE = 0, FN2_DECONV_ROUTE_GEMM = 1, FN2_DECONV_ROUTE_PLANE = 2 };
+/* STEM: Convolution{7, 2, 3} on 3 / 6 / 12 channels (csrc/conv_stem.hip); HEAD: the 2-channel flow heads -- Convolution{3, 1, 1} -> 2
+ * (predict_flow*) and Deconvolution{4, 2, 1} 2 -> 2 (upsample_flow*), csrc/flow_head.hip.  Both read the weight blob as it is ("packing" is a
+ * device copy) and whole blobs only (no channel slices on the bottom; the stem and predict_flow none on the top either). */
+enum { FN2_CONV_ROUTE_NONE = 0, FN2_CONV_ROUTE_DIRECT = 1, FN2_CONV_ROUTE_WINOGRAD = 2, FN2_CONV_ROUTE_PLANE = 3, FN2_CONV_ROUTE_STEM = 4,
+       FN2_CONV_ROUTE_HEAD = 5 };
+enum { FN2_DECONV_ROUTE_NONE = 0, FN2_DECONV_ROUTE_GEMM = 1, FN2_DECONV_ROUTE_PLANE = 2, FN2_DECONV_ROUTE_HEAD = 3 };
 enum { FN2_ROUTE_FORCE = 1 };
 int fn2_conv_route(const fn2_conv_desc* desc, int flags);
 size_t fn2_conv_packed_weight_floats(const fn2_conv_desc* desc, int route);

@@ -146,6 +146,25 @@ def l1loss(b0, b1=None, l2_per_location=False, l2_prescale_by_channels=False, no
     return loss.value, wl.value, d0, d1
 
 
+def flownetc_time(N, H, W, warmup=3, iterations=10, use_cache=True, max_layers=128):
+    """fn2ref_flownetc_time (adapter build, use("adapter") first): a FlowNetC core forward chained from LayerRegistry-created layers -- the
+    adapter's Convolution / Deconvolution / Correlation plug-ins, the reference's own in-place ReLU and Concat -- timed like `caffe time`
+    (tools/caffe.cpp:346-366).  -> dict(total_ms, layers=[(name, ms)], packs, pack_reuses, output_finite)."""
+    L = lib()
+    if not hasattr(L, "fn2ref_flownetc_time"):
+        raise RuntimeError("this shim build has no FlowNetC driver (built without the reference's ReLU / Concat sources)")
+    total = C.c_double()
+    ms = (C.c_double * max_layers)()
+    names = C.create_string_buffer(48 * max_layers)
+    n, packs, reuses, ok = C.c_int(), C.c_longlong(), C.c_longlong(), C.c_int()
+    L.fn2ref_flownetc_time.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p, C.c_int, C.POINTER(C.c_int),
+                                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+    _chk(L.fn2ref_flownetc_time(N, H, W, warmup, iterations, int(bool(use_cache)), C.byref(total), ms, names, max_layers, C.byref(n),
+                                C.byref(packs), C.byref(reuses), C.byref(ok)))
+    layers = [(names.raw[48 * i:48 * (i + 1)].split(b"\0", 1)[0].decode(), ms[i]) for i in range(min(n.value, max_layers))]
+    return {"total_ms": total.value, "layers": layers, "packs": packs.value, "pack_reuses": reuses.value, "output_finite": bool(ok.value)}
+
+
 def convolution(x, weight, bias=None, kernel=3, stride=1, pad=1, deconv=False, relu=False, negative_slope=0.1):
     """The reference's stock Convolution / Deconvolution layer (+ in-place ReLU) with the given weights."""
     x, weight = _f(x), _f(weight)

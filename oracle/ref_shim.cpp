@@ -444,3 +444,163 @@ int fn2ref_custom_data(const char* const* keys, const unsigned char* const* valu
   });
 }
 #endif
+
+#ifdef FN2_SHIM_NET
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// A FlowNetC deploy forward chained from LayerRegistry-created layers and timed like `caffe time` (tools/caffe.cpp:346-366: per-layer
+// Timer around Layer::Forward over `iterations` passes, plus the total).  Adapter build only: "Convolution" / "Deconvolution" /
+// "Correlation" resolve to the plug-ins of flownet2_amd/csrc/caffe_adapter/fn2_caffe_layers.cpp; "ReLU" and "Concat" are the REFERENCE's
+// own layers (relu_layer / concat_layer compiled in place) -- what a Caffe tree with the plug-ins dropped in executes: separate in-place
+// ReLU passes and Concat copies between the convolution kernels, which the fused graph (flownet2_amd/nets.py) does not have.
+// The graph is the FlowNetC core (pre-processed image pair -> predict_flow2) with filler weights; values are not checked here (the layers'
+// parity is tests/test_caffe_adapter.py), only finiteness of the output.  `use_cache` = 0 forces a weight repack in every forward (the
+// round-5 behaviour) by touching the weight blobs' mutable pointers between passes.
+#include <chrono>
+#include <cmath>
+#include <map>
+
+namespace {
+struct MiniNet {
+  struct Step { std::string name; shared_ptr<Layer<float> > layer; vector<Blob<float>*> bottom, top; double ms = 0.0; };
+  std::map<std::string, shared_ptr<Blob<float> > > blobs;
+  vector<Step> steps;
+  Blob<float>* blob(const std::string& n) {
+    shared_ptr<Blob<float> >& b = blobs[n];
+    if (!b) b.reset(new Blob<float>());
+    return b.get();
+  }
+  void add(LayerParameter lp, const vector<std::string>& bottoms, const vector<std::string>& tops) {
+    Step s;
+    s.name = lp.name();
+    lp.set_phase(TEST);
+    s.layer = LayerRegistry<float>::CreateLayer(lp);
+    for (const std::string& b : bottoms) s.bottom.push_back(blob(b));
+    for (const std::string& t : tops) s.top.push_back(blob(t));
+    s.layer->SetUp(s.bottom, s.top);
+    steps.push_back(s);
+  }
+  void conv(const std::string& name, const std::string& in, const std::string& out, int k, int s, int p, int nout, bool deconv = false, bool relu = true) {
+    LayerParameter lp;
+    lp.set_name(name);
+    lp.set_type(deconv ? "Deconvolution" : "Convolution");
+    conv_param(lp, k, s, p, nout, true);
+    add(lp, {in}, {out});
+    // weights: a fixed pseudo-random pattern scaled like an MSRA filler (the stand-in headers carry the constant filler only)
+    Blob<float>& wb = *steps.back().layer->blobs()[0];
+    float* wp = wb.mutable_cpu_data();
+    const float scale = std::sqrt(2.0f / (float)(wb.count() / wb.shape(0)));
+    unsigned st = 12345u + (unsigned)steps.size();
+    for (int i = 0; i < wb.count(); ++i) { st = st * 1664525u + 1013904223u; wp[i] = ((float)(st >> 8) / 8388608.0f - 1.0f) * scale; }
+    if (relu) {
+      LayerParameter rp;
+      rp.set_name(name + "_relu");
+      rp.set_type("ReLU");
+      rp.mutable_relu_param()->set_negative_slope(0.1f);
+      add(rp, {out}, {out});                // in place, like the prototxts
+    }
+  }
+  void concat(const std::string& name, const vector<std::string>& in, const std::string& out) {
+    LayerParameter lp;
+    lp.set_name(name);
+    lp.set_type("Concat");
+    add(lp, in, {out});
+  }
+};
+}  // namespace
+
+extern "C" long long fn2_caffe_adapter_weight_packs();
+extern "C" long long fn2_caffe_adapter_weight_pack_reuses();
+
+extern "C" __attribute__((visibility("default")))
+int fn2ref_flownetc_time(int N, int H, int W, int warmup, int iterations, int use_cache, double* total_ms_per_forward,
+                         double* layer_ms /* [max_layers] */, char* layer_names /* max_layers x 48 */, int max_layers, int* num_layers,
+                         long long* packs, long long* pack_reuses, int* output_finite) {
+  return guard([&] {
+    Caffe::set_mode(Caffe::GPU);
+    MiniNet net;
+    for (const char* t : {"a", "b"}) {
+      Blob<float>* img = net.blob(std::string("img") + t);
+      img->Reshape(N, 3, H, W);
+      float* p = img->mutable_cpu_data();
+      for (int i = 0; i < img->count(); ++i) p[i] = (float)((i * 2654435761u >> 8) & 255) / 255.f - 0.43f;
+    }
+    // siamese towers (the prototxts: two layer instances sharing weights by ParamSpec name; here two instances, same cost)
+    for (const char* t : {"a", "b"}) {
+      const std::string s(t);
+      net.conv("conv1" + s, "img" + s, "conv1" + s, 7, 2, 3, 64);
+      net.conv("conv2" + s, "conv1" + s, "conv2" + s, 5, 2, 2, 128);
+      net.conv("conv3" + s, "conv2" + s, "conv3" + s, 5, 2, 2, 256);
+    }
+    {
+      LayerParameter lp;
+      lp.set_name("corr"); lp.set_type("Correlation");
+      CorrelationParameter* cp = lp.mutable_correlation_param();
+      cp->set_pad(20); cp->set_kernel_size(1); cp->set_max_displacement(20); cp->set_stride_1(1); cp->set_stride_2(2);
+      net.add(lp, {"conv3a", "conv3b"}, {"corr"});
+      LayerParameter rp;
+      rp.set_name("corr_relu"); rp.set_type("ReLU"); rp.mutable_relu_param()->set_negative_slope(0.1f);
+      net.add(rp, {"corr"}, {"corr"});
+    }
+    net.conv("conv_redir", "conv3a", "conv_redir", 1, 1, 0, 32);
+    net.concat("blob20", {"conv_redir", "corr"}, "blob20");
+    net.conv("conv3_1", "blob20", "conv3_1", 3, 1, 1, 256);
+    net.conv("conv4", "conv3_1", "conv4", 3, 2, 1, 512);
+    net.conv("conv4_1", "conv4", "conv4_1", 3, 1, 1, 512);
+    net.conv("conv5", "conv4_1", "conv5", 3, 2, 1, 512);
+    net.conv("conv5_1", "conv5", "conv5_1", 3, 1, 1, 512);
+    net.conv("conv6", "conv5_1", "conv6", 3, 2, 1, 1024);
+    net.conv("conv6_1", "conv6", "conv6_1", 3, 1, 1, 1024);
+    // refinement: predict_flow (3x3 -> 2, no ReLU), deconv (4x4 / 2 + ReLU), upsample_flow (4x4 / 2, 2 -> 2, no ReLU), Concat
+    struct Stage { const char* skip; int level; int deconv_out; };
+    const Stage stages[] = {{"conv5_1", 5, 512}, {"conv4_1", 4, 256}, {"conv3_1", 3, 128}, {"conv2a", 2, 64}};
+    std::string feat = "conv6_1";
+    int lvl = 6;
+    for (const Stage& st : stages) {
+      const std::string l = std::to_string(lvl), m = std::to_string(st.level);
+      net.conv("predict_flow" + l, feat, "predict_flow" + l, 3, 1, 1, 2, false, false);
+      net.conv("deconv" + m, feat, "deconv" + m, 4, 2, 1, st.deconv_out, true, true);
+      net.conv("upsample_flow" + l + "to" + m, "predict_flow" + l, "upsampled_flow" + l + "to" + m, 4, 2, 1, 2, true, false);
+      net.concat("concat" + m, {st.skip, "deconv" + m, "upsampled_flow" + l + "to" + m}, "concat" + m);
+      feat = "concat" + m;
+      lvl = st.level;
+    }
+    net.conv("predict_flow2", feat, "predict_flow2", 3, 1, 1, 2, false, false);
+
+    auto forward_all = [&](bool timed) {
+      for (MiniNet::Step& s : net.steps) {
+        if (!timed) { s.layer->Forward(s.bottom, s.top); continue; }
+        CUDA_CHECK(hipDeviceSynchronize());          // caffe time: Timer (device events) around every layer's Forward
+        const auto t0 = std::chrono::steady_clock::now();
+        s.layer->Forward(s.bottom, s.top);
+        CUDA_CHECK(hipDeviceSynchronize());
+        s.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      }
+    };
+    auto touch_weights = [&] {                       // what a training net does to its weights between forwards: the cached operands must go
+      for (MiniNet::Step& s : net.steps)
+        for (auto& b : s.layer->blobs()) (void)b->mutable_gpu_data();
+    };
+    for (int i = 0; i < warmup; ++i) { if (!use_cache) touch_weights(); forward_all(false); }
+    CUDA_CHECK(hipDeviceSynchronize());
+    const long long p0 = fn2_caffe_adapter_weight_packs(), r0 = fn2_caffe_adapter_weight_pack_reuses();
+    // total: all layers back to back, one synchronisation at the end of every pass (caffe.cpp:352-366 forward_timer)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iterations; ++i) { if (!use_cache) touch_weights(); forward_all(false); }
+    CUDA_CHECK(hipDeviceSynchronize());
+    *total_ms_per_forward = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iterations;
+    *packs = fn2_caffe_adapter_weight_packs() - p0;
+    *pack_reuses = fn2_caffe_adapter_weight_pack_reuses() - r0;
+    for (int i = 0; i < iterations; ++i) { if (!use_cache) touch_weights(); forward_all(true); }
+    *num_layers = (int)net.steps.size();
+    for (int i = 0; i < (int)net.steps.size() && i < max_layers; ++i) {
+      layer_ms[i] = net.steps[i].ms / iterations;
+      std::snprintf(layer_names + 48 * i, 48, "%s", net.steps[i].name.c_str());
+    }
+    const Blob<float>* out = net.blob("predict_flow2");
+    const float* o = out->cpu_data();
+    int ok = out->count() == N * 2 * (H / 4) * (W / 4);
+    for (int i = 0; i < out->count(); ++i) ok &= std::isfinite(o[i]) ? 1 : 0;
+    *output_finite = ok;
+  });
+}
+#endif

@@ -138,11 +138,14 @@ CONV_CASES = [
     (2, 128, 5, 7, 64, 4, 2, 1, True),         # deconv5: a 5x7 plane, the parity-class kernel
     (2, 72, 16, 24, 64, 3, 1, 1, False),       # bottom channels that are no multiple of the kernels' channel groups: the data gradient goes through the scratch
     (2, 40, 10, 14, 64, 3, 1, 1, False),       # ... on a small map (the small-map kernel's route)
+    (2, 96, 16, 24, 2, 3, 1, 1, False),        # predict_flow*: the 2-channel head (round 6: reachable by descriptor, FN2_CONV_ROUTE_HEAD)
+    (2, 2, 8, 12, 2, 4, 2, 1, True),           # upsample_flow*: Deconvolution 2 -> 2 (FN2_DECONV_ROUTE_HEAD)
 ]
+STEM_CASE = (2, 3, 64, 96, 64, 7, 2, 3, False)   # conv1: the 7x7 / 2 stem (FN2_CONV_ROUTE_STEM); forward only -- its bottom is the image (no data gradient kernel)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("case", CONV_CASES + [STEM_CASE])
 def test_adapter_convolution_plugins_match_the_reference_layers(case):
     """Round 5: "Convolution" / "Deconvolution" created BY TYPE STRING through LayerRegistry are the adapter's plug-ins (the kernel family is
     picked inside libflownet2_hip.so, fn2_conv_route / fn2_deconv_route); the same blobs through the reference's own ConvolutionLayer /
@@ -198,3 +201,29 @@ def test_adapter_convolution_plugins_backward_matches_the_reference_layers(case)
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * scale, err_msg=name)
     # accumulation really happened on both sides (the start values are O(1), the gradients O(10..1000))
     assert float(np.abs(dw - wd0).max()) > 1e-2 and float(np.abs(gw - wd0).max()) > 1e-2
+
+
+@pytest.mark.gpu
+def test_flownetc_forward_chained_from_registry_created_layers_and_the_weight_cache():
+    """Round 6: every Convolution / Deconvolution of a FlowNetC graph -- stem, 5x5 / 2, Winograd, small maps, 1x1, the 2-channel heads -- is
+    created BY TYPE STRING (the adapter's plug-ins) and chained with the reference's own in-place ReLU and Concat layers
+    (oracle/ref_shim.cpp: fn2ref_flownetc_time, `caffe time` style, tools/caffe.cpp:346-366).  The packed weight operand is built once:
+    with untouched TEST-phase weights every forward after the first reuses it; touching the weight blobs' mutable pointers between passes
+    (what a solver's update does) makes every forward repack."""
+    if not ref.adapter_available():
+        pytest.skip("adapter library not built")
+    ref.use("adapter")
+    try:
+        if not hasattr(ref.lib(), "fn2ref_flownetc_time"):
+            pytest.skip("adapter shim built without the reference's ReLU / Concat sources")
+        cached = ref.flownetc_time(1, 128, 192, warmup=2, iterations=3, use_cache=True)
+        fresh = ref.flownetc_time(1, 128, 192, warmup=2, iterations=3, use_cache=False)
+    finally:
+        ref.use("ref")
+    names = [n for n, _ in cached["layers"]]
+    convs = [n for n in names if not n.endswith("_relu") and not n.startswith(("concat", "blob20", "corr"))]
+    assert len(convs) == 6 + 8 + 4 * 3 + 1 == 27 and "corr" in names and "blob20" in names and names[-1] == "predict_flow2"
+    assert cached["output_finite"] and fresh["output_finite"]
+    assert cached["packs"] == 0 and cached["pack_reuses"] == 3 * len(convs)          # the operands of the warm-up passes serve the timed ones
+    assert fresh["packs"] == 3 * len(convs) and fresh["pack_reuses"] == 0
+    assert all(ms > 0 for _, ms in cached["layers"]) and cached["total_ms"] > 0

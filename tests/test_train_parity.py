@@ -223,3 +223,35 @@ def test_weight_gradients_on_the_second_stream_are_the_same_bits():
     acc_got, _ = run(36000, accumulate=True)
     for gg, rg in zip(acc_got, acc_ref):
         assert all(torch.equal(gg[k], rg[k]) for k in rg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trainable", [("deconv2.w", "deconv2.b", "upsample_flow3to2.w", "upsample_flow3to2.b", "Convolution5.w", "Convolution5.b"),
+                                       ("upsample_flow5to4.w",), ("deconv4.b", "Convolution3.w")])
+def test_partial_freeze_whose_first_trainable_tensors_are_a_stage_s_own_parameters(trainable):
+    """A fine-tune that freezes everything in front of a refinement stage: the stage's deconvolution / flow up-sampling weights are then the
+    first tensors that require grad, and the in-place Concat route must still put them into the graph (round-5 advisor finding: the stage
+    looked only at its INPUTS and fell through to the inference path, so those parameters silently got no gradient).  The gradients of the
+    trainable subset equal those of the fully trainable net -- same kernels, same operands."""
+    from flownet2_amd import functional as Fn, nets
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.rand(2, 3, 128, 192, device="cuda", generator=g) - 0.43
+    b = torch.rand(2, 3, 128, 192, device="cuda", generator=g) - 0.43
+    gt = torch.randn(2, 2, 128, 192, device="cuda", generator=g) * 3
+
+    def grads(names):
+        P = {k: v.cuda().requires_grad_(names is None or k in names) for k, v in nets.init_params("C", seed=7).items()}
+        loss = nets.multiscale_loss(nets.flownet_c_core(P, a, b, Fn), gt, Fn)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: (None if v.grad is None else v.grad.clone()) for k, v in P.items()}
+
+    l_all, g_all = grads(None)
+    l_part, g_part = grads(set(trainable))
+    assert l_all == l_part
+    for k, v in g_part.items():
+        if k in trainable:
+            assert v is not None, f"{k} is trainable but got no gradient"
+            assert torch.equal(v, g_all[k]), (k, float((v - g_all[k]).abs().max()))
+        else:
+            assert v is None, k
