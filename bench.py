@@ -254,6 +254,7 @@ def rank_seed(rank):
     return 1234 + rank              # every rank its own synthetic batch (weak scaling: per-GPU work fixed)
 
 
+AHEAD = [os.environ.get("FN2_BENCH_TARGETS_AHEAD", "1") == "1"]      # A/B hook: 0 = Downsample(GT) between forward and backward (rounds 1-5)
 WGRAD_SIDE_PIXELS = [36000]       # --wgrad-side-pixels: GradientExchange's second stream for the weight gradients (single-rank jobs)
 
 
@@ -286,8 +287,9 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
 
         def step():
             exchange.zero_grad()
+            tg = nets.loss_targets_ahead(gt, be) if AHEAD[0] else None      # the ground-truth pyramid: issued first, on the second stream
             pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
-            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], be), gt, be)
+            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], be), gt, be, targets=tg)
             loss.backward()
             exchange.finish()
             opt.step()

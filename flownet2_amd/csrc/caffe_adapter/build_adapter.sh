@@ -22,7 +22,7 @@ if [ -d "$REF/src/caffe/layers" ]; then
     $HIPCC $RFLAGS -x hip -c "$REF/src/caffe/layers/$f" -o "$OUT/ref_$f.o"
     STOCK_OBJS="$STOCK_OBJS $OUT/ref_$f.o"
   done
-  NETDEF="-DFN2_SHIM_NET=1"
+  NETDEF="-DFN2_SHIM_NET=1 -I$REF/include"
 fi
 $HIPCC $FLAGS -DFN2_SHIM_L1LOSS=1 -DFN2_SHIM_CONV_REGISTRY=1 $NETDEF -x hip -c "$ROOT/oracle/ref_shim.cpp" -o "$OUT/shim.o"
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfn2_caffe_adapter_test.so" "$OUT/fn2_caffe_layers.o" "$OUT/shim.o" $STOCK_OBJS \

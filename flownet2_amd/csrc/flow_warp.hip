@@ -104,10 +104,14 @@ constexpr int kWarpGatherThreads = 128;
 constexpr int kWarpListMax = 24;      // sources sorted in LDS per target; longer lists fall back to selection passes
 
 // grid: (pixel blocks of 128, n * cgroups + channel group)
+// with_flow (round 6, image-like blobs with ONE channel group): the thread also computes the flow gradient of its own pixel -- the
+// arithmetic of warp_bwd_flow, flow_warp_layer.cu:203-227 -- whose loads are in flight while the lists are chased: one launch less and the
+// gather's idle latency used (84.9 -> see profiles/r06_layer_microbench.md)
 __global__ void __launch_bounds__(kWarpGatherThreads) warp_bwd_gather(const float* __restrict__ flow, const float* __restrict__ warped_diff,
                                                                       const int* __restrict__ head, const int* __restrict__ next,
                                                                       float* __restrict__ image_diff, int N, int C, int H, int W,
-                                                                      int cgroups, int cpg) {
+                                                                      int cgroups, int cpg, const float* __restrict__ image,
+                                                                      float* __restrict__ flow_diff, int with_flow) {
   __shared__ int srcs[kWarpListMax][kWarpGatherThreads];
   const unsigned wh = (unsigned)H * W;
   const unsigned pix = blockIdx.x * (unsigned)kWarpGatherThreads + threadIdx.x;
@@ -120,6 +124,26 @@ __global__ void __launch_bounds__(kWarpGatherThreads) warp_bwd_gather(const floa
     const int* hd = head + (size_t)n * wh;
     const int* nx = next + (size_t)n * wh;
     const float* fl = flow + (size_t)(2 * n) * wh;
+    float du = 0.f, dv = 0.f;
+    if (with_flow) {
+      const WarpTap t = warp_taps(x, y, fl[pix], fl[wh + pix], H, W);
+      if (t.inside) {                                                      // diffs are 0 otherwise (:478-479)
+        for (int c = 0; c < C; ++c) {
+          const size_t ch = ((size_t)n * C + c) * wh;
+          const float g0 = warped_diff[ch + pix];
+          const float* p = image + ch;
+          const float TL = p[t.o[0]], TR = p[t.o[1]], BL = p[t.o[2]], BR = p[t.o[3]];
+          float tu = 0.f;
+          tu += t.gy * (TR - TL);
+          tu += (1 - t.gy) * (BR - BL);
+          du += g0 * tu;                                                   // :211
+          float tv = 0.f;
+          tv += t.gx * (BL - TL);
+          tv += (1 - t.gx) * (BR - TR);
+          dv += g0 * tv;                                                   // :225
+        }
+      }
+    }
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -178,6 +202,10 @@ __global__ void __launch_bounds__(kWarpGatherThreads) warp_bwd_gather(const floa
     float* dst = image_diff + ((size_t)n * C + c0) * wh + pix;
 #pragma unroll
     for (int j = 0; j < 8; ++j) if (c0 + j < c1) dst[(size_t)j * wh] = acc[j];
+    if (with_flow) {
+      flow_diff[(size_t)(2 * n) * wh + pix] = du;
+      flow_diff[(size_t)(2 * n + 1) * wh + pix] = dv;
+    }
   }
 }
 
@@ -289,8 +317,10 @@ FN2_API int fn2_flow_warp_backward(const float* image, const float* flow, const 
     const int cpg = C < 8 ? C : 8;
     const int cgroups = (C + cpg - 1) / cpg;
     const long long groups = (long long)N * cgroups;
+    const int with_flow = propagate_flow && cgroups == 1 && groups <= 65535;
     hipLaunchKernelGGL(warp_bwd_gather, dim3((unsigned)((wh + kWarpGatherThreads - 1) / kWarpGatherThreads), (unsigned)(groups < 65535 ? groups : 65535)),
-                       dim3(kWarpGatherThreads), 0, st, flow, warped_diff, head, next, image_diff, N, C, H, W, cgroups, cpg);
+                       dim3(kWarpGatherThreads), 0, st, flow, warped_diff, head, next, image_diff, N, C, H, W, cgroups, cpg, image, flow_diff, with_flow);
+    if (with_flow) return check_launch("flow_warp_backward");
   } else {
     if (hipMemsetAsync(image_diff, 0, sizeof(float) * wh * C * N, st) != hipSuccess)       // :507
       return fail(FN2_ERR_LAUNCH, "flow_warp_backward: hipMemsetAsync failed");

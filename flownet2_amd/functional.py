@@ -165,6 +165,35 @@ def downsample(x, top_height, top_width):
         return ops.downsample_forward(x.detach().contiguous(), top_height, top_width)
 
 
+def downsample_ahead(x, sizes):
+    """Downsample(x) to every (height, width) of `sizes` on the second HIP stream (the one the weight gradients use), for consumers that
+    need the result much later: the ground-truth pyramid of a training step depends on the ground truth alone, so it is issued at the START
+    of the step and runs beside the first convolutions instead of between the forward and the backward pass (5 launches, 135 us of a
+    FlowNetC step on the critical path).  Returns (tensors, event): the consumer's stream must wait for the event (wait_ahead)."""
+    with torch.no_grad():
+        x = x.detach().contiguous()
+        if not x.is_cuda:
+            return [ops.downsample_forward(x, h, w) for h, w in sizes], None
+        main = torch.cuda.current_stream(x.device)
+        side = _WGRAD_SIDE["streams"].get(x.device)
+        if side is None:
+            side = _WGRAD_SIDE["streams"][x.device] = torch.cuda.Stream(device=x.device)
+        side.wait_stream(main)                    # x was produced under the main stream
+        with torch.cuda.stream(side):
+            outs = [ops.downsample_forward(x, h, w) for h, w in sizes]
+            ev = torch.cuda.Event()
+            ev.record(side)
+        x.record_stream(side)
+        for t in outs:
+            t.record_stream(main)
+        return outs, ev
+
+
+def wait_ahead(event):
+    if event is not None:
+        torch.cuda.current_stream().wait_event(event)
+
+
 class _ChannelNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -251,8 +280,25 @@ class _PredictFlow(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         blob, c0 = _channel_slice(x)
-        dx, dw, db = ops.predict_flow_conv_backward((blob, c0, x.shape[1]), w, g.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                                    ctx.has_bias and ctx.needs_input_grad[2])
+        g = g.contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        side = _wgrad_side_stream(g, x, w) if (need_w or need_b) and need_x else None
+        if side is None:
+            return ops.predict_flow_conv_backward((blob, c0, x.shape[1]), w, g, need_x, need_w, need_b)
+        # round 6: only the data gradient is on the critical path of the backward pass; the head's weight / bias gradient (a pass over the
+        # whole Concat blob in front of it) runs beside the data-gradient chain like the convolutions' weight gradients
+        dx, _, _ = ops.predict_flow_conv_backward((blob, c0, x.shape[1]), w, g, True, False, False)
+        main = torch.cuda.current_stream(g.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _, dw, db = ops.predict_flow_conv_backward((blob, c0, x.shape[1]), w, g, False, need_w, need_b)
+        for t in (g, blob):
+            t.record_stream(side)
+        for t in (dw, db):
+            if t is not None:
+                t.record_stream(main)
+        if dw is not None:
+            _SIDE_PENDING.append((w, dw.data_ptr()))
         return dx, dw, db
 
 

@@ -477,15 +477,35 @@ def deploy_forward(kind: str, P, img0, img1, backend, mean: Optional[torch.Tenso
     return flow * scale.view(1, 2, 1, 1)                                            # 1x1 conv, diagonal filler
 
 
-def multiscale_loss(flows, gt_flow, backend):
-    """Training loss: per scale Downsample(GT * 0.05) -> L1Loss{l2_per_location, normalize_by_num_entries}."""
+def loss_targets_ahead(gt_flow, backend, divisors=None):
+    """The Downsample(GT * 0.05) pyramid of multiscale_loss issued ahead of the forward pass on a second stream (backend.downsample_ahead:
+    it depends on the ground truth alone).  Returns an opaque handle for multiscale_loss(..., targets=handle), or None when the backend
+    has no such form."""
+    if not (hasattr(backend, "downsample_ahead") and gt_flow.is_cuda):
+        return None
+    H, W = gt_flow.shape[2], gt_flow.shape[3]
+    divisors = divisors or {s: 2 ** s for s in LOSS_WEIGHTS}
     gt = gt_flow * (1.0 / FLOW_SCALE)
-    if hasattr(backend, "l1_loss_multi") and gt.is_cuda:
+    sizes = [(H // divisors[s], W // divisors[s]) for s in LOSS_WEIGHTS]
+    tgts, ev = backend.downsample_ahead(gt, sizes)
+    return {"targets": dict(zip(LOSS_WEIGHTS, tgts)), "event": ev, "sizes": dict(zip(LOSS_WEIGHTS, sizes))}
+
+
+def multiscale_loss(flows, gt_flow, backend, targets=None):
+    """Training loss: per scale Downsample(GT * 0.05) -> L1Loss{l2_per_location, normalize_by_num_entries}.  `targets`: the handle of
+    loss_targets_ahead (the same Downsample launches, issued at the start of the step on a second stream)."""
+    if hasattr(backend, "l1_loss_multi") and gt_flow.is_cuda:
         # the five loss layers in one launch per direction, the weighted sum (Net::ForwardFromTo's loss += ...) included
         scales = list(LOSS_WEIGHTS.items())
         preds = [flows[s] for s, _ in scales]
-        tgts = [backend.downsample(gt, p.shape[2], p.shape[3]) for p in preds]
+        if targets is not None and all(tuple(targets["sizes"][s]) == tuple(flows[s].shape[2:]) for s, _ in scales):
+            backend.wait_ahead(targets["event"])
+            tgts = [targets["targets"][s] for s, _ in scales]
+        else:
+            gt = gt_flow * (1.0 / FLOW_SCALE)
+            tgts = [backend.downsample(gt, p.shape[2], p.shape[3]) for p in preds]
         return backend.l1_loss_multi(preds, tgts, [w for _, w in scales], l2_per_location=True, normalize_by_num_entries=True)[0]
+    gt = gt_flow * (1.0 / FLOW_SCALE)
     total = 0.0
     for s, w in LOSS_WEIGHTS.items():
         pred = flows[s]

@@ -459,6 +459,14 @@ int fn2ref_custom_data(const char* const* keys, const unsigned char* const* valu
 #include <cmath>
 #include <map>
 
+#include "caffe/layers/relu_layer.hpp"
+// "ReLU" is registered by layer_factory.cpp in the reference (GetReLULayer, layer_factory.cpp:145-167: the cuDNN / Caffe engine switch),
+// not by relu_layer.cpp: the Caffe-engine branch of that creator, restated for the driver below
+namespace caffe {
+static shared_ptr<Layer<float> > Fn2ShimGetReLULayer(const LayerParameter& p) { return shared_ptr<Layer<float> >(new ReLULayer<float>(p)); }
+static LayerRegisterer<float> g_fn2_shim_relu_creator("ReLU", Fn2ShimGetReLULayer);
+}  // namespace caffe
+
 namespace {
 struct MiniNet {
   struct Step { std::string name; shared_ptr<Layer<float> > layer; vector<Blob<float>*> bottom, top; double ms = 0.0; };
