@@ -158,7 +158,7 @@ static int g_force_generic = 0;
 
 using namespace fn2;
 
-namespace fn2 { extern int g_corr_units; extern int g_corr_units_lds; extern int g_corr_units_abl; extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; } }
+namespace fn2 { extern int g_corr_units; extern int g_corr_units_lds; extern int g_corr_units_abl; extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; extern int g_corr_bwd_separate; } }
 
 FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   fn2::g_corr_dbg = reinterpret_cast<unsigned long long*>(device_buffer);
@@ -180,7 +180,8 @@ FN2_API int fn2_debug_set_correlation_impl(int impl) {
   fn2::g_corr_force_dword = (impl == 3);
   fn2::g_corr_proj = impl == 7 ? 1 : impl == 8 ? 2 : impl == 9 ? 3 : 0;   // profiling builds of the paired-parity forward: 7 = 3/8 of the MFMAs (bf16 x 3 projection), 8 = none (wrong results)
   fn2::bwd::g_corr_bwd_first_gen = (impl == 5);
-  fn2::bwd::g_corr_bwd_gen = (impl == 6) ? 2 : 0;        // 6 = second-generation MFMA backward (LDS-DMA staging, gathered G)       // 5 = first-generation (register-staged) MFMA backward where the LDS-DMA one applies
+  fn2::bwd::g_corr_bwd_gen = (impl == 6) ? 2 : (impl == 15) ? 3 : 0;      // 15 = third generation (G through LDS, one slab ahead) where the fourth applies;        // 6 = second-generation MFMA backward (LDS-DMA staging, gathered G)       // 5 = first-generation (register-staged) MFMA backward where the LDS-DMA one applies
+  fn2::bwd::g_corr_bwd_separate = (impl == 16);           // 16 = one backward launch per bottom where the merged launch applies
   fn2::g_corr_skip_dead = (impl == 14);                  // 14 (profiling, wrong output): no zero-fill workgroups
   fn2::g_corr_simd_plan = (impl != 13);                  // 13 = corr_fwd_pair without the SIMD plan (wave w takes patch column w)
   fn2::g_corr_ablation = (impl >= 64 && impl < 100) ? impl - 64 : 0;
@@ -244,6 +245,10 @@ FN2_API int fn2_correlation_backward(const fn2_corr_params* p, const float* bott
   if (!bottom0 || !bottom1 || !top_diff) return fail(FN2_ERR_INVALID_ARG, "correlation_backward: NULL blob pointer");
   hipStream_t st = as_stream(stream);
   if (!g_force_generic && corr_bwd_mfma_supported(g)) {
+    if (bottom0_diff && bottom1_diff) {
+      rc = corr_bwd_mfma_launch_both(g, bottom0, bottom1, top_diff, bottom0_diff, bottom1_diff, st);
+      if (rc != FN2_ERR_UNSUPPORTED) return rc;
+    }
     if (bottom0_diff) { rc = corr_bwd_mfma_launch(g, 0, bottom1, top_diff, bottom0_diff, st); if (rc) return rc; }
     if (bottom1_diff) { rc = corr_bwd_mfma_launch(g, 1, bottom0, top_diff, bottom1_diff, st); if (rc) return rc; }
     return FN2_OK;

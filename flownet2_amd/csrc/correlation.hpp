@@ -23,5 +23,7 @@ int corr_fwd_units_launch(const CorrGeom& g, const float* b0, const float* b1, f
 int corr_fwd_units_plan_words(int N, int H, int W, int policy, unsigned* out, int max_words);
 bool corr_bwd_mfma_supported(const CorrGeom& g);
 int corr_bwd_mfma_launch(const CorrGeom& g, int which, const float* other, const float* top_diff, float* out, hipStream_t st);
+// both bottom diffs in ONE launch (round 6); FN2_ERR_UNSUPPORTED (no error text) where it does not apply
+int corr_bwd_mfma_launch_both(const CorrGeom& g, const float* b0, const float* b1, const float* top_diff, float* d0, float* d1, hipStream_t st);
 
 }  // namespace fn2

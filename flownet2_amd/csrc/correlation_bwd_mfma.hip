@@ -24,6 +24,7 @@
 namespace fn2 {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 namespace bwd {
 
@@ -442,6 +443,10 @@ corr_bwd_dma(const float* __restrict__ other, const float* __restrict__ top_diff
 // Same products as before, summed row by row over the contraction rows; two accumulators per channel chunk.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace g3 {
+#ifndef FN2_G3_ABL
+#define FN2_G3_ABL 0          // profiling builds (scripts/probes/corr_bwd_variants.sh; wrong results): 1 no G-slab DMA, 2 no other-map DMA, 4 no MFMAs
+#endif
+constexpr int kAbl = FN2_G3_ABL;
 constexpr int R = 10, S2 = 2, D = 21;
 using K = Cfg<S2, R>;
 using lds_ptr_t = __attribute__((address_space(3))) void*;
@@ -478,8 +483,8 @@ __device__ __forceinline__ void stage(const float* bsrc, unsigned bbytes, const 
   for (int i = 0; i < T::RPW; ++i) {
     const int run = i * kWaves + wave;
     if (run < BRUN) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, vb[i], 0, 0, 0);
-    } else if (run < T::NRUN) {
+      if constexpr (!(kAbl & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, vb[i], 0, 0, 0);
+    } else if (run < T::NRUN && !(kAbl & 1)) {
       const int q = WHICH == 0 ? r - i0 - gpi[i] : i0 + gpi[i] - r;          // displacement row of this slab row
       const unsigned v = (gpi[i] >= 0 && q >= -R && q <= R) ? vb[i] : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, v, 0, 0, 0);
@@ -591,11 +596,16 @@ corr_bwd_g3(const float* __restrict__ other, const float* __restrict__ top_diff,
       const float v = sb[aAddr + b * aStep];
       Gv[b] = (amask >> b) & 1 ? v : 0.f;
     }
+    if constexpr (!(kAbl & 4)) {
 #pragma unroll
-    for (int c16 = 0; c16 < kNCH; ++c16)
+      for (int c16 = 0; c16 < kNCH; ++c16)
 #pragma unroll
-      for (int b = 0; b < K::NB; ++b)
-        acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gv[b], sb[bAddr + c16 * kKC * BCS + 8 * b], acc[c16][b & 1], 0, 0, 0);
+        for (int b = 0; b < K::NB; ++b)
+          acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gv[b], sb[bAddr + c16 * kKC * BCS + 8 * b], acc[c16][b & 1], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int b = 0; b < K::NB; ++b) acc[0][b & 1][0] += Gv[b];
+    }
     buf ^= 1;
   }
 #undef FN2_G3_STAGE
@@ -628,7 +638,246 @@ corr_bwd_g3(const float* __restrict__ other, const float* __restrict__ top_diff,
 }
 }  // namespace g3
 
-int g_corr_bwd_gen = 0;           // test hook (fn2_debug_set_correlation_impl(6)): 2 = run generation 2 where generation 3 applies
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fourth generation (round 6).  Ablation builds of generation 3 (scripts/probes/corr_bwd_variants.sh, profiles/r06_corr_bwd_notes.md):
+// without any staging the kernel takes 45 us per bottom, without the other map's rows 61-64 (they come from L2: free), without the G slab
+// 51-55 -- the rows of top_diff are touched ONCE per workgroup quartet and come from HBM, and a one-row-ahead prefetch does not cover that
+// latency; the bottom-1 slab (84 rows x 72 staged pixels, 44 % of them used) also kept that variant at one workgroup per CU.  Here:
+//   * G is staged THREE rows deep (ring of 3 slabs), the other map's row two deep: a row's G has two row times to arrive, and the wait
+//     in front of a row (`s_waitcnt vmcnt(n)`, n = this wave's G instructions of the youngest slab) does not cover it;
+//   * bottom 1 stages, for displacement column oo, only the 32 contraction pixels the workgroup's 16 output columns pair with that
+//     displacement -- a window that slides by 2 pixels per displacement, cut at 16-byte slots: 36 dwords per row (as bottom 0) instead of
+//     76: the slab is 12 KB for both bottoms, 74 KB of LDS per workgroup = two workgroups per CU for both;
+//   * the operand reads of MFMA k + LA are issued behind MFMA k (`sched_barrier`), not as a block in front of the row's MFMAs.
+// Measured and dropped (same bits, profiles/r06_corr_bwd_notes.md): one wave computing BOTH x parities of a patch for half of the channels, so
+// that a conflict-free ds_read_b64 feeds two MFMAs (18 LDS instructions per 24 MFMAs instead of 30): 60.9 / 64.7 us against 60.0 / 60.6 --
+// the LDS conflicts of this kernel (54 % of its LDS cycles) are not what bounds it.
+// Same products, same order (row by row, per row chunk-major over the 6 contraction patches, two accumulators per chunk): the bits of
+// generation 3 (tests/test_gpu_parity.py::test_correlation_backward_generations_agree_bitwise).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace g4 {
+constexpr int R = 10, S2 = 2, D = 21;
+using K = Cfg<S2, R>;
+using lds_ptr_t = __attribute__((address_space(3))) void*;
+constexpr int BSL = K::BPX / 4 + 1;             // 19 slots per channel of the staged row (one pad slot): stride 76 dwords
+constexpr int BCS = 4 * BSL;
+constexpr int BSLOTS = kCQ * BSL;               // 1216 = 19 whole runs
+constexpr int BRUN = BSLOTS / 64;
+constexpr int BBUF = BRUN * 256;                // floats per other-map buffer
+constexpr int GS = 36, GSLS = GS / 4;           // G row: 36 dwords = 9 slots (bottom 0: 32 data + 4 padding; bottom 1: the 36-dword window)
+constexpr int GSLOTS = 4 * D * GSLS;            // 756
+constexpr int GRUN = cdiv(GSLOTS, 64);          // 12
+constexpr int GBUF = GRUN * 256;                // floats per G slab
+constexpr int BRPW = cdiv(BRUN, kWaves), GRPW = cdiv(GRUN, kWaves);     // 3, 2 DMA instructions per wave at most
+constexpr int LDS_FLOATS = cmax(2 * BBUF + 3 * GBUF, K::OUT_FLOATS);
+static_assert(BSLOTS % 64 == 0 && K::OUT_FLOATS <= 2 * BBUF, "the epilogue image fits the other-map buffers");
+constexpr int LA = 3;                           // operand reads run this many MFMAs ahead
+
+template <int WHICH>
+__device__ __forceinline__ void g4_body(const float* __restrict__ other, const float* __restrict__ top_diff, float* __restrict__ out, const Args& g, int L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int t = L;
+  const int cq = t % g.NCQ; t /= g.NCQ;
+  const int span = t % g.NSPAN; t /= g.NSPAN;
+  const int I = t % g.NI; t /= g.NI;
+  const int py = t % S2; t /= S2;
+  const int n = t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = wave % S2, Jw = wave / S2;
+  const int i0 = 4 * I, jS = K::SPANC * span;
+  const int Hc = (g.H - py + S2 - 1) / S2;
+  if (i0 >= Hc) return;
+  const int plane = g.H * g.W;
+  const float* src_n = other + ((size_t)n * g.C + (size_t)cq * kCQ) * plane;
+  const float* td_n = top_diff + (size_t)n * D * D * plane;
+  constexpr unsigned OOB = 0x7ffffff0u;
+
+  const int kk = lane >> 4, pi = (lane & 15) >> 2, pj = lane & 3, ch = lane & 15;
+  const int rlo = i0 - R < 0 ? 0 : i0 - R, rhi = i0 + 3 + R > Hc - 1 ? Hc - 1 : i0 + 3 + R;
+
+  // ---- DMA plan: per-lane byte offsets relative to per-row base pointers (the image row / the displacement row move with r)
+  unsigned vbB[BRPW], vbG[GRPW];
+  int gpi[GRPW];
+#pragma unroll
+  for (int i = 0; i < BRPW; ++i) {
+    const int s = (i * kWaves + wave) * 64 + lane;
+    vbB[i] = OOB;
+    if (s < BSLOTS) {
+      const int c = s / BSL, gq = s % BSL;
+      const int xb = S2 * (jS - R) + 4 * gq;
+      if (gq < K::BPX / 4 && xb >= 0 && xb < g.W) vbB[i] = 4u * (unsigned)(c * plane + xb);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GRPW; ++i) {
+    const int sg = (i * kWaves + wave) * 64 + lane;
+    vbG[i] = OOB; gpi[i] = -1;
+    if (sg < GSLOTS) {
+      const int spi = sg / (D * GSLS), oo = (sg / GSLS) % D, gq = sg % GSLS;
+      if (WHICH == 0) {
+        // top_diff[(q + R) * 21 + oo][y = 2 (i0 + pi) + py][2 jS + 4 gq ..], q = r - i0 - pi:
+        //   channel = (r - i0 + R - 3) * 21  [per-row base]  +  21 * (3 - pi) + oo  [here];  slot 8 of a row is padding
+        const int y = S2 * (i0 + spi) + py, x = S2 * jS + 4 * gq;
+        if (gq < 8 && y < g.H && x < g.W) { vbG[i] = 4u * (unsigned)((D * (3 - spi) + oo) * plane + y * g.W + x); gpi[i] = spi; }
+      } else {
+        // top_diff[(q + R) * 21 + oo][y = 2 r + py][window of displacement column o = oo - R], q = i0 + pi - r: the 16 output columns
+        // jS .. jS + 15 pair with contraction columns jS - o .. jS - o + 15 = pixels 2 (jS - o) .. + 31; the window starts at the 16-byte
+        // slot below (2 (jS - o) is 0 or 2 mod 4: the A operand adds that) and is 9 slots long
+        //   channel = (i0 - r + R) * 21, row y  [per-row base]  +  21 * pi + oo  [here]
+        const int x0 = S2 * (jS - (oo - R));
+        const int xs = x0 - (((x0 % 4) + 4) % 4);
+        const int x = xs + 4 * gq;
+        if (x >= 0 && x < g.W) { vbG[i] = 4u * (unsigned)((D * spi + oo) * plane + x); gpi[i] = spi; }
+      }
+    }
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  const unsigned g_base = lds_base + 4u * 2u * BBUF;
+
+  // ---- operand addresses (dwords)
+  const int bAddr = ch * BCS + S2 * (4 * Jw + kk) + px;                     // + c16 * 16 * BCS + 8 b
+  int aAddr, aStep;
+  int amask = 0;                                                            // bit b: displacement column of patch b is inside the band
+  if (WHICH == 0) {
+    aAddr = (pi * D + (kk - pj)) * GS + S2 * (4 * Jw + pj) + px;            // + b * 4 * GS   (oo = 4 b + kk - pj)
+    aStep = 4 * GS;
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) { const int oo = 4 * b + kk - pj; if (oo >= 0 && oo < D) amask |= 1 << b; }
+  } else {
+    aAddr = (pi * D + (pj + 2 * R - kk)) * GS + S2 * (4 * Jw + pj) + px + 2 * ((pj + kk) & 1);   // + b * (-4 GS)   (oo = pj + 2R - 4 b - kk)
+    aStep = -4 * GS;
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) { const int oo = pj + 2 * R - 4 * b - kk; if (oo >= 0 && oo < D) amask |= 1 << b; }
+  }
+
+  f32x4 acc[kNCH][2];
+#pragma unroll
+  for (int c = 0; c < kNCH; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned td_bytes = 4u * D * D * (unsigned)plane, src_bytes = 4u * kCQ * (unsigned)plane;
+  auto stage_b = [&](int rr, int slot) {
+    const int yb = S2 * rr + py;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src_n + (size_t)yb * g.W), 0,
+                                                                        src_bytes - 4u * (unsigned)(yb * g.W), 0x00020000);
+    const unsigned dst = lds_base + 4u * (unsigned)(slot * BBUF);
+#pragma unroll
+    for (int i = 0; i < BRPW; ++i) {
+      const int run = i * kWaves + wave;
+      if (run < BRUN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, vbB[i], 0, 0, 0);
+    }
+  };
+  auto stage_g = [&](int rr, int slot) {
+    const int yb = S2 * rr + py;
+    // (the base may point below the blob for displacement rows that do not exist: those lanes are masked)
+    const long long goff = WHICH == 0 ? (long long)(rr - i0 + R - 3) * D * plane : (long long)(i0 - rr + R) * D * plane + (long long)yb * g.W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(td_n + goff), 0, (unsigned)((long long)td_bytes - 4 * goff), 0x00020000);
+    const unsigned dst = g_base + 4u * (unsigned)(slot * GBUF);
+#pragma unroll
+    for (int i = 0; i < GRPW; ++i) {
+      const int run = i * kWaves + wave;
+      if (run < GRUN) {
+        const int q = WHICH == 0 ? rr - i0 - gpi[i] : i0 + gpi[i] - rr;          // displacement row of this slab row
+        const unsigned v = (gpi[i] >= 0 && q >= -R && q <= R) ? vbG[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, v, 0, 0, 0);
+      }
+    }
+  };
+  const bool two_g = wave + kWaves < GRUN;          // this wave issues two G instructions per slab (waves 0 .. 3), else one
+
+  stage_b(rlo, 0);
+  stage_g(rlo, 0);
+  if (rlo + 1 <= rhi) stage_g(rlo + 1, 1);
+  int bslot = 0, gslot = 0;
+  for (int r = rlo; r <= rhi; ++r) {
+    // in flight, oldest first: [other map r, G r] issued two rows ago / in the prologue, then G r + 1 (youngest): the wait leaves only that
+    if (r + 1 <= rhi) {
+      if (two_g) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (r + 1 <= rhi) stage_b(r + 1, bslot ^ 1);
+    // (order matters for the wait above: the other map's row first, the slab of row r + 2 last)
+    if (r + 2 <= rhi) stage_g(r + 2, gslot == 0 ? 2 : gslot - 1);
+    const float* sb = smem + bslot * BBUF + bAddr;
+    const float* sg = smem + 2 * BBUF + gslot * GBUF + aAddr;
+    float Gv[K::NB];
+#pragma unroll
+    for (int b = 0; b < K::NB; ++b) {
+      const float v = sg[b * aStep];
+      Gv[b] = (amask >> b) & 1 ? v : 0.f;
+    }
+    // 24 MFMAs, chunk-major; the other-map operand of MFMA k + LA is read behind MFMA k
+    float bv[kNCH * K::NB];
+#pragma unroll
+    for (int k = 0; k < LA; ++k) bv[k] = sb[(k / K::NB) * kKC * BCS + 8 * (k % K::NB)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < kNCH * K::NB; ++k) {
+      const int c16 = k / K::NB, b = k % K::NB;
+      acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gv[b], bv[k], acc[c16][b & 1], 0, 0, 0);
+      if (k + LA < kNCH * K::NB) bv[k + LA] = sb[((k + LA) / K::NB) * kKC * BCS + 8 * ((k + LA) % K::NB)];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bslot ^= 1;
+    gslot = gslot == 2 ? 0 : gslot + 1;
+  }
+
+  // ---- epilogue (as the earlier generations): accumulators -> LDS -> 128-byte rows
+  __syncthreads();
+  const float sumelems = (float)g.C;
+  const bool pow2 = (g.C & (g.C - 1)) == 0;
+  const float rcp = 1.0f / sumelems;
+  const int opi = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < kNCH; ++c) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const float v = acc[c][0][rr] + acc[c][1][rr];
+      smem[((c * kKC + ch) * 4 + opi) * K::XS + S2 * (4 * Jw + rr) + px] = pow2 ? v * rcp : v / sumelems;
+    }
+  }
+  __syncthreads();
+  const int xl = tid % K::SPANPX;
+  const int x = S2 * jS + xl;
+  if (x < g.W) {
+    float* out_n = out + ((size_t)n * g.C + (size_t)cq * kCQ) * plane;
+    for (int rowid = tid / K::SPANPX; rowid < kCQ * 4; rowid += kThreads / K::SPANPX) {
+      const int c = rowid >> 2, rpi = rowid & 3;
+      const int y = S2 * (i0 + rpi) + py;
+      if (y < g.H) out_n[(size_t)c * plane + (size_t)y * g.W + x] = smem[rowid * K::XS + xl];
+    }
+  }
+}
+
+template <int WHICH>
+__global__ void __launch_bounds__(kThreads, 2)
+corr_bwd_g4(const float* __restrict__ other, const float* __restrict__ top_diff, float* __restrict__ out, Args g) {
+  const int L = (int)(blockIdx.x % 8) * g.GP + (int)(blockIdx.x / 8);
+  if (L >= g.G) return;
+  g4_body<WHICH>(other, top_diff, out, g, L);
+}
+
+// BOTH bottoms in one launch: task L of bottom 0 and task L of bottom 1 are neighbours in the grid (same XCD: they read the same rows of
+// top_diff).  Two launches of 640 workgroups on 512 slots are two rounds each -- the second a quarter full; 1280 workgroups in one grid are
+// 2.5 rounds, and the tail of one bottom's work overlaps the head of the other's (profiles/r06_corr_bwd_notes.md).  Same per-task code,
+// same bits.
+__global__ void __launch_bounds__(kThreads, 2)
+corr_bwd_g4_both(const float* __restrict__ bottom0, const float* __restrict__ bottom1, const float* __restrict__ top_diff,
+                 float* __restrict__ diff0, float* __restrict__ diff1, Args g) {
+  const int L2 = (int)(blockIdx.x % 8) * (2 * g.GP) + (int)(blockIdx.x / 8);
+  if (L2 >= 2 * g.G) return;
+  if (L2 & 1) g4_body<1>(bottom0, top_diff, diff1, g, L2 >> 1);
+  else g4_body<0>(bottom1, top_diff, diff0, g, L2 >> 1);
+}
+
+}  // namespace g4
+
+int g_corr_bwd_gen = 0;           // test hook (fn2_debug_set_correlation_impl(6 / 15)): 2 / 3 = run generation 2 / 3 where generation 4 applies
+int g_corr_bwd_separate = 0;      // test hook (fn2_debug_set_correlation_impl(16)): one launch per bottom where the merged launch applies
 int g_corr_bwd_first_gen = 0;     // test hook (fn2_debug_set_correlation_impl(5)): run the first-generation kernel where both apply
 
 template <int S2, int R, int WHICH>
@@ -646,6 +895,16 @@ static int launch(const CorrGeom& cg, const float* other, const float* top_diff,
   g.GP = (g.G + 7) / 8;
   if constexpr (S2 == 2 && R == 10) {
     const bool aligned = cg.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(other) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned && !g_corr_bwd_first_gen && g_corr_bwd_gen == 0 && ((reinterpret_cast<uintptr_t>(top_diff)) & 15) == 0) {
+      const size_t lds4 = sizeof(float) * g4::LDS_FLOATS;
+      static bool attr4_set = false;
+      if (!attr4_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g4::corr_bwd_g4<WHICH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        attr4_set = true;
+      }
+      hipLaunchKernelGGL((g4::corr_bwd_g4<WHICH>), dim3(8 * g.GP), dim3(kThreads), lds4, st, other, top_diff, out, g);
+      return check_launch("correlation_backward (mfma, G ring)");
+    }
     if (aligned && !g_corr_bwd_first_gen && g_corr_bwd_gen != 2 && ((reinterpret_cast<uintptr_t>(top_diff)) & 15) == 0) {
       const size_t lds3 = sizeof(float) * g3::G<WHICH>::LDS_FLOATS;
       static bool attr3_set = false;
@@ -677,7 +936,38 @@ static int launch(const CorrGeom& cg, const float* other, const float* top_diff,
   return check_launch("correlation_backward (mfma)");
 }
 
+// both bottoms of the FlowNetC instance in one grid (generation 4); FN2_ERR_UNSUPPORTED where it does not apply (the caller launches one by one)
+static int launch_both(const CorrGeom& cg, const float* b0, const float* b1, const float* top_diff, float* d0, float* d1, hipStream_t st) {
+  using K = Cfg<2, 10>;
+  if (cg.s2 != 2 || cg.ngr != 10 || g_corr_bwd_first_gen || g_corr_bwd_gen != 0 || g_corr_bwd_separate) return FN2_ERR_UNSUPPORTED;
+  const bool aligned = cg.W % 4 == 0 && ((reinterpret_cast<uintptr_t>(b0) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(d0) |
+                                          reinterpret_cast<uintptr_t>(d1) | reinterpret_cast<uintptr_t>(top_diff)) & 15) == 0;
+  if (!aligned) return FN2_ERR_UNSUPPORTED;
+  Args g;
+  g.N = cg.N; g.C = cg.C; g.H = cg.H; g.W = cg.W;
+  const int Hc = (cg.H + 1) / 2, Wc = (cg.W + 1) / 2;
+  g.NI = (Hc + 3) / 4;
+  g.NSPAN = (Wc + K::SPANC - 1) / K::SPANC;
+  g.NCQ = cg.C / kCQ;
+  const long long G = (long long)cg.N * 2 * g.NI * g.NSPAN * g.NCQ;
+  if (G > (1ll << 29)) return FN2_ERR_UNSUPPORTED;
+  g.G = (int)G;
+  g.GP = (g.G + 7) / 8;
+  const size_t lds4 = sizeof(float) * g4::LDS_FLOATS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&g4::corr_bwd_g4_both), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(g4::corr_bwd_g4_both, dim3(16 * g.GP), dim3(kThreads), lds4, st, b0, b1, top_diff, d0, d1, g);
+  return check_launch("correlation_backward (mfma, both bottoms)");
+}
+
 }  // namespace bwd
+
+int corr_bwd_mfma_launch_both(const CorrGeom& g, const float* b0, const float* b1, const float* top_diff, float* d0, float* d1, hipStream_t st) {
+  return bwd::launch_both(g, b0, b1, top_diff, d0, d1, st);
+}
 
 bool corr_bwd_mfma_supported(const CorrGeom& g) {
   if (g.K != 1 || g.s1 != 1 || g.type != FN2_CORR_MULTIPLY || g.pad != g.md) return false;

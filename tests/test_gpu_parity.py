@@ -958,11 +958,13 @@ def test_correlation_fused_relu_and_channel_slice(case):
     assert_close(out.cpu().numpy(), top, 2e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 128, 16, 24), (2, 64, 11, 28), (8, 256, 40, 56)])
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 128, 16, 24), (2, 64, 11, 28), (8, 256, 40, 56), (1, 64, 9, 12), (3, 64, 30, 72), (1, 64, 4, 4)])
 def test_correlation_backward_generations_agree_bitwise(shape):
-    """Three generations of the MFMA backward.  1 (register-staged) and 2 (LDS-DMA staging, gathered G) perform the same
+    """Four generations of the MFMA backward.  1 (register-staged) and 2 (LDS-DMA staging, gathered G) perform the same
     multiplications in the same order: identical bits.  3 (G through LDS, one contraction row per chunk) sums the same products
-    row by row: equal at rounding level, on ragged heights too; all against the oracle on the small shapes."""
+    row by row: equal at rounding level, on ragged heights too.  4 (round 6: G ring three rows deep, the bottom-1 slab cut to the
+    sliding 36-dword window, operand reads pinned behind the MFMAs) performs generation 3's products in generation 3's order:
+    identical bits to it; all against the oracle on the small shapes."""
     N, C, H, W = shape
     p = ops.corr_params(20, 1, 20, 1, 2)
     b0, b1 = rand(shape, 41), rand(shape, 42)
@@ -972,11 +974,22 @@ def test_correlation_backward_generations_agree_bitwise(shape):
         f0, f1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
         ops.set_correlation_impl(6)
         s0, s1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
-        ops.set_correlation_impl(0)
+        ops.set_correlation_impl(15)
         t0, t1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        ops.set_correlation_impl(16)                  # generation 4, one launch per bottom
+        w0, w1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        ops.set_correlation_impl(0)                   # generation 4, both bottoms in one grid (the default)
+        u0, u1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        v0, v1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td))
+        only0, _ = ops.correlation_backward(p, dev(b0), dev(b1), dev(td), need1=False)
+        _, only1 = ops.correlation_backward(p, dev(b0), dev(b1), dev(td), need0=False)
     finally:
         ops.set_correlation_impl(0)
     assert torch.equal(f0, s0) and torch.equal(f1, s1)
+    assert torch.equal(t0, u0), float((t0 - u0).abs().max())
+    assert torch.equal(t1, u1), float((t1 - u1).abs().max())
+    assert torch.equal(u0, v0) and torch.equal(u1, v1)
+    assert torch.equal(w0, u0) and torch.equal(w1, u1) and torch.equal(only0, u0) and torch.equal(only1, u1)
     assert_close(host(t0), host(f0), 2e-6, "generation 3 vs 1, bottom 0 diff")
     assert_close(host(t1), host(f1), 2e-6, "generation 3 vs 1, bottom 1 diff")
     if N * C * H * W <= 2 * 64 * 24 * 40:
