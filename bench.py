@@ -107,6 +107,18 @@ def corr_roofline(device, batch, h, w, iters):
         cold.append(c0.elapsed_time(c1) * 1e3)
     del flush
     cold_us = sorted(cold)[len(cold) // 2]
+    # the backward of the same layer (both bottom diffs; one launch since round 6), timed the same way: 2 x the forward's flops
+    gtop = torch.randn(batch, D2, H, W, device=device, generator=g)
+    for _ in range(300):
+        ops.correlation_backward(p, a, b, gtop)
+    b0e, b1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0e.record()
+    for _ in range(max(1, iters // 2)):
+        ops.correlation_backward(p, a, b, gtop)
+    b1e.record()
+    torch.cuda.synchronize()
+    t_bwd = b0e.elapsed_time(b1e) * 1e-3 / max(1, iters // 2)
+    del gtop
     # per-launch events (includes launch gaps) vs back-to-back average: take the back-to-back average
     alg_bytes = 4.0 * batch * H * W * (2 * C + D2)               # read both maps once + write top once
     alg_flops = 2.0 * C * D2 * batch * H * W
@@ -153,6 +165,9 @@ def corr_roofline(device, batch, h, w, iters):
         "us_per_launch": round(t * 1e6, 2), "us_per_launch_cold_caches": round(cold_us, 2),
         "alg_flops_per_launch": alg_flops, "alg_bytes_per_launch": alg_bytes,
         "hbm": {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4)},
+        "backward": {"kernel": "corr_bwd (both bottom diffs, one launch)", "us_per_call": round(t_bwd * 1e6, 2), "alg_flops_per_call": 2 * alg_flops,
+                     "achieved": round(2 * alg_flops / t_bwd / 1e12, 3), "unit": "TFLOP/s", "frac": round(2 * alg_flops / t_bwd / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                     "alg_bytes_per_call": 4.0 * batch * H * W * (D2 + 4 * C)},
         "note": "exact-fp32 correlation is FMA-bound (59 flop/B > machine balance); hbm = algorithmic bytes / time",
     }
 
@@ -254,6 +269,7 @@ def rank_seed(rank):
     return 1234 + rank              # every rank its own synthetic batch (weak scaling: per-GPU work fixed)
 
 
+nets.RELU_CHAIN[0] = os.environ.get("FN2_RELU_CHAIN", "1") == "1"       # A/B hook: 0 = every layer undoes its own ReLU in a pass of its own (rounds 1-5)
 AHEAD = [os.environ.get("FN2_BENCH_TARGETS_AHEAD", "1") == "1"]      # A/B hook: 0 = Downsample(GT) between forward and backward (rounds 1-5)
 WGRAD_SIDE_PIXELS = [36000]       # --wgrad-side-pixels: GradientExchange's second stream for the weight gradients (single-rank jobs)
 
@@ -282,14 +298,24 @@ def run_workload(net, mode, B, H, W, steps, warmup, device, world, rank, bucket_
         # identical Adam step on every rank
         # local_grads: the SAME step without the collective (every rank keeps its own gradients) -- the comparison leg from which
         # train_leg() reports how much of the all-reduce is not hidden behind backward
+        NEG_MEAN = [torch.full((3,), -0.43, device=device, dtype=torch.float32)]
         exchange = parallel.GradientExchange([P[k] for k in P], bucket_bytes=bucket_mb << 20, local_only=local_grads, wgrad_side_pixels=WGRAD_SIDE_PIXELS[0],
                                              force_collective=force_collective)
 
         def step():
             exchange.zero_grad()
             tg = nets.loss_targets_ahead(gt, be) if AHEAD[0] else None      # the ground-truth pyramid: issued first, on the second stream
-            pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
-            loss = nets.multiscale_loss(nets.flownet_c_core(P, pre[0], pre[1], be), gt, be, targets=tg)
+            if hasattr(be, "scale_shift") and img0.is_cuda:
+                # Eltwise{1/255} + mean subtraction of both images written straight into the stacked tower batch (product and difference
+                # rounded separately: the bits of `im * (1 / 255) - 0.43`; two launches instead of four element-wise kernels and a concat)
+                towers = torch.empty((2 * B, 3, H, W), device=device, dtype=torch.float32)
+                be.scale_shift(img0, 1.0 / 255.0, NEG_MEAN[0], out=towers[:B])
+                be.scale_shift(img1, 1.0 / 255.0, NEG_MEAN[0], out=towers[B:])
+                flows = nets.flownet_c_core(P, None, None, be, towers=towers)
+            else:
+                pre = [(im * (1.0 / 255.0)) - 0.43 for im in (img0, img1)]
+                flows = nets.flownet_c_core(P, pre[0], pre[1], be)
+            loss = nets.multiscale_loss(flows, gt, be, targets=tg)
             loss.backward()
             exchange.finish()
             opt.step()

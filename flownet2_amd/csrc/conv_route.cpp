@@ -310,6 +310,31 @@ FN2_API int fn2_conv_backward_data_computed_channels(const fn2_conv_desc* d, int
   return (route == FN2_BWD_ROUTE_NONE || route != g.route) ? 0 : g.Cp;
 }
 
+namespace fn2 {
+int tconv_forward_masked(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                         int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                         int Cout, int Hout, int Wout, int top_channels, int top_c0, int kernel, int pad,
+                         int relu, float negative_slope, const float* mask, int mask_channels, int mask_c0, float mask_slope, void* stream);
+}
+
+FN2_API int fn2_conv_backward_data_masked_supported(const fn2_conv_desc* d, int transposed, int route) {
+  const Bwd g = bwd_geom(d, transposed);
+  return route == FN2_BWD_ROUTE_TCONV && route == g.route && g.Cp == g.Cb;
+}
+
+FN2_API int fn2_conv_backward_data_masked(const fn2_conv_desc* d, int transposed, int route, const float* top_diff, int top_channels, int top_c0,
+                                          const float* packed, float* bottom_diff, int bottom_channels, int bottom_c0,
+                                          const float* bottom_data, int data_channels, int data_c0, float negative_slope, void* stream) {
+  if (!fn2_conv_backward_data_masked_supported(d, transposed, route))
+    return fn2::fail(FN2_ERR_UNSUPPORTED, "conv_backward_data_masked: only the transposed-convolution route folds the ReLU derivative of the layer in front");
+  if (!top_diff || !packed || !bottom_diff || !bottom_data) return fn2::fail(FN2_ERR_INVALID_ARG, "conv_backward_data_masked: NULL blob");
+  const Bwd g = bwd_geom(d, transposed);
+  if (top_c0 < 0 || top_c0 + g.Ct > top_channels || bottom_c0 < 0 || bottom_c0 + g.Cb > bottom_channels)
+    return fn2::fail(FN2_ERR_INVALID_ARG, "conv_backward_data_masked: channel slice outside its blob");
+  return fn2::tconv_forward_masked(top_diff, packed, nullptr, bottom_diff, d->N, g.Ct, g.Ht, g.Wt, top_channels, top_c0, g.Cb, g.Hb, g.Wb, bottom_channels,
+                                   bottom_c0, d->kernel, d->pad, 0, 0.f, bottom_data, data_channels, data_c0, negative_slope, stream);
+}
+
 FN2_API int fn2_conv_backward_data(const fn2_conv_desc* d, int transposed, int route, const float* top_diff, int top_channels, int top_c0,
                                    const float* packed, float* bottom_diff, int bottom_channels, int bottom_c0, int bottom_room,
                                    void* workspace, size_t workspace_bytes, void* stream) {
@@ -388,6 +413,23 @@ FN2_API size_t fn2_conv_backward_weights_workspace_bytes(const fn2_conv_desc* d,
   if (stem_class(d, transposed)) return fn2_conv_k7s2_wgrad_workspace_bytes(d->N, d->Cin, d->Hin, d->Win, d->Cout);
   const WG w = wg_geom(d, transposed);
   return fn2_conv_wgrad_workspace_bytes(d->N, w.Ca, w.Ha, w.Wa, w.Cb, w.Hb, w.Wb, d->kernel, d->stride, d->pad);
+}
+
+namespace fn2 {
+int conv_k7s2_wgrad_bias(const float* top_diff, const float* bottom, float* weight_diff, float* bias_diff, int N, int Cin, int Hin, int Win, int Cout,
+                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+}
+
+// weight_diff AND bias_diff of a layer from one pass over top_diff where a kernel has that form (the stem: csrc/conv_stem_wgrad.hip sums
+// the operand it feeds to the matrix pipe); 1 = it has
+FN2_API int fn2_conv_backward_weights_bias_fused(const fn2_conv_desc* d, int transposed) { return valid(d) && stem_class(d, transposed) ? 1 : 0; }
+
+FN2_API int fn2_conv_backward_weights_bias(const fn2_conv_desc* d, int transposed, const float* bottom, const float* top_diff, float* weight_diff,
+                                           float* bias_diff, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!fn2_conv_backward_weights_bias_fused(d, transposed))
+    return fn2::fail(FN2_ERR_UNSUPPORTED, "conv_backward_weights_bias: this layer has no fused weight + bias gradient kernel");
+  if (!bottom || !top_diff || !weight_diff || !bias_diff) return fn2::fail(FN2_ERR_INVALID_ARG, "conv_backward_weights_bias: NULL blob");
+  return fn2::conv_k7s2_wgrad_bias(top_diff, bottom, weight_diff, bias_diff, d->N, d->Cin, d->Hin, d->Win, d->Cout, accumulate, workspace, workspace_bytes, stream);
 }
 
 FN2_API int fn2_conv_backward_weights(const fn2_conv_desc* d, int transposed, const float* bottom, int bottom_channels, int bottom_c0,

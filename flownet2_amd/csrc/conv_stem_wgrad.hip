@@ -117,7 +117,11 @@ __device__ __forceinline__ void stage_unit(const Args& a, int u, unsigned dst, i
   }
 }
 
-template <int CIN>
+// BIAS (round 6): the A operand IS top_diff -- every lane also sums the values it feeds to the matrix pipe (one v_add per k-step), the four
+// pixel lanes of a channel are combined at the end and the part's 64 bias sums travel in the first padding tap column of its slab:
+// backward_gpu_bias (base_conv_layer.cpp:389-393) without a pass of its own over the blob.  Order: per lane its pixels in (unit, row, x)
+// order, then lanes k = 0 .. 3 as ((k0 + k1) + (k2 + k3)), then the parts like the weights.
+template <int CIN, bool BIAS>
 __global__ void __launch_bounds__(256) stem_wgrad(Args a) {
   using G = Geo<CIN>;
   constexpr int NT = G::NT, NSTEP = kR * (kXT / 4);
@@ -144,6 +148,7 @@ __global__ void __launch_bounds__(256) stem_wgrad(Args a) {
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
 
   if (u0 < u1) stage_unit<CIN>(a, u0, lds_base, wave, plan);
   for (int u = u0; u < u1; ++u) {
@@ -174,14 +179,22 @@ __global__ void __launch_bounds__(256) stem_wgrad(Args a) {
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], bv[cur][nt], acc[nt], 0, 0, 0);
         if (st + 1 < NSTEP) __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (BIAS) bsum += av[cur];
     }
   }
   // slab[part][co][NT * 16]: lane (row block rb = lane >> 4, tap column lane & 15) holds rows 4 rb .. 4 rb + 3 of every tile
   float* out = a.slab + (size_t)part * kCout * (G::NT * 16);
+  static_assert(G::TAPS < G::NT * 16, "a padding tap column carries the bias sums");
 #pragma unroll
   for (int nt = 0; nt < G::NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(size_t)(16 * wave + 4 * (lane >> 4) + r) * (G::NT * 16) + 16 * nt + (lane & 15)] = acc[nt][r];
+    for (int r = 0; r < 4; ++r)
+      if (!(BIAS && 16 * nt + (lane & 15) == G::TAPS)) out[(size_t)(16 * wave + 4 * (lane >> 4) + r) * (G::NT * 16) + 16 * nt + (lane & 15)] = acc[nt][r];
+  if constexpr (BIAS) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 16) out[(size_t)(16 * wave + lane) * (G::NT * 16) + G::TAPS] = bsum;
+  }
 }
 
 // dw[co][t] (+)= sum over the parts, in a fixed two-level order: the parts are cut into kSeg contiguous segments [s P / kSeg, (s + 1) P / kSeg);
@@ -237,16 +250,27 @@ static void fill(Args& a, int N, int H, int W) {
 }
 
 template <int CIN>
-static int launch(Args a, float* dw, int accumulate, hipStream_t st) {
+static int launch(Args a, float* dw, float* db, int accumulate, hipStream_t st) {
   using G = Geo<CIN>;
   constexpr size_t lds = sizeof(float) * 2 * G::BUF;
+  if (db) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad<CIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_wgrad: %zu bytes of dynamic LDS refused by the runtime", lds);
+    }
+    hipLaunchKernelGGL((stem_wgrad<CIN, true>), dim3((unsigned)a.parts), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((kCout * G::TAPS + 15) / 16), dim3(256), 0, st, a.slab, dw, G::TAPS, G::NT * 16, a.parts, accumulate);
+    // the bias sums: the same two-level order over the parts, "one tap" wide, from the padding column
+    hipLaunchKernelGGL(stem_wgrad_finalize, dim3((kCout + 15) / 16), dim3(256), 0, st, a.slab + G::TAPS, db, 1, G::NT * 16, a.parts, accumulate);
+    return check_launch("conv_k7s2_wgrad (+ bias)");
+  }
   // 70 / 104 KB of dynamic LDS (above the 64 KB default): set per launch -- the attribute belongs to the CURRENT device's copy of the
   // function, a per-process latch would leave every device after the first without it -- and checked
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad<CIN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
     (void)hipGetLastError();
     return fail(FN2_ERR_UNSUPPORTED, "conv_k7s2_wgrad: %zu bytes of dynamic LDS refused by the runtime", lds);
   }
-  hipLaunchKernelGGL((stem_wgrad<CIN>), dim3((unsigned)a.parts), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((stem_wgrad<CIN, false>), dim3((unsigned)a.parts), dim3(256), lds, st, a);
   hipLaunchKernelGGL(stem_wgrad_finalize, dim3((kCout * G::TAPS + 15) / 16), dim3(256), 0, st, a.slab, dw, G::TAPS, G::NT * 16, a.parts, accumulate);
   return check_launch("conv_k7s2_wgrad");
 }
@@ -274,12 +298,24 @@ FN2_API size_t fn2_conv_k7s2_wgrad_workspace_bytes(int N, int Cin, int Hin, int 
   return sizeof(float) * (size_t)a.parts * sw::kCout * (((Cin * 49 + 15) / 16) * 16);
 }
 
+namespace fn2 {
+int conv_k7s2_wgrad_bias(const float* top_diff, const float* bottom, float* weight_diff, float* bias_diff, int N, int Cin, int Hin, int Win, int Cout,
+                         int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+}
+
 FN2_API int fn2_conv_k7s2_wgrad(const float* top_diff, const float* bottom, float* weight_diff, int N, int Cin, int Hin, int Win, int Cout,
                                 int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  return fn2::conv_k7s2_wgrad_bias(top_diff, bottom, weight_diff, nullptr, N, Cin, Hin, Win, Cout, accumulate, workspace, workspace_bytes, stream);
+}
+
+// bias_diff != NULL: the bias gradient of the same layer comes out of the same pass (stem_wgrad<.., true>)
+int fn2::conv_k7s2_wgrad_bias(const float* top_diff, const float* bottom, float* weight_diff, float* bias_diff, int N, int Cin, int Hin, int Win, int Cout,
+                              int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (N < 0) return fail(FN2_ERR_INVALID_ARG, "conv_k7s2_wgrad: bad batch");
   if (!top_diff || !bottom || !weight_diff) return fail(FN2_ERR_INVALID_ARG, "conv_k7s2_wgrad: null blob");
   if (N == 0) {
     if (!accumulate) (void)hipMemsetAsync(weight_diff, 0, sizeof(float) * (size_t)Cout * Cin * 49, as_stream(stream));
+    if (!accumulate && bias_diff) (void)hipMemsetAsync(bias_diff, 0, sizeof(float) * (size_t)Cout, as_stream(stream));
     return FN2_OK;
   }
   if (!sw::geometry_ok(N, Cin, Hin, Win, Cout))
@@ -292,7 +328,7 @@ FN2_API int fn2_conv_k7s2_wgrad(const float* top_diff, const float* bottom, floa
   sw::fill(a, N, Hin, Win);
   a.d = top_diff; a.b = bottom; a.slab = static_cast<float*>(workspace);
   hipStream_t st = as_stream(stream);
-  if (Cin == 3) return sw::launch<3>(a, weight_diff, accumulate, st);
-  if (Cin == 6) return sw::launch<6>(a, weight_diff, accumulate, st);
-  return sw::launch<12>(a, weight_diff, accumulate, st);
+  if (Cin == 3) return sw::launch<3>(a, weight_diff, bias_diff, accumulate, st);
+  if (Cin == 6) return sw::launch<6>(a, weight_diff, bias_diff, accumulate, st);
+  return sw::launch<12>(a, weight_diff, bias_diff, accumulate, st);
 }

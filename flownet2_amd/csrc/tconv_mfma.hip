@@ -41,6 +41,10 @@ struct Args {
   int tx, ty, ng;
   unsigned total;
   float slope; int relu;
+  // round 6, data-gradient use: the output is the gradient w.r.t. the ACTIVATED output `mask` of the layer in front ([N, mask_ctot, Hout, Wout],
+  // channels from mask_c0 on): multiplied by that layer's leaky-ReLU derivative on the way out (ReLUBackward, relu_layer.cu:33-43, folded
+  // into the kernel that produces its top_diff: one pass over the blob instead of three)
+  const float* mask; int mask_ctot, mask_c0; float mask_slope;
 };
 
 // parity class algebra of one axis: taps k == (p + PAD) (mod 2); tap k reads input position  class position + D(p, k)
@@ -208,6 +212,20 @@ __device__ __forceinline__ void tconv_body(const Args& a, int g, int bx, int by,
             if (a.relu) s = s > 0.f ? s : s * a.slope;
             v[r] = s;
           }
+          if (a.mask) {
+            const float* mrow = a.mask + (((size_t)n * a.mask_ctot + a.mask_c0 + co) * a.Hout + Y) * a.Wout;
+            float m[8];
+            if (X0 + 7 < a.Wout) {
+              const f32x4 m0 = *reinterpret_cast<const f32x4*>(mrow + X0), m1 = *reinterpret_cast<const f32x4*>(mrow + X0 + 4);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { m[r] = m0[r]; m[4 + r] = m1[r]; }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) m[r] = X0 + r < a.Wout ? mrow[X0 + r] : 1.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= m[r] > 0.f ? 1.f : a.mask_slope;      // the expression of bias_leaky_relu_bwd: the same bits
+          }
           if (X0 + 7 < a.Wout) {
             *reinterpret_cast<f32x4*>(orow + X0) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(orow + X0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -308,10 +326,25 @@ FN2_API int fn2_tconv_supported(int Cin, int Hin, int Win, int Cout, int Hout, i
 FN2_API int fn2_debug_set_tconv_variant(int v) { tc::g_forced_variant = v; return FN2_OK; }
 FN2_API int fn2_tconv_num_variants(void) { return tc::kNumVariants; }
 
+namespace fn2 {
+int tconv_forward_masked(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                         int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                         int Cout, int Hout, int Wout, int top_channels, int top_c0, int kernel, int pad,
+                         int relu, float negative_slope, const float* mask, int mask_channels, int mask_c0, float mask_slope, void* stream);
+}
+
 FN2_API int fn2_tconv_forward(const float* bottom, const float* packed_weight, const float* bias, float* top,
                               int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
                               int Cout, int Hout, int Wout, int top_channels, int top_c0, int kernel, int pad,
                               int relu, float negative_slope, void* stream) {
+  return fn2::tconv_forward_masked(bottom, packed_weight, bias, top, N, Cin, Hin, Win, bottom_channels, bottom_c0, Cout, Hout, Wout, top_channels, top_c0,
+                                   kernel, pad, relu, negative_slope, nullptr, 0, 0, 1.f, stream);
+}
+
+int fn2::tconv_forward_masked(const float* bottom, const float* packed_weight, const float* bias, float* top,
+                              int N, int Cin, int Hin, int Win, int bottom_channels, int bottom_c0,
+                              int Cout, int Hout, int Wout, int top_channels, int top_c0, int kernel, int pad,
+                              int relu, float negative_slope, const float* mask, int mask_channels, int mask_c0, float mask_slope, void* stream) {
   if (N < 0) return fail(FN2_ERR_INVALID_ARG, "tconv: bad batch");
   if (N == 0) return FN2_OK;
   if (!bottom || !packed_weight || !top) return fail(FN2_ERR_INVALID_ARG, "tconv: null blob");
@@ -327,6 +360,11 @@ FN2_API int fn2_tconv_forward(const float* bottom, const float* packed_weight, c
   a.Cout = Cout; a.Hout = Hout; a.Wout = Wout; a.out_ctot = top_channels; a.out_c0 = top_c0;
   a.ksteps = tc::ksteps_for(Cin, kernel) + tc::kSpare;
   a.slope = negative_slope; a.relu = relu;
+  if (mask) {
+    if (mask_c0 < 0 || mask_c0 + Cout > mask_channels) return fail(FN2_ERR_INVALID_ARG, "tconv: mask slice outside its blob");
+    if ((reinterpret_cast<uintptr_t>(mask) & 15) != 0) return fail(FN2_ERR_UNSUPPORTED, "tconv: mask blob must be 16-byte aligned");
+  }
+  a.mask = mask; a.mask_ctot = mask_channels; a.mask_c0 = mask_c0; a.mask_slope = mask_slope;
   hipStream_t st = as_stream(stream);
   int best = -1;
   if (tc::g_forced_variant >= 0) {

@@ -373,14 +373,14 @@ def conv_bias_leaky_relu(y, bias, negative_slope=0.1):
     return ops.bias_leaky_relu_(y, bias, negative_slope)
 
 
-def conv_k7s2_relu(x, weight, bias, negative_slope=0.1):
+def conv_k7s2_relu(x, weight, bias, negative_slope=0.1, relu_chain=None):
     """Stem convolution + bias + leaky ReLU.  Returns None when the fused HIP kernel does not apply (autograd needed or
     unsupported shape): the caller then runs the library convolution."""
     if not ops.conv_k7s2_relu_supported(x.shape[1], x.shape[2], x.shape[3], weight.shape[0]):
         return None
     run = lambda xx, ww, bb: ops.conv_k7s2_relu_forward(xx.contiguous(), ww.contiguous(), bb, negative_slope)
     if _needs_grad(x, weight, bias):
-        return _OwnForwardConv.apply(x, weight, bias, run, 2, 3, negative_slope, True, False)
+        return _OwnForwardConv.apply(x, weight, bias, run, 2, 3, negative_slope, True, False, None, relu_chain)
     return run(x, weight, bias)
 
 
@@ -502,7 +502,7 @@ class _OwnForwardConv(torch.autograd.Function):
     (aten::convolution_backward = MIOpen's bwd-data / bwd-weights kernels)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, runner, stride, pad, negative_slope, act, transposed, into=None):
+    def forward(ctx, x, weight, bias, runner, stride, pad, negative_slope, act, transposed, into=None, relu_chain=None):
         # autograd does not record inside forward(): the parameter OBJECT goes to the runner, so that the packed-weight caches
         # (keyed on the parameter and its _version) hit until the optimizer writes the weight.
         # into = (blob, first channel): the runner writes its channels into that slice of the consumer's Concat blob (a plain buffer
@@ -515,6 +515,9 @@ class _OwnForwardConv(torch.autograd.Function):
             y = into[0][:, into[1]:into[1] + co]
         ctx.cfg = (stride, pad, negative_slope, act, bias is not None, transposed)
         ctx.into = into
+        # relu_chain (round 6, set by the graph builder for a layer pair A -> B where B is A's ONLY consumer): bit 0 on A = "my top_diff arrives
+        # already multiplied by my ReLU derivative" (B did it), bit 1 on B = "fold the ReLU derivative of the layer in front into my data gradient"
+        ctx.relu_chain, ctx.chain_cell = (int(relu_chain[0]), relu_chain[1]) if relu_chain else (0, None)
         # the activated output is needed for the ReLU mask: a slice of a Concat blob is kept as the BLOB (a saved view comes back from autograd
         # as a plain strided tensor that has forgotten its base: reading it in place needs the blob and the offset)
         ctx.save_for_backward(x, weight, (into[0] if into is not None else y) if act else None)
@@ -526,9 +529,20 @@ class _OwnForwardConv(torch.autograd.Function):
         stride, pad, slope, act, has_bias, transposed = ctx.cfg
         if act and ctx.into is not None:
             y = (y, ctx.into[1], w.shape[1] if transposed else w.shape[0])          # (blob, first channel, channels)
+        premasked = False
+        if ctx.relu_chain & 1:
+            # the consumer must have folded this layer's ReLU derivative into the gradient it handed over -- checked, not assumed: a consumer
+            # that took another route (a library fallback, a frozen graph) would otherwise leave the gradient unmasked without a sound
+            if not ctx.chain_cell.get("masked"):
+                raise RuntimeError("relu_chain: the consumer of this layer did not fold the ReLU derivative into its data gradient")
+            ctx.chain_cell["masked"] = False
+            premasked = True
         gx, gw, db = conv_backward(x, w, y if act else None, g, stride, pad, slope, transposed, bool(ctx.needs_input_grad[0]),
-                                   bool(ctx.needs_input_grad[1]), has_bias and ctx.needs_input_grad[2])
-        return gx, gw, db, None, None, None, None, None, None, None
+                                   bool(ctx.needs_input_grad[1]), has_bias and ctx.needs_input_grad[2], premasked=premasked,
+                                   mask_bottom=(ctx.chain_cell["slope"] if (ctx.relu_chain & 2) else None))
+        if ctx.relu_chain & 2:
+            ctx.chain_cell["masked"] = True
+        return (gx, gw, db) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
 _GRAD_SLOT = [None]          # parallel.GradientExchange with a collective: weight tensor -> its slot of the flat all-reduce bucket (or None)
@@ -610,6 +624,8 @@ def join_side_streams():
         torch.cuda.current_stream(dev).wait_stream(st)
     pending = list(_SIDE_PENDING)
     _SIDE_PENDING.clear()
+    if _GRAD_SLOT[0] is not None:       # a gradient exchange owns `.grad` (it copies what was not produced in its bucket slot -- on the second stream)
+        return
     for w, ptr in pending:
         if ptr and w.grad is not None and w.grad.data_ptr() != ptr:
             raise RuntimeError("functional.set_wgrad_side_stream: autograd did not move a weight gradient computed on the second stream into "
@@ -617,14 +633,39 @@ def join_side_streams():
                                "(set_wgrad_side_stream(0)) for this graph.")
 
 
-def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, need_b):
+def relu_chain_supported(x_shape, w, stride, pad) -> bool:
+    """Can a Convolution with this weight on a bottom of this shape fold the ReLU derivative of the layer in front into its data gradient
+    (fn2_conv_backward_data_masked: the transposed-convolution route)?"""
+    desc = _layer_desc(w, stride, pad, False, x_shape=x_shape)
+    if desc is None or not w.is_cuda:
+        return False
+    route = ops.conv_backward_data_route(desc, False)
+    return route != 0 and ops.conv_backward_data_masked_supported(desc, False, route)
+
+
+def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, need_b, premasked=False, mask_bottom=None):
     """(bottom_diff, weight_diff, bias_diff) of a Convolution / Deconvolution (+ the leaky ReLU folded into it when `y`, the ACTIVATED
     output, is given) from top_diff g -- ConvolutionLayer / DeconvolutionLayer::Backward_gpu (conv_layer.cu:26-60, deconv_layer.cu:27-58)
     behind ReLULayer::Backward_gpu (relu_layer.cu:33-60).  One fused pass undoes the activation and reduces the bias gradient
     (csrc/bias_act.hip, from the saved output), the two convolution gradients run on the library's own routes (fn2_conv_backward_*); a
     geometry without an own kernel goes to the counted last resort (aten::convolution_backward).  Shared by the autograd function above
     and by the prototxt executor's Convolution / Deconvolution mirrors (stock_layers.py)."""
-    if y is not None:
+    if y is not None and premasked:
+        # the ONE consumer of this layer's output folded this layer's ReLU derivative into its data gradient (relu_chain): g is top_diff of
+        # the convolution itself.  The bias gradient comes out of the weight-gradient kernel where that has the fused form (the stem), else
+        # from a read-only reduction pass
+        d = g.contiguous()
+        db = None
+        if need_w and need_b and not transposed and d.is_cuda:
+            desc = _layer_desc(w, stride, pad, False, x_shape=x.shape)
+            if desc is not None and ops.conv_backward_weights_bias_fused(desc, False) and x.is_contiguous():
+                gw, db = ops.conv_backward_weights_bias(x, d, desc, False, out=_grad_slot(w))
+                gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
+                if not need_x or gx is not None:
+                    return gx, gw, db
+        if need_b:
+            db = ops.conv_backward_bias(d, d.shape[1])
+    elif y is not None:
         # the gradient of a Concat arrives as a channel-slice view of the Concat's top_diff: read in place (no .contiguous() copy)
         gb, g0 = _channel_slice(g)
         if not isinstance(y, tuple):                    # (a tuple: an output that lives in its consumer's Concat blob, read in place too)
@@ -634,7 +675,13 @@ def conv_backward(x, w, y, g, stride, pad, slope, transposed, need_x, need_w, ne
     else:
         g = g.contiguous()
         d, db = g, (g.sum((0, 2, 3)) if need_b else None)
-    gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape) if need_x else None
+    gx = None
+    if need_x and mask_bottom is not None:
+        gx = _own_bwd_data_masked(d, w, stride, pad, x, mask_bottom)
+    if need_x and gx is None:
+        if mask_bottom is not None:
+            raise RuntimeError("relu_chain: the data gradient of this layer has no masked form (relu_chain_supported was not asked?)")
+        gx = _own_bwd_data(d, w, stride, pad, transposed, x.shape)
     gw = None
     if need_w:
         side = _wgrad_side_stream(d, x, w)
@@ -735,11 +782,27 @@ def _own_bwd_data(d, w, stride, pad, transposed, x_shape=None):
     return ops.conv_backward_data(db, packed, desc, transposed, route, top_c0=d0)
 
 
+def _own_bwd_data_masked(d, w, stride, pad, x, slope):
+    """_own_bwd_data with ReLUBackward of the layer in front folded in: x is this layer's bottom = that layer's activated output."""
+    desc = _layer_desc(w, stride, pad, False, x_shape=x.shape)
+    if desc is None or not d.is_cuda:
+        return None
+    route = ops.conv_backward_data_route(desc, False)
+    if route == 0 or not ops.conv_backward_data_masked_supported(desc, False, route):
+        return None
+    key = (desc.N, desc.Hin, desc.Win)
+    packed = _cached_pack(_PACKED_T, w, ("dgrad", route, False, stride, pad) + key,
+                          lambda: ops.conv_backward_data_pack_weights(w.detach().contiguous(), desc, False, route))
+    db, d0 = _channel_slice(d)
+    xb, x0 = _channel_slice(x)
+    return ops.conv_backward_data_masked(db, packed, desc, False, route, xb, slope, top_c0=d0, data_c0=x0)
+
+
 def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0):
+def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, out=None, out_c0=0, relu_chain=None):
     """Convolution + bias (+ leaky ReLU) as ONE MFMA kernel, NCHW in and out, optionally written into a channel slice of `out`:
     Winograd F(2x2, 3x3) for 3x3 / stride 1 / pad 1 (csrc/conv_wino.hip), the direct kernel otherwise (csrc/conv_mfma.hip).
     With autograd active the same forward runs inside an autograd function (library backward).  Returns None when neither kernel
@@ -749,7 +812,7 @@ def conv_mfma_relu(x, weight, bias, stride, pad, negative_slope=0.1, act=True, o
         return None
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         run = lambda xx, ww, bb, o=None, o0=0: _conv_mfma_run(kind, xx, ww, bb, stride, pad, negative_slope, act, o, o0)
-        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, act, False, None if out is None else (out, out_c0))
+        return _OwnForwardConv.apply(x, weight, bias, run, stride, pad, negative_slope, act, False, None if out is None else (out, out_c0), relu_chain)
     return _conv_mfma_run(kind, x, weight, bias, stride, pad, negative_slope, act, out, out_c0)
 
 

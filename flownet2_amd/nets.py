@@ -73,7 +73,7 @@ def num_params(params) -> int:
     return sum(int(v.numel()) for v in params.values())
 
 
-def _conv(x, P, name, stride, pad, act=True, backend=None):
+def _conv(x, P, name, stride, pad, act=True, backend=None, relu_chain=None):
     """Convolution (+ ReLU{negative_slope 0.1}).  With a backend that has conv_bias_leaky_relu the library runs the
     bias-free convolution and bias + activation are one in-place pass (csrc/bias_act.hip) instead of two."""
     w = P[name + ".w"]
@@ -81,6 +81,8 @@ def _conv(x, P, name, stride, pad, act=True, backend=None):
         y = _conv_routed(x, P, name, stride, pad, act, backend)
         print("conv route %-16s in %-22s k%d s%d act=%d -> %s" % (name, tuple(x.shape), w.shape[2], stride, act, _LAST_ROUTE[0]))
         return y
+    if relu_chain is not None:
+        return conv_forward(x, w, P[name + ".b"], stride, pad, act, backend, relu_chain=relu_chain)
     return _conv_routed(x, P, name, stride, pad, act, backend)
 
 
@@ -92,7 +94,7 @@ def _conv_routed(x, P, name, stride, pad, act, backend):
     return conv_forward(x, P[name + ".w"], P[name + ".b"], stride, pad, act, backend)
 
 
-def conv_forward(x, w, b, stride, pad, act, backend, slope=None):
+def conv_forward(x, w, b, stride, pad, act, backend, slope=None, relu_chain=None):
     """Convolution{w, stride, pad} + bias (+ ReLU{NEG_SLOPE} when act) on explicit tensors: the routing every graph of this file and the
     Convolution layer of the prototxt executor (flownet2_amd.layers.ConvolutionLayer) share -- same kernels, same bits."""
     P = {"x.w": w, "x.b": b}
@@ -107,10 +109,15 @@ def conv_forward(x, w, b, stride, pad, act, backend, slope=None):
             _LAST_ROUTE[0] = "fn2 MFMA conv"
             return y
     if act and stride == 2 and pad == 3 and w.shape[2] == 7 and backend is not None and hasattr(backend, "conv_k7s2_relu"):
-        y = backend.conv_k7s2_relu(x, w, P[name + ".b"], slope)       # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
+        y = (backend.conv_k7s2_relu(x, w, P[name + ".b"], slope) if relu_chain is None      # conv1 + ReLU1 in one kernel (csrc/conv_stem.hip)
+             else backend.conv_k7s2_relu(x, w, P[name + ".b"], slope, relu_chain=relu_chain))
+        if y is None and relu_chain is not None:
+            raise RuntimeError("relu_chain: the stem kernel does not take this layer (its consumer was told it would)")
         if y is not None:
             _LAST_ROUTE[0] = "stem kernel"
             return y
+    if relu_chain is not None and _LAST_ROUTE[0] != "stem kernel":
+        raise RuntimeError("relu_chain: only the stem layer is a chain producer on this route")
     if w.shape[2] in (1, 3, 5) and backend is not None and hasattr(backend, "conv_mfma_relu"):
         y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, slope, act)    # Winograd / direct MFMA convolution (1x1: a plain MFMA GEMM), bias + ReLU fused
         if y is not None:
@@ -173,7 +180,7 @@ def deconv_forward(x, w, b, act=True, backend=None, slope=None):
     return F.leaky_relu(y, slope) if act else y
 
 
-def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
+def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend, relu_chain=None):
     """A convolution whose output is the FIRST input of a Concat (a decoder skip tensor): where the own MFMA kernels apply and no
     gradient is needed, the Concat blob [N, Cout + extra_channels, H, W] is allocated here and the convolution writes its channels
     straight into it (ConcatLayer, concat_layer.cu:8-52, becomes a no-op for this input).  Returns (blob or None, the layer's output --
@@ -189,9 +196,12 @@ def _conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
         k = w.shape[2]
         ho, wo = (x.shape[2] + 2 * pad - k) // stride + 1, (x.shape[3] + 2 * pad - k) // stride + 1
         blob = torch.empty((x.shape[0], w.shape[0] + extra_channels, ho, wo), device=x.device, dtype=x.dtype)
-        y = backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0)
+        y = (backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0) if relu_chain is None
+             else backend.conv_mfma_relu(x, w, P[name + ".b"], stride, pad, NEG_SLOPE, True, out=blob, out_c0=0, relu_chain=relu_chain))
         if y is not None:
             return blob, (y if (training and y.requires_grad) else blob[:, :w.shape[0]])
+    if relu_chain is not None:
+        raise RuntimeError("relu_chain: conv '%s' left the own-kernel route after its producer was told it would fold the ReLU derivative" % name)
     return None, _conv(x, P, name, stride, pad, backend=backend)
 
 
@@ -288,9 +298,31 @@ def _decoder(P, conv6_1, conv5_1, conv4_1, conv3_1, conv2, backend=None):
     return {2: flow2, 3: flow3, 4: flow4, 5: flow5, 6: flow6}
 
 
-def _skip_conv(x, P, name, stride, pad, dname, backend):
+def _skip_conv(x, P, name, stride, pad, dname, backend, relu_chain=None):
     """An encoder convolution whose output is also the first input of a refinement Concat: (concat blob or None, output tensor)."""
-    return _conv_into_concat(x, P, name, stride, pad, P[dname + ".w"].shape[1] + 2, backend)
+    return _conv_into_concat(x, P, name, stride, pad, P[dname + ".w"].shape[1] + 2, backend, relu_chain=relu_chain)
+
+
+RELU_CHAIN = [True]      # A/B hook: False = every layer undoes its own ReLU in a pass of its own (rounds 1-5)
+
+
+def _stem_chain(P, x, backend):
+    """conv1 -> conv2 in a TRAINING graph: conv2 is conv1's only consumer, so ReLUBackward of conv1 is folded into the epilogue of conv2's data
+    gradient (the transposed 5x5 / 2 convolution) and conv1's bias gradient comes out of its weight-gradient kernel: no pass over the largest
+    activation of the net (147 MB at batch 8 @448x320: read twice, written once) between the two.  Returns the (producer, consumer) handles
+    for the two layers, or (None, None)."""
+    if not (RELU_CHAIN[0] and CONCAT_IN_PLACE_TRAINING[0] and torch.is_grad_enabled() and x.is_cuda and hasattr(backend, "relu_chain_supported")):
+        return None, None
+    w1, w2 = P["conv1.w"], P["conv2.w"]
+    if not (w1.requires_grad and w2.requires_grad and P["conv1.b"].requires_grad) or x.requires_grad:
+        return None, None
+    if w1.shape[2] != 7 or w1.shape[1] % 4 == 0 or x.shape[3] % 8 != 0:       # (conv1 must take the stem kernel: whole blobs)
+        return None, None
+    c1_shape = (x.shape[0], w1.shape[0], (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1)
+    if not backend.relu_chain_supported(c1_shape, w2, 2, 2):
+        return None, None
+    cell = {"masked": False, "slope": NEG_SLOPE}
+    return (1, cell), (2, cell)
 
 
 CONCAT_IN_PLACE_TRAINING = [True]      # A/B hook: False = torch.cat for the refinement Concats of a training graph (rounds 1-4)
@@ -359,9 +391,10 @@ def flownet_c_core(P, img0, img1, backend, towers=None):
     # siamese towers share weights (param { name: } sharing, net.cpp:451-540): one batch of 2N through conv1-3
     x = towers if towers is not None else torch.cat([img0, img1], 0)
     n = x.shape[0] // 2
-    c1 = _conv(x, P, "conv1", 2, 3, backend=backend)
+    chain1, chain2 = _stem_chain(P, x, backend)
+    c1 = _conv(x, P, "conv1", 2, 3, backend=backend, relu_chain=chain1)
     # conv2 of BOTH towers goes into a [2N, 128 + 64 + 2, h, w] blob: its first N samples are the concat2 blob of the refinement
-    blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend)
+    blob2, c2 = _skip_conv(c1, P, "conv2", 2, 2, "deconv2", backend, relu_chain=chain2)
     training = TOWER_SPLIT_OPS[0] and torch.is_grad_enabled() and c2.requires_grad
     c2_first = None
     if training:

@@ -554,6 +554,39 @@ def conv_backward_weights(bottom, top_diff, desc, transposed=False, out=None, ac
     return out
 
 
+def conv_backward_data_masked_supported(desc, transposed, route) -> bool:
+    return bool(_lib.lib().fn2_conv_backward_data_masked_supported(C.byref(desc), int(bool(transposed)), int(route)))
+
+
+def conv_backward_data_masked(top_diff, packed, desc, transposed, route, bottom_data, negative_slope, top_c0=0, data_c0=0):
+    """bottom_diff = (weight^T x top_diff) * leaky_relu'(bottom_data): the data gradient with ReLUBackward of the layer in front folded into
+    the kernel's epilogue (fn2_conv_backward_data_masked; the transposed-convolution route).  bottom_data = this layer's bottom blob, the
+    activated output of the layer in front (may be a channel slice: data_c0)."""
+    d, y = _chk(top_diff, "top_diff"), _chk(bottom_data, "bottom data")
+    out = torch.empty((desc.N, desc.Cin, desc.Hin, desc.Win), device=d.device, dtype=torch.float32)
+    check(_lib.lib().fn2_conv_backward_data_masked(C.byref(desc), int(bool(transposed)), int(route), _ptr(d), d.shape[1], int(top_c0), _ptr(packed),
+                                                   _ptr(out), desc.Cin, 0, _ptr(y), y.shape[1], int(data_c0), C.c_float(float(negative_slope)), _stream()))
+    return out
+
+
+def conv_backward_weights_bias_fused(desc, transposed=False) -> bool:
+    return bool(_lib.lib().fn2_conv_backward_weights_bias_fused(C.byref(desc), int(bool(transposed))))
+
+
+def conv_backward_weights_bias(bottom, top_diff, desc, transposed=False, out=None):
+    """(weight_diff, bias_diff) of a layer from one pass over top_diff (fn2_conv_backward_weights_bias: the stem kernel sums the operand it
+    feeds to the matrix pipe).  `out`: write weight_diff there (a gradient-bucket slot)."""
+    x, d = _chk(bottom, "bottom"), _chk(top_diff, "top_diff")
+    L, tr = _lib.lib(), int(bool(transposed))
+    k = desc.kernel
+    dw = out if out is not None else torch.empty((desc.Cout, desc.Cin, k, k), device=x.device, dtype=torch.float32)
+    db = torch.empty(desc.Cout, device=x.device, dtype=torch.float32)
+    need = int(L.fn2_conv_backward_weights_workspace_bytes(C.byref(desc), tr))
+    ws = _plane_workspace(x.device, need) if need else None
+    check(L.fn2_conv_backward_weights_bias(C.byref(desc), tr, _ptr(x), _ptr(d), _ptr(dw), _ptr(db), 0, _ptr(ws), need, _stream()))
+    return dw, db
+
+
 def conv_backward_bias(top_diff, C_, top_c0=0, out=None, accumulate=False):
     """bias_diff[c] (+)= sum over n, y, x of top_diff[n, top_c0 + c] (backward_gpu_bias, base_conv_layer.cpp:389-393), fixed order."""
     d = _chk(top_diff, "top_diff")

@@ -175,7 +175,16 @@ class GradientExchange:
             off, n = b["span"][id(p)]
             if p.grad.data_ptr() != b["flat"].data_ptr() + off * b["flat"].element_size():
                 view = self._slot(p)            # not produced in its slot (a bias, a flow head, a library fallback): one copy
-                view.copy_(p.grad)
+                from . import functional
+                side = functional.side_stream_for_collective(view.device) if view.is_cuda else None
+                if side is None:
+                    view.copy_(p.grad)
+                else:
+                    # the gradient may have been computed on the second stream (the flow heads' weight gradients): the copy is ordered behind
+                    # BOTH streams by running on the second one, which has just been made to wait for the main one
+                    with torch.cuda.stream(side):
+                        view.copy_(p.grad)
+                    p.grad.record_stream(side)
                 p.grad = view
                 self.copied_bytes += n * b["flat"].element_size()
         if self._defer:

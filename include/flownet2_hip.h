@@ -542,11 +542,25 @@ int fn2_conv_backward_data_computed_channels(const fn2_conv_desc* desc, int tran
 int fn2_conv_backward_data(const fn2_conv_desc* desc, int transposed, int route, const float* top_diff, int top_channels, int top_c0,
                            const float* packed_weight, float* bottom_diff, int bottom_channels, int bottom_c0, int bottom_room,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same data gradient with ReLUBackward of the layer IN FRONT folded into its epilogue (round 6): bottom_data is that layer's activated
+ * output = this layer's bottom blob; bottom_diff = (weight^T x top_diff) * (bottom_data > 0 ? 1 : negative_slope)  -- relu_layer.cu:33-43
+ * applied where the gradient is produced instead of in a pass of its own (the caller then hands the result to the layer in front as an
+ * already masked top_diff).  Transposed-convolution route only (the stride-2 convolutions: conv2 / conv3 of the encoders); ask _supported. */
+int fn2_conv_backward_data_masked_supported(const fn2_conv_desc* desc, int transposed, int route);
+int fn2_conv_backward_data_masked(const fn2_conv_desc* desc, int transposed, int route, const float* top_diff, int top_channels, int top_c0,
+                                  const float* packed_weight, float* bottom_diff, int bottom_channels, int bottom_c0,
+                                  const float* bottom_data, int data_channels, int data_c0, float negative_slope, void* stream);
 int fn2_conv_backward_weights_supported(const fn2_conv_desc* desc, int transposed);
 size_t fn2_conv_backward_weights_workspace_bytes(const fn2_conv_desc* desc, int transposed);
 int fn2_conv_backward_weights(const fn2_conv_desc* desc, int transposed, const float* bottom, int bottom_channels, int bottom_c0,
                               const float* top_diff, int top_channels, int top_c0, float* weight_diff, int accumulate,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* weight_diff and bias_diff of a layer from ONE pass over top_diff (round 6) where a kernel has that form -- the 7x7 / 2 stem: the kernel sums
+ * the top_diff operand it feeds to the matrix pipe (weight_gpu_gemm + backward_gpu_bias, base_conv_layer.cpp:368-393); whole blobs,
+ * workspace of fn2_conv_backward_weights_workspace_bytes.  _fused tells whether the layer has one. */
+int fn2_conv_backward_weights_bias_fused(const fn2_conv_desc* desc, int transposed);
+int fn2_conv_backward_weights_bias(const fn2_conv_desc* desc, int transposed, const float* bottom, const float* top_diff, float* weight_diff,
+                                   float* bias_diff, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 int fn2_conv_backward_bias(const float* top_diff, int diff_channels, int diff_c0, float* bias_diff, int N, int C, int H, int W,
                            int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -114,10 +114,10 @@ class record_relu_branches:
         self._oc, self._od, self._lr = nets._conv, nets._deconv, F.leaky_relu
         depth = [0]
 
-        def conv(x, P, name, stride, pad, act=True, backend=None):
+        def conv(x, P, name, stride, pad, act=True, backend=None, **kw):
             depth[0] += 1
             try:
-                y = self._oc(x, P, name, stride, pad, act, backend)
+                y = self._oc(x, P, name, stride, pad, act, backend, **kw)
             finally:
                 depth[0] -= 1
             if act:
@@ -152,8 +152,8 @@ class record_relu_branches:
         # since round 5 the training graph too) do not pass through nets._conv / nets._deconv: record them where they run
         self._cic, self._sd = nets._conv_into_concat, nets._stage_deconv
 
-        def conv_into_concat(x, P, name, stride, pad, extra_channels, backend):
-            blob, y = self._cic(x, P, name, stride, pad, extra_channels, backend)
+        def conv_into_concat(x, P, name, stride, pad, extra_channels, backend, **kw):
+            blob, y = self._cic(x, P, name, stride, pad, extra_channels, backend, **kw)
             if blob is not None:                                # (else the fallback went through nets._conv above)
                 self.branches.append((name, (y.detach() > 0).cpu()))
             return blob, y

@@ -21,6 +21,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/corr -o c
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_sq -o corr -- python scripts/corr_microbench.py --iters 10 > /dev/null 2>&1
+# the correlation BACKWARD kernel (round 6: both bottoms in one launch): matrix-pipe and LDS counters, a pass of their own
+timeout 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/pmc_sq_bwd -o corr -- python scripts/corr_microbench.py --iters 10 --backward > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/pmc_bench -o bench -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras --corr-iters 4 > /dev/null 2>&1
 # calibration of FETCH_SIZE / WRITE_SIZE on streaming kernels of known byte count (dword per lane, like the staging loads)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/cal_fetch -o cal -- python scripts/hbm_calibrate.py > $R/cal_stdout.txt 2>/dev/null

@@ -191,7 +191,31 @@ if os.path.exists(pmc_conv):
                                                               100 * busy / (1024.0 * gui_k) if gui_k else 0, conf / act if act else 0))
     open(os.path.join(OUT, f"{tag}_conv_counters.md"), "w").write("\n".join(cl) + "\n")
 
-summary = {"tag": tag, "kernel": "corr_fwd_units [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us,
+# the correlation backward (both bottoms, one launch since round 6): kernel-trace average of the same micro-benchmark run + its own counter pass
+bwd = None
+bwd_rows = [r for r in kernel_stats(os.path.join(R, "corr", "corr_kernel_stats.csv")) if "corr_bwd" in r["Name"]]
+if bwd_rows:
+    bwd_us = sum(float(r["AverageNs"]) for r in bwd_rows) / 1e3          # (one merged kernel, or the two per-bottom kernels of earlier rounds)
+    bwd_flops = 2 * 2.0 * 256 * 441 * 8 * 40 * 56
+    bwd = {"kernels": [short(r["Name"].split("(")[0], 80) for r in bwd_rows], "avg_us_kernel_trace_both_bottoms": bwd_us,
+           "algorithmic_flops_both_bottoms": bwd_flops, "tflops": bwd_flops / (bwd_us * 1e-6) / 1e12,
+           "frac_of_fp32_mfma_peak": bwd_flops / (bwd_us * 1e-6) / 1e12 / 157.3}
+    pb = os.path.join(R, "pmc_sq_bwd", "corr_counter_collection.csv")
+    if os.path.exists(pb):
+        sb = counters(pb, "corr_bwd")
+        gb = sb.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        if gb:
+            bwd.update({"mfma_util": sb["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gb), "sq_insts_mfma": sb.get("SQ_INSTS_MFMA"),
+                        "lds_bank_conflict_over_active": (sb.get("SQ_LDS_BANK_CONFLICT", 0.0) / sb["SQ_LDS_IDX_ACTIVE"]) if sb.get("SQ_LDS_IDX_ACTIVE") else None})
+    lines_b = ["", "## Correlation backward (`%s`) at [8,256,40,56], both bottoms" % ", ".join(bwd["kernels"]), "",
+               "%.2f us per call in the kernel trace above = %.1f TFLOP/s = **%.3f** of the fp32 MFMA peak (8.09 GFLOP algorithmic)%s."
+               % (bwd_us, bwd["tflops"], bwd["frac_of_fp32_mfma_peak"],
+                  ("; matrix pipes %.1f %% busy, %.0f MFMA instructions, LDS bank-conflict / active cycles %.2f (`--pmc` pass of its own)"
+                   % (100 * bwd["mfma_util"], bwd["sq_insts_mfma"], bwd["lds_bank_conflict_over_active"] or 0.0)) if "mfma_util" in bwd else "")]
+    md = os.path.join(OUT, f"{tag}_rocprof_summary.md")
+    open(md, "a").write("\n".join(lines_b) + "\n")
+
+summary = {"tag": tag, "kernel": "corr_fwd_units [8,256,40,56]", "avg_us_kernel_trace": corr_avg_us, "backward": bwd,
            "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "fetch_correction": fetch_factor,
            "write_correction": write_factor, "hbm_read_bytes": fetch_bytes, "hbm_write_bytes": write_bytes,
            "traffic_bytes_per_launch": fetch_bytes + write_bytes, "algorithmic_bytes_per_launch": alg,

@@ -255,3 +255,40 @@ def test_partial_freeze_whose_first_trainable_tensors_are_a_stage_s_own_paramete
             assert torch.equal(v, g_all[k]), (k, float((v - g_all[k]).abs().max()))
         else:
             assert v is None, k
+
+
+@pytest.mark.gpu
+def test_relu_chain_conv1_conv2_gives_the_gradients_of_the_separate_passes():
+    """Round 6: ReLUBackward of conv1 folded into the epilogue of conv2's data gradient (fn2_conv_backward_data_masked) and conv1's bias
+    gradient out of its weight-gradient kernel (fn2_conv_backward_weights_bias) against the graph in which every layer undoes its own ReLU in
+    a pass of its own.  The masked top_diff has the same bits either way (the same product g * (y > 0 ? 1 : slope)), so every WEIGHT gradient
+    and every other bias gradient is bit-identical; conv1's bias gradient is summed in another order (inside the weight-gradient kernel):
+    equal to fp32 rounding.  Run twice: bit-reproducible."""
+    from flownet2_amd import functional as Fn, nets
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.rand(2, 3, 128, 192, device="cuda", generator=g) - 0.43
+    b = torch.rand(2, 3, 128, 192, device="cuda", generator=g) - 0.43
+    gt = torch.randn(2, 2, 128, 192, device="cuda", generator=g) * 3
+
+    def grads(chain):
+        nets.RELU_CHAIN[0] = chain
+        try:
+            P = {k: v.cuda().requires_grad_(True) for k, v in nets.init_params("C", seed=3).items()}
+            loss = nets.multiscale_loss(nets.flownet_c_core(P, a, b, Fn), gt, Fn)
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss.detach()), {k: v.grad.clone() for k, v in P.items()}
+        finally:
+            nets.RELU_CHAIN[0] = True
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    l2, g2 = grads(True)
+    assert l0 == l1 == l2
+    for k in g0:
+        if k == "conv1.b":
+            rel = float((g1[k] - g0[k]).abs().max() / g0[k].abs().max())
+            assert rel <= 2e-6, (k, rel)
+        else:
+            assert torch.equal(g1[k], g0[k]), (k, float((g1[k] - g0[k]).abs().max()))
+        assert torch.equal(g1[k], g2[k]), k
