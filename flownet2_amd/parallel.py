@@ -16,6 +16,8 @@ from typing import Iterable, List, Sequence
 import torch
 import torch.distributed as dist
 
+from . import functional
+
 
 def world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -39,7 +41,6 @@ def broadcast_params(params: Iterable[torch.Tensor], src: int = 0) -> None:
     with torch.no_grad():
         for p in params:
             dist.broadcast(p, src)      # in place on the parameter itself: bumps p._version, which the packed-weight caches check
-    from . import functional
     functional.invalidate_weight_caches()
 
 
@@ -74,7 +75,6 @@ class GradientExchange:
         self.params = [p for p in params if p.requires_grad]
         self.world = 1 if local_only else world()
         self.collective = (not local_only) and (world() > 1 or (force_collective and dist.is_available() and dist.is_initialized()))
-        from . import functional
         functional.set_wgrad_side_stream(wgrad_side_pixels)
         self.launched_in_backward = 0       # buckets whose all-reduce left from a gradient hook during the last backward pass
         self.copied_bytes = 0               # gradient bytes the hooks copied into their slots during the last iteration (not produced there)
@@ -138,7 +138,6 @@ class GradientExchange:
         b["launched"] = True
         if not self.collective:
             return
-        from . import functional
         flat = b["flat"]
         side = functional.side_stream_for_collective(flat.device) if flat.is_cuda else None
         if side is None:
@@ -175,7 +174,6 @@ class GradientExchange:
             off, n = b["span"][id(p)]
             if p.grad.data_ptr() != b["flat"].data_ptr() + off * b["flat"].element_size():
                 view = self._slot(p)            # not produced in its slot (a bias, a flow head, a library fallback): one copy
-                from . import functional
                 side = functional.side_stream_for_collective(view.device) if view.is_cuda else None
                 if side is None:
                     view.copy_(p.grad)
@@ -194,7 +192,6 @@ class GradientExchange:
             self._launch(b)
 
     def finish(self):
-        from . import functional
         n = sum(1 for b in self.buckets if b["pending"] == 0)          # buckets whose exchange was launched from inside backward
         for b in self.buckets:
             if not b["launched"]:
@@ -210,7 +207,6 @@ class GradientExchange:
         return n
 
     def remove(self):
-        from . import functional
         for h in self._handles:
             h.remove()
         self._handles = []
