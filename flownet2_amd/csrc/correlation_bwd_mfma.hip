@@ -673,6 +673,10 @@ constexpr int BRPW = cdiv(BRUN, kWaves), GRPW = cdiv(GRUN, kWaves);     // 3, 2 
 constexpr int LDS_FLOATS = cmax(2 * BBUF + 3 * GBUF, K::OUT_FLOATS);
 static_assert(BSLOTS % 64 == 0 && K::OUT_FLOATS <= 2 * BBUF, "the epilogue image fits the other-map buffers");
 constexpr int LA = 3;                           // operand reads run this many MFMAs ahead
+#ifndef FN2_G4_ABL
+#define FN2_G4_ABL 0          // profiling builds (scripts/probes/corr_bwd_variants.sh; wrong results): 1 no G-slab DMA, 2 no other-map DMA, 4 no MFMAs, 8 no epilogue stores
+#endif
+constexpr int kAbl4 = FN2_G4_ABL;
 
 template <int WHICH>
 __device__ __forceinline__ void g4_body(const float* __restrict__ other, const float* __restrict__ top_diff, float* __restrict__ out, const Args& g, int L) {
@@ -766,7 +770,7 @@ __device__ __forceinline__ void g4_body(const float* __restrict__ other, const f
 #pragma unroll
     for (int i = 0; i < BRPW; ++i) {
       const int run = i * kWaves + wave;
-      if (run < BRUN) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, vbB[i], 0, 0, 0);
+      if (run < BRUN && !(kAbl4 & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, vbB[i], 0, 0, 0);
     }
   };
   auto stage_g = [&](int rr, int slot) {
@@ -778,7 +782,7 @@ __device__ __forceinline__ void g4_body(const float* __restrict__ other, const f
 #pragma unroll
     for (int i = 0; i < GRPW; ++i) {
       const int run = i * kWaves + wave;
-      if (run < GRUN) {
+      if (run < GRUN && !(kAbl4 & 1)) {
         const int q = WHICH == 0 ? rr - i0 - gpi[i] : i0 + gpi[i] - rr;          // displacement row of this slab row
         const unsigned v = (gpi[i] >= 0 && q >= -R && q <= R) ? vbG[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(uintptr_t)(dst + 1024u * (unsigned)run), 16, v, 0, 0, 0);
@@ -818,7 +822,8 @@ __device__ __forceinline__ void g4_body(const float* __restrict__ other, const f
 #pragma unroll
     for (int k = 0; k < kNCH * K::NB; ++k) {
       const int c16 = k / K::NB, b = k % K::NB;
-      acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gv[b], bv[k], acc[c16][b & 1], 0, 0, 0);
+      if constexpr (!(kAbl4 & 4)) acc[c16][b & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Gv[b], bv[k], acc[c16][b & 1], 0, 0, 0);
+      else acc[c16][b & 1][0] += Gv[b] + bv[k];
       if (k + LA < kNCH * K::NB) bv[k + LA] = sb[((k + LA) / K::NB) * kKC * BCS + 8 * ((k + LA) % K::NB)];
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -848,7 +853,7 @@ __device__ __forceinline__ void g4_body(const float* __restrict__ other, const f
     for (int rowid = tid / K::SPANPX; rowid < kCQ * 4; rowid += kThreads / K::SPANPX) {
       const int c = rowid >> 2, rpi = rowid & 3;
       const int y = S2 * (i0 + rpi) + py;
-      if (y < g.H) out_n[(size_t)c * plane + (size_t)y * g.W + x] = smem[rowid * K::XS + xl];
+      if (y < g.H && !(kAbl4 & 8)) out_n[(size_t)c * plane + (size_t)y * g.W + x] = smem[rowid * K::XS + xl];
     }
   }
 }

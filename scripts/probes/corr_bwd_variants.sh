@@ -16,7 +16,7 @@ build() {
 }
 run() {
   echo "== $1" >> $OUT
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/t_$2 -o c -- python scripts/corr_microbench.py --iters 1500 --backward > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/t_$2 -o c -- python scripts/corr_microbench.py --iters 1500 --backward --impl ${FN2_CORR_IMPL:-0} > /dev/null 2>&1
   f=$(find $R/t_$2 -name "*_kernel_stats.csv" | head -1)
   [ -n "$f" ] && python -c "
 import csv,sys
@@ -25,8 +25,10 @@ for r in csv.DictReader(open('$f')):
 " >> $OUT
   rm -rf $R/t_$2
 }
-for v in 0 1 2 3 4 7; do
-  build "-DFN2_G3_ABL=$v"; run "ablation $v (1 no G DMA, 2 no other-map DMA, 4 no MFMA)" $v
-done
+if [ "${FN2_GEN:-4}" = "3" ]; then
+  for v in 0 1 2 3 4 7; do build "-DFN2_G3_ABL=$v"; run "generation 3, ablation $v (1 no G DMA, 2 no other-map DMA, 4 no MFMA)" $v; done
+else
+  for v in 0 1 2 3 4 7 8 15; do build "-DFN2_G4_ABL=$v"; run "generation 4 (both bottoms, one launch), ablation $v (1 no G DMA, 2 no other-map DMA, 4 no MFMA, 8 no stores)" $v; done
+fi
 build ""
 cat $OUT
