@@ -41,7 +41,7 @@ EXPORTS = [
     "fn2_conv_route", "fn2_conv_packed_weight_floats", "fn2_conv_pack_weights", "fn2_conv_workspace_bytes", "fn2_conv_forward",
     "fn2_deconv_route", "fn2_deconv_packed_weight_floats", "fn2_deconv_pack_weights", "fn2_deconv_workspace_bytes", "fn2_deconv_forward",
     "fn2_conv_backward_data_route", "fn2_conv_backward_data_packed_weight_floats", "fn2_conv_backward_data_pack_workspace_bytes",
-    "fn2_conv_backward_data_pack_weights", "fn2_conv_backward_data_workspace_bytes", "fn2_conv_backward_data_computed_channels", "fn2_conv_backward_data",
+    "fn2_conv_backward_data_pack_weights", "fn2_conv_backward_data_workspace_bytes", "fn2_conv_backward_data_workspace_bytes_with_room", "fn2_conv_backward_data_computed_channels", "fn2_conv_backward_data",
     "fn2_conv_backward_data_masked_supported", "fn2_conv_backward_data_masked", "fn2_conv_backward_weights_bias_fused", "fn2_conv_backward_weights_bias",
     "fn2_conv_backward_weights_supported", "fn2_conv_backward_weights_workspace_bytes", "fn2_conv_backward_weights", "fn2_conv_backward_bias",
     "fn2_im2col_forward", "fn2_col2im_bias_relu_forward", "fn2_col2im_bias_relu_forward_into",
@@ -268,6 +268,8 @@ def lib():
     L.fn2_conv_backward_weights_workspace_bytes.argtypes = [dp, i]
     L.fn2_conv_backward_weights_workspace_bytes.restype = sz
     L.fn2_conv_backward_weights.argtypes = [dp, i, fp, i, i, fp, i, i, fp, i, vp, sz, vp]
+    L.fn2_conv_backward_data_workspace_bytes_with_room.argtypes = [dp, i, i, i]
+    L.fn2_conv_backward_data_workspace_bytes_with_room.restype = sz
     L.fn2_conv_backward_data_masked_supported.argtypes = [dp, i, i]
     L.fn2_conv_backward_data_masked.argtypes = [dp, i, i, fp, i, i, fp, fp, i, i, fp, i, i, C.c_float, vp]
     L.fn2_conv_backward_weights_bias_fused.argtypes = [dp, i]

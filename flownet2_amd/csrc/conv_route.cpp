@@ -34,7 +34,10 @@ FN2_API int fn2_conv_route(const fn2_conv_desc* d, int flags) {
   const Out o = conv_out(d);
   // the two geometry classes with kernels of their own (round 6: reachable by descriptor, so that the Caffe adapter's Convolution plug-in
   // serves EVERY layer of the FlowNet graphs): the 7x7 / 2 stem on 3 / 6 / 12 input channels, and the 2-channel predict_flow heads
-  if (k == 7 && s == 2 && p == 3 && fn2_conv_k7s2_relu_supported(Cin, H, W, Cout)) return FN2_CONV_ROUTE_STEM;
+  // (the 12-channel stems of FlowNet2's stacked nets are whole channel quads: the direct kernel does them in one pass -- 174 us against 277 for
+  // the register-resident stem kernel's two passes at batch 4 @768x384 -- so the stem route is for the channel counts the direct kernel does not take)
+  if (k == 7 && s == 2 && p == 3 && !(Cin % 4 == 0 && fn2_conv_mfma_supported(Cin, H, W, Cout, k, s, p)) && fn2_conv_k7s2_relu_supported(Cin, H, W, Cout))
+    return FN2_CONV_ROUTE_STEM;
   if (k == 3 && s == 1 && p == 1 && Cout == 2) return FN2_CONV_ROUTE_HEAD;
   const bool wino_ok = k == 3 && s == 1 && fn2_conv_wino_supported(Cin, H, W, Cout, p) != 0;
   // accumulator blocks of the Winograd kernel (16 channels x an 8x8-pixel block of tiles): from ~1000 on the launch fills the 1024 SIMDs and
@@ -303,6 +306,15 @@ FN2_API size_t fn2_conv_backward_data_workspace_bytes(const fn2_conv_desc* d, in
   size_t b = align256(bwd_kernel_workspace(d, transposed, g));
   if (g.Cp != g.Cb) b += sizeof(float) * (size_t)d->N * g.Cp * g.Hb * g.Wb;       // the padded result, copied into bottom_diff afterwards
   return b;
+}
+
+// the same for a caller whose bottom_diff blob has room for `bottom_room` channels: with room for the computed channels
+// (fn2_conv_backward_data_computed_channels) only the kernel's own scratch is needed -- no padded copy
+FN2_API size_t fn2_conv_backward_data_workspace_bytes_with_room(const fn2_conv_desc* d, int transposed, int route, int bottom_room) {
+  const Bwd g = bwd_geom(d, transposed);
+  if (route == FN2_BWD_ROUTE_NONE || route != g.route) return 0;
+  if (bottom_room >= g.Cp) return bwd_kernel_workspace(d, transposed, g);
+  return fn2_conv_backward_data_workspace_bytes(d, transposed, route);
 }
 
 FN2_API int fn2_conv_backward_data_computed_channels(const fn2_conv_desc* d, int transposed, int route) {

@@ -522,7 +522,7 @@ def conv_backward_data(top_diff, packed_weight, desc, transposed, route, top_c0=
     if Cp == 0:
         raise ValueError("conv_backward_data: route %d is not this layer's" % route)
     out = torch.empty((desc.N, Cp, desc.Hin, desc.Win), device=d.device, dtype=torch.float32)
-    need = int(L.fn2_conv_backward_data_workspace_bytes(C.byref(desc), tr, int(route)))
+    need = int(L.fn2_conv_backward_data_workspace_bytes_with_room(C.byref(desc), tr, int(route), Cp))      # (the blob has room: no padded copy in the scratch)
     ws = _plane_workspace(d.device, need) if need else None
     check(L.fn2_conv_backward_data(C.byref(desc), tr, int(route), _ptr(d), d.shape[1], int(top_c0), _ptr(packed_weight), _ptr(out), Cp, 0, Cp,
                                    _ptr(ws), need, _stream()))

@@ -538,6 +538,7 @@ size_t fn2_conv_backward_data_pack_workspace_bytes(const fn2_conv_desc* desc, in
 int fn2_conv_backward_data_pack_weights(const fn2_conv_desc* desc, int transposed, int route, const float* weight, float* packed,
                                         void* workspace, size_t workspace_bytes, void* stream);
 size_t fn2_conv_backward_data_workspace_bytes(const fn2_conv_desc* desc, int transposed, int route);
+size_t fn2_conv_backward_data_workspace_bytes_with_room(const fn2_conv_desc* desc, int transposed, int route, int bottom_room);   /* bottom_room >= computed channels: the kernel's scratch only */
 int fn2_conv_backward_data_computed_channels(const fn2_conv_desc* desc, int transposed, int route);
 int fn2_conv_backward_data(const fn2_conv_desc* desc, int transposed, int route, const float* top_diff, int top_channels, int top_c0,
                            const float* packed_weight, float* bottom_diff, int bottom_channels, int bottom_c0, int bottom_room,
