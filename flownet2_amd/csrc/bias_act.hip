@@ -43,7 +43,7 @@ constexpr int kBwdChunks = 8;      // blocks per (n, c) plane
 // top_diff may be a channel slice of a wider blob (the gradient of a Concat arrives as one: concat_layer.cu:62-90 hands every bottom its
 // range of top_diff): plane (n, c) of it starts at ((n * dctot + dc0 + c) * hw)
 // MASK = false: the bias gradient alone (a Convolution without a fused ReLU: top_data / bottom_diff unused).
-template <bool MASK>
+template <bool MASK, bool VEC4>
 __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restrict__ top_data, const float* __restrict__ top_diff,
                                                            float* __restrict__ bottom_diff, float* __restrict__ partial,
                                                            unsigned hw, float slope, int C, int dctot, int dc0, int yctot, int yc0) {
@@ -53,19 +53,82 @@ __global__ void __launch_bounds__(256) bias_leaky_relu_bwd(const float* __restri
   const size_t dbase = ((size_t)(plane / (unsigned)C) * dctot + dc0 + plane % (unsigned)C) * hw;
   const size_t ybase = ((size_t)(plane / (unsigned)C) * yctot + yc0 + plane % (unsigned)C) * hw;       // top_data may be a channel slice too
   float acc = 0.f;
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < hw; i += gridDim.x * 256u) {
-    float g = top_diff[dbase + i];
-    if constexpr (MASK) {
-      g *= top_data[ybase + i] > 0.f ? 1.f : slope;
-      bottom_diff[base + i] = g;
+  if constexpr (VEC4) {
+    // 16-byte loads and stores (hw % 4 == 0, 16-byte aligned blobs: every plane then starts on a 16-byte boundary).  The per-thread sum
+    // adds the four lanes of a quad in order: another summation order than the scalar form, fixed for a given geometry
+    const unsigned n4 = hw / 4;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+      f32x4 g = reinterpret_cast<const f32x4*>(top_diff + dbase)[i];
+      if constexpr (MASK) {
+        const f32x4 y = reinterpret_cast<const f32x4*>(top_data + ybase)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] *= y[j] > 0.f ? 1.f : slope;
+        reinterpret_cast<f32x4*>(bottom_diff + base)[i] = g;
+      }
+      acc += (g[0] + g[1]) + (g[2] + g[3]);
     }
-    acc += g;
+  } else {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < hw; i += gridDim.x * 256u) {
+      float g = top_diff[dbase + i];
+      if constexpr (MASK) {
+        g *= top_data[ybase + i] > 0.f ? 1.f : slope;
+        bottom_diff[base + i] = g;
+      }
+      acc += g;
+    }
   }
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partial[(size_t)plane * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Small maps (round 6): ONE workgroup per channel walks all N planes of its channel and finishes the bias gradient itself -- no partials,
+// no second launch (bias_diff_finalize was 15 launches of 5-12 us on the critical path of a FlowNetC training step; the layers from 1/16
+// resolution down have at most a few thousand values per channel).  Order: thread t sums elements t, t + 256, ... of the (sample, pixel)
+// sequence in order, then the fixed butterfly below.
+template <bool MASK, bool VEC4>
+__global__ void __launch_bounds__(256) bias_leaky_relu_bwd_channel(const float* __restrict__ top_data, const float* __restrict__ top_diff,
+                                                                   float* __restrict__ bottom_diff, float* __restrict__ bias_diff,
+                                                                   int N, unsigned hw, float slope, int C, int dctot, int dc0, int yctot, int yc0,
+                                                                   int accumulate) {
+  __shared__ float red[4];
+  const unsigned c = blockIdx.x;
+  float acc = 0.f;
+  if constexpr (VEC4) {
+    const unsigned q = hw / 4, total = (unsigned)N * q;
+    for (unsigned e = threadIdx.x; e < total; e += 256u) {
+      const unsigned n = e / q, i = e - n * q;
+      f32x4 g = reinterpret_cast<const f32x4*>(top_diff + ((size_t)n * dctot + dc0 + c) * hw)[i];
+      if constexpr (MASK) {
+        const f32x4 y = reinterpret_cast<const f32x4*>(top_data + ((size_t)n * yctot + yc0 + c) * hw)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] *= y[j] > 0.f ? 1.f : slope;
+        reinterpret_cast<f32x4*>(bottom_diff + ((size_t)n * C + c) * hw)[i] = g;
+      }
+      acc += (g[0] + g[1]) + (g[2] + g[3]);
+    }
+  } else {
+    const unsigned total = (unsigned)N * hw;
+    for (unsigned e = threadIdx.x; e < total; e += 256u) {
+      const unsigned n = e / hw, i = e - n * hw;
+      float g = top_diff[((size_t)n * dctot + dc0 + c) * hw + i];
+      if constexpr (MASK) {
+        g *= top_data[((size_t)n * yctot + yc0 + c) * hw + i] > 0.f ? 1.f : slope;
+        bottom_diff[((size_t)n * C + c) * hw + i] = g;
+      }
+      acc += g;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && bias_diff) {
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    bias_diff[c] = accumulate ? bias_diff[c] + tot : tot;
+  }
 }
 
 // one wave per channel: the N * chunks partials of the channel spread over the lanes (lane l takes partials l, l + 64, ... in order),
@@ -85,6 +148,9 @@ __global__ void __launch_bounds__(256) bias_diff_finalize(const float* __restric
   for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
   if (lane == 0) bias_diff[c] = accumulate ? bias_diff[c] + acc : acc;
 }
+
+// one workgroup per channel (bias_leaky_relu_bwd_channel) where that fills the chip and a channel is short: a function of the geometry only
+static inline bool small_map(int N, int C, long long hw) { return C >= 128 && (long long)N * hw <= 20000; }
 
 }  // namespace fn2
 
@@ -117,8 +183,18 @@ FN2_API int fn2_bias_leaky_relu_backward_slices2(const float* top_data, int data
   if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "bias_leaky_relu_backward: workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(bias_leaky_relu_bwd<true>, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
-                     (unsigned)hw, negative_slope, C, diff_channels, diff_c0, data_channels, data_c0);
+  const bool vec = hw % 4 == 0 && ((reinterpret_cast<uintptr_t>(top_data) | reinterpret_cast<uintptr_t>(top_diff) | reinterpret_cast<uintptr_t>(bottom_diff)) & 15) == 0;
+  if (small_map(N, C, hw)) {
+    if (vec) hipLaunchKernelGGL((bias_leaky_relu_bwd_channel<true, true>), dim3((unsigned)C), dim3(256), 0, st, top_data, top_diff, bottom_diff, bias_diff, N,
+                                (unsigned)hw, negative_slope, C, diff_channels, diff_c0, data_channels, data_c0, 0);
+    else hipLaunchKernelGGL((bias_leaky_relu_bwd_channel<true, false>), dim3((unsigned)C), dim3(256), 0, st, top_data, top_diff, bottom_diff, bias_diff, N,
+                            (unsigned)hw, negative_slope, C, diff_channels, diff_c0, data_channels, data_c0, 0);
+    return check_launch("bias_leaky_relu_backward");
+  }
+  if (vec) hipLaunchKernelGGL((bias_leaky_relu_bwd<true, true>), dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
+                              (unsigned)hw, negative_slope, C, diff_channels, diff_c0, data_channels, data_c0);
+  else hipLaunchKernelGGL((bias_leaky_relu_bwd<true, false>), dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, top_data, top_diff, bottom_diff, partial,
+                          (unsigned)hw, negative_slope, C, diff_channels, diff_c0, data_channels, data_c0);
   if (bias_diff) hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks, 0);
   return check_launch("bias_leaky_relu_backward");
 }
@@ -135,8 +211,18 @@ FN2_API int fn2_conv_backward_bias(const float* top_diff, int diff_channels, int
   if (!workspace || workspace_bytes < need) return fail(FN2_ERR_WORKSPACE, "conv_backward_bias: workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* partial = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(bias_leaky_relu_bwd<false>, dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, nullptr, top_diff, nullptr, partial,
-                     (unsigned)hw, 1.0f, C, diff_channels, diff_c0, C, 0);
+  const bool vec = hw % 4 == 0 && (reinterpret_cast<uintptr_t>(top_diff) & 15) == 0;
+  if (small_map(N, C, hw)) {
+    if (vec) hipLaunchKernelGGL((bias_leaky_relu_bwd_channel<false, true>), dim3((unsigned)C), dim3(256), 0, st, nullptr, top_diff, nullptr, bias_diff, N,
+                                (unsigned)hw, 1.0f, C, diff_channels, diff_c0, C, 0, accumulate);
+    else hipLaunchKernelGGL((bias_leaky_relu_bwd_channel<false, false>), dim3((unsigned)C), dim3(256), 0, st, nullptr, top_diff, nullptr, bias_diff, N,
+                            (unsigned)hw, 1.0f, C, diff_channels, diff_c0, C, 0, accumulate);
+    return check_launch("conv_backward_bias");
+  }
+  if (vec) hipLaunchKernelGGL((bias_leaky_relu_bwd<false, true>), dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, nullptr, top_diff, nullptr, partial,
+                              (unsigned)hw, 1.0f, C, diff_channels, diff_c0, C, 0);
+  else hipLaunchKernelGGL((bias_leaky_relu_bwd<false, false>), dim3(kBwdChunks, (unsigned)planes), dim3(256), 0, st, nullptr, top_diff, nullptr, partial,
+                          (unsigned)hw, 1.0f, C, diff_channels, diff_c0, C, 0);
   hipLaunchKernelGGL(bias_diff_finalize, dim3((C + 3) / 4), dim3(256), 0, st, partial, bias_diff, N, C, kBwdChunks, accumulate);
   return check_launch("conv_backward_bias");
 }
