@@ -21,6 +21,7 @@ EXPORTS = [
     "fn2_l1loss_multi_workspace_bytes", "fn2_l1loss_multi_sync_bytes", "fn2_l1loss_forward_multi", "fn2_l1loss_backward_multi",
     "fn2_channel_norm_forward", "fn2_channel_norm_forward_slices", "fn2_channel_norm_backward",
     "fn2_downsample_forward",
+    "fn2_downsample_forward_multi",
     "fn2_predict_flow_conv_workspace_bytes", "fn2_predict_flow_conv_forward", "fn2_upsample_flow_deconv_forward", "fn2_upsample_flow_deconv_forward_into",
     "fn2_predict_flow_conv_backward_supported", "fn2_predict_flow_conv_backward_workspace_bytes", "fn2_predict_flow_conv_backward", "fn2_upsample_flow_deconv_backward_workspace_bytes", "fn2_upsample_flow_deconv_backward",
     "fn2_bias_leaky_relu_forward", "fn2_scale_shift_forward", "fn2_bias_leaky_relu_backward_workspace_bytes", "fn2_bias_leaky_relu_backward", "fn2_bias_leaky_relu_backward_slices", "fn2_bias_leaky_relu_backward_slices2",
@@ -151,6 +152,7 @@ def lib():
     L.fn2_channel_norm_forward_slices.argtypes = [fp, i, i, fp, i, i, fp, i, i, i, i, i, i, vp]
     L.fn2_channel_norm_backward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]
     L.fn2_downsample_forward.argtypes = [fp, fp, i, i, i, i, i, i, vp]
+    L.fn2_downsample_forward_multi.argtypes = [fp, C.POINTER(fp), C.POINTER(i), C.POINTER(i), i, i, i, i, i, vp]
     L.fn2_predict_flow_conv_workspace_bytes.argtypes = [i, i, i, i]
     L.fn2_predict_flow_conv_workspace_bytes.restype = sz
     L.fn2_predict_flow_conv_forward.argtypes = [fp, fp, fp, fp, i, i, i, i, vp, sz, vp]

@@ -52,9 +52,12 @@ struct DownArgs {
 // grid: (output pixel blocks, n * C + c).  Tap bounds are clamped once (no test per tap), the row weight is hoisted and
 // four taps of a row are in flight together: the reference's per-tap test serialises 121 load -> use round trips per
 // output for the x4 reduction of a flow field.  Weights keep the reference's expression and order (:52).
-__global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+// (bx, by, gy: the block's coordinates and the y extent of the grid it belongs to -- blockIdx / gridDim of its own launch, or its place in
+// the job of a multi-scale launch, downsample_fwd_multi)
+__device__ __forceinline__ void downsample_thread_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned by,
+                                                       unsigned gy) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout;
-  const unsigned pd = blockIdx.x * 256u + threadIdx.x;
+  const unsigned pd = bx * 256u + threadIdx.x;
   if (pd >= hw_out) return;
   const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
   const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
@@ -62,12 +65,12 @@ __global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ 
   const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                   // :30-31
   const int y0 = max(iboty - a.hradius, 0), y1 = min(iboty + a.hradius, a.Hin - 1);
   const int x0 = max(ibotx - a.wradius, 0), x1 = min(ibotx + a.wradius, a.Win - 1);
-  for (unsigned cn = blockIdx.y; cn < (unsigned)a.NC; cn += gridDim.y) {
+  for (unsigned cn = by; cn < (unsigned)a.NC; cn += gy) {
     const float* p = src + (size_t)cn * a.Hin * a.Win;
     float accum_value = 0.f, accum_weight = 0.f, accum_nan = 0.f;
-    for (int by = y0; by <= y1; ++by) {
-      const float wy = fmaxf(0.0f, 1.0f - (fabsf((float)by - boty) / a.heightScale));
-      const float* row = p + (size_t)by * a.Win;
+    for (int ty = y0; ty <= y1; ++ty) {
+      const float wy = fmaxf(0.0f, 1.0f - (fabsf((float)ty - boty) / a.heightScale));
+      const float* row = p + (size_t)ty * a.Win;
       int bx = x0;
       for (; bx + 3 <= x1; bx += 4) {
         float sm[4];
@@ -96,15 +99,19 @@ __global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ 
   }
 }
 
+__global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+  downsample_thread_body(src, dst, a, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
 // Large reduction factors (the coarse scales of the multi-scale loss: 320x448 -> 5x7 is a 129 x 129 tap window per
 // output): one WAVE per output element, lanes stride over the taps in row-major order, then a fixed-shape butterfly sum
 // (deterministic).  The reference walks the window in one thread (:36-62); one thread per output left 280 threads with
 // 16,641 dependent taps each -- 416 us per call, 14 % of a FlowNetC training step.
-__global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+__device__ __forceinline__ void downsample_wave_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned gx) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout;
   const unsigned lane = threadIdx.x & 63;
   const unsigned long long total = (unsigned long long)a.NC * hw_out;
-  for (unsigned long long o = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6); o < total; o += (unsigned long long)gridDim.x * 4) {
+  for (unsigned long long o = (unsigned long long)bx * 4 + (threadIdx.x >> 6); o < total; o += (unsigned long long)gx * 4) {
     const unsigned cn = (unsigned)(o / hw_out), pd = (unsigned)(o - (unsigned long long)cn * hw_out);
     const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
     const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
@@ -148,16 +155,20 @@ __global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restri
   }
 }
 
+__global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+  downsample_wave_body(src, dst, a, blockIdx.x, gridDim.x);
+}
+
 // The coarsest scales (320x448 -> 10x14 and 5x7: 4,225 and 16,641 taps per output, 2,240 and 560 outputs per batch of 8): a whole WORKGROUP per
 // output element -- with a wave per output the 560 waves of the last scale walked 260 dependent taps per lane (61 us per call, 182 us of a
 // training step for the three coarse scales).  Same tap order per lane class, wave butterfly, then the four wave sums added in wave order
 // (deterministic).
-__global__ void __launch_bounds__(256) downsample_fwd_block(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
-  __shared__ float part[3][4];
+__device__ __forceinline__ void downsample_block_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned gx,
+                                                      float (*part)[4]) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout;
   const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long total = (unsigned long long)a.NC * hw_out;
-  for (unsigned long long o = blockIdx.x; o < total; o += gridDim.x) {
+  for (unsigned long long o = bx; o < total; o += gx) {
     const unsigned cn = (unsigned)(o / hw_out), pd = (unsigned)(o - (unsigned long long)cn * hw_out);
     const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
     const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
@@ -207,6 +218,40 @@ __global__ void __launch_bounds__(256) downsample_fwd_block(const float* __restr
   }
 }
 
+__global__ void __launch_bounds__(256) downsample_fwd_block(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+  __shared__ float part[3][4];
+  downsample_block_body(src, dst, a, blockIdx.x, gridDim.x, part);
+}
+
+// Several top sizes of ONE bottom in one launch (round 6): the ground-truth pyramid of the multi-scale loss is five Downsample layers on the
+// same blob (320x448 -> 80x112 ... 5x7), each a latency-bound launch of 18-37 us that fills a fraction of the chip; as one grid they run side by
+// side.  A job = one top size with the decomposition its own launch would have had (thread / wave / workgroup per output element, same tap order:
+// the result has the bits of fn2_downsample_forward); the coarsest (longest-running) jobs come first in the grid.
+constexpr int kDownMaxJobs = 8;
+struct DownMulti {
+  DownArgs a[kDownMaxJobs];
+  float* dst[kDownMaxJobs];
+  unsigned first[kDownMaxJobs + 1];       // first block of job j; first[count] = the grid
+  unsigned gx[kDownMaxJobs], gy[kDownMaxJobs];
+  int mode[kDownMaxJobs];                 // 0 thread, 1 wave, 2 workgroup per output element
+  int count;
+};
+
+__global__ void __launch_bounds__(256) downsample_fwd_multi(const float* __restrict__ src, DownMulti m) {
+  __shared__ float part[3][4];
+  int j = 0;
+  while (j + 1 < m.count && blockIdx.x >= m.first[j + 1]) ++j;
+  const unsigned b = blockIdx.x - m.first[j];
+  // (the job index is uniform over the workgroup; a switch over constant indices keeps the descriptors in SGPRs)
+#pragma unroll
+  for (int k = 0; k < kDownMaxJobs; ++k) {
+    if (k != j) continue;
+    if (m.mode[k] == 2) downsample_block_body(src, m.dst[k], m.a[k], b, m.gx[k], part);
+    else if (m.mode[k] == 1) downsample_wave_body(src, m.dst[k], m.a[k], b, m.gx[k]);
+    else downsample_thread_body(src, m.dst[k], m.a[k], b % m.gx[k], b / m.gx[k], m.gy[k]);
+  }
+}
+
 }  // namespace fn2
 
 using namespace fn2;
@@ -247,6 +292,26 @@ FN2_API int fn2_channel_norm_backward(const float* bottom, const float* top, con
   return check_launch("channel_norm_backward");
 }
 
+// geometry + decomposition of one Downsample: 0 thread, 1 wave, 2 workgroup per output element (by the tap count); -1: plane too large
+static int down_plan(int N, int C, int Hin, int Win, int Hout, int Wout, DownArgs* out, unsigned* gx, unsigned* gy) {
+  DownArgs a;
+  a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
+  a.widthScale = (float)(Win - 1) / (float)(Wout - 1);     // :104
+  a.heightScale = (float)(Hin - 1) / (float)(Hout - 1);    // :105
+  a.wradius = (int)std::ceil(a.widthScale);                // :107
+  a.hradius = (int)std::ceil(a.heightScale);               // :108
+  if ((long long)Hout * Wout >= (1ll << 31)) return -1;
+  *out = a;
+  const long long taps = (long long)(2 * a.wradius + 1) * (2 * a.hradius + 1);
+  const long long outs = (long long)a.NC * Hout * Wout;
+  *gy = 1;
+  if (taps >= 4096) { *gx = (unsigned)(outs < 65536 ? outs : 65536); return 2; }
+  if (taps >= 512) { const long long blocks = (outs + 3) / 4; *gx = (unsigned)(blocks < 65536 ? blocks : 65536); return 1; }
+  *gx = ((unsigned)Hout * Wout + 255) / 256;
+  *gy = (unsigned)(a.NC < 65535 ? a.NC : 65535);
+  return 0;
+}
+
 FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C, int Hin, int Win, int Hout, int Wout,
                                    void* stream) {
   if (N < 0 || C < 1 || Hin < 1 || Win < 1) return fail(FN2_ERR_INVALID_ARG, "downsample: bad bottom shape");
@@ -263,22 +328,49 @@ FN2_API int fn2_downsample_forward(const float* bottom, float* top, int N, int C
   // a 1-pixel-high or -wide top makes the reference divide by zero (:104-105: scale = inf, radius = (int)ceil(inf) is undefined)
   if (Hout < 2 || Wout < 2) return fail(FN2_ERR_INVALID_ARG, "downsample: top_height and top_width must be at least 2 when the size changes (downsample_layer.cu:104-105 divides by size - 1)");
   DownArgs a;
-  a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
-  a.widthScale = (float)(Win - 1) / (float)(Wout - 1);     // :104
-  a.heightScale = (float)(Hin - 1) / (float)(Hout - 1);    // :105
-  a.wradius = (int)std::ceil(a.widthScale);                // :107
-  a.hradius = (int)std::ceil(a.heightScale);               // :108
-  if ((long long)Hout * Wout >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "downsample: plane too large");
-  const long long taps = (long long)(2 * a.wradius + 1) * (2 * a.hradius + 1);
-  if (taps >= 4096) {                     // workgroup per output element
-    const long long outs = (long long)a.NC * Hout * Wout;
-    hipLaunchKernelGGL(downsample_fwd_block, dim3((unsigned)(outs < 65536 ? outs : 65536)), dim3(256), 0, st, bottom, top, a);
-  } else if (taps >= 512) {               // wave per output element
-    const long long outs = (long long)a.NC * Hout * Wout;
-    const long long blocks = (outs + 3) / 4;
-    hipLaunchKernelGGL(downsample_fwd_wave, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, bottom, top, a);
-  } else {
-    hipLaunchKernelGGL(downsample_fwd, dim3(((unsigned)Hout * Wout + 255) / 256, (unsigned)(a.NC < 65535 ? a.NC : 65535)), dim3(256), 0, st, bottom, top, a);
-  }
+  unsigned gx, gy;
+  const int mode = down_plan(N, C, Hin, Win, Hout, Wout, &a, &gx, &gy);
+  if (mode < 0) return fail(FN2_ERR_UNSUPPORTED, "downsample: plane too large");
+  if (mode == 2) hipLaunchKernelGGL(downsample_fwd_block, dim3(gx), dim3(256), 0, st, bottom, top, a);
+  else if (mode == 1) hipLaunchKernelGGL(downsample_fwd_wave, dim3(gx), dim3(256), 0, st, bottom, top, a);
+  else hipLaunchKernelGGL(downsample_fwd, dim3(gx, gy), dim3(256), 0, st, bottom, top, a);
   return check_launch("downsample_forward");
+}
+
+FN2_API int fn2_downsample_forward_multi(const float* bottom, float* const* tops, const int* top_heights, const int* top_widths, int count,
+                                         int N, int C, int Hin, int Win, void* stream) {
+  if (count < 1 || count > kDownMaxJobs) return fail(FN2_ERR_INVALID_ARG, "downsample_multi: 1 to %d top sizes per launch (got %d)", kDownMaxJobs, count);
+  if (N < 0 || C < 1 || Hin < 1 || Win < 1) return fail(FN2_ERR_INVALID_ARG, "downsample: bad bottom shape");
+  if (!tops || !top_heights || !top_widths) return fail(FN2_ERR_INVALID_ARG, "downsample_multi: NULL size / pointer table");
+  if (N == 0) return FN2_OK;
+  if (!bottom) return fail(FN2_ERR_INVALID_ARG, "downsample: NULL blob pointer");
+  DownMulti m;
+  int order[kDownMaxJobs], modes[kDownMaxJobs];
+  DownArgs as[kDownMaxJobs];
+  unsigned gxs[kDownMaxJobs], gys[kDownMaxJobs];
+  for (int j = 0; j < count; ++j) {
+    if (top_heights[j] < 2 || top_widths[j] < 2 || (top_heights[j] == Hin && top_widths[j] == Win))
+      return fail(FN2_ERR_INVALID_ARG, "downsample_multi: every top must be at least 2 x 2 and differ from the bottom's size (top %d: %d x %d)", j, top_heights[j],
+                  top_widths[j]);
+    if (!tops[j]) return fail(FN2_ERR_INVALID_ARG, "downsample: NULL blob pointer");
+    modes[j] = down_plan(N, C, Hin, Win, top_heights[j], top_widths[j], &as[j], &gxs[j], &gys[j]);
+    if (modes[j] < 0) return fail(FN2_ERR_UNSUPPORTED, "downsample: plane too large");
+    order[j] = j;
+  }
+  // longest-running decompositions first (stable): workgroup per output, wave per output, thread per output
+  for (int i = 1; i < count; ++i)
+    for (int k = i; k > 0 && modes[order[k]] > modes[order[k - 1]]; --k) { const int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t; }
+  unsigned long long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const int j = order[i];
+    m.a[i] = as[j]; m.dst[i] = tops[j]; m.mode[i] = modes[j]; m.gx[i] = gxs[j]; m.gy[i] = gys[j];
+    m.first[i] = (unsigned)blocks;
+    blocks += (unsigned long long)gxs[j] * gys[j];
+    if (blocks >= (1ull << 31)) return fail(FN2_ERR_UNSUPPORTED, "downsample_multi: grid too large");
+  }
+  for (int i = count; i < kDownMaxJobs; ++i) { m.a[i] = m.a[0]; m.dst[i] = nullptr; m.mode[i] = 0; m.gx[i] = 1; m.gy[i] = 1; m.first[i] = (unsigned)blocks; }
+  m.first[count] = (unsigned)blocks;
+  m.count = count;
+  hipLaunchKernelGGL(downsample_fwd_multi, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), bottom, m);
+  return check_launch("downsample_forward_multi");
 }

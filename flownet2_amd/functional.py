@@ -172,6 +172,8 @@ def downsample_ahead(x, sizes):
     FlowNetC step on the critical path).  Returns (tensors, event): the consumer's stream must wait for the event (wait_ahead)."""
     with torch.no_grad():
         x = x.detach().contiguous()
+        many = (lambda: ops.downsample_forward_multi(x, sizes)) if ops.downsample_multi_supported(x.shape, sizes) and x.shape[0] > 0 else \
+            (lambda: [ops.downsample_forward(x, h, w) for h, w in sizes])        # (one launch for the whole pyramid where its sizes allow)
         if not x.is_cuda:
             return [ops.downsample_forward(x, h, w) for h, w in sizes], None
         main = torch.cuda.current_stream(x.device)
@@ -180,7 +182,7 @@ def downsample_ahead(x, sizes):
             side = _WGRAD_SIDE["streams"][x.device] = torch.cuda.Stream(device=x.device)
         side.wait_stream(main)                    # x was produced under the main stream
         with torch.cuda.stream(side):
-            outs = [ops.downsample_forward(x, h, w) for h, w in sizes]
+            outs = many()
             ev = torch.cuda.Event()
             ev.record(side)
         x.record_stream(side)

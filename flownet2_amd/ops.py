@@ -331,6 +331,25 @@ def downsample_forward(x, top_height, top_width):
     return out
 
 
+def downsample_forward_multi(x, sizes):
+    """Downsample(x) to every (height, width) of `sizes` in ONE launch (fn2_downsample_forward_multi: up to 8 tops, each at least 2 x 2 and of
+    another size than x); the bits of downsample_forward per size."""
+    x = _chk(x, "bottom[0]")
+    N, Cc, H, W = x.shape
+    sizes = [(int(h), int(w)) for h, w in sizes]
+    outs = [torch.empty((N, Cc, h, w), device=x.device, dtype=torch.float32) for h, w in sizes]
+    n = len(sizes)
+    ptrs = (C.c_void_p * n)(*[_ptr(o) for o in outs])
+    hs, ws = (C.c_int * n)(*[h for h, _ in sizes]), (C.c_int * n)(*[w for _, w in sizes])
+    check(_lib.lib().fn2_downsample_forward_multi(_ptr(x), ptrs, hs, ws, n, N, Cc, H, W, _stream()))
+    return outs
+
+
+def downsample_multi_supported(x_shape, sizes) -> bool:
+    H, W = int(x_shape[2]), int(x_shape[3])
+    return 1 <= len(sizes) <= 8 and all(int(h) >= 2 and int(w) >= 2 and (int(h), int(w)) != (H, W) for h, w in sizes)
+
+
 def predict_flow_conv_forward(x, weight, bias=None):
     """Convolution{kernel 3, stride 1, pad 1, num_output 2} (the FlowNet predict_flow heads)."""
     x, w = _chk(x, "bottom[0]"), _chk(weight, "weight")

@@ -248,6 +248,11 @@ int fn2_channel_norm_backward(const float* bottom, const float* top, const float
  * ---------------------------------------------------------------------------------------------- */
 int fn2_downsample_forward(const float* bottom, float* top, int N, int C,
                            int Hin, int Win, int Hout, int Wout, void* stream);
+/* `count` (1..8) Downsample layers on the SAME bottom in one launch -- the ground-truth pyramid of the multi-scale loss (five
+ * Downsample layers on one blob in the training prototxts): tops[j] is [N, C, top_heights[j], top_widths[j]], every top at least
+ * 2 x 2 and of another size than the bottom.  Same arithmetic and tap order as `count` calls of fn2_downsample_forward (bit-identical). */
+int fn2_downsample_forward_multi(const float* bottom, float* const* tops, const int* top_heights, const int* top_widths,
+                                 int count, int N, int C, int Hin, int Win, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flow heads of the FlowNet decoders -- stock Caffe layers in the reference, specialised here because a

@@ -234,6 +234,21 @@ def downsample_forward(x, Hout, Wout):
     return out
 
 
+def downsample_forward_multi(x, sizes):
+    """fn2_downsample_forward_multi_cpu: the Downsample layers of `sizes` on one bottom, one after another."""
+    import ctypes as C
+    x = _f32(x)
+    N, Cc, H, W = x.shape
+    outs = [np.empty((N, Cc, int(h), int(w)), np.float32) for h, w in sizes]
+    n = len(outs)
+    ptrs = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    hs, ws = (C.c_int * n)(*[int(h) for h, _ in sizes]), (C.c_int * n)(*[int(w) for _, w in sizes])
+    f = lib().fn2_downsample_forward_multi_cpu
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)] + [C.c_int] * 5
+    _check(f(x.ctypes.data, ptrs, hs, ws, n, N, Cc, H, W), "downsample_forward_multi")
+    return outs
+
+
 def predict_flow_conv_forward(x, weight, bias=None):
     x, weight = _f32(x), _f32(weight)
     bias = _f32(bias) if bias is not None else None

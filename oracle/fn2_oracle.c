@@ -848,6 +848,19 @@ FN2_API int fn2_downsample_forward_cpu(const float* bottom, float* top, int N, i
   return FN2_OK;
 }
 
+/* Several top sizes of one bottom (fn2_downsample_forward_multi: the ground-truth pyramid of the multi-scale loss in one launch): the layers
+ * one after another. */
+FN2_API int fn2_downsample_forward_multi_cpu(const float* bottom, float* const* tops, const int* top_heights, const int* top_widths, int count,
+                                             int N, int C, int Hin, int Win) {
+  if (count < 1 || count > 8 || !tops || !top_heights || !top_widths) return FN2_ERR_INVALID_ARG;
+  for (int j = 0; j < count; ++j) {
+    if (top_heights[j] < 2 || top_widths[j] < 2 || (top_heights[j] == Hin && top_widths[j] == Win)) return FN2_ERR_INVALID_ARG;
+    const int rc = fn2_downsample_forward_cpu(bottom, tops[j], N, C, Hin, Win, top_heights[j], top_widths[j]);
+    if (rc) return rc;
+  }
+  return FN2_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Flow heads: stock Caffe Convolution / Deconvolution arithmetic (conv_layer.cpp:8-40 via im2col + GEMM,
  * deconv_layer.cpp:8-45), restated as direct loops.  The reference sums through cblas_sgemm / cublasSgemm

@@ -12,3 +12,6 @@ def t(f, it=100):
 x = torch.randn(8, 2, 320, 448, device="cuda")
 for s in (4, 8, 16, 32, 64):
     print("downsample [8,2,320,448] -> 1/%d: %.1f us" % (s, t(lambda: ops.downsample_forward(x, 320 // s, 448 // s))))
+sizes = [(320 // s, 448 // s) for s in (4, 8, 16, 32, 64)]
+print("the five as five launches: %.1f us" % t(lambda: [ops.downsample_forward(x, h, w) for h, w in sizes]))
+print("the five in ONE launch (fn2_downsample_forward_multi): %.1f us" % t(lambda: ops.downsample_forward_multi(x, sizes)))

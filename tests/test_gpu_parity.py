@@ -648,6 +648,30 @@ def test_downsample_large_factors(case):
     assert_close(host(ops.downsample_forward(dev(x), ho, wo)), oracle.downsample_forward(x, ho, wo), 3e-6, "downsample, large factor")
 
 
+@pytest.mark.parametrize("case", [((2, 2, 320, 448), [(80, 112), (40, 56), (20, 28), (10, 14), (5, 7)]),
+                                  ((1, 3, 97, 130), [(3, 4), (50, 60), (96, 129)]), ((3, 2, 64, 96), [(16, 24)])])
+def test_downsample_pyramid_in_one_launch_has_the_bits_of_the_single_launches(case):
+    """fn2_downsample_forward_multi (round 6): the ground-truth pyramid of the multi-scale loss -- five Downsample layers on one blob, thread / wave /
+    workgroup per output element by the tap count -- as one grid.  Bit-identical to the launches of their own (same decomposition and tap order
+    per size), NaN votes included; against the oracle's twin at the single launches' tolerance."""
+    shape, sizes = case
+    x = rand(shape, 81, 5.0)
+    x[:, :, : shape[2] // 3, : shape[3] // 2] = np.nan
+    x[:, 0, shape[2] // 2, ::3] = np.nan
+    d = dev(x)
+    many = ops.downsample_forward_multi(d, sizes)
+    want = oracle.downsample_forward_multi(x, sizes)
+    for (h, w), got, ref in zip(sizes, many, want):
+        one = ops.downsample_forward(d, h, w)
+        assert tuple(got.shape) == (shape[0], shape[1], h, w)
+        np.testing.assert_array_equal(host(got).view(np.uint32), host(one).view(np.uint32))
+        assert_close(host(got), ref, 3e-6, "downsample pyramid %dx%d" % (h, w))
+    assert ops.downsample_multi_supported(shape, sizes) and not ops.downsample_multi_supported(shape, [(1, 5)]) \
+        and not ops.downsample_multi_supported(shape, [(shape[2], shape[3])]) and not ops.downsample_multi_supported(shape, [(4, 4)] * 9)
+    with pytest.raises(Exception):
+        ops.downsample_forward_multi(d, [(1, 5)])
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 20, 28), (3, 5, 7, 9), (1, 130, 3, 5), (16, 64, 40, 56)])
 def test_bias_leaky_relu_backward_and_autograd(shape):
     y, g = rand(shape, 90), rand(shape, 91)

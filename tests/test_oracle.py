@@ -322,6 +322,18 @@ def test_downsample_vs_fp64_with_nan_voting(shape):
     np.testing.assert_allclose(np.nan_to_num(out), np.nan_to_num(ref), atol=2e-6)
 
 
+def test_downsample_multi_twin_is_the_layers_one_after_another():
+    x = _rand((2, 2, 33, 47), 21)
+    x[1, 1, 5:20, 7:30] = np.nan
+    sizes = [(16, 23), (8, 11), (4, 5), (2, 2)]
+    for (h, w), got in zip(sizes, oracle.downsample_forward_multi(x, sizes)):
+        np.testing.assert_array_equal(got.view(np.uint32), oracle.downsample_forward(x, h, w).view(np.uint32))
+    with pytest.raises(Exception):
+        oracle.downsample_forward_multi(x, [(1, 4)])
+    with pytest.raises(Exception):
+        oracle.downsample_forward_multi(x, [(33, 47)])
+
+
 def test_bias_leaky_relu_oracle_matches_torch():
     rng = np.random.default_rng(7)
     x = rng.standard_normal((2, 6, 5, 7)).astype(np.float32); b = rng.standard_normal(6).astype(np.float32)
