@@ -54,6 +54,8 @@ struct DownArgs {
 // output for the x4 reduction of a flow field.  Weights keep the reference's expression and order (:52).
 // (bx, by, gy: the block's coordinates and the y extent of the grid it belongs to -- blockIdx / gridDim of its own launch, or its place in
 // the job of a multi-scale launch, downsample_fwd_multi)
+// (Column weights kept in LDS per thread, as the group kernels below keep their row weights, made this kernel SLOWER -- 20 -> 24 us at x4,
+// 25 -> 34 us at x8: its time is the latency of 9-17 short rows per output, not the two divisions per tap.)
 __device__ __forceinline__ void downsample_thread_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned by,
                                                        unsigned gy) {
   const unsigned hw_out = (unsigned)a.Hout * a.Wout;
@@ -71,23 +73,23 @@ __device__ __forceinline__ void downsample_thread_body(const float* __restrict__
     for (int ty = y0; ty <= y1; ++ty) {
       const float wy = fmaxf(0.0f, 1.0f - (fabsf((float)ty - boty) / a.heightScale));
       const float* row = p + (size_t)ty * a.Win;
-      int bx = x0;
-      for (; bx + 3 <= x1; bx += 4) {
+      int tx = x0;
+      for (; tx + 3 <= x1; tx += 4) {
         float sm[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sm[j] = row[bx + j];
+        for (int j = 0; j < 4; ++j) sm[j] = row[tx + j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float sample = sm[j];
-          float weight = fmaxf(0.0f, 1.0f - (fabsf((float)(bx + j) - botx) / a.widthScale)) * wy;   // :52
+          float weight = fmaxf(0.0f, 1.0f - (fabsf((float)(tx + j) - botx) / a.widthScale)) * wy;   // :52
           if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }               // :53-57
           accum_value = fmaf(sample, weight, accum_value);
           accum_weight += weight;
         }
       }
-      for (; bx <= x1; ++bx) {
-        float sample = row[bx];
-        float weight = fmaxf(0.0f, 1.0f - (fabsf((float)bx - botx) / a.widthScale)) * wy;
+      for (; tx <= x1; ++tx) {
+        float sample = row[tx];
+        float weight = fmaxf(0.0f, 1.0f - (fabsf((float)tx - botx) / a.widthScale)) * wy;
         if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }
         accum_value = fmaf(sample, weight, accum_value);
         accum_weight += weight;
@@ -103,15 +105,27 @@ __global__ void __launch_bounds__(256) downsample_fwd(const float* __restrict__ 
   downsample_thread_body(src, dst, a, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
-// Large reduction factors (the coarse scales of the multi-scale loss: 320x448 -> 5x7 is a 129 x 129 tap window per
-// output): one WAVE per output element, lanes stride over the taps in row-major order, then a fixed-shape butterfly sum
-// (deterministic).  The reference walks the window in one thread (:36-62); one thread per output left 280 threads with
-// 16,641 dependent taps each -- 416 us per call, 14 % of a FlowNetC training step.
-__device__ __forceinline__ void downsample_wave_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned gx) {
+// Large reduction factors (the coarse scales of the multi-scale loss: 320x448 -> 5x7 is a 129 x 129 tap window per output).  The reference
+// walks the window in one thread (:36-62); one thread per output left 280 threads with 16,641 dependent taps each -- 416 us per call, 14 % of a
+// FlowNetC training step.  Here a GROUP of threads owns an output element: a wave (512 <= taps < 4096) or a whole workgroup (more).
+// Round 6 layout: thread -> (column slot cx, row slot rs) of the window, CW = the power of two >= the window's width (at most the group).
+// The weight of a tap is separable -- wx(bx) * wy(by), :52 -- and each factor holds an IEEE division: a thread keeps ONE wx for its column,
+// the wy of the window's rows are computed once per output into LDS, so a tap costs a multiply, the NaN test and two adds instead of two
+// divisions (the flat tap index of rounds 3-5 spent ~40 VALU instructions per tap: 30 us for the 9.3 M taps of the coarsest scale).  Loads
+// run along rows (coalesced), four rows per thread in flight.  Order: a thread sums its column top to bottom (rows rs, rs + RS, ...), then a
+// fixed butterfly over the lanes and the waves in wave order -- deterministic; another order than the reference's single thread (3e-6).
+constexpr int kDownMaxRows = 2 * 512 + 1;       // rows of a window the LDS table holds (a reduction factor up to 512)
+
+template <int G>        // threads per output element: 64 (a wave; four outputs per workgroup) or 256
+__device__ __forceinline__ void downsample_group_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned gx,
+                                                      float* wyt, float (*part)[4]) {
+  constexpr int PER = 256 / G;                    // outputs a workgroup works on at a time
   const unsigned hw_out = (unsigned)a.Hout * a.Wout;
-  const unsigned lane = threadIdx.x & 63;
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned gt = G == 64 ? lane : tid;       // thread within its group
+  float* wy = wyt + (G == 64 ? wave * kDownMaxRows : 0);
   const unsigned long long total = (unsigned long long)a.NC * hw_out;
-  for (unsigned long long o = (unsigned long long)bx * 4 + (threadIdx.x >> 6); o < total; o += (unsigned long long)gx * 4) {
+  for (unsigned long long o = (unsigned long long)bx * PER + (G == 64 ? wave : 0); o < total; o += (unsigned long long)gx * PER) {
     const unsigned cn = (unsigned)(o / hw_out), pd = (unsigned)(o - (unsigned long long)cn * hw_out);
     const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
     const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
@@ -119,25 +133,36 @@ __device__ __forceinline__ void downsample_wave_body(const float* __restrict__ s
     const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                   // :30-31
     const int y0 = max(iboty - a.hradius, 0), y1 = min(iboty + a.hradius, a.Hin - 1);
     const int x0 = max(ibotx - a.wradius, 0), x1 = min(ibotx + a.wradius, a.Win - 1);
-    const int nx = x1 - x0 + 1, ntap = nx * (y1 - y0 + 1);
-    const float* p = src + (size_t)cn * a.Hin * a.Win;
+    const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+    int cw = 1;
+    while (cw < nx && cw < G) cw <<= 1;            // column slots (uniform over the group)
+    const int rs_n = G / cw, cx = (int)gt & (cw - 1), rs = (int)gt / cw;
+    if constexpr (G == 256) __syncthreads();       // (the previous output's table is still being read)
+    for (int r = (int)gt; r < ny; r += G) wy[r] = fmaxf(0.0f, 1.0f - (fabsf((float)(y0 + r) - boty) / a.heightScale));
+    if constexpr (G == 256) __syncthreads();
+    const float* p = src + (size_t)cn * a.Hin * a.Win + (size_t)y0 * a.Win;
     float accum_value = 0.f, accum_weight = 0.f, accum_nan = 0.f;
-    for (int t0 = (int)lane; t0 < ntap; t0 += 256) {           // four taps per lane in flight
-      float sm[4];
-      int tby[4], tbx[4];
+    for (int c = cx; c < nx; c += cw) {            // (one pass unless the window is wider than the group)
+      const int tbx = x0 + c;
+      const float wx = fmaxf(0.0f, 1.0f - (fabsf((float)tbx - botx) / a.widthScale));
+      const float* col = p + tbx;
+      // four rows per thread in flight (sixteen, with the tail folded into a predicated round, ran 2.5x SLOWER: 19.6 -> 50.5 us at x64)
+      int r = rs;
+      for (; r + 3 * rs_n < ny; r += 4 * rs_n) {
+        float sm[4], wr[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int t = min(t0 + 64 * j, ntap - 1);
-        tby[j] = y0 + t / nx; tbx[j] = x0 + t % nx;
-        sm[j] = p[(size_t)tby[j] * a.Win + tbx[j]];
+        for (int j = 0; j < 4; ++j) { sm[j] = col[(size_t)(r + j * rs_n) * a.Win]; wr[j] = wy[r + j * rs_n]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float sample = sm[j], weight = wx * wr[j];                                             // :52
+          if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }           // :53-57
+          accum_value = fmaf(sample, weight, accum_value);
+          accum_weight += weight;
+        }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (t0 + 64 * j >= ntap) break;
-        float sample = sm[j];
-        float weight = fmaxf(0.0f, 1.0f - (fabsf((float)tbx[j] - botx) / a.widthScale)) *
-                       fmaxf(0.0f, 1.0f - (fabsf((float)tby[j] - boty) / a.heightScale));   // :52
-        if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }           // :53-57
+      for (; r < ny; r += rs_n) {
+        float sample = col[(size_t)r * a.Win], weight = wx * wy[r];
+        if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }
         accum_value = fmaf(sample, weight, accum_value);
         accum_weight += weight;
       }
@@ -148,79 +173,34 @@ __device__ __forceinline__ void downsample_wave_body(const float* __restrict__ s
       accum_weight += __shfl_xor(accum_weight, m, 64);
       accum_nan += __shfl_xor(accum_nan, m, 64);
     }
-    if (lane == 0) {
-      if (accum_nan / accum_weight > 0.5f) dst[o] = __builtin_bit_cast(float, 0x7fffffffu);   // :64-65
-      else dst[o] = accum_value / accum_weight;                                               // :67
+    if constexpr (G == 64) {
+      if (lane == 0) {
+        if (accum_nan / accum_weight > 0.5f) dst[o] = __builtin_bit_cast(float, 0x7fffffffu);   // :64-65
+        else dst[o] = accum_value / accum_weight;                                               // :67
+      }
+    } else {
+      if (lane == 0) { part[0][wave] = accum_value; part[1][wave] = accum_weight; part[2][wave] = accum_nan; }
+      __syncthreads();
+      if (tid == 0) {
+        const float v = ((part[0][0] + part[0][1]) + part[0][2]) + part[0][3];
+        const float w = ((part[1][0] + part[1][1]) + part[1][2]) + part[1][3];
+        const float nn = ((part[2][0] + part[2][1]) + part[2][2]) + part[2][3];
+        if (nn / w > 0.5f) dst[o] = __builtin_bit_cast(float, 0x7fffffffu);   // :64-65
+        else dst[o] = v / w;                                                   // :67
+      }
     }
   }
 }
 
 __global__ void __launch_bounds__(256) downsample_fwd_wave(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
-  downsample_wave_body(src, dst, a, blockIdx.x, gridDim.x);
-}
-
-// The coarsest scales (320x448 -> 10x14 and 5x7: 4,225 and 16,641 taps per output, 2,240 and 560 outputs per batch of 8): a whole WORKGROUP per
-// output element -- with a wave per output the 560 waves of the last scale walked 260 dependent taps per lane (61 us per call, 182 us of a
-// training step for the three coarse scales).  Same tap order per lane class, wave butterfly, then the four wave sums added in wave order
-// (deterministic).
-__device__ __forceinline__ void downsample_block_body(const float* __restrict__ src, float* __restrict__ dst, const DownArgs& a, unsigned bx, unsigned gx,
-                                                      float (*part)[4]) {
-  const unsigned hw_out = (unsigned)a.Hout * a.Wout;
-  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned long long total = (unsigned long long)a.NC * hw_out;
-  for (unsigned long long o = bx; o < total; o += gx) {
-    const unsigned cn = (unsigned)(o / hw_out), pd = (unsigned)(o - (unsigned long long)cn * hw_out);
-    const int desty = pd / a.Wout, destx = pd - desty * a.Wout;
-    const float botx = ((float)destx / (float)(a.Wout - 1)) * (float)(a.Win - 1);     // :27
-    const float boty = ((float)desty / (float)(a.Hout - 1)) * (float)(a.Hin - 1);     // :28
-    const int ibotx = (int)roundf(botx), iboty = (int)roundf(boty);                   // :30-31
-    const int y0 = max(iboty - a.hradius, 0), y1 = min(iboty + a.hradius, a.Hin - 1);
-    const int x0 = max(ibotx - a.wradius, 0), x1 = min(ibotx + a.wradius, a.Win - 1);
-    const int nx = x1 - x0 + 1, ntap = nx * (y1 - y0 + 1);
-    const float* p = src + (size_t)cn * a.Hin * a.Win;
-    float accum_value = 0.f, accum_weight = 0.f, accum_nan = 0.f;
-    for (int t0 = (int)tid; t0 < ntap; t0 += 1024) {           // four taps per thread in flight
-      float sm[4];
-      int tby[4], tbx[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int t = min(t0 + 256 * j, ntap - 1);
-        tby[j] = y0 + t / nx; tbx[j] = x0 + t % nx;
-        sm[j] = p[(size_t)tby[j] * a.Win + tbx[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (t0 + 256 * j >= ntap) break;
-        float sample = sm[j];
-        float weight = fmaxf(0.0f, 1.0f - (fabsf((float)tbx[j] - botx) / a.widthScale)) *
-                       fmaxf(0.0f, 1.0f - (fabsf((float)tby[j] - boty) / a.heightScale));   // :52
-        if (sample != sample) { accum_nan += weight; sample = 0.f; weight = 0.f; }           // :53-57
-        accum_value = fmaf(sample, weight, accum_value);
-        accum_weight += weight;
-      }
-    }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-      accum_value += __shfl_xor(accum_value, m, 64);
-      accum_weight += __shfl_xor(accum_weight, m, 64);
-      accum_nan += __shfl_xor(accum_nan, m, 64);
-    }
-    if (lane == 0) { part[0][wave] = accum_value; part[1][wave] = accum_weight; part[2][wave] = accum_nan; }
-    __syncthreads();
-    if (tid == 0) {
-      const float v = ((part[0][0] + part[0][1]) + part[0][2]) + part[0][3];
-      const float w = ((part[1][0] + part[1][1]) + part[1][2]) + part[1][3];
-      const float nn = ((part[2][0] + part[2][1]) + part[2][2]) + part[2][3];
-      if (nn / w > 0.5f) dst[o] = __builtin_bit_cast(float, 0x7fffffffu);   // :64-65
-      else dst[o] = v / w;                                                   // :67
-    }
-    __syncthreads();
-  }
+  __shared__ float wyt[4 * kDownMaxRows];
+  downsample_group_body<64>(src, dst, a, blockIdx.x, gridDim.x, wyt, nullptr);
 }
 
 __global__ void __launch_bounds__(256) downsample_fwd_block(const float* __restrict__ src, float* __restrict__ dst, DownArgs a) {
+  __shared__ float wyt[4 * kDownMaxRows];
   __shared__ float part[3][4];
-  downsample_block_body(src, dst, a, blockIdx.x, gridDim.x, part);
+  downsample_group_body<256>(src, dst, a, blockIdx.x, gridDim.x, wyt, part);
 }
 
 // Several top sizes of ONE bottom in one launch (round 6): the ground-truth pyramid of the multi-scale loss is five Downsample layers on the
@@ -239,6 +219,7 @@ struct DownMulti {
 
 __global__ void __launch_bounds__(256) downsample_fwd_multi(const float* __restrict__ src, DownMulti m) {
   __shared__ float part[3][4];
+  __shared__ float wyt[4 * kDownMaxRows];
   int j = 0;
   while (j + 1 < m.count && blockIdx.x >= m.first[j + 1]) ++j;
   const unsigned b = blockIdx.x - m.first[j];
@@ -246,8 +227,8 @@ __global__ void __launch_bounds__(256) downsample_fwd_multi(const float* __restr
 #pragma unroll
   for (int k = 0; k < kDownMaxJobs; ++k) {
     if (k != j) continue;
-    if (m.mode[k] == 2) downsample_block_body(src, m.dst[k], m.a[k], b, m.gx[k], part);
-    else if (m.mode[k] == 1) downsample_wave_body(src, m.dst[k], m.a[k], b, m.gx[k]);
+    if (m.mode[k] == 2) downsample_group_body<256>(src, m.dst[k], m.a[k], b, m.gx[k], wyt, part);
+    else if (m.mode[k] == 1) downsample_group_body<64>(src, m.dst[k], m.a[k], b, m.gx[k], wyt, nullptr);
     else downsample_thread_body(src, m.dst[k], m.a[k], b % m.gx[k], b / m.gx[k], m.gy[k]);
   }
 }
@@ -293,6 +274,8 @@ FN2_API int fn2_channel_norm_backward(const float* bottom, const float* top, con
 }
 
 // geometry + decomposition of one Downsample: 0 thread, 1 wave, 2 workgroup per output element (by the tap count); -1: plane too large
+static int g_down_wave_taps = 256;       // windows from this many taps up get a wave per output element
+#define kDownWaveTaps g_down_wave_taps
 static int down_plan(int N, int C, int Hin, int Win, int Hout, int Wout, DownArgs* out, unsigned* gx, unsigned* gy) {
   DownArgs a;
   a.NC = N * C; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout;
@@ -305,8 +288,9 @@ static int down_plan(int N, int C, int Hin, int Win, int Hout, int Wout, DownArg
   const long long taps = (long long)(2 * a.wradius + 1) * (2 * a.hradius + 1);
   const long long outs = (long long)a.NC * Hout * Wout;
   *gy = 1;
-  if (taps >= 4096) { *gx = (unsigned)(outs < 65536 ? outs : 65536); return 2; }
-  if (taps >= 512) { const long long blocks = (outs + 3) / 4; *gx = (unsigned)(blocks < 65536 ? blocks : 65536); return 1; }
+  const bool table_fits = 2 * a.hradius + 1 <= kDownMaxRows;      // (the LDS table of row weights; a taller window runs on the thread kernel)
+  if (taps >= 4096 && table_fits) { *gx = (unsigned)(outs < 65536 ? outs : 65536); return 2; }
+  if (taps >= kDownWaveTaps && table_fits) { const long long blocks = (outs + 3) / 4; *gx = (unsigned)(blocks < 65536 ? blocks : 65536); return 1; }
   *gx = ((unsigned)Hout * Wout + 255) / 256;
   *gy = (unsigned)(a.NC < 65535 ? a.NC : 65535);
   return 0;

@@ -15,3 +15,5 @@ for s in (4, 8, 16, 32, 64):
 sizes = [(320 // s, 448 // s) for s in (4, 8, 16, 32, 64)]
 print("the five as five launches: %.1f us" % t(lambda: [ops.downsample_forward(x, h, w) for h, w in sizes]))
 print("the five in ONE launch (fn2_downsample_forward_multi): %.1f us" % t(lambda: ops.downsample_forward_multi(x, sizes)))
+y = torch.randn(2, 2, 12, 1200, device="cuda")
+print("wide window [2,2,12,1200] -> (9, 20) (107 x 5 taps): %.1f us;  -> (11, 30) (83 x 5): %.1f us" % (t(lambda: ops.downsample_forward(y, 9, 20)), t(lambda: ops.downsample_forward(y, 11, 30))))

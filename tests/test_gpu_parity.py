@@ -1263,3 +1263,13 @@ def test_bias_leaky_relu_backward_reads_a_concat_gradient_slice_in_place():
     assert torch.equal(d0, d1) and torch.equal(b0, b1)
     with pytest.raises(ValueError):
         ops.bias_leaky_relu_backward(y, (wide, 10, C), 0.1)
+
+
+@pytest.mark.parametrize("case", [((2, 2, 12, 1200), (9, 20)), ((1, 2, 12, 1200), (11, 30)), ((1, 1, 1300, 9), (2, 5)), ((1, 2, 2200, 40), (2, 3))])
+def test_downsample_windows_beyond_the_weight_tables(case):
+    """Windows the separable-weight tables of round 6 do not hold: wider than 24 columns with fewer than 512 taps (column weights per tap, as
+    before), taller than 1025 rows (the thread kernel instead of a wave / workgroup per output)."""
+    shape, (ho, wo) = case
+    x = rand(shape, 82, 3.0)
+    x[:, :, : shape[2] // 2, : shape[3] // 4] = np.nan
+    assert_close(host(ops.downsample_forward(dev(x), ho, wo)), oracle.downsample_forward(x, ho, wo), 3e-6, "downsample, odd window")
