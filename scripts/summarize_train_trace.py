@@ -6,7 +6,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 # steps = calls of a kernel that runs exactly once per training step: the stem's weight gradient (round 4), else the stem's forward kernel
 steps = None
-for pat in ("stem_wgrad", "conv_k7s2_relu<3"):
+for pat in ("stem_wgrad<", "conv_k7s2_relu<3"):       # ("stem_wgrad<": the kernel itself, not its two finalize launches)
     hit = [int(r["Calls"]) for r in rows if pat in r["Name"]]
     if hit:
         steps = max(hit)
@@ -37,8 +37,8 @@ for r in rows:
     c = cat(r["Name"])
     cats[c] = cats.get(c, 0) + float(r["TotalDurationNs"])
 print("steps %d; kernel time per step %.3f ms, SUMMED over the streams (correlation forward excluded: its micro-benchmark shares the trace).  Since round 5 the\n"
-      "weight gradients run on a second HIP stream beside the data-gradient chain: the durations overlap -- a kernel that shares the chip runs longer than alone (bias_leaky_relu_bwd:\n"
-      "69 us per call here, 23 us alone) -- and their sum exceeds the step time (bench.py --mode train: 9.2 ms)." % (steps, tot / 1e6 / steps))
+      "weight gradients run on a second HIP stream beside the data-gradient chain: the durations overlap -- a kernel that shares the chip runs longer than alone (the\n"
+      "correlation backward: 90 us alone) -- and their sum exceeds the step time (bench.py --mode train, same round: profiles/<tag>_bench_train.json)." % (steps, tot / 1e6 / steps))
 for c, v in sorted(cats.items(), key=lambda x: -x[1]):
     print("  %-22s %8.3f ms/step %5.1f %%" % (c, v / 1e6 / steps, 100 * v / tot))
 for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 45]:
