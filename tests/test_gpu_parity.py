@@ -672,7 +672,8 @@ def test_downsample_pyramid_in_one_launch_has_the_bits_of_the_single_launches(ca
         ops.downsample_forward_multi(d, [(1, 5)])
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 20, 28), (3, 5, 7, 9), (1, 130, 3, 5), (16, 64, 40, 56)])
+@pytest.mark.parametrize("shape", [(2, 64, 20, 28), (3, 5, 7, 9), (1, 130, 3, 5), (16, 64, 40, 56), (2, 128, 20, 28), (8, 256, 40, 56), (3, 144, 9, 7),
+                                   (8, 128, 52, 48)])
 def test_bias_leaky_relu_backward_and_autograd(shape):
     y, g = rand(shape, 90), rand(shape, 91)
     d, db = ops.bias_leaky_relu_backward(dev(y), dev(g), 0.1)
@@ -1263,6 +1264,16 @@ def test_bias_leaky_relu_backward_reads_a_concat_gradient_slice_in_place():
     assert torch.equal(d0, d1) and torch.equal(b0, b1)
     with pytest.raises(ValueError):
         ops.bias_leaky_relu_backward(y, (wide, 10, C), 0.1)
+    # the one-launch form (round 6: at least 128 channels of at most 20,000 values each), 16-byte and 4-byte rows, both blobs channel slices
+    for (N, C, H, W) in [(2, 160, 12, 20), (2, 130, 5, 7)]:
+        ywide, wide = dev(rand((N, C + 9, H, W), 362)), dev(rand((N, C + 7, H, W), 363))
+        y = ywide[:, 4:4 + C].contiguous()
+        d0, b0 = ops.bias_leaky_relu_backward(y, wide[:, 5:5 + C].contiguous(), 0.1)
+        d1, b1 = ops.bias_leaky_relu_backward((ywide, 4, C), (wide, 5, C), 0.1)
+        assert torch.equal(d0, d1) and torch.equal(b0, b1)
+        od, odb = oracle.bias_leaky_relu_backward(host(y), host(wide[:, 5:5 + C].contiguous()), 0.1)
+        np.testing.assert_array_equal(host(d1), od)
+        assert_close(host(b1), odb, 2e-6 * np.sqrt(N * H * W), "bias diff, one-launch form")
 
 
 @pytest.mark.parametrize("case", [((2, 2, 12, 1200), (9, 20)), ((1, 2, 12, 1200), (11, 30)), ((1, 1, 1300, 9), (2, 5)), ((1, 2, 2200, 40), (2, 3))])
@@ -1273,3 +1284,23 @@ def test_downsample_windows_beyond_the_weight_tables(case):
     x = rand(shape, 82, 3.0)
     x[:, :, : shape[2] // 2, : shape[3] // 4] = np.nan
     assert_close(host(ops.downsample_forward(dev(x), ho, wo)), oracle.downsample_forward(x, ho, wo), 3e-6, "downsample, odd window")
+
+
+@pytest.mark.parametrize("shape", [(2, 160, 12, 20), (3, 130, 5, 7), (2, 64, 20, 28), (4, 32, 40, 56), (8, 256, 40, 56)])
+def test_conv_backward_bias_both_forms_and_accumulate(shape):
+    """fn2_conv_backward_bias (backward_gpu_bias, base_conv_layer.cpp:389-393: the bias gradient of a Convolution without a fused ReLU) in its
+    two-launch and its one-launch form (round 6: >= 128 channels of <= 20,000 values), on a channel slice of a wider top_diff, with and without
+    accumulation into an existing gradient; against a float64 sum."""
+    N, C, H, W = shape
+    wide = dev(rand((N, C + 6, H, W), 370))
+    d = wide[:, 3:3 + C]
+    ref = d.double().sum((0, 2, 3))
+    tol = 2e-6 * np.sqrt(N * H * W) * max(1.0, float(d.abs().max()))
+    b0 = ops.conv_backward_bias(wide, C, top_c0=3)
+    assert float((b0.double() - ref).abs().max()) <= tol
+    assert torch.equal(b0, ops.conv_backward_bias(d.contiguous(), C)), "slice read in place == copied-out slice"
+    assert torch.equal(b0, ops.conv_backward_bias(wide, C, top_c0=3)), "bit-reproducible"
+    acc = dev(rand((C,), 371))
+    want = acc + b0
+    ops.conv_backward_bias(wide, C, top_c0=3, out=acc, accumulate=True)
+    assert torch.equal(acc, want)
