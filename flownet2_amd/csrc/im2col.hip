@@ -70,6 +70,51 @@ __global__ void __launch_bounds__(256) col2im_bias_relu_kernel(const float* __re
   }
 }
 
+// Deconvolution{4, 2, 1} (every deconv* layer of the FlowNet decoders; H, W even: Hc = H / 2, Wc = W / 2): a thread owns one COLUMN-GRID position
+// (yc0, xc0) and writes the 2 x 2 image pixels (2 yc0 + {0, 1}, 2 xc0 + {0, 1}).  Image row 2 yc0 collects kernel rows i = 3 (from grid row
+// yc0 - 1) and i = 1 (yc0), row 2 yc0 + 1 rows i = 2 (yc0) and i = 0 (yc0 + 1); columns likewise -- every one of the 16 (i, j) planes is read
+// exactly once per thread at a FIXED offset from (yc0, xc0): 16 fully coalesced loads in flight and two 8-byte stores per thread instead of four
+// short-lived threads with 4 loads each (round 6: 26.3 -> see profiles/r06_layer_microbench.md).  Same sums in the same order as the kernel
+// above (grid rows ascending, then columns; a position outside the grid contributes + 0.0f, which leaves a running sum that started at + 0.0f
+// unchanged bit for bit): bit-identical.
+__global__ void __launch_bounds__(256) col2im_k4s2p1_bias_relu_kernel(const float* __restrict__ col, const float* __restrict__ bias,
+                                                                      float* __restrict__ im, ColArgs a) {
+  const unsigned hw = (unsigned)a.H * a.W, hwc = (unsigned)a.Hc * a.Wc;
+  const unsigned plane = blockIdx.y;                       // n * C + c
+  const float* src = col + (size_t)plane * 16 * hwc;
+  const float b = bias ? bias[plane % (unsigned)a.C] : 0.f;
+  float* dst = im + ((size_t)(plane / (unsigned)a.C) * a.im_ctot + a.im_c0 + plane % (unsigned)a.C) * hw;
+  for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < hwc; p += gridDim.x * blockDim.x) {
+    const int yc0 = p / a.Wc, xc0 = p - yc0 * a.Wc;
+    // t[i][j]: plane (i, j) at grid position (yc0 + dy(i), xc0 + dx(j)),  d(3) = -1, d(1) = d(2) = 0, d(0) = +1
+    float t[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int yc = yc0 + (i == 3 ? -1 : i == 0 ? 1 : 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xc = xc0 + (j == 3 ? -1 : j == 0 ? 1 : 0);
+        const bool ok = yc >= 0 && yc < a.Hc && xc >= 0 && xc < a.Wc;
+        t[i][j] = ok ? src[(size_t)(i * 4 + j) * hwc + (unsigned)yc * a.Wc + xc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      const int i0 = py ? 2 : 3, i1 = py ? 0 : 1;          // kernel rows of the lower / higher grid row
+      float o[2];
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int j0 = px ? 2 : 3, j1 = px ? 0 : 1;
+        float v = 0.f;
+        v += t[i0][j0]; v += t[i0][j1]; v += t[i1][j0]; v += t[i1][j1];
+        v += b;
+        o[px] = (a.relu && v <= 0.f) ? v * a.slope : v;
+      }
+      *reinterpret_cast<float2*>(dst + (size_t)(2 * yc0 + py) * a.W + 2 * xc0) = make_float2(o[0], o[1]);
+    }
+  }
+}
+
 static int col_geometry(const char* who, int N, int C, int H, int W, int k, int pad, int stride, ColArgs* a) {
   if (N < 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || pad < 0 || stride <= 0)
     return fail(FN2_ERR_INVALID_ARG, "%s: bad arguments (N %d C %d H %d W %d kernel %d pad %d stride %d)", who, N, C, H, W, k, pad, stride);
@@ -123,10 +168,14 @@ static int col2im_launch(const float* col, const float* bias, float* im, int N, 
   // gridDim.y <= 65535: fold the planes in chunks of whole samples (the kernel derives (n, c) from its plane index)
   const long long step = planes > 65535 ? ((65535 / C) > 0 ? (long long)(65535 / C) * C : 0) : planes;
   if (step == 0) return fail(FN2_ERR_UNSUPPORTED, "col2im_bias_relu: more than 65535 channels");
+  const bool quad = kernel == 4 && stride == 2 && pad == 1 && H % 2 == 0 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(im) & 7) == 0;
+  unsigned bq = (hwc + 255) / 256; if (bq > 64) bq = 64;
   for (long long p0 = 0; p0 < planes; p0 += step) {
     const unsigned py = (unsigned)((planes - p0) < step ? (planes - p0) : step);
-    hipLaunchKernelGGL(col2im_bias_relu_kernel, dim3(bx, py), dim3(256), 0, st, col + (size_t)p0 * kernel * kernel * hwc, bias,
-                       im + (size_t)(p0 / C) * im_ctot * hw, a);
+    if (quad) hipLaunchKernelGGL(col2im_k4s2p1_bias_relu_kernel, dim3(bq, py), dim3(256), 0, st, col + (size_t)p0 * kernel * kernel * hwc, bias,
+                                 im + (size_t)(p0 / C) * im_ctot * hw, a);
+    else hipLaunchKernelGGL(col2im_bias_relu_kernel, dim3(bx, py), dim3(256), 0, st, col + (size_t)p0 * kernel * kernel * hwc, bias,
+                            im + (size_t)(p0 / C) * im_ctot * hw, a);
   }
   return check_launch("col2im_bias_relu_forward");
 }

@@ -1304,3 +1304,24 @@ def test_conv_backward_bias_both_forms_and_accumulate(shape):
     want = acc + b0
     ops.conv_backward_bias(wide, C, top_c0=3, out=acc, accumulate=True)
     assert torch.equal(acc, want)
+
+
+def test_col2im_quad_kernel_keeps_the_bits_on_signed_zeros_and_nans():
+    """The Deconvolution{4, 2, 1} col2im form of round 6 (a thread per column-grid position, 16 loads, positions outside the grid contribute
+    + 0.0f) against the oracle on columns full of - 0.0f, + 0.0f, NaN and infinities: the running sum starts at + 0.0f and can never be - 0.0f,
+    so the padded zeros change no bit; compared as bit patterns."""
+    N, C, H, W = 2, 5, 6, 8
+    rng = np.random.default_rng(5)
+    col = rng.standard_normal((N, C * 16, H * W)).astype(np.float32)
+    pick = rng.integers(0, 6, size=col.shape)
+    col[pick == 0] = -0.0
+    col[pick == 1] = 0.0
+    col[(pick == 2) & (rng.random(col.shape) < 0.05)] = np.nan
+    col[(pick == 3) & (rng.random(col.shape) < 0.05)] = np.inf
+    for relu in (True, False):
+        for bias in (np.zeros(C, np.float32), -np.zeros(C, np.float32), rand((C,), 7)):
+            got = host(ops.col2im_bias_relu_forward(dev(col), dev(bias), N, C, 2 * H, 2 * W, 4, 1, 2, relu, 0.1))
+            want = oracle.col2im_bias_relu_forward(col, bias, N, C, 2 * H, 2 * W, 4, 1, 2, relu, 0.1)
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(got), nan)
+            np.testing.assert_array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
