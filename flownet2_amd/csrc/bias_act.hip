@@ -263,6 +263,7 @@ FN2_API int fn2_bias_leaky_relu_forward(float* data, const float* bias, int N, i
 // DataAugmentation layer (data_augmentation_layer.cu:592-621: x - mean[c]) when the Resample between them is the identity, in one pass,
 // written into a channel slice of the blob the first convolution reads (FlowNetS: [img0 | img1] along the channel axis).
 namespace fn2 {
+template <bool VEC4>
 __global__ void __launch_bounds__(256) scale_shift(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ shift,
                                                    int C, unsigned hw, int out_ctot, int out_c0, float scale) {
   const unsigned plane = blockIdx.y;                       // n * C + c
@@ -270,10 +271,24 @@ __global__ void __launch_bounds__(256) scale_shift(const float* __restrict__ in,
   const float sh = shift ? shift[c] : 0.f;
   const float* p = in + (size_t)plane * hw;
   float* q = out + ((size_t)n * out_ctot + out_c0 + c) * hw;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
-    float prod = p[i] * scale;
-    asm volatile("" : "+v"(prod));       // the product is rounded on its own: hipcc contracts a * b + c into an fma otherwise (also through __fmul_rn)
-    q[i] = prod + sh;
+  if constexpr (VEC4) {                 // 16-byte loads / stores (hw % 4 == 0, 16-byte aligned blobs): 9.5 -> see profiles/r06_rocprof_summary.md
+    const unsigned n4 = hw / 4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+      f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float prod = v[j] * scale;
+        asm volatile("" : "+v"(prod));
+        v[j] = prod + sh;
+      }
+      reinterpret_cast<f32x4*>(q)[i] = v;
+    }
+  } else {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+      float prod = p[i] * scale;
+      asm volatile("" : "+v"(prod));       // the product is rounded on its own: hipcc contracts a * b + c into an fma otherwise (also through __fmul_rn)
+      q[i] = prod + sh;
+    }
   }
 }
 }  // namespace fn2
@@ -286,7 +301,10 @@ FN2_API int fn2_scale_shift_forward(const float* bottom, float* top, const float
   if (!bottom || !top) return fn2::fail(FN2_ERR_INVALID_ARG, "scale_shift: NULL blob pointer");
   if ((long long)N * C > 65535) return fn2::fail(FN2_ERR_UNSUPPORTED, "scale_shift: too many planes");
   const unsigned hw = (unsigned)H * (unsigned)W;
-  hipLaunchKernelGGL(fn2::scale_shift, dim3(fn2::blocks_for(hw, 256, 64), (unsigned)(N * C)), dim3(256), 0, fn2::as_stream(stream), bottom, top, shift,
-                     C, hw, top_channels, top_c0, scale);
+  const bool vec = hw % 4 == 0 && ((reinterpret_cast<uintptr_t>(bottom) | reinterpret_cast<uintptr_t>(top)) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(fn2::scale_shift<true>, dim3(fn2::blocks_for(hw / 4, 256, 256), (unsigned)(N * C)), dim3(256), 0, fn2::as_stream(stream), bottom, top,
+                              shift, C, hw, top_channels, top_c0, scale);
+  else hipLaunchKernelGGL(fn2::scale_shift<false>, dim3(fn2::blocks_for(hw, 256, 64), (unsigned)(N * C)), dim3(256), 0, fn2::as_stream(stream), bottom, top, shift,
+                          C, hw, top_channels, top_c0, scale);
   return fn2::check_launch("scale_shift_forward");
 }
