@@ -25,6 +25,45 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// K wave sums at once (round 6): a reduce-scatter butterfly.  At the step with lane mask m every lane hands HALF of the values it still
+// holds to its partner and keeps the sums of the other half: K / 2 + K / 4 + ... + 1 = K - 1 shuffles and then log2(64 / K) plain butterfly
+// steps on the one value that is left -- K - 1 + log2(64 / K) shuffles instead of the 6 K of K separate butterflies (64 sums: 63 instead
+// of 384; the kernels below are chains of cross-lane operations and nothing else, 70-110 us each beside a matrix kernel).
+// Afterwards v[0] of lane l is the wave-wide sum of the caller's v[l / (64 / K)] (every lane of a group of 64 / K holds it).
+// Order: a fixed tree over the lanes (another one than K separate butterflies, hence other low bits), the same on every run.
+template <int K, int CNT, int M>
+struct ReduceScatterStep {          // (a template recursion, not a loop: every index and lane mask is a constant, the values stay in registers)
+  static __device__ __forceinline__ void run(float (&v)[K], bool (&hi)[6]) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      const float keep = hi[M] ? v[i + CNT] : v[i];
+      const float send = hi[M] ? v[i] : v[i + CNT];
+      v[i] = keep + __shfl_xor(send, 1 << M, 64);
+    }
+    ReduceScatterStep<K, CNT / 2, M - 1>::run(v, hi);
+  }
+};
+template <int K, int M>
+struct ReduceScatterStep<K, 0, M> {
+  static __device__ __forceinline__ void run(float (&v)[K], bool (&)[6]) {
+#pragma unroll
+    for (int b = M; b >= 0; --b) v[0] += __shfl_xor(v[0], 1 << b, 64);
+  }
+};
+template <int K>
+struct ReduceScatterStep<K, 0, -1> {
+  static __device__ __forceinline__ void run(float (&)[K], bool (&)[6]) {}
+};
+
+template <int K>
+__device__ __forceinline__ void wave_reduce_scatter(float (&v)[K], int lane) {
+  static_assert(K >= 2 && K <= 64 && (K & (K - 1)) == 0, "a power of two of values");
+  bool hi[6];
+#pragma unroll
+  for (int b = 0; b < 6; ++b) hi[b] = ((lane >> b) & 1) != 0;
+  ReduceScatterStep<K, K / 2, 5>::run(v, hi);
+}
+
 // partial[(c * parts + part) * 18 + co * 9 + ky * 3 + kx];  bpart[part * 2 + co]
 // Workgroup = (16 bottom channels, sample, band of up to 32 rows): the band of the two top_diff planes (+ halo) is staged once; every WAVE
 // then takes 4 of the channels on its own -- lanes stride over the band's pixels, 18 accumulators, one butterfly per (channel, part) -- so
@@ -78,12 +117,15 @@ __global__ void __launch_bounds__(256) pf_wgrad(const float* __restrict__ bottom
           for (int kx = 0; kx < 3; ++kx)
             acc[co * 9 + ky * 3 + kx] = fmaf(v, gp[co * plane - ky * Wp - kx], acc[co * 9 + ky * 3 + kx]);
     }
-    float mine = 0.f;                                // lane j < 18 ends up holding sum j
+    // lane j < 18 ends up holding sum j: the first 16 through one reduce-scatter (lane l then holds sum l / 4), the last two on their own
+    float first[16];
 #pragma unroll
-    for (int j = 0; j < 18; ++j) {
-      const float s = wave_sum(acc[j]);
-      if (lane == j) mine = s;
-    }
+    for (int j = 0; j < 16; ++j) first[j] = acc[j];
+    wave_reduce_scatter<16>(first, lane);
+    float mine = __shfl(first[0], (lane & 15) * 4, 64);
+    const float s16 = wave_sum(acc[16]), s17 = wave_sum(acc[17]);
+    if (lane == 16) mine = s16;
+    if (lane == 17) mine = s17;
     if (lane < 18) partial[((size_t)c * parts + part) * 18 + lane] = mine;
   }
 }
@@ -100,10 +142,15 @@ __global__ void __launch_bounds__(64) pf_finalize(const float* __restrict__ part
 #pragma unroll
     for (int j = 0; j < 18; ++j) acc[j] += q[j];
   }
+  {
+    float first[16];
 #pragma unroll
-  for (int j = 0; j < 18; ++j) {
-    const float s = wave_sum(acc[j]);
-    if (lane == 0 && wdiff) {
+    for (int j = 0; j < 16; ++j) first[j] = acc[j];
+    wave_reduce_scatter<16>(first, lane);            // lane l: sum l / 4
+    const float s16 = wave_sum(acc[16]), s17 = wave_sum(acc[17]);
+    const int j = (lane & 3) == 0 ? lane >> 2 : lane == 1 ? 16 : lane == 2 ? 17 : -1;
+    const float s = lane == 1 ? s16 : lane == 2 ? s17 : first[0];
+    if (j >= 0 && wdiff) {
       float* d = wdiff + ((size_t)(j / 9) * C + c) * 9 + (j % 9);
       *d = accumulate ? *d + s : s;
     }
@@ -157,9 +204,9 @@ __global__ void __launch_bounds__(256) uf_backward(const float* __restrict__ bot
   const int Ho = 2 * H, Wo = 2 * W;
   if (tid < 64) wl[tid] = weight[tid];
   __syncthreads();
-  float acc[66];
+  float acc[64], bacc[2] = {0.f, 0.f};
 #pragma unroll
-  for (int j = 0; j < 66; ++j) acc[j] = 0.f;
+  for (int j = 0; j < 64; ++j) acc[j] = 0.f;
   if (pix < hw) {
     const int y = pix / W, x = pix - y * W;
     float gv[2][16];
@@ -195,14 +242,15 @@ __global__ void __launch_bounds__(256) uf_backward(const float* __restrict__ bot
         }
       // bias: every top pixel belongs to exactly one bottom pixel's 2 x 2 block (Y in {2y, 2y + 1} <-> ky in {1, 2})
 #pragma unroll
-      for (int co = 0; co < 2; ++co) acc[64 + co] = (gv[co][1 * 4 + 1] + gv[co][1 * 4 + 2]) + (gv[co][2 * 4 + 1] + gv[co][2 * 4 + 2]);
+      for (int co = 0; co < 2; ++co) bacc[co] = (gv[co][1 * 4 + 1] + gv[co][1 * 4 + 2]) + (gv[co][2 * 4 + 1] + gv[co][2 * 4 + 2]);
     }
   }
   if (!want_w) return;
-#pragma unroll
-  for (int j = 0; j < 66; ++j) {
-    const float s = wave_sum(acc[j]);
-    if (lane == 0) red[j][wave] = s;
+  {
+    const float b0 = wave_sum(bacc[0]), b1 = wave_sum(bacc[1]);
+    wave_reduce_scatter<64>(acc, lane);              // lane l: the wave's sum of weight-gradient term l
+    red[lane][wave] = acc[0];
+    if (lane == 0) { red[64][wave] = b0; red[65][wave] = b1; }
   }
   __syncthreads();
   if (tid < 66) partial[(size_t)part * 66 + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
