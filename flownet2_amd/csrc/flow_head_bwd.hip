@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) pf_wgrad(const float* __restrict__ bottom
     if (tid < 2) bpart[part * 2 + tid] = ((red[tid][0] + red[tid][1]) + red[tid][2]) + red[tid][3];
   }
   const int npix = rows * W;
+  const int step_rows = 64 / W, step_cols = 64 - step_rows * W;
   for (int cc = 0; cc < kCG / 4; ++cc) {
     const int c = blockIdx.x * kCG + wave * (kCG / 4) + cc;
     if (c >= C) break;                               // wave-uniform; no barrier below
@@ -103,12 +104,16 @@ __global__ void __launch_bounds__(256) pf_wgrad(const float* __restrict__ bottom
     float acc[18];
 #pragma unroll
     for (int j = 0; j < 18; ++j) acc[j] = 0.f;
+    // (the pixel's row / column advance by 64 / W rows and 64 % W columns per step: the integer division per pixel and channel was a third
+    // of this kernel's 32 M vector instructions per training step)
+    int yy = lane / W, xx = lane - yy * W;
     for (int i = lane; i < npix; i += 64) {
-      const int yy = i / W, xx = i - yy * W;
       const float v = src[i];
       // dw[co][c][ky][kx] += bottom[c][y + ky - 1][x + kx - 1] * top_diff[co][y][x]; with p = (y + ky - 1, x + kx - 1) the bottom pixel:
       // top_diff at p - (ky - 1, kx - 1)  ->  LDS row (yy + 1) - (ky - 1), column (xx + 1) - (kx - 1)
       const float* gp = g + (yy + 2) * Wp + xx + 2;
+      yy += step_rows; xx += step_cols;
+      if (xx >= W) { xx -= W; ++yy; }
 #pragma unroll
       for (int co = 0; co < 2; ++co)
 #pragma unroll
