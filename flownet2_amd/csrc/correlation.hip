@@ -158,7 +158,7 @@ static int g_force_generic = 0;
 
 using namespace fn2;
 
-namespace fn2 { extern int g_corr_units; extern int g_corr_units_lds; extern int g_corr_units_abl; extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; extern int g_corr_bwd_separate; } }
+namespace fn2 { extern int g_corr_units; extern int g_corr_units_lds; extern int g_corr_units_abl; extern int g_corr_ablation; extern int g_corr_force_dword; extern int g_corr_proj; extern int g_corr_skip_dead; extern int g_corr_simd_plan; extern int g_corr1d_force_generic; extern int g_corr1d_no_mfma; extern unsigned long long* g_corr_dbg; namespace bwd { extern int g_corr_bwd_first_gen; extern int g_corr_bwd_gen; extern int g_corr_bwd_separate; } }
 
 FN2_API int fn2_debug_set_correlation_trace(void* device_buffer) {
   fn2::g_corr_dbg = reinterpret_cast<unsigned long long*>(device_buffer);
@@ -177,6 +177,7 @@ FN2_API int fn2_debug_set_correlation_impl(int impl) {
   fn2::g_corr_units_abl = (impl >= 100 && impl < 164) ? impl - 100 : 0;
   g_force_generic = (impl == 1);
   fn2::g_corr1d_force_generic = (impl == 1);
+  fn2::g_corr1d_no_mfma = (impl == 17);                      // Correlation1D: the LDS-tiled VALU forward instead of the MFMA one
   fn2::g_corr_force_dword = (impl == 3);
   fn2::g_corr_proj = impl == 7 ? 1 : impl == 8 ? 2 : impl == 9 ? 3 : 0;   // profiling builds of the paired-parity forward: 7 = 3/8 of the MFMAs (bf16 x 3 projection), 8 = none (wrong results)
   fn2::bwd::g_corr_bwd_first_gen = (impl == 5);

@@ -164,6 +164,114 @@ static void corr1d_tiled_launch(const Corr1dGeom& g, const float* b0, const floa
   hipLaunchKernelGGL(corr1d_fwd_tiled<NO>, dim3((g.topW + kC1Tile - 1) / kC1Tile, g.N * g.H), dim3(256), lds, st, b0, b1, top, g, bw);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same layer on the matrix cores (round 6): per image row the cost volume is a BANDED product between the columns of map 0 (M) and of
+// map 1 (N), contracted over the channels -- top[o][x] = 1/C sum_c A[c][xa] B[c][xa + o + xshift], stride_2 = 1.  A wave owns one M tile
+// of 16 output columns and the NT N tiles the band of that tile touches (16 + ngw - 1 columns of map 1): NT accumulators of
+// v_mfma_f32_16x16x4_f32, whose k-ordered fma chain is the generic kernel's `fmaf` loop over the channels bit for bit.  Workgroup = one
+// image row x 32 output columns (two waves); the channels arrive 32 at a time through LDS (rows padded to a stride of 16 mod 32 floats:
+// the operand reads -- lane (k, m) reads [4 q + k][m] -- are conflict-free); the accumulators go back through LDS, where displacement o of
+// column m sits on the diagonal [m][o + m], and leave as 64-byte runs of one displacement.  The tiled kernel above made one LDS read per
+// fma (59 us for [4,256,48,96] with 41 displacements); this one reads 5 operands per 4 MFMAs = 4,096 fmas.
+// ---------------------------------------------------------------------------------------------------------
+using c1_f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kC1MW = 2;            // waves (M tiles of 16 output columns) per workgroup
+constexpr int kC1MChunk = 32;       // channels per LDS chunk
+
+constexpr int c1_stride(int row) { return row + ((16 - row % 32) + 32) % 32; }     // >= row, == 16 (mod 32)
+
+template <int NT>
+__global__ void __launch_bounds__(64 * kC1MW) corr1d_fwd_mfma(const float* __restrict__ b0, const float* __restrict__ b1, float* __restrict__ top,
+                                                               Corr1dGeom g) {
+  constexpr int AW = 16 * kC1MW, BW = 16 * (kC1MW - 1 + NT), SA = c1_stride(AW), SB = c1_stride(BW), ST = 16 * NT + 1;
+  constexpr int STAGE = kC1MChunk * (SA + SB), TRANS = kC1MW * 16 * ST;
+  __shared__ float lds[STAGE > TRANS ? STAGE : TRANS];
+  float* As = lds;                               // [kC1MChunk][SA]
+  float* Bs = lds + kC1MChunk * SA;              // [kC1MChunk][SB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * AW;
+  const int y = blockIdx.y % g.H, n = blockIdx.y / g.H;
+  const int xa0 = x0 + g.md - g.pad;             // first map-0 column of the workgroup (unpadded coordinates)
+  const int xb0 = xa0 + g.xshift;                // first map-1 column the band of the workgroup reads (stride_2 = 1)
+  const size_t plane = (size_t)g.H * g.W;
+  const float* a_row = b0 + (size_t)n * g.C * plane + (size_t)y * g.W;
+  const float* b_row = b1 + (size_t)n * g.C * plane + (size_t)y * g.W;
+  c1_f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = c1_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int k = lane >> 4, m = lane & 15;
+  // staging: thread (cs = tid / 16, xq = tid % 16) copies column 16 j + xq of channels cs, cs + CS, ... -- every index a shift.  Every load
+  // of a chunk is issued before the first one is used: addresses clamped into the blob, out-of-image / out-of-blob values replaced by 0
+  // afterwards (a load inside a conditional in front of its LDS store is a round trip of its own: 28 serial round trips per chunk made the
+  // first version slower than the kernel it replaces); the loads of chunk c + 1 are in flight while chunk c is multiplied.
+  constexpr int CS = 64 * kC1MW / 16;            // channel rows a pass covers
+  constexpr int NA = AW / 16, NB = BW / 16, CP = kC1MChunk / CS;
+  const int cs = tid >> 4, xq = tid & 15;
+  float va[NA][CP], vb[NB][CP];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int x = min(max(xa0 + 16 * j + xq, 0), g.W - 1);
+#pragma unroll
+      for (int i = 0; i < CP; ++i) va[j][i] = a_row[(size_t)min(c0 + cs + i * CS, g.C - 1) * plane + x];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int x = min(max(xb0 + 16 * j + xq, 0), g.W - 1);
+#pragma unroll
+      for (int i = 0; i < CP; ++i) vb[j][i] = b_row[(size_t)min(c0 + cs + i * CS, g.C - 1) * plane + x];
+    }
+  };
+  load_chunk(0);
+  for (int c0 = 0; c0 < g.C; c0 += kC1MChunk) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int x = xa0 + 16 * j + xq;
+      const bool okx = x >= 0 && x < g.W;
+#pragma unroll
+      for (int i = 0; i < CP; ++i) As[(cs + i * CS) * SA + 16 * j + xq] = (okx && c0 + cs + i * CS < g.C) ? va[j][i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int x = xb0 + 16 * j + xq;
+      const bool okx = x >= 0 && x < g.W;
+#pragma unroll
+      for (int i = 0; i < CP; ++i) Bs[(cs + i * CS) * SB + 16 * j + xq] = (okx && c0 + cs + i * CS < g.C) ? vb[j][i] : 0.f;
+    }
+    __syncthreads();
+    if (c0 + kC1MChunk < g.C) load_chunk(c0 + kC1MChunk);
+    const float* ap = As + k * SA + 16 * wave + m;
+    const float* bp = Bs + k * SB + 16 * wave + m;
+#pragma unroll
+    for (int q = 0; q < kC1MChunk / 4; ++q) {
+      const float av = ap[4 * q * SA];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[4 * q * SB + 16 * t], acc[t], 0, 0, 0);
+    }
+  }
+  __syncthreads();                               // the staging buffers become the transposition image
+  float* T = lds + wave * 16 * ST;               // [16 columns m][16 NT band positions]: D[row = m][col] of tile t at [m][16 t + col]
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) T[(4 * k + j) * ST + 16 * t + m] = acc[t][j];
+  __syncthreads();
+  const int x = x0 + 16 * wave + m;
+  if (x < g.topW) {
+    for (int o = k; o < g.topC; o += 4)          // lanes (k, m): displacement o = k, k + 4, ..., 16 consecutive columns each
+      top[(((size_t)n * g.topC + o) * g.topH + y) * g.topW + x] = T[m * ST + o + m] / (float)g.C;
+  }
+}
+
+static int corr1d_mfma_tiles(const Corr1dGeom& g) {      // N tiles per M tile, or 0 when the kernel does not apply
+  if (g.K != 1 || g.s1 != 1 || g.s2 != 1 || g.type != FN2_CORR_MULTIPLY) return 0;
+  const int overshoot = -(g.md + g.xshift * g.s2);
+  if (overshoot > g.pad) return 0;                       // (as for the tiled kernel: the flat index would reach data of the previous row)
+  const int nt = (15 + g.ngw + 15) / 16;
+  return (nt <= 8 && (long long)g.N * g.H <= 65535) ? nt : 0;
+}
+
 __device__ __forceinline__ int ceil_div1(int a, int s) { return (a >= 0) ? (a + s - 1) / s : -((-a) / s); }
 __device__ __forceinline__ int floor_div1(int a, int s) { return (a >= 0) ? a / s : -((-a + s - 1) / s); }
 
@@ -213,7 +321,7 @@ __global__ void __launch_bounds__(256) corr1d_bwd(const float* __restrict__ b0, 
 using namespace fn2;
 
 // test hook (fn2_debug_set_correlation_impl(1) also forces the generic 1-D kernels)
-namespace fn2 { int g_corr1d_force_generic = 0; }
+namespace fn2 { int g_corr1d_force_generic = 0; int g_corr1d_no_mfma = 0; }      // (impl 2: the LDS-tiled VALU kernel instead of the MFMA one)
 
 FN2_API int fn2_correlation1d_out_shape(const fn2_corr_params* p, int C, int H, int W, int* topC, int* topH, int* topW) {
   Corr1dGeom g;
@@ -233,6 +341,15 @@ FN2_API int fn2_correlation1d_forward(const fn2_corr_params* p, const float* bot
   if (N == 0) return FN2_OK;
   if (!bottom0 || !bottom1 || !top) return fail(FN2_ERR_INVALID_ARG, "correlation1d_forward: NULL blob pointer");
   int no = 0, bw = 0;
+  const int nt = (g_corr1d_force_generic || g_corr1d_no_mfma) ? 0 : corr1d_mfma_tiles(g);
+  if (nt) {
+    const dim3 grid((unsigned)((g.topW + 16 * kC1MW - 1) / (16 * kC1MW)), (unsigned)(g.N * g.H));
+    hipStream_t st = as_stream(stream);
+#define FN2_C1(NT_) case NT_: hipLaunchKernelGGL(corr1d_fwd_mfma<NT_>, grid, dim3(64 * kC1MW), 0, st, bottom0, bottom1, top, g); break
+    switch (nt) { FN2_C1(1); FN2_C1(2); FN2_C1(3); FN2_C1(4); FN2_C1(5); FN2_C1(6); FN2_C1(7); default: hipLaunchKernelGGL(corr1d_fwd_mfma<8>, grid, dim3(64 * kC1MW), 0, st, bottom0, bottom1, top, g); break; }
+#undef FN2_C1
+    return check_launch("correlation1d_forward");
+  }
   if (!g_corr1d_force_generic && corr1d_tiled_supported(g, &no, &bw)) {
     hipStream_t st = as_stream(stream);
     switch (no) {

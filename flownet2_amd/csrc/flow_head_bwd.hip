@@ -77,10 +77,27 @@ __global__ void __launch_bounds__(256) pf_wgrad(const float* __restrict__ bottom
   const int part = blockIdx.y, n = part / bands, band = part - n * bands, parts = gridDim.y;
   const int y0 = band * rb, rows = min(rb, H - y0);
   const int Wp = W + 2, plane = (rb + 2) * Wp;
-  for (int i = tid; i < 2 * plane; i += 256) {
-    const int co = i / plane, r = i - co * plane, yy = r / Wp, xx = r - yy * Wp;
-    const int y = y0 + yy - 1, x = xx - 1;
-    g[i] = (y >= 0 && y < H && x >= 0 && x < W) ? top_diff[((size_t)(n * 2 + co) * H + y) * W + x] : 0.f;
+  // staging, eight elements per thread at a time: all eight loads are issued (addresses clamped into the blob) before the first value is
+  // used -- a conditional load in front of its LDS store is a memory round trip of its own, and a band is 30 of them per thread; the index
+  // decode uses reciprocal multiplies (two integer divisions per element otherwise)
+  {
+    const unsigned inv_plane = 0xffffffffu / (unsigned)plane + 1u, inv_wp = 0xffffffffu / (unsigned)Wp + 1u;      // exact for indices < 2^32 / divisor
+    const float* td = top_diff + (size_t)(n * 2) * H * W;
+    for (int i0 = tid; i0 < 2 * plane; i0 += 256 * 8) {
+      float v[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned i = (unsigned)min(i0 + 256 * u, 2 * plane - 1);
+        const unsigned co = __umulhi(i, inv_plane), r = i - co * (unsigned)plane, yy = __umulhi(r, inv_wp), xx = r - yy * (unsigned)Wp;
+        const int y = y0 + (int)yy - 1, x = (int)xx - 1;
+        ok[u] = y >= 0 && y < H && x >= 0 && x < W;
+        v[u] = td[((size_t)co * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 256 * u < 2 * plane) g[i0 + 256 * u] = ok[u] ? v[u] : 0.f;
+    }
   }
   __syncthreads();
   if (blockIdx.x == 0) {                             // bias gradient of this part: the interior of the band

@@ -88,7 +88,7 @@ add("DataAugmentation spatial + mean [8,3,384,512]->[320,448]", lambda: ops.data
 add("DataAugmentation spatial + eigen + colour + mean (statistics pass first)", lambda: ops.data_augmentation_forward(pa, img_a, c_col, mean_a), 4 * 8 * 3 * (2 * 384 * 512 + 320 * 448))
 a1 = torch.randn(4, 256, 48, 96, device=dev, generator=g); b1 = torch.randn(4, 256, 48, 96, device=dev, generator=g)
 p1d = ops.corr_params(40, 1, 40, 1, 1, single_direction=-1)
-add("Correlation1D fwd [4,256,48,96] md 40 left (LDS-tiled kernel)", lambda: ops.correlation1d_forward(p1d, a1, b1), 4 * 4 * 48 * 96 * (2 * 256 + 41))
+add("Correlation1D fwd [4,256,48,96] md 40 left (MFMA kernel)", lambda: ops.correlation1d_forward(p1d, a1, b1), 4 * 4 * 48 * 96 * (2 * 256 + 41))
 # CustomData sample decode: a batch of 8 FlyingChairs samples (512x384): 10.125 B/pixel of packed bytes in, 9 fp32 planes out
 from flownet2_amd import sample_format as SF
 Hs, Ws, Ns = 384, 512, 8
