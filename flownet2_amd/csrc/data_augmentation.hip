@@ -49,19 +49,39 @@ __device__ __forceinline__ float clampf(float f, float a, float b) { return fmax
 
 // ComputeChromaticEigenspace, :147-187: per pixel the projections on the eigenvectors; batch max |eig|, max / min rgb, and
 // sum of rgb / width / height (divided by num on the host, :517-518).
-__global__ void __launch_bounds__(256) eigenspace_stats(const float* __restrict__ data, int N, int H, int W, EigenSpace* es) {
-  const long long hw = (long long)H * W, total = hw * N;
+struct EigVec { float v[9]; };
+
+// grid: (pixel blocks, sample): 32-bit pixel indices, the eigenvectors in kernel arguments (round 6: the flat 64-bit index cost a 64-bit
+// division per pixel and the nine coefficients were re-read from memory -- 32 us for a batch of 8 at 512x384, most of it integer division)
+__global__ void __launch_bounds__(256) eigenspace_stats(const float* __restrict__ data, int N, int H, int W, float* __restrict__ partial, EigVec ev, int vec4) {
+  const unsigned hw = (unsigned)H * (unsigned)W;
+  const float* img = data + (size_t)blockIdx.y * 3 * hw;
   float sum[3] = {0, 0, 0}, mx_eig[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long n = i / hw, p = i - n * hw;
-    float rgb[3];
-    for (int c = 0; c < 3; ++c) rgb[c] = data[(n * 3 + c) * hw + p];
+  auto pixel = [&](const float (&rgb)[3]) {
     for (int c = 0; c < 3; ++c) {
-      const float eig = es->eigvec[3 * c] * rgb[0] + es->eigvec[3 * c + 1] * rgb[1] + es->eigvec[3 * c + 2] * rgb[2];
+      const float eig = ev.v[3 * c] * rgb[0] + ev.v[3 * c + 1] * rgb[1] + ev.v[3 * c + 2] * rgb[2];
       mx_eig[c] = fmaxf(mx_eig[c], fabsf(eig));
       mx[c] = fmaxf(mx[c], rgb[c]);
       mn[c] = fminf(mn[c], rgb[c]);
       sum[c] += rgb[c] / W / H;                                                                        // :176
+    }
+  };
+  if (vec4) {       // four pixels per thread and step, 16-byte loads (the scalar loop was a chain of memory round trips: 72 per thread)
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < hw / 4; q += gridDim.x * blockDim.x) {
+      f4 v[3];
+      for (int c = 0; c < 3; ++c) v[c] = reinterpret_cast<const f4*>(img + (size_t)c * hw)[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float rgb[3] = {v[0][j], v[1][j], v[2][j]};
+        pixel(rgb);
+      }
+    }
+  } else {
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+      float rgb[3];
+      for (int c = 0; c < 3; ++c) rgb[c] = img[(size_t)c * hw + p];
+      pixel(rgb);
     }
   }
   __shared__ float sh[4][12];
@@ -77,24 +97,16 @@ __global__ void __launch_bounds__(256) eigenspace_stats(const float* __restrict_
   if (lane == 0)
     for (int c = 0; c < 3; ++c) { sh[wave][c] = sum[c]; sh[wave][3 + c] = mx_eig[c]; sh[wave][6 + c] = mx[c]; sh[wave][9 + c] = mn[c]; }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const int c = threadIdx.x;
-    float s = 0, a = 0, b = 0, d = FLT_MAX;
-    for (int w = 0; w < 4; ++w) { s += sh[w][c]; a = fmaxf(a, sh[w][3 + c]); b = fmaxf(b, sh[w][6 + c]); d = fminf(d, sh[w][9 + c]); }
-    atomicAdd(&es->mean_rgb[c], s);
-    // non-negative floats order like their bit patterns; min_rgb may be negative, so compare-and-swap
-    atomicMax(reinterpret_cast<unsigned int*>(&es->max_abs_eig[c]), __float_as_uint(a));
-    if (b > 0) atomicMax(reinterpret_cast<unsigned int*>(&es->max_rgb[c]), __float_as_uint(b));
-    float old = es->min_rgb[c];
-    while (d < old) {
-      const unsigned int prev = atomicCAS(reinterpret_cast<unsigned int*>(&es->min_rgb[c]), __float_as_uint(old), __float_as_uint(d));
-      if (prev == __float_as_uint(old)) break;
-      old = __uint_as_float(prev);
-    }
+  // one row of 12 partial results per workgroup (round 6): the 12 atomics per workgroup on the SAME 12 words were the kernel -- 256 workgroups
+  // x 12 contended atomics = most of its 32 us, 1,024 workgroups 114 us -- and made the mean a sum in arrival order; eigenspace_finish
+  // now reduces the rows in a fixed order
+  if (threadIdx.x < 12) {
+    const int j = threadIdx.x;
+    float r = sh[0][j];
+    for (int w = 1; w < 4; ++w) r = j < 3 ? r + sh[w][j] : j < 9 ? fmaxf(r, sh[w][j]) : fminf(r, sh[w][j]);
+    partial[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 12 + j] = r;
   }
 }
-
-struct EigVec { float v[9]; };
 
 __global__ void eigenspace_init(EigenSpace* es, EigVec ev) {                                              // :491-500
   for (int c = 0; c < 3; ++c) { es->mean_eig[c] = 0; es->mean_rgb[c] = 0; es->max_abs_eig[c] = 0; es->max_rgb[c] = 0; es->min_rgb[c] = FLT_MAX; }
@@ -102,7 +114,26 @@ __global__ void eigenspace_init(EigenSpace* es, EigVec ev) {                    
   for (int i = 0; i < 9; ++i) es->eigvec[i] = ev.v[i];
 }
 
-__global__ void eigenspace_finish(EigenSpace* es, int num) {                                              // :517-534 (host code in the reference)
+// one workgroup: thread t folds rows t, t + 256, ... in order, then a fixed tree over the threads; thread 0 finishes the statistics
+__global__ void __launch_bounds__(256) eigenspace_finish(EigenSpace* es, const float* __restrict__ partial, int rows, int num) {     // :517-534 (host code in the reference)
+  __shared__ float red[256][12];
+  const int t = threadIdx.x;
+  float r[12];
+  for (int j = 0; j < 12; ++j) r[j] = j < 3 ? 0.f : j < 9 ? 0.f : FLT_MAX;
+  for (int row = t; row < rows; row += 256)
+    for (int j = 0; j < 12; ++j) {
+      const float v = partial[(size_t)row * 12 + j];
+      r[j] = j < 3 ? r[j] + v : j < 9 ? fmaxf(r[j], v) : fminf(r[j], v);
+    }
+  for (int j = 0; j < 12; ++j) red[t][j] = r[j];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s)
+      for (int j = 0; j < 12; ++j) red[t][j] = j < 3 ? red[t][j] + red[t + s][j] : j < 9 ? fmaxf(red[t][j], red[t + s][j]) : fminf(red[t][j], red[t + s][j]);
+    __syncthreads();
+  }
+  if (t != 0) return;
+  for (int c = 0; c < 3; ++c) { es->mean_rgb[c] = red[0][c]; es->max_abs_eig[c] = red[0][3 + c]; es->max_rgb[c] = red[0][6 + c]; es->min_rgb[c] = red[0][9 + c]; }
   for (int c = 0; c < 3; ++c) es->mean_rgb[c] = es->mean_rgb[c] / num;
   for (int c = 0; c < 3; ++c) {
     es->mean_eig[c] = es->eigvec[3 * c] * es->mean_rgb[0] + es->eigvec[3 * c + 1] * es->mean_rgb[1] + es->eigvec[3 * c + 2] * es->mean_rgb[2];
@@ -260,7 +291,8 @@ __global__ void __launch_bounds__(256) data_aug_kernel(DataAugArgs a) {
 
 using namespace fn2;
 
-FN2_API size_t fn2_data_augmentation_workspace_bytes(int) { return 256; }
+constexpr int kStatRowsMax = 1024;        // workgroups of the statistics pass (rows of 12 partial results behind the EigenSpace record)
+FN2_API size_t fn2_data_augmentation_workspace_bytes(int) { return 256 + sizeof(float) * 12 * kStatRowsMax; }
 
 FN2_API int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const float* bottom, const float* coeffs, const float* mean,
                                           float* top, int N, int C, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
@@ -327,14 +359,21 @@ FN2_API int fn2_data_augmentation_forward(const fn2_data_aug_params* p, const fl
   }
   if (any_eigen) {
     if (!p->has_chromatic_eigvec) return fail(FN2_ERR_INVALID_ARG, "You need to specify chromatic eigenvectors for Chromatic-Eigen augementation");   // :494
-    if (!workspace || workspace_bytes < sizeof(EigenSpace)) return fail(FN2_ERR_WORKSPACE, "data_augmentation: workspace of %zu bytes needed", sizeof(EigenSpace));
+    if (!workspace || workspace_bytes < fn2_data_augmentation_workspace_bytes(N))
+      return fail(FN2_ERR_WORKSPACE, "data_augmentation: workspace of %zu bytes needed", fn2_data_augmentation_workspace_bytes(N));
+    if (N > kStatRowsMax) return fail(FN2_ERR_UNSUPPORTED, "data_augmentation: more than %d samples per call", kStatRowsMax);
     // :488-536 without the reference's two device <-> host round trips: initialise, reduce and finish on the device
     EigVec ev;
     for (int i = 0; i < 9; ++i) ev.v[i] = p->chromatic_eigvec[i];                                         // :496-497
     EigenSpace* es = static_cast<EigenSpace*>(workspace);
     hipLaunchKernelGGL(eigenspace_init, dim3(1), dim3(1), 0, st, es, ev);
-    hipLaunchKernelGGL(eigenspace_stats, dim3(blocks_for((long long)N * H * W, 256, 256)), dim3(256), 0, st, bottom, N, H, W, es);
-    hipLaunchKernelGGL(eigenspace_finish, dim3(1), dim3(1), 0, st, es, N);
+    if ((long long)H * W >= (1ll << 31) || N > 65535) return fail(FN2_ERR_UNSUPPORTED, "data_augmentation: blob too large for the statistics pass");
+    const int vec4 = ((long long)H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(bottom) & 15) == 0;
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    const unsigned per_sample = (unsigned)(kStatRowsMax / N > 0 ? kStatRowsMax / N : 1);
+    const unsigned bx = blocks_for((long long)H * W / (vec4 ? 4 : 1), 256, per_sample);
+    hipLaunchKernelGGL(eigenspace_stats, dim3(bx, (unsigned)N), dim3(256), 0, st, bottom, N, H, W, partial, ev, vec4);
+    hipLaunchKernelGGL(eigenspace_finish, dim3(1), dim3(256), 0, st, es, partial, (int)(bx * (unsigned)N), N);
   }
   for (int n0 = 0; n0 < N; n0 += kItemChunk) {
     a.n0 = n0;
