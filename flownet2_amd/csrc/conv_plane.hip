@@ -306,15 +306,36 @@ conv_plane(Args a) {
 }
 
 // out[n][c0 + co][pix] = act(bias[co] + ((part0 + part1) + part2) + ...)
-__global__ void plane_reduce(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
-                             int N, int Cout, int P, int out_ctot, int out_c0, int ksplit, int relu, float slope) {
-  const long long total = (long long)N * Cout * P;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    float s = part[i];
-    for (int k = 1; k < ksplit; ++k) s += part[(size_t)k * total + i];
-    const int pix = (int)(i % P);
-    const long long r = i / P;
-    const int co = (int)(r % Cout), n = (int)(r / Cout);
+// KS > 0: the number of parts at compile time -- all KS loads of an element are issued before the first add (a loop over a run-time part
+// count is a chain of memory round trips: load, wait, add, 16 times for conv6_1), the adds keep the part order: the same bits.  KS = 0: any
+// part count, four loads at a time.
+template <int KS>
+__global__ void __launch_bounds__(256) plane_reduce(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                    int N, int Cout, int P, int out_ctot, int out_c0, int ksplit, int relu, float slope) {
+  const unsigned total = (unsigned)N * (unsigned)Cout * (unsigned)P;      // (< 2^31: checked by the launcher)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float s;
+    if constexpr (KS > 0) {
+      float v[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) v[k] = part[(size_t)k * total + i];
+      s = v[0];
+#pragma unroll
+      for (int k = 1; k < KS; ++k) s += v[k];
+    } else {
+      s = part[i];
+      int k = 1;
+      for (; k + 3 < ksplit; k += 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = part[(size_t)(k + j) * total + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[j];
+      }
+      for (; k < ksplit; ++k) s += part[(size_t)k * total + i];
+    }
+    const unsigned r = i / (unsigned)P, pix = i - r * (unsigned)P;
+    const unsigned n = r / (unsigned)Cout, co = r - n * (unsigned)Cout;
     s += bias ? bias[co] : 0.f;
     if (relu) s = s > 0.f ? s : s * slope;
     out[((size_t)n * out_ctot + out_c0 + co) * P + pix] = s;
@@ -509,8 +530,20 @@ static int forward(Args a, int mode, int stride, int ks, void* workspace, size_t
   if (rc != FN2_OK) return rc;
   if (a.ksplit > 1) {
     const long long total = (long long)a.N * a.Cout * Po;
-    hipLaunchKernelGGL(plane_reduce, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, st, a.part, a.bias, a.out, a.N, a.Cout, Po, a.out_ctot, a.out_c0,
-                       a.ksplit, a.relu, a.slope);
+    if (total >= (1ll << 31)) return fail(FN2_ERR_UNSUPPORTED, "%s: blob too large for the part reduction", what);
+    const dim3 rg(blocks_for(total, 256, 4096));
+#define FN2_PR(KS_) hipLaunchKernelGGL(plane_reduce<KS_>, rg, dim3(256), 0, st, a.part, a.bias, a.out, a.N, a.Cout, Po, a.out_ctot, a.out_c0, a.ksplit, a.relu, a.slope)
+    switch (a.ksplit) {
+      case 2: FN2_PR(2); break;
+      case 3: FN2_PR(3); break;
+      case 4: FN2_PR(4); break;
+      case 6: FN2_PR(6); break;
+      case 8: FN2_PR(8); break;
+      case 12: FN2_PR(12); break;
+      case 16: FN2_PR(16); break;
+      default: FN2_PR(0); break;
+    }
+#undef FN2_PR
     return check_launch(what);
   }
   return FN2_OK;
